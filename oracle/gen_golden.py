@@ -1,0 +1,249 @@
+"""oracle/gen_golden.py -- record golden vectors from the REFERENCE ITSELF.
+
+Dev-container only: imports /root/reference's train_physics_vae / torch_models /
+rllib_model_torch unmodified through the stand-in `ray`/`gym` packages in oracle/stubs
+(SURVEY.md Appendix A), drives them on seeded synthetic inputs and writes small .npz
+fixtures into tests/golden/.  Only *data* (inputs' seeds and the reference's outputs)
+is committed; no reference source travels.  Run:  python oracle/gen_golden.py
+
+Inputs are regenerated from seeds by oracle/refpath.py on both sides, so fixtures hold
+outputs (plus the seeds/dims that define the inputs).
+"""
+import argparse
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("PVAE_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path[:0] = [os.path.join(HERE, "stubs"), REF, ROOT]
+if not hasattr(np, "product"):
+    np.product = np.prod                      # numpy 2 dropped it; rmt:600-604 uses it
+
+import torch  # noqa: E402
+
+import train_physics_vae as T  # noqa: E402  (the reference)
+from oracle import refpath as R  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def resolve_grid(cfg):
+    for k, v in list(cfg.items()):
+        if isinstance(v, dict) and "grid_search" in v:
+            assert len(v["grid_search"]) == 1
+            cfg[k] = v["grid_search"][0]
+    return cfg
+
+
+def make_reference_trainer(pkl, arch, batch, m_world, num_data=None):
+    argv = ["--data_train", pkl, "--batch_size", str(batch), "--max_iter", "1000",
+            "--max_iter_world_model", str(m_world), "--latent_dim", str(arch["Z"])]
+    T.args = T.arg_parser().parse_args(argv)
+    T.args.num_data = num_data
+    cfg = resolve_grid(T.get_trainer_config(T.args))
+    cfg["TE_width"], cfg["TE_depth"] = arch["te"]
+    cfg["MD_width"], cfg["MD_depth"] = arch["md"]
+    cfg["world_model_width"], cfg["world_model_depth"] = arch["wm"]
+    return T.TrainModel(cfg)
+
+
+class EpsPatch:
+    """Replace torch.randn_like by a deterministic per-call stream (one call per forward)."""
+
+    def __init__(self, fn):
+        self.fn, self.calls = fn, 0
+
+    def __enter__(self):
+        self.orig = torch.randn_like
+
+        def patched(t, *a, **k):
+            e = self.fn(self.calls, t.shape)
+            self.calls += 1
+            return e
+        torch.randn_like = patched
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like = self.orig
+
+
+def grads_of(model):
+    return {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def single_batch_capture(tr, x, y, eps, world):
+    """Losses, internals and grads from the reference's own compute_loss + backward."""
+    m = tr.model
+    m.set_learnable_task_encoder(not world)
+    m.set_learnable_motor_decoder(not world)
+    m.set_learnable_world_model(world)
+    tr.read_loss_fn_coeff(world=world)
+    tr.model.train()
+    tr.optimizer.zero_grad()
+    with EpsPatch(lambda c, shape: eps):
+        loss = tr.compute_loss(y, x)
+    loss.backward()
+    out = {"total": loss.detach().numpy()}
+    out["mu"] = m._cur_task_encoder_mu.detach().numpy()
+    out["logvar"] = m._cur_task_encoder_logvar.detach().numpy()
+    out["z"] = m._cur_task_encoder_variable.detach().numpy()
+    out["future_state"] = m._cur_future_state.detach().numpy()
+    return out, grads_of(m)
+
+
+def case_single(name, arch, n_ep, n_steps, batch, full):
+    data = R.synth_demo(seed=0, n_episodes=n_ep, n_steps=n_steps, dim_body=arch["Db"],
+                        dim_action=arch["Da"], kind="iid")
+    fix = {}
+    with tempfile.TemporaryDirectory() as td:
+        pkl = os.path.join(td, "demo.pkl")
+        R.write_demo(pkl, data)
+        tr = make_reference_trainer(pkl, arch, batch, m_world=2)
+        sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+        # --- construction facts
+        ref_sd = tr.model.state_dict()
+        fix["sd_keys"] = np.array(list(ref_sd.keys()))
+        fix["sd_shapes"] = np.array([list(v.shape) + [0] * (2 - v.dim()) for v in ref_sd.values()])
+        fix["n_params"] = np.array(sum(v.numel() for v in ref_sd.values()))
+        for k, v in ref_sd.items():          # normc property of the reference's own init
+            if k.endswith("weight"):
+                fix.setdefault("init_row_norms_minmax", []).append(
+                    [float(v.norm(dim=1).min()), float(v.norm(dim=1).max())])
+        fix["init_row_norms_minmax"] = np.array(fix["init_row_norms_minmax"])
+        tr.model.load_state_dict(sd)          # strict: proves our key layout drops in
+        # --- loader facts
+        loader = tr.train_loader
+        fix["n_windows"] = np.array(len(loader.dataset))
+        fix["n_batches"] = np.array(len(loader))
+        fix["sampler"] = np.array(type(loader.sampler).__name__)
+        batches = list(loader)
+        fix["last_batch_size"] = np.array(batches[-1][0].shape[0])
+        for tag, b in (("first", 0), ("mid", len(batches) // 2), ("last", len(batches) - 1)):
+            xb, yb = batches[b]
+            fix["loader_%s_x_digest" % tag] = R.tensor_digest(xb)
+            fix["loader_%s_y_digest" % tag] = R.tensor_digest(yb)
+            if full:
+                fix["loader_%s_x" % tag] = xb.numpy()
+                fix["loader_%s_y" % tag] = yb.numpy()
+        # --- one minibatch, both phases
+        x, y = batches[0]
+        eps = R.eps_stream(2, arch["Z"])(0, (x.shape[0], arch["Z"]))
+        for world in (True, False):
+            tag = "world" if world else "joint"
+            out, grads = single_batch_capture(tr, x, y, eps, world)
+            for k, v in out.items():
+                if full or v.ndim == 0:
+                    fix["%s_%s" % (tag, k)] = v
+                else:
+                    fix["%s_%s_digest" % (tag, k)] = R.tensor_digest(torch.from_numpy(v))
+            # per-term losses via the restated formulas are checked in tests; record terms too
+            fix["%s_grad_keys" % tag] = np.array(list(grads.keys()))
+            for k, g in grads.items():
+                if full:
+                    fix["%s_grad::%s" % (tag, k)] = g.numpy()
+                fix["%s_graddigest::%s" % (tag, k)] = R.tensor_digest(g)
+        # value branch / AppendLogStd do not influence the loss: perturb VB, loss unchanged
+        sd2 = {k: (v + 1.0 if k.startswith("_value_branch") else v) for k, v in sd.items()}
+        tr.model.load_state_dict(sd2)
+        out2, _ = single_batch_capture(tr, x, y, eps, False)
+        fix["joint_total_vb_perturbed"] = out2["total"]
+        tr.model.load_state_dict(sd)
+        # --- checkpoint layout
+        ck = os.path.join(td, "ck")
+        os.makedirs(ck)
+        ret = tr.save_checkpoint(ck)
+        fix["ckpt_return_basename"] = np.array(os.path.basename(ret))
+        files = sorted(os.listdir(ck))
+        fix["ckpt_files"] = np.array(files)
+        for f in files:
+            obj = torch.load(os.path.join(ck, f))
+            if f == "task_encoder.pt":
+                fix["ckpt_te_outer_keys"] = np.array(list(obj.keys()))
+                obj = obj["task_encoder"]
+            fix["ckpt_keys::" + f] = np.array(list(obj.keys()))
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"],
+                            n_ep, n_steps, batch])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
+    print("wrote", name, "keys:", len(fix))
+
+
+def case_training(name, arch, n_ep, n_steps, batch, m_world, n_epochs, full, lr_step=2):
+    """Multi-epoch run crossing the phase switch, eps keyed by global minibatch index."""
+    data = R.synth_demo(seed=0, n_episodes=n_ep, n_steps=n_steps, dim_body=arch["Db"],
+                        dim_action=arch["Da"], kind="dynamics")
+    fix = {}
+    with tempfile.TemporaryDirectory() as td:
+        pkl = os.path.join(td, "demo.pkl")
+        R.write_demo(pkl, data)
+        tr = make_reference_trainer(pkl, arch, batch, m_world=m_world)
+        # shorten StepLR so that the decay is exercised inside the captured run
+        tr.lr_scheduler = torch.optim.lr_scheduler.StepLR(tr.optimizer, step_size=lr_step, gamma=0.7)
+        sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+        tr.model.load_state_dict(sd)
+        eps_fn = R.eps_stream(2, arch["Z"])
+        losses, lrs = [], []
+        with EpsPatch(lambda c, shape: eps_fn(c, shape)) as ep:
+            for e in range(n_epochs):
+                lrs.append(tr.optimizer.param_groups[0]["lr"])
+                losses.append(tr.train()["mean_train_loss"])
+                if e + 1 in (1, m_world, n_epochs):
+                    tag = "after_epoch%d" % (e + 1)
+                    st = tr.model.state_dict()
+                    for k, v in st.items():
+                        if full:
+                            fix["%s::%s" % (tag, k)] = v.detach().numpy().copy()
+                        fix["%s_digest::%s" % (tag, k)] = R.tensor_digest(v)
+            fix["eps_calls"] = np.array(ep.calls)
+        fix["epoch_losses"] = np.array(losses, dtype=np.float64)
+        fix["epoch_lrs"] = np.array(lrs, dtype=np.float64)
+        # Adam bookkeeping: which params have state, and their step counts
+        named = dict(tr.model.named_parameters())
+        steps, have = [], []
+        for k, p in named.items():
+            st = tr.optimizer.state.get(p, {})
+            have.append(len(st) > 0)
+            steps.append(float(st["step"]) if len(st) else -1.0)
+            if len(st) and (full or k.endswith("2._model.0.bias")):
+                fix["adam_exp_avg::" + k] = st["exp_avg"].numpy().copy()
+                fix["adam_exp_avg_sq::" + k] = st["exp_avg_sq"].numpy().copy()
+        fix["adam_keys"] = np.array(list(named.keys()))
+        fix["adam_has_state"] = np.array(have)
+        fix["adam_steps"] = np.array(steps)
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"],
+                            n_ep, n_steps, batch, m_world, n_epochs, lr_step])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
+    print("wrote", name, "losses", losses, "lrs", lrs)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    tiny = R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2))
+    c1 = R.make_arch(197, 45, latent=32, te=(256, 2), md=(256, 2), wm=(256, 2))
+    c2 = R.make_arch(197, 45, latent=32, te=(1024, 4), md=(1024, 4), wm=(1024, 4))
+    dflt = R.make_arch(197, 45)              # DEFAULT_CONFIG arch: 26-tensor layout
+    jobs = {
+        "single_tiny": lambda: case_single("single_tiny", tiny, 2, 14, 8, full=True),
+        "single_c1": lambda: case_single("single_c1", c1, 2, 200, 64, full=False),
+        "single_c2": lambda: case_single("single_c2", c2, 2, 300, 256, full=False),
+        "single_default": lambda: case_single("single_default", dflt, 2, 100, 32, full=False),
+        "train_tiny": lambda: case_training("train_tiny", tiny, 3, 21, 8, m_world=2, n_epochs=5,
+                                            full=True),
+        "train_c1": lambda: case_training("train_c1", c1, 4, 200, 64, m_world=2, n_epochs=4,
+                                          full=False),
+    }
+    for k, fn in jobs.items():
+        if a.only is None or a.only == k:
+            fn()
+
+
+if __name__ == "__main__":
+    main()

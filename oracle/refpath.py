@@ -1,0 +1,474 @@
+"""oracle/refpath.py -- CPU restatement of the PhysicsVAE supervised-training hot path.
+
+TEST INFRASTRUCTURE, NOT PRODUCT.  Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import this module.  The product package
+(`physicsvae_amd/`) never imports it and fails loudly when its HIP library is missing.
+
+What it restates (stock torch CPU fp32 ops, in the reference's op order), with the
+reference lines each piece follows (`tpv` = train_physics_vae.py, `tm` = torch_models.py,
+`rmt` = rllib_model_torch.py under /root/reference):
+
+  * synthetic demo dict in the on-disk schema                     tpv:57-92
+  * sliding (s_t, s_t+1, a_t) windows, float64                    tpv:117-164
+  * per-sample Dataset + sequential DataLoader, partial last batch tm:39-95,166-193
+  * FC stacks / normc init / state_dict key layout                rmt:234-283 + ray 1.11.0
+    SlimFC/normc_initializer (third-party, not in tree: semantics per SURVEY.md App. B)
+  * PhysicsVAE forward: TE -> reparameterise -> MD -> WM -> VB     rmt:742-853
+  * losses (a-rec MSE, KL to N(0,I), s-rec MSE, cycle MSE)        tpv:361-435
+  * two-phase schedule, freezing, Adam, StepLR-per-epoch          tpv:314-351, tm:110-161
+  * five-file checkpoint layout                                   tpv:440-467, rmt:870-928
+
+Pinning: `tests/golden/*.npz` hold outputs of the *reference itself* (imported in the dev
+container through `oracle/stubs`, script `oracle/gen_golden.py`); `tests/test_oracle_golden.py`
+checks this restatement against them.  The reference ships no tests or golden vectors of
+its own, so those captures are the pin.
+"""
+import math
+import os
+import pickle
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+NETS = ("_task_encoder", "_motor_decoder", "_world_model", "_value_branch")
+
+
+# --------------------------------------------------------------------------------------
+# architecture description
+# --------------------------------------------------------------------------------------
+def make_arch(dim_body, dim_action, latent=32, te=(256, 2), md=(512, 3), wm=(1024, 2),
+              vb=(256, 2)):
+    """Widths/depths as `gen_layers(width, depth)` expands them (tpv:180-192, 290-311);
+    defaults are PhysicsVAE.DEFAULT_CONFIG (rmt:462-510)."""
+    return dict(Db=int(dim_body), Da=int(dim_action), Z=int(latent),
+                te=tuple(te), md=tuple(md), wm=tuple(wm), vb=tuple(vb))
+
+
+def net_layer_dims(arch):
+    """(in, out) of every Linear, per net, in registration order (rmt:638-699)."""
+    Db, Da, Z = arch["Db"], arch["Da"], arch["Z"]
+
+    def chain(n_in, wd, n_out):
+        w, d = wd
+        dims, prev = [], n_in
+        for _ in range(d):
+            dims.append((prev, w))
+            prev = w
+        dims.append((prev, n_out))
+        return dims
+
+    return OrderedDict([
+        ("_task_encoder", chain(2 * Db, arch["te"], 2 * Z)),       # rmt:638-644, 612-613
+        ("_motor_decoder", chain(Db + Z, arch["md"], Da)),         # rmt:646-668
+        ("_world_model", chain(Db + Da, arch["wm"], Db)),          # rmt:682-689
+        ("_value_branch", chain(2 * Db, arch["vb"], 1)),           # rmt:693-699
+    ])
+
+
+def state_dict_spec(arch):
+    """Ordered [(key, shape)] exactly as `PhysicsVAE.state_dict()` lists them:
+    `<net>._model.<i>._model.0.{weight,bias}` (FC -> SlimFC -> Sequential(Linear[,ReLU]))."""
+    spec = []
+    for net, dims in net_layer_dims(arch).items():
+        for i, (n_in, n_out) in enumerate(dims):
+            spec.append(("%s._model.%d._model.0.weight" % (net, i), (n_out, n_in)))
+            spec.append(("%s._model.%d._model.0.bias" % (net, i), (n_out,)))
+    return spec
+
+
+def init_state_dict(arch, seed):
+    """normc init (rows L2-normalised to 1.0 for hidden layers, 0.01 for the output
+    layer; bias 0 -- tpv:184-189, ray normc_initializer) drawn from numpy so that both
+    sides of a parity test regenerate bit-identical weights from a seed."""
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    for net, dims in net_layer_dims(arch).items():
+        for i, (n_in, n_out) in enumerate(dims):
+            std = 0.01 if i == len(dims) - 1 else 1.0
+            w = rng.standard_normal((n_out, n_in))
+            w *= std / np.sqrt((w * w).sum(axis=1, keepdims=True))
+            sd["%s._model.%d._model.0.weight" % (net, i)] = torch.from_numpy(w.astype(np.float32))
+            sd["%s._model.%d._model.0.bias" % (net, i)] = torch.zeros(n_out, dtype=torch.float32)
+    return sd
+
+
+def perturb_biases(sd, seed, scale=0.05):
+    """Parity inputs should not have all-zero biases (a wrong bias path would go unseen)."""
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for k, v in sd.items():
+        if k.endswith(".bias"):
+            out[k] = torch.from_numpy((rng.standard_normal(v.shape) * scale).astype(np.float32))
+        else:
+            out[k] = v.clone()
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# synthetic demonstrations in the reference's pickle schema (tpv:57-92; writer
+# envs/rllib_env_imitation.py:63-87,140-144)
+# --------------------------------------------------------------------------------------
+def synth_demo(seed, n_episodes, n_steps, dim_body, dim_action, kind="iid", quantum=1024.0):
+    """kind="iid": N(0,1) states, N(0,1) actions clipped to +-3 (SURVEY.md 8c anchor).
+    kind="dynamics": s_{t+1} = tanh(A s_t + B a_t) + noise, so the world model has
+    something to learn.  Values are rounded to multiples of 1/quantum so the float64 ->
+    float32 conversion (tm:67) is exact on every platform."""
+    rng = np.random.default_rng(seed)
+    episodes = []
+    if kind == "dynamics":
+        A = rng.standard_normal((dim_body, dim_body)) / math.sqrt(dim_body)
+        Bm = rng.standard_normal((dim_action, dim_body)) / math.sqrt(dim_action)
+    for _ in range(n_episodes):
+        act = np.clip(rng.standard_normal((n_steps, dim_action)), -3.0, 3.0)
+        if kind == "iid":
+            sb = rng.standard_normal((n_steps, dim_body))
+        elif kind == "dynamics":
+            sb = np.empty((n_steps, dim_body))
+            sb[0] = rng.standard_normal(dim_body)
+            for t in range(n_steps - 1):
+                sb[t + 1] = np.tanh(sb[t] @ A + act[t] @ Bm) + 0.05 * rng.standard_normal(dim_body)
+        else:
+            raise ValueError(kind)
+        if quantum:
+            sb = np.round(sb * quantum) / quantum
+            act = np.round(act * quantum) / quantum
+        episodes.append({
+            "time": [float(t) / 30.0 for t in range(n_steps)],
+            "state": [np.concatenate([sb[t], sb[min(t + 1, n_steps - 1)]]) for t in range(n_steps)],
+            "state_body": [sb[t].copy() for t in range(n_steps)],
+            "state_task": [sb[min(t + 1, n_steps - 1)].copy() for t in range(n_steps)],
+            "action": [act[t].copy() for t in range(n_steps)],
+            "reward": [0.0] * n_steps,
+        })
+    return {
+        "dim_action": dim_action, "dim_state": 2 * dim_body, "dim_state_body": dim_body,
+        "dim_state_task": dim_body, "exp_std": 0.05, "iter_per_episode": 1,
+        "episodes": episodes,
+    }
+
+
+def write_demo(path, data):
+    with open(path, "wb") as f:
+        pickle.dump(data, f)
+
+
+def merge_demo_files(files):
+    """tpv:94-114: first file is the base, later files must agree on the meta fields
+    and contribute their episodes."""
+    merged = None
+    for n, path in enumerate(files):
+        with open(path, "rb") as f:
+            d = pickle.load(f)
+        if n == 0:
+            merged = d
+            continue
+        for key in ("iter_per_episode", "dim_state", "dim_state_body", "dim_state_task",
+                    "dim_action", "exp_std"):
+            assert merged[key] == d[key], key
+        merged["episodes"] = merged["episodes"] + d["episodes"]
+    return merged
+
+
+def build_windows(data, lookahead=1, num_samples=None):
+    """tpv:117-164 with cond="abs", use_a_gt=False.  Returns float64
+    X[N, L, 2*Db] = [sb[i+j] | sb[i+j+1]], Y[N, L, Da] = a[i+j]; episode order, i ascending;
+    the `num_samples` cap stops at exactly that many windows (tpv:137-138)."""
+    assert lookahead >= 1
+    X, Y = [], []
+    for ep in data["episodes"]:
+        T = len(ep["time"])
+        assert T >= lookahead
+        for i in range(T - lookahead):
+            if num_samples is not None and len(X) >= num_samples:
+                break
+            X.append(np.vstack([np.hstack([ep["state_body"][i + j], ep["state_body"][i + j + 1]])
+                                for j in range(lookahead)]))
+            Y.append(np.vstack([ep["action"][i + j] for j in range(lookahead)]))
+    return np.array(X), np.array(Y)
+
+
+class WindowDataset(torch.utils.data.Dataset):
+    """tm:39-95 with normalize_x = normalize_y = False (tpv:163-164): per-sample
+    float64 -> float32 `torch.Tensor(...)` copies."""
+
+    def __init__(self, X, Y):
+        self.X, self.Y = X, Y
+
+    def __len__(self):
+        return len(self.X)
+
+    def __getitem__(self, i):
+        return torch.Tensor(self.X[i]), torch.Tensor(self.Y[i])
+
+
+def make_loader(X, Y, batch_size):
+    """tm:166-193: shuffle is None in practice (the "suffle_data" typo, tpv:260 vs tm:181)
+    -> SequentialSampler, drop_last False."""
+    return torch.utils.data.DataLoader(WindowDataset(X, Y), batch_size=batch_size, shuffle=None)
+
+
+# --------------------------------------------------------------------------------------
+# model (own nn.Module reproducing the state_dict layout)
+# --------------------------------------------------------------------------------------
+class _Slim(nn.Module):
+    def __init__(self, n_in, n_out, relu):
+        super().__init__()
+        mods = [nn.Linear(n_in, n_out)]
+        if relu:
+            mods.append(nn.ReLU())
+        self._model = nn.Sequential(*mods)
+
+    def forward(self, x):
+        return self._model(x)
+
+
+class _Stack(nn.Module):
+    def __init__(self, dims):
+        super().__init__()
+        self._model = nn.Sequential(*[_Slim(i, o, relu=(n < len(dims) - 1))
+                                      for n, (i, o) in enumerate(dims)])
+
+    def forward(self, x):
+        return self._model(x)
+
+
+class RefModel(nn.Module):
+    """PhysicsVAE restated (rmt:461-950) for latent_prior_type "normal_zero_mean_one_std",
+    inputs ["body","task"] for both TE and MD, constant log_std (sample_std 0.1)."""
+
+    def __init__(self, arch):
+        super().__init__()
+        self.arch = arch
+        dims = net_layer_dims(arch)
+        self._task_encoder = _Stack(dims["_task_encoder"])
+        self._motor_decoder = _Stack(dims["_motor_decoder"])
+        self._world_model = _Stack(dims["_world_model"])
+        self._value_branch = _Stack(dims["_value_branch"])
+        self.log_std = math.log(0.1)            # AppendLogStd constant (rmt:160-206, 466)
+        self.latent_prior_noise = True          # rmt:705
+        self.eps_source = None                  # callable(shape) -> eps, else torch.randn
+
+    # rmt:734-740
+    def reparameterize(self, mu, logvar):
+        if not self.latent_prior_noise:
+            return mu
+        std = torch.exp(0.5 * logvar)
+        eps = self.eps_source(std.shape) if self.eps_source is not None else torch.randn_like(std)
+        self.cur_eps = eps
+        return mu + eps * std
+
+    # rmt:742-771 (+773-853)
+    def forward(self, obs):
+        Db, Da, Z = self.arch["Db"], self.arch["Da"], self.arch["Z"]
+        obs = obs.float()
+        h = self._task_encoder(obs)                                   # rmt:788-793
+        self.cur_mu, self.cur_logvar = h[..., :Z], h[..., Z:]         # rmt:795-800
+        z = self.reparameterize(self.cur_mu, self.cur_logvar)
+        self.cur_z = z
+        a_hat = self._motor_decoder(torch.cat([obs[..., :Db], z], dim=-1))     # rmt:822-831
+        logits = torch.cat([a_hat, torch.full_like(a_hat, self.log_std)], dim=-1)
+        self.cur_future_state = self.forward_world(obs, logits)       # rmt:758
+        self.cur_value = self._value_branch(obs).squeeze(1)           # rmt:760-769
+        return logits
+
+    # rmt:839-844
+    def forward_world(self, obs, logits):
+        Db, Da = self.arch["Db"], self.arch["Da"]
+        return self._world_model(torch.cat([obs[..., :Db], logits[..., :Da]], dim=-1))
+
+    def set_learnable(self, net, flag):                               # rmt:930-950
+        for p in getattr(self, net).parameters():
+            p.requires_grad = flag
+
+
+DEFAULT_COEFFS = dict(vae_kl_coeff=1.0, a_rec_coeff=1.0, s_rec_coeff=0.0, vae_cycle_coeff=1e-3)
+
+
+def phase_coeffs(world, cfg=None):
+    """tpv:331-335: world phase = (0, 0, 1, 0); joint = config values (tpv:282-285)."""
+    cfg = dict(DEFAULT_COEFFS, **(cfg or {}))
+    if world:
+        return dict(vae_kl_coeff=0.0, a_rec_coeff=0.0, s_rec_coeff=1.0, vae_cycle_coeff=0.0)
+    return cfg
+
+
+def compute_loss(model, x, y, coeffs):
+    """tpv:361-435 with lookahead == 1.  x [B,1,2Db], y [B,1,Da].  Returns (total, terms).
+    The full forward always runs (tpv:378), including in the world phase."""
+    Db = model.arch["Db"]
+    Da = model.arch["Da"]
+    mse = nn.MSELoss()
+    x0 = x[:, 0, :]
+    y0 = y[:, 0, :]
+    s1, s2 = x0[:, :Db], x0[:, Db:]
+    logits = model(torch.cat([s1, s2], dim=-1))
+    a_hat = logits[:, :Da]                                            # tpv:356-359
+    zero = torch.zeros((), dtype=torch.float32)
+    loss_a = loss_kl = loss_s = loss_cyc = zero
+    if coeffs["a_rec_coeff"] > 0.0:
+        loss_a = mse(y0, a_hat)                                       # tpv:381-382
+        if coeffs["vae_kl_coeff"] > 0.0:
+            mu, lv = model.cur_mu, model.cur_logvar
+            loss_kl = torch.mean(-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp(), dim=1), dim=0)
+    if coeffs["s_rec_coeff"] > 0:
+        s2_gt_act = model.forward_world(s1, y0)                       # tpv:411-414
+        loss_s = mse(s2, s2_gt_act)
+    if coeffs["vae_cycle_coeff"] > 0:
+        loss_cyc = mse(s2, model.cur_future_state)                    # tpv:417-419
+    total = (coeffs["a_rec_coeff"] * loss_a + coeffs["vae_kl_coeff"] * loss_kl +
+             coeffs["s_rec_coeff"] * loss_s + coeffs["vae_cycle_coeff"] * loss_cyc)
+    return total, dict(loss_a=loss_a, loss_kl=loss_kl, loss_s=loss_s, loss_cyc=loss_cyc)
+
+
+def loss_and_grads(arch, sd, x, y, eps, world, coeff_cfg=None):
+    """One minibatch through the restated graph; returns forward internals, loss terms and
+    every trainable gradient (frozen nets get no gradient, tpv:326-329, 347-350)."""
+    model = RefModel(arch)
+    model.load_state_dict(sd)
+    model.train()
+    model.eps_source = (lambda shape: eps) if eps is not None else None
+    model.set_learnable("_task_encoder", not world)
+    model.set_learnable("_motor_decoder", not world)
+    model.set_learnable("_world_model", world)
+    coeffs = phase_coeffs(world, coeff_cfg)
+    total, terms = compute_loss(model, x, y, coeffs)
+    total.backward()
+    grads = OrderedDict((k, p.grad.detach().clone()) for k, p in model.named_parameters()
+                        if p.grad is not None)
+    Da = arch["Da"]
+    out = dict(total=total.detach(), mu=model.cur_mu.detach(), logvar=model.cur_logvar.detach(),
+               z=model.cur_z.detach(), future_state=model.cur_future_state.detach(),
+               grads=grads)
+    out.update({k: v.detach() for k, v in terms.items()})
+    with torch.no_grad():
+        Db = arch["Db"]
+        x0 = x[:, 0, :]
+        out["a_hat"] = model._motor_decoder(torch.cat([x0[:, :Db], out["z"]], dim=-1))
+        out["s2_from_gt_action"] = model.forward_world(x0, torch.cat([y[:, 0, :], y[:, 0, :]], -1))
+    return out
+
+
+def adam_reference_update(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam single-tensor update, amsgrad False, weight_decay 0 (tm:119-122):
+    m <- lerp(m, g, 1-b1); v <- b2 v + (1-b2) g^2;
+    p <- p - (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  `step` is the 1-based count."""
+    m = m + (g - m) * (1.0 - beta1)
+    v = v * beta2 + g * g * (1.0 - beta2)
+    bc1 = 1.0 - beta1 ** step
+    bc2_sqrt = math.sqrt(1.0 - beta2 ** step)
+    p = p - (lr / bc1) * (m / (v.sqrt() / bc2_sqrt + eps))
+    return p, m, v
+
+
+def lr_for_epoch(epoch_1based, lr0=5e-4, step_size=50, gamma=0.7):
+    """StepLR ticking once per epoch (tm:158-159): lr during epoch e = lr0 * gamma^floor((e-1)/step)."""
+    return lr0 * gamma ** ((epoch_1based - 1) // step_size)
+
+
+# --------------------------------------------------------------------------------------
+# the whole loop, as the reference runs it (this is also the timed CPU baseline)
+# --------------------------------------------------------------------------------------
+class RefTrainer:
+    """tm:109-161 + tpv:313-351 restated: Adam over *all* parameters (frozen ones are
+    skipped because their .grad stays None), StepLR per epoch, phase
+    flip when `iter == max_iter_world_model` is seen *before* the increment."""
+
+    def __init__(self, arch, sd, X, Y, batch_size, max_iter_world_model, lr=5e-4,
+                 lr_step=50, lr_gamma=0.7, coeff_cfg=None, eps_fn=None):
+        self.arch = arch
+        self.model = RefModel(arch)
+        self.model.load_state_dict(sd)
+        self.loader = make_loader(X, Y, batch_size)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=0.0)
+        self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=lr_step, gamma=lr_gamma)
+        self.max_iter_world_model = max_iter_world_model
+        self.coeff_cfg = coeff_cfg
+        self.iter = 0
+        self.global_batch = 0
+        self.eps_fn = eps_fn
+        self.world = True
+        self._apply_phase()
+
+    def _apply_phase(self):
+        self.model.set_learnable("_task_encoder", not self.world)
+        self.model.set_learnable("_motor_decoder", not self.world)
+        self.model.set_learnable("_world_model", self.world)
+        self.coeffs = phase_coeffs(self.world, self.coeff_cfg)
+
+    def step(self, max_batches=None):
+        if self.iter == self.max_iter_world_model:
+            self.world = False
+            self._apply_phase()
+        self.iter += 1
+        self.model.train()
+        acc, n = 0.0, 0
+        for x, y in self.loader:
+            if self.eps_fn is not None:
+                gb = self.global_batch
+                self.model.eps_source = lambda shape, gb=gb: self.eps_fn(gb, shape)
+            self.opt.zero_grad()
+            loss, _ = compute_loss(self.model, x, y, self.coeffs)
+            loss.backward()
+            self.opt.step()
+            acc += loss.item()
+            n += 1
+            self.global_batch += 1
+            if max_batches is not None and n >= max_batches:
+                break
+        self.sched.step()
+        return {"mean_train_loss": acc / (len(self.loader) if max_batches is None else n),
+                "mean_test_loss": 0.0}
+
+
+def eps_stream(seed, latent):
+    """Deterministic epsilon per *global minibatch index* (one randn_like per forward,
+    SURVEY.md 3.2): both the reference capture and the HIP path consume eps(gb)."""
+    def fn(global_batch, shape):
+        rng = np.random.default_rng([seed, int(global_batch)])
+        e = rng.standard_normal((int(shape[0]), latent)).astype(np.float32)
+        return torch.from_numpy(e)
+    return fn
+
+
+def time_cpu_baseline(arch, sd, X, Y, batch_size, world, n_batches, warmup=2, threads=None):
+    """Timed leg for bench.py's `cpu_baseline`: the reference's op sequence (per-sample
+    Dataset, collate, full forward incl. value branch and the world-phase extra forward,
+    autograd, torch.optim.Adam, per-batch .item()) on the host cores."""
+    if threads:
+        torch.set_num_threads(threads)
+    tr = RefTrainer(arch, sd, X, Y, batch_size, max_iter_world_model=(10 ** 9 if world else 0))
+    tr.step(max_batches=warmup)
+    t0 = time.perf_counter()
+    tr.step(max_batches=n_batches)
+    dt = time.perf_counter() - t0
+    done = min(n_batches, len(tr.loader))
+    samples = min(done * batch_size, len(X))
+    return dict(samples_per_s=samples / dt, seconds=dt, batches=done, samples=samples,
+                threads=torch.get_num_threads())
+
+
+# --------------------------------------------------------------------------------------
+# checkpoint layout (tpv:440-467, tm:209-213, rmt:870-928)
+# --------------------------------------------------------------------------------------
+def checkpoint_files(model_sd):
+    """Returns {filename: object} exactly as the reference writes them."""
+    def sub(net):
+        pre = net + "."
+        return OrderedDict((k[len(pre):], v) for k, v in model_sd.items() if k.startswith(pre))
+    return OrderedDict([
+        ("model.pth", OrderedDict(model_sd)),
+        ("model.pt", OrderedDict(model_sd)),
+        ("task_encoder.pt", {"task_encoder": sub("_task_encoder")}),
+        ("motor_decoder.pt", sub("_motor_decoder")),
+        ("world_model.pt", sub("_world_model")),
+    ])
+
+
+def tensor_digest(t, n_samples=16, seed=12345):
+    """Small fingerprint of a big tensor for fixtures: sum, abs-sum, L2, fixed samples."""
+    a = t.detach().double().reshape(-1).numpy()
+    idx = np.random.default_rng(seed).integers(0, a.size, size=n_samples)
+    return np.concatenate([[a.sum(), np.abs(a).sum(), math.sqrt(float((a * a).sum()))], a[idx]])

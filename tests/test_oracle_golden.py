@@ -1,0 +1,204 @@
+"""Pin oracle/refpath.py (our CPU restatement) to outputs captured from the reference
+itself (tests/golden/*.npz, produced by oracle/gen_golden.py in the dev container).
+Runs anywhere, no GPU, no /root/reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import refpath as R
+
+
+def arch_from_meta(meta):
+    Db, Da, Z, tw, td, mw, md_, ww, wd = [int(v) for v in meta[:9]]
+    return R.make_arch(Db, Da, latent=Z, te=(tw, td), md=(mw, md_), wm=(ww, wd))
+
+
+SINGLE = ["single_tiny", "single_c1", "single_c2", "single_default"]
+
+
+@pytest.mark.parametrize("name", SINGLE)
+def test_state_dict_layout_matches_reference(golden, name):
+    g = golden(name)
+    arch = arch_from_meta(g["meta"])
+    spec = R.state_dict_spec(arch)
+    assert [k for k, _ in spec] == list(g["sd_keys"])
+    shapes = [list(s) + [0] * (2 - len(s)) for _, s in spec]
+    assert shapes == g["sd_shapes"].tolist()
+    assert sum(int(np.prod(s)) for _, s in spec) == int(g["n_params"])
+    # normc property of the reference's own init: hidden rows norm 1, output rows 0.01
+    dims = R.net_layer_dims(arch)
+    expect = [0.01 if i == len(d) - 1 else 1.0 for d in dims.values() for i in range(len(d))]
+    np.testing.assert_allclose(g["init_row_norms_minmax"][:, 0], expect, rtol=1e-5)
+    np.testing.assert_allclose(g["init_row_norms_minmax"][:, 1], expect, rtol=1e-5)
+    sd = R.init_state_dict(arch, seed=1)
+    for k, v in sd.items():
+        if k.endswith("weight"):
+            i = int(k.split(".")[2])
+            net = k.split(".")[0]
+            std = 0.01 if i == len(dims[net]) - 1 else 1.0
+            np.testing.assert_allclose(v.norm(dim=1).numpy(), std, rtol=1e-5)
+
+
+def test_tensor_counts_26_24_36(golden):
+    assert len(golden("single_default")["sd_keys"]) == 26
+    assert len(golden("single_c1")["sd_keys"]) == 24
+    assert len(golden("single_c2")["sd_keys"]) == 36
+
+
+@pytest.mark.parametrize("name", SINGLE)
+def test_windows_and_loader_match_reference(golden, name):
+    g = golden(name)
+    arch = arch_from_meta(g["meta"])
+    n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
+    data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="iid")
+    X, Y = R.build_windows(data)
+    assert X.dtype == np.float64 and X.shape == (n_ep * (n_steps - 1), 1, 2 * arch["Db"])
+    assert len(X) == int(g["n_windows"])
+    loader = R.make_loader(X, Y, batch)
+    assert len(loader) == int(g["n_batches"])
+    assert str(g["sampler"]) == "SequentialSampler"
+    batches = list(loader)
+    assert batches[-1][0].shape[0] == int(g["last_batch_size"])
+    for tag, b in (("first", 0), ("mid", len(batches) // 2), ("last", len(batches) - 1)):
+        xb, yb = batches[b]
+        np.testing.assert_array_equal(R.tensor_digest(xb), g["loader_%s_x_digest" % tag])
+        np.testing.assert_array_equal(R.tensor_digest(yb), g["loader_%s_y_digest" % tag])
+        if "loader_%s_x" % tag in g:
+            np.testing.assert_array_equal(xb.numpy(), g["loader_%s_x" % tag])
+            np.testing.assert_array_equal(yb.numpy(), g["loader_%s_y" % tag])
+
+
+def test_num_samples_cap_is_exact():
+    data = R.synth_demo(0, 3, 20, 5, 2)
+    X, _ = R.build_windows(data, num_samples=25)
+    assert len(X) == 25
+    X2, _ = R.build_windows(data)
+    np.testing.assert_array_equal(X, X2[:25])
+
+
+@pytest.mark.parametrize("name", SINGLE)
+def test_single_batch_losses_and_grads_match_reference(golden, name):
+    g = golden(name)
+    arch = arch_from_meta(g["meta"])
+    n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
+    data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="iid")
+    X, Y = R.build_windows(data)
+    x, y = next(iter(R.make_loader(X, Y, batch)))
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    eps = R.eps_stream(2, arch["Z"])(0, (x.shape[0], arch["Z"]))
+    for world in (True, False):
+        tag = "world" if world else "joint"
+        out = R.loss_and_grads(arch, sd, x, y, eps, world)
+        # same ops, same order, same machine class -> essentially exact
+        np.testing.assert_allclose(out["total"].numpy(), g[tag + "_total"], rtol=1e-6)
+        for k in ("mu", "logvar", "z", "future_state"):
+            if tag + "_" + k in g:
+                np.testing.assert_allclose(out[k].numpy(), g[tag + "_" + k], rtol=1e-5, atol=1e-6)
+            else:
+                np.testing.assert_allclose(R.tensor_digest(out[k]), g["%s_%s_digest" % (tag, k)],
+                                           rtol=1e-5, atol=1e-6)
+        assert list(out["grads"].keys()) == list(g[tag + "_grad_keys"])
+        for k, gr in out["grads"].items():
+            ref = g["%s_graddigest::%s" % (tag, k)]
+            np.testing.assert_allclose(R.tensor_digest(gr), ref, rtol=2e-4, atol=1e-9)
+            full = "%s_grad::%s" % (tag, k)
+            if full in g:
+                np.testing.assert_allclose(gr.numpy(), g[full], rtol=1e-4, atol=1e-8)
+        # loss decomposition
+        if world:
+            np.testing.assert_allclose(out["loss_s"].numpy(), g["world_total"], rtol=1e-6)
+        else:
+            tot = out["loss_a"] + out["loss_kl"] + 1e-3 * out["loss_cyc"]
+            np.testing.assert_allclose(tot.numpy(), g["joint_total"], rtol=1e-6)
+    # value branch does not influence the loss (reference capture with VB weights + 1)
+    np.testing.assert_array_equal(g["joint_total_vb_perturbed"], g["joint_total"])
+
+
+def test_frozen_nets_get_no_grad(golden):
+    g = golden("single_tiny")
+    assert all(str(k).startswith("_world_model") for k in g["world_grad_keys"])
+    assert all(str(k).startswith(("_task_encoder", "_motor_decoder")) for k in g["joint_grad_keys"])
+
+
+def test_checkpoint_layout_matches_reference(golden):
+    g = golden("single_default")
+    arch = arch_from_meta(g["meta"])
+    sd = R.init_state_dict(arch, 1)
+    files = R.checkpoint_files(sd)
+    assert sorted(files) == list(g["ckpt_files"])
+    assert str(g["ckpt_return_basename"]) == "model.pth"
+    assert list(g["ckpt_te_outer_keys"]) == ["task_encoder"]
+    for f, obj in files.items():
+        if f == "task_encoder.pt":
+            obj = obj["task_encoder"]
+        assert list(obj.keys()) == list(g["ckpt_keys::" + f]), f
+
+
+@pytest.mark.parametrize("name", ["train_tiny", "train_c1"])
+def test_training_run_matches_reference(golden, name):
+    g = golden(name)
+    arch = arch_from_meta(g["meta"])
+    n_ep, n_steps, batch, m_world, n_epochs, lr_step = [int(v) for v in g["meta"][9:15]]
+    data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
+    X, Y = R.build_windows(data)
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    tr = R.RefTrainer(arch, sd, X, Y, batch, m_world, lr_step=lr_step,
+                      eps_fn=R.eps_stream(2, arch["Z"]))
+    losses = []
+    for e in range(n_epochs):
+        lr = tr.opt.param_groups[0]["lr"]
+        assert lr == pytest.approx(g["epoch_lrs"][e], rel=1e-12)
+        assert lr == pytest.approx(R.lr_for_epoch(e + 1, step_size=lr_step), rel=1e-12)
+        losses.append(tr.step()["mean_train_loss"])
+        tag = "after_epoch%d" % (e + 1)
+        if any(k.startswith(tag + "_digest::") for k in g.files):
+            for k, v in tr.model.state_dict().items():
+                np.testing.assert_allclose(R.tensor_digest(v), g["%s_digest::%s" % (tag, k)],
+                                           rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(losses, g["epoch_losses"], rtol=1e-5)
+    assert tr.global_batch == int(g["eps_calls"])
+    # Adam bookkeeping (lazy state, WM stops at the switch, TE/MD start at t = 1, VB never)
+    named = dict(tr.model.named_parameters())
+    assert list(named.keys()) == list(g["adam_keys"])
+    nb = len(tr.loader)
+    for k, has, st in zip(g["adam_keys"], g["adam_has_state"], g["adam_steps"]):
+        k = str(k)
+        if k.startswith("_value_branch"):
+            assert not has
+        elif k.startswith("_world_model"):
+            assert has and st == nb * m_world
+        else:
+            assert has and st == nb * (n_epochs - m_world)
+        ours = tr.opt.state.get(named[k], {})
+        assert (len(ours) > 0) == bool(has)
+        if "adam_exp_avg::" + k in g:
+            np.testing.assert_allclose(ours["exp_avg"].numpy(), g["adam_exp_avg::" + k],
+                                       rtol=1e-3, atol=1e-9)
+            np.testing.assert_allclose(ours["exp_avg_sq"].numpy(), g["adam_exp_avg_sq::" + k],
+                                       rtol=1e-3, atol=1e-12)
+
+
+def test_world_model_frozen_after_switch(golden):
+    g = golden("train_tiny")
+    m_world = int(g["meta"][12])
+    n_epochs = int(g["meta"][13])
+    for k in g.files:
+        if k.startswith("after_epoch%d::_world_model" % m_world):
+            tail = k.split("::")[1]
+            np.testing.assert_array_equal(g[k], g["after_epoch%d::%s" % (n_epochs, tail)])
+
+
+def test_adam_restatement_matches_torch():
+    torch.manual_seed(0)
+    p = torch.randn(37, 11)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([ref], lr=5e-4)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    q = p.clone()
+    for t in range(1, 6):
+        gr = torch.randn(37, 11)
+        ref.grad = gr.clone()
+        opt.step()
+        q, m, v = R.adam_reference_update(q, gr, m, v, t, 5e-4)
+        np.testing.assert_allclose(q.numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-7)
