@@ -1,0 +1,192 @@
+/* pvae.h -- C ABI of libpvae_gfx950.so: the MI355X-native hot path of the PhysicsVAE
+ * supervised training loop (world model + conditional VAE).
+ *
+ * The reference has no FFI on this path: it is pure Python calling stock PyTorch ops
+ * (SURVEY.md 8b).  The entry points below are therefore the boundary a maintainer would
+ * bind from the reference's own Python (ctypes stub in INTEGRATION.md); each one names
+ * the reference code it replaces.  `tpv` = train_physics_vae.py, `tm` = torch_models.py,
+ * `rmt` = rllib_model_torch.py.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every call returns 0 on success, <0 on error; pvae_last_error() gives the text
+ *     (thread-local).  No call synchronises the host with the device.
+ *   - the CALLER owns every device buffer (parameters, Adam moments, gradients, dataset,
+ *     workspace) and passes the hipStream_t (as void*) to launch on.  The library owns
+ *     only the opaque pvae_ctx (layout tables + bound pointers).  One ctx per process per
+ *     GPU; a ctx is not thread-safe.
+ *   - all arithmetic is fp32 (v_mfma_f32_16x16x4_f32 for the contractions).
+ *
+ * Parameter arena.  The three trainable stacks live in ONE flat fp32 arena
+ *   [ task encoder | motor decoder | world model ]
+ * each Linear stored as W[n_out_pad][ld] (row-major, ld = n_in rounded up to 64 floats,
+ * n_out_pad = n_out rounded up to 64) followed by bias[n_out_pad]; pad entries are zero
+ * and stay zero.  The checkpoint tensor `<net>._model.<i>._model.0.weight` of shape
+ * [n_out, n_in] (rmt:234-283) is the strided view W[:n_out, :n_in] of that block, so the
+ * reference's state_dict layout is the source of truth and no packing pass exists.
+ * Gradients and the two Adam moments use arenas of the same layout.
+ */
+#ifndef PVAE_H
+#define PVAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVAE_ABI_VERSION 1
+
+typedef struct pvae_ctx pvae_ctx;
+
+enum { PVAE_NET_TE = 0, PVAE_NET_MD = 1, PVAE_NET_WM = 2, PVAE_NUM_NETS = 3 };
+enum { PVAE_PHASE_WORLD = 0, PVAE_PHASE_JOINT = 1 };
+
+/* flags for pvae_forward_backward */
+enum {
+    PVAE_FLAG_FUSED_ADAM = 1, /* apply Adam inside the weight-gradient kernels (1 GPU)       */
+    PVAE_FLAG_NO_BACKWARD = 2 /* forward + losses only (tm:147-156 test loop, parity probes) */
+};
+
+/* Architecture.  Mirrors the dict keys of tpv:247-286 / gen_layers tpv:180-192:
+ * TE: 2*Db -> te_width x te_depth -> 2*Z ; MD: Db+Z -> ... -> Da ; WM: Db+Da -> ... -> Db.
+ * ReLU after every hidden layer, linear output layer. */
+typedef struct pvae_config {
+    int32_t dim_body;   /* Db */
+    int32_t dim_action; /* Da */
+    int32_t latent;     /* Z  */
+    int32_t te_width, te_depth;
+    int32_t md_width, md_depth;
+    int32_t wm_width, wm_depth;
+    int32_t max_batch;  /* largest minibatch (rows) this ctx will be asked to process */
+} pvae_config;
+
+typedef struct pvae_layer_info {
+    int32_t net;       /* PVAE_NET_*                                    */
+    int32_t index;     /* position inside the stack (0 = first Linear)  */
+    int32_t n_in;      /* checkpoint shape is [n_out, n_in]             */
+    int32_t n_out;
+    int32_t ld;        /* row stride of W in floats (n_in padded to 64) */
+    int32_t n_out_pad; /* rows allocated (n_out padded to 64)           */
+    int64_t w_offset;  /* float offset of W[0][0] in the arena          */
+    int64_t b_offset;  /* float offset of bias[0] in the arena          */
+} pvae_layer_info;
+
+/* Loss weights and Adam hyper-parameters of one optimizer step.
+ * tpv:331-335 (phase coefficients), tm:119-122 (Adam defaults), tm:158-159 (lr from StepLR). */
+typedef struct pvae_step_params {
+    float a_rec_coeff;     /* motor_decoder_a_rec_coeff (1.0)  */
+    float kl_coeff;        /* vae_kl_coeff (beta)              */
+    float s_rec_coeff;     /* world_model_s_rec_coeff          */
+    float cycle_coeff;     /* vae_cycle_coeff (1e-3)           */
+    float lr;              /* learning rate of this epoch      */
+    float beta1, beta2, adam_eps;
+    int32_t adam_t[PVAE_NUM_NETS]; /* 1-based Adam step count per net for THIS update */
+    int32_t global_rows;   /* rows of the global minibatch (= rows on 1 GPU); losses and
+                              gradients are scaled by 1/global_rows so a sum all-reduce over
+                              ranks yields the reference's batch-mean gradient */
+    uint64_t rng_seed;     /* Philox key when eps == NULL      */
+    uint64_t rng_offset;   /* (global step, first global row) -> counter */
+} pvae_step_params;
+
+/* ---- layout queries (pure host arithmetic, no GPU needed) --------------------------- */
+int pvae_abi_version(void);
+const char* pvae_last_error(void);
+int pvae_num_layers(const pvae_config* cfg);
+int pvae_layer(const pvae_config* cfg, int i, pvae_layer_info* out);
+int64_t pvae_arena_floats(const pvae_config* cfg);
+/* contiguous [offset, offset+count) of one net inside the arena */
+int pvae_net_segment(const pvae_config* cfg, int net, int64_t* offset, int64_t* count);
+size_t pvae_workspace_bytes(const pvae_config* cfg);
+
+/* ---- context ------------------------------------------------------------------------ */
+int pvae_create(const pvae_config* cfg, pvae_ctx** out);
+void pvae_destroy(pvae_ctx* ctx);
+/* params / grads / exp_avg / exp_avg_sq: device arenas of pvae_arena_floats() floats.
+ * Replaces the per-tensor storage of nn.Linear + torch.optim.Adam state (tm:119-122). */
+int pvae_bind_arenas(pvae_ctx* ctx, float* params, float* grads, float* exp_avg,
+                     float* exp_avg_sq);
+int pvae_bind_workspace(pvae_ctx* ctx, void* workspace, size_t bytes);
+/* Demonstration set resident in HBM, de-duplicated: states[n_rows][Db], actions[n_rows][Da]
+ * (fp32, dense), window_row[n_windows] = row of s_t (s_{t+1} is row+1, a_t is the same row).
+ * Replaces the float64 X[N,1,2Db] / Y[N,1,Da] arrays of load_dataset_for_PhysicsVAE
+ * (tpv:117-164) and DatasetBase.__getitem__ (tm:52-56). */
+int pvae_bind_dataset(pvae_ctx* ctx, const float* states, const float* actions,
+                      const int32_t* window_row, int64_t n_rows, int64_t n_windows);
+
+/* ---- hot path ------------------------------------------------------------------------ */
+/* Minibatch gather: windows [first_window, first_window+rows) -> network input panels.
+ * Replaces DataLoader + default collate over DatasetBase (tm:166-175, 137-139). */
+int pvae_gather(pvae_ctx* ctx, int64_t first_window, int32_t rows, void* stream);
+/* Same, from explicit device tensors x[rows][2*Db], y[rows][Da] (dense fp32): the
+ * compute_loss(y, x) entry of tpv:361 for callers that bring their own batch. */
+int pvae_set_batch(pvae_ctx* ctx, const float* x, const float* y, int32_t rows, void* stream);
+
+/* Forward + losses (+ backward, + optional fused Adam) over the batch staged by
+ * pvae_gather/pvae_set_batch.  Replaces compute_loss (tpv:361-435), PhysicsVAE.forward
+ * (rmt:742-853), loss.backward() (tm:142) and, with PVAE_FLAG_FUSED_ADAM,
+ * optimizer.step() (tm:143).
+ *   eps      : device [rows][Z] standard-normal draws for the reparameterisation
+ *              (rmt:734-740), or NULL to draw them on chip (Philox4x32-10, Box-Muller).
+ *   loss_out : device float[5] = {total, loss_a, loss_kl, loss_s, loss_cyc} (this rank's
+ *              share: sums over local rows / global_rows).
+ * World phase: only the world model runs (the reference's discarded TE/MD/VB forward,
+ * tpv:378, is not algorithmically required and is skipped). */
+int pvae_forward_backward(pvae_ctx* ctx, int phase, int32_t rows, const pvae_step_params* sp,
+                          const float* eps, float* loss_out, int flags, void* stream);
+/* Adam over the nets in net_mask (bit n = PVAE_NET_n) using the bound grads arena.
+ * Replaces torch.optim.Adam.step (tm:143) for the data-parallel path (after the gradient
+ * all-reduce). */
+int pvae_adam(pvae_ctx* ctx, int net_mask, const pvae_step_params* sp, void* stream);
+
+/* One whole optimizer step on the bound dataset: gather + forward/backward + Adam.
+ * This is the body of the `for data in self.train_loader` loop (tm:137-144). */
+int pvae_train_step(pvae_ctx* ctx, int phase, int64_t first_window, int32_t rows,
+                    const pvae_step_params* sp, const float* eps, float* loss_out, void* stream);
+
+/* ---- inspection (parity tests) ------------------------------------------------------- */
+/* Copy a forward intermediate of the last pvae_forward_backward into dst (dense
+ * [rows][width] fp32, device).  what: 0 = mu, 1 = logvar, 2 = z, 3 = a_hat (MD output),
+ * 4 = s2_hat (WM output), 5 = eps actually used. */
+int pvae_read_tensor(pvae_ctx* ctx, int what, float* dst, int32_t rows, void* stream);
+
+/* Rollout inference (rmt:742-771 at small batch): obs[rows][2*Db] -> a_hat[rows][Da]
+ * (+ optional s2_hat[rows][Db], mu/logvar/z).  eps NULL + noise=0 -> z = mu
+ * (latent_prior_noise False). */
+int pvae_infer(pvae_ctx* ctx, const float* obs, int32_t rows, const float* eps, int noise,
+               uint64_t rng_seed, uint64_t rng_offset, float* a_hat, float* s2_hat, float* z_out,
+               void* stream);
+
+/* One stack on its own: in[rows][n_in] (dense) -> out[rows][n_out] (dense).  The building
+ * block behind forward_encoder / forward_decoder / forward_world (rmt:773-844) when a caller
+ * drives the stages separately (e.g. EnvRunner pass_through: z ~ N(0,I) straight into the
+ * motor decoder, envs/rllib_env_imitation.py:234-266). */
+int pvae_net_forward(pvae_ctx* ctx, int net, const float* in, int32_t rows, float* out, void* stream);
+/* Sampler on its own (rmt:734-740): mu_logvar[rows][2Z] -> z[rows][Z];
+ * eps NULL -> Philox; noise = 0 -> z = mu. */
+int pvae_reparam(pvae_ctx* ctx, const float* mu_logvar, int32_t rows, const float* eps, int noise,
+                 uint64_t rng_seed, uint64_t rng_offset, float* z_out, void* stream);
+
+/* Per-kernel timing with HIP events on the launch stream (bench.py's `roofline` object).
+ * While enabled every contraction launch is bracketed by an event pair (this serialises the
+ * host a little, so it is used in a separate instrumented pass, never in a timed region).
+ * category: 0 = forward tile kernel, 1 = input-gradient, 2 = weight-gradient(+Adam).
+ * pvae_profile_read synchronises on the recorded events and returns the summed duration
+ * (ms), launch count and ALGORITHMIC flops (2*rows*n_in*n_out on the unpadded dims). */
+int pvae_profile_enable(int on);
+int pvae_profile_read(int category, double* total_ms, int64_t* launches, double* total_flops);
+
+/* GEMM micro-entry for kernel-level parity/roofline probes:
+ * kind 0: C[M][N] = relu?(A[M][K] * W[N][K]^T + bias)   (forward layer)
+ * kind 1: C[M][K] = (dZ[M][N] * W[N][K]) (.* (mask > 0)) (input gradient)
+ * kind 2: C[N][K] = dZ[M][N]^T * X[M][K]                 (weight gradient)
+ * All dims multiples of 64 (M of 32), leading dims given in floats. */
+int pvae_gemm_probe(int kind, const float* a, int lda, const float* b, int ldb, float* c, int ldc,
+                    const float* bias_or_mask, int ld_mask, int m, int n, int k, int relu,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVAE_H */

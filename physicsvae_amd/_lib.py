@@ -1,0 +1,94 @@
+"""ctypes binding of include/pvae.h.  There is no fallback: if the HIP library is missing
+or a call fails, a RuntimeError is raised."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpvae_gfx950.so")
+
+NET_TE, NET_MD, NET_WM = 0, 1, 2
+NET_NAMES = {NET_TE: "_task_encoder", NET_MD: "_motor_decoder", NET_WM: "_world_model"}
+PHASE_WORLD, PHASE_JOINT = 0, 1
+FLAG_FUSED_ADAM, FLAG_NO_BACKWARD = 1, 2
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dim_body", "dim_action", "latent", "te_width", "te_depth", "md_width", "md_depth",
+        "wm_width", "wm_depth", "max_batch")]
+
+
+class LayerInfo(C.Structure):
+    _fields_ = [("net", C.c_int32), ("index", C.c_int32), ("n_in", C.c_int32),
+                ("n_out", C.c_int32), ("ld", C.c_int32), ("n_out_pad", C.c_int32),
+                ("w_offset", C.c_int64), ("b_offset", C.c_int64)]
+
+
+class StepParams(C.Structure):
+    _fields_ = [("a_rec_coeff", C.c_float), ("kl_coeff", C.c_float), ("s_rec_coeff", C.c_float),
+                ("cycle_coeff", C.c_float), ("lr", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("adam_eps", C.c_float), ("adam_t", C.c_int32 * 3),
+                ("global_rows", C.c_int32), ("rng_seed", C.c_uint64), ("rng_offset", C.c_uint64)]
+
+
+_P = C.c_void_p
+_SIGS = {
+    "pvae_abi_version": (C.c_int, []),
+    "pvae_last_error": (C.c_char_p, []),
+    "pvae_num_layers": (C.c_int, [C.POINTER(Config)]),
+    "pvae_layer": (C.c_int, [C.POINTER(Config), C.c_int, C.POINTER(LayerInfo)]),
+    "pvae_arena_floats": (C.c_int64, [C.POINTER(Config)]),
+    "pvae_net_segment": (C.c_int, [C.POINTER(Config), C.c_int, C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int64)]),
+    "pvae_workspace_bytes": (C.c_size_t, [C.POINTER(Config)]),
+    "pvae_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "pvae_destroy": (None, [_P]),
+    "pvae_bind_arenas": (C.c_int, [_P, _P, _P, _P, _P]),
+    "pvae_bind_workspace": (C.c_int, [_P, _P, C.c_size_t]),
+    "pvae_bind_dataset": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64]),
+    "pvae_gather": (C.c_int, [_P, C.c_int64, C.c_int32, _P]),
+    "pvae_set_batch": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
+    "pvae_forward_backward": (C.c_int, [_P, C.c_int, C.c_int32, C.POINTER(StepParams), _P, _P,
+                                        C.c_int, _P]),
+    "pvae_adam": (C.c_int, [_P, C.c_int, C.POINTER(StepParams), _P]),
+    "pvae_train_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P,
+                                  _P]),
+    "pvae_read_tensor": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P]),
+    "pvae_infer": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
+    "pvae_net_forward": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P, _P]),
+    "pvae_reparam": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int, C.c_uint64, C.c_uint64, _P, _P]),
+    "pvae_profile_enable": (C.c_int, [C.c_int]),
+    "pvae_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_double)]),
+    "pvae_gemm_probe": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+}
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def load():
+    """Load libpvae_gfx950.so (built by physicsvae_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "%s is missing: the HIP hot path is not built (run `python -m physicsvae_amd.build`); "
+            "there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pvae_abi_version() != 1:
+        raise RuntimeError("libpvae ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc < 0:
+        msg = load().pvae_last_error().decode("utf-8", "replace")
+        raise RuntimeError("libpvae %s failed (%d): %s" % (what, rc, msg))
+    return rc

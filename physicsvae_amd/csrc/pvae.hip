@@ -1,0 +1,887 @@
+// pvae.hip -- libpvae_gfx950.so: C-ABI (include/pvae.h) + glue kernels around the MFMA
+// tile kernel of pvae_gemm.h.  gfx950 (MI355X) only; built with
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared pvae.hip -o libpvae_gfx950.so
+//
+// Reference lines restated by each kernel are cited at the kernel (tpv / tm / rmt as in
+// include/pvae.h).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "pvae_gemm.h"
+#include "pvae_layout.h"
+
+using namespace pvae;
+
+// ---------------------------------------------------------------------------------------
+// error handling
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) return fail(-10, "%s: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// optional per-launch timing (HIP events on the launch stream)
+// ---------------------------------------------------------------------------------------
+struct Profiler {
+    bool on = false;
+    static constexpr int kMax = 8192;
+    hipEvent_t ev[kMax][2];
+    int cat[kMax];
+    double flops[kMax];
+    int n = 0, created = 0;
+    int begin(int category, double fl, hipStream_t st) {
+        if (!on || n >= kMax) return -1;
+        if (n >= created) {
+            if (hipEventCreate(&ev[n][0]) != hipSuccess || hipEventCreate(&ev[n][1]) != hipSuccess) return -1;
+            created = n + 1;
+        }
+        cat[n] = category;
+        flops[n] = fl;
+        hipEventRecord(ev[n][0], st);
+        return n;
+    }
+    void end(int slot, hipStream_t st) {
+        if (slot < 0) return;
+        hipEventRecord(ev[slot][1], st);
+        n = slot + 1;
+    }
+};
+static Profiler g_prof;
+
+struct pvae_ctx {
+    Layout L;
+    Workspace W;
+    float* params = nullptr;
+    float* grads = nullptr;
+    float* m = nullptr;
+    float* v = nullptr;
+    float* ws = nullptr;
+    const float* states = nullptr;
+    const float* actions = nullptr;
+    const int32_t* window_row = nullptr;
+    int64_t n_rows = 0, n_windows = 0;
+    int staged_rows = 0;
+    double staged_rows_f = 0;    // rows of the batch being processed (for the profiler's flop count)
+};
+
+// ---------------------------------------------------------------------------------------
+// glue kernels
+// ---------------------------------------------------------------------------------------
+
+// Minibatch staging.  One block per (padded) batch row.  Builds the three network input
+// panels and the two target panels from either the HBM-resident demonstration set
+// (window_row != null: rows s and s+1 of `states`, row s of `actions`; tpv:133-156 windows,
+// tm:52-56 float64->float32, tm:166-175 collate) or explicit x[rows][2Db] / y[rows][Da]
+// (tpv:365-376).  Pad rows and pad columns are written as zeros so that every GEMM can run
+// on whole tiles without bounds checks.
+__global__ void __launch_bounds__(256)
+stage_batch_kernel(const float* __restrict__ states, const float* __restrict__ actions,
+                   const int32_t* __restrict__ window_row, long long first_window,
+                   const float* __restrict__ x, const float* __restrict__ y, int rows, int Db, int Da,
+                   float* __restrict__ te_in, int ld_te, float* __restrict__ md_in, int ld_md,
+                   float* __restrict__ wm_in, int ld_wm, float* __restrict__ s2, int ld_s2,
+                   float* __restrict__ act_t, int ld_a) {
+    const int r = blockIdx.x;
+    const bool valid = r < rows;
+    const float* p1 = nullptr;
+    const float* p2 = nullptr;
+    const float* pa = nullptr;
+    if (valid) {
+        if (window_row) {
+            const long long s = window_row[first_window + r];
+            p1 = states + s * Db;
+            p2 = p1 + Db;
+            pa = actions + s * Da;
+        } else {
+            p1 = x + (size_t)r * 2 * Db;
+            p2 = p1 + Db;
+            pa = y ? y + (size_t)r * Da : nullptr;
+        }
+    }
+    int ld_max = ld_te;
+    if (ld_md > ld_max) ld_max = ld_md;
+    if (ld_wm > ld_max) ld_max = ld_wm;
+    for (int c = threadIdx.x; c < ld_max; c += 256) {
+        const float v1 = (valid && c < Db) ? p1[c] : 0.f;
+        const float v2 = (valid && c < Db) ? p2[c] : 0.f;
+        const float va = (valid && pa && c < Da) ? pa[c] : 0.f;
+        if (c < ld_te) {
+            float t = v1;
+            if (c >= Db) t = (valid && c < 2 * Db) ? p2[c - Db] : 0.f;
+            te_in[(size_t)r * ld_te + c] = t;
+        }
+        if (c < ld_md) md_in[(size_t)r * ld_md + c] = v1;      // z columns filled by reparam
+        if (c < ld_wm) {
+            float t = v1;
+            if (c >= Db) t = (valid && pa && c < Db + Da) ? pa[c - Db] : 0.f;
+            wm_in[(size_t)r * ld_wm + c] = t;
+        }
+        if (c < ld_s2) s2[(size_t)r * ld_s2 + c] = v2;
+        if (c < ld_a) act_t[(size_t)r * ld_a + c] = va;
+    }
+}
+
+__device__ inline float block_sum_256(float v) {
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// nn.MSELoss (tm:99) of pred vs target over rows x D, plus its gradient:
+//   partial[b] = sum (pred - target)^2 over this block's rows      (finalize scales by 1/(B*D))
+//   dz = grad_scale * (pred - target) [+ extra]                    grad_scale = coeff*2/(B*D)
+// Used for the world-model MSE (tpv:411-414), the cycle loss (tpv:417-419) and the action
+// reconstruction loss (tpv:381-382; `extra` = gradient arriving through the frozen world
+// model, columns [Db, Db+Da) of d(wm_in)).
+__global__ void __launch_bounds__(256)
+mse_grad_kernel(const float* __restrict__ pred, int ldp, const float* __restrict__ target, int ldt,
+                float* __restrict__ dz, int ldz, int rows, int rows_pad, int D, float grad_scale,
+                const float* __restrict__ extra, int lde, int extra_col0, float* __restrict__ partial) {
+    float acc = 0.f;
+    for (int r = blockIdx.x; r < rows_pad; r += gridDim.x) {
+        const bool valid = r < rows;
+        for (int c = threadIdx.x; c < ldz; c += 256) {
+            float g = 0.f;
+            if (valid && c < D) {
+                const float d = pred[(size_t)r * ldp + c] - target[(size_t)r * ldt + c];
+                acc += d * d;
+                g = grad_scale * d;
+                if (extra) g += extra[(size_t)r * lde + extra_col0 + c];
+            }
+            if (dz) dz[(size_t)r * ldz + c] = g;
+        }
+    }
+    const float s = block_sum_256(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// Philox4x32-10 (Salmon et al., SC'11) -> one standard normal via Box-Muller.
+__device__ inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ inline float philox_normal(uint64_t seed, uint64_t offset, uint32_t row, uint32_t col) {
+    uint32_t c[4] = {(uint32_t)offset, (uint32_t)(offset >> 32), row, col};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const float u1 = ((float)c[0] + 0.5f) * 2.3283064365386963e-10f;   // (0,1)
+    const float u2 = ((float)c[1] + 0.5f) * 2.3283064365386963e-10f;
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+// Reparameterisation sampler + KL-to-N(0,I) partial sums (rmt:734-740, 795-800; tpv:384-389):
+//   z = mu + eps * exp(0.5 logvar)      written into md_in[:, Db:Db+Z]
+//   partial[b] = sum -0.5 (1 + logvar - mu^2 - exp(logvar))     (finalize scales by 1/B)
+__global__ void __launch_bounds__(256)
+reparam_kernel(const float* __restrict__ te_out, int ldte, const float* __restrict__ eps_in,
+               float* __restrict__ eps_used, float* __restrict__ md_in, int ld_md, int Db, int Z, int rows,
+               int rows_pad, int noise, unsigned long long seed, unsigned long long offset,
+               float* __restrict__ partial) {
+    float acc = 0.f;
+    const int total = rows_pad * Z;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int r = idx / Z, c = idx - r * Z;
+        float z = 0.f, e = 0.f;
+        if (r < rows) {
+            const float mu = te_out[(size_t)r * ldte + c];
+            const float lv = te_out[(size_t)r * ldte + Z + c];
+            if (noise) e = eps_in ? eps_in[(size_t)r * Z + c] : philox_normal(seed, offset, r, c);
+            z = mu + e * expf(0.5f * lv);
+            acc += -0.5f * (1.0f + lv - mu * mu - expf(lv));
+        }
+        md_in[(size_t)r * ld_md + Db + c] = z;
+        eps_used[(size_t)r * Z + c] = e;
+    }
+    const float s = block_sum_256(acc);
+    if (threadIdx.x == 0 && partial) partial[blockIdx.x] = s;
+}
+
+// Backward of the sampler + KL (autograd of rmt:734-740 and tpv:388):
+//   dmu = dz + (beta/B) mu ;  dlogvar = dz * eps * 0.5 exp(0.5 lv) + (beta/B) 0.5 (exp(lv) - 1)
+__global__ void __launch_bounds__(256)
+reparam_bwd_kernel(const float* __restrict__ d_md_in, int ld_md, int Db, const float* __restrict__ te_out,
+                   int ldte, const float* __restrict__ eps_used, float* __restrict__ dz_te, int ld_dz,
+                   int rows, int rows_pad, int Z, float kl_scale) {
+    const int total = rows_pad * ld_dz;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int r = idx / ld_dz, c = idx - r * ld_dz;
+        float g = 0.f;
+        if (r < rows && c < 2 * Z) {
+            const int cz = c < Z ? c : c - Z;
+            const float dzv = d_md_in[(size_t)r * ld_md + Db + cz];
+            const float mu = te_out[(size_t)r * ldte + cz];
+            const float lv = te_out[(size_t)r * ldte + Z + cz];
+            if (c < Z) {
+                g = dzv + kl_scale * mu;
+            } else {
+                const float e = eps_used[(size_t)r * Z + cz];
+                g = dzv * e * 0.5f * expf(0.5f * lv) + kl_scale * 0.5f * (expf(lv) - 1.0f);
+            }
+        }
+        dz_te[idx] = g;
+    }
+}
+
+// dst[r][dst_col0 + c] = src[r][src_col0 + c]
+__global__ void __launch_bounds__(256)
+copy_cols_kernel(const float* __restrict__ src, int lds_, int src_col0, float* __restrict__ dst, int ldd,
+                 int dst_col0, int rows, int ncols) {
+    const int total = rows * ncols;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int r = idx / ncols, c = idx - r * ncols;
+        dst[(size_t)r * ldd + dst_col0 + c] = src[(size_t)r * lds_ + src_col0 + c];
+    }
+}
+
+// dst[rows_pad][ld] = zero-padded copy of dense src[rows][n]
+__global__ void __launch_bounds__(256)
+pad_copy_kernel(const float* __restrict__ src, int n, int rows, float* __restrict__ dst, int ld, int rows_pad) {
+    const int total = rows_pad * ld;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int r = idx / ld, c = idx - r * ld;
+        dst[idx] = (r < rows && c < n) ? src[(size_t)r * n + c] : 0.f;
+    }
+}
+
+// Bias gradients db[n] = sum_rows dZ[r][n] (autograd of nn.Linear bias) for up to 16 layers
+// in one launch, consumed by Adam in registers (fused) or stored to the gradient arena.
+struct BiasJob {
+    const float* dz;
+    int ld;            // = n_out_pad
+    float* b;          // params bias (fused) or grads bias (store)
+    float* m;
+    float* v;
+    int net;
+};
+struct BiasJobs {
+    BiasJob job[16];
+    int n;
+    AdamScalars s[PVAE_NUM_NETS];
+};
+
+__global__ void __launch_bounds__(256)
+bias_grad_kernel(BiasJobs jobs, int rows_pad, int fused) {
+    const BiasJob j = jobs.job[blockIdx.y];
+    const int c0 = blockIdx.x * 64;
+    if (c0 >= j.ld) return;
+    const int col = c0 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int r = part; r < rows_pad; r += 4) acc += j.dz[(size_t)r * j.ld + col];
+    __shared__ float red[4][64];
+    red[part][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (part == 0) {
+        const int t = threadIdx.x;
+        const float g = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+        if (fused) {
+            float p = j.b[col], m = j.m[col], v = j.v[col];
+            adam_update(g, p, m, v, jobs.s[j.net]);
+            j.b[col] = p; j.m[col] = m; j.v[col] = v;
+        } else {
+            j.b[col] = g;
+        }
+    }
+}
+
+// Fixed-order sum of the per-block partials -> {total, loss_a, loss_kl, loss_s, loss_cyc}
+// (tpv:430-435 weighting).
+struct LossFinal {
+    float scale[4];    // a, kl, s, cyc: 1/(B*Da), 1/B, 1/(B*Db), 1/(B*Db)
+    float coeff[4];
+    int active[4];
+    int nparts[4];
+};
+__global__ void finalize_loss_kernel(const float* __restrict__ partial, LossFinal f, float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int t = 0; t < 4; ++t) {
+            float s = 0.f;
+            if (f.active[t]) {
+                for (int i = 0; i < f.nparts[t]; ++i) s += partial[(t + 1) * kLossParts + i];
+                s *= f.scale[t];
+            }
+            out[1 + t] = s;
+            total += f.coeff[t] * s;
+        }
+        out[0] = total;
+    }
+}
+
+// Multi-tensor Adam over one contiguous arena segment (data-parallel path, after the
+// gradient all-reduce).  28 B/param of traffic: read p,g,m,v, write p,m,v.
+__global__ void __launch_bounds__(256)
+adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                 float* __restrict__ v, long long n4, AdamScalars s) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += gridDim.x * 256ll) {
+        v4f pp = reinterpret_cast<v4f*>(p)[i];
+        const v4f gg = reinterpret_cast<const v4f*>(g)[i];
+        v4f mm = reinterpret_cast<v4f*>(m)[i];
+        v4f vv = reinterpret_cast<v4f*>(v)[i];
+        adam_update4(gg, pp, mm, vv, s);
+        reinterpret_cast<v4f*>(p)[i] = pp;
+        reinterpret_cast<v4f*>(m)[i] = mm;
+        reinterpret_cast<v4f*>(v)[i] = vv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------------------
+static AdamScalars adam_scalars(const pvae_step_params* sp, int net) {
+    // torch computes the bias corrections in Python floats (double): tm:119-122 -> torch/optim/adam.py
+    const int t = sp->adam_t[net] > 0 ? sp->adam_t[net] : 1;
+    const double bc1 = 1.0 - std::pow((double)sp->beta1, t);
+    const double bc2 = 1.0 - std::pow((double)sp->beta2, t);
+    AdamScalars s;
+    s.step_size = (float)((double)sp->lr / bc1);
+    s.bc2_sqrt = (float)std::sqrt(bc2);
+    s.beta1 = sp->beta1;
+    s.beta2 = sp->beta2;
+    s.eps = sp->adam_eps;
+    return s;
+}
+
+static int check_ready(const pvae_ctx* c, bool need_arenas) {
+    if (!c) return fail(-1, "null ctx");
+    if (!c->ws) return fail(-2, "workspace not bound");
+    if (need_arenas && !c->params) return fail(-2, "parameter arena not bound");
+    return 0;
+}
+
+static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st) {
+    const NetLayout& N = c->L.net[n];
+    const float* x = c->ws + c->W.net[n].in;
+    int ldx = N.layers[0].ld;
+    for (const Layer& l : N.layers) {
+        float* out = c->ws + c->W.net[n].act[l.index];
+        const int ps = g_prof.begin(0, 2.0 * c->staged_rows_f * l.n_in * l.n_out, st);
+        HIP_TRY(gemm_forward(x, ldx, c->params + l.w_off, l.ld, c->params + l.b_off, out, l.n_out_pad,
+                             rows_pad, l.n_out_pad, l.ld, l.last ? 0 : 1, st));
+        g_prof.end(ps, st);
+        x = out;
+        ldx = l.n_out_pad;
+    }
+    return 0;
+}
+
+// dz[last] must be filled.  For each layer, last to first: input gradient (reads W), then
+// weight gradient (+Adam, writes W) -- in that order on one stream so W is never updated
+// before its last reader has run.
+static int backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool input_grad,
+                        const pvae_step_params* sp, bool fused, hipStream_t st) {
+    const NetLayout& N = c->L.net[n];
+    const NetWork& w = c->W.net[n];
+    const AdamScalars as = adam_scalars(sp, n);
+    for (int i = (int)N.layers.size() - 1; i >= 0; --i) {
+        const Layer& l = N.layers[i];
+        const float* dz = c->ws + w.dz[i];
+        const float* xin = i == 0 ? c->ws + w.in : c->ws + w.act[i - 1];
+        const double fl = 2.0 * c->staged_rows_f * l.n_in * l.n_out;
+        if (i > 0) {
+            const int ps = g_prof.begin(1, fl, st);
+            HIP_TRY(gemm_dgrad(dz, l.n_out_pad, c->params + l.w_off, l.ld, xin, l.ld, c->ws + w.dz[i - 1],
+                               l.ld, rows_pad, l.ld, l.n_out_pad, st));
+            g_prof.end(ps, st);
+        } else if (input_grad) {
+            // only the columns that carry a gradient onward are algorithmically needed:
+            // [Db, Db+Da) of d(wm_in) or [Db, Db+Z) of d(md_in)  
+            const int need = n == PVAE_NET_WM ? c->L.cfg.dim_action : c->L.cfg.latent;
+            const int ps = g_prof.begin(1, 2.0 * c->staged_rows_f * need * l.n_out, st);
+            HIP_TRY(gemm_dgrad(dz, l.n_out_pad, c->params + l.w_off, l.ld, nullptr, 0, c->ws + w.d_in, l.ld,
+                               rows_pad, l.ld, l.n_out_pad, st));
+            g_prof.end(ps, st);
+        }
+        const int pw = train ? g_prof.begin(2, fl, st) : -1;
+        if (train) {
+            if (fused) {
+                EpiGradAdam e{c->params + l.w_off, c->m + l.w_off, c->v + l.w_off, l.ld, as};
+                HIP_TRY(gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
+            } else {
+                EpiGradStore e{c->grads + l.w_off, l.ld};
+                HIP_TRY(gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
+            }
+        }
+        g_prof.end(pw, st);
+    }
+    return 0;
+}
+
+static int bias_grads(pvae_ctx* c, int net_mask, int rows_pad, const pvae_step_params* sp, bool fused,
+                      hipStream_t st) {
+    BiasJobs jobs;
+    memset(&jobs, 0, sizeof(jobs));
+    int max_ld = 0;
+    auto flush = [&]() -> int {
+        if (jobs.n == 0) return 0;
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(max_ld / 64, jobs.n), dim3(256), 0, st, jobs, rows_pad,
+                           fused ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+        jobs.n = 0;
+        max_ld = 0;
+        return 0;
+    };
+    for (int n = 0; n < PVAE_NUM_NETS; ++n) {
+        jobs.s[n] = adam_scalars(sp, n);
+    }
+    for (int n = 0; n < PVAE_NUM_NETS; ++n) {
+        if (!(net_mask & (1 << n))) continue;
+        for (const Layer& l : c->L.net[n].layers) {
+            BiasJob& j = jobs.job[jobs.n++];
+            j.dz = c->ws + c->W.net[n].dz[l.index];
+            j.ld = l.n_out_pad;
+            j.b = (fused ? c->params : c->grads) + l.b_off;
+            j.m = c->m + l.b_off;
+            j.v = c->v + l.b_off;
+            j.net = n;
+            if (l.n_out_pad > max_ld) max_ld = l.n_out_pad;
+            if (jobs.n == 16) { int rc = flush(); if (rc) return rc; }
+        }
+    }
+    return flush();
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int pvae_abi_version(void) { return PVAE_ABI_VERSION; }
+const char* pvae_last_error(void) { return g_err; }
+
+int pvae_num_layers(const pvae_config* cfg) {
+    if (!cfg) return fail(-1, "null cfg");
+    Layout L = make_layout(*cfg);
+    if (!L.ok) return fail(-1, "bad config: %s", L.why);
+    int n = 0;
+    for (auto& N : L.net) n += (int)N.layers.size();
+    return n;
+}
+
+int pvae_layer(const pvae_config* cfg, int i, pvae_layer_info* out) {
+    if (!cfg || !out) return fail(-1, "null argument");
+    Layout L = make_layout(*cfg);
+    if (!L.ok) return fail(-1, "bad config: %s", L.why);
+    for (auto& N : L.net) {
+        if (i < (int)N.layers.size()) {
+            const Layer& l = N.layers[i];
+            out->net = l.net; out->index = l.index; out->n_in = l.n_in; out->n_out = l.n_out;
+            out->ld = l.ld; out->n_out_pad = l.n_out_pad; out->w_offset = l.w_off; out->b_offset = l.b_off;
+            return 0;
+        }
+        i -= (int)N.layers.size();
+    }
+    return fail(-1, "layer index out of range");
+}
+
+int64_t pvae_arena_floats(const pvae_config* cfg) {
+    if (!cfg) return fail(-1, "null cfg");
+    Layout L = make_layout(*cfg);
+    if (!L.ok) return fail(-1, "bad config: %s", L.why);
+    return L.arena_floats;
+}
+
+int pvae_net_segment(const pvae_config* cfg, int net, int64_t* offset, int64_t* count) {
+    if (!cfg || !offset || !count) return fail(-1, "null argument");
+    if (net < 0 || net >= PVAE_NUM_NETS) return fail(-1, "bad net id %d", net);
+    Layout L = make_layout(*cfg);
+    if (!L.ok) return fail(-1, "bad config: %s", L.why);
+    *offset = L.net[net].off;
+    *count = L.net[net].count;
+    return 0;
+}
+
+size_t pvae_workspace_bytes(const pvae_config* cfg) {
+    if (!cfg) return 0;
+    Layout L = make_layout(*cfg);
+    if (!L.ok) return 0;
+    return (size_t)make_workspace(L).total_floats * sizeof(float);
+}
+
+int pvae_create(const pvae_config* cfg, pvae_ctx** out) {
+    if (!cfg || !out) return fail(-1, "null argument");
+    Layout L = make_layout(*cfg);
+    if (!L.ok) return fail(-1, "bad config: %s", L.why);
+    pvae_ctx* c = new (std::nothrow) pvae_ctx();
+    if (!c) return fail(-3, "out of host memory");
+    c->L = L;
+    c->W = make_workspace(L);
+    *out = c;
+    return 0;
+}
+
+void pvae_destroy(pvae_ctx* ctx) { delete ctx; }
+
+int pvae_bind_arenas(pvae_ctx* c, float* params, float* grads, float* exp_avg, float* exp_avg_sq) {
+    if (!c) return fail(-1, "null ctx");
+    if (!params) return fail(-1, "params arena is null");
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
+        return fail(-1, "arenas must be 16-byte aligned");
+    c->params = params; c->grads = grads; c->m = exp_avg; c->v = exp_avg_sq;
+    return 0;
+}
+
+int pvae_bind_workspace(pvae_ctx* c, void* workspace, size_t bytes) {
+    if (!c) return fail(-1, "null ctx");
+    if (!workspace || ((uintptr_t)workspace & 255)) return fail(-1, "workspace must be 256-byte aligned");
+    if (bytes < (size_t)c->W.total_floats * sizeof(float))
+        return fail(-1, "workspace too small: %zu < %zu", bytes, (size_t)c->W.total_floats * sizeof(float));
+    c->ws = (float*)workspace;
+    return 0;
+}
+
+int pvae_bind_dataset(pvae_ctx* c, const float* states, const float* actions, const int32_t* window_row,
+                      int64_t n_rows, int64_t n_windows) {
+    if (!c) return fail(-1, "null ctx");
+    if (!states || !actions || !window_row) return fail(-1, "null dataset pointer");
+    if (n_rows < 2 || n_windows < 1) return fail(-1, "empty dataset");
+    if (n_rows > 2147483647ll) return fail(-1, "more than 2^31-1 rows");
+    c->states = states; c->actions = actions; c->window_row = window_row;
+    c->n_rows = n_rows; c->n_windows = n_windows;
+    return 0;
+}
+
+static int stage(pvae_ctx* c, long long first_window, const float* x, const float* y, int rows, bool from_set,
+                 hipStream_t st) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
+    const int rows_pad = pad32(rows);
+    const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action;
+    float* w = c->ws;
+    hipLaunchKernelGGL(stage_batch_kernel, dim3(rows_pad), dim3(256), 0, st,
+                       from_set ? c->states : nullptr, from_set ? c->actions : nullptr,
+                       from_set ? c->window_row : nullptr, first_window, x, y, rows, Db, Da,
+                       w + c->W.net[PVAE_NET_TE].in, c->L.net[PVAE_NET_TE].layers[0].ld,
+                       w + c->W.net[PVAE_NET_MD].in, c->L.net[PVAE_NET_MD].layers[0].ld,
+                       w + c->W.net[PVAE_NET_WM].in, c->L.net[PVAE_NET_WM].layers[0].ld,
+                       w + c->W.s2, pad64(Db), w + c->W.act_t, pad64(Da));
+    HIP_TRY(hipGetLastError());
+    c->staged_rows = rows;
+    c->staged_rows_f = rows;
+    return 0;
+}
+
+int pvae_gather(pvae_ctx* c, int64_t first_window, int32_t rows, void* stream) {
+    if (!c) return fail(-1, "null ctx");
+    if (!c->states) return fail(-2, "dataset not bound");
+    if (first_window < 0 || first_window + rows > c->n_windows)
+        return fail(-1, "windows [%lld, %lld) outside [0, %lld)", (long long)first_window,
+                    (long long)(first_window + rows), (long long)c->n_windows);
+    return stage(c, first_window, nullptr, nullptr, rows, true, (hipStream_t)stream);
+}
+
+int pvae_set_batch(pvae_ctx* c, const float* x, const float* y, int32_t rows, void* stream) {
+    if (!c) return fail(-1, "null ctx");
+    if (!x) return fail(-1, "x is null");
+    return stage(c, 0, x, y, rows, false, (hipStream_t)stream);
+}
+
+int pvae_forward_backward(pvae_ctx* c, int phase, int32_t rows, const pvae_step_params* sp, const float* eps,
+                          float* loss_out, int flags, void* stream) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!sp) return fail(-1, "null step params");
+    if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
+    if (rows != c->staged_rows) return fail(-2, "rows %d != staged rows %d", rows, c->staged_rows);
+    const bool backward = !(flags & PVAE_FLAG_NO_BACKWARD);
+    const bool fused = (flags & PVAE_FLAG_FUSED_ADAM) != 0;
+    if (backward && fused && (!c->m || !c->v)) return fail(-2, "Adam moment arenas not bound");
+    if (backward && !fused && !c->grads) return fail(-2, "gradient arena not bound");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows_pad = pad32(rows);
+    const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
+    const float Bg = (float)(sp->global_rows > 0 ? sp->global_rows : rows);
+    float* w = c->ws;
+    float* part = w + c->W.loss_part;
+    const NetLayout& TE = c->L.net[PVAE_NET_TE];
+    const NetLayout& MD = c->L.net[PVAE_NET_MD];
+    const NetLayout& WM = c->L.net[PVAE_NET_WM];
+    const NetWork& wte = c->W.net[PVAE_NET_TE];
+    const NetWork& wmd = c->W.net[PVAE_NET_MD];
+    const NetWork& wwm = c->W.net[PVAE_NET_WM];
+    const int nparts = rows_pad < kLossParts ? rows_pad : kLossParts;
+    LossFinal lf;
+    memset(&lf, 0, sizeof(lf));
+    lf.scale[0] = 1.0f / (Bg * Da); lf.scale[1] = 1.0f / Bg;
+    lf.scale[2] = 1.0f / (Bg * Db); lf.scale[3] = 1.0f / (Bg * Db);
+    lf.coeff[0] = sp->a_rec_coeff; lf.coeff[1] = sp->kl_coeff;
+    lf.coeff[2] = sp->s_rec_coeff; lf.coeff[3] = sp->cycle_coeff;
+
+    if (phase == PVAE_PHASE_WORLD) {
+        // tpv:411-414: L = s_rec * MSE(s2, WM(s1, a_gt)); only the world model learns (tpv:326-329)
+        if ((rc = forward_net(c, PVAE_NET_WM, rows_pad, st))) return rc;
+        const float gs = sp->s_rec_coeff * 2.0f / (Bg * Db);
+        hipLaunchKernelGGL(mse_grad_kernel, dim3(nparts), dim3(256), 0, st, w + wwm.act.back(),
+                           WM.layers.back().n_out_pad, w + c->W.s2, pad64(Db), backward ? w + wwm.dz.back() : nullptr,
+                           WM.layers.back().n_out_pad, rows, rows_pad, Db, gs, (const float*)nullptr, 0, 0,
+                           part + 3 * kLossParts);
+        HIP_TRY(hipGetLastError());
+        lf.active[2] = 1; lf.nparts[2] = nparts;
+        if (backward) {
+            if ((rc = backward_net(c, PVAE_NET_WM, rows_pad, true, false, sp, fused, st))) return rc;
+            if ((rc = bias_grads(c, 1 << PVAE_NET_WM, rows_pad, sp, fused, st))) return rc;
+        }
+    } else if (phase == PVAE_PHASE_JOINT) {
+        if (sp->s_rec_coeff != 0.0f)
+            return fail(-4, "joint phase with world_model_s_rec_coeff != 0 is not supported "
+                            "(reference default is 0.0, tpv:284)");
+        // forward: TE -> sampler -> MD -> WM (rmt:742-771)
+        if ((rc = forward_net(c, PVAE_NET_TE, rows_pad, st))) return rc;
+        const int gridz = (rows_pad * Z + 255) / 256 < kLossParts ? (rows_pad * Z + 255) / 256 : kLossParts;
+        hipLaunchKernelGGL(reparam_kernel, dim3(gridz), dim3(256), 0, st, w + wte.act.back(),
+                           TE.layers.back().n_out_pad, eps, w + c->W.eps, w + wmd.in, MD.layers[0].ld, Db, Z, rows,
+                           rows_pad, 1, (unsigned long long)sp->rng_seed, (unsigned long long)sp->rng_offset,
+                           part + 2 * kLossParts);
+        HIP_TRY(hipGetLastError());
+        lf.active[1] = sp->kl_coeff > 0.0f && sp->a_rec_coeff > 0.0f;   // tpv:381-384 nesting
+        lf.nparts[1] = gridz;
+        if ((rc = forward_net(c, PVAE_NET_MD, rows_pad, st))) return rc;
+        hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, w + wmd.act.back(),
+                           MD.layers.back().n_out_pad, 0, w + wwm.in, WM.layers[0].ld, Db, rows_pad, Da);
+        HIP_TRY(hipGetLastError());
+        if ((rc = forward_net(c, PVAE_NET_WM, rows_pad, st))) return rc;
+        // cycle loss (tpv:417-419) and its gradient into the frozen world model
+        const float gc = sp->cycle_coeff * 2.0f / (Bg * Db);
+        hipLaunchKernelGGL(mse_grad_kernel, dim3(nparts), dim3(256), 0, st, w + wwm.act.back(),
+                           WM.layers.back().n_out_pad, w + c->W.s2, pad64(Db), backward ? w + wwm.dz.back() : nullptr,
+                           WM.layers.back().n_out_pad, rows, rows_pad, Db, gc, (const float*)nullptr, 0, 0,
+                           part + 4 * kLossParts);
+        HIP_TRY(hipGetLastError());
+        lf.active[3] = sp->cycle_coeff > 0.0f; lf.nparts[3] = nparts;
+        const bool cyc_grad = backward && sp->cycle_coeff > 0.0f;
+        if (cyc_grad) {
+            if ((rc = backward_net(c, PVAE_NET_WM, rows_pad, false, true, sp, fused, st))) return rc;
+        }
+        // action reconstruction (tpv:381-382) + gradient arriving through the world model
+        const float ga = sp->a_rec_coeff * 2.0f / (Bg * Da);
+        hipLaunchKernelGGL(mse_grad_kernel, dim3(nparts), dim3(256), 0, st, w + wmd.act.back(),
+                           MD.layers.back().n_out_pad, w + c->W.act_t, pad64(Da), backward ? w + wmd.dz.back() : nullptr,
+                           MD.layers.back().n_out_pad, rows, rows_pad, Da, ga,
+                           cyc_grad ? w + wwm.d_in : (const float*)nullptr, WM.layers[0].ld, Db,
+                           part + 1 * kLossParts);
+        HIP_TRY(hipGetLastError());
+        lf.active[0] = sp->a_rec_coeff > 0.0f; lf.nparts[0] = nparts;
+        if (backward) {
+            if ((rc = backward_net(c, PVAE_NET_MD, rows_pad, true, true, sp, fused, st))) return rc;
+            const float kls = lf.active[1] ? sp->kl_coeff / Bg : 0.0f;
+            const int tot = rows_pad * TE.layers.back().n_out_pad;
+            hipLaunchKernelGGL(reparam_bwd_kernel, dim3((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256), dim3(256), 0,
+                               st, w + wmd.d_in, MD.layers[0].ld, Db, w + wte.act.back(), TE.layers.back().n_out_pad,
+                               w + c->W.eps, w + wte.dz.back(), TE.layers.back().n_out_pad, rows, rows_pad, Z, kls);
+            HIP_TRY(hipGetLastError());
+            if ((rc = backward_net(c, PVAE_NET_TE, rows_pad, true, false, sp, fused, st))) return rc;
+            if ((rc = bias_grads(c, (1 << PVAE_NET_TE) | (1 << PVAE_NET_MD), rows_pad, sp, fused, st))) return rc;
+        }
+    } else {
+        return fail(-1, "unknown phase %d", phase);
+    }
+    if (loss_out) {
+        hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(64), 0, st, part, lf, loss_out);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+int pvae_adam(pvae_ctx* c, int net_mask, const pvae_step_params* sp, void* stream) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!sp) return fail(-1, "null step params");
+    if (!c->grads || !c->m || !c->v) return fail(-2, "grads / Adam moment arenas not bound");
+    for (int n = 0; n < PVAE_NUM_NETS; ++n) {
+        if (!(net_mask & (1 << n))) continue;
+        const NetLayout& N = c->L.net[n];
+        const long long n4 = N.count / 4;      // segments are multiples of 64 floats
+        int grid = (int)((n4 + 255) / 256);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, c->params + N.off,
+                           c->grads + N.off, c->m + N.off, c->v + N.off, n4, adam_scalars(sp, n));
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+int pvae_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t rows, const pvae_step_params* sp,
+                    const float* eps, float* loss_out, void* stream) {
+    int rc = pvae_gather(c, first_window, rows, stream);
+    if (rc) return rc;
+    return pvae_forward_backward(c, phase, rows, sp, eps, loss_out, PVAE_FLAG_FUSED_ADAM, stream);
+}
+
+int pvae_read_tensor(pvae_ctx* c, int what, float* dst, int32_t rows, void* stream) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!dst || rows < 1 || rows > c->W.Bp) return fail(-1, "bad dst/rows");
+    const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
+    const float* src; int ld, col0, nc;
+    const NetWork& wte = c->W.net[PVAE_NET_TE];
+    switch (what) {
+        case 0: src = c->ws + wte.act.back(); ld = c->L.net[PVAE_NET_TE].layers.back().n_out_pad; col0 = 0; nc = Z; break;
+        case 1: src = c->ws + wte.act.back(); ld = c->L.net[PVAE_NET_TE].layers.back().n_out_pad; col0 = Z; nc = Z; break;
+        case 2: src = c->ws + c->W.net[PVAE_NET_MD].in; ld = c->L.net[PVAE_NET_MD].layers[0].ld; col0 = Db; nc = Z; break;
+        case 3: src = c->ws + c->W.net[PVAE_NET_MD].act.back(); ld = c->L.net[PVAE_NET_MD].layers.back().n_out_pad; col0 = 0; nc = Da; break;
+        case 4: src = c->ws + c->W.net[PVAE_NET_WM].act.back(); ld = c->L.net[PVAE_NET_WM].layers.back().n_out_pad; col0 = 0; nc = Db; break;
+        case 5: src = c->ws + c->W.eps; ld = Z; col0 = 0; nc = Z; break;
+        default: return fail(-1, "unknown tensor id %d", what);
+    }
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, src, ld, col0, dst, nc, 0, rows, nc);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, int noise, uint64_t rng_seed,
+               uint64_t rng_offset, float* a_hat, float* s2_hat, float* z_out, void* stream) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!obs || !a_hat) return fail(-1, "obs / a_hat is null");
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = stage(c, 0, obs, nullptr, rows, false, st))) return rc;
+    const int rows_pad = pad32(rows);
+    const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
+    float* w = c->ws;
+    const NetLayout& TE = c->L.net[PVAE_NET_TE];
+    const NetLayout& MD = c->L.net[PVAE_NET_MD];
+    const NetLayout& WM = c->L.net[PVAE_NET_WM];
+    if ((rc = forward_net(c, PVAE_NET_TE, rows_pad, st))) return rc;
+    const int gridz = (rows_pad * Z + 255) / 256 < kLossParts ? (rows_pad * Z + 255) / 256 : kLossParts;
+    hipLaunchKernelGGL(reparam_kernel, dim3(gridz), dim3(256), 0, st, w + c->W.net[PVAE_NET_TE].act.back(),
+                       TE.layers.back().n_out_pad, eps, w + c->W.eps, w + c->W.net[PVAE_NET_MD].in, MD.layers[0].ld, Db,
+                       Z, rows, rows_pad, noise ? 1 : 0, (unsigned long long)rng_seed, (unsigned long long)rng_offset,
+                       (float*)nullptr);
+    HIP_TRY(hipGetLastError());
+    if ((rc = forward_net(c, PVAE_NET_MD, rows_pad, st))) return rc;
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, w + c->W.net[PVAE_NET_MD].act.back(),
+                       MD.layers.back().n_out_pad, 0, a_hat, Da, 0, rows, Da);
+    HIP_TRY(hipGetLastError());
+    if (z_out) {
+        hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, w + c->W.net[PVAE_NET_MD].in, MD.layers[0].ld,
+                           Db, z_out, Z, 0, rows, Z);
+        HIP_TRY(hipGetLastError());
+    }
+    if (s2_hat) {
+        hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, w + c->W.net[PVAE_NET_MD].act.back(),
+                           MD.layers.back().n_out_pad, 0, w + c->W.net[PVAE_NET_WM].in, WM.layers[0].ld, Db, rows_pad, Da);
+        HIP_TRY(hipGetLastError());
+        if ((rc = forward_net(c, PVAE_NET_WM, rows_pad, st))) return rc;
+        hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, w + c->W.net[PVAE_NET_WM].act.back(),
+                           WM.layers.back().n_out_pad, 0, s2_hat, Db, 0, rows, Db);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+int pvae_net_forward(pvae_ctx* c, int net, const float* in, int32_t rows, float* out, void* stream) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (net < 0 || net >= PVAE_NUM_NETS) return fail(-1, "bad net id %d", net);
+    if (!in || !out) return fail(-1, "in / out is null");
+    if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    const NetLayout& N = c->L.net[net];
+    const int rows_pad = pad32(rows), ld = N.layers[0].ld;
+    int grid = (rows_pad * ld + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(pad_copy_kernel, dim3(grid), dim3(256), 0, st, in, N.n_in, rows, c->ws + c->W.net[net].in, ld,
+                       rows_pad);
+    HIP_TRY(hipGetLastError());
+    c->staged_rows = 0;     // the training panels are no longer a coherent batch
+    c->staged_rows_f = rows;
+    if ((rc = forward_net(c, net, rows_pad, st))) return rc;
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, c->ws + c->W.net[net].act.back(),
+                       N.layers.back().n_out_pad, 0, out, N.n_out, 0, rows, N.n_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int pvae_reparam(pvae_ctx* c, const float* mu_logvar, int32_t rows, const float* eps, int noise, uint64_t rng_seed,
+                 uint64_t rng_offset, float* z_out, void* stream) {
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!mu_logvar || !z_out) return fail(-1, "mu_logvar / z_out is null");
+    if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    const int Db = c->L.cfg.dim_body, Z = c->L.cfg.latent;
+    const int ld_md = c->L.net[PVAE_NET_MD].layers[0].ld;
+    const int gridz = (rows * Z + 255) / 256 < kLossParts ? (rows * Z + 255) / 256 : kLossParts;
+    c->staged_rows = 0;
+    hipLaunchKernelGGL(reparam_kernel, dim3(gridz), dim3(256), 0, st, mu_logvar, 2 * Z, eps, c->ws + c->W.eps,
+                       c->ws + c->W.net[PVAE_NET_MD].in, ld_md, Db, Z, rows, rows, noise ? 1 : 0,
+                       (unsigned long long)rng_seed, (unsigned long long)rng_offset, (float*)nullptr);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, c->ws + c->W.net[PVAE_NET_MD].in, ld_md, Db, z_out,
+                       Z, 0, rows, Z);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int pvae_profile_enable(int on) {
+    g_prof.on = on != 0;
+    if (on) g_prof.n = 0;
+    return 0;
+}
+
+int pvae_profile_read(int category, double* total_ms, int64_t* launches, double* total_flops) {
+    if (!total_ms || !launches || !total_flops) return fail(-1, "null output");
+    double ms = 0, fl = 0;
+    int64_t cnt = 0;
+    for (int i = 0; i < g_prof.n; ++i) {
+        if (g_prof.cat[i] != category) continue;
+        HIP_TRY(hipEventSynchronize(g_prof.ev[i][1]));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, g_prof.ev[i][0], g_prof.ev[i][1]));
+        ms += t; fl += g_prof.flops[i]; ++cnt;
+    }
+    *total_ms = ms; *launches = cnt; *total_flops = fl;
+    return 0;
+}
+
+int pvae_gemm_probe(int kind, const float* a, int lda, const float* b, int ldb, float* cc, int ldc,
+                    const float* bias_or_mask, int ld_mask, int m, int n, int k, int relu, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!a || !b || !cc) return fail(-1, "null operand");
+    if (kind == 0) {
+        if (m % 32 || n % 32 || k % 64) return fail(-1, "forward probe needs M%%32==0, N%%32==0, K%%64==0");
+        HIP_TRY(gemm_forward(a, lda, b, ldb, bias_or_mask, cc, ldc, m, n, k, relu, st));
+    } else if (kind == 1) {
+        if (m % 32 || k % 32 || n % 64) return fail(-1, "dgrad probe needs M%%32==0, K%%32==0, N%%64==0");
+        HIP_TRY(gemm_dgrad(a, lda, b, ldb, bias_or_mask, ld_mask, cc, ldc, m, k, n, st));
+    } else if (kind == 2) {
+        if (m % 32 || n % 64 || k % 64) return fail(-1, "wgrad probe needs M%%32==0, N%%64==0, K%%64==0");
+        EpiGradStore e{cc, ldc};
+        HIP_TRY(gemm_wgrad(a, lda, b, ldb, n, k, m, e, st));
+    } else {
+        return fail(-1, "unknown probe kind %d", kind);
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+// pvae_layout.h -- host-side layout arithmetic shared by the API and the tests:
+// where every Linear of the three trainable stacks lives in the flat fp32 arena, and how
+// the workspace is carved.  Pure C++ (no HIP), so the layout queries work without a GPU.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/pvae.h"
+
+namespace pvae {
+
+inline int pad64(int x) { return (x + 63) / 64 * 64; }
+inline int pad32(int x) { return (x + 31) / 32 * 32; }
+
+struct Layer {
+    int net, index, n_in, n_out, ld, n_out_pad;
+    int64_t w_off, b_off;
+    bool last;
+};
+
+struct NetLayout {
+    std::vector<Layer> layers;
+    int64_t off = 0, count = 0;   // segment of the arena
+    int n_in = 0, n_out = 0;
+};
+
+struct Layout {
+    pvae_config cfg{};
+    NetLayout net[PVAE_NUM_NETS];
+    int64_t arena_floats = 0;
+    bool ok = false;
+    const char* why = "";
+};
+
+inline Layout make_layout(const pvae_config& c) {
+    Layout L;
+    L.cfg = c;
+    if (c.dim_body <= 0 || c.dim_action <= 0 || c.latent <= 0) { L.why = "dims must be positive"; return L; }
+    if (c.te_width <= 0 || c.md_width <= 0 || c.wm_width <= 0 || c.te_depth <= 0 || c.md_depth <= 0 ||
+        c.wm_depth <= 0) { L.why = "width/depth must be positive"; return L; }
+    if (c.te_depth > 15 || c.md_depth > 15 || c.wm_depth > 15) { L.why = "depth > 15 unsupported"; return L; }
+    if (c.max_batch <= 0 || c.max_batch > 65536) { L.why = "max_batch out of range"; return L; }
+    const int Db = c.dim_body, Da = c.dim_action, Z = c.latent;
+    const int ins[3] = {2 * Db, Db + Z, Db + Da};        // rmt:638-644, 646-668, 682-689
+    const int outs[3] = {2 * Z, Da, Db};
+    const int widths[3] = {c.te_width, c.md_width, c.wm_width};
+    const int depths[3] = {c.te_depth, c.md_depth, c.wm_depth};
+    int64_t off = 0;
+    for (int n = 0; n < PVAE_NUM_NETS; ++n) {
+        NetLayout& N = L.net[n];
+        N.off = off;
+        N.n_in = ins[n];
+        N.n_out = outs[n];
+        int prev = ins[n];
+        for (int i = 0; i <= depths[n]; ++i) {
+            Layer l;
+            l.net = n; l.index = i; l.n_in = prev;
+            l.last = (i == depths[n]);
+            l.n_out = l.last ? outs[n] : widths[n];
+            l.ld = pad64(l.n_in);
+            l.n_out_pad = pad64(l.n_out);
+            l.w_off = off; off += (int64_t)l.n_out_pad * l.ld;
+            l.b_off = off; off += l.n_out_pad;
+            N.layers.push_back(l);
+            prev = l.n_out;
+        }
+        N.count = off - N.off;
+    }
+    L.arena_floats = off;
+    L.ok = true;
+    return L;
+}
+
+// Workspace carving (all offsets in floats, every buffer 64-float aligned).
+struct NetWork {
+    std::vector<int64_t> act;   // act[i]: output of layer i  [Bp][n_out_pad_i]
+    std::vector<int64_t> dz;    // dz[i]: grad wrt pre-activation of layer i, same shape
+    int64_t in = 0, d_in = 0;   // input panel [Bp][ld0] and its gradient
+};
+
+struct Workspace {
+    int Bp = 0;                 // rows allocated (max_batch padded to 32)
+    NetWork net[PVAE_NUM_NETS];
+    int64_t s2 = 0, act_t = 0;  // targets: next state [Bp][pad64(Db)], action [Bp][pad64(Da)]
+    int64_t eps = 0;            // eps actually used [Bp][Z]
+    int64_t loss_part = 0;      // [5][kLossParts] partial sums
+    int64_t total_floats = 0;
+};
+
+constexpr int kLossParts = 64;
+
+inline Workspace make_workspace(const Layout& L) {
+    Workspace W;
+    W.Bp = pad32(L.cfg.max_batch);
+    int64_t off = 0;
+    auto take = [&](int64_t n) { int64_t o = off; off += (n + 63) / 64 * 64; return o; };
+    for (int n = 0; n < PVAE_NUM_NETS; ++n) {
+        const NetLayout& N = L.net[n];
+        W.net[n].in = take((int64_t)W.Bp * N.layers[0].ld);
+        W.net[n].d_in = take((int64_t)W.Bp * N.layers[0].ld);
+        for (const Layer& l : N.layers) {
+            W.net[n].act.push_back(take((int64_t)W.Bp * l.n_out_pad));
+            W.net[n].dz.push_back(take((int64_t)W.Bp * l.n_out_pad));
+        }
+    }
+    W.s2 = take((int64_t)W.Bp * pad64(L.cfg.dim_body));
+    W.act_t = take((int64_t)W.Bp * pad64(L.cfg.dim_action));
+    W.eps = take((int64_t)W.Bp * L.cfg.latent);
+    W.loss_part = take(5 * kLossParts);
+    W.total_floats = off;
+    return W;
+}
+
+}  // namespace pvae

@@ -1,0 +1,252 @@
+"""HipEngine -- owns the device buffers the C-ABI library works on and wraps its calls.
+
+PyTorch is used for what it is good at here: device memory, streams, `torch.save`.  All
+arithmetic of the hot path happens in libpvae_gfx950.so (physicsvae_amd/csrc).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (FLAG_FUSED_ADAM, FLAG_NO_BACKWARD, NET_MD, NET_NAMES, NET_TE, NET_WM,
+                   PHASE_JOINT, PHASE_WORLD)
+
+TENSOR_IDS = {"mu": 0, "logvar": 1, "z": 2, "a_hat": 3, "s2_hat": 4, "eps": 5}
+
+
+class Arch:
+    """Dims of the three trainable stacks (tpv:247-286 keys, gen_layers tpv:180-192)."""
+
+    def __init__(self, dim_body, dim_action, latent, te, md, wm):
+        self.Db, self.Da, self.Z = int(dim_body), int(dim_action), int(latent)
+        self.te, self.md, self.wm = tuple(te), tuple(md), tuple(wm)
+
+    def config(self, max_batch):
+        return _lib.Config(self.Db, self.Da, self.Z, self.te[0], self.te[1], self.md[0],
+                           self.md[1], self.wm[0], self.wm[1], int(max_batch))
+
+    def key(self):
+        return (self.Db, self.Da, self.Z, self.te, self.md, self.wm)
+
+
+def make_step_params(lr, adam_t=(1, 1, 1), a_rec=1.0, kl=1.0, s_rec=0.0, cyc=1e-3,
+                     global_rows=0, seed=0, offset=0, beta1=0.9, beta2=0.999, eps=1e-8):
+    sp = _lib.StepParams()
+    sp.a_rec_coeff, sp.kl_coeff, sp.s_rec_coeff, sp.cycle_coeff = a_rec, kl, s_rec, cyc
+    sp.lr, sp.beta1, sp.beta2, sp.adam_eps = lr, beta1, beta2, eps
+    for i in range(3):
+        sp.adam_t[i] = int(adam_t[i])
+    sp.global_rows = int(global_rows)
+    sp.rng_seed, sp.rng_offset = int(seed), int(offset)
+    return sp
+
+
+class HipEngine:
+    def __init__(self, arch, max_batch, device="cuda"):
+        self.lib = _lib.load()
+        self.arch = arch
+        self.max_batch = int(max_batch)
+        self.device = torch.device(device)
+        self.cfg = arch.config(max_batch)
+        n = self.lib.pvae_arena_floats(C.byref(self.cfg))
+        _lib.check(int(n), "pvae_arena_floats")
+        self.arena_floats = int(n)
+        self.layers = []
+        info = _lib.LayerInfo()
+        for i in range(_lib.check(self.lib.pvae_num_layers(C.byref(self.cfg)))):
+            _lib.check(self.lib.pvae_layer(C.byref(self.cfg), i, C.byref(info)))
+            self.layers.append({f: getattr(info, f) for f, _ in _lib.LayerInfo._fields_})
+        self.segments = {}
+        for net in (NET_TE, NET_MD, NET_WM):
+            off, cnt = C.c_int64(), C.c_int64()
+            _lib.check(self.lib.pvae_net_segment(C.byref(self.cfg), net, C.byref(off), C.byref(cnt)))
+            self.segments[net] = (off.value, cnt.value)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(self.arena_floats, **f32)
+        self.grads = torch.zeros(self.arena_floats, **f32)
+        self.exp_avg = torch.zeros(self.arena_floats, **f32)
+        self.exp_avg_sq = torch.zeros(self.arena_floats, **f32)
+        self.ctx = None
+        self.workspace = None
+        self.dataset = None
+        self._loss_scratch = None
+        if self.device.type == "cuda":
+            self._create_ctx()
+
+    # -- lifetime -------------------------------------------------------------------
+    def _create_ctx(self):
+        ctx = C.c_void_p()
+        _lib.check(self.lib.pvae_create(C.byref(self.cfg), C.byref(ctx)), "pvae_create")
+        self.ctx = ctx
+        nbytes = self.lib.pvae_workspace_bytes(C.byref(self.cfg))
+        self.workspace = torch.zeros(nbytes // 4 + 64, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.pvae_bind_arenas(ctx, self.params.data_ptr(), self.grads.data_ptr(),
+                                             self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()))
+        _lib.check(self.lib.pvae_bind_workspace(ctx, self.workspace.data_ptr(), nbytes))
+        self._loss_scratch = torch.zeros(5, dtype=torch.float32, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.pvae_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    def _need_gpu(self):
+        if self.ctx is None:
+            raise RuntimeError("HipEngine was created on %s: the HIP hot path needs a GPU "
+                               "(there is no CPU fallback)" % self.device)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    # -- parameter views (checkpoint layout, rmt:234-283) -------------------------------
+    def _view(self, arena, info, kind):
+        if kind == "weight":
+            blk = arena[info["w_offset"]: info["w_offset"] + info["n_out_pad"] * info["ld"]]
+            return blk.view(info["n_out_pad"], info["ld"])[: info["n_out"], : info["n_in"]]
+        return arena[info["b_offset"]: info["b_offset"] + info["n_out"]]
+
+    def named_views(self, arena=None):
+        """{'<net>._model.<i>._model.0.weight|bias': strided view into the arena}."""
+        arena = self.params if arena is None else arena
+        out = {}
+        for info in self.layers:
+            base = "%s._model.%d._model.0." % (NET_NAMES[info["net"]], info["index"])
+            out[base + "weight"] = self._view(arena, info, "weight")
+            out[base + "bias"] = self._view(arena, info, "bias")
+        return out
+
+    def segment(self, arena, nets):
+        """Contiguous slice of `arena` covering the given nets (TE+MD are adjacent)."""
+        offs = [self.segments[n] for n in sorted(nets)]
+        lo = offs[0][0]
+        hi = offs[-1][0] + offs[-1][1]
+        assert sum(c for _, c in offs) == hi - lo, "nets are not adjacent in the arena"
+        return arena[lo:hi]
+
+    # -- data ---------------------------------------------------------------------------
+    def bind_dataset(self, states, actions, window_row):
+        self._need_gpu()
+        states = states.to(self.device, torch.float32).contiguous()
+        actions = actions.to(self.device, torch.float32).contiguous()
+        window_row = window_row.to(self.device, torch.int32).contiguous()
+        assert states.shape[1] == self.arch.Db and actions.shape[1] == self.arch.Da
+        assert int(window_row.max()) + 1 < states.shape[0]
+        self.dataset = (states, actions, window_row)
+        _lib.check(self.lib.pvae_bind_dataset(self.ctx, states.data_ptr(), actions.data_ptr(),
+                                              window_row.data_ptr(), states.shape[0],
+                                              window_row.shape[0]), "pvae_bind_dataset")
+
+    def gather(self, first_window, rows):
+        self._need_gpu()
+        _lib.check(self.lib.pvae_gather(self.ctx, int(first_window), int(rows), self._stream()),
+                   "pvae_gather")
+
+    def set_batch(self, x, y):
+        """x [B, 2Db] (or [B,1,2Db]), y [B, Da] (or [B,1,Da]) -- tpv:365-376."""
+        self._need_gpu()
+        x = x.reshape(x.shape[0], -1).to(self.device, torch.float32).contiguous()
+        yp = None
+        if y is not None:
+            y = y.reshape(y.shape[0], -1).to(self.device, torch.float32).contiguous()
+            yp = y.data_ptr()
+        self._keep = (x, y)
+        _lib.check(self.lib.pvae_set_batch(self.ctx, x.data_ptr(), yp, x.shape[0], self._stream()),
+                   "pvae_set_batch")
+        return x.shape[0]
+
+    # -- compute ------------------------------------------------------------------------
+    def forward_backward(self, phase, rows, sp, eps=None, fused_adam=False, backward=True,
+                         loss_out=None):
+        self._need_gpu()
+        flags = (FLAG_FUSED_ADAM if fused_adam else 0) | (0 if backward else FLAG_NO_BACKWARD)
+        if eps is not None:
+            eps = eps.to(self.device, torch.float32).contiguous()
+            assert eps.shape == (rows, self.arch.Z)
+            self._keep_eps = eps
+        out = self._loss_scratch if loss_out is None else loss_out
+        _lib.check(self.lib.pvae_forward_backward(
+            self.ctx, phase, int(rows), C.byref(sp), eps.data_ptr() if eps is not None else None,
+            out.data_ptr(), flags, self._stream()), "pvae_forward_backward")
+        return out
+
+    def adam(self, nets, sp):
+        self._need_gpu()
+        mask = 0
+        for n in nets:
+            mask |= 1 << n
+        _lib.check(self.lib.pvae_adam(self.ctx, mask, C.byref(sp), self._stream()), "pvae_adam")
+
+    def train_step(self, phase, first_window, rows, sp, eps=None, loss_out=None):
+        self._need_gpu()
+        if eps is not None:
+            eps = eps.to(self.device, torch.float32).contiguous()
+            self._keep_eps = eps
+        out = self._loss_scratch if loss_out is None else loss_out
+        _lib.check(self.lib.pvae_train_step(
+            self.ctx, phase, int(first_window), int(rows), C.byref(sp),
+            eps.data_ptr() if eps is not None else None, out.data_ptr(), self._stream()),
+            "pvae_train_step")
+        return out
+
+    def read(self, name, rows):
+        self._need_gpu()
+        width = {"mu": self.arch.Z, "logvar": self.arch.Z, "z": self.arch.Z, "eps": self.arch.Z,
+                 "a_hat": self.arch.Da, "s2_hat": self.arch.Db}[name]
+        dst = torch.empty(rows, width, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.pvae_read_tensor(self.ctx, TENSOR_IDS[name], dst.data_ptr(), rows,
+                                             self._stream()), "pvae_read_tensor")
+        return dst
+
+    def infer(self, obs, eps=None, noise=True, seed=0, offset=0, want_s2=True):
+        """rmt:742-771 forward at rollout batch sizes: returns (a_hat, s2_hat|None, z)."""
+        self._need_gpu()
+        obs = obs.reshape(obs.shape[0], -1).to(self.device, torch.float32).contiguous()
+        rows = obs.shape[0]
+        a_hat = torch.empty(rows, self.arch.Da, dtype=torch.float32, device=self.device)
+        s2 = torch.empty(rows, self.arch.Db, dtype=torch.float32, device=self.device) if want_s2 else None
+        z = torch.empty(rows, self.arch.Z, dtype=torch.float32, device=self.device)
+        if eps is not None:
+            eps = eps.to(self.device, torch.float32).contiguous()
+        _lib.check(self.lib.pvae_infer(
+            self.ctx, obs.data_ptr(), rows, eps.data_ptr() if eps is not None else None,
+            1 if noise else 0, int(seed), int(offset), a_hat.data_ptr(),
+            s2.data_ptr() if s2 is not None else None, z.data_ptr(), self._stream()), "pvae_infer")
+        return a_hat, s2, z
+
+
+    def net_forward(self, net, x):
+        self._need_gpu()
+        x = x.reshape(x.shape[0], -1).to(self.device, torch.float32).contiguous()
+        n_out = [l for l in self.layers if l["net"] == net][-1]["n_out"]
+        out = torch.empty(x.shape[0], n_out, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.pvae_net_forward(self.ctx, net, x.data_ptr(), x.shape[0], out.data_ptr(),
+                                             self._stream()), "pvae_net_forward")
+        return out
+
+    def reparam(self, mu_logvar, eps=None, noise=True, seed=0, offset=0):
+        self._need_gpu()
+        ml = mu_logvar.to(self.device, torch.float32).contiguous()
+        z = torch.empty(ml.shape[0], self.arch.Z, dtype=torch.float32, device=self.device)
+        if eps is not None:
+            eps = eps.to(self.device, torch.float32).contiguous()
+        _lib.check(self.lib.pvae_reparam(self.ctx, ml.data_ptr(), ml.shape[0],
+                                         eps.data_ptr() if eps is not None else None,
+                                         1 if noise else 0, int(seed), int(offset), z.data_ptr(),
+                                         self._stream()), "pvae_reparam")
+        return z
+
+
+def gemm_probe(kind, a, b, c, bias_or_mask=None, relu=False, m=0, n=0, k=0):
+    """Kernel-level entry (tests / roofline probes).  Tensors are dense fp32 on the GPU."""
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.pvae_gemm_probe(
+        kind, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0),
+        bias_or_mask.data_ptr() if bias_or_mask is not None else None,
+        bias_or_mask.stride(0) if (bias_or_mask is not None and bias_or_mask.dim() == 2) else 0,
+        m, n, k, 1 if relu else 0, st), "pvae_gemm_probe")
+    return c

@@ -1,0 +1,399 @@
+"""PhysicsVAE module surface (reference: rllib_model_torch.py `PhysicsVAE`, rmt:461-950) on
+top of the HIP engine.
+
+What is kept from the reference so that checkpoints and callers drop in unchanged:
+  * constructor signature (obs_space, action_space, num_outputs, model_config, name)
+  * sub-module names -> state_dict keys `<net>._model.<i>._model.0.{weight,bias}` with
+    shapes [n_out, n_in] / [n_out] (rmt:234-283 + ray SlimFC)
+  * forward(input_dict, state, seq_lens) -> (logits[B, 2*Da], state), value_function(),
+    forward_encoder/decoder/world/value_branch, task_encoder_variable(),
+    set_exploration_std, save_/load_weights*, set_learnable_*
+
+What is different by design: the task-encoder, motor-decoder and world-model parameters
+are strided views into ONE flat device arena owned by `HipEngine` (include/pvae.h), the
+layer arithmetic runs in hand-written gfx950 kernels, and no ray/gym import is needed.
+The value branch (rmt:693-699) never enters the training loss (tpv:356-435) and is not
+part of the hot path: it is kept as ordinary torch parameters so the 26-tensor checkpoint
+layout is complete, and evaluated with torch ops when a caller asks for value_function().
+"""
+import copy
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ._lib import NET_MD, NET_NAMES, NET_TE, NET_WM
+from .engine import Arch, HipEngine
+
+
+def fc_spec(width, depth, out_size="output", act_hidden="relu", act_out="linear"):
+    """Layer-spec list in the reference's dict format (what gen_layers emits, tpv:180-192)."""
+    assert depth > 0 and width > 0
+    hidden = {"type": "fc", "hidden_size": width, "activation": act_hidden,
+              "init_weight": {"name": "normc", "std": 1.0}}
+    last = {"type": "fc", "hidden_size": out_size, "activation": act_out,
+            "init_weight": {"name": "normc", "std": 0.01}}
+    return [dict(hidden) for _ in range(depth)] + [last]
+
+
+DEFAULT_FC_256X2 = fc_spec(256, 2)
+DEFAULT_FC_512X3 = fc_spec(512, 3)
+DEFAULT_FC_1024X2 = fc_spec(1024, 2)
+
+
+def normc_(tensor, std=1.0):
+    """ray 1.11.0 `normc_initializer` semantics: N(0,1) then every output
+    row rescaled to L2 norm `std`.  Works in place on (strided) views."""
+    with torch.no_grad():
+        w = torch.randn(tensor.shape, dtype=torch.float32)
+        w *= std / torch.sqrt(w.pow(2).sum(1, keepdim=True))
+        tensor.copy_(w)
+    return tensor
+
+
+def _uniform_relu_stack(layers, what):
+    """The HIP path covers what train_physics_vae.py can generate: fc layers of one width with
+    ReLU, then a linear fc output layer.  Anything else is refused loudly."""
+    if not layers or any(l.get("type") != "fc" for l in layers):
+        raise NotImplementedError("%s: only 'fc' layers are supported on the HIP path" % what)
+    *hidden, last = layers
+    if not hidden:
+        raise NotImplementedError("%s: at least one hidden layer is required" % what)
+    widths = {l["hidden_size"] for l in hidden}
+    if len(widths) != 1 or not isinstance(next(iter(widths)), int):
+        raise NotImplementedError("%s: hidden layers must share one integer width, got %s" % (what, widths))
+    if any(l.get("activation") != "relu" for l in hidden) or last.get("activation") not in ("linear", None):
+        raise NotImplementedError("%s: hidden activation must be relu and the output linear" % what)
+    if last["hidden_size"] != "output":
+        raise NotImplementedError("%s: last layer must have hidden_size 'output'" % what)
+    return next(iter(widths)), len(hidden)
+
+
+class SlimFC(nn.Module):
+    """Linear (+ReLU) held as `self._model = nn.Sequential(...)` -- the ray SlimFC shape that
+    gives the `._model.0.weight` key suffix."""
+
+    def __init__(self, in_size, out_size, relu, init_std, weight=None, bias=None):
+        super().__init__()
+        lin = nn.Linear(in_size, out_size)
+        if weight is not None:                 # alias the engine arena instead of own storage
+            lin.weight = nn.Parameter(weight)
+            lin.bias = nn.Parameter(bias)
+        normc_(lin.weight.data, init_std)
+        with torch.no_grad():
+            lin.bias.zero_()
+        self._model = nn.Sequential(*([lin, nn.ReLU()] if relu else [lin]))
+
+    def forward(self, x):
+        return self._model(x)
+
+
+class AppendLogStd(nn.Module):
+    """rmt:160-206 with type "constant": log_std is a plain tensor (NOT a parameter or buffer,
+    so it is absent from state_dict) appended to the decoder output."""
+
+    def __init__(self, init_val, dim):
+        super().__init__()
+        self.type = "constant"
+        self.log_std = torch.full((dim,), float(init_val), dtype=torch.float32)
+
+    def set_val(self, val):
+        assert np.isscalar(val), "Only scalar is currently supported"
+        self.log_std[:] = float(val)
+
+    def forward(self, x):
+        ls = self.log_std.to(x.device).reshape([1] * (x.dim() - 1) + [-1])
+        return torch.cat([x, ls.expand(*x.shape[:-1], -1)], dim=-1)
+
+
+class FC(nn.Module):
+    """rmt:234-283: `self._model = nn.Sequential(SlimFC..., [AppendLogStd])`."""
+
+    def __init__(self, dims, views=None, append_log_std=False, sample_std=1.0):
+        super().__init__()
+        mods = []
+        for i, (n_in, n_out) in enumerate(dims):
+            last = i == len(dims) - 1
+            w, b = (views[i] if views is not None else (None, None))
+            mods.append(SlimFC(n_in, n_out, relu=not last, init_std=0.01 if last else 1.0,
+                               weight=w, bias=b))
+        if append_log_std:
+            mods.append(AppendLogStd(math.log(sample_std), dims[-1][1]))
+        self._model = nn.Sequential(*mods)
+
+    def forward(self, x):
+        return self._model(x)
+
+    def save_weights(self, file):
+        torch.save(_portable(self.state_dict()), file)
+
+    def load_weights(self, file):
+        self.load_state_dict(torch.load(file, map_location="cpu"))
+        self.eval()
+
+
+def _portable(sd):
+    """Contiguous CPU copies: checkpoints must not carry the arena's strides or device
+    (the reference saves whatever device the model is on, rmt:870-871)."""
+    return OrderedDict((k, v.detach().to("cpu").contiguous().clone()) for k, v in sd.items())
+
+
+class PhysicsVAE(nn.Module):
+    DEFAULT_CONFIG = {
+        "project_dir": None,
+        "log_std_type": "constant",
+        "sample_std": 0.1,
+        "load_weights": None,
+        "task_encoder_inputs": ["body", "task"],
+        "task_encoder_layers": DEFAULT_FC_256X2,
+        "task_encoder_load_weights": None,
+        "task_encoder_learnable": True,
+        "task_encoder_output_dim": 32,
+        "latent_prior_type": "normal_zero_mean_one_std",
+        "latent_prior_layers": None,
+        "motor_decoder_inputs": ["body", "task"],
+        "motor_decoder_layers": DEFAULT_FC_512X3,
+        "motor_decoder_load_weights": None,
+        "motor_decoder_learnable": True,
+        "motor_decoder_helper_enable": False,
+        "value_fn_layers": DEFAULT_FC_256X2,
+        "world_model_layers": DEFAULT_FC_1024X2,
+        "world_model_load_weights": None,
+        "world_model_learnable": True,
+        "observation_space": None,
+        "observation_space_body": None,
+        "observation_space_task": None,
+        "action_space": None,
+        # ours: where the arena lives and how many rows one call may carry
+        "device": None,
+        "max_batch": 256,
+    }
+
+    def __init__(self, obs_space, action_space, num_outputs, model_config, name, **kwargs):
+        super().__init__()
+        self.obs_space, self.action_space = obs_space, action_space
+        self.model_config, self.name = model_config, name
+        assert num_outputs % 2 == 0, ("num_outputs must be divisible by two", num_outputs)
+        self.num_outputs = num_outputs
+        cfg = copy.deepcopy(PhysicsVAE.DEFAULT_CONFIG)
+        cfg.update(model_config.get("custom_model_config") or {})
+        if cfg["log_std_type"] != "constant":
+            raise NotImplementedError("only log_std_type 'constant' (the trainer's setting, rmt:466)")
+        if cfg["latent_prior_type"] != "normal_zero_mean_one_std":
+            # the other two priors crash in the reference itself
+            raise NotImplementedError("latent_prior_type %r" % (cfg["latent_prior_type"],))
+        if cfg["task_encoder_inputs"] != ["body", "task"] or cfg["motor_decoder_inputs"] != ["body", "task"]:
+            raise NotImplementedError("task-encoder / motor-decoder inputs must be ['body','task']")
+        if cfg.get("motor_decoder_helper_enable"):
+            raise NotImplementedError("motor_decoder_helper is not part of the training path")
+
+        self.dim_state_body = int(np.prod(cfg["observation_space_body"].shape))
+        self.dim_state_task = int(np.prod(cfg["observation_space_task"].shape))
+        self.dim_state = int(np.prod(obs_space.shape))
+        self.dim_action = int(np.prod(action_space.shape))
+        assert self.dim_state == self.dim_state_body + self.dim_state_task
+        assert self.dim_state_task == self.dim_state_body, "PhysicsVAE training uses s_task = s_body(t+1)"
+        assert num_outputs // 2 == self.dim_action
+        Z = int(cfg["task_encoder_output_dim"])
+        self._task_encoder_output_dim = Z
+        self._latent_prior_type = cfg["latent_prior_type"]
+        self._latent_prior = None
+        self._motor_decoder_helper = None
+
+        te = _uniform_relu_stack(cfg["task_encoder_layers"], "task_encoder_layers")
+        md = _uniform_relu_stack(cfg["motor_decoder_layers"], "motor_decoder_layers")
+        wm = _uniform_relu_stack(cfg["world_model_layers"], "world_model_layers")
+        vb = _uniform_relu_stack(cfg["value_fn_layers"], "value_fn_layers")
+        self.arch = Arch(self.dim_state_body, self.dim_action, Z, te, md, wm)
+        device = cfg["device"] or ("cuda" if torch.cuda.is_available() else "cpu")
+        self.engine = HipEngine(self.arch, int(cfg["max_batch"]), device=device)
+
+        views = self.engine.named_views()
+        per_net = {n: [] for n in (NET_TE, NET_MD, NET_WM)}
+        for info in self.engine.layers:
+            base = "%s._model.%d._model.0." % (NET_NAMES[info["net"]], info["index"])
+            per_net[info["net"]].append(((info["n_in"], info["n_out"]),
+                                         (views[base + "weight"], views[base + "bias"])))
+
+        def build(net, **kw):
+            dims = [d for d, _ in per_net[net]]
+            vws = [v for _, v in per_net[net]]
+            return FC(dims, views=vws, **kw)
+
+        # registration order fixes the state_dict order: TE, MD, WM, VB (rmt:638-699)
+        self._task_encoder = build(NET_TE)
+        self._motor_decoder = build(NET_MD, append_log_std=True, sample_std=cfg["sample_std"])
+        self._world_model = build(NET_WM)
+        vb_dims, prev = [], self.dim_state
+        for _ in range(vb[1]):
+            vb_dims.append((prev, vb[0]))
+            prev = vb[0]
+        vb_dims.append((prev, 1))
+        self._value_branch = FC(vb_dims).to(self.engine.device)
+
+        self._cur_value = None
+        self._cur_task_encoder_variable = None
+        self._cur_body_encoder_variable = None
+        self._cur_task_encoder_mu = None
+        self._cur_task_encoder_logvar = None
+        self._cur_future_state = None
+        self.latent_prior_noise = True
+        self._rng_seed, self._rng_calls = 0, 0
+
+        def rooted(path):
+            import os
+            return os.path.join(cfg["project_dir"], path) if cfg.get("project_dir") else path
+
+        if cfg.get("load_weights"):
+            self.load_weights(rooted(cfg["load_weights"]))
+        if cfg.get("task_encoder_load_weights"):
+            self.load_weights_task_encoder(rooted(cfg["task_encoder_load_weights"]))
+            self.set_learnable_task_encoder(cfg["task_encoder_learnable"])
+        if cfg.get("motor_decoder_load_weights"):
+            self.load_weights_motor_decoder(rooted(cfg["motor_decoder_load_weights"]))
+            self.set_learnable_motor_decoder(cfg["motor_decoder_learnable"])
+        if cfg.get("world_model_load_weights"):
+            self.load_weights_world_model(rooted(cfg["world_model_load_weights"]))
+            self.set_learnable_world_model(cfg["world_model_learnable"])
+
+    # -- nn.Module plumbing ---------------------------------------------------------------
+    def _apply(self, fn, recurse=True):
+        """`.to()/.cuda()/.float()` would re-allocate the arena-backed parameters and break
+        the aliasing; the device is chosen at construction (custom_model_config['device'])."""
+        probe = fn(torch.zeros(1, device=self.engine.device))
+        if probe.device != self.engine.device or probe.dtype != torch.float32:
+            raise RuntimeError("PhysicsVAE lives on %s/float32 (chosen at construction); "
+                               "rebuild it with custom_model_config['device'] instead of .to()"
+                               % self.engine.device)
+        return self
+
+    def get_initial_state(self):
+        return []
+
+    def seed(self, seed):
+        """Key of the on-chip Philox stream used when no eps is supplied."""
+        self._rng_seed, self._rng_calls = int(seed), 0
+
+    # -- forward (rmt:742-853), all contractions on the HIP kernels ---------------------------
+    def __call__(self, input_dict, state=None, seq_lens=None):
+        # ModelV2.__call__ semantics: obs_flat = obs, then forward
+        d = dict(input_dict)
+        d["obs_flat"] = d["obs"] if "obs" in d else d["obs_flat"]
+        out, st = self.forward(d, state or [], seq_lens)
+        return out, st
+
+    def forward(self, input_dict, state, seq_lens, eps=None):
+        obs = input_dict["obs_flat"].float()
+        z_body, z_task, _ = self.forward_encoder(obs, state, seq_lens, 0, eps=eps)
+        logits, _ = self.forward_decoder(z_body, z_task, state, seq_lens, 0)
+        self._cur_future_state = self.forward_world(obs, logits)
+        val, _ = self.forward_value_branch(obs, state, seq_lens, 0)
+        self._cur_body_encoder_variable = z_body
+        self._cur_task_encoder_variable = z_task
+        self._cur_value = val.squeeze(1)
+        return logits, state
+
+    def forward_encoder(self, obs, state=None, seq_lens=None, state_cnt=0, eps=None):
+        Z = self._task_encoder_output_dim
+        obs = obs.to(self.engine.device)
+        h = self.engine.net_forward(NET_TE, obs)
+        self._cur_task_encoder_mu, self._cur_task_encoder_logvar = h[:, :Z], h[:, Z:]
+        z_task = self._reparameterize(h, eps)
+        return obs[..., : self.dim_state_body], z_task, state_cnt
+
+    def _reparameterize(self, mu_logvar, eps=None):
+        self._rng_calls += 1
+        return self.engine.reparam(mu_logvar, eps=eps, noise=self.latent_prior_noise,
+                                   seed=self._rng_seed, offset=self._rng_calls)
+
+    def forward_decoder(self, z_body, z_task, state=None, seq_lens=None, state_cnt=0):
+        z = torch.cat([z_body.to(self.engine.device), z_task.to(self.engine.device)], dim=-1)
+        a_hat = self.engine.net_forward(NET_MD, z)
+        return self._motor_decoder._model[-1](a_hat), state_cnt
+
+    def forward_world(self, obs, logits):
+        x = torch.cat([obs[..., : self.dim_state_body].to(self.engine.device),
+                       logits[..., : self.dim_action].to(self.engine.device)], dim=-1)
+        return self.engine.net_forward(NET_WM, x)
+
+    def forward_value_branch(self, obs, state=None, seq_lens=None, state_cnt=0):
+        with torch.no_grad():
+            return self._value_branch(obs.to(self.engine.device).float()), state_cnt
+
+    def value_function(self):
+        assert self._cur_value is not None, "must call forward() first"
+        return self._cur_value
+
+    def set_exploration_std(self, std):
+        self._motor_decoder._model[-1].set_val(float(np.log(std)))
+
+    def task_encoder_variable(self):
+        return self._cur_task_encoder_variable
+
+    def body_encoder_variable(self):
+        return self._cur_body_encoder_variable
+
+    # -- weights I/O (rmt:870-928) ----------------------------------------------------------
+    def portable_state_dict(self):
+        return _portable(self.state_dict())
+
+    def save_weights(self, file):
+        torch.save(self.portable_state_dict(), file)
+
+    def load_weights(self, file):
+        self.load_state_dict(torch.load(file, map_location="cpu"))
+        self.eval()
+
+    def save_weights_task_encoder(self, file):
+        torch.save({"task_encoder": _portable(self._task_encoder.state_dict())}, file)
+
+    def load_weights_task_encoder(self, file):
+        self._task_encoder.load_state_dict(torch.load(file, map_location="cpu")["task_encoder"])
+        self._task_encoder.eval()
+
+    def save_weights_motor_decoder(self, file):
+        torch.save(_portable(self._motor_decoder.state_dict()), file)
+
+    def load_weights_motor_decoder(self, file):
+        loaded = torch.load(file, map_location="cpu")
+        current = self._motor_decoder.state_dict()
+        for key in list(loaded.keys()):          # keep our log_std (rmt:895-905)
+            if "log_std" in key:
+                loaded[key] = current[key]
+        self._motor_decoder.load_state_dict(loaded)
+        self._motor_decoder.eval()
+
+    def save_weights_world_model(self, file):
+        torch.save(_portable(self._world_model.state_dict()), file)
+
+    def load_weights_world_model(self, file):
+        self._world_model.load_state_dict(torch.load(file, map_location="cpu"))
+        self._world_model.eval()
+
+    def save_weights_latent_prior(self, file):
+        pass                                     # no learnable prior (see __init__)
+
+    def load_weights_latent_prior(self, file):
+        pass
+
+    # -- freezing (rmt:930-950) -----------------------------------------------------------
+    def set_learnable_task_encoder(self, learnable):
+        for p in self._task_encoder.parameters():
+            p.requires_grad = learnable
+
+    def set_learnable_motor_decoder(self, learnable, free_log_std=True):
+        for p in self._motor_decoder.parameters():
+            p.requires_grad = learnable
+
+    def set_learnable_world_model(self, learnable):
+        for p in self._world_model.parameters():
+            p.requires_grad = learnable
+
+    def learnable_nets(self):
+        def on(m):
+            return all(p.requires_grad for p in m.parameters())
+        return [n for n, m in ((NET_TE, self._task_encoder), (NET_MD, self._motor_decoder),
+                               (NET_WM, self._world_model)) if on(m)]

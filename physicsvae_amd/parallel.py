@@ -1,0 +1,66 @@
+"""Data-parallel sharding of the minibatch schedule: one process per GPU, gradients summed
+with an RCCL all-reduce over xGMI (`torch.distributed` backend "nccl" on ROCm; "gloo" in the
+CPU tests).
+
+The path shards over independent samples with ONE exchange per optimizer step (SURVEY.md
+8e): global minibatch g covers windows [g*Bg, (g+1)*Bg) in the reference's sequential
+order, Bg = world * batch_size; rank r takes the contiguous slice starting at r*batch_size.
+Every rank scales its loss terms and gradients by 1/global_rows (not by its local row
+count), so a plain SUM all-reduce reproduces the reference's batch-mean gradient, including
+on the ragged last global batch where shards may be short or empty.  Parameters and Adam
+moments are replicated and every rank applies the identical update to the identical
+reduced gradient, so replicas stay bit-identical.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, rank=0, world=1, group=None):
+        self.rank, self.world, self.group = int(rank), int(world), group
+
+    @classmethod
+    def from_env(cls):
+        if dist.is_available() and dist.is_initialized():
+            return cls(dist.get_rank(), dist.get_world_size())
+        return cls(0, 1)
+
+    def global_steps(self, n_windows, batch_size):
+        bg = batch_size * self.world
+        return (n_windows + bg - 1) // bg
+
+    def global_first(self, g, batch_size):
+        return g * batch_size * self.world
+
+    def shard(self, g, n_windows, batch_size):
+        """-> (first_window, rows, global_rows) of this rank in global minibatch g."""
+        gfirst = self.global_first(g, batch_size)
+        gend = min(gfirst + batch_size * self.world, n_windows)
+        first = gfirst + self.rank * batch_size
+        rows = max(0, min(batch_size, gend - first))
+        return (first if rows else 0), rows, gend - gfirst
+
+    def all_reduce(self, tensor):
+        if self.world > 1:
+            dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
+        return tensor
+
+
+def init_from_env(backend=None):
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT).
+    Returns (rank, world, local_rank).  No-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local

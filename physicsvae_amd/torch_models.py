@@ -1,0 +1,291 @@
+"""Module API of the reference's torch_models.py, re-implemented for the HIP hot path.
+
+Same names and call contracts (tm:21-216): `get_lr_scheduler`, `DatasetBase`, `get_loss_fn`,
+`TrainModel` with the Trainable hooks `setup / step / save_checkpoint / load_checkpoint` and
+the overridable `load_dataset / get_data_loader / prepare_data / create_model /
+compute_model / compute_loss / compute_test_loss`.
+
+Differences by design:
+  * `step()` does not iterate a DataLoader: the demonstration set is resident in HBM and each
+    minibatch is one `pvae_train_step` (gather -> forward/backward -> Adam, all HIP).  The
+    per-batch `loss.item()` host sync of tm:144 is gone: losses land in a device array and
+    are read once per epoch; the returned dict is the same.
+  * the optimizer is `HipAdam` (fused into the weight-gradient kernels on one GPU, a flat
+    multi-tensor kernel after the RCCL all-reduce on several); torch's lr schedulers drive it
+    unchanged through `param_groups`.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from . import parallel, tune
+from ._lib import NET_MD, NET_TE, NET_WM, PHASE_JOINT, PHASE_WORLD
+from .engine import make_step_params
+
+EPSILON = np.finfo(np.float32).eps
+
+
+def get_lr_scheduler(optimizer, name, params):
+    """tm:21-37: 'cosine' | 'cosine_restart' | 'step' | anything else -> None."""
+    table = {
+        "cosine": lambda: optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=params["T_max"]),
+        "cosine_restart": lambda: optim.lr_scheduler.CosineAnnealingWarmRestarts(
+            optimizer, T_0=params["T_0"], T_mult=params["T_mult"]),
+        "step": lambda: optim.lr_scheduler.StepLR(
+            optimizer, step_size=params["step_size"], gamma=params["gamma"]),
+    }
+    return table[name]() if name in table else None
+
+
+def get_loss_fn(loss):
+    """tm:97-107.  Only MSE runs on the HIP path; the others are returned for API parity."""
+    if loss == "MSE":
+        return nn.MSELoss()
+    if loss in ("MAE", "L1"):
+        return nn.L1Loss()
+    if loss == "CrossEntropy":
+        return nn.CrossEntropyLoss()
+    if loss == "NLLLoss":
+        return nn.NLLLoss()
+    raise NotImplementedError(loss)
+
+
+class DatasetBase(torch.utils.data.Dataset):
+    """tm:39-95: (X, Y) arrays with optional per-feature standardisation."""
+
+    def __init__(self, X, Y, normalize_x=True, normalize_y=True):
+        self.X, self.Y = X, Y
+        self.normalize_x, self.normalize_y = normalize_x, normalize_y
+        if normalize_x:
+            self.X_mean, self.X_std = np.mean(X, axis=0), np.std(X, axis=0)
+        if normalize_y:
+            self.Y_mean, self.Y_std = np.mean(Y, axis=0), np.std(Y, axis=0)
+
+    def __len__(self):
+        return len(self.X)
+
+    def __getitem__(self, index):
+        return self.preprocess_x(self.X[index]), self.preprocess_y(self.Y[index])
+
+    @staticmethod
+    def _wrap(a, return_tensor):
+        return torch.Tensor(a) if return_tensor else a
+
+    def preprocess_x(self, x, return_tensor=True):
+        if self.normalize_x:
+            x = (x - self.X_mean) / (self.X_std + EPSILON)
+        return self._wrap(x, return_tensor)
+
+    def postprocess_x(self, x, return_tensor=True):
+        if self.normalize_x:
+            x = self.X_mean + np.multiply(x, self.X_std)
+        return self._wrap(x, return_tensor)
+
+    def preprocess_y(self, y, return_tensor=True):
+        if self.normalize_y:
+            y = (y - self.Y_mean) / (self.Y_std + EPSILON)
+        return self._wrap(y, return_tensor)
+
+    def postprocess_y(self, y, return_tensor=True):
+        if self.normalize_y:
+            y = self.Y_mean + np.multiply(y, self.Y_std)
+        return self._wrap(y, return_tensor)
+
+
+class WindowLoader:
+    """Sequential, non-shuffled, keep-last-partial minibatch schedule over a window dataset
+    -- what `DataLoader(dataset, batch_size, shuffle=None)` yields in the reference (tm:166-175;
+    the "suffle_data" typo of tpv:260 means shuffle is always None).  `len()` = number of
+    minibatches; iterating yields the same (x, y) float32 tensors as the reference's loader
+    (host side, for inspection); `spans()` yields (first_window, rows) for the HIP path."""
+
+    def __init__(self, dataset, batch_size, shuffle=None):
+        if shuffle:
+            raise NotImplementedError("shuffled sampling: the reference never shuffles (tpv:260 vs tm:181)")
+        self.dataset, self.batch_size = dataset, int(batch_size)
+
+    def __len__(self):
+        return math.ceil(len(self.dataset) / self.batch_size)
+
+    def spans(self):
+        n = len(self.dataset)
+        for first in range(0, n, self.batch_size):
+            yield first, min(self.batch_size, n - first)
+
+    def __iter__(self):
+        for first, rows in self.spans():
+            xs, ys = zip(*(self.dataset[i] for i in range(first, first + rows)))
+            yield torch.stack(xs), torch.stack(ys)
+
+
+class HipAdam(optim.Optimizer):
+    """Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) as tm:119-122 constructs it, with
+    the update executed by the HIP kernels.  Holds what torch's schedulers and callers look
+    at (`param_groups[0]['lr']`) plus the per-net 1-based step counters: state is created
+    lazily per parameter in torch, so a net's counter starts when it first receives a
+    gradient (TE/MD start at 1 at the phase switch; SURVEY.md section 7 hard part 7)."""
+
+    def __init__(self, params, engine, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if weight_decay != 0.0:
+            raise NotImplementedError("weight_decay != 0 (the trainer uses 0.0, tpv:253)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.engine = engine
+        self.net_steps = {NET_TE: 0, NET_MD: 0, NET_WM: 0}
+
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    def next_counts(self, nets):
+        """Advance and return adam_t for the nets updated by the coming step."""
+        for n in nets:
+            self.net_steps[n] += 1
+        return [max(self.net_steps[n], 1) for n in (NET_TE, NET_MD, NET_WM)]
+
+    def step(self, closure=None):
+        # the update itself is issued by TrainModel (fused or after the all-reduce)
+        return None
+
+    def zero_grad(self, set_to_none=True):
+        return None
+
+    def moments(self):
+        """{key: (exp_avg view, exp_avg_sq view)} in checkpoint key naming."""
+        m, v = self.engine.named_views(self.engine.exp_avg), self.engine.named_views(self.engine.exp_avg_sq)
+        return {k: (m[k], v[k]) for k in m}
+
+
+class TrainModel(tune.Trainable):
+    """Epoch-per-step supervised trainer (tm:109-216)."""
+
+    # -- Trainable hooks ------------------------------------------------------------------
+    def setup(self, config):
+        self.model = self.create_model(config)
+        self.engine = self.model.engine
+        self.device = self.engine.device
+        self.dp = parallel.DataParallel.from_env()
+        self.prepare_data(config)
+        self.optimizer = HipAdam(self.model.parameters(), self.engine,
+                                 lr=config.get("lr", 1e-3),
+                                 weight_decay=config.get("weight_decay", 0.0))
+        self.lr_scheduler = get_lr_scheduler(self.optimizer, config.get("lr_schedule", None),
+                                             config.get("lr_schedule_params", None))
+        if config.get("loss", "MSE") != "MSE" or config.get("loss_test", "MSE") != "MSE":
+            raise NotImplementedError("the HIP path implements the MSE losses the trainer uses (tpv:257-258)")
+        self.loss_fn = get_loss_fn("MSE")
+        self.loss_fn_test = get_loss_fn("MSE")
+        self.iter = 0
+        self.global_batch = 0                     # minibatches consumed so far (eps / Philox key)
+        self.eps_fn = config.get("eps_fn")        # callable(global_batch, (rows, Z)) -> eps, or None
+        self.rng_seed = int(config.get("seed", 0))
+        self.last_loss_terms = None
+
+    def step(self):
+        self.iter += 1
+        self.model.train()
+        losses = self.run_epoch(self.train_loader, train=True)
+        mean_train = float(losses[:, 0].mean()) if len(losses) else 0.0
+        self.last_loss_terms = losses.mean(dim=0).tolist() if len(losses) else None
+        mean_test = 0.0
+        if self.test_loader:
+            test = self.run_epoch(self.test_loader, train=False)
+            mean_test = float(test[:, 0].mean()) if len(test) else 0.0
+        if self.lr_scheduler:
+            self.lr_scheduler.step()              # once per EPOCH (tm:158-159)
+        return {"mean_train_loss": mean_train, "mean_test_loss": mean_test}
+
+    # -- the hot loop ---------------------------------------------------------------------
+    def phase(self):
+        """World phase <=> only the world model is learnable (tpv:326-329 / 347-350)."""
+        nets = self.model.learnable_nets()
+        if nets == [NET_WM]:
+            return PHASE_WORLD, nets
+        if nets == [NET_TE, NET_MD]:
+            return PHASE_JOINT, nets
+        raise NotImplementedError("learnable nets %s: the trainer only uses {WM} or {TE, MD}" % nets)
+
+    def step_params(self, nets, global_rows, train):
+        raise NotImplementedError
+
+    def run_epoch(self, loader, train):
+        """One pass over `loader` (tm:137-144 / 147-156).  Returns a host tensor
+        [n_minibatches, 5] = {total, a, kl, s, cyc} per minibatch (unweighted: the epoch
+        figure is the plain mean of minibatch means, tm:145)."""
+        eng, dp = self.engine, self.dp
+        phase, nets = self.phase()
+        eng.bind_dataset(*loader.dataset.device_arrays(eng.device))
+        n_glob = dp.global_steps(len(loader.dataset), loader.batch_size)
+        out = torch.zeros(max(n_glob, 1), 5, dtype=torch.float32, device=eng.device)
+        for g in range(n_glob):
+            first, rows, global_rows = dp.shard(g, len(loader.dataset), loader.batch_size)
+            sp = self.step_params(nets, global_rows, train)
+            sp.rng_seed = self.rng_seed
+            sp.rng_offset = self.global_batch * 65536 + dp.rank
+            eps = None
+            if self.eps_fn is not None and phase == PHASE_JOINT:
+                full = self.eps_fn(self.global_batch, (global_rows, self.engine.arch.Z))
+                lo = first - dp.global_first(g, loader.batch_size)
+                eps = full[lo: lo + rows]
+            if not train:
+                if rows:
+                    eng.gather(first, rows)
+                    eng.forward_backward(phase, rows, sp, eps=eps, backward=False, loss_out=out[g])
+            elif dp.world == 1:
+                eng.train_step(phase, first, rows, sp, eps=eps, loss_out=out[g])
+            else:
+                seg = eng.segment(eng.grads, nets)
+                if rows:
+                    eng.gather(first, rows)
+                    eng.forward_backward(phase, rows, sp, eps=eps, fused_adam=False, loss_out=out[g])
+                else:
+                    seg.zero_()                   # empty shard of a ragged last global batch
+                dp.all_reduce(seg)
+                eng.adam(nets, sp)
+            if train:
+                self.optimizer.step()             # bookkeeping only (scheduler call order)
+            self.global_batch += 1
+        if dp.world > 1:
+            dp.all_reduce(out)
+        return out[:n_glob].cpu()                 # the single host sync of the epoch
+
+    # -- overridables, reference names ----------------------------------------------------
+    def load_dataset(self, file):
+        raise NotImplementedError
+
+    def get_data_loader(self, dataset, batch_size, shuffle):
+        return WindowLoader(dataset, batch_size, shuffle)
+
+    def prepare_data(self, config):
+        train = self.load_dataset(config.get("dataset_train"))
+        test = config.get("dataset_test")
+        if test is not None:
+            test = self.load_dataset(test)
+        bs, shuffle = config.get("batch_size"), config.get("shuffle_data")
+        self.train_loader = self.get_data_loader(train, bs, shuffle)
+        self.test_loader = self.get_data_loader(test, bs, shuffle) if test is not None else None
+
+    def create_model(self, config):
+        return config.get("model")
+
+    def compute_model(self, x):
+        raise NotImplementedError
+
+    def compute_loss(self, y, x):
+        raise NotImplementedError
+
+    def compute_test_loss(self, y, x):
+        return self.compute_loss(y, x)
+
+    def save_checkpoint(self, checkpoint_dir):
+        print(checkpoint_dir)
+        path = os.path.join(checkpoint_dir, "model.pth")
+        torch.save(self.model.portable_state_dict(), path)
+        return path
+
+    def load_checkpoint(self, checkpoint_path):
+        # weights only -- optimizer, scheduler, iter are not restored (tm:215-216, App. C-7)
+        self.model.load_state_dict(torch.load(checkpoint_path, map_location="cpu"))

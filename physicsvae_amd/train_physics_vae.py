@@ -1,0 +1,340 @@
+"""The reference's train_physics_vae.py surface on the MI355X-native hot path.
+
+Same CLI flags (tpv:30-55), same dataset schema (tpv:57-92), same trainer-config keys
+(tpv:247-286), same two-phase schedule and loss (tpv:313-435), same five checkpoint files
+(tpv:440-467) -- driven by HIP kernels instead of a PyTorch autograd graph, and without a
+ray / gym dependency.  Extra flags (ours): --TE_width/--TE_depth/--MD_*/--world_model_* to
+pick the MLP sizes from the command line, --seed.
+
+    python -m physicsvae_amd.train_physics_vae --data_train demo.pkl \\
+        --max_iter 800 --max_iter_world_model 300
+"""
+import argparse
+import copy
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from . import torch_models, tune
+from ._lib import NET_MD, NET_TE, NET_WM, PHASE_JOINT, PHASE_WORLD
+from .engine import make_step_params
+from .model import PhysicsVAE, fc_spec
+from .spaces import Box
+
+args = None          # module-global, as in the reference (read by TrainModel.load_dataset, tpv:339)
+
+
+def arg_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--max_iter_world_model", type=int, default=0)
+    p.add_argument("--max_iter", type=int, default=100)
+    p.add_argument("--num_cpus", type=int, default=1)
+    p.add_argument("--num_gpus", type=int, default=0)
+    p.add_argument("--data_train", action="append", required=True, type=str, default=None)
+    p.add_argument("--data_test", action="append", type=str, default=None)
+    p.add_argument("--num_data", type=int, default=None)
+    p.add_argument("--output", type=str, default=None)
+    p.add_argument("--lr", type=float, default=0.0005)
+    p.add_argument("--lr_schedule", type=str, default="step")
+    p.add_argument("--batch_size", type=int, default=256)
+    p.add_argument("--checkpoint_freq", type=int, default=100)
+    p.add_argument("--checkpoint", type=str, default=None)
+    p.add_argument("--cluster", action="store_true")
+    p.add_argument("--resume", action="store_true")
+    p.add_argument("--name", type=str, default=None)
+    p.add_argument("--local_dir", type=str, default="~/ray_results")
+    p.add_argument("--world_model", type=str, default=None)
+    p.add_argument("--latent_dim", type=int, default=32)
+    # NB (reference quirk kept): action='append' on a list default
+    # APPENDS to the default, so `--vae_kl_coeff 0.1` means a sweep over [1.0, 0.1].
+    p.add_argument("--vae_kl_coeff", type=float, action="append", default=[1.0])
+    p.add_argument("--vae_cycle_coeff", type=float, action="append", default=[1e-3])
+    p.add_argument("--latent_prior_type", type=str, action="append",
+                   default=["normal_zero_mean_one_std"])
+    # ours: MLP sizes are dict-only in the reference (tpv:263-280)
+    p.add_argument("--TE_width", type=int, default=256)
+    p.add_argument("--TE_depth", type=int, default=2)
+    p.add_argument("--MD_width", type=int, default=512)
+    p.add_argument("--MD_depth", type=int, default=3)
+    p.add_argument("--world_model_width", type=int, default=1024)
+    p.add_argument("--world_model_depth", type=int, default=2)
+    p.add_argument("--seed", type=int, default=0)
+    return p
+
+
+META_KEYS = ("iter_per_episode", "dim_state", "dim_state_body", "dim_state_task", "dim_action", "exp_std")
+
+
+def merge_dataset(files):
+    """Concatenate the episode lists of several demo pickles; later files must agree with
+    the first on the meta fields (tpv:94-114)."""
+    merged = None
+    for path in files:
+        with open(path, "rb") as f:
+            data = pickle.load(f)
+        print(path, "is loaded")
+        if merged is None:
+            merged = data
+            continue
+        for key in META_KEYS:
+            assert merged[key] == data[key], "dataset meta mismatch on %r" % key
+        merged["episodes"] = merged["episodes"] + data["episodes"]
+    return merged
+
+
+class WindowDataset(torch_models.DatasetBase):
+    """(s_t, s_{t+1}, a_t) windows over demonstration episodes, stored ONCE.
+
+    The reference materialises X[N, L, 2*Db] / Y[N, L, Da] in float64 with every state row
+    duplicated (tpv:133-156: 6.4 GB for 1e6 transitions at Db=400).  Here the episodes are
+    packed as float32 `states[R, Db]`, `actions[R, Da]` plus `window_row[N]` (row of s_t; s_{t+1}
+    is the next row) -- the layout the gather kernel reads from HBM.  `__getitem__`, `X`, `Y`
+    reproduce the reference's tensors on demand."""
+
+    def __init__(self, states, actions, window_row):
+        self.states = np.ascontiguousarray(states, dtype=np.float32)
+        self.actions = np.ascontiguousarray(actions, dtype=np.float32)
+        self.window_row = np.ascontiguousarray(window_row, dtype=np.int32)
+        self.normalize_x = self.normalize_y = False        # tpv:163-164
+        self._dev = None
+
+    def __len__(self):
+        return len(self.window_row)
+
+    def __getitem__(self, index):
+        r = int(self.window_row[index])
+        x = np.concatenate([self.states[r], self.states[r + 1]])[None, :]
+        return torch.from_numpy(x.copy()), torch.from_numpy(self.actions[r][None, :].copy())
+
+    @property
+    def X(self):
+        r = self.window_row
+        return np.concatenate([self.states[r], self.states[r + 1]], axis=1)[:, None, :].astype(np.float64)
+
+    @property
+    def Y(self):
+        return self.actions[self.window_row][:, None, :].astype(np.float64)
+
+    def device_arrays(self, device):
+        if self._dev is None or self._dev[0].device != torch.device(device):
+            self._dev = tuple(torch.from_numpy(a).to(device)
+                              for a in (self.states, self.actions, self.window_row))
+        return self._dev
+
+
+def load_dataset_for_PhysicsVAE(files, num_samples=None, lookahead=1, cond="abs", use_a_gt=False):
+    """tpv:117-164.  Windows are emitted episode by episode, i ascending; `num_samples` caps the
+    total at exactly that many (tpv:137-138)."""
+    assert files and len(files) > 0
+    if lookahead != 1:
+        raise NotImplementedError("lookahead > 1 (the trainer hard-wires 1, tpv:277)")
+    if cond != "abs":
+        raise NotImplementedError("cond=%r (the trainer uses 'abs')" % cond)
+    data = merge_dataset(files)
+    episodes = data["episodes"]
+    states, actions, rows = [], [], []
+    base = 0
+    for ep in episodes:
+        T = len(ep["time"])
+        assert T >= lookahead
+        sb = np.asarray(ep["state_body"], dtype=np.float64)
+        ac = np.asarray(ep["action_gt" if use_a_gt else "action"], dtype=np.float64)
+        n = T - lookahead
+        if num_samples is not None:
+            n = max(0, min(n, num_samples - len(rows)))
+        states.append(sb.astype(np.float32))
+        actions.append(ac.astype(np.float32))
+        rows.extend(range(base, base + n))
+        base += T
+    ds = WindowDataset(np.concatenate(states), np.concatenate(actions), np.asarray(rows, dtype=np.int32))
+    print("------------------Data Loaded------------------")
+    print("File:", files)
+    print("Num Episodes:", len(episodes))
+    print("Num Transitions (Tuples):", len(ds))
+    print("-----------------------------------------------")
+    return ds
+
+
+def create_model(config):
+    mc = config["model"]
+    cmc = mc["custom_model_config"]
+    return PhysicsVAE(obs_space=cmc["observation_space"], action_space=cmc["action_space"],
+                      num_outputs=2 * cmc["action_space"].shape[0], model_config=mc,
+                      name="physics_vae")
+
+
+MODEL_CONFIG = copy.deepcopy(PhysicsVAE.DEFAULT_CONFIG)
+
+
+def gen_layers(width, depth, out_size="output", act_hidden="relu", act_out="linear", add_softmax=False):
+    """tpv:180-192."""
+    if add_softmax:
+        raise NotImplementedError("softmax heads are not used by the PhysicsVAE trainer")
+    return fc_spec(width, depth, out_size=out_size, act_hidden=act_hidden, act_out=act_out)
+
+
+def inspect_dataset(path):
+    with open(path, "rb") as f:
+        ep0 = pickle.load(f)["episodes"][0]
+    db, da = len(ep0["state_body"][0]), len(ep0["action"][0])
+    return 2 * db, db, db, da
+
+
+def get_trainer_config(a):
+    """tpv:194-288.  s_t = (sb_t, sb_{t+1}): the model's observation is two body states."""
+    assert a.max_iter_world_model <= a.max_iter
+    dim_state, dim_body, dim_task, dim_action = inspect_dataset(a.data_train[0])
+
+    def box(n, scale):
+        return Box(low=-scale * np.ones(n), high=scale * np.ones(n), dtype=np.float64)
+
+    cmc = copy.deepcopy(MODEL_CONFIG)
+    cmc.update(observation_space=box(dim_state, 1000.0), observation_space_body=box(dim_body, 1000.0),
+               observation_space_task=box(dim_task, 1000.0), action_space=box(dim_action, 3.0),
+               world_model_load_weights=a.world_model, max_batch=a.batch_size)
+    return {
+        "max_iter_world_model": a.max_iter_world_model,
+        "model": {"custom_model": "physics_vae", "custom_model_config": cmc},
+        "lr": a.lr,
+        "lr_schedule_params": {"step_size": 50, "gamma": 0.70},
+        "lr_schedule": a.lr_schedule,
+        "weight_decay": 0.0,
+        "dataset_train": a.data_train,
+        "dataset_test": a.data_test,
+        "use_gpu": False,
+        "loss": "MSE",
+        "loss_test": "MSE",
+        "batch_size": a.batch_size,
+        "suffle_data": True,            # sic -- the key the reference sets; nothing reads it
+        "latent_dim": a.latent_dim,
+        "latent_prior_type": tune.grid_search(a.latent_prior_type),
+        "act_fn": "relu",
+        "MD_width": tune.grid_search([getattr(a, "MD_width", 512)]),
+        "MD_depth": tune.grid_search([getattr(a, "MD_depth", 3)]),
+        "TE_width": tune.grid_search([getattr(a, "TE_width", 256)]),
+        "TE_depth": tune.grid_search([getattr(a, "TE_depth", 2)]),
+        "lookahead": 1,
+        "world_model_width": tune.grid_search([getattr(a, "world_model_width", 1024)]),
+        "world_model_depth": tune.grid_search([getattr(a, "world_model_depth", 2)]),
+        "vae_kl_coeff": tune.grid_search(a.vae_kl_coeff),
+        "motor_decoder_a_rec_coeff": 1.0,
+        "world_model_s_rec_coeff": 0.0,
+        "vae_cycle_coeff": tune.grid_search(a.vae_cycle_coeff),
+        "seed": getattr(a, "seed", 0),
+    }
+
+
+def update_model_config(trainer_config):
+    """tpv:290-311: expand width/depth into layer-spec lists inside custom_model_config."""
+    cmc = trainer_config["model"]["custom_model_config"]
+    act = trainer_config.get("act_fn")
+    cmc["task_encoder_output_dim"] = trainer_config.get("latent_dim")
+    cmc["latent_prior_type"] = trainer_config.get("latent_prior_type")
+    for key, prefix in (("task_encoder_layers", "TE"), ("motor_decoder_layers", "MD"),
+                        ("world_model_layers", "world_model")):
+        cmc[key] = gen_layers(width=trainer_config.get(prefix + "_width"),
+                              depth=trainer_config.get(prefix + "_depth"), act_hidden=act)
+    cmc["max_batch"] = trainer_config.get("batch_size", cmc.get("max_batch", 256))
+
+
+class TrainModel(torch_models.TrainModel):
+    """tpv:313-467."""
+
+    def setup(self, config):
+        update_model_config(config)
+        self.config = config
+        self.max_iter_world_model = config.get("max_iter_world_model")
+        self.latent_prior_type = config.get("latent_prior_type")
+        self.lookahead = config.get("lookahead")
+        super().setup(config)
+        self.model.set_learnable_task_encoder(False)
+        self.model.set_learnable_motor_decoder(False)
+        self.model.set_learnable_world_model(True)
+        self.read_loss_fn_coeff(world=True)
+
+    def read_loss_fn_coeff(self, world):
+        c = self.config
+        self.vae_kl_coeff = 0.0 if world else c.get("vae_kl_coeff")
+        self.a_rec_coeff = 0.0 if world else c.get("motor_decoder_a_rec_coeff")
+        self.s_rec_coeff = 1.0 if world else c.get("world_model_s_rec_coeff")
+        self.vae_cycle_coeff = 0.0 if world else c.get("vae_cycle_coeff")
+
+    def load_dataset(self, file):
+        num = getattr(args, "num_data", None) if args is not None else None
+        return load_dataset_for_PhysicsVAE(file, num_samples=num, lookahead=self.lookahead)
+
+    def step(self):
+        # the flip is tested BEFORE the increment: epochs 1..M are world, M+1.. joint (tpv:342)
+        if self.iter == self.max_iter_world_model:
+            self.model.set_learnable_task_encoder(True)
+            self.model.set_learnable_motor_decoder(True)
+            self.model.set_learnable_world_model(False)
+            self.read_loss_fn_coeff(world=False)
+        return super().step()
+
+    def create_model(self, config):
+        return create_model(config)
+
+    def step_params(self, nets, global_rows, train):
+        t = self.optimizer.next_counts(nets) if train else [1, 1, 1]
+        return make_step_params(lr=self.optimizer.lr, adam_t=t, a_rec=self.a_rec_coeff,
+                                kl=self.vae_kl_coeff, s_rec=self.s_rec_coeff, cyc=self.vae_cycle_coeff,
+                                global_rows=global_rows)
+
+    # explicit-batch entry points with the reference's signatures (tpv:356-435) -------------
+    def compute_model(self, x, eps=None):
+        logits, _ = self.model(input_dict={"obs": x, "obs_flat": x}, state=None, seq_lens=None)
+        return logits[..., : logits.shape[1] // 2]
+
+    def compute_loss(self, y, x, eps=None):
+        """Loss of one caller-supplied minibatch (x [B,1,2Db], y [B,1,Da]), forward only.
+        Returns the 0-dim total (device tensor); per-term values in `self.last_loss_terms`."""
+        phase, nets = self.phase()
+        rows = self.engine.set_batch(x, y)
+        sp = make_step_params(lr=self.optimizer.lr, a_rec=self.a_rec_coeff, kl=self.vae_kl_coeff,
+                              s_rec=self.s_rec_coeff, cyc=self.vae_cycle_coeff, global_rows=rows,
+                              seed=self.rng_seed, offset=self.global_batch * 65536)
+        out = torch.zeros(5, dtype=torch.float32, device=self.engine.device)
+        self.engine.forward_backward(phase, rows, sp, eps=eps, backward=False, loss_out=out)
+        self.last_loss_terms = out
+        return out[0]
+
+    def save_checkpoint(self, checkpoint_dir):
+        path = super().save_checkpoint(checkpoint_dir)
+        m = self.model
+        for fname, fn in (("model.pt", m.save_weights), ("task_encoder.pt", m.save_weights_task_encoder),
+                          ("motor_decoder.pt", m.save_weights_motor_decoder),
+                          ("world_model.pt", m.save_weights_world_model)):
+            target = os.path.join(checkpoint_dir, fname)
+            fn(target)
+            print("Saved:", target)
+        return path
+
+
+def main(argv=None):
+    global args
+    args = arg_parser().parse_args(argv)
+    from . import parallel
+    parallel.init_from_env()
+    torch.manual_seed(args.seed)
+    trainer_config = get_trainer_config(args)
+    if args.checkpoint is None:
+        analysis = tune.run(TrainModel, stop={"training_iteration": args.max_iter},
+                            checkpoint_freq=args.checkpoint_freq, checkpoint_at_end=True,
+                            config=trainer_config, local_dir=args.local_dir, name=args.name)
+        checkpoint = analysis.get_best_checkpoint()
+    else:
+        checkpoint = args.checkpoint
+    if args.output is not None:
+        # the reference's --output branch instantiates the abstract base and cannot work
+        # (SURVEY.md App. C-3); here it exports the full state_dict as intended
+        trainer = TrainModel(trainer_config)
+        trainer.restore(checkpoint)
+        torch.save(trainer.model.portable_state_dict(), args.output)
+        print("Model Saved:", args.output)
+
+
+if __name__ == "__main__":
+    main()

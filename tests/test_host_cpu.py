@@ -1,0 +1,279 @@
+"""CPU-side checks (no GPU): C-ABI library loads and exports every declared symbol, arena
+layout, module/state_dict/ checkpoint layout against the reference captures, dataset
+windowing against the oracle, the minibatch schedule, and the data-parallel plumbing with
+a world_size-2 gloo group."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import refpath as R
+from physicsvae_amd import _lib, parallel
+from physicsvae_amd import torch_models as TM
+from physicsvae_amd import train_physics_vae as T
+from util import arch_from_meta, make_trainer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "pvae.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)        # drop comments
+    declared = set(re.findall(r"\b(pvae_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pvae_abi_version() == 1
+
+
+def test_layout_queries_without_gpu():
+    lib = _lib.load()
+    cfg = _lib.Config(197, 45, 32, 1024, 4, 1024, 4, 1024, 4, 256)
+    assert lib.pvae_num_layers(C.byref(cfg)) == 15
+    info = _lib.LayerInfo()
+    end = 0
+    for i in range(15):
+        assert lib.pvae_layer(C.byref(cfg), i, C.byref(info)) == 0
+        assert info.ld % 64 == 0 and info.n_out_pad % 64 == 0
+        assert info.ld >= info.n_in and info.n_out_pad >= info.n_out
+        assert info.w_offset == end                      # densely packed, in order
+        assert info.b_offset == info.w_offset + info.n_out_pad * info.ld
+        end = info.b_offset + info.n_out_pad
+    assert lib.pvae_arena_floats(C.byref(cfg)) == end
+    off, cnt = C.c_int64(), C.c_int64()
+    tot = 0
+    for net in range(3):
+        assert lib.pvae_net_segment(C.byref(cfg), net, C.byref(off), C.byref(cnt)) == 0
+        assert off.value == tot
+        tot += cnt.value
+    assert tot == end
+    assert lib.pvae_workspace_bytes(C.byref(cfg)) > 0
+
+
+def test_bad_config_is_an_error_not_a_crash():
+    lib = _lib.load()
+    cfg = _lib.Config(0, 45, 32, 1024, 4, 1024, 4, 1024, 4, 256)
+    assert lib.pvae_num_layers(C.byref(cfg)) < 0
+    assert b"bad config" in lib.pvae_last_error()
+    ctx = C.c_void_p()
+    assert lib.pvae_create(C.byref(cfg), C.byref(ctx)) < 0
+
+
+def test_compute_without_gpu_fails_loudly():
+    data = R.synth_demo(0, 2, 20, 7, 3)
+    arch = R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2))
+    tr = make_trainer(arch, data, batch=8, device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tr.step()
+
+
+@pytest.mark.parametrize("name", ["single_tiny", "single_c1", "single_c2", "single_default"])
+def test_module_state_dict_matches_reference_layout(golden, name):
+    g = golden(name)
+    arch = arch_from_meta(g["meta"])
+    n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
+    data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"])
+    tr = make_trainer(arch, data, batch, device="cpu")
+    sd = tr.model.state_dict()
+    assert list(sd.keys()) == list(g["sd_keys"])
+    assert [list(v.shape) + [0] * (2 - v.dim()) for v in sd.values()] == g["sd_shapes"].tolist()
+    assert sum(v.numel() for v in sd.values()) == int(g["n_params"])
+    assert all(v.dtype == torch.float32 for v in sd.values())
+    # normc init: hidden rows norm 1, output rows 0.01, bias 0 (tpv:184-189)
+    for k, v in sd.items():
+        if k.endswith("weight"):
+            n_layers = len([q for q in sd if q.startswith(k.split(".")[0]) and q.endswith("weight")])
+            std = 0.01 if int(k.split(".")[2]) == n_layers - 1 else 1.0
+            np.testing.assert_allclose(v.norm(dim=1).numpy(), std, rtol=1e-4)
+        else:
+            assert float(v.abs().max()) == 0.0
+    # loading the oracle's weights writes through to the flat arena; padding stays zero
+    ref = R.perturb_biases(R.init_state_dict(arch, 1), 3)
+    tr.model.load_state_dict(ref)
+    views = tr.engine.named_views()
+    for k in views:
+        assert torch.equal(views[k], ref[k])
+    used = sum(v.numel() for k, v in ref.items() if not k.startswith("_value_branch"))
+    assert int((tr.engine.params != 0).sum()) <= used
+    assert tr.engine.params.abs().sum().item() == pytest.approx(
+        sum(v.abs().double().sum().item() for k, v in ref.items() if not k.startswith("_value_branch")), rel=1e-5)
+    # freezing state after setup (tpv:326-329)
+    assert tr.model.learnable_nets() == [_lib.NET_WM]
+    n_train = sum(p.numel() for p in tr.model.parameters() if p.requires_grad)
+    wm_vb = sum(v.numel() for k, v in ref.items() if k.startswith(("_world_model", "_value_branch")))
+    assert n_train == wm_vb
+
+
+def test_checkpoint_files_match_reference_and_roundtrip(golden, tmp_path):
+    g = golden("single_default")
+    arch = arch_from_meta(g["meta"])
+    data = R.synth_demo(0, 2, 100, arch["Db"], arch["Da"])
+    tr = make_trainer(arch, data, 32, device="cpu")
+    ref = R.perturb_biases(R.init_state_dict(arch, 1), 3)
+    tr.model.load_state_dict(ref)
+    ret = tr.save_checkpoint(str(tmp_path))
+    assert os.path.basename(ret) == str(g["ckpt_return_basename"])
+    assert sorted(os.listdir(tmp_path)) == list(g["ckpt_files"])
+    for f in g["ckpt_files"]:
+        obj = torch.load(os.path.join(tmp_path, str(f)))          # weights_only default: plain tensors
+        if str(f) == "task_encoder.pt":
+            assert list(obj.keys()) == list(g["ckpt_te_outer_keys"])
+            obj = obj["task_encoder"]
+        assert list(obj.keys()) == list(g["ckpt_keys::" + str(f)])
+        for v in obj.values():
+            assert v.device.type == "cpu" and v.is_contiguous() and v.dtype == torch.float32
+    # files load into the oracle's module (same layout as the reference's class, pinned above)
+    m = R.RefModel(arch)
+    m.load_state_dict(torch.load(os.path.join(tmp_path, "model.pth")))
+    m._world_model.load_state_dict(torch.load(os.path.join(tmp_path, "world_model.pt")))
+    m._motor_decoder.load_state_dict(torch.load(os.path.join(tmp_path, "motor_decoder.pt")))
+    m._task_encoder.load_state_dict(torch.load(os.path.join(tmp_path, "task_encoder.pt"))["task_encoder"])
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, ref[k])
+    # and back: restore() of a fresh trainer reproduces the weights; per-net loaders too
+    tr2 = make_trainer(arch, data, 32, device="cpu")
+    tr2.restore(ret)
+    for k, v in tr2.model.state_dict().items():
+        assert torch.equal(v, ref[k])
+    tr3 = make_trainer(arch, data, 32, device="cpu")
+    tr3.model.load_weights_world_model(os.path.join(tmp_path, "world_model.pt"))
+    tr3.model.load_weights_motor_decoder(os.path.join(tmp_path, "motor_decoder.pt"))
+    tr3.model.load_weights_task_encoder(os.path.join(tmp_path, "task_encoder.pt"))
+    for k, v in tr3.model.state_dict().items():
+        if not k.startswith("_value_branch"):
+            assert torch.equal(v, ref[k])
+
+
+def test_window_dataset_equals_oracle_windows(tmp_path):
+    data = R.synth_demo(0, 3, 21, 7, 3)
+    pkl = str(tmp_path / "d.pkl")
+    R.write_demo(pkl, data)
+    X, Y = R.build_windows(data)
+    ds = T.load_dataset_for_PhysicsVAE([pkl])
+    assert len(ds) == len(X) == 60
+    np.testing.assert_array_equal(ds.X, X)
+    np.testing.assert_array_equal(ds.Y, Y)
+    x5, y5 = ds[5]
+    assert x5.shape == (1, 14) and x5.dtype == torch.float32
+    np.testing.assert_array_equal(x5.numpy(), X[5].astype(np.float32))
+    # states are stored once: R rows instead of 2N
+    assert ds.states.shape == (63, 7) and ds.states.dtype == np.float32
+    # cap semantics (tpv:137-138) and multi-file merge (tpv:94-114)
+    capped = T.load_dataset_for_PhysicsVAE([pkl], num_samples=25)
+    np.testing.assert_array_equal(capped.X, X[:25])
+    both = T.load_dataset_for_PhysicsVAE([pkl, pkl])
+    assert len(both) == 120
+    np.testing.assert_array_equal(both.X[60:], X)
+    bad = dict(data, dim_action=99)
+    pkl2 = str(tmp_path / "bad.pkl")
+    R.write_demo(pkl2, bad)
+    with pytest.raises(AssertionError):
+        T.merge_dataset([pkl, pkl2])
+
+
+def test_loader_schedule_is_sequential_with_partial_last_batch():
+    data = R.synth_demo(0, 2, 14, 7, 3)
+    arch = R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2))
+    tr = make_trainer(arch, data, batch=8, device="cpu")
+    X, Y = R.build_windows(data)
+    ref = list(R.make_loader(X, Y, 8))
+    ours = list(tr.train_loader)
+    assert len(tr.train_loader) == len(ref) == 4
+    assert list(tr.train_loader.spans()) == [(0, 8), (8, 8), (16, 8), (24, 2)]
+    for (xa, ya), (xb, yb) in zip(ours, ref):
+        assert torch.equal(xa, xb) and torch.equal(ya, yb)
+    with pytest.raises(NotImplementedError):
+        TM.WindowLoader(tr.train_loader.dataset, 8, shuffle=True)
+
+
+def test_phase_machine_and_adam_counters():
+    data = R.synth_demo(0, 2, 14, 7, 3)
+    arch = R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2))
+    tr = make_trainer(arch, data, batch=8, m_world=2, device="cpu")
+    assert tr.phase() == (_lib.PHASE_WORLD, [_lib.NET_WM])
+    assert (tr.s_rec_coeff, tr.a_rec_coeff, tr.vae_kl_coeff, tr.vae_cycle_coeff) == (1.0, 0.0, 0.0, 0.0)
+    sp = tr.step_params([_lib.NET_WM], 8, True)
+    assert list(sp.adam_t) == [1, 1, 1] and tr.optimizer.net_steps[_lib.NET_WM] == 1
+    tr.iter = 2                                   # as if two world epochs had run
+    tr.model.set_learnable_task_encoder(True)
+    tr.model.set_learnable_motor_decoder(True)
+    tr.model.set_learnable_world_model(False)
+    tr.read_loss_fn_coeff(world=False)
+    assert tr.phase() == (_lib.PHASE_JOINT, [_lib.NET_TE, _lib.NET_MD])
+    assert (tr.s_rec_coeff, tr.a_rec_coeff, tr.vae_kl_coeff, tr.vae_cycle_coeff) == (0.0, 1.0, 1.0, 1e-3)
+    sp = tr.step_params([_lib.NET_TE, _lib.NET_MD], 8, True)
+    assert list(sp.adam_t) == [1, 1, 1]           # TE/MD start at t = 1, WM stays where it was
+    sp = tr.step_params([_lib.NET_TE, _lib.NET_MD], 8, True)
+    assert list(sp.adam_t) == [2, 2, 1]
+    # StepLR drives HipAdam through param_groups, once per epoch
+    sched = TM.get_lr_scheduler(tr.optimizer, "step", {"step_size": 2, "gamma": 0.7})
+    lrs = []
+    for _ in range(5):
+        lrs.append(tr.optimizer.lr)
+        sched.step()
+    np.testing.assert_allclose(lrs, [R.lr_for_epoch(e, step_size=2) for e in range(1, 6)], rtol=1e-12)
+    assert TM.get_lr_scheduler(tr.optimizer, None, None) is None
+    assert TM.get_lr_scheduler(tr.optimizer, "cosine", {"T_max": 10}) is not None
+
+
+def test_unsupported_configs_are_refused():
+    data = R.synth_demo(0, 2, 14, 7, 3)
+    arch = R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2))
+    with pytest.raises(NotImplementedError):
+        make_trainer(arch, data, 8, device="cpu", extra={"latent_prior_type": "hypersphere_uniform"})
+    with pytest.raises(NotImplementedError):
+        make_trainer(arch, data, 8, device="cpu", extra={"loss": "L1"})
+
+
+def test_shard_arithmetic_matches_reference_order():
+    n, b = 1000, 64
+    for world in (1, 2, 4, 8):
+        seen = []
+        steps = parallel.DataParallel(0, world).global_steps(n, b)
+        for g in range(steps):
+            tot = 0
+            for r in range(world):
+                first, rows, grows = parallel.DataParallel(r, world).shard(g, n, b)
+                seen.extend(range(first, first + rows))
+                tot += rows
+            assert tot == grows
+        assert seen == list(range(n))             # every window once, in sequential order
+
+
+DP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from physicsvae_amd import parallel
+rank, world, _ = parallel.init_from_env(backend="gloo")
+dp = parallel.DataParallel.from_env()
+assert (dp.rank, dp.world) == (rank, 2)
+# each rank contributes sum-scaled shard gradients; SUM all-reduce == full-batch mean gradient
+torch.manual_seed(0)
+per_sample = torch.randn(10, 33)                 # per-sample gradient contributions
+first, rows, grows = dp.shard(0, 10, 6)          # ragged: 6 + 4
+local = per_sample[first:first + rows].sum(0) / grows
+dp.all_reduce(local)
+assert torch.allclose(local, per_sample.mean(0), atol=1e-6), (local - per_sample.mean(0)).abs().max()
+first, rows, grows = dp.shard(1, 13, 6)          # second global batch: rank 0 has 1 row, rank 1 none
+assert (rows, grows) == ((1, 1) if rank == 0 else (0, 1))
+dist.barrier()
+print("OK", rank)
+'''
+
+
+def test_data_parallel_allreduce_gloo_world2(tmp_path):
+    script = tmp_path / "dp_worker.py"
+    script.write_text(DP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "OK %d" % r in o

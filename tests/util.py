@@ -1,0 +1,50 @@
+"""Shared helpers for the tests (oracle = checker only)."""
+import os
+import tempfile
+
+import numpy as np
+import torch
+
+from oracle import refpath as R
+from physicsvae_amd import train_physics_vae as T
+
+
+def arch_from_meta(meta):
+    Db, Da, Z, tw, td, mw, md_, ww, wd = [int(v) for v in meta[:9]]
+    return R.make_arch(Db, Da, latent=Z, te=(tw, td), md=(mw, md_), wm=(ww, wd))
+
+
+def make_trainer(arch, data, batch, m_world=2, device=None, eps_fn=None, lr_step=50, extra=None):
+    """physicsvae_amd TrainModel over a synthetic demo dict (written to a temp pickle)."""
+    td = tempfile.mkdtemp(prefix="pvae_test_")
+    pkl = os.path.join(td, "demo.pkl")
+    R.write_demo(pkl, data)
+    argv = ["--data_train", pkl, "--batch_size", str(batch), "--max_iter_world_model", str(m_world),
+            "--latent_dim", str(arch["Z"]),
+            "--TE_width", str(arch["te"][0]), "--TE_depth", str(arch["te"][1]),
+            "--MD_width", str(arch["md"][0]), "--MD_depth", str(arch["md"][1]),
+            "--world_model_width", str(arch["wm"][0]), "--world_model_depth", str(arch["wm"][1])]
+    T.args = T.arg_parser().parse_args(argv)
+    cfg = T.get_trainer_config(T.args)
+    cfg["lr_schedule_params"] = {"step_size": lr_step, "gamma": 0.7}
+    if device is not None:
+        cfg["model"]["custom_model_config"]["device"] = device
+    if eps_fn is not None:
+        cfg["eps_fn"] = eps_fn
+    cfg.update(extra or {})
+    tr = T.TrainModel(cfg)
+    tr._tmpdir = td
+    return tr
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64).reshape(-1)
+    b = torch.as_tensor(b, dtype=torch.float64).reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def max_err_scaled(a, b):
+    """max |a-b| / (max|b| + tiny): elementwise check robust to near-zero entries."""
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
