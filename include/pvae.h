@@ -99,6 +99,11 @@ int64_t pvae_arena_floats(const pvae_config* cfg);
 /* contiguous [offset, offset+count) of one net inside the arena */
 int pvae_net_segment(const pvae_config* cfg, int net, int64_t* offset, int64_t* count);
 size_t pvae_workspace_bytes(const pvae_config* cfg);
+/* Float offset of a workspace panel (inspection / tests).  kind: 0 = input panel of `net`
+ * [Bp][ld0], 1 = its gradient, 2 = output of layer `layer` [Bp][n_out_pad], 3 = gradient wrt the
+ * pre-activation of that layer, 4 = target next-state panel, 5 = target action panel,
+ * 6 = eps [Bp][Z].  Bp = max_batch rounded up to 32.  Returns <0 on bad arguments. */
+int64_t pvae_workspace_offset(const pvae_config* cfg, int kind, int net, int layer);
 
 /* ---- context ------------------------------------------------------------------------ */
 int pvae_create(const pvae_config* cfg, pvae_ctx** out);

@@ -351,6 +351,37 @@ def loss_and_grads(arch, sd, x, y, eps, world, coeff_cfg=None):
     return out
 
 
+def relu_kink_margin(arch, sd, x, y, eps, world):
+    """Per-sample min |pre-activation| over every hidden ReLU that the phase's backward pass
+    goes through.  ReLU is not differentiable at 0: a unit whose pre-activation is within
+    fp32 rounding of zero lands on either side depending on summation order, which flips one
+    sample's gradient path in ANY two fp32 implementations (MKL vs MFMA, CPU vs GPU).  Parity
+    tests drop such samples (margin below a few ulps of the activation scale) before comparing
+    gradients tightly."""
+    model = RefModel(arch)
+    model.load_state_dict(sd)
+    model.eps_source = (lambda shape: eps) if eps is not None else None
+    margins = []
+
+    def hook(mod, inp, out):
+        margins.append(out.detach().abs().min(dim=1).values)
+
+    nets = ["_world_model"] if world else ["_task_encoder", "_motor_decoder", "_world_model"]
+    hs = []
+    for net in nets:
+        for slim in list(getattr(model, net)._model)[:-1]:        # hidden layers only
+            hs.append(slim._model[0].register_forward_hook(hook))
+    with torch.no_grad():
+        x0 = x[:, 0, :]
+        if world:
+            model.forward_world(x0, torch.cat([y[:, 0, :], y[:, 0, :]], -1))
+        else:
+            model(x0)
+    for h in hs:
+        h.remove()
+    return torch.stack(margins).min(dim=0).values
+
+
 def adam_reference_update(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     """torch.optim.Adam single-tensor update, amsgrad False, weight_decay 0 (tm:119-122):
     m <- lerp(m, g, 1-b1); v <- b2 v + (1-b2) g^2;

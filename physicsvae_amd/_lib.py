@@ -41,6 +41,7 @@ _SIGS = {
     "pvae_net_segment": (C.c_int, [C.POINTER(Config), C.c_int, C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int64)]),
     "pvae_workspace_bytes": (C.c_size_t, [C.POINTER(Config)]),
+    "pvae_workspace_offset": (C.c_int64, [C.POINTER(Config), C.c_int, C.c_int, C.c_int]),
     "pvae_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "pvae_destroy": (None, [_P]),
     "pvae_bind_arenas": (C.c_int, [_P, _P, _P, _P, _P]),

@@ -527,6 +527,27 @@ size_t pvae_workspace_bytes(const pvae_config* cfg) {
     return (size_t)make_workspace(L).total_floats * sizeof(float);
 }
 
+int64_t pvae_workspace_offset(const pvae_config* cfg, int kind, int net, int layer) {
+    if (!cfg) return fail(-1, "null cfg");
+    Layout L = make_layout(*cfg);
+    if (!L.ok) return fail(-1, "bad config: %s", L.why);
+    Workspace W = make_workspace(L);
+    if (kind >= 0 && kind <= 3) {
+        if (net < 0 || net >= PVAE_NUM_NETS) return fail(-1, "bad net id %d", net);
+        if (kind >= 2 && (layer < 0 || layer >= (int)L.net[net].layers.size())) return fail(-1, "bad layer %d", layer);
+    }
+    switch (kind) {
+        case 0: return W.net[net].in;
+        case 1: return W.net[net].d_in;
+        case 2: return W.net[net].act[layer];
+        case 3: return W.net[net].dz[layer];
+        case 4: return W.s2;
+        case 5: return W.act_t;
+        case 6: return W.eps;
+        default: return fail(-1, "bad kind %d", kind);
+    }
+}
+
 int pvae_create(const pvae_config* cfg, pvae_ctx** out) {
     if (!cfg || !out) return fail(-1, "null argument");
     Layout L = make_layout(*cfg);

@@ -210,10 +210,12 @@ struct AdamScalars {
 // torch.optim.Adam single-tensor update (amsgrad False, weight_decay 0), tm:119-122,143:
 //   m <- m + (g - m)(1 - b1) ; v <- v b2 + (1 - b2) g g ; p <- p - step_size * m / (sqrt(v)/bc2_sqrt + eps)
 __device__ inline void adam_update(float g, float& p, float& m, float& v, const AdamScalars& s) {
-    m = m + (g - m) * (1.0f - s.beta1);
-    v = v * s.beta2 + ((1.0f - s.beta2) * g) * g;
-    const float denom = sqrtf(v) / s.bc2_sqrt + s.eps;
-    p = p - s.step_size * (m / denom);
+    // every operation is pinned (no context-dependent fma contraction), so the fused
+    // epilogue and the flat multi-tensor kernel produce bit-identical parameters
+    m = __fmaf_rn(__fsub_rn(g, m), __fsub_rn(1.0f, s.beta1), m);
+    v = __fmaf_rn(v, s.beta2, __fmul_rn(__fmul_rn(__fsub_rn(1.0f, s.beta2), g), g));
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), s.bc2_sqrt), s.eps);
+    p = __fmaf_rn(-s.step_size, __fdiv_rn(m, denom), p);
 }
 
 __device__ inline void adam_update4(const v4f& g, v4f& p, v4f& m, v4f& v, const AdamScalars& s) {

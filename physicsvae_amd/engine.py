@@ -218,6 +218,19 @@ class HipEngine:
         return a_hat, s2, z
 
 
+    def panel(self, kind, net=0, layer=0):
+        """Workspace panel as a [Bp, width] view (inspection / tests).  kind: 'in', 'd_in',
+        'act', 'dz', 's2', 'act_t', 'eps'."""
+        kinds = {"in": 0, "d_in": 1, "act": 2, "dz": 3, "s2": 4, "act_t": 5, "eps": 6}
+        off = _lib.check(int(self.lib.pvae_workspace_offset(C.byref(self.cfg), kinds[kind], net, layer)))
+        bp = (self.max_batch + 31) // 32 * 32
+        lays = [l for l in self.layers if l["net"] == net]
+        pad64 = lambda v: (v + 63) // 64 * 64
+        width = {"in": lays[0]["ld"], "d_in": lays[0]["ld"], "act": lays[layer]["n_out_pad"],
+                 "dz": lays[layer]["n_out_pad"], "s2": pad64(self.arch.Db), "act_t": pad64(self.arch.Da),
+                 "eps": self.arch.Z}[kind]
+        return self.workspace[off: off + bp * width].view(bp, width)
+
     def net_forward(self, net, x):
         self._need_gpu()
         x = x.reshape(x.shape[0], -1).to(self.device, torch.float32).contiguous()

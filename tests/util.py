@@ -20,6 +20,7 @@ def make_trainer(arch, data, batch, m_world=2, device=None, eps_fn=None, lr_step
     pkl = os.path.join(td, "demo.pkl")
     R.write_demo(pkl, data)
     argv = ["--data_train", pkl, "--batch_size", str(batch), "--max_iter_world_model", str(m_world),
+            "--max_iter", str(max(m_world, 100)),
             "--latent_dim", str(arch["Z"]),
             "--TE_width", str(arch["te"][0]), "--TE_depth", str(arch["te"][1]),
             "--MD_width", str(arch["md"][0]), "--MD_depth", str(arch["md"][1]),
