@@ -80,8 +80,9 @@ typedef struct pvae_step_params {
     float kl_coeff;        /* vae_kl_coeff (beta)              */
     float s_rec_coeff;     /* world_model_s_rec_coeff          */
     float cycle_coeff;     /* vae_cycle_coeff (1e-3)           */
-    float lr;              /* learning rate of this epoch      */
-    float beta1, beta2, adam_eps;
+    double lr;             /* learning rate of this epoch (double: torch keeps these as   */
+    double beta1, beta2, adam_eps; /* Python floats; 1 - beta and the bias corrections are   */
+                           /* formed in double before rounding to fp32)               */
     int32_t adam_t[PVAE_NUM_NETS]; /* 1-based Adam step count per net for THIS update */
     int32_t global_rows;   /* rows of the global minibatch (= rows on 1 GPU); losses and
                               gradients are scaled by 1/global_rows so a sum all-reduce over

@@ -26,8 +26,8 @@ class LayerInfo(C.Structure):
 
 class StepParams(C.Structure):
     _fields_ = [("a_rec_coeff", C.c_float), ("kl_coeff", C.c_float), ("s_rec_coeff", C.c_float),
-                ("cycle_coeff", C.c_float), ("lr", C.c_float), ("beta1", C.c_float),
-                ("beta2", C.c_float), ("adam_eps", C.c_float), ("adam_t", C.c_int32 * 3),
+                ("cycle_coeff", C.c_float), ("lr", C.c_double), ("beta1", C.c_double),
+                ("beta2", C.c_double), ("adam_eps", C.c_double), ("adam_t", C.c_int32 * 3),
                 ("global_rows", C.c_int32), ("rng_seed", C.c_uint64), ("rng_offset", C.c_uint64)]
 
 

@@ -139,12 +139,7 @@ stage_batch_kernel(const float* __restrict__ states, const float* __restrict__ a
 
 __device__ inline float block_sum_256(float v) {
     __shared__ float red[4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    return block_sum_256(v, red);
 }
 
 // nn.MSELoss (tm:99) of pred vs target over rows x D, plus its gradient:
@@ -273,69 +268,8 @@ pad_copy_kernel(const float* __restrict__ src, int n, int rows, float* __restric
     }
 }
 
-// Bias gradients db[n] = sum_rows dZ[r][n] (autograd of nn.Linear bias) for up to 16 layers
-// in one launch, consumed by Adam in registers (fused) or stored to the gradient arena.
-struct BiasJob {
-    const float* dz;
-    int ld;            // = n_out_pad
-    float* b;          // params bias (fused) or grads bias (store)
-    float* m;
-    float* v;
-    int net;
-};
-struct BiasJobs {
-    BiasJob job[16];
-    int n;
-    AdamScalars s[PVAE_NUM_NETS];
-};
-
-__global__ void __launch_bounds__(256)
-bias_grad_kernel(BiasJobs jobs, int rows_pad, int fused) {
-    const BiasJob j = jobs.job[blockIdx.y];
-    const int c0 = blockIdx.x * 64;
-    if (c0 >= j.ld) return;
-    const int col = c0 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-    float acc = 0.f;
-    for (int r = part; r < rows_pad; r += 4) acc += j.dz[(size_t)r * j.ld + col];
-    __shared__ float red[4][64];
-    red[part][threadIdx.x & 63] = acc;
-    __syncthreads();
-    if (part == 0) {
-        const int t = threadIdx.x;
-        const float g = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-        if (fused) {
-            float p = j.b[col], m = j.m[col], v = j.v[col];
-            adam_update(g, p, m, v, jobs.s[j.net]);
-            j.b[col] = p; j.m[col] = m; j.v[col] = v;
-        } else {
-            j.b[col] = g;
-        }
-    }
-}
-
-// Fixed-order sum of the per-block partials -> {total, loss_a, loss_kl, loss_s, loss_cyc}
-// (tpv:430-435 weighting).
-struct LossFinal {
-    float scale[4];    // a, kl, s, cyc: 1/(B*Da), 1/B, 1/(B*Db), 1/(B*Db)
-    float coeff[4];
-    int active[4];
-    int nparts[4];
-};
-__global__ void finalize_loss_kernel(const float* __restrict__ partial, LossFinal f, float* __restrict__ out) {
-    if (threadIdx.x == 0) {
-        float total = 0.f;
-        for (int t = 0; t < 4; ++t) {
-            float s = 0.f;
-            if (f.active[t]) {
-                for (int i = 0; i < f.nparts[t]; ++i) s += partial[(t + 1) * kLossParts + i];
-                s *= f.scale[t];
-            }
-            out[1 + t] = s;
-            total += f.coeff[t] * s;
-        }
-        out[0] = total;
-    }
-}
+// Evaluation-only finalisation (training folds it into the last weight-gradient launch).
+__global__ void finalize_loss_kernel(LossFinal f) { finalize_loss_wave(f, threadIdx.x); }
 
 // Multi-tensor Adam over one contiguous arena segment (data-parallel path, after the
 // gradient all-reduce).  28 B/param of traffic: read p,g,m,v, write p,m,v.
@@ -360,14 +294,16 @@ adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __re
 static AdamScalars adam_scalars(const pvae_step_params* sp, int net) {
     // torch computes the bias corrections in Python floats (double): tm:119-122 -> torch/optim/adam.py
     const int t = sp->adam_t[net] > 0 ? sp->adam_t[net] : 1;
-    const double bc1 = 1.0 - std::pow((double)sp->beta1, t);
-    const double bc2 = 1.0 - std::pow((double)sp->beta2, t);
+    const double bc1 = 1.0 - std::pow(sp->beta1, t);
+    const double bc2 = 1.0 - std::pow(sp->beta2, t);
     AdamScalars s;
-    s.step_size = (float)((double)sp->lr / bc1);
+    s.step_size = (float)(sp->lr / bc1);
     s.bc2_sqrt = (float)std::sqrt(bc2);
-    s.beta1 = sp->beta1;
-    s.beta2 = sp->beta2;
-    s.eps = sp->adam_eps;
+    s.beta1 = (float)sp->beta1;
+    s.beta2 = (float)sp->beta2;
+    s.eps = (float)sp->adam_eps;
+    s.one_minus_beta1 = (float)(1.0 - sp->beta1);
+    s.one_minus_beta2 = (float)(1.0 - sp->beta2);
     return s;
 }
 
@@ -378,15 +314,28 @@ static int check_ready(const pvae_ctx* c, bool need_arenas) {
     return 0;
 }
 
-static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st) {
+struct FwdTail {              // what the output layer's epilogue does besides bias
+    const EpiMse* mse = nullptr;      // fused MSE loss + gradient
+    float* out2 = nullptr;            // or: copy the first n2 output columns to out2[:, off2:]
+    int ld2 = 0, off2 = 0, n2 = 0;
+};
+
+static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st, const FwdTail& tail = FwdTail()) {
     const NetLayout& N = c->L.net[n];
     const float* x = c->ws + c->W.net[n].in;
     int ldx = N.layers[0].ld;
     for (const Layer& l : N.layers) {
         float* out = c->ws + c->W.net[n].act[l.index];
         const int ps = g_prof.begin(0, 2.0 * c->staged_rows_f * l.n_in * l.n_out, st);
-        HIP_TRY(gemm_forward(x, ldx, c->params + l.w_off, l.ld, c->params + l.b_off, out, l.n_out_pad,
-                             rows_pad, l.n_out_pad, l.ld, l.last ? 0 : 1, st));
+        if (l.last && tail.mse) {
+            EpiMse e = *tail.mse;
+            e.out = out; e.ldo = l.n_out_pad; e.bias = c->params + l.b_off;
+            HIP_TRY(gemm_forward_epi(x, ldx, c->params + l.w_off, l.ld, rows_pad, l.n_out_pad, l.ld, e, st));
+        } else {
+            EpiBiasAct e{out, l.n_out_pad, c->params + l.b_off, l.last ? 0 : 1};
+            if (l.last && tail.out2) { e.out2 = tail.out2; e.ld2 = tail.ld2; e.off2 = tail.off2; e.n2 = tail.n2; }
+            HIP_TRY(gemm_forward_epi(x, ldx, c->params + l.w_off, l.ld, rows_pad, l.n_out_pad, l.ld, e, st));
+        }
         g_prof.end(ps, st);
         x = out;
         ldx = l.n_out_pad;
@@ -395,10 +344,11 @@ static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st) {
 }
 
 // dz[last] must be filled.  For each layer, last to first: input gradient (reads W), then
-// weight gradient (+Adam, writes W) -- in that order on one stream so W is never updated
-// before its last reader has run.
+// weight gradient (+bias gradient, +Adam, writes W) -- in that order on one stream so W is never
+// updated before its last reader has run.  `fold` (optional) is executed by the layer-0 launch.
 static int backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool input_grad,
-                        const pvae_step_params* sp, bool fused, hipStream_t st) {
+                        const pvae_step_params* sp, bool fused, hipStream_t st,
+                        const LossFinal* fold = nullptr) {
     const NetLayout& N = c->L.net[n];
     const NetWork& w = c->W.net[n];
     const AdamScalars as = adam_scalars(sp, n);
@@ -421,53 +371,22 @@ static int backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool input
                                rows_pad, l.ld, l.n_out_pad, st));
             g_prof.end(ps, st);
         }
-        const int pw = train ? g_prof.begin(2, fl, st) : -1;
-        if (train) {
-            if (fused) {
-                EpiGradAdam e{c->params + l.w_off, c->m + l.w_off, c->v + l.w_off, l.ld, as};
-                HIP_TRY(gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
-            } else {
-                EpiGradStore e{c->grads + l.w_off, l.ld};
-                HIP_TRY(gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
-            }
+        if (!train) continue;
+        const int pw = g_prof.begin(2, fl, st);
+        if (fused) {
+            EpiGradAdam e{c->params + l.w_off, c->m + l.w_off, c->v + l.w_off, l.ld, as};
+            e.b = c->params + l.b_off; e.bm = c->m + l.b_off; e.bv = c->v + l.b_off;
+            if (i == 0 && fold) e.loss = *fold;
+            HIP_TRY(gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
+        } else {
+            EpiGradStore e{c->grads + l.w_off, l.ld};
+            e.gb = c->grads + l.b_off;
+            if (i == 0 && fold) e.loss = *fold;
+            HIP_TRY(gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
         }
         g_prof.end(pw, st);
     }
     return 0;
-}
-
-static int bias_grads(pvae_ctx* c, int net_mask, int rows_pad, const pvae_step_params* sp, bool fused,
-                      hipStream_t st) {
-    BiasJobs jobs;
-    memset(&jobs, 0, sizeof(jobs));
-    int max_ld = 0;
-    auto flush = [&]() -> int {
-        if (jobs.n == 0) return 0;
-        hipLaunchKernelGGL(bias_grad_kernel, dim3(max_ld / 64, jobs.n), dim3(256), 0, st, jobs, rows_pad,
-                           fused ? 1 : 0);
-        HIP_TRY(hipGetLastError());
-        jobs.n = 0;
-        max_ld = 0;
-        return 0;
-    };
-    for (int n = 0; n < PVAE_NUM_NETS; ++n) {
-        jobs.s[n] = adam_scalars(sp, n);
-    }
-    for (int n = 0; n < PVAE_NUM_NETS; ++n) {
-        if (!(net_mask & (1 << n))) continue;
-        for (const Layer& l : c->L.net[n].layers) {
-            BiasJob& j = jobs.job[jobs.n++];
-            j.dz = c->ws + c->W.net[n].dz[l.index];
-            j.ld = l.n_out_pad;
-            j.b = (fused ? c->params : c->grads) + l.b_off;
-            j.m = c->m + l.b_off;
-            j.v = c->v + l.b_off;
-            j.net = n;
-            if (l.n_out_pad > max_ld) max_ld = l.n_out_pad;
-            if (jobs.n == 16) { int rc = flush(); if (rc) return rc; }
-        }
-    }
-    return flush();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -650,27 +569,36 @@ int pvae_forward_backward(pvae_ctx* c, int phase, int32_t rows, const pvae_step_
     const NetWork& wte = c->W.net[PVAE_NET_TE];
     const NetWork& wmd = c->W.net[PVAE_NET_MD];
     const NetWork& wwm = c->W.net[PVAE_NET_WM];
-    const int nparts = rows_pad < kLossParts ? rows_pad : kLossParts;
+    const int wm_out_pad = WM.layers.back().n_out_pad;
+    const int wm_tiles = (rows_pad / 32) * (wm_out_pad / 32);       // workgroups of the fused-MSE launch
+    if (wm_tiles > kLossParts) return fail(-1, "batch x dim_body too large for the loss partial buffer");
     LossFinal lf;
     memset(&lf, 0, sizeof(lf));
+    for (int t = 0; t < 4; ++t) lf.part[t] = part + (t + 1) * kLossParts;
+    lf.out = loss_out;
     lf.scale[0] = 1.0f / (Bg * Da); lf.scale[1] = 1.0f / Bg;
     lf.scale[2] = 1.0f / (Bg * Db); lf.scale[3] = 1.0f / (Bg * Db);
     lf.coeff[0] = sp->a_rec_coeff; lf.coeff[1] = sp->kl_coeff;
     lf.coeff[2] = sp->s_rec_coeff; lf.coeff[3] = sp->cycle_coeff;
 
+    // world-model output layer fused with MSE(s2, .) and its gradient
+    EpiMse mse;
+    memset(&mse, 0, sizeof(mse));
+    mse.target = w + c->W.s2; mse.ldt = pad64(Db);
+    mse.dz = backward ? w + wwm.dz.back() : nullptr; mse.ldz = wm_out_pad;
+    mse.rows = rows; mse.D = Db;
+    FwdTail wm_tail;
+    wm_tail.mse = &mse;
+
     if (phase == PVAE_PHASE_WORLD) {
         // tpv:411-414: L = s_rec * MSE(s2, WM(s1, a_gt)); only the world model learns (tpv:326-329)
-        if ((rc = forward_net(c, PVAE_NET_WM, rows_pad, st))) return rc;
-        const float gs = sp->s_rec_coeff * 2.0f / (Bg * Db);
-        hipLaunchKernelGGL(mse_grad_kernel, dim3(nparts), dim3(256), 0, st, w + wwm.act.back(),
-                           WM.layers.back().n_out_pad, w + c->W.s2, pad64(Db), backward ? w + wwm.dz.back() : nullptr,
-                           WM.layers.back().n_out_pad, rows, rows_pad, Db, gs, (const float*)nullptr, 0, 0,
-                           part + 3 * kLossParts);
-        HIP_TRY(hipGetLastError());
-        lf.active[2] = 1; lf.nparts[2] = nparts;
+        mse.grad_scale = sp->s_rec_coeff * 2.0f / (Bg * Db);
+        mse.partial = part + 3 * kLossParts;
+        lf.nparts[2] = wm_tiles;
+        if ((rc = forward_net(c, PVAE_NET_WM, rows_pad, st, wm_tail))) return rc;
         if (backward) {
-            if ((rc = backward_net(c, PVAE_NET_WM, rows_pad, true, false, sp, fused, st))) return rc;
-            if ((rc = bias_grads(c, 1 << PVAE_NET_WM, rows_pad, sp, fused, st))) return rc;
+            if ((rc = backward_net(c, PVAE_NET_WM, rows_pad, true, false, sp, fused, st, loss_out ? &lf : nullptr)))
+                return rc;
         }
     } else if (phase == PVAE_PHASE_JOINT) {
         if (sp->s_rec_coeff != 0.0f)
@@ -678,56 +606,51 @@ int pvae_forward_backward(pvae_ctx* c, int phase, int32_t rows, const pvae_step_
                             "(reference default is 0.0, tpv:284)");
         // forward: TE -> sampler -> MD -> WM (rmt:742-771)
         if ((rc = forward_net(c, PVAE_NET_TE, rows_pad, st))) return rc;
-        const int gridz = (rows_pad * Z + 255) / 256 < kLossParts ? (rows_pad * Z + 255) / 256 : kLossParts;
+        const int gridz = (rows_pad * Z + 255) / 256 < 64 ? (rows_pad * Z + 255) / 256 : 64;
         hipLaunchKernelGGL(reparam_kernel, dim3(gridz), dim3(256), 0, st, w + wte.act.back(),
                            TE.layers.back().n_out_pad, eps, w + c->W.eps, w + wmd.in, MD.layers[0].ld, Db, Z, rows,
                            rows_pad, 1, (unsigned long long)sp->rng_seed, (unsigned long long)sp->rng_offset,
                            part + 2 * kLossParts);
         HIP_TRY(hipGetLastError());
-        lf.active[1] = sp->kl_coeff > 0.0f && sp->a_rec_coeff > 0.0f;   // tpv:381-384 nesting
-        lf.nparts[1] = gridz;
-        if ((rc = forward_net(c, PVAE_NET_MD, rows_pad, st))) return rc;
-        hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, w + wmd.act.back(),
-                           MD.layers.back().n_out_pad, 0, w + wwm.in, WM.layers[0].ld, Db, rows_pad, Da);
-        HIP_TRY(hipGetLastError());
-        if ((rc = forward_net(c, PVAE_NET_WM, rows_pad, st))) return rc;
-        // cycle loss (tpv:417-419) and its gradient into the frozen world model
-        const float gc = sp->cycle_coeff * 2.0f / (Bg * Db);
-        hipLaunchKernelGGL(mse_grad_kernel, dim3(nparts), dim3(256), 0, st, w + wwm.act.back(),
-                           WM.layers.back().n_out_pad, w + c->W.s2, pad64(Db), backward ? w + wwm.dz.back() : nullptr,
-                           WM.layers.back().n_out_pad, rows, rows_pad, Db, gc, (const float*)nullptr, 0, 0,
-                           part + 4 * kLossParts);
-        HIP_TRY(hipGetLastError());
-        lf.active[3] = sp->cycle_coeff > 0.0f; lf.nparts[3] = nparts;
+        if (sp->kl_coeff > 0.0f && sp->a_rec_coeff > 0.0f) lf.nparts[1] = gridz;      // tpv:381-384 nesting
+        FwdTail md_tail;                       // a_hat also lands in the action columns of the WM input
+        md_tail.out2 = w + wwm.in; md_tail.ld2 = WM.layers[0].ld; md_tail.off2 = Db; md_tail.n2 = Da;
+        if ((rc = forward_net(c, PVAE_NET_MD, rows_pad, st, md_tail))) return rc;
+        // cycle loss (tpv:417-419) fused into the world model's output layer
+        mse.grad_scale = sp->cycle_coeff * 2.0f / (Bg * Db);
+        mse.partial = part + 4 * kLossParts;
+        if (sp->cycle_coeff > 0.0f) lf.nparts[3] = wm_tiles;
+        if ((rc = forward_net(c, PVAE_NET_WM, rows_pad, st, wm_tail))) return rc;
         const bool cyc_grad = backward && sp->cycle_coeff > 0.0f;
-        if (cyc_grad) {
+        if (cyc_grad) {                        // gradient through the frozen world model (dgrad only)
             if ((rc = backward_net(c, PVAE_NET_WM, rows_pad, false, true, sp, fused, st))) return rc;
         }
         // action reconstruction (tpv:381-382) + gradient arriving through the world model
         const float ga = sp->a_rec_coeff * 2.0f / (Bg * Da);
+        const int nparts = rows_pad < 64 ? rows_pad : 64;
         hipLaunchKernelGGL(mse_grad_kernel, dim3(nparts), dim3(256), 0, st, w + wmd.act.back(),
                            MD.layers.back().n_out_pad, w + c->W.act_t, pad64(Da), backward ? w + wmd.dz.back() : nullptr,
                            MD.layers.back().n_out_pad, rows, rows_pad, Da, ga,
                            cyc_grad ? w + wwm.d_in : (const float*)nullptr, WM.layers[0].ld, Db,
                            part + 1 * kLossParts);
         HIP_TRY(hipGetLastError());
-        lf.active[0] = sp->a_rec_coeff > 0.0f; lf.nparts[0] = nparts;
+        if (sp->a_rec_coeff > 0.0f) lf.nparts[0] = nparts;
         if (backward) {
             if ((rc = backward_net(c, PVAE_NET_MD, rows_pad, true, true, sp, fused, st))) return rc;
-            const float kls = lf.active[1] ? sp->kl_coeff / Bg : 0.0f;
+            const float kls = lf.nparts[1] ? sp->kl_coeff / Bg : 0.0f;
             const int tot = rows_pad * TE.layers.back().n_out_pad;
             hipLaunchKernelGGL(reparam_bwd_kernel, dim3((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256), dim3(256), 0,
                                st, w + wmd.d_in, MD.layers[0].ld, Db, w + wte.act.back(), TE.layers.back().n_out_pad,
                                w + c->W.eps, w + wte.dz.back(), TE.layers.back().n_out_pad, rows, rows_pad, Z, kls);
             HIP_TRY(hipGetLastError());
-            if ((rc = backward_net(c, PVAE_NET_TE, rows_pad, true, false, sp, fused, st))) return rc;
-            if ((rc = bias_grads(c, (1 << PVAE_NET_TE) | (1 << PVAE_NET_MD), rows_pad, sp, fused, st))) return rc;
+            if ((rc = backward_net(c, PVAE_NET_TE, rows_pad, true, false, sp, fused, st, loss_out ? &lf : nullptr)))
+                return rc;
         }
     } else {
         return fail(-1, "unknown phase %d", phase);
     }
-    if (loss_out) {
-        hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(64), 0, st, part, lf, loss_out);
+    if (loss_out && !backward) {
+        hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(64), 0, st, lf);
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -793,13 +716,15 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
     const NetLayout& MD = c->L.net[PVAE_NET_MD];
     const NetLayout& WM = c->L.net[PVAE_NET_WM];
     if ((rc = forward_net(c, PVAE_NET_TE, rows_pad, st))) return rc;
-    const int gridz = (rows_pad * Z + 255) / 256 < kLossParts ? (rows_pad * Z + 255) / 256 : kLossParts;
+    const int gridz = (rows_pad * Z + 255) / 256 < 64 ? (rows_pad * Z + 255) / 256 : 64;
     hipLaunchKernelGGL(reparam_kernel, dim3(gridz), dim3(256), 0, st, w + c->W.net[PVAE_NET_TE].act.back(),
                        TE.layers.back().n_out_pad, eps, w + c->W.eps, w + c->W.net[PVAE_NET_MD].in, MD.layers[0].ld, Db,
                        Z, rows, rows_pad, noise ? 1 : 0, (unsigned long long)rng_seed, (unsigned long long)rng_offset,
                        (float*)nullptr);
     HIP_TRY(hipGetLastError());
-    if ((rc = forward_net(c, PVAE_NET_MD, rows_pad, st))) return rc;
+    FwdTail md_tail;
+    md_tail.out2 = w + c->W.net[PVAE_NET_WM].in; md_tail.ld2 = WM.layers[0].ld; md_tail.off2 = Db; md_tail.n2 = Da;
+    if ((rc = forward_net(c, PVAE_NET_MD, rows_pad, st, md_tail))) return rc;
     hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, w + c->W.net[PVAE_NET_MD].act.back(),
                        MD.layers.back().n_out_pad, 0, a_hat, Da, 0, rows, Da);
     HIP_TRY(hipGetLastError());
@@ -809,9 +734,6 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
         HIP_TRY(hipGetLastError());
     }
     if (s2_hat) {
-        hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, w + c->W.net[PVAE_NET_MD].act.back(),
-                           MD.layers.back().n_out_pad, 0, w + c->W.net[PVAE_NET_WM].in, WM.layers[0].ld, Db, rows_pad, Da);
-        HIP_TRY(hipGetLastError());
         if ((rc = forward_net(c, PVAE_NET_WM, rows_pad, st))) return rc;
         hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, w + c->W.net[PVAE_NET_WM].act.back(),
                            WM.layers.back().n_out_pad, 0, s2_hat, Db, 0, rows, Db);
@@ -852,7 +774,7 @@ int pvae_reparam(pvae_ctx* c, const float* mu_logvar, int32_t rows, const float*
     hipStream_t st = (hipStream_t)stream;
     const int Db = c->L.cfg.dim_body, Z = c->L.cfg.latent;
     const int ld_md = c->L.net[PVAE_NET_MD].layers[0].ld;
-    const int gridz = (rows * Z + 255) / 256 < kLossParts ? (rows * Z + 255) / 256 : kLossParts;
+    const int gridz = (rows * Z + 255) / 256 < 64 ? (rows * Z + 255) / 256 : 64;
     c->staged_rows = 0;
     hipLaunchKernelGGL(reparam_kernel, dim3(gridz), dim3(256), 0, st, mu_logvar, 2 * Z, eps, c->ws + c->W.eps,
                        c->ws + c->W.net[PVAE_NET_MD].in, ld_md, Db, Z, rows, rows, noise ? 1 : 0,

@@ -1,5 +1,5 @@
-// pvae_gemm.h -- fp32 MFMA tile kernel for the three contractions of an MLP layer at
-// minibatch scale (M = 32..512 rows).  gfx950 only.
+// pvae_gemm.h -- fp32 MFMA kernels for the three contractions of an MLP layer at minibatch
+// scale (M = 32..512 rows).  gfx950 only.
 //
 //   C[q][p] = sum_k Q(q,k) * P(p,k)            C row-major, p contiguous
 //
@@ -7,175 +7,518 @@
 //   dgrad    : q = batch row, p = in feature,  k = out feature  Q = dZ (k-contig)  P = W  (p-contig)
 //   wgrad    : q = out feat,  p = in feature,  k = batch row    Q = dZ (q-contig)  P = X  (p-contig)
 //
-// An operand is "ROW" when its reduction index is the contiguous one in memory and "COL"
-// when its output index is.  Either way tiles are fetched with full-line float4 loads along
-// the contiguous index and kept in that orientation in LDS, so no transposes are needed:
-//   ROW tile  [rows][BK+4]  -> fragment = one ds_read_b64  (2 k-values, conflict-free)
-//   COL tile  [BK][cols+8]  -> fragment = two ds_read_b32  (conflict-free)
-// One 8-deep k-chunk feeds two v_mfma_f32_16x16x4_f32: lane (i = l&15, h = l>>4) supplies
-// k = kk + 2h + s for step s in {0,1}; the k-order inside a chunk is a permutation, which a
-// sum does not care about as long as both operands use the same one.
+// An operand is "ROW" when its reduction index is the contiguous one in memory and "COL" when
+// its output index is.  Tiles are fetched with full-line 16-byte accesses along the contiguous
+// index and kept in that orientation in LDS (no transposes); the MFMA is
+// v_mfma_f32_16x16x4_f32 (exact fp32 fma chain, 157 TFLOP/s peak).  The MFMA "A" slot takes the P
+// fragment and the "B" slot the Q fragment, so D = C^T-tile: each lane ends up with consecutive
+// p of one q -> float4 epilogue loads/stores.
 //
-// The MFMA "A" slot takes the P fragment and the "B" slot the Q fragment, so D = C^T-tile:
-// each lane ends up with 4 *consecutive p* of one q  ->  float4 epilogue loads/stores.
+// Block -> tile mapping is XCD-aware: block b runs on XCD b%8 (observed dispatch order, used for
+// L2 locality only); each XCD is given a contiguous range of p-tiles and all q-tiles of it, so
+// the P panel it streams is fetched once per XCD and the (small) Q operand stays in that L2.
 //
-// 256 threads = 4 waves in a 2x2 arrangement; each wave owns (BQ/2)x(BP/2) of the tile as
-// TQ x TP MFMA tiles.  With a 1x1 wave tile two accumulators alternate over k so the
-// dependent-issue latency of the 16x16x4 MFMA (40 cycles vs 32 issue) is covered.
-//
-// Pipeline: global->register prefetch of tile t+1 is issued before the MFMAs of tile t, the
-// registers are written to the other LDS stage afterwards, one barrier per k-tile.
-//
-// Block -> tile mapping is XCD-aware: block b runs on XCD b%8 (observed dispatch order,
-// used for L2 locality only); each XCD is given a contiguous range of p-tiles and all
-// q-tiles of it, so the P panel it streams is fetched once per XCD and the (small) Q
-// operand stays resident in that XCD's L2.
+// What bounds these kernels (tools/gemm_ablate.hip on MI355X, profiles/): a 32x32 output tile
+// per CU is 8 flop per operand byte, and the per-CU load path sustains ~27 B/clk for this
+// pattern (~14 TB/s over 256 CUs, L2-resident): 250-330 ns per 16 KB k-tile against 213 ns of
+// MFMA work, so forward/dgrad are load-path bound at B = 256; wgrad (64x64 tiles, 16 flop/B)
+// is matrix-pipe bound in its main loop and HBM-bound in its Adam epilogue.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 namespace pvae {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int BX, int BK, bool ROW>
-struct OperandTile {
-    static constexpr int kContig = ROW ? BK : BX;       // floats per tile row in memory order
-    static constexpr int kRows = ROW ? BX : BK;
-    static constexpr int kStride = ROW ? (BK + 4) : (BX + 8);
-    static constexpr int kFloats = kRows * kStride;
-    static constexpr int kVecs = kRows * kContig / 4;   // float4 per tile
-    static constexpr int kPerThread = kVecs / 256;
-    static_assert(kVecs % 256 == 0, "tile must split evenly over 256 threads");
+// ---------------------------------------------------------------------------------------
+// Ring-pipelined kernels (the production path).
+//
+// Two measured facts shape them (profiles/r01_*):
+//  (1) one k-tile in flight per CU leaves the loop at the mercy of the L2 / Infinity-Cache
+//      round trip -> operand tiles travel by LDS-DMA (global_load_lds_dwordx4, no VGPR
+//      staging) into a ring of STAGES slots, STAGES-1 k-tiles in flight per CU behind counted
+//      `s_waitcnt vmcnt(N)` and ONE raw s_barrier per k-tile;
+//  (2) with one wave per SIMD, ds_read_b32/b64 issue at ~1/5 of the LDS rate (~40 cycles per
+//      wave-instruction, MI355X_MICROARCH.md LDS table) while ds_read_b128 runs at full rate
+//      -> fragments are fetched with as few, as wide DS reads as the MFMA layout allows:
+//        * k-contiguous ("ROW") operands: ONE ds_read_b128 = 4 k-values of one row per lane;
+//          lane (i, h) holds k = 16c + 4h + s, MFMA step s takes element s (the k order
+//          inside a 16-chunk is a permutation, shared by both operands);
+//        * output-contiguous ("COL") operands: ds_read_b64 = 2 consecutive outputs of one k
+//          per lane, feeding TWO interleaved MFMA tiles (tile u owns outputs 2i + u);
+//        * the 4 waves of a workgroup split K instead of the tile (forward / dgrad): every
+//          wave owns the whole 32x32 output as 2x2 MFMA tiles, so each fragment feeds two
+//          MFMAs; partial tiles are summed through LDS in a fixed order at the end.
+//
+// The DMA writes LDS lane-linearly (wave-uniform base + lane*16 B), so tiles are unpadded and
+// bank conflicts are removed by permuting the per-lane SOURCE address and, identically, the
+// fragment read address (involutions):
+//   ROW tile [32][64]   b128 reads : 16-byte chunk ^= row & 15
+//   COL tile [64 k][32] b64 reads  : LDS row = k ^ ((k >> 2) & 1)   (rows k, k+4 of one
+//                                    32-lane group land in different bank halves)
+//   COL tile [32 k][64] b64 reads  : chunk ^= (row & 1) << 3        (rows k, k+1 likewise)
+// ---------------------------------------------------------------------------------------
+template <int N>
+__device__ inline void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
-    // x0: tile origin along the operand's output index; k0: along the reduction index
-    __device__ static inline void load(const float* __restrict__ g, int ld, int x0, int k0, int tid,
-                                       v4f (&r)[kPerThread]) {
-#pragma unroll
-        for (int u = 0; u < kPerThread; ++u) {
-            const int v = tid + 256 * u;
-            const int row = v / (kContig / 4);
-            const int c4 = v % (kContig / 4);
-            const size_t off = ROW ? ((size_t)(x0 + row) * ld + k0 + c4 * 4)
-                                   : ((size_t)(k0 + row) * ld + x0 + c4 * 4);
-            r[u] = *reinterpret_cast<const v4f*>(g + off);
-        }
-    }
-    __device__ static inline void store(float* s, int tid, const v4f (&r)[kPerThread]) {
-#pragma unroll
-        for (int u = 0; u < kPerThread; ++u) {
-            const int v = tid + 256 * u;
-            const int row = v / (kContig / 4);
-            const int c4 = v % (kContig / 4);
-            *reinterpret_cast<v4f*>(s + row * kStride + c4 * 4) = r[u];
-        }
-    }
-    // fragment for the 16 outputs starting at x (tile-local), k-chunk kk, lane (i,h)
-    __device__ static inline v2f frag(const float* s, int x, int kk, int i, int h) {
-        if (ROW) {
-            return *reinterpret_cast<const v2f*>(s + (x + i) * kStride + kk + 2 * h);
-        } else {
-            v2f f;
-            f.x = s[(kk + 2 * h) * kStride + x + i];
-            f.y = s[(kk + 2 * h + 1) * kStride + x + i];
-            return f;
-        }
-    }
-};
+__device__ inline void lds_dma16(const float* src, float* dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+}
 
-template <int BQ, int BP, int BK, bool Q_ROW, bool P_ROW, class Epi>
+template <int STAGES, int G>
+__device__ inline void wait_tile_landed(int younger_in_flight) {
+    // tile t of this wave has landed once at most `younger_in_flight` tiles (G DMA instructions
+    // each) issued after it are still outstanding
+    switch (younger_in_flight) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<(STAGES > 2 ? 1 : 0) * G>(); break;
+        case 2: wait_vmcnt<(STAGES > 3 ? 2 : 0) * G>(); break;
+        case 3: wait_vmcnt<(STAGES > 4 ? 3 : 0) * G>(); break;
+        case 4: wait_vmcnt<(STAGES > 5 ? 4 : 0) * G>(); break;
+        case 5: wait_vmcnt<(STAGES > 6 ? 5 : 0) * G>(); break;
+        default: wait_vmcnt<(STAGES > 7 ? 6 : 0) * G>(); break;
+    }
+}
+
+// ---- forward / dgrad: C[32 q][32 p] per workgroup, BK = 64, waves split K ------------------
+//   Q is always ROW (X or dZ, k-contiguous).  P_ROW: W[p][k] (forward);  !P_ROW: W[k][p] (dgrad).
+// ABL (tools/gemm_ablate.hip only; 0 in production): 1 = no DMA refill in the loop, 2 = no LDS
+// fragment reads, 4 = no MFMA, 8 = no barrier / vmcnt wait.
+template <bool P_ROW, int STAGES, class Epi, int ABL = 0>
 __global__ void __launch_bounds__(256)
-gemm_tile_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ P, int ldp, int K,
-                 int tiles_q, int tiles_p, int p_per_xcd, Epi epi) {
-    using QT = OperandTile<BQ, BK, Q_ROW>;
-    using PT = OperandTile<BP, BK, P_ROW>;
-    constexpr int TQ = BQ / 32, TP = BP / 32;
-    constexpr int NACC = (TQ * TP == 1) ? 2 : 1;
+gemm_splitk_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ P, int ldp, int K,
+                   int tiles_q, int tiles_p, int p_per_xcd, Epi epi) {
+    constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, G = 4;
+    static_assert((STAGES - 2) * G <= 63, "vmcnt is a 6-bit counter");
+    static_assert(STAGES * kStage >= 4 * 32 * 36, "ring must hold the split-K reduction buffer");
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3;
     const int tile_p = xcd * p_per_xcd + loc / tiles_q;
     const int tile_q = loc % tiles_q;
     if (tile_p >= tiles_p) return;
-    const int q0 = tile_q * BQ, p0 = tile_p * BP;
+    const int q0 = tile_q * 32, p0 = tile_p * 32;
 
-    __shared__ __attribute__((aligned(16))) float lds[2 * (QT::kFloats + PT::kFloats)];
-    constexpr int kStage = QT::kFloats + PT::kFloats;     // one pipeline stage: [Q tile | P tile]
+    __shared__ __attribute__((aligned(16))) float lds[STAGES * kStage];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lh = lane >> 4;
-    const int wq = (wave >> 1) * (BQ / 2), wp = (wave & 1) * (BP / 2);
 
-    v4f acc[TQ][TP][NACC];
+    // per-lane DMA sources (k-tile 0); slot j = 16-byte position inside the 8 KB tile image
+    const float* sq[2];
+    const float* sp[2];
 #pragma unroll
-    for (int a = 0; a < TQ; ++a)
+    for (int u = 0; u < 2; ++u) {
+        const int j = (wave + 4 * u) * 64 + lane;
+        {
+            const int row = j >> 4, c = (j & 15) ^ (row & 15);
+            sq[u] = Q + (size_t)(q0 + row) * ldq + c * 4;
+        }
+        if (P_ROW) {
+            const int row = j >> 4, c = (j & 15) ^ (row & 15);
+            sp[u] = P + (size_t)(p0 + row) * ldp + c * 4;
+        } else {
+            const int r = j >> 3, k = r ^ ((r >> 2) & 1);
+            sp[u] = P + (size_t)k * ldp + p0 + (j & 7) * 4;
+        }
+    }
+    const size_t kstep_p = P_ROW ? (size_t)BK : (size_t)BK * ldp;
+    auto issue = [&](int t, float* slot) {
 #pragma unroll
-        for (int b = 0; b < TP; ++b)
-#pragma unroll
-            for (int c = 0; c < NACC; ++c) acc[a][b][c] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < 2; ++u) {
+            lds_dma16(sq[u] + (size_t)t * BK, slot + (wave + 4 * u) * 256);
+            lds_dma16(sp[u] + (size_t)t * kstep_p, slot + kTile + (wave + 4 * u) * 256);
+        }
+    };
 
-    v4f rq[QT::kPerThread], rp[PT::kPerThread];
+    v4f acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (floats) inside a stage
+    int oq[2], op[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int row = 16 * a + li;
+        oq[a] = row * 64 + (((4 * wave + lh) ^ (row & 15)) << 2);
+        op[a] = kTile + oq[a];                                   // P_ROW: same image shape
+    }
+    const int kq = 16 * wave + 4 * lh;                           // first k of this lane's 4-chunk
+
     const int nk = K / BK;
-
-    QT::load(Q, ldq, q0, 0, tid, rq);
-    PT::load(P, ldp, p0, 0, tid, rp);
-    QT::store(lds, tid, rq);
-    PT::store(lds + QT::kFloats, tid, rp);
-    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nk) issue(t, lds + t * kStage);
 
     for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) {
-            QT::load(Q, ldq, q0, (t + 1) * BK, tid, rq);
-            PT::load(P, ldp, p0, (t + 1) * BK, tid, rp);
+        const int rem = (nk - 1 - t) < (STAGES - 2) ? (nk - 1 - t) : (STAGES - 2);
+        if (!(ABL & 8)) {
+            wait_tile_landed<STAGES, G>((ABL & 1) ? 0 : rem);
+            __builtin_amdgcn_s_barrier();   // every wave's share of tile t landed; tile t-1 fully read
         }
-        const float* cq = lds + cur * kStage;
-        const float* cp = cq + QT::kFloats;
+        asm volatile("" ::: "memory");
+        const int tn = t + STAGES - 1;
+        if (!(ABL & 1) && tn < nk) issue(tn, lds + (tn % STAGES) * kStage);   // refill the slot tile t-1 vacated
+        const float* st = lds + (t % STAGES) * kStage;
+        v4f fq[2], fp[2];
+        v2f fc[4];
+        if (ABL & 2) {
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 8) {
-            v2f fq[TQ], fp[TP];
+            for (int a = 0; a < 2; ++a) { fq[a] = v4f{1.f, 2.f, 3.f, 4.f} * (float)lane; fp[a] = fq[a] + 1.f; }
 #pragma unroll
-            for (int a = 0; a < TQ; ++a) fq[a] = QT::frag(cq, wq + a * 16, kk, li, lh);
+            for (int s2 = 0; s2 < 4; ++s2) fc[s2] = v2f{1.f + s2, 2.f} * (float)lane;
+            asm volatile("" : "+v"(fq[0]), "+v"(fq[1]), "+v"(fp[0]), "+v"(fp[1]));
+        } else {
 #pragma unroll
-            for (int b = 0; b < TP; ++b) fp[b] = PT::frag(cp, wp + b * 16, kk, li, lh);
+        for (int a = 0; a < 2; ++a) fq[a] = *reinterpret_cast<const v4f*>(st + oq[a]);
+        if (P_ROW) {
 #pragma unroll
-            for (int a = 0; a < TQ; ++a)
+            for (int b = 0; b < 2; ++b) fp[b] = *reinterpret_cast<const v4f*>(st + op[b]);
+        } else {
 #pragma unroll
-                for (int b = 0; b < TP; ++b) {
-                    acc[a][b][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[b].x, fq[a].x,
-                                                                         acc[a][b][0], 0, 0, 0);
-                    acc[a][b][NACC - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                        fp[b].y, fq[a].y, acc[a][b][NACC - 1], 0, 0, 0);
+            for (int s2 = 0; s2 < 4; ++s2)       // global row k = kq + s2 lives in LDS row k ^ ((k>>2)&1) = k ^ (lh&1)
+                fc[s2] = *reinterpret_cast<const v2f*>(st + kTile + (((kq + s2) ^ (lh & 1)) * 32) + 2 * li);
+        }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float pv = P_ROW ? fp[b][s2] : fc[s2][b];
+                    if (ABL & 4) {
+                        acc[a][b][0] += pv * fq[a][s2];
+                    } else {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, fq[a][s2], acc[a][b], 0, 0, 0);
+                    }
                 }
-        }
-        if (t + 1 < nk) {
-            float* nq = lds + (cur ^ 1) * kStage;
-            QT::store(nq, tid, rq);
-            PT::store(nq + QT::kFloats, tid, rp);
-        }
-        __syncthreads();
     }
 
-    // D[i = p-local][j = q-local]: lane holds q = li, p = 4*lh + r (r = 0..3)
+    // split-K reduction through LDS (fixed order: wave 0..3), then the epilogue on float4s.
+    // D[i = 4*lh + r][j = li]: i indexes the P side, j the Q side.
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    constexpr int RS = 36;                                       // padded row stride of the partial tiles
+    float* red = lds + wave * (32 * RS);
 #pragma unroll
-    for (int a = 0; a < TQ; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < TP; ++b) {
-            v4f v = acc[a][b][0];
-            if (NACC == 2) v += acc[a][b][NACC - 1];
-            epi(q0 + wq + a * 16 + li, p0 + wp + b * 16 + 4 * lh, v);
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = 16 * a + li;
+                const int pl = P_ROW ? (16 * b + 4 * lh + r) : (8 * lh + 2 * r + b);
+                red[ql * RS + pl] = acc[a][b][r];
+            }
+    __syncthreads();
+    {
+        const int ql = tid >> 3, pl = (tid & 7) << 2;
+        v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (32 * RS) + ql * RS + pl);
+        epi(q0 + ql, p0 + pl, v);
+    }
+    epi.finish(lds, tile_q * tiles_p + tile_p, tid);
+}
+
+// ---- register-staged twin of gemm_splitk_kernel -------------------------------------------
+// Same LDS image and fragment reads, but tiles travel global -> VGPR (plain global_load_dwordx4,
+// D = 4 tiles = 64 VGPRs in flight per lane) -> ds_write_b128 into a 2-slot LDS ring.  The
+// ablation (tools/gemm_ablate.hip) prices an LDS-DMA instruction at ~150 issue cycles on the
+// wave that also feeds the matrix pipe; a plain load + ds_write_b128 pair is ~20.
+template <bool P_ROW, class Epi, int ABL = 0>
+__global__ void __launch_bounds__(256)
+gemm_splitk_reg_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ P, int ldp, int K,
+                       int tiles_q, int tiles_p, int p_per_xcd, Epi epi) {
+    constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, D = 4, S = 2;
+    static_assert(S * kStage >= 4 * 32 * 36, "ring must hold the split-K reduction buffer");
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int tile_p = xcd * p_per_xcd + loc / tiles_q;
+    const int tile_q = loc % tiles_q;
+    if (tile_p >= tiles_p) return;
+    const int q0 = tile_q * 32, p0 = tile_p * 32;
+
+    __shared__ __attribute__((aligned(16))) float lds[S * kStage];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15, lh = lane >> 4;
+
+    const float* sq[2];
+    const float* sp[2];
+    int slot_off[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = (wave + 4 * u) * 64 + lane;
+        slot_off[u] = j * 4;
+        {
+            const int row = j >> 4, c = (j & 15) ^ (row & 15);
+            sq[u] = Q + (size_t)(q0 + row) * ldq + c * 4;
         }
+        if (P_ROW) {
+            const int row = j >> 4, c = (j & 15) ^ (row & 15);
+            sp[u] = P + (size_t)(p0 + row) * ldp + c * 4;
+        } else {
+            const int r = j >> 3, k = r ^ ((r >> 2) & 1);
+            sp[u] = P + (size_t)k * ldp + p0 + (j & 7) * 4;
+        }
+    }
+    const size_t kstep_p = P_ROW ? (size_t)BK : (size_t)BK * ldp;
+
+    v4f rg[D][4];
+    auto gload = [&](int t, v4f(&r)[4]) {
+        r[0] = *reinterpret_cast<const v4f*>(sq[0] + (size_t)t * BK);
+        r[1] = *reinterpret_cast<const v4f*>(sp[0] + (size_t)t * kstep_p);
+        r[2] = *reinterpret_cast<const v4f*>(sq[1] + (size_t)t * BK);
+        r[3] = *reinterpret_cast<const v4f*>(sp[1] + (size_t)t * kstep_p);
+    };
+    auto lwrite = [&](float* slot, const v4f(&r)[4]) {
+        *reinterpret_cast<v4f*>(slot + slot_off[0]) = r[0];
+        *reinterpret_cast<v4f*>(slot + kTile + slot_off[0]) = r[1];
+        *reinterpret_cast<v4f*>(slot + slot_off[1]) = r[2];
+        *reinterpret_cast<v4f*>(slot + kTile + slot_off[1]) = r[3];
+    };
+
+    v4f acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    int oq[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int row = 16 * a + li;
+        oq[a] = row * 64 + (((4 * wave + lh) ^ (row & 15)) << 2);
+    }
+    const int kq = 16 * wave + 4 * lh;
+
+    const int nk = K / BK;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nk) gload(d, rg[d]);
+    lwrite(lds, rg[0]);
+    if (D < nk) gload(D, rg[0]);
+    __syncthreads();
+
+    for (int t0 = 0; t0 < nk; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int t = t0 + d;
+            if (t < nk) {
+                const float* st = lds + (t & 1) * kStage;
+                v4f fq[2], fp[2];
+                v2f fc[4];
+                if (ABL & 2) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) { fq[a] = v4f{1.f, 2.f, 3.f, 4.f} * (float)lane; fp[a] = fq[a] + 1.f; }
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) fc[s2] = v2f{1.f + s2, 2.f} * (float)lane;
+                    asm volatile("" : "+v"(fq[0]), "+v"(fq[1]), "+v"(fp[0]), "+v"(fp[1]));
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) fq[a] = *reinterpret_cast<const v4f*>(st + oq[a]);
+                    if (P_ROW) {
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) fp[b] = *reinterpret_cast<const v4f*>(st + kTile + oq[b]);
+                    } else {
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2)
+                            fc[s2] = *reinterpret_cast<const v2f*>(st + kTile + (((kq + s2) ^ (lh & 1)) * 32) + 2 * li);
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const float pv = P_ROW ? fp[b][s2] : fc[s2][b];
+                            if (ABL & 4) acc[a][b][0] += pv * fq[a][s2];
+                            else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, fq[a][s2], acc[a][b], 0, 0, 0);
+                        }
+                    if (s2 == 1 && !(ABL & 1) && t + 1 < nk) {
+                        // tile t+1 sits in register set (d+1)%D: park it in the other LDS slot and
+                        // refill the registers with tile t+1+D
+                        lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
+                        if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D]);
+                    }
+                }
+                if (!(ABL & 8)) __syncthreads();
+            }
+        }
+    }
+
+    constexpr int RS = 36;
+    float* red = lds + wave * (32 * RS);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = 16 * a + li;
+                const int pl = P_ROW ? (16 * b + 4 * lh + r) : (8 * lh + 2 * r + b);
+                red[ql * RS + pl] = acc[a][b][r];
+            }
+    __syncthreads();
+    {
+        const int ql = tid >> 3, pl = (tid & 7) << 2;
+        v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (32 * RS) + ql * RS + pl);
+        epi(q0 + ql, p0 + pl, v);
+    }
+    epi.finish(lds, tile_q * tiles_p + tile_p, tid);
+}
+
+// ---- wgrad: G[64 q][64 p] per workgroup, reduction over batch rows (BK = 32), both operands COL
+template <int STAGES, class Epi, int ABL = 0>
+__global__ void __launch_bounds__(256)
+gemm_wgrad_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ P, int ldp, int K,
+                  int tiles_q, int tiles_p, int p_per_xcd, Epi epi) {
+    constexpr int BK = 32, kTile = 32 * 64, kStage = 2 * kTile, G = 4;
+    static_assert((STAGES - 2) * G <= 63, "vmcnt is a 6-bit counter");
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int tile_p = xcd * p_per_xcd + loc / tiles_q;
+    const int tile_q = loc % tiles_q;
+    if (tile_p >= tiles_p) return;
+    const int q0 = tile_q * 64, p0 = tile_p * 64;
+
+    __shared__ __attribute__((aligned(16))) float lds[STAGES * kStage];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lh = lane >> 4;
+    const int wq = (wave >> 1) * 32, wp = (wave & 1) * 32;
+
+    const float* sq[2];
+    const float* sp[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = (wave + 4 * u) * 64 + lane;
+        const int row = j >> 4, c = (j & 15) ^ ((row & 1) << 3);
+        sq[u] = Q + (size_t)row * ldq + q0 + c * 4;
+        sp[u] = P + (size_t)row * ldp + p0 + c * 4;
+    }
+    auto issue = [&](int t, float* slot) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            lds_dma16(sq[u] + (size_t)t * BK * ldq, slot + (wave + 4 * u) * 256);
+            lds_dma16(sp[u] + (size_t)t * BK * ldp, slot + kTile + (wave + 4 * u) * 256);
+        }
+    };
+
+    v4f acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+    v2f bsum = v2f{0.f, 0.f};   // running column sums of the Q (dZ) fragments = bias gradient
+
+    // lane (li, lh) reads row k = kk + lh, outputs (w + 2*li, w + 2*li + 1)
+    const int sw = (lh & 1) << 3;                                // chunk swizzle of odd rows
+    const int cq = wq + 2 * li, cp = wp + 2 * li;
+    const int oq = lh * 64 + ((((cq >> 2) ^ sw)) << 2) + (cq & 3);
+    const int op = kTile + lh * 64 + ((((cp >> 2) ^ sw)) << 2) + (cp & 3);
+
+    const int nk = K / BK;
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nk) issue(t, lds + t * kStage);
+
+    for (int t = 0; t < nk; ++t) {
+        const int rem = (nk - 1 - t) < (STAGES - 2) ? (nk - 1 - t) : (STAGES - 2);
+        if (!(ABL & 8)) {
+            wait_tile_landed<STAGES, G>((ABL & 1) ? 0 : rem);
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("" ::: "memory");
+        const int tn = t + STAGES - 1;
+        if (!(ABL & 1) && tn < nk) issue(tn, lds + (tn % STAGES) * kStage);
+        const float* st = lds + (t % STAGES) * kStage;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            v2f fq, fp;
+            if (ABL & 2) {
+                fq = v2f{1.f, 2.f} * (float)(lane + kk);
+                fp = v2f{3.f, 4.f} * (float)(lane + kk);
+                asm volatile("" : "+v"(fq), "+v"(fp));
+            } else {
+                fq = *reinterpret_cast<const v2f*>(st + oq + kk * 64);
+                fp = *reinterpret_cast<const v2f*>(st + op + kk * 64);
+            }
+            bsum += fq;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (ABL & 4) {
+                        acc[a][b][0] += fp[b] * fq[a];
+                    } else {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[b], fq[a], acc[a][b], 0, 0, 0);
+                    }
+                }
+        }
+    }
+
+    // lane holds q = wq + 2*li + a ; p = wp + 8*lh + 2*r + b  -> two float4 per q-row
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int q = q0 + wq + 2 * li + a, p = p0 + wp + 8 * lh;
+        epi(q, p, v4f{acc[a][0][0], acc[a][1][0], acc[a][0][1], acc[a][1][1]});
+        epi(q, p + 4, v4f{acc[a][0][2], acc[a][1][2], acc[a][0][3], acc[a][1][3]});
+    }
+    // bias gradient db[q] = sum over batch rows of dZ[:, q] (autograd of nn.Linear's bias): the
+    // first p-tile's two q-halves (waves 0 and 2) own it; lanes lh = 0..3 hold k = lh (mod 4)
+    if (epi.has_bias() && tile_p == 0 && (wave & 1) == 0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float v = bsum[e];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lh == 0) epi.bias(q0 + wq + 2 * li + e, v);
+        }
+    }
+    if (epi.loss.out && bid == 0 && wave == 3) finalize_loss_wave(epi.loss, lane);
 }
 
 // ---------------------------------------------------------------------------------------
 // epilogues: (q, p, 4 consecutive p values)
 // ---------------------------------------------------------------------------------------
+__device__ inline float block_sum_256(float v, float* scratch) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+
 struct EpiBiasAct {           // forward layer: out = act(acc + bias)
     float* out;
     int ldo;
     const float* bias;        // may be null
     int relu;
+    float* out2 = nullptr;    // optional second destination for columns [0, n2): out2[q][off2 + p]
+    int ld2 = 0, off2 = 0, n2 = 0;   // (motor-decoder output -> action columns of the world-model input)
     __device__ inline void operator()(int q, int p, v4f v) const {
         if (bias) v += *reinterpret_cast<const v4f*>(bias + p);
         if (relu) {
@@ -183,6 +526,48 @@ struct EpiBiasAct {           // forward layer: out = act(acc + bias)
             v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         *reinterpret_cast<v4f*>(out + (size_t)q * ldo + p) = v;
+        if (out2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (p + e < n2) out2[(size_t)q * ld2 + off2 + p + e] = v[e];
+        }
+    }
+    __device__ inline void finish(float*, int, int) const {}
+};
+
+// Output layer fused with nn.MSELoss (tm:99) and its gradient (world-model MSE tpv:411-414,
+// cycle loss tpv:417-419): pred = acc + bias is stored, dz = grad_scale * (pred - target) for
+// valid rows/columns (zeros elsewhere, so padded tiles stay inert downstream), and the
+// workgroup's squared-error sum goes to partial[tile] (summed later in a fixed order).
+struct EpiMse {
+    float* out;
+    int ldo;
+    const float* bias;
+    const float* target;
+    int ldt;
+    float* dz;                // may be null (forward only)
+    int ldz;
+    int rows, D;
+    float grad_scale;
+    float* partial;
+    float sq = 0.f;
+    __device__ inline void operator()(int q, int p, v4f v) {
+        if (bias) v += *reinterpret_cast<const v4f*>(bias + p);
+        *reinterpret_cast<v4f*>(out + (size_t)q * ldo + p) = v;
+        const v4f t = *reinterpret_cast<const v4f*>(target + (size_t)q * ldt + p);
+        v4f g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool valid = q < rows && p + e < D;
+            const float d = v[e] - t[e];
+            if (valid) sq += d * d;
+            g[e] = valid ? grad_scale * d : 0.f;
+        }
+        if (dz) *reinterpret_cast<v4f*>(dz + (size_t)q * ldz + p) = g;
+    }
+    __device__ inline void finish(float* scratch, int tile, int tid) {
+        const float s = block_sum_256(sq, scratch);
+        if (tid == 0) partial[tile] = s;
     }
 };
 
@@ -199,12 +584,14 @@ struct EpiMask {              // input gradient: out = acc * (act > 0)
         }
         *reinterpret_cast<v4f*>(out + (size_t)q * ldo + p) = v;
     }
+    __device__ inline void finish(float*, int, int) const {}
 };
 
 struct AdamScalars {
     float step_size;          // lr / (1 - beta1^t)
     float bc2_sqrt;           // sqrt(1 - beta2^t)
     float beta1, beta2, eps;
+    float one_minus_beta1, one_minus_beta2;   // computed in double on the host, as torch does
 };
 
 // torch.optim.Adam single-tensor update (amsgrad False, weight_decay 0), tm:119-122,143:
@@ -212,8 +599,8 @@ struct AdamScalars {
 __device__ inline void adam_update(float g, float& p, float& m, float& v, const AdamScalars& s) {
     // every operation is pinned (no context-dependent fma contraction), so the fused
     // epilogue and the flat multi-tensor kernel produce bit-identical parameters
-    m = __fmaf_rn(__fsub_rn(g, m), __fsub_rn(1.0f, s.beta1), m);
-    v = __fmaf_rn(v, s.beta2, __fmul_rn(__fmul_rn(__fsub_rn(1.0f, s.beta2), g), g));
+    m = __fmaf_rn(__fsub_rn(g, m), s.one_minus_beta1, m);
+    v = __fmaf_rn(v, s.beta2, __fmul_rn(__fmul_rn(s.one_minus_beta2, g), g));
     const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), s.bc2_sqrt), s.eps);
     p = __fmaf_rn(-s.step_size, __fdiv_rn(m, denom), p);
 }
@@ -227,12 +614,41 @@ __device__ inline void adam_update4(const v4f& g, v4f& p, v4f& m, v4f& v, const 
     }
 }
 
+// Fixed-order sum of the per-workgroup loss partials -> {total, loss_a, loss_kl, loss_s,
+// loss_cyc} (tpv:430-435 weighting).  Runs in one wave: as the tail of the step's last
+// weight-gradient launch (training) or as its own tiny kernel (evaluation).
+struct LossFinal {
+    const float* part[4];     // per-term partial arrays (a, kl, s, cyc)
+    float* out;               // null = nothing to do
+    float scale[4];           // a, kl, s, cyc: 1/(B*Da), 1/B, 1/(B*Db), 1/(B*Db)
+    float coeff[4];
+    int nparts[4];            // 0 = term inactive
+};
+__device__ inline void finalize_loss_wave(const LossFinal& f, int lane) {
+    float total = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float s = 0.f;
+        for (int i = lane; i < f.nparts[t]; i += 64) s += f.part[t][i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        s *= f.scale[t];
+        if (lane == 0) f.out[1 + t] = s;
+        total += f.coeff[t] * s;
+    }
+    if (lane == 0) f.out[0] = total;
+}
+
 struct EpiGradStore {         // weight gradient -> gradient arena (data-parallel path)
     float* g;
     int ld;
+    float* gb = nullptr;      // bias gradient destination (null = none)
+    LossFinal loss{};
     __device__ inline void operator()(int q, int p, v4f v) const {
         *reinterpret_cast<v4f*>(g + (size_t)q * ld + p) = v;
     }
+    __device__ inline bool has_bias() const { return gb != nullptr; }
+    __device__ inline void bias(int q, float v) const { gb[q] = v; }
 };
 
 struct EpiGradAdam {          // weight gradient consumed in registers by Adam (1-GPU path)
@@ -241,6 +657,10 @@ struct EpiGradAdam {          // weight gradient consumed in registers by Adam (
     float* v;
     int ld;
     AdamScalars s;
+    float* b = nullptr;       // bias / its moments (null = none)
+    float* bm = nullptr;
+    float* bv = nullptr;
+    LossFinal loss{};
     __device__ inline void operator()(int q, int p, v4f g) const {
         const size_t o = (size_t)q * ld + p;
         v4f pw = *reinterpret_cast<v4f*>(w + o);
@@ -251,39 +671,80 @@ struct EpiGradAdam {          // weight gradient consumed in registers by Adam (
         *reinterpret_cast<v4f*>(m + o) = pm;
         *reinterpret_cast<v4f*>(v + o) = pv;
     }
+    __device__ inline bool has_bias() const { return b != nullptr; }
+    __device__ inline void bias(int q, float g) const {
+        float pb = b[q], pm = bm[q], pv = bv[q];
+        adam_update(g, pb, pm, pv, s);
+        b[q] = pb; bm[q] = pm; bv[q] = pv;
+    }
 };
 
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
-template <int BQ, int BP, int BK, bool Q_ROW, bool P_ROW, class Epi>
-inline hipError_t launch_gemm(const float* Q, int ldq, const float* P, int ldp, int rows_q, int cols_p,
-                              int K, const Epi& epi, hipStream_t st) {
-    const int tiles_q = rows_q / BQ, tiles_p = cols_p / BP;
-    const int p_per_xcd = (tiles_p + 7) / 8;
-    const int grid = 8 * p_per_xcd * tiles_q;
-    hipLaunchKernelGGL((gemm_tile_kernel<BQ, BP, BK, Q_ROW, P_ROW, Epi>), dim3(grid), dim3(256), 0, st,
-                       Q, ldq, P, ldp, K, tiles_q, tiles_p, p_per_xcd, epi);
-    return hipGetLastError();
+// Variant switch for A/B measurements (PVAE_GEMM): default "reg" = register-staged ring for
+// forward/dgrad (+ LDS-DMA ring for wgrad); "dma" = LDS-DMA ring everywhere.
+inline int gemm_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PVAE_GEMM");
+        v = (e && e[0] == 'd') ? 2 : 0;
+    }
+    return v;
+}
+constexpr int kRingStages = 8;
+
+struct GemmGrid {
+    int tiles_q, tiles_p, p_per_xcd, grid;
+};
+inline GemmGrid make_grid(int rows_q, int cols_p, int bq, int bp) {
+    GemmGrid g;
+    g.tiles_q = rows_q / bq;
+    g.tiles_p = cols_p / bp;
+    g.p_per_xcd = (g.tiles_p + 7) / 8;
+    g.grid = 8 * g.p_per_xcd * g.tiles_q;
+    return g;
 }
 
 // forward: out[M][N] = act(X[M][K] W[N][K]^T + b)
+template <class Epi>
+inline hipError_t gemm_forward_epi(const float* X, int ldx, const float* W, int ldw, int M, int N, int K,
+                                   const Epi& e, hipStream_t st) {
+    const GemmGrid g = make_grid(M, N, 32, 32);
+    if (gemm_variant() == 2)
+        hipLaunchKernelGGL((gemm_splitk_kernel<true, kRingStages, Epi>), dim3(g.grid), dim3(256), 0, st, X, ldx, W,
+                           ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd, e);
+    else
+        hipLaunchKernelGGL((gemm_splitk_reg_kernel<true, Epi>), dim3(g.grid), dim3(256), 0, st, X, ldx, W, ldw, K,
+                           g.tiles_q, g.tiles_p, g.p_per_xcd, e);
+    return hipGetLastError();
+}
 inline hipError_t gemm_forward(const float* X, int ldx, const float* W, int ldw, const float* bias,
                                float* out, int ldo, int M, int N, int K, int relu, hipStream_t st) {
     EpiBiasAct e{out, ldo, bias, relu};
-    return launch_gemm<32, 32, 64, true, true>(X, ldx, W, ldw, M, N, K, e, st);
+    return gemm_forward_epi(X, ldx, W, ldw, M, N, K, e, st);
 }
 // dgrad: dX[M][Kin] = (dZ[M][N] W[N][Kin]) .* (mask > 0)
 inline hipError_t gemm_dgrad(const float* dZ, int ldz, const float* W, int ldw, const float* mask,
                              int ldm, float* dX, int ldo, int M, int Kin, int N, hipStream_t st) {
-    EpiMask e{dX, ldo, mask, ldm};
-    return launch_gemm<32, 32, 64, true, false>(dZ, ldz, W, ldw, M, Kin, N, e, st);
+    const EpiMask e{dX, ldo, mask, ldm};
+    const GemmGrid g = make_grid(M, Kin, 32, 32);
+    if (gemm_variant() == 2)
+        hipLaunchKernelGGL((gemm_splitk_kernel<false, kRingStages, EpiMask>), dim3(g.grid), dim3(256), 0, st, dZ, ldz,
+                           W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd, e);
+    else
+        hipLaunchKernelGGL((gemm_splitk_reg_kernel<false, EpiMask>), dim3(g.grid), dim3(256), 0, st, dZ, ldz, W, ldw,
+                           N, g.tiles_q, g.tiles_p, g.p_per_xcd, e);
+    return hipGetLastError();
 }
-// wgrad: G[N][Kin] = dZ[M][N]^T X[M][Kin]
+// wgrad: G[N][Kin] = dZ[M][N]^T X[M][Kin]  (+ bias gradient, + optional loss finalisation)
 template <class Epi>
 inline hipError_t gemm_wgrad(const float* dZ, int ldz, const float* X, int ldx, int N, int Kin, int M,
                              const Epi& e, hipStream_t st) {
-    return launch_gemm<64, 64, 32, false, false>(dZ, ldz, X, ldx, N, Kin, M, e, st);
+    const GemmGrid g = make_grid(N, Kin, 64, 64);
+    hipLaunchKernelGGL((gemm_wgrad_kernel<kRingStages, Epi>), dim3(g.grid), dim3(256), 0, st, dZ, ldz, X, ldx, M,
+                       g.tiles_q, g.tiles_p, g.p_per_xcd, e);
+    return hipGetLastError();
 }
 
 }  // namespace pvae
