@@ -78,6 +78,7 @@ struct pvae_ctx {
     int64_t n_rows = 0, n_windows = 0;
     int staged_rows = 0;
     double staged_rows_f = 0;    // rows of the batch being processed (for the profiler's flop count)
+    bool pair_launch = true;     // PVAE_PAIR=0 launches every contraction on its own (A/B)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -343,48 +344,80 @@ static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st, const F
     return 0;
 }
 
-// dz[last] must be filled.  For each layer, last to first: input gradient (reads W), then
-// weight gradient (+bias gradient, +Adam, writes W) -- in that order on one stream so W is never
-// updated before its last reader has run.  `fold` (optional) is executed by the layer-0 launch.
+// dz[last] must be filled.  Layer by layer, last to first: the input gradient of layer i reads
+// W_i, then the weight gradient of layer i (+bias gradient, +Adam) may overwrite it.  When both
+// exist, dgrad_{i-1} (needs dz_{i-1}, W_{i-1}) and wgrad_i (needs dz_i, x_i; writes W_i) are
+// independent and go out as ONE horizontally fused launch:
+//     dgrad_L | dgrad_{L-1} + wgrad_L | ... | dgrad_1 + wgrad_2 | [dgrad_0] + wgrad_1 | wgrad_0
+// `fold` (optional) is executed by the layer-0 weight-gradient blocks.
 static int backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool input_grad,
                         const pvae_step_params* sp, bool fused, hipStream_t st,
                         const LossFinal* fold = nullptr) {
     const NetLayout& N = c->L.net[n];
     const NetWork& w = c->W.net[n];
     const AdamScalars as = adam_scalars(sp, n);
-    for (int i = (int)N.layers.size() - 1; i >= 0; --i) {
+    const int last = (int)N.layers.size() - 1;
+    const bool pair = train && c->pair_launch && !g_prof.on;
+
+    // dgrad of layer i: dz[i] (.) W_i -> dz[i-1] (masked) or d_in (i == 0, unmasked)
+    auto has_dgrad = [&](int i) { return i > 0 || input_grad; };
+    auto dgrad = [&](int i) -> int {
+        const Layer& l = N.layers[i];
+        const float* xin = i == 0 ? c->ws + w.in : c->ws + w.act[i - 1];
+        const int need = n == PVAE_NET_WM ? c->L.cfg.dim_action : c->L.cfg.latent;
+        const int ps = g_prof.begin(1, 2.0 * c->staged_rows_f * (i > 0 ? l.n_in : need) * l.n_out, st);
+        HIP_TRY(gemm_dgrad(c->ws + w.dz[i], l.n_out_pad, c->params + l.w_off, l.ld, i > 0 ? xin : nullptr, l.ld,
+                           i > 0 ? c->ws + w.dz[i - 1] : c->ws + w.d_in, l.ld, rows_pad, l.ld, l.n_out_pad, st));
+        g_prof.end(ps, st);
+        return 0;
+    };
+    // wgrad of layer i, optionally fused with the dgrad of layer j (j < 0: alone)
+    auto wgrad = [&](int i, int j) -> int {
         const Layer& l = N.layers[i];
         const float* dz = c->ws + w.dz[i];
         const float* xin = i == 0 ? c->ws + w.in : c->ws + w.act[i - 1];
-        const double fl = 2.0 * c->staged_rows_f * l.n_in * l.n_out;
-        if (i > 0) {
-            const int ps = g_prof.begin(1, fl, st);
-            HIP_TRY(gemm_dgrad(dz, l.n_out_pad, c->params + l.w_off, l.ld, xin, l.ld, c->ws + w.dz[i - 1],
-                               l.ld, rows_pad, l.ld, l.n_out_pad, st));
-            g_prof.end(ps, st);
-        } else if (input_grad) {
-            // only the columns that carry a gradient onward are algorithmically needed:
-            // [Db, Db+Da) of d(wm_in) or [Db, Db+Z) of d(md_in)  
-            const int need = n == PVAE_NET_WM ? c->L.cfg.dim_action : c->L.cfg.latent;
-            const int ps = g_prof.begin(1, 2.0 * c->staged_rows_f * need * l.n_out, st);
-            HIP_TRY(gemm_dgrad(dz, l.n_out_pad, c->params + l.w_off, l.ld, nullptr, 0, c->ws + w.d_in, l.ld,
-                               rows_pad, l.ld, l.n_out_pad, st));
-            g_prof.end(ps, st);
-        }
-        if (!train) continue;
-        const int pw = g_prof.begin(2, fl, st);
+        auto go = [&](auto e) -> int {
+            if (i == 0 && fold) e.loss = *fold;
+            if (j >= 0) {
+                const Layer& d = N.layers[j];
+                const float* dx_in = j == 0 ? c->ws + w.in : c->ws + w.act[j - 1];
+                HIP_TRY(gemm_bwd_pair(c->ws + w.dz[j], d.n_out_pad, c->params + d.w_off, d.ld, j > 0 ? dx_in : nullptr,
+                                      d.ld, j > 0 ? c->ws + w.dz[j - 1] : c->ws + w.d_in, d.ld, rows_pad, d.ld,
+                                      d.n_out_pad, dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
+            } else {
+                const int pw = g_prof.begin(2, 2.0 * c->staged_rows_f * l.n_in * l.n_out, st);
+                HIP_TRY(gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
+                g_prof.end(pw, st);
+            }
+            return 0;
+        };
         if (fused) {
             EpiGradAdam e{c->params + l.w_off, c->m + l.w_off, c->v + l.w_off, l.ld, as};
             e.b = c->params + l.b_off; e.bm = c->m + l.b_off; e.bv = c->v + l.b_off;
-            if (i == 0 && fold) e.loss = *fold;
-            HIP_TRY(gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
-        } else {
-            EpiGradStore e{c->grads + l.w_off, l.ld};
-            e.gb = c->grads + l.b_off;
-            if (i == 0 && fold) e.loss = *fold;
-            HIP_TRY(gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
+            return go(e);
         }
-        g_prof.end(pw, st);
+        EpiGradStore e{c->grads + l.w_off, l.ld};
+        e.gb = c->grads + l.b_off;
+        return go(e);
+    };
+
+    int rc;
+    if (!train) {
+        for (int i = last; i >= 0; --i)
+            if (has_dgrad(i) && (rc = dgrad(i))) return rc;
+        return 0;
+    }
+    if (!pair) {
+        for (int i = last; i >= 0; --i) {
+            if (has_dgrad(i) && (rc = dgrad(i))) return rc;
+            if ((rc = wgrad(i, -1))) return rc;
+        }
+        return 0;
+    }
+    if (has_dgrad(last) && (rc = dgrad(last))) return rc;
+    for (int i = last; i >= 0; --i) {
+        const int j = i - 1;                       // dgrad_{i-1} rides with wgrad_i
+        if ((rc = wgrad(i, (j >= 0 && has_dgrad(j)) ? j : -1))) return rc;
     }
     return 0;
 }
@@ -475,6 +508,8 @@ int pvae_create(const pvae_config* cfg, pvae_ctx** out) {
     if (!c) return fail(-3, "out of host memory");
     c->L = L;
     c->W = make_workspace(L);
+    const char* pv = getenv("PVAE_PAIR");
+    c->pair_launch = !(pv && pv[0] == '0');
     *out = c;
     return 0;
 }

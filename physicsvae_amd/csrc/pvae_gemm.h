@@ -237,21 +237,28 @@ gemm_splitk_kernel(const float* __restrict__ Q, int ldq, const float* __restrict
 // D = 4 tiles = 64 VGPRs in flight per lane) -> ds_write_b128 into a 2-slot LDS ring.  The
 // ablation (tools/gemm_ablate.hip) prices an LDS-DMA instruction at ~150 issue cycles on the
 // wave that also feeds the matrix pipe; a plain load + ds_write_b128 pair is ~20.
+struct GemmArgs {
+    const float* Q;
+    int ldq;
+    const float* P;
+    int ldp;
+    int K, tiles_q, tiles_p, p_per_xcd;
+};
+constexpr int kRegRingFloats = 2 * 2 * 32 * 64;      // 2 LDS slots x (Q tile + P tile) = 32 KB
+
 template <bool P_ROW, class Epi, int ABL = 0>
-__global__ void __launch_bounds__(256)
-gemm_splitk_reg_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ P, int ldp, int K,
-                       int tiles_q, int tiles_p, int p_per_xcd, Epi epi) {
+__device__ inline void splitk_reg_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
     constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, D = 4, S = 2;
     static_assert(S * kStage >= 4 * 32 * 36, "ring must hold the split-K reduction buffer");
+    const float* __restrict__ Q = ga.Q;
+    const float* __restrict__ P = ga.P;
+    const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
 
-    const int bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3;
-    const int tile_p = xcd * p_per_xcd + loc / tiles_q;
+    const int tile_p = xcd * ga.p_per_xcd + loc / tiles_q;
     const int tile_q = loc % tiles_q;
     if (tile_p >= tiles_p) return;
     const int q0 = tile_q * 32, p0 = tile_p * 32;
-
-    __shared__ __attribute__((aligned(16))) float lds[S * kStage];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -386,6 +393,13 @@ gemm_splitk_reg_kernel(const float* __restrict__ Q, int ldq, const float* __rest
     epi.finish(lds, tile_q * tiles_p + tile_p, tid);
 }
 
+template <bool P_ROW, class Epi, int ABL = 0>
+__global__ void __launch_bounds__(256)
+gemm_splitk_reg_kernel(GemmArgs ga, Epi epi) {
+    __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
+    splitk_reg_body<P_ROW, Epi, ABL>(lds, blockIdx.x, ga, epi);
+}
+
 // ---- wgrad: G[64 q][64 p] per workgroup, reduction over batch rows (BK = 32), both operands COL
 template <int STAGES, class Epi, int ABL = 0>
 __global__ void __launch_bounds__(256)
@@ -498,6 +512,153 @@ gemm_wgrad_kernel(const float* __restrict__ Q, int ldq, const float* __restrict_
         }
     }
     if (epi.loss.out && bid == 0 && wave == 3) finalize_loss_wave(epi.loss, lane);
+}
+
+// ---- register-staged twin of gemm_wgrad_kernel; the epilogue operands (Adam's p, m, v) are
+// fetched under the main loop ------------------------------------------------------------------
+template <class Epi, int ABL = 0>
+__device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
+    constexpr int BK = 32, kTile = 32 * 64, kStage = 2 * kTile, D = 4, S = 2;
+    static_assert(S * kStage == kRegRingFloats, "LDS budget");
+    const float* __restrict__ Q = ga.Q;
+    const float* __restrict__ P = ga.P;
+    const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
+
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int tile_p = xcd * ga.p_per_xcd + loc / tiles_q;
+    const int tile_q = loc % tiles_q;
+    if (tile_p >= tiles_p) return;
+    const int q0 = tile_q * 64, p0 = tile_p * 64;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15, lh = lane >> 4;
+    const int wq = (wave >> 1) * 32, wp = (wave & 1) * 32;
+
+    const float* sq[2];
+    const float* sp[2];
+    int slot_off[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = (wave + 4 * u) * 64 + lane;
+        slot_off[u] = j * 4;
+        const int row = j >> 4, c = (j & 15) ^ ((row & 1) << 3);
+        sq[u] = Q + (size_t)row * ldq + q0 + c * 4;
+        sp[u] = P + (size_t)row * ldp + p0 + c * 4;
+    }
+    v4f rg[D][4];
+    auto gload = [&](int t, v4f(&r)[4]) {
+        r[0] = *reinterpret_cast<const v4f*>(sq[0] + (size_t)t * BK * ldq);
+        r[1] = *reinterpret_cast<const v4f*>(sp[0] + (size_t)t * BK * ldp);
+        r[2] = *reinterpret_cast<const v4f*>(sq[1] + (size_t)t * BK * ldq);
+        r[3] = *reinterpret_cast<const v4f*>(sp[1] + (size_t)t * BK * ldp);
+    };
+    auto lwrite = [&](float* slot, const v4f(&r)[4]) {
+        *reinterpret_cast<v4f*>(slot + slot_off[0]) = r[0];
+        *reinterpret_cast<v4f*>(slot + kTile + slot_off[0]) = r[1];
+        *reinterpret_cast<v4f*>(slot + slot_off[1]) = r[2];
+        *reinterpret_cast<v4f*>(slot + kTile + slot_off[1]) = r[3];
+    };
+
+    v4f acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+    v2f bsum = v2f{0.f, 0.f};
+
+    const int sw = (lh & 1) << 3;
+    const int cq = wq + 2 * li, cp = wp + 2 * li;
+    const int oq = lh * 64 + ((((cq >> 2) ^ sw)) << 2) + (cq & 3);
+    const int op = kTile + lh * 64 + ((((cp >> 2) ^ sw)) << 2) + (cp & 3);
+
+    const int nk = K / BK;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nk) gload(d, rg[d]);
+    lwrite(lds, rg[0]);
+    if (D < nk) gload(D, rg[0]);
+    // epilogue operands: queued behind the first D tiles, they arrive while the loop runs
+    typename Epi::Pre pre[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        pre[a][0] = epi.load(q0 + wq + 2 * li + a, p0 + wp + 8 * lh);
+        pre[a][1] = epi.load(q0 + wq + 2 * li + a, p0 + wp + 8 * lh + 4);
+    }
+    __syncthreads();
+
+    for (int t0 = 0; t0 < nk; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int t = t0 + d;
+            if (t < nk) {
+                const float* st = lds + (t & 1) * kStage;
+#pragma unroll
+                for (int kk = 0; kk < BK; kk += 4) {
+                    v2f fq, fp;
+                    if (ABL & 2) {
+                        fq = v2f{1.f, 2.f} * (float)(lane + kk);
+                        fp = v2f{3.f, 4.f} * (float)(lane + kk);
+                        asm volatile("" : "+v"(fq), "+v"(fp));
+                    } else {
+                        fq = *reinterpret_cast<const v2f*>(st + oq + kk * 64);
+                        fp = *reinterpret_cast<const v2f*>(st + op + kk * 64);
+                    }
+                    bsum += fq;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            if (ABL & 4) acc[a][b][0] += fp[b] * fq[a];
+                            else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[b], fq[a], acc[a][b], 0, 0, 0);
+                        }
+                    if (kk == 12 && !(ABL & 1) && t + 1 < nk) {
+                        lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
+                        if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D]);
+                    }
+                }
+                if (!(ABL & 8)) __syncthreads();
+            }
+        }
+    }
+
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int q = q0 + wq + 2 * li + a, p = p0 + wp + 8 * lh;
+        epi.apply(q, p, v4f{acc[a][0][0], acc[a][1][0], acc[a][0][1], acc[a][1][1]}, pre[a][0]);
+        epi.apply(q, p + 4, v4f{acc[a][0][2], acc[a][1][2], acc[a][0][3], acc[a][1][3]}, pre[a][1]);
+    }
+    if (epi.has_bias() && tile_p == 0 && (wave & 1) == 0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float v = bsum[e];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lh == 0) epi.bias(q0 + wq + 2 * li + e, v);
+        }
+    }
+    if (epi.loss.out && bid == 0 && wave == 3) finalize_loss_wave(epi.loss, lane);
+}
+
+template <class Epi, int ABL = 0>
+__global__ void __launch_bounds__(256)
+gemm_wgrad_reg_kernel(GemmArgs ga, Epi epi) {
+    __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
+    wgrad_reg_body<Epi, ABL>(lds, blockIdx.x, ga, epi);
+}
+
+// Horizontal fusion of two independent backward contractions in ONE launch: blocks [0, nd) run
+// the input-gradient tiles of layer l-1, blocks [nd, nd + nw) the weight-gradient(+Adam) tiles of
+// layer l.  The dgrad blocks are dispatched first (one per CU), the wgrad blocks land beside
+// them (2 waves per SIMD), so one workgroup's load / Adam-traffic phases hide under the other's
+// MFMA phases, and a launch boundary disappears.
+template <class EpiD, class EpiW>
+__global__ void __launch_bounds__(256)
+bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew) {
+    __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
+    if ((int)blockIdx.x < nd) splitk_reg_body<false, EpiD>(lds, blockIdx.x, gd, ed);
+    else wgrad_reg_body<EpiW>(lds, blockIdx.x - nd, gw, ew);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -644,6 +805,9 @@ struct EpiGradStore {         // weight gradient -> gradient arena (data-paralle
     int ld;
     float* gb = nullptr;      // bias gradient destination (null = none)
     LossFinal loss{};
+    struct Pre {};
+    __device__ inline Pre load(int, int) const { return Pre{}; }
+    __device__ inline void apply(int q, int p, v4f v, const Pre&) const { (*this)(q, p, v); }
     __device__ inline void operator()(int q, int p, v4f v) const {
         *reinterpret_cast<v4f*>(g + (size_t)q * ld + p) = v;
     }
@@ -661,16 +825,22 @@ struct EpiGradAdam {          // weight gradient consumed in registers by Adam (
     float* bm = nullptr;
     float* bv = nullptr;
     LossFinal loss{};
-    __device__ inline void operator()(int q, int p, v4f g) const {
+    struct Pre { v4f w, m, v; };
+    // the Adam operands of a tile are fetched while the contraction runs (load) and consumed
+    // in registers afterwards (apply)
+    __device__ inline Pre load(int q, int p) const {
         const size_t o = (size_t)q * ld + p;
-        v4f pw = *reinterpret_cast<v4f*>(w + o);
-        v4f pm = *reinterpret_cast<v4f*>(m + o);
-        v4f pv = *reinterpret_cast<v4f*>(v + o);
-        adam_update4(g, pw, pm, pv, s);
-        *reinterpret_cast<v4f*>(w + o) = pw;
-        *reinterpret_cast<v4f*>(m + o) = pm;
-        *reinterpret_cast<v4f*>(v + o) = pv;
+        return Pre{*reinterpret_cast<const v4f*>(w + o), *reinterpret_cast<const v4f*>(m + o),
+                   *reinterpret_cast<const v4f*>(v + o)};
     }
+    __device__ inline void apply(int q, int p, v4f g, Pre pre) const {
+        const size_t o = (size_t)q * ld + p;
+        adam_update4(g, pre.w, pre.m, pre.v, s);
+        *reinterpret_cast<v4f*>(w + o) = pre.w;
+        *reinterpret_cast<v4f*>(m + o) = pre.m;
+        *reinterpret_cast<v4f*>(v + o) = pre.v;
+    }
+    __device__ inline void operator()(int q, int p, v4f g) const { apply(q, p, g, load(q, p)); }
     __device__ inline bool has_bias() const { return b != nullptr; }
     __device__ inline void bias(int q, float g) const {
         float pb = b[q], pm = bm[q], pv = bv[q];
@@ -715,8 +885,8 @@ inline hipError_t gemm_forward_epi(const float* X, int ldx, const float* W, int 
         hipLaunchKernelGGL((gemm_splitk_kernel<true, kRingStages, Epi>), dim3(g.grid), dim3(256), 0, st, X, ldx, W,
                            ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd, e);
     else
-        hipLaunchKernelGGL((gemm_splitk_reg_kernel<true, Epi>), dim3(g.grid), dim3(256), 0, st, X, ldx, W, ldw, K,
-                           g.tiles_q, g.tiles_p, g.p_per_xcd, e);
+        hipLaunchKernelGGL((gemm_splitk_reg_kernel<true, Epi>), dim3(g.grid), dim3(256), 0, st,
+                           GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
     return hipGetLastError();
 }
 inline hipError_t gemm_forward(const float* X, int ldx, const float* W, int ldw, const float* bias,
@@ -733,8 +903,8 @@ inline hipError_t gemm_dgrad(const float* dZ, int ldz, const float* W, int ldw, 
         hipLaunchKernelGGL((gemm_splitk_kernel<false, kRingStages, EpiMask>), dim3(g.grid), dim3(256), 0, st, dZ, ldz,
                            W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd, e);
     else
-        hipLaunchKernelGGL((gemm_splitk_reg_kernel<false, EpiMask>), dim3(g.grid), dim3(256), 0, st, dZ, ldz, W, ldw,
-                           N, g.tiles_q, g.tiles_p, g.p_per_xcd, e);
+        hipLaunchKernelGGL((gemm_splitk_reg_kernel<false, EpiMask>), dim3(g.grid), dim3(256), 0, st,
+                           GemmArgs{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
     return hipGetLastError();
 }
 // wgrad: G[N][Kin] = dZ[M][N]^T X[M][Kin]  (+ bias gradient, + optional loss finalisation)
@@ -742,8 +912,26 @@ template <class Epi>
 inline hipError_t gemm_wgrad(const float* dZ, int ldz, const float* X, int ldx, int N, int Kin, int M,
                              const Epi& e, hipStream_t st) {
     const GemmGrid g = make_grid(N, Kin, 64, 64);
-    hipLaunchKernelGGL((gemm_wgrad_kernel<kRingStages, Epi>), dim3(g.grid), dim3(256), 0, st, dZ, ldz, X, ldx, M,
-                       g.tiles_q, g.tiles_p, g.p_per_xcd, e);
+    if (gemm_variant() == 2)
+        hipLaunchKernelGGL((gemm_wgrad_kernel<kRingStages, Epi>), dim3(g.grid), dim3(256), 0, st, dZ, ldz, X, ldx, M,
+                           g.tiles_q, g.tiles_p, g.p_per_xcd, e);
+    else
+        hipLaunchKernelGGL((gemm_wgrad_reg_kernel<Epi>), dim3(g.grid), dim3(256), 0, st,
+                           GemmArgs{dZ, ldz, X, ldx, M, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+    return hipGetLastError();
+}
+// one launch: dX'[M][Kin'] = (dZ'[M][N'] W'[N'][Kin']) .* mask   ||   G[N][Kin] = dZ[M][N]^T X[M][Kin]
+template <class EpiW>
+inline hipError_t gemm_bwd_pair(const float* dZd, int ldzd, const float* Wd, int ldwd, const float* mask, int ldm,
+                                float* dXd, int ldod, int Md, int Kind, int Nd,
+                                const float* dZw, int ldzw, const float* Xw, int ldxw, int Nw, int Kinw, int Mw,
+                                const EpiW& ew, hipStream_t st) {
+    const EpiMask ed{dXd, ldod, mask, ldm};
+    const GemmGrid g1 = make_grid(Md, Kind, 32, 32);
+    const GemmGrid g2 = make_grid(Nw, Kinw, 64, 64);
+    hipLaunchKernelGGL((bwd_pair_kernel<EpiMask, EpiW>), dim3(g1.grid + g2.grid), dim3(256), 0, st,
+                       GemmArgs{dZd, ldzd, Wd, ldwd, Nd, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, g1.grid,
+                       GemmArgs{dZw, ldzw, Xw, ldxw, Mw, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, ew);
     return hipGetLastError();
 }
 
