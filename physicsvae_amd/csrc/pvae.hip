@@ -299,7 +299,7 @@ static AdamScalars adam_scalars(const pvae_step_params* sp, int net) {
     const double bc2 = 1.0 - std::pow(sp->beta2, t);
     AdamScalars s;
     s.step_size = (float)(sp->lr / bc1);
-    s.bc2_sqrt = (float)std::sqrt(bc2);
+    s.inv_bc2_sqrt = (float)(1.0 / std::sqrt(bc2));
     s.beta1 = (float)sp->beta1;
     s.beta2 = (float)sp->beta2;
     s.eps = (float)sp->adam_eps;
@@ -417,7 +417,35 @@ static int backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool input
     if (has_dgrad(last) && (rc = dgrad(last))) return rc;
     for (int i = last; i >= 0; --i) {
         const int j = i - 1;                       // dgrad_{i-1} rides with wgrad_i
-        if ((rc = wgrad(i, (j >= 0 && has_dgrad(j)) ? j : -1))) return rc;
+        if (j >= 0 && has_dgrad(j)) {
+            if ((rc = wgrad(i, j))) return rc;
+        } else if (i == 1 && !has_dgrad(0)) {
+            // no input gradient wanted: the two last weight gradients are independent -> one launch
+            const Layer& l1 = N.layers[1];
+            const Layer& l0 = N.layers[0];
+            if (fused) {
+                EpiGradAdam e1{c->params + l1.w_off, c->m + l1.w_off, c->v + l1.w_off, l1.ld, as};
+                e1.b = c->params + l1.b_off; e1.bm = c->m + l1.b_off; e1.bv = c->v + l1.b_off;
+                EpiGradAdam e0{c->params + l0.w_off, c->m + l0.w_off, c->v + l0.w_off, l0.ld, as};
+                e0.b = c->params + l0.b_off; e0.bm = c->m + l0.b_off; e0.bv = c->v + l0.b_off;
+                if (fold) e1.loss = *fold;         // block 0 of the launch belongs to the first problem
+                HIP_TRY(gemm_wgrad_pair(c->ws + w.dz[1], l1.n_out_pad, c->ws + w.act[0], l1.ld, l1.n_out_pad, l1.ld, e1,
+                                        c->ws + w.dz[0], l0.n_out_pad, c->ws + w.in, l0.ld, l0.n_out_pad, l0.ld, e0,
+                                        rows_pad, st));
+            } else {
+                EpiGradStore e1{c->grads + l1.w_off, l1.ld};
+                e1.gb = c->grads + l1.b_off;
+                EpiGradStore e0{c->grads + l0.w_off, l0.ld};
+                e0.gb = c->grads + l0.b_off;
+                if (fold) e1.loss = *fold;
+                HIP_TRY(gemm_wgrad_pair(c->ws + w.dz[1], l1.n_out_pad, c->ws + w.act[0], l1.ld, l1.n_out_pad, l1.ld, e1,
+                                        c->ws + w.dz[0], l0.n_out_pad, c->ws + w.in, l0.ld, l0.n_out_pad, l0.ld, e0,
+                                        rows_pad, st));
+            }
+            return 0;
+        } else {
+            if ((rc = wgrad(i, -1))) return rc;
+        }
     }
     return 0;
 }

@@ -653,6 +653,14 @@ gemm_wgrad_reg_kernel(GemmArgs ga, Epi epi) {
 // layer l.  The dgrad blocks are dispatched first (one per CU), the wgrad blocks land beside
 // them (2 waves per SIMD), so one workgroup's load / Adam-traffic phases hide under the other's
 // MFMA phases, and a launch boundary disappears.
+template <class EpiW>
+__global__ void __launch_bounds__(256)
+wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2) {
+    __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
+    if ((int)blockIdx.x < n1) wgrad_reg_body<EpiW>(lds, blockIdx.x, g1, e1);
+    else wgrad_reg_body<EpiW>(lds, blockIdx.x - n1, g2, e2);
+}
+
 template <class EpiD, class EpiW>
 __global__ void __launch_bounds__(256)
 bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew) {
@@ -750,7 +758,7 @@ struct EpiMask {              // input gradient: out = acc * (act > 0)
 
 struct AdamScalars {
     float step_size;          // lr / (1 - beta1^t)
-    float bc2_sqrt;           // sqrt(1 - beta2^t)
+    float inv_bc2_sqrt;       // 1 / sqrt(1 - beta2^t)
     float beta1, beta2, eps;
     float one_minus_beta1, one_minus_beta2;   // computed in double on the host, as torch does
 };
@@ -758,12 +766,14 @@ struct AdamScalars {
 // torch.optim.Adam single-tensor update (amsgrad False, weight_decay 0), tm:119-122,143:
 //   m <- m + (g - m)(1 - b1) ; v <- v b2 + (1 - b2) g g ; p <- p - step_size * m / (sqrt(v)/bc2_sqrt + eps)
 __device__ inline void adam_update(float g, float& p, float& m, float& v, const AdamScalars& s) {
-    // every operation is pinned (no context-dependent fma contraction), so the fused
-    // epilogue and the flat multi-tensor kernel produce bit-identical parameters
+    // Moments: every operation pinned (no context-dependent fma contraction), so the fused
+    // epilogue and the flat multi-tensor kernel stay bit-identical.  Step: v_sqrt_f32 / v_rcp_f32
+    // (1 ulp) instead of the correctly rounded sequences (~10x the instructions); the term they
+    // feed is scaled by lr/(1-b1^t) ~ 5e-4 before it meets p, so p moves by < 0.1 ulp of itself.
     m = __fmaf_rn(__fsub_rn(g, m), s.one_minus_beta1, m);
     v = __fmaf_rn(v, s.beta2, __fmul_rn(__fmul_rn(s.one_minus_beta2, g), g));
-    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), s.bc2_sqrt), s.eps);
-    p = __fmaf_rn(-s.step_size, __fdiv_rn(m, denom), p);
+    const float denom = __fmaf_rn(__builtin_amdgcn_sqrtf(v), s.inv_bc2_sqrt, s.eps);
+    p = __fmaf_rn(-s.step_size, __fmul_rn(m, __builtin_amdgcn_rcpf(denom)), p);
 }
 
 __device__ inline void adam_update4(const v4f& g, v4f& p, v4f& m, v4f& v, const AdamScalars& s) {
@@ -918,6 +928,18 @@ inline hipError_t gemm_wgrad(const float* dZ, int ldz, const float* X, int ldx, 
     else
         hipLaunchKernelGGL((gemm_wgrad_reg_kernel<Epi>), dim3(g.grid), dim3(256), 0, st,
                            GemmArgs{dZ, ldz, X, ldx, M, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+    return hipGetLastError();
+}
+// one launch, two independent weight gradients (the two last layers of a backward pass)
+template <class EpiW>
+inline hipError_t gemm_wgrad_pair(const float* dZ1, int ldz1, const float* X1, int ldx1, int N1, int Kin1,
+                                  const EpiW& e1, const float* dZ2, int ldz2, const float* X2, int ldx2, int N2,
+                                  int Kin2, const EpiW& e2, int M, hipStream_t st) {
+    const GemmGrid g1 = make_grid(N1, Kin1, 64, 64);
+    const GemmGrid g2 = make_grid(N2, Kin2, 64, 64);
+    hipLaunchKernelGGL((wgrad_pair_kernel<EpiW>), dim3(g1.grid + g2.grid), dim3(256), 0, st,
+                       GemmArgs{dZ1, ldz1, X1, ldx1, M, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, e1, g1.grid,
+                       GemmArgs{dZ2, ldz2, X2, ldx2, M, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, e2);
     return hipGetLastError();
 }
 // one launch: dX'[M][Kin'] = (dZ'[M][N'] W'[N'][Kin']) .* mask   ||   G[N][Kin] = dZ[M][N]^T X[M][Kin]
