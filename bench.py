@@ -166,10 +166,13 @@ def main():
                 eng.forward_backward(phase, rows, sp, fused_adam=False, loss_out=loss_buf)
         torch.cuda.synchronize()
         lib.pvae_profile_enable(0)
-        names = {0: "gemm_tile_kernel<32,32,64,row,row> forward", 1: "gemm_tile_kernel<32,32,64,row,col> dgrad",
-                 2: "gemm_tile_kernel<64,64,32,col,col> wgrad%s" % ("+Adam" if dp.world == 1 else "")}
+        adam = "+Adam" if dp.world == 1 else ""
+        names = {0: "gemm_splitk_reg_kernel<P_ROW> (forward layer, 32x32 tile)",
+                 1: "gemm_splitk_reg_kernel<P_COL> (input gradient, 32x32 tile)",
+                 2: "gemm_wgrad_reg_kernel / wgrad_pair_kernel (weight gradient%s, 64x64 tiles)" % adam,
+                 3: "bwd_pair_kernel (input gradient of layer l-1 || weight gradient%s of layer l)" % adam}
         cats = {}
-        for c in (0, 1, 2):
+        for c in (0, 1, 2, 3):
             ms, cnt, fls = C.c_double(), C.c_int64(), C.c_double()
             _lib.check(lib.pvae_profile_read(c, C.byref(ms), C.byref(cnt), C.byref(fls)))
             if cnt.value:
@@ -179,8 +182,23 @@ def main():
                                tflops=fls.value / (ms.value * 1e-3) / 1e12)
         dom = max(cats, key=lambda c: cats[c]["total_ms"])
         d = cats[dom]
+        # HBM traffic per launch of that kernel: PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE,
+        # MI355X_MICROARCH.md HBM section) of this same command, summarised under profiles/
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))[::-1]:
+                summ = json.load(open(f))
+                key = {3: "bwd_pair_kernel<EpiMask,EpiGradAdam>", 2: "wgrad_pair_kernel<EpiGradAdam>",
+                       0: "gemm_splitk_reg_kernel<P_ROW,EpiBiasAct>", 1: "gemm_splitk_reg_kernel<P_COL,EpiMask>"}[dom]
+                if key in summ and "hbm_traffic_MB" in summ[key] and dp.world == 1 and a.phase == "world":
+                    traffic, traffic_src = summ[key]["hbm_traffic_MB"] * 1e6, os.path.relpath(f, ROOT)
+                    break
+        except Exception:
+            pass
         out["roofline"] = {"bound": "mfma", "achieved": d["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": d["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                           "unit": "TFLOP/s", "frac": d["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                           "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC)", "traffic_source": traffic_src,
                            "kernel": d["kernel"], "avg_launch_us": d["avg_us"],
                            "algorithmic_gflop_per_launch": d["algo_gflop_per_launch"],
                            "launches_per_step": d["launches"] / n_prof}

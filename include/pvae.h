@@ -177,7 +177,9 @@ int pvae_reparam(pvae_ctx* ctx, const float* mu_logvar, int32_t rows, const floa
 /* Per-kernel timing with HIP events on the launch stream (bench.py's `roofline` object).
  * While enabled every contraction launch is bracketed by an event pair (this serialises the
  * host a little, so it is used in a separate instrumented pass, never in a timed region).
- * category: 0 = forward tile kernel, 1 = input-gradient, 2 = weight-gradient(+Adam).
+ * category: 0 = forward kernel, 1 = input-gradient kernel (alone), 2 = weight-gradient(+Adam)
+ * launches (single or the two trailing layers in one launch), 3 = fused input-gradient +
+ * weight-gradient(+Adam) launch.
  * pvae_profile_read synchronises on the recorded events and returns the summed duration
  * (ms), launch count and ALGORITHMIC flops (2*rows*n_in*n_out on the unpadded dims). */
 int pvae_profile_enable(int on);

@@ -357,7 +357,7 @@ static int backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool input
     const NetWork& w = c->W.net[n];
     const AdamScalars as = adam_scalars(sp, n);
     const int last = (int)N.layers.size() - 1;
-    const bool pair = train && c->pair_launch && !g_prof.on;
+    const bool pair = train && c->pair_launch;
 
     // dgrad of layer i: dz[i] (.) W_i -> dz[i-1] (masked) or d_in (i == 0, unmasked)
     auto has_dgrad = [&](int i) { return i > 0 || input_grad; };
@@ -381,9 +381,13 @@ static int backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool input
             if (j >= 0) {
                 const Layer& d = N.layers[j];
                 const float* dx_in = j == 0 ? c->ws + w.in : c->ws + w.act[j - 1];
+                const int need = n == PVAE_NET_WM ? c->L.cfg.dim_action : c->L.cfg.latent;
+                const int pp = g_prof.begin(3, 2.0 * c->staged_rows_f * ((double)l.n_in * l.n_out +
+                                               (double)(j > 0 ? d.n_in : need) * d.n_out), st);
                 HIP_TRY(gemm_bwd_pair(c->ws + w.dz[j], d.n_out_pad, c->params + d.w_off, d.ld, j > 0 ? dx_in : nullptr,
                                       d.ld, j > 0 ? c->ws + w.dz[j - 1] : c->ws + w.d_in, d.ld, rows_pad, d.ld,
                                       d.n_out_pad, dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
+                g_prof.end(pp, st);
             } else {
                 const int pw = g_prof.begin(2, 2.0 * c->staged_rows_f * l.n_in * l.n_out, st);
                 HIP_TRY(gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
@@ -423,6 +427,8 @@ static int backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool input
             // no input gradient wanted: the two last weight gradients are independent -> one launch
             const Layer& l1 = N.layers[1];
             const Layer& l0 = N.layers[0];
+            const int pw2 = g_prof.begin(2, 2.0 * c->staged_rows_f * ((double)l1.n_in * l1.n_out +
+                                            (double)l0.n_in * l0.n_out), st);
             if (fused) {
                 EpiGradAdam e1{c->params + l1.w_off, c->m + l1.w_off, c->v + l1.w_off, l1.ld, as};
                 e1.b = c->params + l1.b_off; e1.bm = c->m + l1.b_off; e1.bv = c->v + l1.b_off;
@@ -442,6 +448,7 @@ static int backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool input
                                         c->ws + w.dz[0], l0.n_out_pad, c->ws + w.in, l0.ld, l0.n_out_pad, l0.ld, e0,
                                         rows_pad, st));
             }
+            g_prof.end(pw2, st);
             return 0;
         } else {
             if ((rc = wgrad(i, -1))) return rc;

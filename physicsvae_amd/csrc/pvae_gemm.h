@@ -34,209 +34,35 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------
-// Ring-pipelined kernels (the production path).
+// The contraction kernels.
 //
-// Two measured facts shape them (profiles/r01_*):
-//  (1) one k-tile in flight per CU leaves the loop at the mercy of the L2 / Infinity-Cache
-//      round trip -> operand tiles travel by LDS-DMA (global_load_lds_dwordx4, no VGPR
-//      staging) into a ring of STAGES slots, STAGES-1 k-tiles in flight per CU behind counted
-//      `s_waitcnt vmcnt(N)` and ONE raw s_barrier per k-tile;
-//  (2) with one wave per SIMD, ds_read_b32/b64 issue at ~1/5 of the LDS rate (~40 cycles per
-//      wave-instruction, MI355X_MICROARCH.md LDS table) while ds_read_b128 runs at full rate
-//      -> fragments are fetched with as few, as wide DS reads as the MFMA layout allows:
-//        * k-contiguous ("ROW") operands: ONE ds_read_b128 = 4 k-values of one row per lane;
-//          lane (i, h) holds k = 16c + 4h + s, MFMA step s takes element s (the k order
-//          inside a 16-chunk is a permutation, shared by both operands);
-//        * output-contiguous ("COL") operands: ds_read_b64 = 2 consecutive outputs of one k
-//          per lane, feeding TWO interleaved MFMA tiles (tile u owns outputs 2i + u);
-//        * the 4 waves of a workgroup split K instead of the tile (forward / dgrad): every
-//          wave owns the whole 32x32 output as 2x2 MFMA tiles, so each fragment feeds two
-//          MFMAs; partial tiles are summed through LDS in a fixed order at the end.
-//
-// The DMA writes LDS lane-linearly (wave-uniform base + lane*16 B), so tiles are unpadded and
-// bank conflicts are removed by permuting the per-lane SOURCE address and, identically, the
-// fragment read address (involutions):
-//   ROW tile [32][64]   b128 reads : 16-byte chunk ^= row & 15
-//   COL tile [64 k][32] b64 reads  : LDS row = k ^ ((k >> 2) & 1)   (rows k, k+4 of one
-//                                    32-lane group land in different bank halves)
+// Fragments are fetched with as few, as wide DS reads as the MFMA layout allows, because with
+// one wave per SIMD ds_read_b32/b64 issue at ~1/5 of the LDS rate (MI355X_MICROARCH.md LDS
+// table) while ds_read_b128 runs at full rate:
+//   * k-contiguous ("ROW") operands: ONE ds_read_b128 = 4 k-values of one row per lane; lane
+//     (i, h) holds k = 16c + 4h + s, MFMA step s takes element s (the k order inside a 16-chunk
+//     is a permutation, shared by both operands);
+//   * output-contiguous ("COL") operands: ds_read_b64 = 2 consecutive outputs of one k per
+//     lane, feeding TWO interleaved MFMA tiles (tile u owns outputs 2i + u);
+//   * the 4 waves of a workgroup split K instead of the tile (forward / dgrad): every wave owns
+//     the whole 32x32 output as 2x2 MFMA tiles, so each fragment feeds two MFMAs; partial tiles
+//     are summed through LDS in a fixed order at the end.
+// Tiles travel global -> VGPR (plain global_load_dwordx4, D = 4 register sets per lane) ->
+// ds_write_b128 into a 2-slot LDS image.  The image is lane-linear (slot j = 16-byte chunk j of
+// the tile) with the chunk order XOR-permuted on the way in and, identically, on the fragment
+// read (involutions), which removes bank conflicts without padding:
+//   ROW tile [32][64]   b128 reads : chunk ^= row & 15
+//   COL tile [64 k][32] b64 reads  : LDS row = k ^ ((k >> 2) & 1)   (rows k, k+4 of one 32-lane
+//                                    group land in different bank halves)
 //   COL tile [32 k][64] b64 reads  : chunk ^= (row & 1) << 3        (rows k, k+1 likewise)
+// (An LDS-DMA ring variant of the same kernels -- global_load_lds, 8 stages, counted vmcnt --
+// measured ~12 % slower because a DMA instruction costs ~150 issue cycles on the wave that also
+// feeds the matrix pipe; it lives in tools/gemm_dma_ring.h with the ablation harness.)
 // ---------------------------------------------------------------------------------------
-template <int N>
-__device__ inline void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-__device__ inline void lds_dma16(const float* src, float* dst_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
-}
-
-template <int STAGES, int G>
-__device__ inline void wait_tile_landed(int younger_in_flight) {
-    // tile t of this wave has landed once at most `younger_in_flight` tiles (G DMA instructions
-    // each) issued after it are still outstanding
-    switch (younger_in_flight) {
-        case 0: wait_vmcnt<0>(); break;
-        case 1: wait_vmcnt<(STAGES > 2 ? 1 : 0) * G>(); break;
-        case 2: wait_vmcnt<(STAGES > 3 ? 2 : 0) * G>(); break;
-        case 3: wait_vmcnt<(STAGES > 4 ? 3 : 0) * G>(); break;
-        case 4: wait_vmcnt<(STAGES > 5 ? 4 : 0) * G>(); break;
-        case 5: wait_vmcnt<(STAGES > 6 ? 5 : 0) * G>(); break;
-        default: wait_vmcnt<(STAGES > 7 ? 6 : 0) * G>(); break;
-    }
-}
-
-// ---- forward / dgrad: C[32 q][32 p] per workgroup, BK = 64, waves split K ------------------
+// ---- forward / dgrad: C[32 q][32 p] per workgroup, BK = 64, the 4 waves split K -------------
 //   Q is always ROW (X or dZ, k-contiguous).  P_ROW: W[p][k] (forward);  !P_ROW: W[k][p] (dgrad).
-// ABL (tools/gemm_ablate.hip only; 0 in production): 1 = no DMA refill in the loop, 2 = no LDS
-// fragment reads, 4 = no MFMA, 8 = no barrier / vmcnt wait.
-template <bool P_ROW, int STAGES, class Epi, int ABL = 0>
-__global__ void __launch_bounds__(256)
-gemm_splitk_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ P, int ldp, int K,
-                   int tiles_q, int tiles_p, int p_per_xcd, Epi epi) {
-    constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, G = 4;
-    static_assert((STAGES - 2) * G <= 63, "vmcnt is a 6-bit counter");
-    static_assert(STAGES * kStage >= 4 * 32 * 36, "ring must hold the split-K reduction buffer");
-
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, loc = bid >> 3;
-    const int tile_p = xcd * p_per_xcd + loc / tiles_q;
-    const int tile_q = loc % tiles_q;
-    if (tile_p >= tiles_p) return;
-    const int q0 = tile_q * 32, p0 = tile_p * 32;
-
-    __shared__ __attribute__((aligned(16))) float lds[STAGES * kStage];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lh = lane >> 4;
-
-    // per-lane DMA sources (k-tile 0); slot j = 16-byte position inside the 8 KB tile image
-    const float* sq[2];
-    const float* sp[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int j = (wave + 4 * u) * 64 + lane;
-        {
-            const int row = j >> 4, c = (j & 15) ^ (row & 15);
-            sq[u] = Q + (size_t)(q0 + row) * ldq + c * 4;
-        }
-        if (P_ROW) {
-            const int row = j >> 4, c = (j & 15) ^ (row & 15);
-            sp[u] = P + (size_t)(p0 + row) * ldp + c * 4;
-        } else {
-            const int r = j >> 3, k = r ^ ((r >> 2) & 1);
-            sp[u] = P + (size_t)k * ldp + p0 + (j & 7) * 4;
-        }
-    }
-    const size_t kstep_p = P_ROW ? (size_t)BK : (size_t)BK * ldp;
-    auto issue = [&](int t, float* slot) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            lds_dma16(sq[u] + (size_t)t * BK, slot + (wave + 4 * u) * 256);
-            lds_dma16(sp[u] + (size_t)t * kstep_p, slot + kTile + (wave + 4 * u) * 256);
-        }
-    };
-
-    v4f acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
-
-    // fragment read offsets (floats) inside a stage
-    int oq[2], op[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int row = 16 * a + li;
-        oq[a] = row * 64 + (((4 * wave + lh) ^ (row & 15)) << 2);
-        op[a] = kTile + oq[a];                                   // P_ROW: same image shape
-    }
-    const int kq = 16 * wave + 4 * lh;                           // first k of this lane's 4-chunk
-
-    const int nk = K / BK;
-#pragma unroll
-    for (int t = 0; t < STAGES - 1; ++t)
-        if (t < nk) issue(t, lds + t * kStage);
-
-    for (int t = 0; t < nk; ++t) {
-        const int rem = (nk - 1 - t) < (STAGES - 2) ? (nk - 1 - t) : (STAGES - 2);
-        if (!(ABL & 8)) {
-            wait_tile_landed<STAGES, G>((ABL & 1) ? 0 : rem);
-            __builtin_amdgcn_s_barrier();   // every wave's share of tile t landed; tile t-1 fully read
-        }
-        asm volatile("" ::: "memory");
-        const int tn = t + STAGES - 1;
-        if (!(ABL & 1) && tn < nk) issue(tn, lds + (tn % STAGES) * kStage);   // refill the slot tile t-1 vacated
-        const float* st = lds + (t % STAGES) * kStage;
-        v4f fq[2], fp[2];
-        v2f fc[4];
-        if (ABL & 2) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a) { fq[a] = v4f{1.f, 2.f, 3.f, 4.f} * (float)lane; fp[a] = fq[a] + 1.f; }
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) fc[s2] = v2f{1.f + s2, 2.f} * (float)lane;
-            asm volatile("" : "+v"(fq[0]), "+v"(fq[1]), "+v"(fp[0]), "+v"(fp[1]));
-        } else {
-#pragma unroll
-        for (int a = 0; a < 2; ++a) fq[a] = *reinterpret_cast<const v4f*>(st + oq[a]);
-        if (P_ROW) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b) fp[b] = *reinterpret_cast<const v4f*>(st + op[b]);
-        } else {
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)       // global row k = kq + s2 lives in LDS row k ^ ((k>>2)&1) = k ^ (lh&1)
-                fc[s2] = *reinterpret_cast<const v2f*>(st + kTile + (((kq + s2) ^ (lh & 1)) * 32) + 2 * li);
-        }
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const float pv = P_ROW ? fp[b][s2] : fc[s2][b];
-                    if (ABL & 4) {
-                        acc[a][b][0] += pv * fq[a][s2];
-                    } else {
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, fq[a][s2], acc[a][b], 0, 0, 0);
-                    }
-                }
-    }
-
-    // split-K reduction through LDS (fixed order: wave 0..3), then the epilogue on float4s.
-    // D[i = 4*lh + r][j = li]: i indexes the P side, j the Q side.
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    constexpr int RS = 36;                                       // padded row stride of the partial tiles
-    float* red = lds + wave * (32 * RS);
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ql = 16 * a + li;
-                const int pl = P_ROW ? (16 * b + 4 * lh + r) : (8 * lh + 2 * r + b);
-                red[ql * RS + pl] = acc[a][b][r];
-            }
-    __syncthreads();
-    {
-        const int ql = tid >> 3, pl = (tid & 7) << 2;
-        v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
-#pragma unroll
-        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (32 * RS) + ql * RS + pl);
-        epi(q0 + ql, p0 + pl, v);
-    }
-    epi.finish(lds, tile_q * tiles_p + tile_p, tid);
-}
-
-// ---- register-staged twin of gemm_splitk_kernel -------------------------------------------
-// Same LDS image and fragment reads, but tiles travel global -> VGPR (plain global_load_dwordx4,
-// D = 4 tiles = 64 VGPRs in flight per lane) -> ds_write_b128 into a 2-slot LDS ring.  The
-// ablation (tools/gemm_ablate.hip) prices an LDS-DMA instruction at ~150 issue cycles on the
-// wave that also feeds the matrix pipe; a plain load + ds_write_b128 pair is ~20.
+// ABL (tools/gemm_ablate.hip only; 0 in production): 1 = no tile staging in the loop, 2 = no LDS
+// fragment reads, 4 = no MFMA, 8 = no barrier.
 struct GemmArgs {
     const float* Q;
     int ldq;
@@ -400,122 +226,8 @@ gemm_splitk_reg_kernel(GemmArgs ga, Epi epi) {
     splitk_reg_body<P_ROW, Epi, ABL>(lds, blockIdx.x, ga, epi);
 }
 
-// ---- wgrad: G[64 q][64 p] per workgroup, reduction over batch rows (BK = 32), both operands COL
-template <int STAGES, class Epi, int ABL = 0>
-__global__ void __launch_bounds__(256)
-gemm_wgrad_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ P, int ldp, int K,
-                  int tiles_q, int tiles_p, int p_per_xcd, Epi epi) {
-    constexpr int BK = 32, kTile = 32 * 64, kStage = 2 * kTile, G = 4;
-    static_assert((STAGES - 2) * G <= 63, "vmcnt is a 6-bit counter");
-
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, loc = bid >> 3;
-    const int tile_p = xcd * p_per_xcd + loc / tiles_q;
-    const int tile_q = loc % tiles_q;
-    if (tile_p >= tiles_p) return;
-    const int q0 = tile_q * 64, p0 = tile_p * 64;
-
-    __shared__ __attribute__((aligned(16))) float lds[STAGES * kStage];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lh = lane >> 4;
-    const int wq = (wave >> 1) * 32, wp = (wave & 1) * 32;
-
-    const float* sq[2];
-    const float* sp[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int j = (wave + 4 * u) * 64 + lane;
-        const int row = j >> 4, c = (j & 15) ^ ((row & 1) << 3);
-        sq[u] = Q + (size_t)row * ldq + q0 + c * 4;
-        sp[u] = P + (size_t)row * ldp + p0 + c * 4;
-    }
-    auto issue = [&](int t, float* slot) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            lds_dma16(sq[u] + (size_t)t * BK * ldq, slot + (wave + 4 * u) * 256);
-            lds_dma16(sp[u] + (size_t)t * BK * ldp, slot + kTile + (wave + 4 * u) * 256);
-        }
-    };
-
-    v4f acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
-    v2f bsum = v2f{0.f, 0.f};   // running column sums of the Q (dZ) fragments = bias gradient
-
-    // lane (li, lh) reads row k = kk + lh, outputs (w + 2*li, w + 2*li + 1)
-    const int sw = (lh & 1) << 3;                                // chunk swizzle of odd rows
-    const int cq = wq + 2 * li, cp = wp + 2 * li;
-    const int oq = lh * 64 + ((((cq >> 2) ^ sw)) << 2) + (cq & 3);
-    const int op = kTile + lh * 64 + ((((cp >> 2) ^ sw)) << 2) + (cp & 3);
-
-    const int nk = K / BK;
-#pragma unroll
-    for (int t = 0; t < STAGES - 1; ++t)
-        if (t < nk) issue(t, lds + t * kStage);
-
-    for (int t = 0; t < nk; ++t) {
-        const int rem = (nk - 1 - t) < (STAGES - 2) ? (nk - 1 - t) : (STAGES - 2);
-        if (!(ABL & 8)) {
-            wait_tile_landed<STAGES, G>((ABL & 1) ? 0 : rem);
-            __builtin_amdgcn_s_barrier();
-        }
-        asm volatile("" ::: "memory");
-        const int tn = t + STAGES - 1;
-        if (!(ABL & 1) && tn < nk) issue(tn, lds + (tn % STAGES) * kStage);
-        const float* st = lds + (t % STAGES) * kStage;
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 4) {
-            v2f fq, fp;
-            if (ABL & 2) {
-                fq = v2f{1.f, 2.f} * (float)(lane + kk);
-                fp = v2f{3.f, 4.f} * (float)(lane + kk);
-                asm volatile("" : "+v"(fq), "+v"(fp));
-            } else {
-                fq = *reinterpret_cast<const v2f*>(st + oq + kk * 64);
-                fp = *reinterpret_cast<const v2f*>(st + op + kk * 64);
-            }
-            bsum += fq;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    if (ABL & 4) {
-                        acc[a][b][0] += fp[b] * fq[a];
-                    } else {
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[b], fq[a], acc[a][b], 0, 0, 0);
-                    }
-                }
-        }
-    }
-
-    // lane holds q = wq + 2*li + a ; p = wp + 8*lh + 2*r + b  -> two float4 per q-row
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int q = q0 + wq + 2 * li + a, p = p0 + wp + 8 * lh;
-        epi(q, p, v4f{acc[a][0][0], acc[a][1][0], acc[a][0][1], acc[a][1][1]});
-        epi(q, p + 4, v4f{acc[a][0][2], acc[a][1][2], acc[a][0][3], acc[a][1][3]});
-    }
-    // bias gradient db[q] = sum over batch rows of dZ[:, q] (autograd of nn.Linear's bias): the
-    // first p-tile's two q-halves (waves 0 and 2) own it; lanes lh = 0..3 hold k = lh (mod 4)
-    if (epi.has_bias() && tile_p == 0 && (wave & 1) == 0) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float v = bsum[e];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (lh == 0) epi.bias(q0 + wq + 2 * li + e, v);
-        }
-    }
-    if (epi.loss.out && bid == 0 && wave == 3) finalize_loss_wave(epi.loss, lane);
-}
-
-// ---- register-staged twin of gemm_wgrad_kernel; the epilogue operands (Adam's p, m, v) are
-// fetched under the main loop ------------------------------------------------------------------
+// ---- wgrad: G[64 q][64 p] per workgroup, reduction over batch rows (BK = 32), both operands COL,
+// waves 2x2 with 32x32 each; the epilogue operands (Adam's p, m, v) are fetched under the loop --
 template <class Epi, int ABL = 0>
 __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
     constexpr int BK = 32, kTile = 32 * 64, kStage = 2 * kTile, D = 4, S = 2;
@@ -862,18 +574,6 @@ struct EpiGradAdam {          // weight gradient consumed in registers by Adam (
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
-// Variant switch for A/B measurements (PVAE_GEMM): default "reg" = register-staged ring for
-// forward/dgrad (+ LDS-DMA ring for wgrad); "dma" = LDS-DMA ring everywhere.
-inline int gemm_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("PVAE_GEMM");
-        v = (e && e[0] == 'd') ? 2 : 0;
-    }
-    return v;
-}
-constexpr int kRingStages = 8;
-
 struct GemmGrid {
     int tiles_q, tiles_p, p_per_xcd, grid;
 };
@@ -891,12 +591,8 @@ template <class Epi>
 inline hipError_t gemm_forward_epi(const float* X, int ldx, const float* W, int ldw, int M, int N, int K,
                                    const Epi& e, hipStream_t st) {
     const GemmGrid g = make_grid(M, N, 32, 32);
-    if (gemm_variant() == 2)
-        hipLaunchKernelGGL((gemm_splitk_kernel<true, kRingStages, Epi>), dim3(g.grid), dim3(256), 0, st, X, ldx, W,
-                           ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd, e);
-    else
-        hipLaunchKernelGGL((gemm_splitk_reg_kernel<true, Epi>), dim3(g.grid), dim3(256), 0, st,
-                           GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+    hipLaunchKernelGGL((gemm_splitk_reg_kernel<true, Epi>), dim3(g.grid), dim3(256), 0, st,
+                       GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
     return hipGetLastError();
 }
 inline hipError_t gemm_forward(const float* X, int ldx, const float* W, int ldw, const float* bias,
@@ -909,12 +605,8 @@ inline hipError_t gemm_dgrad(const float* dZ, int ldz, const float* W, int ldw, 
                              int ldm, float* dX, int ldo, int M, int Kin, int N, hipStream_t st) {
     const EpiMask e{dX, ldo, mask, ldm};
     const GemmGrid g = make_grid(M, Kin, 32, 32);
-    if (gemm_variant() == 2)
-        hipLaunchKernelGGL((gemm_splitk_kernel<false, kRingStages, EpiMask>), dim3(g.grid), dim3(256), 0, st, dZ, ldz,
-                           W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd, e);
-    else
-        hipLaunchKernelGGL((gemm_splitk_reg_kernel<false, EpiMask>), dim3(g.grid), dim3(256), 0, st,
-                           GemmArgs{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+    hipLaunchKernelGGL((gemm_splitk_reg_kernel<false, EpiMask>), dim3(g.grid), dim3(256), 0, st,
+                       GemmArgs{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
     return hipGetLastError();
 }
 // wgrad: G[N][Kin] = dZ[M][N]^T X[M][Kin]  (+ bias gradient, + optional loss finalisation)
@@ -922,12 +614,8 @@ template <class Epi>
 inline hipError_t gemm_wgrad(const float* dZ, int ldz, const float* X, int ldx, int N, int Kin, int M,
                              const Epi& e, hipStream_t st) {
     const GemmGrid g = make_grid(N, Kin, 64, 64);
-    if (gemm_variant() == 2)
-        hipLaunchKernelGGL((gemm_wgrad_kernel<kRingStages, Epi>), dim3(g.grid), dim3(256), 0, st, dZ, ldz, X, ldx, M,
-                           g.tiles_q, g.tiles_p, g.p_per_xcd, e);
-    else
-        hipLaunchKernelGGL((gemm_wgrad_reg_kernel<Epi>), dim3(g.grid), dim3(256), 0, st,
-                           GemmArgs{dZ, ldz, X, ldx, M, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+    hipLaunchKernelGGL((gemm_wgrad_reg_kernel<Epi>), dim3(g.grid), dim3(256), 0, st,
+                       GemmArgs{dZ, ldz, X, ldx, M, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
     return hipGetLastError();
 }
 // one launch, two independent weight gradients (the two last layers of a backward pass)

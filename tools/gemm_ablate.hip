@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <vector>
 #include "../physicsvae_amd/csrc/pvae_gemm.h"
+#include "gemm_dma_ring.h"
 using namespace pvae;
 static int g_pad = 0;   // extra floats of row pitch
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
@@ -36,8 +37,8 @@ template <int ABL> float run_reg(bool prow, const float* X, const float* W, floa
     const GemmGrid g = make_grid(M, N, 32, 32);
     EpiBiasAct e{out, N, nullptr, 1};
     auto go = [&]() {
-        if (prow) hipLaunchKernelGGL((gemm_splitk_reg_kernel<true, EpiBiasAct, ABL>), dim3(g.grid), dim3(256), 0, st, X, K + g_pad, W, K + g_pad, K, g.tiles_q, g.tiles_p, g.p_per_xcd, e);
-        else hipLaunchKernelGGL((gemm_splitk_reg_kernel<false, EpiBiasAct, ABL>), dim3(g.grid), dim3(256), 0, st, X, K + g_pad, W, N + g_pad, K, g.tiles_q, g.tiles_p, g.p_per_xcd, e);
+        if (prow) hipLaunchKernelGGL((gemm_splitk_reg_kernel<true, EpiBiasAct, ABL>), dim3(g.grid), dim3(256), 0, st, GemmArgs{X, K + g_pad, W, K + g_pad, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+        else hipLaunchKernelGGL((gemm_splitk_reg_kernel<false, EpiBiasAct, ABL>), dim3(g.grid), dim3(256), 0, st, GemmArgs{X, K + g_pad, W, N + g_pad, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
     };
     for (int i = 0; i < 20; ++i) go();
     hipStreamSynchronize(st);
