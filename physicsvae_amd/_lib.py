@@ -3,6 +3,12 @@ or a call fails, a RuntimeError is raised."""
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be the first one
+# the process loads: our library then binds to the SAME runtime instance (same soname), which is
+# what makes torch's device pointers and streams valid inside libpvae.  Loading libpvae first
+# would pull in /opt/rocm's runtime instead and leave two runtimes that do not share a context.
+import torch  # noqa: F401  (load order matters)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpvae_gfx950.so")
 
