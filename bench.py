@@ -104,10 +104,7 @@ def main():
             if dp.world == 1:
                 eng.train_step(phase, first, rows, sp, loss_out=loss_buf)
             else:
-                eng.gather(first, rows)
-                eng.forward_backward(phase, rows, sp, fused_adam=False, loss_out=loss_buf)
-                dp.all_reduce(eng.segment(eng.grads, nets))
-                eng.adam(nets, sp)
+                tr.dp_step(phase, nets, first, rows, sp, None, loss_buf)
             rows_done += grows
         return rows_done
 
@@ -139,7 +136,7 @@ def main():
                                "dim_action 45, batch 256/GPU, TE/MD/WM 4x1024, %s phase" % a.phase,
                    "phase": a.phase, "global_batch": a.batch * a.gpus,
                    "parallelism": "dp%d" % a.gpus, "optimizer": "Adam fused in wgrad" if a.gpus == 1
-                   else "RCCL all-reduce + flat Adam"},
+                   else "per-layer async RCCL all-reduce overlapped with backward + per-slice Adam"},
         "last_loss": last_loss,
     }
     fl_world, fl_joint = algorithmic_flops_per_sample(Db, Da, Z, W, D)

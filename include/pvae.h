@@ -146,6 +146,23 @@ int pvae_forward_backward(pvae_ctx* ctx, int phase, int32_t rows, const pvae_ste
  * all-reduce). */
 int pvae_adam(pvae_ctx* ctx, int net_mask, const pvae_step_params* sp, void* stream);
 
+/* Staged variant for data-parallel training (overlap of the gradient all-reduce with backward):
+ *   pvae_forward_seed          forward + loss partials + gradient seeds (no backward launches)
+ *   pvae_backward_stage(k)     launch k of the backward pass, k = 0 .. *num_stages-1 in order;
+ *                              [*ready_offset, +*ready_count) is the slice of the GRADIENT arena
+ *                              (net *ready_net) that is final after this stage (count 0: none) --
+ *                              the caller may start its all-reduce immediately; loss_out (may be
+ *                              NULL) is finalised by the last stage
+ *   pvae_adam_segment          Adam on one such slice once its reduction has completed
+ * Together they replace loss.backward() + optimizer.step() (tm:142-143) on N GPUs. */
+int pvae_forward_seed(pvae_ctx* ctx, int phase, int32_t rows, const pvae_step_params* sp, const float* eps,
+                      void* stream);
+int pvae_backward_stage(pvae_ctx* ctx, int phase, int32_t rows, const pvae_step_params* sp, int stage,
+                        float* loss_out, void* stream, int64_t* ready_offset, int64_t* ready_count,
+                        int* ready_net, int* num_stages);
+int pvae_adam_segment(pvae_ctx* ctx, int net, int64_t offset, int64_t count, const pvae_step_params* sp,
+                      void* stream);
+
 /* One whole optimizer step on the bound dataset: gather + forward/backward + Adam.
  * This is the body of the `for data in self.train_loader` loop (tm:137-144). */
 int pvae_train_step(pvae_ctx* ctx, int phase, int64_t first_window, int32_t rows,

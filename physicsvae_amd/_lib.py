@@ -58,6 +58,11 @@ _SIGS = {
     "pvae_forward_backward": (C.c_int, [_P, C.c_int, C.c_int32, C.POINTER(StepParams), _P, _P,
                                         C.c_int, _P]),
     "pvae_adam": (C.c_int, [_P, C.c_int, C.POINTER(StepParams), _P]),
+    "pvae_forward_seed": (C.c_int, [_P, C.c_int, C.c_int32, C.POINTER(StepParams), _P, _P]),
+    "pvae_backward_stage": (C.c_int, [_P, C.c_int, C.c_int32, C.POINTER(StepParams), C.c_int, _P, _P,
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int)]),
+    "pvae_adam_segment": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.POINTER(StepParams), _P]),
     "pvae_train_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P,
                                   _P]),
     "pvae_read_tensor": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P]),

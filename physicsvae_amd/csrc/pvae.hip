@@ -10,7 +10,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <new>
+#include <vector>
 
 #include "pvae_gemm.h"
 #include "pvae_layout.h"
@@ -344,117 +346,137 @@ static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st, const F
     return 0;
 }
 
+// A backward pass is a list of stages = launches in stream order.  `ready_*` names the slice of
+// the gradient arena that is final once the stage has run (data-parallel callers start that
+// slice's all-reduce right away, while later stages execute).
+struct Stage {
+    std::function<int()> run;
+    int64_t ready_off = 0, ready_cnt = 0;
+    int net = -1;
+};
+typedef std::vector<Stage> Plan;
+
 // dz[last] must be filled.  Layer by layer, last to first: the input gradient of layer i reads
 // W_i, then the weight gradient of layer i (+bias gradient, +Adam) may overwrite it.  When both
 // exist, dgrad_{i-1} (needs dz_{i-1}, W_{i-1}) and wgrad_i (needs dz_i, x_i; writes W_i) are
 // independent and go out as ONE horizontally fused launch:
 //     dgrad_L | dgrad_{L-1} + wgrad_L | ... | dgrad_1 + wgrad_2 | [dgrad_0] + wgrad_1 | wgrad_0
-// `fold` (optional) is executed by the layer-0 weight-gradient blocks.
-static int backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool input_grad,
-                        const pvae_step_params* sp, bool fused, hipStream_t st,
-                        const LossFinal* fold = nullptr) {
-    const NetLayout& N = c->L.net[n];
-    const NetWork& w = c->W.net[n];
+// (without an input gradient the two last weight gradients share a launch).  `fold` (optional)
+// is executed by the blocks of the last launch.
+static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool input_grad,
+                              const pvae_step_params* sp, bool fused, hipStream_t st, const LossFinal* fold,
+                              Plan& plan) {
+    const NetLayout* N = &c->L.net[n];
+    const NetWork* w = &c->W.net[n];
     const AdamScalars as = adam_scalars(sp, n);
-    const int last = (int)N.layers.size() - 1;
+    const int last = (int)N->layers.size() - 1;
     const bool pair = train && c->pair_launch;
+    const double rowsf = c->staged_rows_f;
+    const int need = n == PVAE_NET_WM ? c->L.cfg.dim_action : c->L.cfg.latent;
+    LossFinal foldv;
+    memset(&foldv, 0, sizeof(foldv));
+    if (fold) foldv = *fold;
 
+    auto has_dgrad = [=](int i) { return i > 0 || input_grad; };
+    auto seg_of = [=](int lo, int hi, Stage& s) {       // layers lo..hi (lo <= hi) of this net
+        s.ready_off = N->layers[lo].w_off;
+        s.ready_cnt = N->layers[hi].b_off + N->layers[hi].n_out_pad - N->layers[lo].w_off;
+        s.net = n;
+    };
     // dgrad of layer i: dz[i] (.) W_i -> dz[i-1] (masked) or d_in (i == 0, unmasked)
-    auto has_dgrad = [&](int i) { return i > 0 || input_grad; };
-    auto dgrad = [&](int i) -> int {
-        const Layer& l = N.layers[i];
-        const float* xin = i == 0 ? c->ws + w.in : c->ws + w.act[i - 1];
-        const int need = n == PVAE_NET_WM ? c->L.cfg.dim_action : c->L.cfg.latent;
-        const int ps = g_prof.begin(1, 2.0 * c->staged_rows_f * (i > 0 ? l.n_in : need) * l.n_out, st);
-        HIP_TRY(gemm_dgrad(c->ws + w.dz[i], l.n_out_pad, c->params + l.w_off, l.ld, i > 0 ? xin : nullptr, l.ld,
-                           i > 0 ? c->ws + w.dz[i - 1] : c->ws + w.d_in, l.ld, rows_pad, l.ld, l.n_out_pad, st));
+    auto dgrad = [=](int i) -> int {
+        const Layer& l = N->layers[i];
+        const float* xin = i == 0 ? c->ws + w->in : c->ws + w->act[i - 1];
+        const int ps = g_prof.begin(1, 2.0 * rowsf * (i > 0 ? l.n_in : need) * l.n_out, st);
+        HIP_TRY(gemm_dgrad(c->ws + w->dz[i], l.n_out_pad, c->params + l.w_off, l.ld, i > 0 ? xin : nullptr, l.ld,
+                           i > 0 ? c->ws + w->dz[i - 1] : c->ws + w->d_in, l.ld, rows_pad, l.ld, l.n_out_pad, st));
         g_prof.end(ps, st);
         return 0;
     };
+    auto adam_epi = [=](const Layer& l) {
+        EpiGradAdam e{c->params + l.w_off, c->m + l.w_off, c->v + l.w_off, l.ld, as};
+        e.b = c->params + l.b_off; e.bm = c->m + l.b_off; e.bv = c->v + l.b_off;
+        return e;
+    };
+    auto store_epi = [=](const Layer& l) {
+        EpiGradStore e{c->grads + l.w_off, l.ld};
+        e.gb = c->grads + l.b_off;
+        return e;
+    };
     // wgrad of layer i, optionally fused with the dgrad of layer j (j < 0: alone)
-    auto wgrad = [&](int i, int j) -> int {
-        const Layer& l = N.layers[i];
-        const float* dz = c->ws + w.dz[i];
-        const float* xin = i == 0 ? c->ws + w.in : c->ws + w.act[i - 1];
+    auto wgrad = [=](int i, int j, bool with_fold) -> int {
+        const Layer& l = N->layers[i];
+        const float* dz = c->ws + w->dz[i];
+        const float* xin = i == 0 ? c->ws + w->in : c->ws + w->act[i - 1];
         auto go = [&](auto e) -> int {
-            if (i == 0 && fold) e.loss = *fold;
+            if (with_fold) e.loss = foldv;
             if (j >= 0) {
-                const Layer& d = N.layers[j];
-                const float* dx_in = j == 0 ? c->ws + w.in : c->ws + w.act[j - 1];
-                const int need = n == PVAE_NET_WM ? c->L.cfg.dim_action : c->L.cfg.latent;
-                const int pp = g_prof.begin(3, 2.0 * c->staged_rows_f * ((double)l.n_in * l.n_out +
+                const Layer& d = N->layers[j];
+                const float* dx_in = j == 0 ? c->ws + w->in : c->ws + w->act[j - 1];
+                const int pp = g_prof.begin(3, 2.0 * rowsf * ((double)l.n_in * l.n_out +
                                                (double)(j > 0 ? d.n_in : need) * d.n_out), st);
-                HIP_TRY(gemm_bwd_pair(c->ws + w.dz[j], d.n_out_pad, c->params + d.w_off, d.ld, j > 0 ? dx_in : nullptr,
-                                      d.ld, j > 0 ? c->ws + w.dz[j - 1] : c->ws + w.d_in, d.ld, rows_pad, d.ld,
+                HIP_TRY(gemm_bwd_pair(c->ws + w->dz[j], d.n_out_pad, c->params + d.w_off, d.ld, j > 0 ? dx_in : nullptr,
+                                      d.ld, j > 0 ? c->ws + w->dz[j - 1] : c->ws + w->d_in, d.ld, rows_pad, d.ld,
                                       d.n_out_pad, dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
                 g_prof.end(pp, st);
             } else {
-                const int pw = g_prof.begin(2, 2.0 * c->staged_rows_f * l.n_in * l.n_out, st);
+                const int pw = g_prof.begin(2, 2.0 * rowsf * l.n_in * l.n_out, st);
                 HIP_TRY(gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
                 g_prof.end(pw, st);
             }
             return 0;
         };
-        if (fused) {
-            EpiGradAdam e{c->params + l.w_off, c->m + l.w_off, c->v + l.w_off, l.ld, as};
-            e.b = c->params + l.b_off; e.bm = c->m + l.b_off; e.bv = c->v + l.b_off;
-            return go(e);
-        }
-        EpiGradStore e{c->grads + l.w_off, l.ld};
-        e.gb = c->grads + l.b_off;
-        return go(e);
+        return fused ? go(adam_epi(l)) : go(store_epi(l));
+    };
+    auto wgrad_pair10 = [=](bool with_fold) -> int {    // layers 1 and 0 in one launch
+        const Layer& l1 = N->layers[1];
+        const Layer& l0 = N->layers[0];
+        const int pw2 = g_prof.begin(2, 2.0 * rowsf * ((double)l1.n_in * l1.n_out + (double)l0.n_in * l0.n_out), st);
+        auto go = [&](auto e1, auto e0) -> int {
+            if (with_fold) e1.loss = foldv;            // block 0 of the launch belongs to the first problem
+            HIP_TRY(gemm_wgrad_pair(c->ws + w->dz[1], l1.n_out_pad, c->ws + w->act[0], l1.ld, l1.n_out_pad, l1.ld, e1,
+                                    c->ws + w->dz[0], l0.n_out_pad, c->ws + w->in, l0.ld, l0.n_out_pad, l0.ld, e0,
+                                    rows_pad, st));
+            return 0;
+        };
+        const int rc = fused ? go(adam_epi(l1), adam_epi(l0)) : go(store_epi(l1), store_epi(l0));
+        g_prof.end(pw2, st);
+        return rc;
     };
 
-    int rc;
+    auto push = [&](std::function<int()> f) -> Stage& {
+        plan.emplace_back();
+        plan.back().run = std::move(f);
+        return plan.back();
+    };
     if (!train) {
         for (int i = last; i >= 0; --i)
-            if (has_dgrad(i) && (rc = dgrad(i))) return rc;
-        return 0;
+            if (has_dgrad(i)) push([=] { return dgrad(i); });
+        return;
     }
     if (!pair) {
         for (int i = last; i >= 0; --i) {
-            if (has_dgrad(i) && (rc = dgrad(i))) return rc;
-            if ((rc = wgrad(i, -1))) return rc;
+            if (has_dgrad(i)) push([=] { return dgrad(i); });
+            const bool f = fold && i == 0;
+            seg_of(i, i, push([=] { return wgrad(i, -1, f); }));
         }
-        return 0;
+        return;
     }
-    if (has_dgrad(last) && (rc = dgrad(last))) return rc;
+    if (has_dgrad(last)) push([=] { return dgrad(last); });
     for (int i = last; i >= 0; --i) {
         const int j = i - 1;                       // dgrad_{i-1} rides with wgrad_i
         if (j >= 0 && has_dgrad(j)) {
-            if ((rc = wgrad(i, j))) return rc;
+            const bool f = fold && i == 0;
+            seg_of(i, i, push([=] { return wgrad(i, j, f); }));
         } else if (i == 1 && !has_dgrad(0)) {
-            // no input gradient wanted: the two last weight gradients are independent -> one launch
-            const Layer& l1 = N.layers[1];
-            const Layer& l0 = N.layers[0];
-            const int pw2 = g_prof.begin(2, 2.0 * c->staged_rows_f * ((double)l1.n_in * l1.n_out +
-                                            (double)l0.n_in * l0.n_out), st);
-            if (fused) {
-                EpiGradAdam e1{c->params + l1.w_off, c->m + l1.w_off, c->v + l1.w_off, l1.ld, as};
-                e1.b = c->params + l1.b_off; e1.bm = c->m + l1.b_off; e1.bv = c->v + l1.b_off;
-                EpiGradAdam e0{c->params + l0.w_off, c->m + l0.w_off, c->v + l0.w_off, l0.ld, as};
-                e0.b = c->params + l0.b_off; e0.bm = c->m + l0.b_off; e0.bv = c->v + l0.b_off;
-                if (fold) e1.loss = *fold;         // block 0 of the launch belongs to the first problem
-                HIP_TRY(gemm_wgrad_pair(c->ws + w.dz[1], l1.n_out_pad, c->ws + w.act[0], l1.ld, l1.n_out_pad, l1.ld, e1,
-                                        c->ws + w.dz[0], l0.n_out_pad, c->ws + w.in, l0.ld, l0.n_out_pad, l0.ld, e0,
-                                        rows_pad, st));
-            } else {
-                EpiGradStore e1{c->grads + l1.w_off, l1.ld};
-                e1.gb = c->grads + l1.b_off;
-                EpiGradStore e0{c->grads + l0.w_off, l0.ld};
-                e0.gb = c->grads + l0.b_off;
-                if (fold) e1.loss = *fold;
-                HIP_TRY(gemm_wgrad_pair(c->ws + w.dz[1], l1.n_out_pad, c->ws + w.act[0], l1.ld, l1.n_out_pad, l1.ld, e1,
-                                        c->ws + w.dz[0], l0.n_out_pad, c->ws + w.in, l0.ld, l0.n_out_pad, l0.ld, e0,
-                                        rows_pad, st));
-            }
-            g_prof.end(pw2, st);
-            return 0;
+            const bool f = fold != nullptr;
+            seg_of(0, 1, push([=] { return wgrad_pair10(f); }));
+            return;
         } else {
-            if ((rc = wgrad(i, -1))) return rc;
+            const bool f = fold && i == 0;
+            seg_of(i, i, push([=] { return wgrad(i, -1, f); }));
         }
     }
-    return 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -616,21 +638,65 @@ int pvae_set_batch(pvae_ctx* c, const float* x, const float* y, int32_t rows, vo
     return stage(c, 0, x, y, rows, false, (hipStream_t)stream);
 }
 
-int pvae_forward_backward(pvae_ctx* c, int phase, int32_t rows, const pvae_step_params* sp, const float* eps,
-                          float* loss_out, int flags, void* stream) {
+}  // extern "C"
+
+// Everything a step needs that is a pure function of (phase, rows, step params).
+struct StepShape {
+    int rows_pad, wm_tiles, gridz, nparts_a;
+    float Bg;
+    bool cyc_grad, kl_active;
+    LossFinal lf;
+};
+
+static int step_shape(pvae_ctx* c, int phase, int rows, const pvae_step_params* sp, float* loss_out, bool backward,
+                      StepShape& S) {
+    const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
+    S.rows_pad = pad32(rows);
+    S.Bg = (float)(sp->global_rows > 0 ? sp->global_rows : rows);
+    S.wm_tiles = (S.rows_pad / 32) * (c->L.net[PVAE_NET_WM].layers.back().n_out_pad / 32);
+    if (S.wm_tiles > kLossParts) return fail(-1, "batch x dim_body too large for the loss partial buffer");
+    S.gridz = (S.rows_pad * Z + 255) / 256 < 64 ? (S.rows_pad * Z + 255) / 256 : 64;
+    S.nparts_a = S.rows_pad < 64 ? S.rows_pad : 64;
+    S.cyc_grad = backward && phase == PVAE_PHASE_JOINT && sp->cycle_coeff > 0.0f;
+    S.kl_active = phase == PVAE_PHASE_JOINT && sp->kl_coeff > 0.0f && sp->a_rec_coeff > 0.0f;   // tpv:381-384
+    float* part = c->ws + c->W.loss_part;
+    memset(&S.lf, 0, sizeof(S.lf));
+    for (int t = 0; t < 4; ++t) S.lf.part[t] = part + (t + 1) * kLossParts;
+    S.lf.out = loss_out;
+    S.lf.scale[0] = 1.0f / (S.Bg * Da); S.lf.scale[1] = 1.0f / S.Bg;
+    S.lf.scale[2] = 1.0f / (S.Bg * Db); S.lf.scale[3] = 1.0f / (S.Bg * Db);
+    S.lf.coeff[0] = sp->a_rec_coeff; S.lf.coeff[1] = sp->kl_coeff;
+    S.lf.coeff[2] = sp->s_rec_coeff; S.lf.coeff[3] = sp->cycle_coeff;
+    if (phase == PVAE_PHASE_WORLD) {
+        S.lf.nparts[2] = S.wm_tiles;
+    } else {
+        if (sp->a_rec_coeff > 0.0f) S.lf.nparts[0] = S.nparts_a;
+        if (S.kl_active) S.lf.nparts[1] = S.gridz;
+        if (sp->cycle_coeff > 0.0f) S.lf.nparts[3] = S.wm_tiles;
+    }
+    return 0;
+}
+
+static int check_step(pvae_ctx* c, int phase, int32_t rows, const pvae_step_params* sp, bool backward, bool fused) {
     int rc = check_ready(c, true);
     if (rc) return rc;
     if (!sp) return fail(-1, "null step params");
+    if (phase != PVAE_PHASE_WORLD && phase != PVAE_PHASE_JOINT) return fail(-1, "unknown phase %d", phase);
     if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
     if (rows != c->staged_rows) return fail(-2, "rows %d != staged rows %d", rows, c->staged_rows);
-    const bool backward = !(flags & PVAE_FLAG_NO_BACKWARD);
-    const bool fused = (flags & PVAE_FLAG_FUSED_ADAM) != 0;
     if (backward && fused && (!c->m || !c->v)) return fail(-2, "Adam moment arenas not bound");
     if (backward && !fused && !c->grads) return fail(-2, "gradient arena not bound");
-    hipStream_t st = (hipStream_t)stream;
-    const int rows_pad = pad32(rows);
+    if (phase == PVAE_PHASE_JOINT && sp->s_rec_coeff != 0.0f)
+        return fail(-4, "joint phase with world_model_s_rec_coeff != 0 is not supported "
+                        "(reference default is 0.0, tpv:284)");
+    return 0;
+}
+
+// Forward launches + loss partials + the gradient seed of the world model's output layer.
+static int run_forward(pvae_ctx* c, int phase, int rows, const pvae_step_params* sp, const float* eps, bool backward,
+                       const StepShape& S, hipStream_t st) {
+    int rc;
     const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
-    const float Bg = (float)(sp->global_rows > 0 ? sp->global_rows : rows);
     float* w = c->ws;
     float* part = w + c->W.loss_part;
     const NetLayout& TE = c->L.net[PVAE_NET_TE];
@@ -639,90 +705,157 @@ int pvae_forward_backward(pvae_ctx* c, int phase, int32_t rows, const pvae_step_
     const NetWork& wte = c->W.net[PVAE_NET_TE];
     const NetWork& wmd = c->W.net[PVAE_NET_MD];
     const NetWork& wwm = c->W.net[PVAE_NET_WM];
-    const int wm_out_pad = WM.layers.back().n_out_pad;
-    const int wm_tiles = (rows_pad / 32) * (wm_out_pad / 32);       // workgroups of the fused-MSE launch
-    if (wm_tiles > kLossParts) return fail(-1, "batch x dim_body too large for the loss partial buffer");
-    LossFinal lf;
-    memset(&lf, 0, sizeof(lf));
-    for (int t = 0; t < 4; ++t) lf.part[t] = part + (t + 1) * kLossParts;
-    lf.out = loss_out;
-    lf.scale[0] = 1.0f / (Bg * Da); lf.scale[1] = 1.0f / Bg;
-    lf.scale[2] = 1.0f / (Bg * Db); lf.scale[3] = 1.0f / (Bg * Db);
-    lf.coeff[0] = sp->a_rec_coeff; lf.coeff[1] = sp->kl_coeff;
-    lf.coeff[2] = sp->s_rec_coeff; lf.coeff[3] = sp->cycle_coeff;
-
     // world-model output layer fused with MSE(s2, .) and its gradient
     EpiMse mse;
     memset(&mse, 0, sizeof(mse));
     mse.target = w + c->W.s2; mse.ldt = pad64(Db);
-    mse.dz = backward ? w + wwm.dz.back() : nullptr; mse.ldz = wm_out_pad;
+    mse.dz = backward ? w + wwm.dz.back() : nullptr; mse.ldz = WM.layers.back().n_out_pad;
     mse.rows = rows; mse.D = Db;
     FwdTail wm_tail;
     wm_tail.mse = &mse;
-
     if (phase == PVAE_PHASE_WORLD) {
         // tpv:411-414: L = s_rec * MSE(s2, WM(s1, a_gt)); only the world model learns (tpv:326-329)
-        mse.grad_scale = sp->s_rec_coeff * 2.0f / (Bg * Db);
+        mse.grad_scale = sp->s_rec_coeff * 2.0f / (S.Bg * Db);
         mse.partial = part + 3 * kLossParts;
-        lf.nparts[2] = wm_tiles;
-        if ((rc = forward_net(c, PVAE_NET_WM, rows_pad, st, wm_tail))) return rc;
-        if (backward) {
-            if ((rc = backward_net(c, PVAE_NET_WM, rows_pad, true, false, sp, fused, st, loss_out ? &lf : nullptr)))
-                return rc;
-        }
-    } else if (phase == PVAE_PHASE_JOINT) {
-        if (sp->s_rec_coeff != 0.0f)
-            return fail(-4, "joint phase with world_model_s_rec_coeff != 0 is not supported "
-                            "(reference default is 0.0, tpv:284)");
-        // forward: TE -> sampler -> MD -> WM (rmt:742-771)
-        if ((rc = forward_net(c, PVAE_NET_TE, rows_pad, st))) return rc;
-        const int gridz = (rows_pad * Z + 255) / 256 < 64 ? (rows_pad * Z + 255) / 256 : 64;
-        hipLaunchKernelGGL(reparam_kernel, dim3(gridz), dim3(256), 0, st, w + wte.act.back(),
-                           TE.layers.back().n_out_pad, eps, w + c->W.eps, w + wmd.in, MD.layers[0].ld, Db, Z, rows,
-                           rows_pad, 1, (unsigned long long)sp->rng_seed, (unsigned long long)sp->rng_offset,
-                           part + 2 * kLossParts);
-        HIP_TRY(hipGetLastError());
-        if (sp->kl_coeff > 0.0f && sp->a_rec_coeff > 0.0f) lf.nparts[1] = gridz;      // tpv:381-384 nesting
-        FwdTail md_tail;                       // a_hat also lands in the action columns of the WM input
-        md_tail.out2 = w + wwm.in; md_tail.ld2 = WM.layers[0].ld; md_tail.off2 = Db; md_tail.n2 = Da;
-        if ((rc = forward_net(c, PVAE_NET_MD, rows_pad, st, md_tail))) return rc;
-        // cycle loss (tpv:417-419) fused into the world model's output layer
-        mse.grad_scale = sp->cycle_coeff * 2.0f / (Bg * Db);
-        mse.partial = part + 4 * kLossParts;
-        if (sp->cycle_coeff > 0.0f) lf.nparts[3] = wm_tiles;
-        if ((rc = forward_net(c, PVAE_NET_WM, rows_pad, st, wm_tail))) return rc;
-        const bool cyc_grad = backward && sp->cycle_coeff > 0.0f;
-        if (cyc_grad) {                        // gradient through the frozen world model (dgrad only)
-            if ((rc = backward_net(c, PVAE_NET_WM, rows_pad, false, true, sp, fused, st))) return rc;
-        }
-        // action reconstruction (tpv:381-382) + gradient arriving through the world model
-        const float ga = sp->a_rec_coeff * 2.0f / (Bg * Da);
-        const int nparts = rows_pad < 64 ? rows_pad : 64;
-        hipLaunchKernelGGL(mse_grad_kernel, dim3(nparts), dim3(256), 0, st, w + wmd.act.back(),
-                           MD.layers.back().n_out_pad, w + c->W.act_t, pad64(Da), backward ? w + wmd.dz.back() : nullptr,
-                           MD.layers.back().n_out_pad, rows, rows_pad, Da, ga,
-                           cyc_grad ? w + wwm.d_in : (const float*)nullptr, WM.layers[0].ld, Db,
-                           part + 1 * kLossParts);
-        HIP_TRY(hipGetLastError());
-        if (sp->a_rec_coeff > 0.0f) lf.nparts[0] = nparts;
-        if (backward) {
-            if ((rc = backward_net(c, PVAE_NET_MD, rows_pad, true, true, sp, fused, st))) return rc;
-            const float kls = lf.nparts[1] ? sp->kl_coeff / Bg : 0.0f;
-            const int tot = rows_pad * TE.layers.back().n_out_pad;
-            hipLaunchKernelGGL(reparam_bwd_kernel, dim3((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256), dim3(256), 0,
-                               st, w + wmd.d_in, MD.layers[0].ld, Db, w + wte.act.back(), TE.layers.back().n_out_pad,
-                               w + c->W.eps, w + wte.dz.back(), TE.layers.back().n_out_pad, rows, rows_pad, Z, kls);
+        return forward_net(c, PVAE_NET_WM, S.rows_pad, st, wm_tail);
+    }
+    // joint forward: TE -> sampler -> MD -> WM (rmt:742-771)
+    if ((rc = forward_net(c, PVAE_NET_TE, S.rows_pad, st))) return rc;
+    hipLaunchKernelGGL(reparam_kernel, dim3(S.gridz), dim3(256), 0, st, w + wte.act.back(),
+                       TE.layers.back().n_out_pad, eps, w + c->W.eps, w + wmd.in, MD.layers[0].ld, Db, Z, rows,
+                       S.rows_pad, 1, (unsigned long long)sp->rng_seed, (unsigned long long)sp->rng_offset,
+                       part + 2 * kLossParts);
+    HIP_TRY(hipGetLastError());
+    FwdTail md_tail;                           // a_hat also lands in the action columns of the WM input
+    md_tail.out2 = w + wwm.in; md_tail.ld2 = WM.layers[0].ld; md_tail.off2 = Db; md_tail.n2 = Da;
+    if ((rc = forward_net(c, PVAE_NET_MD, S.rows_pad, st, md_tail))) return rc;
+    // cycle loss (tpv:417-419) fused into the world model's output layer
+    mse.grad_scale = sp->cycle_coeff * 2.0f / (S.Bg * Db);
+    mse.partial = part + 4 * kLossParts;
+    return forward_net(c, PVAE_NET_WM, S.rows_pad, st, wm_tail);
+}
+
+// Everything after the forward pass, as stages.  (The action-reconstruction loss sits here: its
+// gradient needs what came back through the frozen world model.)
+static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_params* sp, bool backward, bool fused,
+                          const StepShape& S, hipStream_t st, Plan& plan) {
+    const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
+    float* w = c->ws;
+    float* part = w + c->W.loss_part;
+    const LossFinal* fold = S.lf.out ? &S.lf : nullptr;
+    if (phase == PVAE_PHASE_WORLD) {
+        if (backward) plan_backward_net(c, PVAE_NET_WM, S.rows_pad, true, false, sp, fused, st, fold, plan);
+        return;
+    }
+    const NetLayout* TE = &c->L.net[PVAE_NET_TE];
+    const NetLayout* MD = &c->L.net[PVAE_NET_MD];
+    const NetLayout* WM = &c->L.net[PVAE_NET_WM];
+    const NetWork* wte = &c->W.net[PVAE_NET_TE];
+    const NetWork* wmd = &c->W.net[PVAE_NET_MD];
+    const NetWork* wwm = &c->W.net[PVAE_NET_WM];
+    if (S.cyc_grad)                            // gradient through the frozen world model (dgrad only)
+        plan_backward_net(c, PVAE_NET_WM, S.rows_pad, false, true, sp, fused, st, nullptr, plan);
+    // action reconstruction (tpv:381-382) + gradient arriving through the world model
+    {
+        const float ga = sp->a_rec_coeff * 2.0f / (S.Bg * Da);
+        const int nparts = S.nparts_a, rows_pad = S.rows_pad;
+        const bool cyc = S.cyc_grad;
+        plan.emplace_back();
+        plan.back().run = [=]() -> int {
+            hipLaunchKernelGGL(mse_grad_kernel, dim3(nparts), dim3(256), 0, st, w + wmd->act.back(),
+                               MD->layers.back().n_out_pad, w + c->W.act_t, pad64(Da),
+                               backward ? w + wmd->dz.back() : nullptr, MD->layers.back().n_out_pad, rows, rows_pad,
+                               Da, ga, cyc ? w + wwm->d_in : (const float*)nullptr, WM->layers[0].ld, Db,
+                               part + 1 * kLossParts);
             HIP_TRY(hipGetLastError());
-            if ((rc = backward_net(c, PVAE_NET_TE, rows_pad, true, false, sp, fused, st, loss_out ? &lf : nullptr)))
-                return rc;
-        }
-    } else {
-        return fail(-1, "unknown phase %d", phase);
+            return 0;
+        };
     }
+    if (!backward) return;
+    plan_backward_net(c, PVAE_NET_MD, S.rows_pad, true, true, sp, fused, st, nullptr, plan);
+    {
+        const float kls = S.kl_active ? sp->kl_coeff / S.Bg : 0.0f;
+        const int rows_pad = S.rows_pad;
+        const int tot = rows_pad * TE->layers.back().n_out_pad;
+        plan.emplace_back();
+        plan.back().run = [=]() -> int {
+            hipLaunchKernelGGL(reparam_bwd_kernel, dim3((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256), dim3(256), 0,
+                               st, w + wmd->d_in, MD->layers[0].ld, Db, w + wte->act.back(), TE->layers.back().n_out_pad,
+                               w + c->W.eps, w + wte->dz.back(), TE->layers.back().n_out_pad, rows, rows_pad, Z, kls);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        };
+    }
+    plan_backward_net(c, PVAE_NET_TE, S.rows_pad, true, false, sp, fused, st, fold, plan);
+}
+
+extern "C" {
+
+int pvae_forward_backward(pvae_ctx* c, int phase, int32_t rows, const pvae_step_params* sp, const float* eps,
+                          float* loss_out, int flags, void* stream) {
+    const bool backward = !(flags & PVAE_FLAG_NO_BACKWARD);
+    const bool fused = (flags & PVAE_FLAG_FUSED_ADAM) != 0;
+    int rc = check_step(c, phase, rows, sp, backward, fused);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    StepShape S;
+    if ((rc = step_shape(c, phase, rows, sp, loss_out, backward, S))) return rc;
+    if ((rc = run_forward(c, phase, rows, sp, eps, backward, S, st))) return rc;
+    Plan plan;
+    plan_backward(c, phase, rows, sp, backward, fused, S, st, plan);
+    for (Stage& s : plan)
+        if ((rc = s.run())) return rc;
     if (loss_out && !backward) {
-        hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(64), 0, st, lf);
+        hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(64), 0, st, S.lf);
         HIP_TRY(hipGetLastError());
     }
+    return 0;
+}
+
+int pvae_forward_seed(pvae_ctx* c, int phase, int32_t rows, const pvae_step_params* sp, const float* eps,
+                      void* stream) {
+    int rc = check_step(c, phase, rows, sp, true, false);
+    if (rc) return rc;
+    StepShape S;
+    if ((rc = step_shape(c, phase, rows, sp, nullptr, true, S))) return rc;
+    return run_forward(c, phase, rows, sp, eps, true, S, (hipStream_t)stream);
+}
+
+int pvae_backward_stage(pvae_ctx* c, int phase, int32_t rows, const pvae_step_params* sp, int stage,
+                        float* loss_out, void* stream, int64_t* ready_offset, int64_t* ready_count,
+                        int* ready_net, int* num_stages) {
+    int rc = check_step(c, phase, rows, sp, true, false);
+    if (rc) return rc;
+    StepShape S;
+    if ((rc = step_shape(c, phase, rows, sp, loss_out, true, S))) return rc;
+    Plan plan;
+    plan_backward(c, phase, rows, sp, true, false, S, (hipStream_t)stream, plan);
+    if (num_stages) *num_stages = (int)plan.size();
+    if (stage < 0 || stage >= (int)plan.size()) return fail(-1, "stage %d outside [0, %d)", stage, (int)plan.size());
+    if (ready_offset) *ready_offset = plan[stage].ready_off;
+    if (ready_count) *ready_count = plan[stage].ready_cnt;
+    if (ready_net) *ready_net = plan[stage].net;
+    return plan[stage].run();
+}
+
+int pvae_adam_segment(pvae_ctx* c, int net, int64_t offset, int64_t count, const pvae_step_params* sp,
+                      void* stream) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!sp) return fail(-1, "null step params");
+    if (!c->grads || !c->m || !c->v) return fail(-2, "grads / Adam moment arenas not bound");
+    if (net < 0 || net >= PVAE_NUM_NETS) return fail(-1, "bad net id %d", net);
+    const NetLayout& N = c->L.net[net];
+    if (offset < N.off || count < 0 || offset + count > N.off + N.count || (offset & 3) || (count & 3))
+        return fail(-1, "segment [%lld, +%lld) not inside net %d or not float4-aligned", (long long)offset,
+                    (long long)count, net);
+    if (count == 0) return 0;
+    const long long n4 = count / 4;
+    int grid = (int)((n4 + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, c->params + offset,
+                       c->grads + offset, c->m + offset, c->v + offset, n4, adam_scalars(sp, net));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

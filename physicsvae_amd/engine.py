@@ -173,6 +173,32 @@ class HipEngine:
             out.data_ptr(), flags, self._stream()), "pvae_forward_backward")
         return out
 
+    def forward_seed(self, phase, rows, sp, eps=None):
+        self._need_gpu()
+        if eps is not None:
+            eps = eps.to(self.device, torch.float32).contiguous()
+            self._keep_eps = eps
+        _lib.check(self.lib.pvae_forward_seed(self.ctx, phase, int(rows), C.byref(sp),
+                                              eps.data_ptr() if eps is not None else None, self._stream()),
+                   "pvae_forward_seed")
+
+    def backward_stage(self, phase, rows, sp, stage, loss_out=None):
+        """Launch `stage` of the backward pass.  Returns (grad_slice | None, net, n_stages): the
+        slice of the gradient arena that is final after this stage."""
+        self._need_gpu()
+        off, cnt, net, n = C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
+        _lib.check(self.lib.pvae_backward_stage(
+            self.ctx, phase, int(rows), C.byref(sp), int(stage),
+            loss_out.data_ptr() if loss_out is not None else None, self._stream(),
+            C.byref(off), C.byref(cnt), C.byref(net), C.byref(n)), "pvae_backward_stage")
+        seg = (off.value, cnt.value) if cnt.value else None
+        return seg, net.value, n.value
+
+    def adam_segment(self, net, off, cnt, sp):
+        self._need_gpu()
+        _lib.check(self.lib.pvae_adam_segment(self.ctx, int(net), int(off), int(cnt), C.byref(sp), self._stream()),
+                   "pvae_adam_segment")
+
     def adam(self, nets, sp):
         self._need_gpu()
         mask = 0

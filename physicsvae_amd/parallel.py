@@ -48,6 +48,18 @@ class DataParallel:
         return tensor
 
 
+def _all_reduce_async(self, tensor):
+    """SUM all-reduce that returns a Work handle (None for a single process).  With the nccl
+    backend the collective is stream-ordered behind the kernels already queued on the current
+    stream, and `work.wait()` only makes the current stream wait for it."""
+    if self.world <= 1:
+        return None
+    return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+
+DataParallel.all_reduce_async = _all_reduce_async
+
+
 def init_from_env(backend=None):
     """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT).
     Returns (rank, world, local_rank).  No-op for a single process."""

@@ -237,20 +237,39 @@ class TrainModel(tune.Trainable):
             elif dp.world == 1:
                 eng.train_step(phase, first, rows, sp, eps=eps, loss_out=out[g])
             else:
-                seg = eng.segment(eng.grads, nets)
-                if rows:
-                    eng.gather(first, rows)
-                    eng.forward_backward(phase, rows, sp, eps=eps, fused_adam=False, loss_out=out[g])
-                else:
-                    seg.zero_()                   # empty shard of a ragged last global batch
-                dp.all_reduce(seg)
-                eng.adam(nets, sp)
+                self.dp_step(phase, nets, first, rows, sp, eps, out[g])
             if train:
                 self.optimizer.step()             # bookkeeping only (scheduler call order)
             self.global_batch += 1
         if dp.world > 1:
             dp.all_reduce(out)
         return out[:n_glob].cpu()                 # the single host sync of the epoch
+
+    def dp_step(self, phase, nets, first, rows, sp, eps, loss_out):
+        """One data-parallel optimizer step: every backward launch that finishes a layer's
+        gradient is followed at once by an asynchronous SUM all-reduce of that slice (RCCL runs
+        it on its own stream, behind the launch that produced it), the remaining launches keep
+        the GPU busy meanwhile, and Adam is applied slice by slice as the reductions complete."""
+        eng, dp = self.engine, self.dp
+        if not rows:                              # empty shard of a ragged last global batch
+            seg = eng.segment(eng.grads, nets)
+            seg.zero_()
+            dp.all_reduce(seg)
+            eng.adam(nets, sp)
+            return
+        eng.gather(first, rows)
+        eng.forward_seed(phase, rows, sp, eps=eps)
+        pending, k, n = [], 0, 1
+        while k < n:
+            seg, net, n = eng.backward_stage(phase, rows, sp, k, loss_out=loss_out)
+            if seg is not None:
+                off, cnt = seg
+                pending.append((net, off, cnt, dp.all_reduce_async(eng.grads[off: off + cnt])))
+            k += 1
+        for net, off, cnt, work in pending:
+            if work is not None:
+                work.wait()
+            eng.adam_segment(net, off, cnt, sp)
 
     # -- overridables, reference names ----------------------------------------------------
     def load_dataset(self, file):
