@@ -50,7 +50,10 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--phase", choices=["world", "joint"], default="world")
-    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=None, help="rows per GPU (default 256; 512 for --config c5)")
+    ap.add_argument("--config", choices=["c2", "c5"], default="c2",
+                    help="c2 = BASELINE configs[1..3] sizes (default); c5 = configs[4]: 1e6 transitions, "
+                         "dim_state_body 400, dim_action 90, 512 rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary-phase and roofline passes")
     a = ap.parse_args()
@@ -65,17 +68,40 @@ def main():
     from physicsvae_amd.engine import make_step_params
     from util import make_trainer
 
-    Db, Da, Z, W, D = 197, 45, 32, 1024, 4
-    arch = R.make_arch(Db, Da, latent=Z, te=(W, D), md=(W, D), wm=(W, D))
-    data = R.synth_demo(0, 10, 1000, Db, Da, kind="iid")
     import contextlib
     import io
+    Z, W, D = 32, 1024, 4
+    if a.config == "c2":
+        Db, Da = 197, 45
+        a.batch = a.batch or 256
+        data = R.synth_demo(0, 10, 1000, Db, Da, kind="iid")
+        workload = "BASELINE configs[1]: synthetic loco demo 10x1000, dim_state_body 197, dim_action 45"
+    else:
+        Db, Da = 400, 90
+        a.batch = a.batch or 512
+        data = R.synth_demo(0, 1, 4, Db, Da, kind="iid")        # placeholder file; the real set is built below
+        workload = "BASELINE configs[4]: synthetic demo 1000x1001 (1e6 transitions), dim_state_body 400, dim_action 90"
+    arch = R.make_arch(Db, Da, latent=Z, te=(W, D), md=(W, D), wm=(W, D))
     with contextlib.redirect_stdout(io.StringIO()):
         tr = make_trainer(arch, data, a.batch, m_world=10 ** 9, device=dev)
     sd = R.init_state_dict(arch, seed=1)
     tr.model.load_state_dict(sd)
     eng, dp = tr.engine, tr.dp
     ds = tr.train_loader.dataset
+    if a.config == "c5":
+        # 1000 episodes x 1001 steps in the packed layout the gather kernel reads (states stored
+        # once: 1.6 GB + 0.36 GB fp32); generated on the device, values ~N(0,1) / clipped actions
+        import numpy as np
+        from physicsvae_amd.train_physics_vae import WindowDataset
+        gen = torch.Generator(device=dev).manual_seed(0)
+        E, T = 1000, 1001
+        states = torch.randn(E * T, Db, generator=gen, device=dev)
+        actions = torch.randn(E * T, Da, generator=gen, device=dev).clamp_(-3, 3)
+        rows_idx = (torch.arange(E, device=dev)[:, None] * T + torch.arange(T - 1, device=dev)[None, :]).reshape(-1)
+        ds = WindowDataset(np.zeros((2, Db), np.float32), np.zeros((2, Da), np.float32), np.zeros(1, np.int32))
+        ds._dev = (states, actions, rows_idx.to(torch.int32))
+        ds.window_row = np.empty(E * (T - 1), dtype=np.int8)     # length only (host copy not needed)
+        tr.train_loader.dataset = ds
     eng.bind_dataset(*ds.device_arrays(eng.device))
     n_win = len(ds)
     steps_per_epoch = dp.global_steps(n_win, a.batch)
@@ -132,8 +158,7 @@ def main():
         "value": value, "unit": "samples/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: synthetic loco demo 10x1000, dim_state_body 197, "
-                               "dim_action 45, batch 256/GPU, TE/MD/WM 4x1024, %s phase" % a.phase,
+        "config": {"workload": "%s, batch %d/GPU, TE/MD/WM 4x1024, %s phase" % (workload, a.batch, a.phase),
                    "phase": a.phase, "global_batch": a.batch * a.gpus,
                    "parallelism": "dp%d" % a.gpus, "optimizer": "Adam fused in wgrad" if a.gpus == 1
                    else "per-layer async RCCL all-reduce overlapped with backward + per-slice Adam"},
@@ -188,7 +213,7 @@ def main():
                 summ = json.load(open(f))
                 key = {3: "bwd_pair_kernel<EpiMask,EpiGradAdam>", 2: "wgrad_pair_kernel<EpiGradAdam>",
                        0: "gemm_splitk_reg_kernel<P_ROW,EpiBiasAct>", 1: "gemm_splitk_reg_kernel<P_COL,EpiMask>"}[dom]
-                if key in summ and "hbm_traffic_MB" in summ[key] and dp.world == 1 and a.phase == "world":
+                if key in summ and "hbm_traffic_MB" in summ[key] and dp.world == 1 and a.phase == "world" and a.config == "c2":
                     traffic, traffic_src = summ[key]["hbm_traffic_MB"] * 1e6, os.path.relpath(f, ROOT)
                     break
         except Exception:
@@ -203,22 +228,24 @@ def main():
         out["gemm_time_share_of_step"] = sum(c["total_ms"] for c in cats.values()) / n_prof / ms_per_step
 
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
+        if a.config != "c2":
+            data = R.synth_demo(0, 10, 1000, Db, Da, kind="iid")   # bounded CPU sample of the same shape
         X, Y = R.build_windows(data)
-        n_b = 3 * 39
+        n_b = 3 * 39 if a.config == "c2" else 2 * (len(X) // a.batch)
         t0 = time.perf_counter()
         trc = R.RefTrainer(arch, sd, X, Y, a.batch, max_iter_world_model=(10 ** 9 if a.phase == "world" else 0))
         trc.step(max_batches=2)
         t1 = time.perf_counter()
-        done = 0
+        done, per = 0, min(39, len(X) // a.batch)
         while done < n_b:
-            trc.step(max_batches=min(39, n_b - done))
-            done += 39
+            trc.step(max_batches=min(per, n_b - done))
+            done += per
         dt = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": n_b * a.batch / dt, "unit": "samples/s",
                                "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": "%d minibatches of %d (3 passes over the first 39 full minibatches of the "
-                                         "same synthetic demo), %s phase, oracle/refpath.RefTrainer (stock torch "
-                                         "CPU ops in the reference's op order), %.1f s" % (n_b, a.batch, a.phase, dt),
+                               "sample": "%d minibatches of %d (passes over the full minibatches of a 10x1000 "
+                                         "synthetic demo of the same dims), %s phase, oracle/refpath.RefTrainer (stock "
+                                         "torch CPU ops in the reference's op order), %.1f s" % (n_b, a.batch, a.phase, dt),
                                "host_cpus": os.cpu_count()}
     if rank == 0:
         print(json.dumps(out))

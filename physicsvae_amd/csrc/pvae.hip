@@ -317,6 +317,44 @@ static int check_ready(const pvae_ctx* c, bool need_arenas) {
     return 0;
 }
 
+// Rollout-batch forward layer (rows <= 4; rmt:742-771 runs at B = 1 inside the 30 Hz control
+// loop): out[r][n] = act(sum_k x[r][k] W[n][k] + b[n]).  One wave per output feature streams its
+// weight row once with float4 loads (all 256 CUs busy: n_out/4 blocks of 4 waves), the R input
+// rows come from L1/L2, lanes split K and combine with a shuffle tree.  HBM/L2-bound: 4 B per
+// weight, ~2 flops per byte -- the tile kernels would push the same panel through 32 workgroups.
+template <int R>
+__global__ void __launch_bounds__(256)
+gemv_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W, int ldw,
+                 const float* __restrict__ bias, float* __restrict__ out, int ldo, int K, int relu,
+                 float* __restrict__ out2, int ld2, int off2, int n2) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const float* wrow = W + (size_t)n * ldw;
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const v4f wv = *reinterpret_cast<const v4f*>(wrow + k);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const v4f xv = *reinterpret_cast<const v4f*>(x + (size_t)r * ldx + k);
+            acc[r] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[r]))));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float v = acc[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) {
+            v += bias[n];
+            if (relu) v = fmaxf(v, 0.f);
+            out[(size_t)r * ldo + n] = v;
+            if (out2 && n < n2) out2[(size_t)r * ld2 + off2 + n] = v;
+        }
+    }
+}
+
 struct FwdTail {              // what the output layer's epilogue does besides bias
     const EpiMse* mse = nullptr;      // fused MSE loss + gradient
     float* out2 = nullptr;            // or: copy the first n2 output columns to out2[:, off2:]
@@ -330,7 +368,19 @@ static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st, const F
     for (const Layer& l : N.layers) {
         float* out = c->ws + c->W.net[n].act[l.index];
         const int ps = g_prof.begin(0, 2.0 * c->staged_rows_f * l.n_in * l.n_out, st);
-        if (l.last && tail.mse) {
+        const int rows = (int)c->staged_rows_f;
+        if (rows <= 4 && !tail.mse) {            // rollout batch: stream W once over all CUs
+            float* o2 = (l.last && tail.out2) ? tail.out2 : nullptr;
+            const dim3 grid(l.n_out_pad / 4), block(256);
+#define PVAE_GEMV(R)                                                                                        \
+    hipLaunchKernelGGL((gemv_rows_kernel<R>), grid, block, 0, st, x, ldx, c->params + l.w_off, l.ld,           \
+                       c->params + l.b_off, out, l.n_out_pad, l.ld, l.last ? 0 : 1, o2, tail.ld2, tail.off2, tail.n2)
+            if (rows == 1) PVAE_GEMV(1);
+            else if (rows == 2) PVAE_GEMV(2);
+            else PVAE_GEMV(4);
+#undef PVAE_GEMV
+            HIP_TRY(hipGetLastError());
+        } else if (l.last && tail.mse) {
             EpiMse e = *tail.mse;
             e.out = out; e.ldo = l.n_out_pad; e.bias = c->params + l.b_off;
             HIP_TRY(gemm_forward_epi(x, ldx, c->params + l.w_off, l.ld, rows_pad, l.n_out_pad, l.ld, e, st));

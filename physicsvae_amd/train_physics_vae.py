@@ -124,10 +124,74 @@ class WindowDataset(torch_models.DatasetBase):
         return self._dev
 
 
+PACK_MAGIC = b"PVAEDEMO1\n"
+
+
+def save_packed(dataset, path, meta=None):
+    """Write a WindowDataset as ONE mmap-able file: magic, a JSON header line (dims, counts,
+    byte offsets, the pickle's meta fields), then the raw little-endian arrays, each 64-byte
+    aligned: states fp32 [R][Db], actions fp32 [R][Da], window_row int32 [N].  This is the
+    layout the gather kernel reads from HBM, so loading is a straight copy (no float64 blow-up:
+    config 5's 6.4 GB of X/Y becomes 1.96 GB)."""
+    import json
+    arrays = [("states", dataset.states), ("actions", dataset.actions), ("window_row", dataset.window_row)]
+    header = {"version": 1, "dim_state_body": int(dataset.states.shape[1]),
+              "dim_action": int(dataset.actions.shape[1]), "n_rows": int(dataset.states.shape[0]),
+              "n_windows": int(len(dataset.window_row)), "meta": meta or {}}
+    pos = 4096                                   # header block is padded to 4 KB
+    for name, arr in arrays:
+        pos = (pos + 63) // 64 * 64
+        header[name] = {"offset": pos, "dtype": str(arr.dtype), "shape": list(arr.shape)}
+        pos += arr.nbytes
+    blob = PACK_MAGIC + json.dumps(header).encode() + b"\n"
+    assert len(blob) <= 4096, "header too large"
+    with open(path, "wb") as f:
+        f.write(blob.ljust(4096, b"\0"))
+        for name, arr in arrays:
+            f.seek(header[name]["offset"])
+            f.write(np.ascontiguousarray(arr).tobytes())
+    return path
+
+
+def load_packed(path):
+    """Memory-map a file written by save_packed (or tools/pack_demo.py) as a WindowDataset."""
+    import json
+    with open(path, "rb") as f:
+        head = f.read(4096)
+    if not head.startswith(PACK_MAGIC):
+        raise ValueError("%s is not a packed PhysicsVAE demonstration file" % path)
+    header = json.loads(head[len(PACK_MAGIC):].split(b"\n", 1)[0])
+    arrs = {}
+    for name in ("states", "actions", "window_row"):
+        h = header[name]
+        arrs[name] = np.memmap(path, mode="r", dtype=np.dtype(h["dtype"]), offset=h["offset"], shape=tuple(h["shape"]))
+    ds = WindowDataset(arrs["states"], arrs["actions"], arrs["window_row"])
+    ds.meta = header.get("meta", {})
+    return ds
+
+
 def load_dataset_for_PhysicsVAE(files, num_samples=None, lookahead=1, cond="abs", use_a_gt=False):
     """tpv:117-164.  Windows are emitted episode by episode, i ascending; `num_samples` caps the
-    total at exactly that many (tpv:137-138)."""
+    total at exactly that many (tpv:137-138).  Files ending in .pvd are packed demonstration
+    files (save_packed); anything else is the reference's pickle."""
     assert files and len(files) > 0
+    if all(str(f).endswith(".pvd") for f in files):
+        parts = [load_packed(f) for f in files]
+        for p_ in parts[1:]:                     # same compatibility rule as merge_dataset
+            assert p_.states.shape[1] == parts[0].states.shape[1] and p_.actions.shape[1] == parts[0].actions.shape[1]
+            for key in META_KEYS:
+                assert parts[0].meta.get(key) == p_.meta.get(key), "dataset meta mismatch on %r" % key
+        if len(parts) == 1 and num_samples is None:
+            ds = parts[0]
+        else:
+            offs = np.cumsum([0] + [len(p_.states) for p_ in parts[:-1]])
+            rows = np.concatenate([np.asarray(p_.window_row, dtype=np.int64) + o for p_, o in zip(parts, offs)])
+            if num_samples is not None:
+                rows = rows[:num_samples]
+            ds = WindowDataset(np.concatenate([p_.states for p_ in parts]),
+                               np.concatenate([p_.actions for p_ in parts]), rows.astype(np.int32))
+        print("Packed demonstrations:", files, "windows:", len(ds))
+        return ds
     if lookahead != 1:
         raise NotImplementedError("lookahead > 1 (the trainer hard-wires 1, tpv:277)")
     if cond != "abs":
@@ -149,6 +213,7 @@ def load_dataset_for_PhysicsVAE(files, num_samples=None, lookahead=1, cond="abs"
         rows.extend(range(base, base + n))
         base += T
     ds = WindowDataset(np.concatenate(states), np.concatenate(actions), np.asarray(rows, dtype=np.int32))
+    ds.meta = {k: data.get(k) for k in META_KEYS}
     print("------------------Data Loaded------------------")
     print("File:", files)
     print("Num Episodes:", len(episodes))
@@ -176,6 +241,10 @@ def gen_layers(width, depth, out_size="output", act_hidden="relu", act_out="line
 
 
 def inspect_dataset(path):
+    if str(path).endswith(".pvd"):
+        ds = load_packed(path)
+        db, da = ds.states.shape[1], ds.actions.shape[1]
+        return 2 * db, db, db, da
     with open(path, "rb") as f:
         ep0 = pickle.load(f)["episodes"][0]
     db, da = len(ep0["state_body"][0]), len(ep0["action"][0])

@@ -152,6 +152,36 @@ def test_single_batch_matches_oracle_and_golden(golden, name, world):
     assert seg.abs().double().sum().item() == pytest.approx(real, rel=1e-9)
 
 
+@pytest.mark.parametrize("world", [True, False])
+def test_config5_dims_single_batch_matches_oracle(world):
+    """BASELINE config 5 sizes: dim_state_body 400, dim_action 90, 512 rows per GPU, 4x1024."""
+    arch = R.make_arch(400, 90, latent=32, te=(1024, 4), md=(1024, 4), wm=(1024, 4))
+    data = R.synth_demo(0, 1, 520, 400, 90, kind="iid")
+    X, Y = R.build_windows(data)
+    x, y = next(iter(R.make_loader(X, Y, 512)))
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    eps = R.eps_stream(2, 32)(0, (512, 32))
+    tr = make_trainer(arch, data, 512, device=DEV)
+    tr.model.load_state_dict(sd)
+    keep = R.relu_kink_margin(arch, sd, x, y, eps, world) > 4e-6
+    x, y, eps = x[keep], y[keep], eps[keep]
+    rows = x.shape[0]
+    assert rows >= 384
+    want = R.loss_and_grads(arch, sd, x, y, eps, world)
+    c = R.phase_coeffs(world)
+    sp = make_step_params(lr=5e-4, a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"], s_rec=c["s_rec_coeff"],
+                          cyc=c["vae_cycle_coeff"], global_rows=rows)
+    eng = tr.engine
+    eng.set_batch(x, y)
+    loss = eng.forward_backward(_lib.PHASE_WORLD if world else _lib.PHASE_JOINT, rows, sp,
+                                eps=None if world else eps, fused_adam=False).cpu()
+    assert float(loss[0]) == pytest.approx(float(want["total"]), rel=1e-5)
+    gv = eng.named_views(eng.grads)
+    for k, gr in want["grads"].items():
+        assert max_err_scaled(gv[k].cpu(), gr) < 1e-4, k
+        assert rel_err(gv[k].cpu(), gr) < 1e-4, k
+
+
 def test_value_branch_and_frozen_nets_untouched(golden):
     g, arch, data, x, y, sd, eps, tr = _setup_single(golden, "single_tiny")
     before = tr.engine.params.clone()

@@ -177,6 +177,33 @@ def test_window_dataset_equals_oracle_windows(tmp_path):
         T.merge_dataset([pkl, pkl2])
 
 
+def test_packed_file_roundtrip_and_trainer_config(tmp_path):
+    data = R.synth_demo(0, 3, 21, 7, 3)
+    pkl = str(tmp_path / "d.pkl")
+    R.write_demo(pkl, data)
+    ds = T.load_dataset_for_PhysicsVAE([pkl])
+    pvd = str(tmp_path / "d.pvd")
+    T.save_packed(ds, pvd, meta=ds.meta)
+    back = T.load_dataset_for_PhysicsVAE([pvd])
+    assert not back.states.flags.owndata                          # mapped, not copied
+    np.testing.assert_array_equal(back.X, ds.X)
+    np.testing.assert_array_equal(back.Y, ds.Y)
+    assert back.meta["dim_action"] == 3 and back.meta["exp_std"] == 0.05
+    # caps and multi-file merges behave like the pickle path
+    X, _ = R.build_windows(data)
+    np.testing.assert_array_equal(T.load_dataset_for_PhysicsVAE([pvd], num_samples=25).X, X[:25])
+    np.testing.assert_array_equal(T.load_dataset_for_PhysicsVAE([pvd, pvd]).X[60:], X)
+    assert T.inspect_dataset(pvd) == T.inspect_dataset(pkl) == (14, 7, 7, 3)
+    # the converter CLI
+    out = str(tmp_path / "cli.pvd")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pack_demo.py"), pkl, "-o", out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    np.testing.assert_array_equal(T.load_packed(out).X, ds.X)
+    with pytest.raises(ValueError):
+        T.load_packed(pkl)
+
+
 def test_loader_schedule_is_sequential_with_partial_last_batch():
     data = R.synth_demo(0, 2, 14, 7, 3)
     arch = R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2))
