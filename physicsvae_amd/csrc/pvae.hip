@@ -703,7 +703,7 @@ static int step_shape(pvae_ctx* c, int phase, int rows, const pvae_step_params* 
     const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
     S.rows_pad = pad32(rows);
     S.Bg = (float)(sp->global_rows > 0 ? sp->global_rows : rows);
-    S.wm_tiles = (S.rows_pad / 32) * (c->L.net[PVAE_NET_WM].layers.back().n_out_pad / 32);
+    S.wm_tiles = forward_tiles(S.rows_pad, c->L.net[PVAE_NET_WM].layers.back().n_out_pad);
     if (S.wm_tiles > kLossParts) return fail(-1, "batch x dim_body too large for the loss partial buffer");
     S.gridz = (S.rows_pad * Z + 255) / 256 < 64 ? (S.rows_pad * Z + 255) / 256 : 64;
     S.nparts_a = S.rows_pad < 64 ? S.rows_pad : 64;

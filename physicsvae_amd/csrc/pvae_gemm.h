@@ -226,6 +226,101 @@ gemm_splitk_reg_kernel(GemmArgs ga, Epi epi) {
     splitk_reg_body<P_ROW, Epi, ABL>(lds, blockIdx.x, ga, epi);
 }
 
+// ---- forward, 16x16 tile per workgroup (narrow output layers) ----------------------------------
+// An output layer with few features (197 / 64 / 45 -> 8 or fewer 32-wide p-tiles) gives the 32x32
+// kernel under 128 workgroups: most CUs idle for a full K = 1024 pass.  Same algorithm on a
+// 16x16 tile (one MFMA tile per wave, two accumulators alternating over the k-steps so the
+// dependent-issue latency is covered; the 4 waves still split K): 4x the workgroups, each
+// streaming (16 + 16) rows.  4 flop/B, so it only pays when the grid would otherwise be small.
+template <class Epi>
+__device__ inline void splitk_reg16_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
+    constexpr int BK = 64, kTile = 16 * 64, kStage = 2 * kTile, D = 4;
+    const float* __restrict__ Q = ga.Q;
+    const float* __restrict__ P = ga.P;
+    const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
+
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int tile_p = xcd * ga.p_per_xcd + loc / tiles_q;
+    const int tile_q = loc % tiles_q;
+    if (tile_p >= tiles_p) return;
+    const int q0 = tile_q * 16, p0 = tile_p * 16;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15, lh = lane >> 4;
+
+    // one 16-byte chunk of each operand tile per thread: slot j = tid, row j>>4, chunk (j&15)^row
+    const int srow = tid >> 4, schunk = (tid & 15) ^ srow;
+    const float* sq = Q + (size_t)(q0 + srow) * ldq + schunk * 4;
+    const float* sp = P + (size_t)(p0 + srow) * ldp + schunk * 4;
+    const int slot_off = tid * 4;
+
+    v4f rg[D][2];
+    auto gload = [&](int t, v4f(&r)[2]) {
+        r[0] = *reinterpret_cast<const v4f*>(sq + (size_t)t * BK);
+        r[1] = *reinterpret_cast<const v4f*>(sp + (size_t)t * BK);
+    };
+    auto lwrite = [&](float* slot, const v4f(&r)[2]) {
+        *reinterpret_cast<v4f*>(slot + slot_off) = r[0];
+        *reinterpret_cast<v4f*>(slot + kTile + slot_off) = r[1];
+    };
+    v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+    const int of = li * 64 + (((4 * wave + lh) ^ li) << 2);
+
+    const int nk = K / BK;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nk) gload(d, rg[d]);
+    lwrite(lds, rg[0]);
+    if (D < nk) gload(D, rg[0]);
+    __syncthreads();
+
+    for (int t0 = 0; t0 < nk; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int t = t0 + d;
+            if (t < nk) {
+                const float* st = lds + (t & 1) * kStage;
+                const v4f fq = *reinterpret_cast<const v4f*>(st + of);
+                const v4f fp = *reinterpret_cast<const v4f*>(st + kTile + of);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    acc[s2 & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[s2], fq[s2], acc[s2 & 1], 0, 0, 0);
+                    if (s2 == 1 && t + 1 < nk) {
+                        lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
+                        if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D]);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // split-K reduction (fixed order) + epilogue: 64 threads x float4 cover the 16x16 tile
+    constexpr int RS = 20;
+    float* red = lds + wave * (16 * RS);
+    const v4f mine = acc[0] + acc[1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[li * RS + 4 * lh + r] = mine[r];
+    __syncthreads();
+    if (tid < 64) {
+        const int ql = tid >> 2, pl = (tid & 3) << 2;
+        v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (16 * RS) + ql * RS + pl);
+        epi(q0 + ql, p0 + pl, v);
+    }
+    epi.finish(lds, tile_q * tiles_p + tile_p, tid);
+}
+
+template <class Epi>
+__global__ void __launch_bounds__(256)
+gemm_splitk_reg16_kernel(GemmArgs ga, Epi epi) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * 16 * 64];
+    splitk_reg16_body<Epi>(lds, blockIdx.x, ga, epi);
+}
+
 // ---- wgrad: G[64 q][64 p] per workgroup, reduction over batch rows (BK = 32), both operands COL,
 // waves 2x2 with 32x32 each; the epilogue operands (Adam's p, m, v) are fetched under the loop --
 template <class Epi, int ABL = 0>
@@ -586,10 +681,22 @@ inline GemmGrid make_grid(int rows_q, int cols_p, int bq, int bp) {
     return g;
 }
 
+// narrow outputs: under 128 workgroups of 32x32 -> use 16x16 tiles (4x the workgroups)
+inline bool forward_uses_16x16(int M, int N) { return (M / 32) * (N / 32) < 128; }
+inline int forward_tiles(int M, int N) {
+    return forward_uses_16x16(M, N) ? (M / 16) * (N / 16) : (M / 32) * (N / 32);
+}
+
 // forward: out[M][N] = act(X[M][K] W[N][K]^T + b)
 template <class Epi>
 inline hipError_t gemm_forward_epi(const float* X, int ldx, const float* W, int ldw, int M, int N, int K,
                                    const Epi& e, hipStream_t st) {
+    if (forward_uses_16x16(M, N)) {
+        const GemmGrid g = make_grid(M, N, 16, 16);
+        hipLaunchKernelGGL((gemm_splitk_reg16_kernel<Epi>), dim3(g.grid), dim3(256), 0, st,
+                           GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+        return hipGetLastError();
+    }
     const GemmGrid g = make_grid(M, N, 32, 32);
     hipLaunchKernelGGL((gemm_splitk_reg_kernel<true, Epi>), dim3(g.grid), dim3(256), 0, st,
                        GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);

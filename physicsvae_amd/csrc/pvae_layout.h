@@ -88,7 +88,7 @@ struct Workspace {
     int64_t total_floats = 0;
 };
 
-constexpr int kLossParts = 1024;   // max workgroups contributing to one loss term
+constexpr int kLossParts = 8192;   // max workgroups contributing to one loss term
 
 inline Workspace make_workspace(const Layout& L) {
     Workspace W;
