@@ -13,6 +13,8 @@ def short(n):
     if "wgrad_pair" in n: return "wgrad_pair_kernel<EpiGradAdam>"
     if "bwd_pair" in n: return "bwd_pair_kernel<EpiMask,EpiGradAdam>"
     if "wgrad_reg" in n: return "gemm_wgrad_reg_kernel<EpiGradAdam>"
+    if "reg16" in n and "EpiMse" in n: return "gemm_splitk_reg16_kernel<EpiMse>"
+    if "reg16" in n: return "gemm_splitk_reg16_kernel<EpiBiasAct>"
     if "EpiMse" in n: return "gemm_splitk_reg_kernel<P_ROW,EpiMse>"
     if "EpiBiasAct" in n: return "gemm_splitk_reg_kernel<P_ROW,EpiBiasAct>"
     if "EpiMask" in n: return "gemm_splitk_reg_kernel<P_COL,EpiMask>"
