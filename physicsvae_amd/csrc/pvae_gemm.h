@@ -226,6 +226,193 @@ gemm_splitk_reg_kernel(GemmArgs ga, Epi epi) {
     splitk_reg_body<P_ROW, Epi, ABL>(lds, blockIdx.x, ga, epi);
 }
 
+// ---- forward / dgrad, wave-specialised LDS-DMA ring (512 threads) ----------------------------
+// 8 waves = 4 compute + 4 loaders.  The loaders only issue global_load_lds_dwordx4 (tiles land in
+// LDS without touching a VGPR) into a ring of kWsStages slots and certify "tile t+1 has landed"
+// at barrier t; the compute waves do nothing but ds_read_b128/b64 + MFMA, with the fragments of
+// tile t+1 read while the MFMAs of tile t run.  An LDS-DMA instruction costs ~150 issue cycles,
+// which is why it must not sit in the instruction stream that feeds the matrix pipe (a 4-wave
+// DMA ring measured 9.5 us for 256x1024x1024; this one 7.7 us; the register-staged loop 8.45).
+// Ring depth: 4 is the optimum on MI355X -- 3 starves, 5..8 get progressively slower (8: 8.5 us);
+// more requests in flight per CU do not help the L2 -> CU path, they hurt it.
+// Same LDS image / swizzles / split-K layout as splitk_reg_body, results are bit-identical.
+constexpr int kWsStages = 4;
+constexpr int kWsFloats = kWsStages * 2 * 32 * 64;       // 64 KB
+
+template <int N>
+__device__ inline void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ inline void lds_dma16(const float* src, float* dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+}
+// this wave's DMAs of a tile have landed once at most `younger` tiles (4 instructions each)
+// issued after it are still in flight
+__device__ inline void wait_dma_tile(int younger) {
+    switch (younger) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<4>(); break;
+        default: wait_vmcnt<8>(); break;          // kWsStages - 2 = 2 is the most that can be younger
+    }
+}
+
+template <bool P_ROW, class Epi>
+__device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
+    constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, S = kWsStages;
+    static_assert(S == 4, "wait_dma_tile is written for a 4-slot ring");
+    const float* __restrict__ Q = ga.Q;
+    const float* __restrict__ P = ga.P;
+    const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int tile_p = xcd * ga.p_per_xcd + loc / tiles_q;
+    const int tile_q = loc % tiles_q;
+    if (tile_p >= tiles_p) return;
+    const int q0 = tile_q * 32, p0 = tile_p * 32;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lh = lane >> 4;
+    const int nk = K / BK;
+    v4f acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    if (wave >= 4) {
+        // ---------------- loader waves ----------------
+        const int u0 = wave - 4;
+        const float* sq[2];
+        const float* sp[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = (u0 + 4 * u) * 64 + lane;       // 16-byte slot inside the 8 KB tile image
+            {
+                const int row = j >> 4, c = (j & 15) ^ (row & 15);
+                sq[u] = Q + (size_t)(q0 + row) * ldq + c * 4;
+            }
+            if (P_ROW) {
+                const int row = j >> 4, c = (j & 15) ^ (row & 15);
+                sp[u] = P + (size_t)(p0 + row) * ldp + c * 4;
+            } else {
+                const int r = j >> 3, k = r ^ ((r >> 2) & 1);
+                sp[u] = P + (size_t)k * ldp + p0 + (j & 7) * 4;
+            }
+        }
+        const size_t kstep_p = P_ROW ? (size_t)BK : (size_t)BK * ldp;
+        auto issue = [&](int t) {
+            float* slot = lds + (t % S) * kStage;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                lds_dma16(sq[u] + (size_t)t * BK, slot + (u0 + 4 * u) * 256);
+                lds_dma16(sp[u] + (size_t)t * kstep_p, slot + kTile + (u0 + 4 * u) * 256);
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < S - 1; ++t)
+            if (t < nk) issue(t);
+        wait_dma_tile(nk - 1 < S - 2 ? nk - 1 : S - 2);          // tile 0 landed
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nk; ++t) {
+            // tile t+1 landed: younger tiles in flight = t+2 .. min(t+S-2, nk-1)
+            int y = nk - 2 - t;
+            if (y > S - 3) y = S - 3;
+            if (y < 0) y = 0;
+            wait_dma_tile(y);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + S - 1 < nk) issue(t + S - 1);                  // refill the slot tile t-1 vacated
+        }
+    } else {
+        // ---------------- compute waves ----------------
+        int oq[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int row = 16 * a + li;
+            oq[a] = row * 64 + (((4 * wave + lh) ^ (row & 15)) << 2);
+        }
+        const int kq = 16 * wave + 4 * lh;
+        struct Frag { v4f q[2], p[2]; v2f c[4]; };
+        auto fread = [&](const float* st, Frag& f) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) f.q[a] = *reinterpret_cast<const v4f*>(st + oq[a]);
+            if (P_ROW) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) f.p[b] = *reinterpret_cast<const v4f*>(st + kTile + oq[b]);
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+                    f.c[s2] = *reinterpret_cast<const v2f*>(st + kTile + (((kq + s2) ^ (lh & 1)) * 32) + 2 * li);
+            }
+        };
+        auto mfmas = [&](const Frag& f) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const float pv = P_ROW ? f.p[b][s2] : f.c[s2][b];
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, f.q[a][s2], acc[a][b], 0, 0, 0);
+                    }
+        };
+        __builtin_amdgcn_s_barrier();                              // tile 0 landed
+        asm volatile("" ::: "memory");
+        Frag F0, F1;
+        fread(lds, F0);
+        for (int t0 = 0; t0 < nk; t0 += 2) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const int t = t0 + d;
+                if (t < nk) {
+                    Frag& F = d ? F1 : F0;
+                    Frag& Gf = d ? F0 : F1;
+                    __builtin_amdgcn_s_barrier();                  // tile t+1 landed; tile t-1's slot is free
+                    asm volatile("" ::: "memory");
+                    fread(lds + ((t + 1) % S) * kStage, Gf);       // (past the end: stale slot, never used)
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(F);
+                }
+            }
+        }
+    }
+    // split-K reduction through LDS (fixed order: compute wave 0..3), epilogue on float4s by the
+    // 256 compute threads; every wave takes part in the barriers
+    __syncthreads();
+    constexpr int RS = 36;
+    if (wave < 4) {
+        float* red = lds + wave * (32 * RS);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = 16 * a + li;
+                    const int pl = P_ROW ? (16 * b + 4 * lh + r) : (8 * lh + 2 * r + b);
+                    red[ql * RS + pl] = acc[a][b][r];
+                }
+    }
+    __syncthreads();
+    if (wave < 4) {
+        const int ql = tid >> 3, pl = (tid & 7) << 2;
+        v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (32 * RS) + ql * RS + pl);
+        epi(q0 + ql, p0 + pl, v);
+    }
+    epi.finish(lds, tile_q * tiles_p + tile_p, tid);
+}
+
+template <bool P_ROW, class Epi>
+__global__ void __launch_bounds__(512)
+gemm_splitk_ws_kernel(GemmArgs ga, Epi epi) {
+    __shared__ __attribute__((aligned(16))) float lds[kWsFloats];
+    splitk_ws_body<P_ROW, Epi>(lds, blockIdx.x, ga, epi);
+}
+
 // ---- forward, 16x16 tile per workgroup (narrow output layers) ----------------------------------
 // An output layer with few features (197 / 64 / 45 -> 8 or fewer 32-wide p-tiles) gives the 32x32
 // kernel under 128 workgroups: most CUs idle for a full K = 1024 pass.  Same algorithm on a
@@ -468,6 +655,8 @@ wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2) {
     else wgrad_reg_body<EpiW>(lds, blockIdx.x - n1, g2, e2);
 }
 
+// (The dgrad half stays on the register-staged body here: with the wave-specialised body the
+// pair needs 512-thread blocks and 64 KB of LDS per workgroup and measured 15 % slower.)
 template <class EpiD, class EpiW>
 __global__ void __launch_bounds__(256)
 bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew) {
@@ -479,13 +668,16 @@ bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew) {
 // ---------------------------------------------------------------------------------------
 // epilogues: (q, p, 4 consecutive p values)
 // ---------------------------------------------------------------------------------------
+// sum over a block of 256 or 512 threads (fixed order: deterministic)
 __device__ inline float block_sum_256(float v, float* scratch) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     __syncthreads();
-    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    float s = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    if (blockDim.x > 256) s += (scratch[4] + scratch[5]) + (scratch[6] + scratch[7]);
+    return s;
 }
 
 struct EpiBiasAct {           // forward layer: out = act(acc + bias)
@@ -698,7 +890,7 @@ inline hipError_t gemm_forward_epi(const float* X, int ldx, const float* W, int 
         return hipGetLastError();
     }
     const GemmGrid g = make_grid(M, N, 32, 32);
-    hipLaunchKernelGGL((gemm_splitk_reg_kernel<true, Epi>), dim3(g.grid), dim3(256), 0, st,
+    hipLaunchKernelGGL((gemm_splitk_ws_kernel<true, Epi>), dim3(g.grid), dim3(512), 0, st,
                        GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
     return hipGetLastError();
 }
@@ -712,7 +904,7 @@ inline hipError_t gemm_dgrad(const float* dZ, int ldz, const float* W, int ldw, 
                              int ldm, float* dX, int ldo, int M, int Kin, int N, hipStream_t st) {
     const EpiMask e{dX, ldo, mask, ldm};
     const GemmGrid g = make_grid(M, Kin, 32, 32);
-    hipLaunchKernelGGL((gemm_splitk_reg_kernel<false, EpiMask>), dim3(g.grid), dim3(256), 0, st,
+    hipLaunchKernelGGL((gemm_splitk_ws_kernel<false, EpiMask>), dim3(g.grid), dim3(512), 0, st,
                        GemmArgs{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
     return hipGetLastError();
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cmath>
 #include "../physicsvae_amd/csrc/pvae_gemm.h"
 #include "gemm_dma_ring.h"
 using namespace pvae;
@@ -48,6 +49,28 @@ template <int ABL> float run_reg(bool prow, const float* X, const float* W, floa
     float ms; hipEventElapsedTime(&ms, a, b);
     return ms * 1e3f / iters;
 }
+template <int ST> float run_ws(bool prow, const float* X, const float* W, float* out, int M, int N, int K, hipStream_t st, int iters) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    const GemmGrid g = make_grid(M, N, 32, 32);
+    EpiBiasAct e{out, N, nullptr, 1};
+    auto go = [&]() {
+        if (prow) hipLaunchKernelGGL((gemm_splitk_wsN_kernel<true, ST, EpiBiasAct>), dim3(g.grid), dim3(512), 0, st, GemmArgs{X, K, W, K, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+        else hipLaunchKernelGGL((gemm_splitk_wsN_kernel<false, ST, EpiBiasAct>), dim3(g.grid), dim3(512), 0, st, GemmArgs{X, K, W, N, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+    };
+    for (int i = 0; i < 20; ++i) go();
+    hipStreamSynchronize(st);
+    hipEventRecord(a, st);
+    for (int i = 0; i < iters; ++i) go();
+    hipEventRecord(b, st); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    return ms * 1e3f / iters;
+}
+// max |a-b| between two device buffers (n floats)
+static float max_diff(const float* a, const float* b, size_t n) {
+    std::vector<float> ha(n), hb(n);
+    hipMemcpy(ha.data(), a, n * 4, hipMemcpyDeviceToHost); hipMemcpy(hb.data(), b, n * 4, hipMemcpyDeviceToHost);
+    float m = 0; for (size_t i = 0; i < n; ++i) { float d = fabsf(ha[i] - hb[i]); if (d > m) m = d; } return m;
+}
 template <int ABL> float run_wgrad(const float* dZ, const float* X, float* out, int M, int N, int K, hipStream_t st, int iters) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const GemmGrid g = make_grid(N, K, 64, 64);
@@ -82,7 +105,26 @@ int main() {
            run_reg<0>(true, X, W, out, M, N, 4096, st, it), run_reg<1>(true, X, W, out, M, N, 4096, st, it),
            run_reg<2>(true, X, W, out, M, N, 4096, st, it), run_reg<4>(true, X, W, out, M, N, 4096, st, it),
            run_reg<11>(true, X, W, out, M, N, 4096, st, it));
-    for (int pad : {0, 16, 32, 64, 96}) {
+    printf("\nWS(8 stages) fwd 256x1024, K sweep: ");
+    for (int K : {256, 448, 1024, 2048, 4096}) printf("K=%d %.2fus  ", K, run_ws<8>(true, X, W, out, M, N, K, st, it));
+    printf("\nWS(8 stages) dgrad 256x1024, K sweep: ");
+    for (int K : {256, 448, 1024, 2048, 4096}) printf("K=%d %.2fus  ", K, run_ws<8>(false, X, W, out, M, N, K, st, it));
+    printf("\nWS stage sweep, K=1024 fwd/dgrad, K=4096 fwd: ");
+    printf(" S=3 %.2f/%.2f/%.2f", run_ws<3>(true, X, W, out, M, N, 1024, st, it), run_ws<3>(false, X, W, out, M, N, 1024, st, it), run_ws<3>(true, X, W, out, M, N, 4096, st, it));
+    printf(" S=4 %.2f/%.2f/%.2f", run_ws<4>(true, X, W, out, M, N, 1024, st, it), run_ws<4>(false, X, W, out, M, N, 1024, st, it), run_ws<4>(true, X, W, out, M, N, 4096, st, it));
+    printf(" S=5 %.2f/%.2f/%.2f", run_ws<5>(true, X, W, out, M, N, 1024, st, it), run_ws<5>(false, X, W, out, M, N, 1024, st, it), run_ws<5>(true, X, W, out, M, N, 4096, st, it));
+    printf(" S=6 %.2f/%.2f/%.2f", run_ws<6>(true, X, W, out, M, N, 1024, st, it), run_ws<6>(false, X, W, out, M, N, 1024, st, it), run_ws<6>(true, X, W, out, M, N, 4096, st, it));
+    {   // correctness of WS vs REG on the same data
+        run_reg<0>(true, X, W, out, M, N, 1024, st, 1); 
+        run_ws<8>(true, X, W, big, M, N, 1024, st, 1);
+        hipDeviceSynchronize();
+        printf("\nWS vs REG fwd max|diff| = %g", max_diff(out, big, (size_t)M * N));
+        run_reg<0>(false, X, W, out, M, N, 1024, st, 1);
+        run_ws<8>(false, X, W, big, M, N, 1024, st, 1);
+        hipDeviceSynchronize();
+        printf(" ; dgrad max|diff| = %g", max_diff(out, big, (size_t)M * N));
+    }
+    for (int pad : {0}) {
         g_pad = pad;
         printf("\npitch +%d floats:  DMA fwd K=1024 %.2f K=4096 %.2f | REG fwd K=1024 %.2f K=4096 %.2f | DMA dgrad K=1024 %.2f | REG dgrad K=1024 %.2f | DMA-only(no MFMA/LDS) K=4096 %.2f | REG stage-only %.2f",
                pad, run_fwd<0>(true, X, W, out, M, N, 1024, st, it, true), run_fwd<0>(true, X, W, out, M, N, 4096, st, it, true),

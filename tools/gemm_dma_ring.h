@@ -6,16 +6,6 @@
 #pragma once
 namespace pvae {
 
-template <int N>
-__device__ inline void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-__device__ inline void lds_dma16(const float* src, float* dst_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
-}
-
 template <int STAGES, int G>
 __device__ inline void wait_tile_landed(int younger_in_flight) {
     // tile t of this wave has landed once at most `younger_in_flight` tiles (G DMA instructions
@@ -289,6 +279,161 @@ gemm_wgrad_kernel(const float* __restrict__ Q, int ldq, const float* __restrict_
         }
     }
     if (epi.loss.out && bid == 0 && wave == 3) finalize_loss_wave(epi.loss, lane);
+}
+
+// ---- wave-specialised LDS-DMA ring: 8 waves = 4 compute (split K, ds_read + MFMA only, fragments
+// double-buffered in registers) + 4 loaders (global_load_lds only).  The loaders run one tile ahead
+// of what the compute waves read, STAGES-1 tiles ahead in flight.
+template <bool P_ROW, int STAGES, class Epi>
+__global__ void __launch_bounds__(512)
+gemm_splitk_wsN_kernel(GemmArgs ga, Epi epi) {
+    constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, G = 4;
+    const float* __restrict__ Q = ga.Q;
+    const float* __restrict__ P = ga.P;
+    const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int tile_p = xcd * ga.p_per_xcd + loc / tiles_q;
+    const int tile_q = loc % tiles_q;
+    if (tile_p >= tiles_p) return;
+    const int q0 = tile_q * 32, p0 = tile_p * 32;
+
+    __shared__ __attribute__((aligned(16))) float lds[STAGES * kStage];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lh = lane >> 4;
+    const int nk = K / BK;
+
+    if (wave >= 4) {
+        // ---------------- loader waves ----------------
+        const int u0 = wave - 4;
+        const float* sq[2];
+        const float* sp[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = (u0 + 4 * u) * 64 + lane;
+            {
+                const int row = j >> 4, c = (j & 15) ^ (row & 15);
+                sq[u] = Q + (size_t)(q0 + row) * ldq + c * 4;
+            }
+            if (P_ROW) {
+                const int row = j >> 4, c = (j & 15) ^ (row & 15);
+                sp[u] = P + (size_t)(p0 + row) * ldp + c * 4;
+            } else {
+                const int r = j >> 3, k = r ^ ((r >> 2) & 1);
+                sp[u] = P + (size_t)k * ldp + p0 + (j & 7) * 4;
+            }
+        }
+        const size_t kstep_p = P_ROW ? (size_t)BK : (size_t)BK * ldp;
+        auto issue = [&](int t) {
+            float* slot = lds + (t % STAGES) * kStage;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                lds_dma16(sq[u] + (size_t)t * BK, slot + (u0 + 4 * u) * 256);
+                lds_dma16(sp[u] + (size_t)t * kstep_p, slot + kTile + (u0 + 4 * u) * 256);
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < STAGES - 1; ++t)
+            if (t < nk) issue(t);
+        {   // tile 0 landed
+            const int y = nk - 1 < STAGES - 2 ? nk - 1 : STAGES - 2;
+            wait_tile_landed<STAGES, G>(y);
+        }
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nk; ++t) {
+            // tile t+1 landed: younger tiles in flight = t+2 .. min(t+STAGES-2, nk-1)
+            int y = nk - 2 - t;
+            if (y > STAGES - 3) y = STAGES - 3;
+            if (y < 0) y = 0;
+            wait_tile_landed<STAGES, G>(y);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + STAGES - 1 < nk) issue(t + STAGES - 1);
+        }
+        __syncthreads();
+        __syncthreads();
+        return;
+    }
+
+    // ---------------- compute waves ----------------
+    int oq[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int row = 16 * a + li;
+        oq[a] = row * 64 + (((4 * wave + lh) ^ (row & 15)) << 2);
+    }
+    const int kq = 16 * wave + 4 * lh;
+    struct Frag { v4f q[2], p[2]; v2f c[4]; };
+    auto fread = [&](const float* st, Frag& f) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) f.q[a] = *reinterpret_cast<const v4f*>(st + oq[a]);
+        if (P_ROW) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) f.p[b] = *reinterpret_cast<const v4f*>(st + kTile + oq[b]);
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+                f.c[s2] = *reinterpret_cast<const v2f*>(st + kTile + (((kq + s2) ^ (lh & 1)) * 32) + 2 * li);
+        }
+    };
+    v4f acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+    auto mfmas = [&](const Frag& f) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float pv = P_ROW ? f.p[b][s2] : f.c[s2][b];
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, f.q[a][s2], acc[a][b], 0, 0, 0);
+                }
+    };
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    Frag F0, F1;
+    fread(lds, F0);
+    for (int t0 = 0; t0 < nk; t0 += 2) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int t = t0 + d;
+            if (t < nk) {
+                Frag& F = d ? F1 : F0;
+                Frag& Gf = d ? F0 : F1;
+                __builtin_amdgcn_s_barrier();          // tile t+1 landed (all loaders), tile t-1's slot is free
+                asm volatile("" ::: "memory");
+                fread(lds + ((t + 1) % STAGES) * kStage, Gf);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(F);
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int RS = 36;
+    float* red = lds + wave * (32 * RS);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = 16 * a + li;
+                const int pl = P_ROW ? (16 * b + 4 * lh + r) : (8 * lh + 2 * r + b);
+                red[ql * RS + pl] = acc[a][b][r];
+            }
+    __syncthreads();
+    {
+        const int ql = tid >> 3, pl = (tid & 7) << 2;
+        v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (32 * RS) + ql * RS + pl);
+        epi(q0 + ql, p0 + pl, v);
+    }
 }
 
 }  // namespace pvae

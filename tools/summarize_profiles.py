@@ -15,6 +15,9 @@ def short(n):
     if "wgrad_reg" in n: return "gemm_wgrad_reg_kernel<EpiGradAdam>"
     if "reg16" in n and "EpiMse" in n: return "gemm_splitk_reg16_kernel<EpiMse>"
     if "reg16" in n: return "gemm_splitk_reg16_kernel<EpiBiasAct>"
+    if "splitk_ws" in n and "EpiMse" in n: return "gemm_splitk_ws_kernel<P_ROW,EpiMse>"
+    if "splitk_ws" in n and "EpiBiasAct" in n: return "gemm_splitk_ws_kernel<P_ROW,EpiBiasAct>"
+    if "splitk_ws" in n and "EpiMask" in n: return "gemm_splitk_ws_kernel<P_COL,EpiMask>"
     if "EpiMse" in n: return "gemm_splitk_reg_kernel<P_ROW,EpiMse>"
     if "EpiBiasAct" in n: return "gemm_splitk_reg_kernel<P_ROW,EpiBiasAct>"
     if "EpiMask" in n: return "gemm_splitk_reg_kernel<P_COL,EpiMask>"
