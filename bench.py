@@ -65,7 +65,6 @@ def main():
     dev = "cuda:%d" % local
 
     from oracle import refpath as R          # synthetic data generator + the CPU-baseline leg only
-    from physicsvae_amd.engine import make_step_params
     from util import make_trainer
 
     import contextlib

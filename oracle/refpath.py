@@ -24,7 +24,6 @@ checks this restatement against them.  The reference ships no tests or golden ve
 its own, so those captures are the pin.
 """
 import math
-import os
 import pickle
 import time
 from collections import OrderedDict

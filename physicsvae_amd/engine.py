@@ -4,13 +4,11 @@ PyTorch is used for what it is good at here: device memory, streams, `torch.save
 arithmetic of the hot path happens in libpvae_gfx950.so (physicsvae_amd/csrc).
 """
 import ctypes as C
-import math
 
 import torch
 
 from . import _lib
-from ._lib import (FLAG_FUSED_ADAM, FLAG_NO_BACKWARD, NET_MD, NET_NAMES, NET_TE, NET_WM,
-                   PHASE_JOINT, PHASE_WORLD)
+from ._lib import FLAG_FUSED_ADAM, FLAG_NO_BACKWARD, NET_MD, NET_NAMES, NET_TE, NET_WM
 
 TENSOR_IDS = {"mu": 0, "logvar": 1, "z": 2, "a_hat": 3, "s2_hat": 4, "eps": 5}
 

@@ -23,7 +23,6 @@ from collections import OrderedDict
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ._lib import NET_MD, NET_NAMES, NET_TE, NET_WM
 from .engine import Arch, HipEngine

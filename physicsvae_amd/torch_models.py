@@ -24,7 +24,6 @@ import torch.optim as optim
 
 from . import parallel, tune
 from ._lib import NET_MD, NET_TE, NET_WM, PHASE_JOINT, PHASE_WORLD
-from .engine import make_step_params
 
 EPSILON = np.finfo(np.float32).eps
 

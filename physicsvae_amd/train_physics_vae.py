@@ -18,7 +18,6 @@ import numpy as np
 import torch
 
 from . import torch_models, tune
-from ._lib import NET_MD, NET_TE, NET_WM, PHASE_JOINT, PHASE_WORLD
 from .engine import make_step_params
 from .model import PhysicsVAE, fc_spec
 from .spaces import Box

@@ -182,6 +182,60 @@ def test_config5_dims_single_batch_matches_oracle(world):
         assert rel_err(gv[k].cpu(), gr) < 1e-4, k
 
 
+@pytest.mark.parametrize("rows", [1, 33, 63])
+def test_odd_minibatch_sizes_full_step(golden, rows):
+    """Row counts that are not tile multiples (1 row crashes the reference itself, App. C-5):
+    loss and the post-Adam parameters of one fused optimizer step vs the oracle."""
+    g, arch, data, x, y, sd, eps, tr = _setup_single(golden, "single_c1")
+    x, y, eps = x[:rows], y[:rows], eps[:rows]
+    eng = tr.engine
+    for world in (True, False):
+        keep = R.relu_kink_margin(arch, sd, x, y, eps, world) > 4e-6
+        xs, ys, es = x[keep], y[keep], eps[keep]
+        n = xs.shape[0]
+        if n == 0:
+            continue
+        want = R.loss_and_grads(arch, sd, xs, ys, es, world)
+        c = R.phase_coeffs(world)
+        tr.model.load_state_dict(sd)
+        eng.exp_avg.zero_()
+        eng.exp_avg_sq.zero_()
+        sp = make_step_params(lr=5e-4, adam_t=(1, 1, 1), a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"],
+                              s_rec=c["s_rec_coeff"], cyc=c["vae_cycle_coeff"], global_rows=n)
+        eng.set_batch(xs, ys)
+        loss = eng.forward_backward(_lib.PHASE_WORLD if world else _lib.PHASE_JOINT, n, sp,
+                                    eps=None if world else es, fused_adam=True).cpu()
+        assert float(loss[0]) == pytest.approx(float(want["total"]), rel=1e-5)
+        mom = tr.optimizer.moments()
+        for k, gr in want["grads"].items():           # after step 1: exp_avg = 0.1 * g
+            assert max_err_scaled(mom[k][0].cpu(), 0.1 * gr) < 1e-4, (rows, world, k)
+
+
+def test_eval_loop_and_cosine_schedule(golden, tmp_path):
+    """compute_test_loss path (tm:147-156): forward-only epoch over a test set leaves the
+    parameters untouched and reproduces the oracle's mean loss; cosine LR drives HipAdam."""
+    g, arch, data, x, y, sd, eps, tr0 = _setup_single(golden, "single_tiny")
+    import os
+    import tempfile
+    td = tempfile.mkdtemp()
+    test_pkl = os.path.join(td, "test.pkl")
+    test_data = R.synth_demo(5, 2, 14, arch["Db"], arch["Da"])
+    R.write_demo(test_pkl, test_data)
+    tr = make_trainer(arch, data, 8, m_world=1, device=DEV,
+                      extra={"dataset_test": [test_pkl], "lr_schedule": "cosine", "lr_schedule_params": {"T_max": 4}})
+    tr.model.load_state_dict(sd)
+    before = tr.engine.params.clone()
+    out = tr.run_epoch(tr.test_loader, train=False)
+    assert torch.equal(tr.engine.params, before)
+    Xt, Yt = R.build_windows(test_data)
+    want = [float(R.loss_and_grads(arch, sd, xb, yb, None, True)["total"]) for xb, yb in R.make_loader(Xt, Yt, 8)]
+    np.testing.assert_allclose(out[:, 0].numpy(), want, rtol=1e-5)
+    res = tr.train()
+    assert res["mean_test_loss"] > 0 and res["mean_train_loss"] > 0
+    import math
+    assert tr.optimizer.lr == pytest.approx(5e-4 * (1 + math.cos(math.pi / 4)) / 2, rel=1e-9)
+
+
 def test_value_branch_and_frozen_nets_untouched(golden):
     g, arch, data, x, y, sd, eps, tr = _setup_single(golden, "single_tiny")
     before = tr.engine.params.clone()

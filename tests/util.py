@@ -2,7 +2,6 @@
 import os
 import tempfile
 
-import numpy as np
 import torch
 
 from oracle import refpath as R
