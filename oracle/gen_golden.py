@@ -40,7 +40,7 @@ def resolve_grid(cfg):
     return cfg
 
 
-def make_reference_trainer(pkl, arch, batch, m_world, num_data=None):
+def make_reference_trainer(pkl, arch, batch, m_world, num_data=None, lookahead=1):
     argv = ["--data_train", pkl, "--batch_size", str(batch), "--max_iter", "1000",
             "--max_iter_world_model", str(m_world), "--latent_dim", str(arch["Z"])]
     T.args = T.arg_parser().parse_args(argv)
@@ -49,6 +49,7 @@ def make_reference_trainer(pkl, arch, batch, m_world, num_data=None):
     cfg["TE_width"], cfg["TE_depth"] = arch["te"]
     cfg["MD_width"], cfg["MD_depth"] = arch["md"]
     cfg["world_model_width"], cfg["world_model_depth"] = arch["wm"]
+    cfg["lookahead"] = lookahead              # tpv:277 hard-wires 1; users edit the dict
     return T.TrainModel(cfg)
 
 
@@ -85,7 +86,7 @@ def single_batch_capture(tr, x, y, eps, world):
     tr.read_loss_fn_coeff(world=world)
     tr.model.train()
     tr.optimizer.zero_grad()
-    with EpsPatch(lambda c, shape: eps):
+    with EpsPatch(lambda c, shape: eps if eps.dim() == 2 else eps[c]):
         loss = tr.compute_loss(y, x)
     loss.backward()
     out = {"total": loss.detach().numpy()}
@@ -172,7 +173,48 @@ def case_single(name, arch, n_ep, n_steps, batch, full):
     print("wrote", name, "keys:", len(fix))
 
 
-def case_training(name, arch, n_ep, n_steps, batch, m_world, n_epochs, full, lr_step=2):
+def case_lookahead(name, arch, n_ep, n_steps, batch, lookahead, full):
+    """One minibatch through the reference's multi-step unroll (tpv:367-428), both phases."""
+    data = R.synth_demo(seed=0, n_episodes=n_ep, n_steps=n_steps, dim_body=arch["Db"],
+                        dim_action=arch["Da"], kind="dynamics")
+    fix = {}
+    with tempfile.TemporaryDirectory() as td:
+        pkl = os.path.join(td, "demo.pkl")
+        R.write_demo(pkl, data)
+        tr = make_reference_trainer(pkl, arch, batch, m_world=2, lookahead=lookahead)
+        sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+        tr.model.load_state_dict(sd)
+        loader = tr.train_loader
+        fix["n_windows"] = np.array(len(loader.dataset))
+        fix["n_batches"] = np.array(len(loader))
+        batches = list(loader)
+        fix["last_batch_size"] = np.array(batches[-1][0].shape[0])
+        fix["loader_last_x_digest"] = R.tensor_digest(batches[-1][0])
+        fix["loader_last_y_digest"] = R.tensor_digest(batches[-1][1])
+        x, y = batches[0]
+        fix["x_shape"] = np.array(x.shape)
+        es = R.eps_stream(2, arch["Z"])
+        eps = torch.stack([es(t, (x.shape[0], arch["Z"])) for t in range(lookahead)])
+        for world in (True, False):
+            tag = "world" if world else "joint"
+            out, grads = single_batch_capture(tr, x, y, eps, world)
+            for k, v in out.items():
+                if full or v.ndim == 0:
+                    fix["%s_%s" % (tag, k)] = v
+                else:
+                    fix["%s_%s_digest" % (tag, k)] = R.tensor_digest(torch.from_numpy(v))
+            fix["%s_grad_keys" % tag] = np.array(list(grads.keys()))
+            for k, g in grads.items():
+                if full:
+                    fix["%s_grad::%s" % (tag, k)] = g.numpy()
+                fix["%s_graddigest::%s" % (tag, k)] = R.tensor_digest(g)
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"],
+                            n_ep, n_steps, batch, lookahead])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
+    print("wrote", name, "keys:", len(fix), "world", fix["world_total"], "joint", fix["joint_total"])
+
+
+def case_training(name, arch, n_ep, n_steps, batch, m_world, n_epochs, full, lr_step=2, lookahead=1):
     """Multi-epoch run crossing the phase switch, eps keyed by global minibatch index."""
     data = R.synth_demo(seed=0, n_episodes=n_ep, n_steps=n_steps, dim_body=arch["Db"],
                         dim_action=arch["Da"], kind="dynamics")
@@ -180,7 +222,7 @@ def case_training(name, arch, n_ep, n_steps, batch, m_world, n_epochs, full, lr_
     with tempfile.TemporaryDirectory() as td:
         pkl = os.path.join(td, "demo.pkl")
         R.write_demo(pkl, data)
-        tr = make_reference_trainer(pkl, arch, batch, m_world=m_world)
+        tr = make_reference_trainer(pkl, arch, batch, m_world=m_world, lookahead=lookahead)
         # shorten StepLR so that the decay is exercised inside the captured run
         tr.lr_scheduler = torch.optim.lr_scheduler.StepLR(tr.optimizer, step_size=lr_step, gamma=0.7)
         sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
@@ -215,7 +257,7 @@ def case_training(name, arch, n_ep, n_steps, batch, m_world, n_epochs, full, lr_
         fix["adam_has_state"] = np.array(have)
         fix["adam_steps"] = np.array(steps)
     fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"],
-                            n_ep, n_steps, batch, m_world, n_epochs, lr_step])
+                            n_ep, n_steps, batch, m_world, n_epochs, lr_step, lookahead])
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
     print("wrote", name, "losses", losses, "lrs", lrs)
 
@@ -239,6 +281,10 @@ def main():
                                             full=True),
         "train_c1": lambda: case_training("train_c1", c1, 4, 200, 64, m_world=2, n_epochs=4,
                                           full=False),
+        "look3_tiny": lambda: case_lookahead("look3_tiny", tiny, 2, 15, 8, lookahead=3, full=True),
+        "look2_c1": lambda: case_lookahead("look2_c1", c1, 2, 200, 64, lookahead=2, full=False),
+        "train_tiny_look2": lambda: case_training("train_tiny_look2", tiny, 3, 22, 8, m_world=2, n_epochs=5,
+                                                  full=True, lookahead=2),
     }
     for k, fn in jobs.items():
         if a.only is None or a.only == k:

@@ -249,6 +249,7 @@ class RefModel(nn.Module):
         self.log_std = math.log(0.1)            # AppendLogStd constant (rmt:160-206, 466)
         self.latent_prior_noise = True          # rmt:705
         self.eps_source = None                  # callable(shape) -> eps, else torch.randn
+        self.trace = None                       # list -> one dict of internals per forward call
 
     # rmt:734-740
     def reparameterize(self, mu, logvar):
@@ -271,6 +272,9 @@ class RefModel(nn.Module):
         logits = torch.cat([a_hat, torch.full_like(a_hat, self.log_std)], dim=-1)
         self.cur_future_state = self.forward_world(obs, logits)       # rmt:758
         self.cur_value = self._value_branch(obs).squeeze(1)           # rmt:760-769
+        if self.trace is not None:
+            self.trace.append(dict(mu=self.cur_mu.detach(), logvar=self.cur_logvar.detach(), z=z.detach(),
+                                   a_hat=a_hat.detach(), future_state=self.cur_future_state.detach()))
         return logits
 
     # rmt:839-844
@@ -295,31 +299,51 @@ def phase_coeffs(world, cfg=None):
 
 
 def compute_loss(model, x, y, coeffs):
-    """tpv:361-435 with lookahead == 1.  x [B,1,2Db], y [B,1,Da].  Returns (total, terms).
-    The full forward always runs (tpv:378), including in the world phase."""
+    """tpv:361-435.  x [B,L,2Db], y [B,L,Da], L = lookahead.  Returns (total, terms).
+    The full forward always runs (tpv:378), including in the world phase.  For L > 1 the
+    state fed to step t+1 is the model's own prediction `_cur_future_state` of step t
+    (tpv:421, not detached: the gradient flows back through the world model, the motor
+    decoder and the task encoder of every earlier step), and each term is the mean over
+    the L steps (tpv:423-428)."""
     Db = model.arch["Db"]
     Da = model.arch["Da"]
+    L = x.shape[1]
     mse = nn.MSELoss()
-    x0 = x[:, 0, :]
-    y0 = y[:, 0, :]
-    s1, s2 = x0[:, :Db], x0[:, Db:]
-    logits = model(torch.cat([s1, s2], dim=-1))
-    a_hat = logits[:, :Da]                                            # tpv:356-359
     zero = torch.zeros((), dtype=torch.float32)
     loss_a = loss_kl = loss_s = loss_cyc = zero
-    if coeffs["a_rec_coeff"] > 0.0:
-        loss_a = mse(y0, a_hat)                                       # tpv:381-382
-        if coeffs["vae_kl_coeff"] > 0.0:
-            mu, lv = model.cur_mu, model.cur_logvar
-            loss_kl = torch.mean(-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp(), dim=1), dim=0)
-    if coeffs["s_rec_coeff"] > 0:
-        s2_gt_act = model.forward_world(s1, y0)                       # tpv:411-414
-        loss_s = mse(s2, s2_gt_act)
-    if coeffs["vae_cycle_coeff"] > 0:
-        loss_cyc = mse(s2, model.cur_future_state)                    # tpv:417-419
+    s1 = x[:, 0, :Db]                                                 # tpv:365
+    for t in range(L):
+        x_t, y_t = x[:, t, :], y[:, t, :]                             # tpv:369-370 (B > 1)
+        s2 = x_t[:, Db:]                                              # tpv:375
+        logits = model(torch.cat([s1, s2], dim=-1))                   # tpv:377-378
+        a_hat = logits[:, :Da]                                        # tpv:356-359
+        if coeffs["a_rec_coeff"] > 0.0:
+            loss_a = loss_a + mse(y_t, a_hat)                         # tpv:381-382
+            if coeffs["vae_kl_coeff"] > 0.0:
+                mu, lv = model.cur_mu, model.cur_logvar
+                loss_kl = loss_kl + torch.mean(-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp(), dim=1), dim=0)
+        if coeffs["s_rec_coeff"] > 0:
+            s2_gt_act = model.forward_world(s1, y_t)                  # tpv:411-414
+            loss_s = loss_s + mse(s2, s2_gt_act)
+        if coeffs["vae_cycle_coeff"] > 0:
+            loss_cyc = loss_cyc + mse(s2, model.cur_future_state)     # tpv:417-419
+        s1 = model.cur_future_state                                   # tpv:421
+    if L > 1:                                                         # tpv:423-428
+        n = float(L)
+        loss_a, loss_kl, loss_s, loss_cyc = loss_a / n, loss_kl / n, loss_s / n, loss_cyc / n
     total = (coeffs["a_rec_coeff"] * loss_a + coeffs["vae_kl_coeff"] * loss_kl +
              coeffs["s_rec_coeff"] * loss_s + coeffs["vae_cycle_coeff"] * loss_cyc)
     return total, dict(loss_a=loss_a, loss_kl=loss_kl, loss_s=loss_s, loss_cyc=loss_cyc)
+
+
+def _eps_feeder(eps):
+    """eps [B,Z] (one forward) or [L,B,Z] (one slice per forward call, in call order)."""
+    if eps is None:
+        return None
+    if eps.dim() == 2:
+        return lambda shape: eps
+    it = iter(eps)
+    return lambda shape: next(it)
 
 
 def loss_and_grads(arch, sd, x, y, eps, world, coeff_cfg=None):
@@ -328,11 +352,12 @@ def loss_and_grads(arch, sd, x, y, eps, world, coeff_cfg=None):
     model = RefModel(arch)
     model.load_state_dict(sd)
     model.train()
-    model.eps_source = (lambda shape: eps) if eps is not None else None
+    model.eps_source = _eps_feeder(eps)
     model.set_learnable("_task_encoder", not world)
     model.set_learnable("_motor_decoder", not world)
     model.set_learnable("_world_model", world)
     coeffs = phase_coeffs(world, coeff_cfg)
+    model.trace = []
     total, terms = compute_loss(model, x, y, coeffs)
     total.backward()
     grads = OrderedDict((k, p.grad.detach().clone()) for k, p in model.named_parameters()
@@ -340,12 +365,13 @@ def loss_and_grads(arch, sd, x, y, eps, world, coeff_cfg=None):
     Da = arch["Da"]
     out = dict(total=total.detach(), mu=model.cur_mu.detach(), logvar=model.cur_logvar.detach(),
                z=model.cur_z.detach(), future_state=model.cur_future_state.detach(),
-               grads=grads)
+               grads=grads, steps=model.trace)
+    model.trace = None
     out.update({k: v.detach() for k, v in terms.items()})
     with torch.no_grad():
         Db = arch["Db"]
         x0 = x[:, 0, :]
-        out["a_hat"] = model._motor_decoder(torch.cat([x0[:, :Db], out["z"]], dim=-1))
+        out["a_hat"] = out["steps"][-1]["a_hat"]
         out["s2_from_gt_action"] = model.forward_world(x0, torch.cat([y[:, 0, :], y[:, 0, :]], -1))
     return out
 
@@ -359,23 +385,27 @@ def relu_kink_margin(arch, sd, x, y, eps, world):
     gradients tightly."""
     model = RefModel(arch)
     model.load_state_dict(sd)
-    model.eps_source = (lambda shape: eps) if eps is not None else None
     margins = []
 
     def hook(mod, inp, out):
         margins.append(out.detach().abs().min(dim=1).values)
 
-    nets = ["_world_model"] if world else ["_task_encoder", "_motor_decoder", "_world_model"]
+    L = x.shape[1]
+    model.eps_source = _eps_feeder(eps)
+    nets = (["_world_model"] if world and L == 1 else
+            ["_task_encoder", "_motor_decoder", "_world_model"])
     hs = []
     for net in nets:
         for slim in list(getattr(model, net)._model)[:-1]:        # hidden layers only
             hs.append(slim._model[0].register_forward_hook(hook))
     with torch.no_grad():
         x0 = x[:, 0, :]
-        if world:
+        if world and L == 1:
             model.forward_world(x0, torch.cat([y[:, 0, :], y[:, 0, :]], -1))
-        else:
+        elif L == 1:
             model(x0)
+        else:                                   # every step's every stack carries gradient
+            compute_loss(model, x, y, phase_coeffs(world))
     for h in hs:
         h.remove()
     return torch.stack(margins).min(dim=0).values
@@ -418,6 +448,7 @@ class RefTrainer:
         self.coeff_cfg = coeff_cfg
         self.iter = 0
         self.global_batch = 0
+        self.eps_calls = 0                      # one draw per model forward = lookahead per minibatch
         self.eps_fn = eps_fn
         self.world = True
         self._apply_phase()
@@ -428,6 +459,11 @@ class RefTrainer:
         self.model.set_learnable("_world_model", self.world)
         self.coeffs = phase_coeffs(self.world, self.coeff_cfg)
 
+    def _next_eps(self, shape):
+        e = self.eps_fn(self.eps_calls, shape)
+        self.eps_calls += 1
+        return e
+
     def step(self, max_batches=None):
         if self.iter == self.max_iter_world_model:
             self.world = False
@@ -437,8 +473,7 @@ class RefTrainer:
         acc, n = 0.0, 0
         for x, y in self.loader:
             if self.eps_fn is not None:
-                gb = self.global_batch
-                self.model.eps_source = lambda shape, gb=gb: self.eps_fn(gb, shape)
+                self.model.eps_source = self._next_eps
             self.opt.zero_grad()
             loss, _ = compute_loss(self.model, x, y, self.coeffs)
             loss.backward()
@@ -454,8 +489,9 @@ class RefTrainer:
 
 
 def eps_stream(seed, latent):
-    """Deterministic epsilon per *global minibatch index* (one randn_like per forward,
-    SURVEY.md 3.2): both the reference capture and the HIP path consume eps(gb)."""
+    """Deterministic epsilon per *forward call index* (one randn_like per model forward,
+    SURVEY.md 3.2; call = global minibatch * lookahead + t): both the reference capture and
+    the HIP path consume eps(call)."""
     def fn(global_batch, shape):
         rng = np.random.default_rng([seed, int(global_batch)])
         e = rng.standard_normal((int(shape[0]), latent)).astype(np.float32)

@@ -114,6 +114,48 @@ def test_single_batch_losses_and_grads_match_reference(golden, name):
     np.testing.assert_array_equal(g["joint_total_vb_perturbed"], g["joint_total"])
 
 
+@pytest.mark.parametrize("name", ["look3_tiny", "look2_c1"])
+def test_lookahead_unroll_matches_reference(golden, name):
+    """tpv:367-428 with lookahead 3 / 2: windows, ragged last batch, loss terms averaged over the
+    steps, and the gradients of the back-propagation through every earlier step."""
+    g = golden(name)
+    arch = arch_from_meta(g["meta"])
+    n_ep, n_steps, batch, L = [int(v) for v in g["meta"][9:13]]
+    data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
+    X, Y = R.build_windows(data, lookahead=L)
+    assert X.shape == (n_ep * (n_steps - L), L, 2 * arch["Db"]) and len(X) == int(g["n_windows"])
+    batches = list(R.make_loader(X, Y, batch))
+    assert len(batches) == int(g["n_batches"]) and batches[-1][0].shape[0] == int(g["last_batch_size"])
+    np.testing.assert_array_equal(R.tensor_digest(batches[-1][0]), g["loader_last_x_digest"])
+    np.testing.assert_array_equal(R.tensor_digest(batches[-1][1]), g["loader_last_y_digest"])
+    x, y = batches[0]
+    assert list(x.shape) == g["x_shape"].tolist()
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    es = R.eps_stream(2, arch["Z"])
+    eps = torch.stack([es(t, (x.shape[0], arch["Z"])) for t in range(L)])
+    for world in (True, False):
+        tag = "world" if world else "joint"
+        out = R.loss_and_grads(arch, sd, x, y, eps, world)
+        np.testing.assert_allclose(out["total"].numpy(), g[tag + "_total"], rtol=1e-6)
+        for k in ("mu", "logvar", "z", "future_state"):           # internals of the LAST step
+            if tag + "_" + k in g:
+                np.testing.assert_allclose(out[k].numpy(), g[tag + "_" + k], rtol=1e-5, atol=1e-6)
+            else:
+                np.testing.assert_allclose(R.tensor_digest(out[k]), g["%s_%s_digest" % (tag, k)],
+                                           rtol=1e-5, atol=1e-6)
+        assert len(out["steps"]) == L
+        assert list(out["grads"].keys()) == list(g[tag + "_grad_keys"])
+        for k, gr in out["grads"].items():
+            np.testing.assert_allclose(R.tensor_digest(gr), g["%s_graddigest::%s" % (tag, k)],
+                                       rtol=2e-4, atol=1e-9)
+            full = "%s_grad::%s" % (tag, k)
+            if full in g:
+                np.testing.assert_allclose(gr.numpy(), g[full], rtol=1e-4, atol=1e-8)
+    # world phase with L > 1 still trains only the world model, but its gradient now also
+    # arrives through the (frozen) encoder/decoder of the earlier steps
+    assert all(str(k).startswith("_world_model") for k in g["world_grad_keys"])
+
+
 def test_frozen_nets_get_no_grad(golden):
     g = golden("single_tiny")
     assert all(str(k).startswith("_world_model") for k in g["world_grad_keys"])
@@ -134,13 +176,14 @@ def test_checkpoint_layout_matches_reference(golden):
         assert list(obj.keys()) == list(g["ckpt_keys::" + f]), f
 
 
-@pytest.mark.parametrize("name", ["train_tiny", "train_c1"])
+@pytest.mark.parametrize("name", ["train_tiny", "train_c1", "train_tiny_look2"])
 def test_training_run_matches_reference(golden, name):
     g = golden(name)
     arch = arch_from_meta(g["meta"])
     n_ep, n_steps, batch, m_world, n_epochs, lr_step = [int(v) for v in g["meta"][9:15]]
+    L = int(g["meta"][15]) if len(g["meta"]) > 15 else 1
     data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
-    X, Y = R.build_windows(data)
+    X, Y = R.build_windows(data, lookahead=L)
     sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
     tr = R.RefTrainer(arch, sd, X, Y, batch, m_world, lr_step=lr_step,
                       eps_fn=R.eps_stream(2, arch["Z"]))
@@ -156,7 +199,7 @@ def test_training_run_matches_reference(golden, name):
                 np.testing.assert_allclose(R.tensor_digest(v), g["%s_digest::%s" % (tag, k)],
                                            rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(losses, g["epoch_losses"], rtol=1e-5)
-    assert tr.global_batch == int(g["eps_calls"])
+    assert tr.eps_calls == int(g["eps_calls"]) == tr.global_batch * L
     # Adam bookkeeping (lazy state, WM stops at the switch, TE/MD start at t = 1, VB never)
     named = dict(tr.model.named_parameters())
     assert list(named.keys()) == list(g["adam_keys"])
