@@ -125,7 +125,7 @@ def main():
             g = (start + i) % full
             first, rows, grows = dp.shard(g, n_win, a.batch)
             sp = tr.step_params(nets, grows, True)
-            sp.rng_seed, sp.rng_offset = 7, (start + i) * 65536 + dp.rank
+            sp.rng_seed, sp.rng_offset = 7, (start + i) * 65536 + dp.rank * 64
             if dp.world == 1:
                 eng.train_step(phase, first, rows, sp, loss_out=loss_buf)
             else:

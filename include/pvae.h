@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PVAE_ABI_VERSION 1
+#define PVAE_ABI_VERSION 2
 
 typedef struct pvae_ctx pvae_ctx;
 
@@ -60,6 +60,8 @@ typedef struct pvae_config {
     int32_t md_width, md_depth;
     int32_t wm_width, wm_depth;
     int32_t max_batch;  /* largest minibatch (rows) this ctx will be asked to process */
+    int32_t lookahead;  /* L >= 1: steps unrolled through the world model per sample (tpv:277,
+                           367-428); sizes the workspace (L blocks per panel) */
 } pvae_config;
 
 typedef struct pvae_layer_info {
@@ -115,7 +117,8 @@ int pvae_bind_arenas(pvae_ctx* ctx, float* params, float* grads, float* exp_avg,
                      float* exp_avg_sq);
 int pvae_bind_workspace(pvae_ctx* ctx, void* workspace, size_t bytes);
 /* Demonstration set resident in HBM, de-duplicated: states[n_rows][Db], actions[n_rows][Da]
- * (fp32, dense), window_row[n_windows] = row of s_t (s_{t+1} is row+1, a_t is the same row).
+ * (fp32, dense), window_row[n_windows] = row of s_t (s_{t+1} is row+1, a_t is the same row;
+ * with lookahead L the window spans rows row .. row+L, which must stay inside one episode).
  * Replaces the float64 X[N,1,2Db] / Y[N,1,Da] arrays of load_dataset_for_PhysicsVAE
  * (tpv:117-164) and DatasetBase.__getitem__ (tm:52-56). */
 int pvae_bind_dataset(pvae_ctx* ctx, const float* states, const float* actions,
@@ -125,20 +128,25 @@ int pvae_bind_dataset(pvae_ctx* ctx, const float* states, const float* actions,
 /* Minibatch gather: windows [first_window, first_window+rows) -> network input panels.
  * Replaces DataLoader + default collate over DatasetBase (tm:166-175, 137-139). */
 int pvae_gather(pvae_ctx* ctx, int64_t first_window, int32_t rows, void* stream);
-/* Same, from explicit device tensors x[rows][2*Db], y[rows][Da] (dense fp32): the
- * compute_loss(y, x) entry of tpv:361 for callers that bring their own batch. */
+/* Same, from explicit device tensors x[rows][L][2*Db], y[rows][L][Da] (dense fp32, L =
+ * lookahead): the compute_loss(y, x) entry of tpv:361 for callers that bring their own batch. */
 int pvae_set_batch(pvae_ctx* ctx, const float* x, const float* y, int32_t rows, void* stream);
 
 /* Forward + losses (+ backward, + optional fused Adam) over the batch staged by
  * pvae_gather/pvae_set_batch.  Replaces compute_loss (tpv:361-435), PhysicsVAE.forward
  * (rmt:742-853), loss.backward() (tm:142) and, with PVAE_FLAG_FUSED_ADAM,
  * optimizer.step() (tm:143).
- *   eps      : device [rows][Z] standard-normal draws for the reparameterisation
- *              (rmt:734-740), or NULL to draw them on chip (Philox4x32-10, Box-Muller).
+ *   eps      : device [L][rows][Z] standard-normal draws for the reparameterisation
+ *              (rmt:734-740; one [rows][Z] slice per unrolled step, in call order), or NULL to
+ *              draw them on chip (Philox4x32-10, Box-Muller; step t uses rng_offset + t).
  *   loss_out : device float[5] = {total, loss_a, loss_kl, loss_s, loss_cyc} (this rank's
  *              share: sums over local rows / global_rows).
- * World phase: only the world model runs (the reference's discarded TE/MD/VB forward,
- * tpv:378, is not algorithmically required and is skipped). */
+ * World phase, lookahead 1: only the world model runs (the reference's discarded TE/MD/VB
+ * forward, tpv:378, is not algorithmically required and is skipped).
+ * lookahead L > 1 (tpv:367-428): step t+1 starts from the world model's own prediction of step
+ * t, so encoder, sampler, decoder and world model run for every step in BOTH phases, the
+ * backward pass walks the steps last to first through all three stacks, and each layer's weight
+ * gradient is one contraction over the L stacked steps.  Terms are means over the L steps. */
 int pvae_forward_backward(pvae_ctx* ctx, int phase, int32_t rows, const pvae_step_params* sp,
                           const float* eps, float* loss_out, int flags, void* stream);
 /* Adam over the nets in net_mask (bit n = PVAE_NET_n) using the bound grads arena.
@@ -171,7 +179,8 @@ int pvae_train_step(pvae_ctx* ctx, int phase, int64_t first_window, int32_t rows
 /* ---- inspection (parity tests) ------------------------------------------------------- */
 /* Copy a forward intermediate of the last pvae_forward_backward into dst (dense
  * [rows][width] fp32, device).  what: 0 = mu, 1 = logvar, 2 = z, 3 = a_hat (MD output),
- * 4 = s2_hat (WM output), 5 = eps actually used. */
+ * 4 = s2_hat (WM output; with lookahead > 1 the prediction that feeds the next step), 5 = eps
+ * actually used.  Add 8*t to read time step t of a lookahead > 1 batch. */
 int pvae_read_tensor(pvae_ctx* ctx, int what, float* dst, int32_t rows, void* stream);
 
 /* Rollout inference (rmt:742-771 at small batch): obs[rows][2*Db] -> a_hat[rows][Da]

@@ -16,12 +16,13 @@ NET_TE, NET_MD, NET_WM = 0, 1, 2
 NET_NAMES = {NET_TE: "_task_encoder", NET_MD: "_motor_decoder", NET_WM: "_world_model"}
 PHASE_WORLD, PHASE_JOINT = 0, 1
 FLAG_FUSED_ADAM, FLAG_NO_BACKWARD = 1, 2
+ABI_VERSION = 2
 
 
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dim_body", "dim_action", "latent", "te_width", "te_depth", "md_width", "md_depth",
-        "wm_width", "wm_depth", "max_batch")]
+        "wm_width", "wm_depth", "max_batch", "lookahead")]
 
 
 class LayerInfo(C.Structure):
@@ -93,7 +94,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.pvae_abi_version() != 1:
+    if lib.pvae_abi_version() != ABI_VERSION:
         raise RuntimeError("libpvae ABI version mismatch")
     _lib = lib
     return lib

@@ -87,56 +87,100 @@ struct pvae_ctx {
 // glue kernels
 // ---------------------------------------------------------------------------------------
 
-// Minibatch staging.  One block per (padded) batch row.  Builds the three network input
-// panels and the two target panels from either the HBM-resident demonstration set
-// (window_row != null: rows s and s+1 of `states`, row s of `actions`; tpv:133-156 windows,
-// tm:52-56 float64->float32, tm:166-175 collate) or explicit x[rows][2Db] / y[rows][Da]
-// (tpv:365-376).  Pad rows and pad columns are written as zeros so that every GEMM can run
-// on whole tiles without bounds checks.
+// Minibatch staging.  One block per (padded) batch row and time step (blockIdx.y = t < L).
+// Builds the network input panels and the two target panels from either the HBM-resident
+// demonstration set (window_row != null: step t of window i reads rows s+t and s+t+1 of
+// `states`, row s+t of `actions`; tpv:133-156 windows, tm:52-56 float64->float32, tm:166-175
+// collate) or explicit x[rows][L][2Db] / y[rows][L][Da] (tpv:365-376).  Pad rows and pad columns
+// are written as zeros so that every GEMM can run on whole tiles without bounds checks.
+// Time step t lives in row block t of every panel (pvae_layout.h).  For t > 0 the current-state
+// columns are left zero here: they are the world model's own prediction of step t-1 (tpv:421),
+// copied in by scatter_state_kernel during the forward pass.  `wm_pred` (L > 1 only) is the
+// input panel of the world-model invocations that take the decoder's action.
 __global__ void __launch_bounds__(256)
 stage_batch_kernel(const float* __restrict__ states, const float* __restrict__ actions,
                    const int32_t* __restrict__ window_row, long long first_window,
                    const float* __restrict__ x, const float* __restrict__ y, int rows, int Db, int Da,
                    float* __restrict__ te_in, int ld_te, float* __restrict__ md_in, int ld_md,
                    float* __restrict__ wm_in, int ld_wm, float* __restrict__ s2, int ld_s2,
-                   float* __restrict__ act_t, int ld_a) {
+                   float* __restrict__ act_t, int ld_a, float* __restrict__ wm_pred, int L) {
     const int r = blockIdx.x;
+    const int t = blockIdx.y;
+    const size_t prow = (size_t)t * gridDim.x + r;        // row inside the stacked panels
     const bool valid = r < rows;
+    const bool first = t == 0;
     const float* p1 = nullptr;
     const float* p2 = nullptr;
     const float* pa = nullptr;
     if (valid) {
         if (window_row) {
-            const long long s = window_row[first_window + r];
+            const long long s = (long long)window_row[first_window + r] + t;
             p1 = states + s * Db;
             p2 = p1 + Db;
             pa = actions + s * Da;
         } else {
-            p1 = x + (size_t)r * 2 * Db;
+            p1 = x + ((size_t)r * L + t) * 2 * Db;
             p2 = p1 + Db;
-            pa = y ? y + (size_t)r * Da : nullptr;
+            pa = y ? y + ((size_t)r * L + t) * Da : nullptr;
         }
     }
     int ld_max = ld_te;
     if (ld_md > ld_max) ld_max = ld_md;
     if (ld_wm > ld_max) ld_max = ld_wm;
     for (int c = threadIdx.x; c < ld_max; c += 256) {
-        const float v1 = (valid && c < Db) ? p1[c] : 0.f;
+        const float v1 = (valid && first && c < Db) ? p1[c] : 0.f;
         const float v2 = (valid && c < Db) ? p2[c] : 0.f;
         const float va = (valid && pa && c < Da) ? pa[c] : 0.f;
         if (c < ld_te) {
-            float t = v1;
-            if (c >= Db) t = (valid && c < 2 * Db) ? p2[c - Db] : 0.f;
-            te_in[(size_t)r * ld_te + c] = t;
+            float u = v1;
+            if (c >= Db) u = (valid && c < 2 * Db) ? p2[c - Db] : 0.f;
+            te_in[prow * ld_te + c] = u;
         }
-        if (c < ld_md) md_in[(size_t)r * ld_md + c] = v1;      // z columns filled by reparam
+        if (c < ld_md) md_in[prow * ld_md + c] = v1;          // z columns filled by reparam
         if (c < ld_wm) {
-            float t = v1;
-            if (c >= Db) t = (valid && pa && c < Db + Da) ? pa[c - Db] : 0.f;
-            wm_in[(size_t)r * ld_wm + c] = t;
+            float u = v1;
+            if (c >= Db) u = (valid && pa && c < Db + Da) ? pa[c - Db] : 0.f;
+            wm_in[prow * ld_wm + c] = u;
+            if (wm_pred) wm_pred[prow * ld_wm + c] = c < Db ? v1 : 0.f;   // a_hat columns filled by the decoder
         }
-        if (c < ld_s2) s2[(size_t)r * ld_s2 + c] = v2;
-        if (c < ld_a) act_t[(size_t)r * ld_a + c] = va;
+        if (c < ld_s2) s2[prow * ld_s2 + c] = v2;
+        if (c < ld_a) act_t[prow * ld_a + c] = va;
+    }
+}
+
+// s1 of step t+1 = world-model prediction of step t (tpv:421): copy the first Db columns of the
+// valid rows of `src` into the current-state columns of up to four input panels.
+__global__ void __launch_bounds__(256)
+scatter_state_kernel(const float* __restrict__ src, int lds_, int rows, int Db, float* __restrict__ d0, int ld0,
+                     float* __restrict__ d1, int ld1, float* __restrict__ d2, int ld2, float* __restrict__ d3,
+                     int ld3) {
+    const int total = rows * Db;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int r = idx / Db, c = idx - r * Db;
+        const float v = src[(size_t)r * lds_ + c];
+        d0[(size_t)r * ld0 + c] = v;
+        if (d1) d1[(size_t)r * ld1 + c] = v;
+        if (d2) d2[(size_t)r * ld2 + c] = v;
+        if (d3) d3[(size_t)r * ld3 + c] = v;
+    }
+}
+
+// dst[r][c] += s0[r][c] (+ s1 + s2 + s3), c < n, r < rows: the gradient wrt the state handed from
+// step t to step t+1 is the sum of what came back through every consumer of that state (encoder,
+// decoder and the world-model invocations of step t+1).  Fixed summation order.
+__global__ void __launch_bounds__(256)
+add_cols_kernel(float* __restrict__ dst, int ldd, int rows, int n, const float* __restrict__ s0, int l0,
+                const float* __restrict__ s1, int l1, const float* __restrict__ s2, int l2,
+                const float* __restrict__ s3, int l3) {
+    const int total = rows * n;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int r = idx / n, c = idx - r * n;
+        float v = dst[(size_t)r * ldd + c];
+        if (s0) v += s0[(size_t)r * l0 + c];
+        if (s1) v += s1[(size_t)r * l1 + c];
+        if (s2) v += s2[(size_t)r * l2 + c];
+        if (s3) v += s3[(size_t)r * l3 + c];
+        dst[(size_t)r * ldd + c] = v;
     }
 }
 
@@ -361,12 +405,14 @@ struct FwdTail {              // what the output layer's epilogue does besides b
     int ld2 = 0, off2 = 0, n2 = 0;
 };
 
-static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st, const FwdTail& tail = FwdTail()) {
+// `row0`: first row of the time-step block to run on (0 unless lookahead > 1)
+static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st, const FwdTail& tail = FwdTail(),
+                       int64_t row0 = 0) {
     const NetLayout& N = c->L.net[n];
-    const float* x = c->ws + c->W.net[n].in;
+    const float* x = c->ws + c->W.net[n].in + row0 * N.layers[0].ld;
     int ldx = N.layers[0].ld;
     for (const Layer& l : N.layers) {
-        float* out = c->ws + c->W.net[n].act[l.index];
+        float* out = c->ws + c->W.net[n].act[l.index] + row0 * l.n_out_pad;
         const int ps = g_prof.begin(0, 2.0 * c->staged_rows_f * l.n_in * l.n_out, st);
         const int rows = (int)c->staged_rows_f;
         if (rows <= 4 && !tail.mse) {            // rollout batch: stream W once over all CUs
@@ -652,21 +698,24 @@ int pvae_bind_dataset(pvae_ctx* c, const float* states, const float* actions, co
     return 0;
 }
 
+// `steps`: time steps to stage (the ctx's lookahead for training batches, 1 for rollout inference)
 static int stage(pvae_ctx* c, long long first_window, const float* x, const float* y, int rows, bool from_set,
-                 hipStream_t st) {
+                 hipStream_t st, int steps) {
     int rc = check_ready(c, false);
     if (rc) return rc;
     if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
     const int rows_pad = pad32(rows);
     const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action;
     float* w = c->ws;
-    hipLaunchKernelGGL(stage_batch_kernel, dim3(rows_pad), dim3(256), 0, st,
+    const int T = steps;
+    const int ld_wm = c->L.net[PVAE_NET_WM].layers[0].ld;
+    hipLaunchKernelGGL(stage_batch_kernel, dim3(rows_pad, T), dim3(256), 0, st,
                        from_set ? c->states : nullptr, from_set ? c->actions : nullptr,
                        from_set ? c->window_row : nullptr, first_window, x, y, rows, Db, Da,
                        w + c->W.net[PVAE_NET_TE].in, c->L.net[PVAE_NET_TE].layers[0].ld,
                        w + c->W.net[PVAE_NET_MD].in, c->L.net[PVAE_NET_MD].layers[0].ld,
-                       w + c->W.net[PVAE_NET_WM].in, c->L.net[PVAE_NET_WM].layers[0].ld,
-                       w + c->W.s2, pad64(Db), w + c->W.act_t, pad64(Da));
+                       w + c->W.net[PVAE_NET_WM].in, ld_wm, w + c->W.s2, pad64(Db), w + c->W.act_t, pad64(Da),
+                       T > 1 ? w + c->W.net[PVAE_NET_WM].in + (int64_t)T * rows_pad * ld_wm : (float*)nullptr, T);
     HIP_TRY(hipGetLastError());
     c->staged_rows = rows;
     c->staged_rows_f = rows;
@@ -679,13 +728,13 @@ int pvae_gather(pvae_ctx* c, int64_t first_window, int32_t rows, void* stream) {
     if (first_window < 0 || first_window + rows > c->n_windows)
         return fail(-1, "windows [%lld, %lld) outside [0, %lld)", (long long)first_window,
                     (long long)(first_window + rows), (long long)c->n_windows);
-    return stage(c, first_window, nullptr, nullptr, rows, true, (hipStream_t)stream);
+    return stage(c, first_window, nullptr, nullptr, rows, true, (hipStream_t)stream, c->W.L);
 }
 
 int pvae_set_batch(pvae_ctx* c, const float* x, const float* y, int32_t rows, void* stream) {
     if (!c) return fail(-1, "null ctx");
     if (!x) return fail(-1, "x is null");
-    return stage(c, 0, x, y, rows, false, (hipStream_t)stream);
+    return stage(c, 0, x, y, rows, false, (hipStream_t)stream, c->W.L);
 }
 
 }  // extern "C"
@@ -703,8 +752,11 @@ static int step_shape(pvae_ctx* c, int phase, int rows, const pvae_step_params* 
     const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
     S.rows_pad = pad32(rows);
     S.Bg = (float)(sp->global_rows > 0 ? sp->global_rows : rows);
+    const int T = c->W.L;
     S.wm_tiles = forward_tiles(S.rows_pad, c->L.net[PVAE_NET_WM].layers.back().n_out_pad);
-    if (S.wm_tiles > kLossParts) return fail(-1, "batch x dim_body too large for the loss partial buffer");
+    if ((int64_t)S.wm_tiles * T > kLossParts)
+        return fail(-1, "batch x dim_body x lookahead too large for the loss partial buffer");
+    S.Bg *= (float)T;                          // every term is the mean over the L steps (tpv:423-428)
     S.gridz = (S.rows_pad * Z + 255) / 256 < 64 ? (S.rows_pad * Z + 255) / 256 : 64;
     S.nparts_a = S.rows_pad < 64 ? S.rows_pad : 64;
     S.cyc_grad = backward && phase == PVAE_PHASE_JOINT && sp->cycle_coeff > 0.0f;
@@ -718,11 +770,11 @@ static int step_shape(pvae_ctx* c, int phase, int rows, const pvae_step_params* 
     S.lf.coeff[0] = sp->a_rec_coeff; S.lf.coeff[1] = sp->kl_coeff;
     S.lf.coeff[2] = sp->s_rec_coeff; S.lf.coeff[3] = sp->cycle_coeff;
     if (phase == PVAE_PHASE_WORLD) {
-        S.lf.nparts[2] = S.wm_tiles;
+        S.lf.nparts[2] = S.wm_tiles * T;
     } else {
-        if (sp->a_rec_coeff > 0.0f) S.lf.nparts[0] = S.nparts_a;
-        if (S.kl_active) S.lf.nparts[1] = S.gridz;
-        if (sp->cycle_coeff > 0.0f) S.lf.nparts[3] = S.wm_tiles;
+        if (sp->a_rec_coeff > 0.0f) S.lf.nparts[0] = S.nparts_a * T;
+        if (S.kl_active) S.lf.nparts[1] = S.gridz * T;
+        if (sp->cycle_coeff > 0.0f) S.lf.nparts[3] = S.wm_tiles * T;
     }
     return 0;
 }
@@ -742,9 +794,15 @@ static int check_step(pvae_ctx* c, int phase, int32_t rows, const pvae_step_para
     return 0;
 }
 
+static int run_forward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_step_params* sp, const float* eps,
+                                bool backward, const StepShape& S, hipStream_t st);
+static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_step_params* sp, bool backward,
+                                   bool fused, const StepShape& S, hipStream_t st, Plan& plan);
+
 // Forward launches + loss partials + the gradient seed of the world model's output layer.
 static int run_forward(pvae_ctx* c, int phase, int rows, const pvae_step_params* sp, const float* eps, bool backward,
                        const StepShape& S, hipStream_t st) {
+    if (c->W.L > 1) return run_forward_unrolled(c, phase, rows, sp, eps, backward, S, st);
     int rc;
     const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
     float* w = c->ws;
@@ -790,6 +848,10 @@ static int run_forward(pvae_ctx* c, int phase, int rows, const pvae_step_params*
 static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_params* sp, bool backward, bool fused,
                           const StepShape& S, hipStream_t st, Plan& plan) {
     const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
+    if (c->W.L > 1) {
+        plan_backward_unrolled(c, phase, rows, sp, backward, fused, S, st, plan);
+        return;
+    }
     float* w = c->ws;
     float* part = w + c->W.loss_part;
     const LossFinal* fold = S.lf.out ? &S.lf : nullptr;
@@ -837,6 +899,263 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
         };
     }
     plan_backward_net(c, PVAE_NET_TE, S.rows_pad, true, false, sp, fused, st, fold, plan);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// lookahead > 1: the multi-step unroll of tpv:367-428
+// ---------------------------------------------------------------------------------------
+// Per step t: x_t = [s1_t | s2gt_t] -> encoder -> sampler -> decoder -> world model with the
+// decoder's action (its output is both the cycle-loss prediction and s1_{t+1}, tpv:417-421) and,
+// when world_model_s_rec_coeff > 0, the world model with the demonstrated action (tpv:411-414).
+// All of it runs in BOTH phases (the world phase needs the chain because s1_{t+1} is a
+// prediction), in row block t of every panel; the world model uses block t for the
+// demonstrated-action invocation and block L+t for the predicted-action one.
+struct Unroll {
+    int T, rows, rows_pad;
+    bool use_g;                        // demonstrated-action world-model invocations exist
+    int64_t blk(int slot) const { return (int64_t)slot * rows_pad; }
+};
+
+static Unroll make_unroll(const pvae_ctx* c, int phase, int rows, const pvae_step_params* sp) {
+    Unroll u;
+    u.T = c->W.L; u.rows = rows; u.rows_pad = pad32(rows);
+    u.use_g = phase == PVAE_PHASE_WORLD && sp->s_rec_coeff > 0.0f;
+    return u;
+}
+
+static int run_forward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_step_params* sp, const float* eps,
+                                bool backward, const StepShape& S, hipStream_t st) {
+    int rc;
+    const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
+    const Unroll u = make_unroll(c, phase, rows, sp);
+    float* w = c->ws;
+    float* part = w + c->W.loss_part;
+    const NetLayout& TE = c->L.net[PVAE_NET_TE];
+    const NetLayout& MD = c->L.net[PVAE_NET_MD];
+    const NetLayout& WM = c->L.net[PVAE_NET_WM];
+    const NetWork& wte = c->W.net[PVAE_NET_TE];
+    const NetWork& wmd = c->W.net[PVAE_NET_MD];
+    const NetWork& wwm = c->W.net[PVAE_NET_WM];
+    const int ld_te = TE.layers[0].ld, ld_md = MD.layers[0].ld, ld_wm = WM.layers[0].ld;
+    const int ldo_te = TE.layers.back().n_out_pad, ldo_wm = WM.layers.back().n_out_pad;
+    const bool joint = phase == PVAE_PHASE_JOINT;
+    for (int t = 0; t < u.T; ++t) {
+        const int64_t bt = u.blk(t), bp = u.blk(u.T + t);
+        if ((rc = forward_net(c, PVAE_NET_TE, u.rows_pad, st, FwdTail(), bt))) return rc;
+        hipLaunchKernelGGL(reparam_kernel, dim3(S.gridz), dim3(256), 0, st, w + wte.act.back() + bt * ldo_te, ldo_te,
+                           eps ? eps + (size_t)t * rows * Z : (const float*)nullptr, w + c->W.eps + bt * Z,
+                           w + wmd.in + bt * ld_md, ld_md, Db, Z, rows, u.rows_pad, 1,
+                           (unsigned long long)sp->rng_seed, (unsigned long long)(sp->rng_offset + t),
+                           part + 2 * kLossParts + t * S.gridz);
+        HIP_TRY(hipGetLastError());
+        FwdTail md_tail;                       // a_hat -> action columns of the predicted-action WM input
+        md_tail.out2 = w + wwm.in + bp * ld_wm; md_tail.ld2 = ld_wm; md_tail.off2 = Db; md_tail.n2 = Da;
+        if ((rc = forward_net(c, PVAE_NET_MD, u.rows_pad, st, md_tail, bt))) return rc;
+        EpiMse mse;
+        memset(&mse, 0, sizeof(mse));
+        mse.target = w + c->W.s2 + bt * pad64(Db); mse.ldt = pad64(Db);
+        mse.ldz = ldo_wm; mse.rows = rows; mse.D = Db;
+        FwdTail wm_tail;
+        wm_tail.mse = &mse;
+        // predicted action: cycle loss (tpv:417-419) + the state of the next step
+        mse.dz = backward ? w + wwm.dz.back() + bp * ldo_wm : nullptr;
+        mse.grad_scale = joint ? sp->cycle_coeff * 2.0f / (S.Bg * Db) : 0.0f;
+        mse.partial = part + 4 * kLossParts + t * S.wm_tiles;
+        if ((rc = forward_net(c, PVAE_NET_WM, u.rows_pad, st, wm_tail, bp))) return rc;
+        if (u.use_g) {                         // demonstrated action: state reconstruction (tpv:411-414)
+            mse.dz = backward ? w + wwm.dz.back() + bt * ldo_wm : nullptr;
+            mse.grad_scale = sp->s_rec_coeff * 2.0f / (S.Bg * Db);
+            mse.partial = part + 3 * kLossParts + t * S.wm_tiles;
+            if ((rc = forward_net(c, PVAE_NET_WM, u.rows_pad, st, wm_tail, bt))) return rc;
+        }
+        if (t + 1 < u.T) {                     // s1 of the next step (tpv:421)
+            const int64_t nt = u.blk(t + 1), np = u.blk(u.T + t + 1);
+            const int grid = (rows * Db + 255) / 256 < 256 ? (rows * Db + 255) / 256 : 256;
+            hipLaunchKernelGGL(scatter_state_kernel, dim3(grid), dim3(256), 0, st,
+                               w + wwm.act.back() + bp * ldo_wm, ldo_wm, rows, Db, w + wte.in + nt * ld_te, ld_te,
+                               w + wmd.in + nt * ld_md, ld_md, w + wwm.in + np * ld_wm, ld_wm,
+                               u.use_g ? w + wwm.in + nt * ld_wm : (float*)nullptr, ld_wm);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return 0;
+}
+
+// Backward through the unroll, last step first.  Input gradients are needed in full here (the
+// current-state columns of every consumer feed the previous step), weight gradients contract over
+// ALL steps at once: the time-step blocks are stacked along the row axis, so one launch per layer
+// with K = blocks * rows_pad yields sum_t X_t^T dZ_t (and Adam runs once, in its epilogue).
+static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_step_params* sp, bool backward,
+                                   bool fused, const StepShape& S, hipStream_t st, Plan& plan) {
+    const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
+    const Unroll u = make_unroll(c, phase, rows, sp);
+    const int T = u.T;
+    float* w = c->ws;
+    float* part = w + c->W.loss_part;
+    const bool joint = phase == PVAE_PHASE_JOINT;
+    const NetLayout* NL = c->L.net;
+    const NetWork* NW = c->W.net;
+    const double rowsf = c->staged_rows_f;
+    auto push = [&](std::function<int()> f) -> Stage& {
+        plan.emplace_back();
+        plan.back().run = std::move(f);
+        return plan.back();
+    };
+    // which invocations carry gradient (evaluated last step first)
+    const bool a_grad = joint && sp->a_rec_coeff > 0.0f;
+    std::vector<char> p_act(T, 0), md_act(T, 0), any(T + 1, 0);
+    for (int t = T - 1; t >= 0; --t) {
+        p_act[t] = S.cyc_grad || (t + 1 < T && any[t + 1]);
+        md_act[t] = a_grad || p_act[t];
+        any[t] = md_act[t] || p_act[t] || u.use_g;
+    }
+    // full dgrad chain of net n over row block `slot`; layer 0 only when its input gradient is consumed
+    auto dgrad_chain = [&](int n, int slot, bool layer0) {
+        const NetLayout* N = &NL[n];
+        const NetWork* nw = &NW[n];
+        const int64_t b = u.blk(slot);
+        const int rows_pad = u.rows_pad;
+        for (int i = (int)N->layers.size() - 1; i >= (layer0 ? 0 : 1); --i) {
+            push([=]() -> int {
+                const Layer& l = N->layers[i];
+                const float* mask = i > 0 ? w + nw->act[i - 1] + b * l.ld : nullptr;
+                float* out = i > 0 ? w + nw->dz[i - 1] + b * l.ld : w + nw->d_in + b * l.ld;
+                const int ps = g_prof.begin(1, 2.0 * rowsf * l.n_in * l.n_out, st);
+                HIP_TRY(gemm_dgrad(w + nw->dz[i] + b * l.n_out_pad, l.n_out_pad, c->params + l.w_off, l.ld, mask, l.ld,
+                                   out, l.ld, rows_pad, l.ld, l.n_out_pad, st));
+                g_prof.end(ps, st);
+                return 0;
+            });
+        }
+    };
+    const int ld_te = NL[PVAE_NET_TE].layers[0].ld, ld_md = NL[PVAE_NET_MD].layers[0].ld;
+    const int ld_wm = NL[PVAE_NET_WM].layers[0].ld;
+    const int ldo_te = NL[PVAE_NET_TE].layers.back().n_out_pad, ldo_md = NL[PVAE_NET_MD].layers.back().n_out_pad;
+    const int ldo_wm = NL[PVAE_NET_WM].layers.back().n_out_pad;
+    const NetWork* wte = &NW[PVAE_NET_TE];
+    const NetWork* wmd = &NW[PVAE_NET_MD];
+    const NetWork* wwm = &NW[PVAE_NET_WM];
+    for (int t = T - 1; t >= 0; --t) {
+        const int64_t bt = u.blk(t), bp = u.blk(T + t);
+        const int rows_pad = u.rows_pad;
+        if (backward && u.use_g) dgrad_chain(PVAE_NET_WM, t, t > 0);
+        if (backward && p_act[t]) {
+            if (t + 1 < T && any[t + 1]) {        // + gradient wrt s1_{t+1}, from every consumer of it
+                const int64_t nt = u.blk(t + 1), np = u.blk(T + t + 1);
+                const float* s_te = md_act[t + 1] ? w + wte->d_in + nt * ld_te : nullptr;
+                const float* s_md = md_act[t + 1] ? w + wmd->d_in + nt * ld_md : nullptr;
+                const float* s_p = p_act[t + 1] ? w + wwm->d_in + np * ld_wm : nullptr;
+                const float* s_g = u.use_g ? w + wwm->d_in + nt * ld_wm : nullptr;
+                push([=]() -> int {
+                    const int grid = (rows * Db + 255) / 256 < 256 ? (rows * Db + 255) / 256 : 256;
+                    hipLaunchKernelGGL(add_cols_kernel, dim3(grid), dim3(256), 0, st, w + wwm->dz.back() + bp * ldo_wm,
+                                       ldo_wm, rows, Db, s_te, ld_te, s_md, ld_md, s_p, ld_wm, s_g, ld_wm);
+                    HIP_TRY(hipGetLastError());
+                    return 0;
+                });
+            }
+            dgrad_chain(PVAE_NET_WM, T + t, true);
+        }
+        // action reconstruction (tpv:381-382) + gradient arriving through the world model
+        if (md_act[t] || (joint && sp->a_rec_coeff > 0.0f)) {
+            const float ga = joint ? sp->a_rec_coeff * 2.0f / (S.Bg * Da) : 0.0f;
+            const int nparts = S.nparts_a;
+            const bool extra = p_act[t] && backward;
+            push([=]() -> int {
+                hipLaunchKernelGGL(mse_grad_kernel, dim3(nparts), dim3(256), 0, st, w + wmd->act.back() + bt * ldo_md,
+                                   ldo_md, w + c->W.act_t + bt * pad64(Da), pad64(Da),
+                                   backward ? w + wmd->dz.back() + bt * ldo_md : (float*)nullptr, ldo_md, rows, rows_pad,
+                                   Da, ga, extra ? w + wwm->d_in + bp * ld_wm : (const float*)nullptr, ld_wm, Db,
+                                   part + 1 * kLossParts + t * nparts);
+                HIP_TRY(hipGetLastError());
+                return 0;
+            });
+        }
+        if (!backward || !md_act[t]) continue;
+        dgrad_chain(PVAE_NET_MD, t, true);
+        {
+            const float kls = S.kl_active ? sp->kl_coeff / S.Bg : 0.0f;
+            const int tot = rows_pad * ldo_te;
+            push([=]() -> int {
+                hipLaunchKernelGGL(reparam_bwd_kernel, dim3((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256), dim3(256),
+                                   0, st, w + wmd->d_in + bt * ld_md, ld_md, Db, w + wte->act.back() + bt * ldo_te, ldo_te,
+                                   w + c->W.eps + bt * Z, w + wte->dz.back() + bt * ldo_te, ldo_te, rows, rows_pad, Z,
+                                   kls);
+                HIP_TRY(hipGetLastError());
+                return 0;
+            });
+        }
+        dgrad_chain(PVAE_NET_TE, t, t > 0);
+    }
+    if (!backward) return;
+
+    // weight gradients: one contraction per layer over the stacked blocks
+    const LossFinal* fold = S.lf.out ? &S.lf : nullptr;
+    std::vector<int> train_nets;
+    if (joint) { train_nets.push_back(PVAE_NET_MD); train_nets.push_back(PVAE_NET_TE); }
+    else train_nets.push_back(PVAE_NET_WM);
+    for (size_t k = 0; k < train_nets.size(); ++k) {
+        const int n = train_nets[k];
+        const NetLayout* N = &NL[n];
+        const NetWork* nw = &NW[n];
+        // active row blocks of this net; trailing inactive ones are cut off, others are zeroed
+        std::vector<char> act;
+        if (n == PVAE_NET_WM) {
+            for (int t = 0; t < T; ++t) act.push_back(u.use_g);
+            for (int t = 0; t < T; ++t) act.push_back(p_act[t]);
+        } else {
+            for (int t = 0; t < T; ++t) act.push_back(md_act[t]);
+        }
+        int blocks = (int)act.size();
+        while (blocks > 0 && !act[blocks - 1]) --blocks;
+        for (int b = 0; b < blocks; ++b) {
+            if (act[b]) continue;
+            const int64_t r0 = u.blk(b);
+            const size_t nrows = (size_t)u.rows_pad;
+            push([=]() -> int {
+                for (const Layer& l : N->layers)
+                    HIP_TRY(hipMemsetAsync(w + nw->dz[l.index] + r0 * l.n_out_pad, 0, nrows * l.n_out_pad * sizeof(float), st));
+                return 0;
+            });
+        }
+        const int krows = blocks * u.rows_pad;
+        const AdamScalars as = adam_scalars(sp, n);
+        const bool last_net = k + 1 == train_nets.size();
+        for (int i = (int)N->layers.size() - 1; i >= 0; --i) {
+            const bool with_fold = fold && last_net && i == 0;
+            LossFinal foldv;
+            memset(&foldv, 0, sizeof(foldv));
+            if (with_fold) foldv = *fold;
+            Stage& sref = push([=]() -> int {
+                const Layer& l = N->layers[i];
+                const float* dz = w + nw->dz[i];
+                const float* xin = i == 0 ? w + nw->in : w + nw->act[i - 1];
+                const int pw = g_prof.begin(2, 2.0 * rowsf * blocks * l.n_in * l.n_out, st);
+                int rc2 = 0;
+                if (krows == 0) {
+                    rc2 = 0;                   // nothing reached this net: gradient stays as it is
+                } else if (fused) {
+                    EpiGradAdam e{c->params + l.w_off, c->m + l.w_off, c->v + l.w_off, l.ld, as};
+                    e.b = c->params + l.b_off; e.bm = c->m + l.b_off; e.bv = c->v + l.b_off;
+                    if (with_fold) e.loss = foldv;
+                    hipError_t he = gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, krows, e, st);
+                    if (he != hipSuccess) rc2 = fail(-10, "gemm_wgrad: %s", hipGetErrorString(he));
+                } else {
+                    EpiGradStore e{c->grads + l.w_off, l.ld};
+                    e.gb = c->grads + l.b_off;
+                    if (with_fold) e.loss = foldv;
+                    hipError_t he = gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, krows, e, st);
+                    if (he != hipSuccess) rc2 = fail(-10, "gemm_wgrad: %s", hipGetErrorString(he));
+                }
+                g_prof.end(pw, st);
+                return rc2;
+            });
+            sref.ready_off = N->layers[i].w_off;
+            sref.ready_cnt = N->layers[i].b_off + N->layers[i].n_out_pad - N->layers[i].w_off;
+            sref.net = n;
+        }
+    }
 }
 
 extern "C" {
@@ -939,6 +1258,11 @@ int pvae_read_tensor(pvae_ctx* c, int what, float* dst, int32_t rows, void* stre
     if (rc) return rc;
     if (!dst || rows < 1 || rows > c->W.Bp) return fail(-1, "bad dst/rows");
     const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
+    const int t = what >> 3;                   // time step (lookahead > 1), 0 otherwise
+    what &= 7;
+    if (t < 0 || t >= c->W.L) return fail(-1, "time step %d outside [0, %d)", t, c->W.L);
+    const int rows_pad = pad32(c->staged_rows > 0 ? c->staged_rows : rows);
+    int64_t blk = (int64_t)t * rows_pad;
     const float* src; int ld, col0, nc;
     const NetWork& wte = c->W.net[PVAE_NET_TE];
     switch (what) {
@@ -946,10 +1270,13 @@ int pvae_read_tensor(pvae_ctx* c, int what, float* dst, int32_t rows, void* stre
         case 1: src = c->ws + wte.act.back(); ld = c->L.net[PVAE_NET_TE].layers.back().n_out_pad; col0 = Z; nc = Z; break;
         case 2: src = c->ws + c->W.net[PVAE_NET_MD].in; ld = c->L.net[PVAE_NET_MD].layers[0].ld; col0 = Db; nc = Z; break;
         case 3: src = c->ws + c->W.net[PVAE_NET_MD].act.back(); ld = c->L.net[PVAE_NET_MD].layers.back().n_out_pad; col0 = 0; nc = Da; break;
-        case 4: src = c->ws + c->W.net[PVAE_NET_WM].act.back(); ld = c->L.net[PVAE_NET_WM].layers.back().n_out_pad; col0 = 0; nc = Db; break;
+        case 4: src = c->ws + c->W.net[PVAE_NET_WM].act.back(); ld = c->L.net[PVAE_NET_WM].layers.back().n_out_pad; col0 = 0; nc = Db;
+                if (c->W.L > 1) blk += (int64_t)c->W.L * rows_pad;      // the predicted-action invocation
+                break;
         case 5: src = c->ws + c->W.eps; ld = Z; col0 = 0; nc = Z; break;
         default: return fail(-1, "unknown tensor id %d", what);
     }
+    src += blk * ld;
     hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, src, ld, col0, dst, nc, 0, rows, nc);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -961,7 +1288,8 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
     if (rc) return rc;
     if (!obs || !a_hat) return fail(-1, "obs / a_hat is null");
     hipStream_t st = (hipStream_t)stream;
-    if ((rc = stage(c, 0, obs, nullptr, rows, false, st))) return rc;
+    if ((rc = stage(c, 0, obs, nullptr, rows, false, st, 1))) return rc;
+    c->staged_rows = 0;      // not a training batch
     const int rows_pad = pad32(rows);
     const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
     float* w = c->ws;

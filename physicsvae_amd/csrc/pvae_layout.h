@@ -41,6 +41,7 @@ inline Layout make_layout(const pvae_config& c) {
         c.wm_depth <= 0) { L.why = "width/depth must be positive"; return L; }
     if (c.te_depth > 15 || c.md_depth > 15 || c.wm_depth > 15) { L.why = "depth > 15 unsupported"; return L; }
     if (c.max_batch <= 0 || c.max_batch > 65536) { L.why = "max_batch out of range"; return L; }
+    if (c.lookahead < 1 || c.lookahead > 64) { L.why = "lookahead must be in [1, 64]"; return L; }
     const int Db = c.dim_body, Da = c.dim_action, Z = c.latent;
     const int ins[3] = {2 * Db, Db + Z, Db + Da};        // rmt:638-644, 646-668, 682-689
     const int outs[3] = {2 * Z, Da, Db};
@@ -73,17 +74,26 @@ inline Layout make_layout(const pvae_config& c) {
 }
 
 // Workspace carving (all offsets in floats, every buffer 64-float aligned).
+//
+// lookahead L > 1 (tpv:367-428): every panel holds `slots` time-step blocks stacked along the
+// row axis, block s at rows [s*rows_pad, (s+1)*rows_pad) of the CURRENT batch (rows_pad =
+// rows rounded up to 32).  TE/MD: one block per step.  WM: blocks [0, L) are the invocations
+// with the demonstrated action (tpv:411-414), blocks [L, 2L) those with the decoder's action
+// (rmt:758, the state fed to the next step).  Stacking is what lets ONE weight-gradient
+// launch per layer contract over all steps (K = slots * rows_pad).
 struct NetWork {
-    std::vector<int64_t> act;   // act[i]: output of layer i  [Bp][n_out_pad_i]
+    std::vector<int64_t> act;   // act[i]: output of layer i  [slots*Bp][n_out_pad_i]
     std::vector<int64_t> dz;    // dz[i]: grad wrt pre-activation of layer i, same shape
-    int64_t in = 0, d_in = 0;   // input panel [Bp][ld0] and its gradient
+    int64_t in = 0, d_in = 0;   // input panel [slots*Bp][ld0] and its gradient
+    int slots = 1;
 };
 
 struct Workspace {
-    int Bp = 0;                 // rows allocated (max_batch padded to 32)
+    int Bp = 0;                 // rows allocated per block (max_batch padded to 32)
+    int L = 1;                  // lookahead
     NetWork net[PVAE_NUM_NETS];
-    int64_t s2 = 0, act_t = 0;  // targets: next state [Bp][pad64(Db)], action [Bp][pad64(Da)]
-    int64_t eps = 0;            // eps actually used [Bp][Z]
+    int64_t s2 = 0, act_t = 0;  // targets: next state [L*Bp][pad64(Db)], action [L*Bp][pad64(Da)]
+    int64_t eps = 0;            // eps actually used [L*Bp][Z]
     int64_t loss_part = 0;      // [5][kLossParts] partial sums
     int64_t total_floats = 0;
 };
@@ -93,20 +103,24 @@ constexpr int kLossParts = 8192;   // max workgroups contributing to one loss te
 inline Workspace make_workspace(const Layout& L) {
     Workspace W;
     W.Bp = pad32(L.cfg.max_batch);
+    W.L = L.cfg.lookahead;
+    const int64_t T = W.L;
     int64_t off = 0;
     auto take = [&](int64_t n) { int64_t o = off; off += (n + 63) / 64 * 64; return o; };
     for (int n = 0; n < PVAE_NUM_NETS; ++n) {
         const NetLayout& N = L.net[n];
-        W.net[n].in = take((int64_t)W.Bp * N.layers[0].ld);
-        W.net[n].d_in = take((int64_t)W.Bp * N.layers[0].ld);
+        const int64_t slots = (T > 1 && n == PVAE_NET_WM) ? 2 * T : T;
+        W.net[n].slots = (int)slots;
+        W.net[n].in = take(slots * W.Bp * N.layers[0].ld);
+        W.net[n].d_in = take(slots * W.Bp * N.layers[0].ld);
         for (const Layer& l : N.layers) {
-            W.net[n].act.push_back(take((int64_t)W.Bp * l.n_out_pad));
-            W.net[n].dz.push_back(take((int64_t)W.Bp * l.n_out_pad));
+            W.net[n].act.push_back(take(slots * W.Bp * l.n_out_pad));
+            W.net[n].dz.push_back(take(slots * W.Bp * l.n_out_pad));
         }
     }
-    W.s2 = take((int64_t)W.Bp * pad64(L.cfg.dim_body));
-    W.act_t = take((int64_t)W.Bp * pad64(L.cfg.dim_action));
-    W.eps = take((int64_t)W.Bp * L.cfg.latent);
+    W.s2 = take(T * W.Bp * pad64(L.cfg.dim_body));
+    W.act_t = take(T * W.Bp * pad64(L.cfg.dim_action));
+    W.eps = take(T * W.Bp * L.cfg.latent);
     W.loss_part = take(5 * kLossParts);
     W.total_floats = off;
     return W;

@@ -20,9 +20,9 @@ class Arch:
         self.Db, self.Da, self.Z = int(dim_body), int(dim_action), int(latent)
         self.te, self.md, self.wm = tuple(te), tuple(md), tuple(wm)
 
-    def config(self, max_batch):
+    def config(self, max_batch, lookahead=1):
         return _lib.Config(self.Db, self.Da, self.Z, self.te[0], self.te[1], self.md[0],
-                           self.md[1], self.wm[0], self.wm[1], int(max_batch))
+                           self.md[1], self.wm[0], self.wm[1], int(max_batch), int(lookahead))
 
     def key(self):
         return (self.Db, self.Da, self.Z, self.te, self.md, self.wm)
@@ -41,12 +41,13 @@ def make_step_params(lr, adam_t=(1, 1, 1), a_rec=1.0, kl=1.0, s_rec=0.0, cyc=1e-
 
 
 class HipEngine:
-    def __init__(self, arch, max_batch, device="cuda"):
+    def __init__(self, arch, max_batch, device="cuda", lookahead=1):
         self.lib = _lib.load()
         self.arch = arch
         self.max_batch = int(max_batch)
+        self.lookahead = int(lookahead)          # steps unrolled per sample (tpv:277, 367-428)
         self.device = torch.device(device)
-        self.cfg = arch.config(max_batch)
+        self.cfg = arch.config(max_batch, self.lookahead)
         n = self.lib.pvae_arena_floats(C.byref(self.cfg))
         _lib.check(int(n), "pvae_arena_floats")
         self.arena_floats = int(n)
@@ -132,7 +133,7 @@ class HipEngine:
         actions = actions.to(self.device, torch.float32).contiguous()
         window_row = window_row.to(self.device, torch.int32).contiguous()
         assert states.shape[1] == self.arch.Db and actions.shape[1] == self.arch.Da
-        assert int(window_row.max()) + 1 < states.shape[0]
+        assert int(window_row.max()) + self.lookahead < states.shape[0]
         self.dataset = (states, actions, window_row)
         _lib.check(self.lib.pvae_bind_dataset(self.ctx, states.data_ptr(), actions.data_ptr(),
                                               window_row.data_ptr(), states.shape[0],
@@ -144,12 +145,14 @@ class HipEngine:
                    "pvae_gather")
 
     def set_batch(self, x, y):
-        """x [B, 2Db] (or [B,1,2Db]), y [B, Da] (or [B,1,Da]) -- tpv:365-376."""
+        """x [B, L, 2Db] (L == 1 may be squeezed), y [B, L, Da] -- tpv:365-376."""
         self._need_gpu()
         x = x.reshape(x.shape[0], -1).to(self.device, torch.float32).contiguous()
+        assert x.shape[1] == self.lookahead * 2 * self.arch.Db, "x must be [B, lookahead, 2*Db]"
         yp = None
         if y is not None:
             y = y.reshape(y.shape[0], -1).to(self.device, torch.float32).contiguous()
+            assert y.shape[1] == self.lookahead * self.arch.Da, "y must be [B, lookahead, Da]"
             yp = y.data_ptr()
         self._keep = (x, y)
         _lib.check(self.lib.pvae_set_batch(self.ctx, x.data_ptr(), yp, x.shape[0], self._stream()),
@@ -162,20 +165,26 @@ class HipEngine:
         self._need_gpu()
         flags = (FLAG_FUSED_ADAM if fused_adam else 0) | (0 if backward else FLAG_NO_BACKWARD)
         if eps is not None:
-            eps = eps.to(self.device, torch.float32).contiguous()
-            assert eps.shape == (rows, self.arch.Z)
-            self._keep_eps = eps
+            eps = self._eps(eps, rows)
         out = self._loss_scratch if loss_out is None else loss_out
         _lib.check(self.lib.pvae_forward_backward(
             self.ctx, phase, int(rows), C.byref(sp), eps.data_ptr() if eps is not None else None,
             out.data_ptr(), flags, self._stream()), "pvae_forward_backward")
         return out
 
+    def _eps(self, eps, rows):
+        """[rows, Z] (lookahead 1) or [lookahead, rows, Z]: one slice per unrolled step."""
+        eps = eps.to(self.device, torch.float32).contiguous()
+        want = (self.lookahead, rows, self.arch.Z)
+        assert tuple(eps.shape) == want or (self.lookahead == 1 and tuple(eps.shape) == want[1:]), \
+            "eps must be [lookahead, rows, Z]"
+        self._keep_eps = eps
+        return eps
+
     def forward_seed(self, phase, rows, sp, eps=None):
         self._need_gpu()
         if eps is not None:
-            eps = eps.to(self.device, torch.float32).contiguous()
-            self._keep_eps = eps
+            eps = self._eps(eps, rows)
         _lib.check(self.lib.pvae_forward_seed(self.ctx, phase, int(rows), C.byref(sp),
                                               eps.data_ptr() if eps is not None else None, self._stream()),
                    "pvae_forward_seed")
@@ -207,8 +216,7 @@ class HipEngine:
     def train_step(self, phase, first_window, rows, sp, eps=None, loss_out=None):
         self._need_gpu()
         if eps is not None:
-            eps = eps.to(self.device, torch.float32).contiguous()
-            self._keep_eps = eps
+            eps = self._eps(eps, rows)
         out = self._loss_scratch if loss_out is None else loss_out
         _lib.check(self.lib.pvae_train_step(
             self.ctx, phase, int(first_window), int(rows), C.byref(sp),
@@ -216,12 +224,13 @@ class HipEngine:
             "pvae_train_step")
         return out
 
-    def read(self, name, rows):
+    def read(self, name, rows, step=0):
+        """Forward intermediate of time step `step` of the last batch."""
         self._need_gpu()
         width = {"mu": self.arch.Z, "logvar": self.arch.Z, "z": self.arch.Z, "eps": self.arch.Z,
                  "a_hat": self.arch.Da, "s2_hat": self.arch.Db}[name]
         dst = torch.empty(rows, width, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.pvae_read_tensor(self.ctx, TENSOR_IDS[name], dst.data_ptr(), rows,
+        _lib.check(self.lib.pvae_read_tensor(self.ctx, TENSOR_IDS[name] + 8 * int(step), dst.data_ptr(), rows,
                                              self._stream()), "pvae_read_tensor")
         return dst
 
@@ -240,7 +249,6 @@ class HipEngine:
             1 if noise else 0, int(seed), int(offset), a_hat.data_ptr(),
             s2.data_ptr() if s2 is not None else None, z.data_ptr(), self._stream()), "pvae_infer")
         return a_hat, s2, z
-
 
     def panel(self, kind, net=0, layer=0):
         """Workspace panel as a [Bp, width] view (inspection / tests).  kind: 'in', 'd_in',

@@ -169,6 +169,7 @@ class PhysicsVAE(nn.Module):
         # ours: where the arena lives and how many rows one call may carry
         "device": None,
         "max_batch": 256,
+        "lookahead": 1,
     }
 
     def __init__(self, obs_space, action_space, num_outputs, model_config, name, **kwargs):
@@ -208,7 +209,8 @@ class PhysicsVAE(nn.Module):
         vb = _uniform_relu_stack(cfg["value_fn_layers"], "value_fn_layers")
         self.arch = Arch(self.dim_state_body, self.dim_action, Z, te, md, wm)
         device = cfg["device"] or ("cuda" if torch.cuda.is_available() else "cpu")
-        self.engine = HipEngine(self.arch, int(cfg["max_batch"]), device=device)
+        self.engine = HipEngine(self.arch, int(cfg["max_batch"]), device=device,
+                                lookahead=int(cfg.get("lookahead", 1) or 1))
 
         views = self.engine.named_views()
         per_net = {n: [] for n in (NET_TE, NET_MD, NET_WM)}

@@ -179,7 +179,7 @@ class TrainModel(tune.Trainable):
         self.loss_fn_test = get_loss_fn("MSE")
         self.iter = 0
         self.global_batch = 0                     # minibatches consumed so far (eps / Philox key)
-        self.eps_fn = config.get("eps_fn")        # callable(global_batch, (rows, Z)) -> eps, or None
+        self.eps_fn = config.get("eps_fn")        # callable(forward_call, (rows, Z)) -> eps, or None
         self.rng_seed = int(config.get("seed", 0))
         self.last_loss_terms = None
 
@@ -223,12 +223,14 @@ class TrainModel(tune.Trainable):
             first, rows, global_rows = dp.shard(g, len(loader.dataset), loader.batch_size)
             sp = self.step_params(nets, global_rows, train)
             sp.rng_seed = self.rng_seed
-            sp.rng_offset = self.global_batch * 65536 + dp.rank
+            sp.rng_offset = self.global_batch * 65536 + dp.rank * 64     # + t per unrolled step
             eps = None
-            if self.eps_fn is not None and phase == PHASE_JOINT:
-                full = self.eps_fn(self.global_batch, (global_rows, self.engine.arch.Z))
+            L = eng.lookahead
+            if self.eps_fn is not None and (phase == PHASE_JOINT or L > 1):
+                # one draw per model forward, i.e. per unrolled step (call = minibatch * L + t)
                 lo = first - dp.global_first(g, loader.batch_size)
-                eps = full[lo: lo + rows]
+                eps = torch.stack([self.eps_fn(self.global_batch * L + t, (global_rows, eng.arch.Z))[lo: lo + rows]
+                                   for t in range(L)])
             if not train:
                 if rows:
                     eng.gather(first, rows)

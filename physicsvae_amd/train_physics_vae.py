@@ -60,6 +60,8 @@ def arg_parser():
     p.add_argument("--world_model_width", type=int, default=1024)
     p.add_argument("--world_model_depth", type=int, default=2)
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--lookahead", type=int, default=1,
+                   help="steps unrolled through the world model per sample (config key tpv:277)")
     return p
 
 
@@ -92,29 +94,51 @@ class WindowDataset(torch_models.DatasetBase):
     is the next row) -- the layout the gather kernel reads from HBM.  `__getitem__`, `X`, `Y`
     reproduce the reference's tensors on demand."""
 
-    def __init__(self, states, actions, window_row):
+    def __init__(self, states, actions, window_row, lookahead=1):
         self.states = np.ascontiguousarray(states, dtype=np.float32)
         self.actions = np.ascontiguousarray(actions, dtype=np.float32)
         self.window_row = np.ascontiguousarray(window_row, dtype=np.int32)
+        self.lookahead = int(lookahead)          # steps per window: rows r .. r+L of one episode
         self.normalize_x = self.normalize_y = False        # tpv:163-164
         self._dev = None
 
     def __len__(self):
         return len(self.window_row)
 
+    def _steps(self, rows):
+        return np.asarray(rows)[..., None] + np.arange(self.lookahead)
+
     def __getitem__(self, index):
-        r = int(self.window_row[index])
-        x = np.concatenate([self.states[r], self.states[r + 1]])[None, :]
-        return torch.from_numpy(x.copy()), torch.from_numpy(self.actions[r][None, :].copy())
+        r = self._steps(int(self.window_row[index]))                      # [L]
+        x = np.concatenate([self.states[r], self.states[r + 1]], axis=1)  # tpv:141-154
+        return torch.from_numpy(x.copy()), torch.from_numpy(self.actions[r].copy())
 
     @property
     def X(self):
-        r = self.window_row
-        return np.concatenate([self.states[r], self.states[r + 1]], axis=1)[:, None, :].astype(np.float64)
+        r = self._steps(self.window_row)                                   # [N, L]
+        return np.concatenate([self.states[r], self.states[r + 1]], axis=2).astype(np.float64)
 
     @property
     def Y(self):
-        return self.actions[self.window_row][:, None, :].astype(np.float64)
+        return self.actions[self._steps(self.window_row)].astype(np.float64)
+
+    def with_lookahead(self, lookahead):
+        """Windows of `lookahead` steps over the same rows: keeps the starts whose next
+        lookahead-1 rows are window starts too (i.e. the span stays inside one episode)."""
+        lookahead = int(lookahead)
+        if lookahead == self.lookahead:
+            return self
+        if self.lookahead != 1:
+            raise ValueError("can only widen a lookahead-1 window list")
+        starts = np.asarray(self.window_row, dtype=np.int64)
+        have = np.zeros(len(self.states) + lookahead, dtype=bool)
+        have[starts] = True
+        keep = np.ones(len(starts), dtype=bool)
+        for j in range(1, lookahead):
+            keep &= have[starts + j]
+        ds = WindowDataset(self.states, self.actions, starts[keep].astype(np.int32), lookahead)
+        ds.meta = getattr(self, "meta", {})
+        return ds
 
     def device_arrays(self, device):
         if self._dev is None or self._dev[0].device != torch.device(device):
@@ -136,7 +160,8 @@ def save_packed(dataset, path, meta=None):
     arrays = [("states", dataset.states), ("actions", dataset.actions), ("window_row", dataset.window_row)]
     header = {"version": 1, "dim_state_body": int(dataset.states.shape[1]),
               "dim_action": int(dataset.actions.shape[1]), "n_rows": int(dataset.states.shape[0]),
-              "n_windows": int(len(dataset.window_row)), "meta": meta or {}}
+              "n_windows": int(len(dataset.window_row)), "lookahead": int(dataset.lookahead),
+              "meta": meta or {}}
     pos = 4096                                   # header block is padded to 4 KB
     for name, arr in arrays:
         pos = (pos + 63) // 64 * 64
@@ -164,7 +189,7 @@ def load_packed(path):
     for name in ("states", "actions", "window_row"):
         h = header[name]
         arrs[name] = np.memmap(path, mode="r", dtype=np.dtype(h["dtype"]), offset=h["offset"], shape=tuple(h["shape"]))
-    ds = WindowDataset(arrs["states"], arrs["actions"], arrs["window_row"])
+    ds = WindowDataset(arrs["states"], arrs["actions"], arrs["window_row"], header.get("lookahead", 1))
     ds.meta = header.get("meta", {})
     return ds
 
@@ -174,8 +199,9 @@ def load_dataset_for_PhysicsVAE(files, num_samples=None, lookahead=1, cond="abs"
     total at exactly that many (tpv:137-138).  Files ending in .pvd are packed demonstration
     files (save_packed); anything else is the reference's pickle."""
     assert files and len(files) > 0
+    assert lookahead >= 1
     if all(str(f).endswith(".pvd") for f in files):
-        parts = [load_packed(f) for f in files]
+        parts = [load_packed(f).with_lookahead(lookahead) for f in files]
         for p_ in parts[1:]:                     # same compatibility rule as merge_dataset
             assert p_.states.shape[1] == parts[0].states.shape[1] and p_.actions.shape[1] == parts[0].actions.shape[1]
             for key in META_KEYS:
@@ -188,11 +214,9 @@ def load_dataset_for_PhysicsVAE(files, num_samples=None, lookahead=1, cond="abs"
             if num_samples is not None:
                 rows = rows[:num_samples]
             ds = WindowDataset(np.concatenate([p_.states for p_ in parts]),
-                               np.concatenate([p_.actions for p_ in parts]), rows.astype(np.int32))
+                               np.concatenate([p_.actions for p_ in parts]), rows.astype(np.int32), lookahead)
         print("Packed demonstrations:", files, "windows:", len(ds))
         return ds
-    if lookahead != 1:
-        raise NotImplementedError("lookahead > 1 (the trainer hard-wires 1, tpv:277)")
     if cond != "abs":
         raise NotImplementedError("cond=%r (the trainer uses 'abs')" % cond)
     data = merge_dataset(files)
@@ -211,7 +235,7 @@ def load_dataset_for_PhysicsVAE(files, num_samples=None, lookahead=1, cond="abs"
         actions.append(ac.astype(np.float32))
         rows.extend(range(base, base + n))
         base += T
-    ds = WindowDataset(np.concatenate(states), np.concatenate(actions), np.asarray(rows, dtype=np.int32))
+    ds = WindowDataset(np.concatenate(states), np.concatenate(actions), np.asarray(rows, dtype=np.int32), lookahead)
     ds.meta = {k: data.get(k) for k in META_KEYS}
     print("------------------Data Loaded------------------")
     print("File:", files)
@@ -283,7 +307,7 @@ def get_trainer_config(a):
         "MD_depth": tune.grid_search([getattr(a, "MD_depth", 3)]),
         "TE_width": tune.grid_search([getattr(a, "TE_width", 256)]),
         "TE_depth": tune.grid_search([getattr(a, "TE_depth", 2)]),
-        "lookahead": 1,
+        "lookahead": getattr(a, "lookahead", 1),       # tpv:277 hard-wires 1; --lookahead exposes it
         "world_model_width": tune.grid_search([getattr(a, "world_model_width", 1024)]),
         "world_model_depth": tune.grid_search([getattr(a, "world_model_depth", 2)]),
         "vae_kl_coeff": tune.grid_search(a.vae_kl_coeff),
@@ -305,6 +329,7 @@ def update_model_config(trainer_config):
         cmc[key] = gen_layers(width=trainer_config.get(prefix + "_width"),
                               depth=trainer_config.get(prefix + "_depth"), act_hidden=act)
     cmc["max_batch"] = trainer_config.get("batch_size", cmc.get("max_batch", 256))
+    cmc["lookahead"] = trainer_config.get("lookahead", 1) or 1     # sizes the unroll workspace
 
 
 class TrainModel(torch_models.TrainModel):
@@ -357,7 +382,7 @@ class TrainModel(torch_models.TrainModel):
         return logits[..., : logits.shape[1] // 2]
 
     def compute_loss(self, y, x, eps=None):
-        """Loss of one caller-supplied minibatch (x [B,1,2Db], y [B,1,Da]), forward only.
+        """Loss of one caller-supplied minibatch (x [B,L,2Db], y [B,L,Da]), forward only.
         Returns the 0-dim total (device tensor); per-term values in `self.last_loss_terms`."""
         phase, nets = self.phase()
         rows = self.engine.set_batch(x, y)

@@ -29,12 +29,12 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pvae_abi_version() == 1
+    assert lib.pvae_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_layout_queries_without_gpu():
     lib = _lib.load()
-    cfg = _lib.Config(197, 45, 32, 1024, 4, 1024, 4, 1024, 4, 256)
+    cfg = _lib.Config(197, 45, 32, 1024, 4, 1024, 4, 1024, 4, 256, 1)
     assert lib.pvae_num_layers(C.byref(cfg)) == 15
     info = _lib.LayerInfo()
     end = 0
@@ -58,7 +58,7 @@ def test_layout_queries_without_gpu():
 
 def test_bad_config_is_an_error_not_a_crash():
     lib = _lib.load()
-    cfg = _lib.Config(0, 45, 32, 1024, 4, 1024, 4, 1024, 4, 256)
+    cfg = _lib.Config(0, 45, 32, 1024, 4, 1024, 4, 1024, 4, 256, 1)
     assert lib.pvae_num_layers(C.byref(cfg)) < 0
     assert b"bad config" in lib.pvae_last_error()
     ctx = C.c_void_p()
@@ -202,6 +202,38 @@ def test_packed_file_roundtrip_and_trainer_config(tmp_path):
     np.testing.assert_array_equal(T.load_packed(out).X, ds.X)
     with pytest.raises(ValueError):
         T.load_packed(pkl)
+
+
+@pytest.mark.parametrize("L", [2, 3])
+def test_lookahead_windows_equal_oracle_windows(tmp_path, golden, L):
+    """tpv:131-156 with lookahead > 1: T-L windows per episode, never across an episode boundary;
+    the pickle path, the packed-file path (widened from its lookahead-1 window list) and the
+    loader's [B, L, .] tensors all equal the oracle's (hence the reference's) windows."""
+    data = R.synth_demo(0, 3, 21, 7, 3, kind="dynamics")
+    pkl = str(tmp_path / "d.pkl")
+    R.write_demo(pkl, data)
+    X, Y = R.build_windows(data, lookahead=L)
+    ds = T.load_dataset_for_PhysicsVAE([pkl], lookahead=L)
+    assert len(ds) == 3 * (21 - L) and ds.lookahead == L
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    np.testing.assert_array_equal(ds.X, f32(X))
+    np.testing.assert_array_equal(ds.Y, f32(Y))
+    x5, y5 = ds[5]
+    assert x5.shape == (L, 14) and y5.shape == (L, 3)
+    np.testing.assert_array_equal(x5.numpy(), X[5].astype(np.float32))
+    pvd = str(tmp_path / "d.pvd")
+    T.save_packed(T.load_dataset_for_PhysicsVAE([pkl]), pvd)
+    np.testing.assert_array_equal(T.load_dataset_for_PhysicsVAE([pvd], lookahead=L).X, f32(X))
+    np.testing.assert_array_equal(T.load_dataset_for_PhysicsVAE([pkl], num_samples=25, lookahead=L).X, f32(X[:25]))
+    if L == 3:                                    # window / batch counts of the reference capture
+        g = golden("look3_tiny")
+        d2 = R.synth_demo(0, 2, 15, 7, 3, kind="dynamics")
+        arch = R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2))
+        tr = make_trainer(arch, d2, batch=8, device="cpu", extra={"lookahead": 3})
+        assert len(tr.train_loader.dataset) == int(g["n_windows"])
+        assert len(tr.train_loader) == int(g["n_batches"])
+        assert list(tr.train_loader.spans())[-1][1] == int(g["last_batch_size"])
+        np.testing.assert_array_equal(R.tensor_digest(list(tr.train_loader)[-1][0]), g["loader_last_x_digest"])
 
 
 def test_loader_schedule_is_sequential_with_partial_last_batch():
