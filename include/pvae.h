@@ -42,6 +42,8 @@ typedef struct pvae_ctx pvae_ctx;
 
 enum { PVAE_NET_TE = 0, PVAE_NET_MD = 1, PVAE_NET_WM = 2, PVAE_NUM_NETS = 3 };
 enum { PVAE_PHASE_WORLD = 0, PVAE_PHASE_JOINT = 1 };
+/* loss_fn of the three reconstruction terms (get_loss_fn tm:97-107; trainer key "loss", tpv:257) */
+enum { PVAE_LOSS_MSE = 0, PVAE_LOSS_L1 = 1 };
 
 /* flags for pvae_forward_backward */
 enum {
@@ -91,6 +93,8 @@ typedef struct pvae_step_params {
                               ranks yields the reference's batch-mean gradient */
     uint64_t rng_seed;     /* Philox key when eps == NULL      */
     uint64_t rng_offset;   /* (global step, first global row) -> counter */
+    int32_t loss_kind;     /* PVAE_LOSS_MSE (nn.MSELoss, the trainer's setting) or PVAE_LOSS_L1 */
+    int32_t reserved;
 } pvae_step_params;
 
 /* ---- layout queries (pure host arithmetic, no GPU needed) --------------------------- */

@@ -40,7 +40,7 @@ def resolve_grid(cfg):
     return cfg
 
 
-def make_reference_trainer(pkl, arch, batch, m_world, num_data=None, lookahead=1):
+def make_reference_trainer(pkl, arch, batch, m_world, num_data=None, lookahead=1, loss="MSE"):
     argv = ["--data_train", pkl, "--batch_size", str(batch), "--max_iter", "1000",
             "--max_iter_world_model", str(m_world), "--latent_dim", str(arch["Z"])]
     T.args = T.arg_parser().parse_args(argv)
@@ -50,6 +50,7 @@ def make_reference_trainer(pkl, arch, batch, m_world, num_data=None, lookahead=1
     cfg["MD_width"], cfg["MD_depth"] = arch["md"]
     cfg["world_model_width"], cfg["world_model_depth"] = arch["wm"]
     cfg["lookahead"] = lookahead              # tpv:277 hard-wires 1; users edit the dict
+    cfg["loss"] = loss                        # tpv:257 -> get_loss_fn (tm:97-107)
     return T.TrainModel(cfg)
 
 
@@ -173,7 +174,7 @@ def case_single(name, arch, n_ep, n_steps, batch, full):
     print("wrote", name, "keys:", len(fix))
 
 
-def case_lookahead(name, arch, n_ep, n_steps, batch, lookahead, full):
+def case_lookahead(name, arch, n_ep, n_steps, batch, lookahead, full, loss="MSE"):
     """One minibatch through the reference's multi-step unroll (tpv:367-428), both phases."""
     data = R.synth_demo(seed=0, n_episodes=n_ep, n_steps=n_steps, dim_body=arch["Db"],
                         dim_action=arch["Da"], kind="dynamics")
@@ -181,7 +182,7 @@ def case_lookahead(name, arch, n_ep, n_steps, batch, lookahead, full):
     with tempfile.TemporaryDirectory() as td:
         pkl = os.path.join(td, "demo.pkl")
         R.write_demo(pkl, data)
-        tr = make_reference_trainer(pkl, arch, batch, m_world=2, lookahead=lookahead)
+        tr = make_reference_trainer(pkl, arch, batch, m_world=2, lookahead=lookahead, loss=loss)
         sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
         tr.model.load_state_dict(sd)
         loader = tr.train_loader
@@ -283,6 +284,8 @@ def main():
                                           full=False),
         "look3_tiny": lambda: case_lookahead("look3_tiny", tiny, 2, 15, 8, lookahead=3, full=True),
         "look2_c1": lambda: case_lookahead("look2_c1", c1, 2, 200, 64, lookahead=2, full=False),
+        "l1_tiny": lambda: case_lookahead("l1_tiny", tiny, 2, 15, 8, lookahead=1, full=True, loss="L1"),
+        "l1_look2_c1": lambda: case_lookahead("l1_look2_c1", c1, 2, 200, 64, lookahead=2, full=False, loss="L1"),
         "train_tiny_look2": lambda: case_training("train_tiny_look2", tiny, 3, 22, 8, m_world=2, n_epochs=5,
                                                   full=True, lookahead=2),
     }

@@ -298,8 +298,8 @@ def phase_coeffs(world, cfg=None):
     return cfg
 
 
-def compute_loss(model, x, y, coeffs):
-    """tpv:361-435.  x [B,L,2Db], y [B,L,Da], L = lookahead.  Returns (total, terms).
+def compute_loss(model, x, y, coeffs, loss="MSE"):
+    """tpv:361-435; `loss` selects self.loss_fn (tm:97-107, 126: "MSE" | "L1" | "MAE").  x [B,L,2Db], y [B,L,Da], L = lookahead.  Returns (total, terms).
     The full forward always runs (tpv:378), including in the world phase.  For L > 1 the
     state fed to step t+1 is the model's own prediction `_cur_future_state` of step t
     (tpv:421, not detached: the gradient flows back through the world model, the motor
@@ -308,7 +308,7 @@ def compute_loss(model, x, y, coeffs):
     Db = model.arch["Db"]
     Da = model.arch["Da"]
     L = x.shape[1]
-    mse = nn.MSELoss()
+    mse = nn.MSELoss() if loss == "MSE" else nn.L1Loss()
     zero = torch.zeros((), dtype=torch.float32)
     loss_a = loss_kl = loss_s = loss_cyc = zero
     s1 = x[:, 0, :Db]                                                 # tpv:365
@@ -346,7 +346,7 @@ def _eps_feeder(eps):
     return lambda shape: next(it)
 
 
-def loss_and_grads(arch, sd, x, y, eps, world, coeff_cfg=None):
+def loss_and_grads(arch, sd, x, y, eps, world, coeff_cfg=None, loss="MSE"):
     """One minibatch through the restated graph; returns forward internals, loss terms and
     every trainable gradient (frozen nets get no gradient, tpv:326-329, 347-350)."""
     model = RefModel(arch)
@@ -358,7 +358,7 @@ def loss_and_grads(arch, sd, x, y, eps, world, coeff_cfg=None):
     model.set_learnable("_world_model", world)
     coeffs = phase_coeffs(world, coeff_cfg)
     model.trace = []
-    total, terms = compute_loss(model, x, y, coeffs)
+    total, terms = compute_loss(model, x, y, coeffs, loss)
     total.backward()
     grads = OrderedDict((k, p.grad.detach().clone()) for k, p in model.named_parameters()
                         if p.grad is not None)
@@ -437,8 +437,9 @@ class RefTrainer:
     flip when `iter == max_iter_world_model` is seen *before* the increment."""
 
     def __init__(self, arch, sd, X, Y, batch_size, max_iter_world_model, lr=5e-4,
-                 lr_step=50, lr_gamma=0.7, coeff_cfg=None, eps_fn=None):
+                 lr_step=50, lr_gamma=0.7, coeff_cfg=None, eps_fn=None, loss="MSE"):
         self.arch = arch
+        self.loss = loss
         self.model = RefModel(arch)
         self.model.load_state_dict(sd)
         self.loader = make_loader(X, Y, batch_size)
@@ -475,7 +476,7 @@ class RefTrainer:
             if self.eps_fn is not None:
                 self.model.eps_source = self._next_eps
             self.opt.zero_grad()
-            loss, _ = compute_loss(self.model, x, y, self.coeffs)
+            loss, _ = compute_loss(self.model, x, y, self.coeffs, self.loss)
             loss.backward()
             self.opt.step()
             acc += loss.item()

@@ -17,6 +17,7 @@ NET_NAMES = {NET_TE: "_task_encoder", NET_MD: "_motor_decoder", NET_WM: "_world_
 PHASE_WORLD, PHASE_JOINT = 0, 1
 FLAG_FUSED_ADAM, FLAG_NO_BACKWARD = 1, 2
 ABI_VERSION = 2
+LOSS_MSE, LOSS_L1 = 0, 1
 
 
 class Config(C.Structure):
@@ -35,7 +36,8 @@ class StepParams(C.Structure):
     _fields_ = [("a_rec_coeff", C.c_float), ("kl_coeff", C.c_float), ("s_rec_coeff", C.c_float),
                 ("cycle_coeff", C.c_float), ("lr", C.c_double), ("beta1", C.c_double),
                 ("beta2", C.c_double), ("adam_eps", C.c_double), ("adam_t", C.c_int32 * 3),
-                ("global_rows", C.c_int32), ("rng_seed", C.c_uint64), ("rng_offset", C.c_uint64)]
+                ("global_rows", C.c_int32), ("rng_seed", C.c_uint64), ("rng_offset", C.c_uint64),
+                ("loss_kind", C.c_int32), ("reserved", C.c_int32)]
 
 
 _P = C.c_void_p

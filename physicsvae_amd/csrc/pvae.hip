@@ -189,16 +189,18 @@ __device__ inline float block_sum_256(float v) {
     return block_sum_256(v, red);
 }
 
-// nn.MSELoss (tm:99) of pred vs target over rows x D, plus its gradient:
+// nn.MSELoss (tm:99; or nn.L1Loss, tm:100-101, when l1) of pred vs target over rows x D, plus its
+// gradient:
 //   partial[b] = sum (pred - target)^2 over this block's rows      (finalize scales by 1/(B*D))
 //   dz = grad_scale * (pred - target) [+ extra]                    grad_scale = coeff*2/(B*D)
+//   L1: partial = sum |pred - target|, dz = grad_scale * sign(pred - target), grad_scale = coeff/(B*D)
 // Used for the world-model MSE (tpv:411-414), the cycle loss (tpv:417-419) and the action
 // reconstruction loss (tpv:381-382; `extra` = gradient arriving through the frozen world
 // model, columns [Db, Db+Da) of d(wm_in)).
 __global__ void __launch_bounds__(256)
 mse_grad_kernel(const float* __restrict__ pred, int ldp, const float* __restrict__ target, int ldt,
                 float* __restrict__ dz, int ldz, int rows, int rows_pad, int D, float grad_scale,
-                const float* __restrict__ extra, int lde, int extra_col0, float* __restrict__ partial) {
+                const float* __restrict__ extra, int lde, int extra_col0, float* __restrict__ partial, int l1) {
     float acc = 0.f;
     for (int r = blockIdx.x; r < rows_pad; r += gridDim.x) {
         const bool valid = r < rows;
@@ -206,8 +208,8 @@ mse_grad_kernel(const float* __restrict__ pred, int ldp, const float* __restrict
             float g = 0.f;
             if (valid && c < D) {
                 const float d = pred[(size_t)r * ldp + c] - target[(size_t)r * ldt + c];
-                acc += d * d;
-                g = grad_scale * d;
+                acc += l1 ? fabsf(d) : d * d;
+                g = grad_scale * (l1 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : d);
                 if (extra) g += extra[(size_t)r * lde + extra_col0 + c];
             }
             if (dz) dz[(size_t)r * ldz + c] = g;
@@ -742,6 +744,8 @@ int pvae_set_batch(pvae_ctx* c, const float* x, const float* y, int32_t rows, vo
 // Everything a step needs that is a pure function of (phase, rows, step params).
 struct StepShape {
     int rows_pad, wm_tiles, gridz, nparts_a;
+    int l1;                    // loss_kind of the three reconstruction terms
+    float gs;                  // d(mean loss)/d(residual) factor: 2 for MSE, 1 for L1
     float Bg;
     bool cyc_grad, kl_active;
     LossFinal lf;
@@ -751,6 +755,8 @@ static int step_shape(pvae_ctx* c, int phase, int rows, const pvae_step_params* 
                       StepShape& S) {
     const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
     S.rows_pad = pad32(rows);
+    S.l1 = sp->loss_kind == PVAE_LOSS_L1 ? 1 : 0;
+    S.gs = S.l1 ? 1.0f : 2.0f;
     S.Bg = (float)(sp->global_rows > 0 ? sp->global_rows : rows);
     const int T = c->W.L;
     S.wm_tiles = forward_tiles(S.rows_pad, c->L.net[PVAE_NET_WM].layers.back().n_out_pad);
@@ -784,6 +790,7 @@ static int check_step(pvae_ctx* c, int phase, int32_t rows, const pvae_step_para
     if (rc) return rc;
     if (!sp) return fail(-1, "null step params");
     if (phase != PVAE_PHASE_WORLD && phase != PVAE_PHASE_JOINT) return fail(-1, "unknown phase %d", phase);
+    if (sp->loss_kind != PVAE_LOSS_MSE && sp->loss_kind != PVAE_LOSS_L1) return fail(-1, "unknown loss_kind %d", sp->loss_kind);
     if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
     if (rows != c->staged_rows) return fail(-2, "rows %d != staged rows %d", rows, c->staged_rows);
     if (backward && fused && (!c->m || !c->v)) return fail(-2, "Adam moment arenas not bound");
@@ -818,12 +825,12 @@ static int run_forward(pvae_ctx* c, int phase, int rows, const pvae_step_params*
     memset(&mse, 0, sizeof(mse));
     mse.target = w + c->W.s2; mse.ldt = pad64(Db);
     mse.dz = backward ? w + wwm.dz.back() : nullptr; mse.ldz = WM.layers.back().n_out_pad;
-    mse.rows = rows; mse.D = Db;
+    mse.rows = rows; mse.D = Db; mse.l1 = S.l1;
     FwdTail wm_tail;
     wm_tail.mse = &mse;
     if (phase == PVAE_PHASE_WORLD) {
         // tpv:411-414: L = s_rec * MSE(s2, WM(s1, a_gt)); only the world model learns (tpv:326-329)
-        mse.grad_scale = sp->s_rec_coeff * 2.0f / (S.Bg * Db);
+        mse.grad_scale = sp->s_rec_coeff * S.gs / (S.Bg * Db);
         mse.partial = part + 3 * kLossParts;
         return forward_net(c, PVAE_NET_WM, S.rows_pad, st, wm_tail);
     }
@@ -838,7 +845,7 @@ static int run_forward(pvae_ctx* c, int phase, int rows, const pvae_step_params*
     md_tail.out2 = w + wwm.in; md_tail.ld2 = WM.layers[0].ld; md_tail.off2 = Db; md_tail.n2 = Da;
     if ((rc = forward_net(c, PVAE_NET_MD, S.rows_pad, st, md_tail))) return rc;
     // cycle loss (tpv:417-419) fused into the world model's output layer
-    mse.grad_scale = sp->cycle_coeff * 2.0f / (S.Bg * Db);
+    mse.grad_scale = sp->cycle_coeff * S.gs / (S.Bg * Db);
     mse.partial = part + 4 * kLossParts;
     return forward_net(c, PVAE_NET_WM, S.rows_pad, st, wm_tail);
 }
@@ -869,8 +876,8 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
         plan_backward_net(c, PVAE_NET_WM, S.rows_pad, false, true, sp, fused, st, nullptr, plan);
     // action reconstruction (tpv:381-382) + gradient arriving through the world model
     {
-        const float ga = sp->a_rec_coeff * 2.0f / (S.Bg * Da);
-        const int nparts = S.nparts_a, rows_pad = S.rows_pad;
+        const float ga = sp->a_rec_coeff * S.gs / (S.Bg * Da);
+        const int nparts = S.nparts_a, rows_pad = S.rows_pad, l1 = S.l1;
         const bool cyc = S.cyc_grad;
         plan.emplace_back();
         plan.back().run = [=]() -> int {
@@ -878,7 +885,7 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
                                MD->layers.back().n_out_pad, w + c->W.act_t, pad64(Da),
                                backward ? w + wmd->dz.back() : nullptr, MD->layers.back().n_out_pad, rows, rows_pad,
                                Da, ga, cyc ? w + wwm->d_in : (const float*)nullptr, WM->layers[0].ld, Db,
-                               part + 1 * kLossParts);
+                               part + 1 * kLossParts, l1);
             HIP_TRY(hipGetLastError());
             return 0;
         };
@@ -955,17 +962,17 @@ static int run_forward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_ste
         EpiMse mse;
         memset(&mse, 0, sizeof(mse));
         mse.target = w + c->W.s2 + bt * pad64(Db); mse.ldt = pad64(Db);
-        mse.ldz = ldo_wm; mse.rows = rows; mse.D = Db;
+        mse.ldz = ldo_wm; mse.rows = rows; mse.D = Db; mse.l1 = S.l1;
         FwdTail wm_tail;
         wm_tail.mse = &mse;
         // predicted action: cycle loss (tpv:417-419) + the state of the next step
         mse.dz = backward ? w + wwm.dz.back() + bp * ldo_wm : nullptr;
-        mse.grad_scale = joint ? sp->cycle_coeff * 2.0f / (S.Bg * Db) : 0.0f;
+        mse.grad_scale = joint ? sp->cycle_coeff * S.gs / (S.Bg * Db) : 0.0f;
         mse.partial = part + 4 * kLossParts + t * S.wm_tiles;
         if ((rc = forward_net(c, PVAE_NET_WM, u.rows_pad, st, wm_tail, bp))) return rc;
         if (u.use_g) {                         // demonstrated action: state reconstruction (tpv:411-414)
             mse.dz = backward ? w + wwm.dz.back() + bt * ldo_wm : nullptr;
-            mse.grad_scale = sp->s_rec_coeff * 2.0f / (S.Bg * Db);
+            mse.grad_scale = sp->s_rec_coeff * S.gs / (S.Bg * Db);
             mse.partial = part + 3 * kLossParts + t * S.wm_tiles;
             if ((rc = forward_net(c, PVAE_NET_WM, u.rows_pad, st, wm_tail, bt))) return rc;
         }
@@ -1059,15 +1066,15 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
         }
         // action reconstruction (tpv:381-382) + gradient arriving through the world model
         if (md_act[t] || (joint && sp->a_rec_coeff > 0.0f)) {
-            const float ga = joint ? sp->a_rec_coeff * 2.0f / (S.Bg * Da) : 0.0f;
-            const int nparts = S.nparts_a;
+            const float ga = joint ? sp->a_rec_coeff * S.gs / (S.Bg * Da) : 0.0f;
+            const int nparts = S.nparts_a, l1 = S.l1;
             const bool extra = p_act[t] && backward;
             push([=]() -> int {
                 hipLaunchKernelGGL(mse_grad_kernel, dim3(nparts), dim3(256), 0, st, w + wmd->act.back() + bt * ldo_md,
                                    ldo_md, w + c->W.act_t + bt * pad64(Da), pad64(Da),
                                    backward ? w + wmd->dz.back() + bt * ldo_md : (float*)nullptr, ldo_md, rows, rows_pad,
                                    Da, ga, extra ? w + wwm->d_in + bp * ld_wm : (const float*)nullptr, ld_wm, Db,
-                                   part + 1 * kLossParts + t * nparts);
+                                   part + 1 * kLossParts + t * nparts, l1);
                 HIP_TRY(hipGetLastError());
                 return 0;
             });

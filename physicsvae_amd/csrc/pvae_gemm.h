@@ -718,6 +718,7 @@ struct EpiMse {
     int rows, D;
     float grad_scale;
     float* partial;
+    int l1;                   // 0: nn.MSELoss (sum d^2, grad 2d/n), 1: nn.L1Loss (sum |d|, grad sign(d)/n)
     float sq = 0.f;
     __device__ inline void operator()(int q, int p, v4f v) {
         if (bias) v += *reinterpret_cast<const v4f*>(bias + p);
@@ -728,8 +729,9 @@ struct EpiMse {
         for (int e = 0; e < 4; ++e) {
             const bool valid = q < rows && p + e < D;
             const float d = v[e] - t[e];
-            if (valid) sq += d * d;
-            g[e] = valid ? grad_scale * d : 0.f;
+            if (valid) sq += l1 ? fabsf(d) : d * d;
+            const float gd = l1 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : d;
+            g[e] = valid ? grad_scale * gd : 0.f;
         }
         if (dz) *reinterpret_cast<v4f*>(dz + (size_t)q * ldz + p) = g;
     }

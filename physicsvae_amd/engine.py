@@ -29,8 +29,9 @@ class Arch:
 
 
 def make_step_params(lr, adam_t=(1, 1, 1), a_rec=1.0, kl=1.0, s_rec=0.0, cyc=1e-3,
-                     global_rows=0, seed=0, offset=0, beta1=0.9, beta2=0.999, eps=1e-8):
+                     global_rows=0, seed=0, offset=0, beta1=0.9, beta2=0.999, eps=1e-8, loss="MSE"):
     sp = _lib.StepParams()
+    sp.loss_kind = {"MSE": _lib.LOSS_MSE, "L1": _lib.LOSS_L1, "MAE": _lib.LOSS_L1}[loss]
     sp.a_rec_coeff, sp.kl_coeff, sp.s_rec_coeff, sp.cycle_coeff = a_rec, kl, s_rec, cyc
     sp.lr, sp.beta1, sp.beta2, sp.adam_eps = lr, beta1, beta2, eps
     for i in range(3):

@@ -173,10 +173,12 @@ class TrainModel(tune.Trainable):
                                  weight_decay=config.get("weight_decay", 0.0))
         self.lr_scheduler = get_lr_scheduler(self.optimizer, config.get("lr_schedule", None),
                                              config.get("lr_schedule_params", None))
-        if config.get("loss", "MSE") != "MSE" or config.get("loss_test", "MSE") != "MSE":
-            raise NotImplementedError("the HIP path implements the MSE losses the trainer uses (tpv:257-258)")
-        self.loss_fn = get_loss_fn("MSE")
-        self.loss_fn_test = get_loss_fn("MSE")
+        self.loss_name = config.get("loss", "MSE")
+        if self.loss_name not in ("MSE", "L1", "MAE"):
+            raise NotImplementedError("loss %r: the HIP path implements MSE (the trainer's setting, "
+                                      "tpv:257-258) and L1/MAE for the reconstruction terms" % self.loss_name)
+        self.loss_fn = get_loss_fn(self.loss_name)
+        self.loss_fn_test = get_loss_fn(config.get("loss_test", "MSE"))   # built, never used (tm:127, as upstream)
         self.iter = 0
         self.global_batch = 0                     # minibatches consumed so far (eps / Philox key)
         self.eps_fn = config.get("eps_fn")        # callable(forward_call, (rows, Z)) -> eps, or None

@@ -374,7 +374,7 @@ class TrainModel(torch_models.TrainModel):
         t = self.optimizer.next_counts(nets) if train else [1, 1, 1]
         return make_step_params(lr=self.optimizer.lr, adam_t=t, a_rec=self.a_rec_coeff,
                                 kl=self.vae_kl_coeff, s_rec=self.s_rec_coeff, cyc=self.vae_cycle_coeff,
-                                global_rows=global_rows)
+                                global_rows=global_rows, loss=self.loss_name)
 
     # explicit-batch entry points with the reference's signatures (tpv:356-435) -------------
     def compute_model(self, x, eps=None):
@@ -388,7 +388,7 @@ class TrainModel(torch_models.TrainModel):
         rows = self.engine.set_batch(x, y)
         sp = make_step_params(lr=self.optimizer.lr, a_rec=self.a_rec_coeff, kl=self.vae_kl_coeff,
                               s_rec=self.s_rec_coeff, cyc=self.vae_cycle_coeff, global_rows=rows,
-                              seed=self.rng_seed, offset=self.global_batch * 65536)
+                              seed=self.rng_seed, offset=self.global_batch * 65536, loss=self.loss_name)
         out = torch.zeros(5, dtype=torch.float32, device=self.engine.device)
         self.engine.forward_backward(phase, rows, sp, eps=eps, backward=False, loss_out=out)
         self.last_loss_terms = out

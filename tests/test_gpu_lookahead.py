@@ -14,6 +14,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+def _loss_of(name):
+    return "L1" if name.startswith("l1_") else "MSE"
+
+
 def _params(world, rows, **kw):
     c = R.phase_coeffs(world)
     return make_step_params(lr=5e-4, a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"], s_rec=c["s_rec_coeff"],
@@ -30,23 +34,25 @@ def _setup(golden, name):
     sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
     es = R.eps_stream(2, arch["Z"])
     eps = torch.stack([es(t, (x.shape[0], arch["Z"])) for t in range(L)])
-    tr = make_trainer(arch, data, batch, device=DEV, extra={"lookahead": L})
+    tr = make_trainer(arch, data, batch, device=DEV, extra={"lookahead": L, "loss": _loss_of(name)})
     tr.model.load_state_dict(sd)
     assert tr.engine.lookahead == L and len(tr.train_loader.dataset) == int(g["n_windows"])
     return g, arch, data, x, y, sd, eps, tr, L
 
 
-@pytest.mark.parametrize("name", ["look3_tiny", "look2_c1"])
+@pytest.mark.parametrize("name", ["look3_tiny", "look2_c1", "l1_tiny", "l1_look2_c1"])
 @pytest.mark.parametrize("world", [True, False])
 def test_unrolled_batch_matches_oracle_and_golden(golden, name, world):
+    """l1_*: trainer key "loss" = "L1" (tm:100-101), lookahead 1 and 2."""
     g, arch, data, x, y, sd, eps, tr, L = _setup(golden, name)
+    lk = _loss_of(name)
     eng = tr.engine
     tag = "world" if world else "joint"
     phase = _lib.PHASE_WORLD if world else _lib.PHASE_JOINT
     rows = x.shape[0]
     # (1) the full minibatch against the reference capture
     eng.set_batch(x, y)
-    loss = eng.forward_backward(phase, rows, _params(world, rows), eps=eps, fused_adam=False).cpu()
+    loss = eng.forward_backward(phase, rows, _params(world, rows, loss=lk), eps=eps, fused_adam=False).cpu()
     assert float(loss[0]) == pytest.approx(float(g[tag + "_total"]), rel=1e-5)
     gv = eng.named_views(eng.grads)
     for k in g[tag + "_grad_keys"]:
@@ -57,15 +63,17 @@ def test_unrolled_batch_matches_oracle_and_golden(golden, name, world):
     assert int(keep.sum()) >= rows - max(4, rows // 4)
     x, y, eps = x[keep], y[keep], eps[:, keep]
     rows = x.shape[0]
-    want = R.loss_and_grads(arch, sd, x, y, eps, world)
+    want = R.loss_and_grads(arch, sd, x, y, eps, world, loss=lk)
     eng.set_batch(x, y)
     eng.grads.fill_(float("nan"))
-    loss = eng.forward_backward(phase, rows, _params(world, rows), eps=eps, fused_adam=False).cpu()
+    loss = eng.forward_backward(phase, rows, _params(world, rows, loss=lk), eps=eps, fused_adam=False).cpu()
     assert float(loss[0]) == pytest.approx(float(want["total"]), rel=1e-5)
     for i, k in enumerate(("loss_a", "loss_kl", "loss_s", "loss_cyc")):
         assert float(loss[1 + i]) == pytest.approx(float(want[k]), rel=1e-5, abs=1e-9), k
     # forward internals of EVERY step (the state of step t+1 is the prediction of step t)
-    for t in range(L):
+    if L == 1 and world:                           # only the world model runs (pvae.h)
+        assert max_err_scaled(eng.read("s2_hat", rows).cpu(), want["s2_from_gt_action"]) < 3e-5
+    for t in range(L if not (L == 1 and world) else 0):
         st = want["steps"][t]
         for ours, theirs in (("mu", "mu"), ("logvar", "logvar"), ("z", "z"), ("a_hat", "a_hat"),
                              ("s2_hat", "future_state")):

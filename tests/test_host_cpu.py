@@ -287,7 +287,8 @@ def test_unsupported_configs_are_refused():
     with pytest.raises(NotImplementedError):
         make_trainer(arch, data, 8, device="cpu", extra={"latent_prior_type": "hypersphere_uniform"})
     with pytest.raises(NotImplementedError):
-        make_trainer(arch, data, 8, device="cpu", extra={"loss": "L1"})
+        make_trainer(arch, data, 8, device="cpu", extra={"loss": "CrossEntropy"})
+    assert make_trainer(arch, data, 8, device="cpu", extra={"loss": "L1"}).loss_name == "L1"
 
 
 def test_shard_arithmetic_matches_reference_order():

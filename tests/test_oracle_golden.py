@@ -114,11 +114,13 @@ def test_single_batch_losses_and_grads_match_reference(golden, name):
     np.testing.assert_array_equal(g["joint_total_vb_perturbed"], g["joint_total"])
 
 
-@pytest.mark.parametrize("name", ["look3_tiny", "look2_c1"])
+@pytest.mark.parametrize("name", ["look3_tiny", "look2_c1", "l1_tiny", "l1_look2_c1"])
 def test_lookahead_unroll_matches_reference(golden, name):
     """tpv:367-428 with lookahead 3 / 2: windows, ragged last batch, loss terms averaged over the
-    steps, and the gradients of the back-propagation through every earlier step."""
+    steps, and the gradients of the back-propagation through every earlier step.  The l1_* cases
+    were captured with trainer key "loss" = "L1" (nn.L1Loss for the three reconstruction terms)."""
     g = golden(name)
+    loss = "L1" if name.startswith("l1_") else "MSE"
     arch = arch_from_meta(g["meta"])
     n_ep, n_steps, batch, L = [int(v) for v in g["meta"][9:13]]
     data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
@@ -135,7 +137,7 @@ def test_lookahead_unroll_matches_reference(golden, name):
     eps = torch.stack([es(t, (x.shape[0], arch["Z"])) for t in range(L)])
     for world in (True, False):
         tag = "world" if world else "joint"
-        out = R.loss_and_grads(arch, sd, x, y, eps, world)
+        out = R.loss_and_grads(arch, sd, x, y, eps if L > 1 else eps[0], world, loss=loss)
         np.testing.assert_allclose(out["total"].numpy(), g[tag + "_total"], rtol=1e-6)
         for k in ("mu", "logvar", "z", "future_state"):           # internals of the LAST step
             if tag + "_" + k in g:
