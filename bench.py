@@ -126,7 +126,7 @@ def main():
             first, rows, grows = dp.shard(g, n_win, a.batch)
             sp = tr.step_params(nets, grows, True)
             sp.rng_seed, sp.rng_offset = 7, (start + i) * 65536 + dp.rank * 64
-            if dp.world == 1:
+            if not dp.collective:
                 eng.train_step(phase, first, rows, sp, loss_out=loss_buf)
             else:
                 tr.dp_step(phase, nets, first, rows, sp, None, loss_buf)
@@ -246,11 +246,16 @@ def main():
                                          "synthetic demo of the same dims), %s phase, oracle/refpath.RefTrainer (stock "
                                          "torch CPU ops in the reference's op order), %.1f s" % (n_b, a.batch, a.phase, dt),
                                "host_cpus": os.cpu_count()}
-    if rank == 0:
-        print(json.dumps(out))
-    if dp.world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL writes an init banner through C stdio, which a pipe would otherwise deliver AFTER
+    # Python's output: drain it first so that the JSON object is the last line on stdout.
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -18,13 +18,21 @@ import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, rank=0, world=1, group=None):
+    def __init__(self, rank=0, world=1, group=None, always_reduce=False):
         self.rank, self.world, self.group = int(rank), int(world), group
+        # run the staged backward + collective + per-slice Adam path even for a single rank
+        # (PVAE_DP_ALWAYS_REDUCE=1): exercises RCCL and its stream ordering on a 1-GPU box
+        self.always_reduce = bool(always_reduce) and dist.is_available() and dist.is_initialized()
+
+    @property
+    def collective(self):
+        return self.world > 1 or self.always_reduce
 
     @classmethod
     def from_env(cls):
+        force = os.environ.get("PVAE_DP_ALWAYS_REDUCE", "0") == "1"
         if dist.is_available() and dist.is_initialized():
-            return cls(dist.get_rank(), dist.get_world_size())
+            return cls(dist.get_rank(), dist.get_world_size(), always_reduce=force)
         return cls(0, 1)
 
     def global_steps(self, n_windows, batch_size):
@@ -43,7 +51,7 @@ class DataParallel:
         return (first if rows else 0), rows, gend - gfirst
 
     def all_reduce(self, tensor):
-        if self.world > 1:
+        if self.collective:
             dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
         return tensor
 
@@ -52,7 +60,7 @@ def _all_reduce_async(self, tensor):
     """SUM all-reduce that returns a Work handle (None for a single process).  With the nccl
     backend the collective is stream-ordered behind the kernels already queued on the current
     stream, and `work.wait()` only makes the current stream wait for it."""
-    if self.world <= 1:
+    if not self.collective:
         return None
     return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -66,7 +74,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("PVAE_DP_ALWAYS_REDUCE", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

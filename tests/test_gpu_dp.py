@@ -17,7 +17,7 @@ import os, sys, io, contextlib, torch
 root = sys.argv[1]; out = sys.argv[2]
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 from physicsvae_amd import parallel
-rank, world, _ = parallel.init_from_env(backend="gloo")
+rank, world, _ = parallel.init_from_env(backend=os.environ.get("PVAE_TEST_BACKEND", "gloo"))
 from oracle import refpath as R
 from util import make_trainer
 arch = R.make_arch(23, 7, latent=8, te=(64, 2), md=(96, 2), wm=(128, 3))
@@ -35,11 +35,11 @@ print("DONE", rank, losses)
 '''
 
 
-def _run(tmp_path, world, per_gpu, tag):
+def _run(tmp_path, world, per_gpu, tag, **extra_env):
     script = tmp_path / "dp_worker.py"
     script.write_text(WORKER)
     out = str(tmp_path / tag)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", WORLD_SIZE=str(world))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", WORLD_SIZE=str(world), **extra_env)
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, out, str(per_gpu)],
                               env=dict(env, RANK=str(r), LOCAL_RANK="0"),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -62,3 +62,16 @@ def test_two_ranks_equal_one_process_with_global_batch(tmp_path):
             continue
         err = float((a["sd"][k] - v).norm() / (v.norm() + 1e-30))
         assert err < 2e-3, (k, err)
+
+
+def test_rccl_collective_path_single_rank_is_bit_identical(tmp_path):
+    """The data-parallel step (staged backward, one asynchronous all-reduce per finished layer on
+    RCCL's stream, Adam per slice after `wait()`) driven through the real `nccl` backend with one
+    rank: the reduction is the identity, so any mis-ordering between the library's launches on the
+    compute stream and RCCL's stream would show up as a difference from the fused single-GPU step,
+    which it must match bit for bit."""
+    rccl = _run(tmp_path, 1, 32, "rccl", PVAE_DP_ALWAYS_REDUCE="1", PVAE_TEST_BACKEND="nccl")[0]
+    single = _run(tmp_path, 1, 32, "plain")[0]
+    assert rccl["steps"] == single["steps"] and rccl["losses"] == single["losses"]
+    for k, v in single["sd"].items():
+        assert torch.equal(rccl["sd"][k], v), k
