@@ -159,8 +159,10 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s, batch %d/GPU, TE/MD/WM 4x1024, %s phase" % (workload, a.batch, a.phase),
                    "phase": a.phase, "global_batch": a.batch * a.gpus,
-                   "parallelism": "dp%d" % a.gpus, "optimizer": "Adam fused in wgrad" if a.gpus == 1
-                   else "per-layer async RCCL all-reduce overlapped with backward + per-slice Adam"},
+                   "parallelism": "dp%d" % a.gpus,
+                   "optimizer": "Adam fused in wgrad" if not dp.collective else
+                   ("in-library RCCL all-reduce per net (same stream) + Adam" if eng.has_comm else
+                    "torch.distributed bucketed async all-reduce + per-bucket Adam")},
         "last_loss": last_loss,
     }
     fl_world, fl_joint = algorithmic_flops_per_sample(Db, Da, Z, W, D)
@@ -247,7 +249,9 @@ def main():
                                          "torch CPU ops in the reference's op order), %.1f s" % (n_b, a.batch, a.phase, dt),
                                "host_cpus": os.cpu_count()}
     if dist.is_initialized():
+        torch.cuda.synchronize()
         dist.barrier()
+        eng.comm_destroy()
         dist.destroy_process_group()
     # RCCL writes an init banner through C stdio, which a pipe would otherwise deliver AFTER
     # Python's output: drain it first so that the JSON object is the last line on stdout.

@@ -175,6 +175,26 @@ int pvae_backward_stage(pvae_ctx* ctx, int phase, int32_t rows, const pvae_step_
 int pvae_adam_segment(pvae_ctx* ctx, int net, int64_t offset, int64_t count, const pvae_step_params* sp,
                       void* stream);
 
+/* Data-parallel exchange issued by the library itself (RCCL over xGMI; one process per GPU).
+ * Replaces what DistributedDataParallel would add around tm:142-143; the reference has no
+ * multi-GPU path (tm:115-118 moves one model to one device).
+ *   pvae_comm_unique_id   rank 0: 128-byte RCCL id, to be handed to every rank by the caller
+ *                         (torch.distributed broadcast, a file, MPI ...)
+ *   pvae_comm_init        collective: every rank joins the communicator (rank, world, id)
+ *   pvae_allreduce_grads  in-place SUM all-reduce of a slice of the gradient arena, stream-ordered
+ *                         on `stream` like any other launch of this library (no side stream)
+ *   pvae_dp_train_step    one data-parallel optimizer step in ONE call: gather + forward +
+ *                         backward (gradients scaled by 1/global_rows) + per-net all-reduce +
+ *                         Adam; rows may be 0 (empty shard of a ragged last global batch).
+ * The RCCL library is resolved at run time (the copy PyTorch already loaded, else the system
+ * one); a missing library is an error from these calls only. */
+int pvae_comm_unique_id(void* id128);
+int pvae_comm_init(pvae_ctx* ctx, int rank, int world, const void* id128);
+int pvae_comm_destroy(pvae_ctx* ctx);
+int pvae_allreduce_grads(pvae_ctx* ctx, int64_t offset, int64_t count, void* stream);
+int pvae_dp_train_step(pvae_ctx* ctx, int phase, int64_t first_window, int32_t rows,
+                       const pvae_step_params* sp, const float* eps, float* loss_out, void* stream);
+
 /* One whole optimizer step on the bound dataset: gather + forward/backward + Adam.
  * This is the body of the `for data in self.train_loader` loop (tm:137-144). */
 int pvae_train_step(pvae_ctx* ctx, int phase, int64_t first_window, int32_t rows,

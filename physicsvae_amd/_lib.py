@@ -66,6 +66,11 @@ _SIGS = {
                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int),
                                       C.POINTER(C.c_int)]),
     "pvae_adam_segment": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.POINTER(StepParams), _P]),
+    "pvae_comm_unique_id": (C.c_int, [_P]),
+    "pvae_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "pvae_comm_destroy": (C.c_int, [_P]),
+    "pvae_allreduce_grads": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
+    "pvae_dp_train_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P, _P]),
     "pvae_train_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P,
                                   _P]),
     "pvae_read_tensor": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P]),

@@ -5,6 +5,7 @@
 // Reference lines restated by each kernel are cited at the kernel (tpv / tm / rmt as in
 // include/pvae.h).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -66,7 +67,56 @@ struct Profiler {
 };
 static Profiler g_prof;
 
+// ---------------------------------------------------------------------------------------
+// RCCL, resolved at run time.  PyTorch-ROCm ships its own librccl.so.1 and has it loaded; the
+// library binds to THAT instance (RTLD_NOLOAD first) instead of linking a second copy, and
+// falls back to the system one (/opt/rocm/lib) when used without torch.  Only the five entry
+// points of the data-parallel exchange are needed; prototypes as in rccl/rccl.h (2.2x).
+// ---------------------------------------------------------------------------------------
+struct RcclId { char internal[128]; };                 // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;          // id is passed BY VALUE
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok() const { return h && GetUniqueId && CommInitRank && AllReduce && CommDestroy && GetErrorString; }
+};
+static Rccl g_rccl;
+enum { kNcclSum = 0, kNcclFloat32 = 7 };
+
+static int rccl_load() {
+    if (g_rccl.ok()) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;            // the instance torch already mapped
+    if (!h)
+        for (const char* n : names)
+            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return fail(-20, "RCCL not found (librccl.so.1): %s", dlerror());
+    g_rccl.h = h;
+    g_rccl.GetUniqueId = (int (*)(RcclId*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.ok()) {
+        g_rccl = Rccl();
+        return fail(-20, "RCCL library lacks an expected symbol");
+    }
+    return 0;
+}
+#define RCCL_TRY(expr)                                                                        \
+    do {                                                                                      \
+        int r_ = (expr);                                                                      \
+        if (r_ != 0) return fail(-21, "%s: %s", #expr, g_rccl.GetErrorString(r_));            \
+    } while (0)
+
 struct pvae_ctx {
+    void* comm = nullptr;        // ncclComm_t of the data-parallel group (pvae_comm_init)
+    int comm_rank = 0, comm_world = 1;
     Layout L;
     Workspace W;
     float* params = nullptr;
@@ -669,7 +719,10 @@ int pvae_create(const pvae_config* cfg, pvae_ctx** out) {
     return 0;
 }
 
-void pvae_destroy(pvae_ctx* ctx) { delete ctx; }
+void pvae_destroy(pvae_ctx* ctx) {
+    if (ctx && ctx->comm && g_rccl.ok()) g_rccl.CommDestroy(ctx->comm);
+    delete ctx;
+}
 
 int pvae_bind_arenas(pvae_ctx* c, float* params, float* grads, float* exp_avg, float* exp_avg_sq) {
     if (!c) return fail(-1, "null ctx");
@@ -1249,6 +1302,97 @@ int pvae_adam(pvae_ctx* c, int net_mask, const pvae_step_params* sp, void* strea
         hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, c->params + N.off,
                            c->grads + N.off, c->m + N.off, c->v + N.off, n4, adam_scalars(sp, n));
         HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+// ---- data-parallel exchange inside the library ---------------------------------------------
+int pvae_comm_unique_id(void* id128) {
+    if (!id128) return fail(-1, "null id buffer");
+    int rc = rccl_load();
+    if (rc) return rc;
+    RcclId id;
+    RCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(id128, id.internal, sizeof(id.internal));
+    return 0;
+}
+
+int pvae_comm_init(pvae_ctx* c, int rank, int world, const void* id128) {
+    if (!c || !id128) return fail(-1, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(-1, "rank %d outside [0, %d)", rank, world);
+    if (c->comm) return fail(-2, "communicator already initialised");
+    int rc = rccl_load();
+    if (rc) return rc;
+    RcclId id;
+    memcpy(id.internal, id128, sizeof(id.internal));
+    void* comm = nullptr;
+    RCCL_TRY(g_rccl.CommInitRank(&comm, world, id, rank));
+    c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+    return 0;
+}
+
+int pvae_comm_destroy(pvae_ctx* c) {
+    if (!c) return fail(-1, "null ctx");
+    if (c->comm) {
+        RCCL_TRY(g_rccl.CommDestroy(c->comm));
+        c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0;
+    }
+    return 0;
+}
+
+int pvae_allreduce_grads(pvae_ctx* c, int64_t offset, int64_t count, void* stream) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!c->comm) return fail(-2, "no communicator (pvae_comm_init)");
+    if (!c->grads) return fail(-2, "gradient arena not bound");
+    if (offset < 0 || count < 0 || offset + count > c->L.arena_floats)
+        return fail(-1, "slice [%lld, +%lld) outside the arena", (long long)offset, (long long)count);
+    if (count == 0) return 0;
+    RCCL_TRY(g_rccl.AllReduce(c->grads + offset, c->grads + offset, (size_t)count, kNcclFloat32, kNcclSum, c->comm,
+                              (hipStream_t)stream));
+    return 0;
+}
+
+int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t rows, const pvae_step_params* sp,
+                       const float* eps, float* loss_out, void* stream) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!c->comm) return fail(-2, "no communicator (pvae_comm_init)");
+    if (!sp) return fail(-1, "null step params");
+    if (!c->grads || !c->m || !c->v) return fail(-2, "grads / Adam moment arenas not bound");
+    if (phase != PVAE_PHASE_WORLD && phase != PVAE_PHASE_JOINT) return fail(-1, "unknown phase %d", phase);
+    hipStream_t st = (hipStream_t)stream;
+    const int nets[2] = {phase == PVAE_PHASE_WORLD ? PVAE_NET_WM : PVAE_NET_MD,
+                         phase == PVAE_PHASE_WORLD ? -1 : PVAE_NET_TE};      // backward order
+    if (rows == 0) {
+        // empty shard of a ragged last global batch: contribute zeros, apply the same update
+        for (int n : nets) {
+            if (n < 0) continue;
+            const NetLayout& N = c->L.net[n];
+            HIP_TRY(hipMemsetAsync(c->grads + N.off, 0, (size_t)N.count * sizeof(float), st));
+            if ((rc = pvae_allreduce_grads(c, N.off, N.count, stream))) return rc;
+            if ((rc = pvae_adam_segment(c, n, N.off, N.count, sp, stream))) return rc;
+        }
+        return 0;
+    }
+    if ((rc = pvae_gather(c, first_window, rows, stream))) return rc;
+    if ((rc = check_step(c, phase, rows, sp, true, false))) return rc;
+    StepShape S;
+    if ((rc = step_shape(c, phase, rows, sp, loss_out, true, S))) return rc;
+    if ((rc = run_forward(c, phase, rows, sp, eps, true, S, st))) return rc;
+    Plan plan;
+    plan_backward(c, phase, rows, sp, true, false, S, st, plan);
+    // One bucket per net: the net's slices become final last layer first; when the slice that
+    // starts at the net's offset is done, the whole segment is reduced in place on THIS stream
+    // (no cross-stream hand-off) and Adam follows.  In the joint phase the decoder's reduction
+    // is queued before the encoder's backward launches and runs ahead of them in stream order.
+    for (Stage& s : plan) {
+        if ((rc = s.run())) return rc;
+        if (s.ready_cnt > 0 && s.net >= 0 && s.ready_off == c->L.net[s.net].off) {
+            const NetLayout& N = c->L.net[s.net];
+            if ((rc = pvae_allreduce_grads(c, N.off, N.count, stream))) return rc;
+            if ((rc = pvae_adam_segment(c, s.net, N.off, N.count, sp, stream))) return rc;
+        }
     }
     return 0;
 }

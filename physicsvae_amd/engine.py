@@ -68,6 +68,7 @@ class HipEngine:
         self.exp_avg = torch.zeros(self.arena_floats, **f32)
         self.exp_avg_sq = torch.zeros(self.arena_floats, **f32)
         self.ctx = None
+        self.has_comm = False                    # RCCL communicator owned by the ctx (comm_init)
         self.workspace = None
         self.dataset = None
         self._loss_scratch = None
@@ -223,6 +224,38 @@ class HipEngine:
             self.ctx, phase, int(first_window), int(rows), C.byref(sp),
             eps.data_ptr() if eps is not None else None, out.data_ptr(), self._stream()),
             "pvae_train_step")
+        return out
+
+    # -- data-parallel exchange inside the library (RCCL) ----------------------------------------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        _lib.check(self.lib.pvae_comm_unique_id(buf), "pvae_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        self._need_gpu()
+        assert len(unique_id) == 128
+        _lib.check(self.lib.pvae_comm_init(self.ctx, int(rank), int(world), C.c_char_p(unique_id)), "pvae_comm_init")
+        self.has_comm = True
+
+    def comm_destroy(self):
+        if self.ctx is not None and self.has_comm:
+            _lib.check(self.lib.pvae_comm_destroy(self.ctx), "pvae_comm_destroy")
+            self.has_comm = False
+
+    def allreduce_grads(self, off, cnt):
+        self._need_gpu()
+        _lib.check(self.lib.pvae_allreduce_grads(self.ctx, int(off), int(cnt), self._stream()), "pvae_allreduce_grads")
+
+    def dp_train_step(self, phase, first_window, rows, sp, eps=None, loss_out=None):
+        self._need_gpu()
+        if eps is not None and rows:
+            eps = self._eps(eps, rows)
+        out = self._loss_scratch if loss_out is None else loss_out
+        _lib.check(self.lib.pvae_dp_train_step(
+            self.ctx, phase, int(first_window), int(rows), C.byref(sp),
+            eps.data_ptr() if (eps is not None and rows) else None, out.data_ptr(), self._stream()),
+            "pvae_dp_train_step")
         return out
 
     def read(self, name, rows, step=0):

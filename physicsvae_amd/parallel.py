@@ -50,6 +50,25 @@ class DataParallel:
         rows = max(0, min(batch_size, gend - first))
         return (first if rows else 0), rows, gend - gfirst
 
+    def attach(self, engine):
+        """Give `engine`'s ctx its own RCCL communicator so the whole data-parallel step runs inside
+        the library (`pvae_dp_train_step`: all-reduce stream-ordered with the kernels, no Python
+        between launches).  Needs the nccl backend (one GPU per rank); PVAE_DP_TRANSPORT=torch keeps
+        torch.distributed as the transport, which is also what gloo runs and any failure to set the
+        communicator up fall back to -- a different transport for the same exchange."""
+        if not self.collective or engine.has_comm or engine.ctx is None:
+            return engine.has_comm
+        if os.environ.get("PVAE_DP_TRANSPORT", "rccl") != "rccl" or dist.get_backend(self.group) != "nccl":
+            return False
+        try:
+            box = [engine.comm_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=self.group)
+            engine.comm_init(self.rank, self.world, box[0])
+        except Exception as exc:                                   # noqa: BLE001
+            print("[physicsvae_amd] in-library RCCL exchange unavailable (%s); using torch.distributed" % exc)
+            return False
+        return True
+
     def all_reduce(self, tensor):
         if self.collective:
             dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)

@@ -168,6 +168,7 @@ class TrainModel(tune.Trainable):
         self.device = self.engine.device
         self.dp = parallel.DataParallel.from_env()
         self.dp_bucket_mb = float(config.get("dp_bucket_mb", os.environ.get("PVAE_DP_BUCKET_MB", 0)))
+        self.dp.attach(self.engine)
         self.prepare_data(config)
         self.optimizer = HipAdam(self.model.parameters(), self.engine,
                                  lr=config.get("lr", 1e-3),
@@ -263,6 +264,9 @@ class TrainModel(tune.Trainable):
         which at ~120 us per step outweighs what finer-grained overlap could hide (measured with
         one rank through RCCL: 5 collectives per step 206 us, 1 per step see DESIGN.md)."""
         eng, dp = self.engine, self.dp
+        if eng.has_comm:                          # whole step inside the library (RCCL, one stream)
+            eng.dp_train_step(phase, first, rows, sp, eps=eps, loss_out=loss_out)
+            return
         if not rows:                              # empty shard of a ragged last global batch
             seg = eng.segment(eng.grads, nets)
             seg.zero_()

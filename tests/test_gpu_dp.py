@@ -26,6 +26,8 @@ per_gpu = int(sys.argv[3])
 with contextlib.redirect_stdout(io.StringIO()):
     tr = make_trainer(arch, data, per_gpu, m_world=1, device="cuda:0", eps_fn=R.eps_stream(2, 8))
 tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, 1), 3))
+if "PVAE_TEST_EXPECT_COMM" in os.environ:
+    assert tr.engine.has_comm == (os.environ["PVAE_TEST_EXPECT_COMM"] == "1"), tr.engine.has_comm
 losses = [tr.train()["mean_train_loss"] for _ in range(2)]
 sd = {k: v.cpu() for k, v in tr.model.state_dict().items()}
 torch.save({"sd": sd, "losses": losses, "steps": dict(tr.optimizer.net_steps)}, out + ".%d" % rank)
@@ -64,13 +66,16 @@ def test_two_ranks_equal_one_process_with_global_batch(tmp_path):
         assert err < 2e-3, (k, err)
 
 
-def test_rccl_collective_path_single_rank_is_bit_identical(tmp_path):
-    """The data-parallel step (staged backward, one asynchronous all-reduce per finished layer on
-    RCCL's stream, Adam per slice after `wait()`) driven through the real `nccl` backend with one
-    rank: the reduction is the identity, so any mis-ordering between the library's launches on the
-    compute stream and RCCL's stream would show up as a difference from the fused single-GPU step,
-    which it must match bit for bit."""
-    rccl = _run(tmp_path, 1, 32, "rccl", PVAE_DP_ALWAYS_REDUCE="1", PVAE_TEST_BACKEND="nccl")[0]
+@pytest.mark.parametrize("transport", ["rccl", "torch"])
+def test_rccl_collective_path_single_rank_is_bit_identical(tmp_path, transport):
+    """The data-parallel step driven through the real RCCL library with one rank: the reduction is
+    the identity, so any mis-ordering between the backward launches, the collective and Adam would
+    show up as a difference from the fused single-GPU step, which it must match bit for bit.
+    transport "rccl": the library's own communicator, everything on one stream inside
+    `pvae_dp_train_step`; "torch": staged backward + torch.distributed's nccl backend (bucketed
+    asynchronous all-reduce on RCCL's stream, Adam per bucket after `wait()`)."""
+    rccl = _run(tmp_path, 1, 32, "rccl", PVAE_DP_ALWAYS_REDUCE="1", PVAE_TEST_BACKEND="nccl",
+                PVAE_DP_TRANSPORT=transport, PVAE_TEST_EXPECT_COMM="1" if transport == "rccl" else "0")[0]
     single = _run(tmp_path, 1, 32, "plain")[0]
     assert rccl["steps"] == single["steps"] and rccl["losses"] == single["losses"]
     for k, v in single["sd"].items():
