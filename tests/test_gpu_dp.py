@@ -80,3 +80,54 @@ def test_rccl_collective_path_single_rank_is_bit_identical(tmp_path, transport):
     assert rccl["steps"] == single["steps"] and rccl["losses"] == single["losses"]
     for k, v in single["sd"].items():
         assert torch.equal(rccl["sd"][k], v), k
+
+
+def test_in_library_exchange_calls(golden):
+    """pvae_comm_* / pvae_dp_train_step / pvae_allreduce_grads driven directly (one-rank
+    communicator, no torch.distributed at all): a data-parallel step equals the fused step bit for
+    bit in both phases, and an EMPTY shard (rows = 0, ragged last global batch) contributes zeros
+    and applies the same Adam update as every other rank."""
+    import numpy as np  # noqa: F401
+    from oracle import refpath as R
+    from physicsvae_amd import _lib
+    from physicsvae_amd.engine import make_step_params
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_trainer
+    arch = R.make_arch(23, 7, latent=8, te=(64, 2), md=(96, 2), wm=(128, 3))
+    data = R.synth_demo(0, 3, 40, 23, 7, kind="dynamics")
+    tr = make_trainer(arch, data, 32, device="cuda")
+    sd = R.perturb_biases(R.init_state_dict(arch, 1), 3)
+    eng = tr.engine
+    eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
+    with pytest.raises(RuntimeError):
+        eng.allreduce_grads(0, 64)                                  # no communicator yet
+    eng.comm_init(0, 1, eng.comm_unique_id())
+    assert eng.has_comm
+    eps = R.eps_stream(2, 8)(0, (32, 8))
+    for phase, world, nets in ((_lib.PHASE_WORLD, True, [_lib.NET_WM]), (_lib.PHASE_JOINT, False, [_lib.NET_TE, _lib.NET_MD])):
+        c = R.phase_coeffs(world)
+        res = []
+        for dp in (False, True):
+            tr.model.load_state_dict(sd)
+            eng.exp_avg.zero_(); eng.exp_avg_sq.zero_()
+            out = torch.zeros(5, device="cuda")
+            for t in (1, 2, 3):
+                sp = make_step_params(lr=5e-4, adam_t=(t, t, t), a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"],
+                                      s_rec=c["s_rec_coeff"], cyc=c["vae_cycle_coeff"], global_rows=32)
+                (eng.dp_train_step if dp else eng.train_step)(phase, 32 * (t - 1), 32, sp, eps=eps, loss_out=out)
+            res.append((eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(), out.clone()))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+        # empty shard: zero gradient through the collective, then Adam
+        p0, m0, v0 = eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone()
+        sp = make_step_params(lr=5e-4, adam_t=(4, 4, 4), global_rows=17)
+        eng.grads.fill_(3.0)
+        eng.dp_train_step(phase, 0, 0, sp)
+        got = eng.params.clone()
+        eng.params.copy_(p0); eng.exp_avg.copy_(m0); eng.exp_avg_sq.copy_(v0)
+        eng.segment(eng.grads, nets).zero_()
+        eng.adam(nets, sp)
+        assert torch.equal(eng.params, got)
+        assert not torch.equal(got, p0)                             # the moments still move the weights
+    eng.comm_destroy()
+    assert not eng.has_comm
