@@ -63,13 +63,32 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 //   Q is always ROW (X or dZ, k-contiguous).  P_ROW: W[p][k] (forward);  !P_ROW: W[k][p] (dgrad).
 // ABL (tools/gemm_ablate.hip only; 0 in production): 1 = no tile staging in the loop, 2 = no LDS
 // fragment reads, 4 = no MFMA, 8 = no barrier.
+// host-side default for GemmArgs::krot: off (measured: no gain); PVAE_KROT=1 enables
+static int g_krot = [] { const char* e = getenv("PVAE_KROT"); return (e && e[0] == '1') ? 1 : 0; }();
 struct GemmArgs {
     const float* Q;
     int ldq;
     const float* P;
     int ldp;
     int K, tiles_q, tiles_p, p_per_xcd;
+    int krot = g_krot;        // rotate each workgroup's K order (see k_rotation)
 };
+
+// Experiment (off by default): start each workgroup at a different k-tile and wrap around, so that
+// the workgroups of an XCD that share operand rows (same q-tile: X rows, same p-tile: W rows) do
+// not walk K in lockstep -- a k-slab would be pulled into L2 by one workgroup and found there by the
+// others a few tiles later.  Hypothesis: lockstep first-touch misses bound the tile rate.
+// Measured: no change to slightly worse (hidden layer 8.44 -> 8.47 us, step 114 -> 117 us), i.e.
+// the per-iteration rate is not miss-latency bound.  The summation order over K would differ per
+// workgroup but stay a fixed function of the block index (deterministic).
+__device__ inline int k_rotation(const GemmArgs& ga, int loc, int tile_q, int nk) {
+    if (!ga.krot || nk < 2) return 0;
+    const int pi = loc / ga.tiles_q;                       // position among this XCD's p-tiles
+    int sq = nk / ga.p_per_xcd, sp = nk / ga.tiles_q;
+    if (sq < 1) sq = 1;
+    if (sp < 1) sp = 1;
+    return (pi * sq + tile_q * sp) % nk;
+}
 constexpr int kRegRingFloats = 2 * 2 * 32 * 64;      // 2 LDS slots x (Q tile + P tile) = 32 KB
 
 template <bool P_ROW, class Epi, int ABL = 0>
@@ -302,12 +321,15 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
             }
         }
         const size_t kstep_p = P_ROW ? (size_t)BK : (size_t)BK * ldp;
+        const int rot = k_rotation(ga, loc, tile_q, nk);
         auto issue = [&](int t) {
             float* slot = lds + (t % S) * kStage;
+            int kt = t + rot;                             // k-tile this workgroup reads at step t
+            if (kt >= nk) kt -= nk;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                lds_dma16(sq[u] + (size_t)t * BK, slot + (u0 + 4 * u) * 256);
-                lds_dma16(sp[u] + (size_t)t * kstep_p, slot + kTile + (u0 + 4 * u) * 256);
+                lds_dma16(sq[u] + (size_t)kt * BK, slot + (u0 + 4 * u) * 256);
+                lds_dma16(sp[u] + (size_t)kt * kstep_p, slot + kTile + (u0 + 4 * u) * 256);
             }
         };
 #pragma unroll

@@ -337,3 +337,12 @@ def test_data_parallel_allreduce_gloo_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "OK %d" % r in o
+
+
+def test_graft_entry_build_runs_without_gpu():
+    """The driver's "does it build" check: compiles (or finds fresh) the gfx950 library, loads it,
+    checks the ABI version and imports the package -- all without a GPU."""
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "built" in r.stdout
