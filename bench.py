@@ -127,7 +127,9 @@ def main():
             sp = tr.step_params(nets, grows, True)
             sp.rng_seed, sp.rng_offset = 7, (start + i) * 65536 + dp.rank * 64
             if not dp.collective:
-                eng.train_step(phase, first, rows, sp, loss_out=loss_buf)
+                nfirst, nrows, _ = dp.shard((start + i + 1) % full, n_win, a.batch)
+                eng.train_step(phase, first, rows, sp, loss_out=loss_buf,
+                               next_span=(nfirst, nrows) if tr.prefetch_gather else None)
             else:
                 tr.dp_step(phase, nets, first, rows, sp, None, loss_buf)
             rows_done += grows

@@ -200,6 +200,15 @@ int pvae_dp_train_step(pvae_ctx* ctx, int phase, int64_t first_window, int32_t r
 int pvae_train_step(pvae_ctx* ctx, int phase, int64_t first_window, int32_t rows,
                     const pvae_step_params* sp, const float* eps, float* loss_out, void* stream);
 
+/* pvae_train_step that also gathers the NEXT minibatch (windows [next_first, +next_rows), 0 rows:
+ * none): the gather rides as extra workgroups in this step's last launch and lands in a second set
+ * of input panels; the following call finds its minibatch already staged and skips the gather
+ * launch (falls back to a normal gather whenever what was prefetched is not what is asked for).
+ * Same results as pvae_train_step, one launch less per step (lookahead 1). */
+int pvae_train_step_prefetch(pvae_ctx* ctx, int phase, int64_t first_window, int32_t rows,
+                             const pvae_step_params* sp, const float* eps, float* loss_out,
+                             int64_t next_first, int32_t next_rows, void* stream);
+
 /* ---- inspection (parity tests) ------------------------------------------------------- */
 /* Copy a forward intermediate of the last pvae_forward_backward into dst (dense
  * [rows][width] fp32, device).  what: 0 = mu, 1 = logvar, 2 = z, 3 = a_hat (MD output),

@@ -73,6 +73,8 @@ _SIGS = {
     "pvae_dp_train_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P, _P]),
     "pvae_train_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P,
                                   _P]),
+    "pvae_train_step_prefetch": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P,
+                                           C.c_int64, C.c_int32, _P]),
     "pvae_read_tensor": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P]),
     "pvae_infer": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
     "pvae_net_forward": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P, _P]),

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <functional>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "pvae_gemm.h"
@@ -131,71 +132,21 @@ struct pvae_ctx {
     int staged_rows = 0;
     double staged_rows_f = 0;    // rows of the batch being processed (for the profiler's flop count)
     bool pair_launch = true;     // PVAE_PAIR=0 launches every contraction on its own (A/B)
+    // gather prefetch (pvae_train_step_prefetch): what the alternate staging panels hold, and the
+    // staging job the current step's last launch should carry
+    struct { bool valid = false; int64_t first = 0; int rows = 0; const float* states = nullptr; } pf;
+    StageArgs next_stage;        // rows_pad > 0: pending for the last launch of this step
+    bool next_carried = false;   // set by the launch that took it
 };
 
 // ---------------------------------------------------------------------------------------
 // glue kernels
 // ---------------------------------------------------------------------------------------
 
-// Minibatch staging.  One block per (padded) batch row and time step (blockIdx.y = t < L).
-// Builds the network input panels and the two target panels from either the HBM-resident
-// demonstration set (window_row != null: step t of window i reads rows s+t and s+t+1 of
-// `states`, row s+t of `actions`; tpv:133-156 windows, tm:52-56 float64->float32, tm:166-175
-// collate) or explicit x[rows][L][2Db] / y[rows][L][Da] (tpv:365-376).  Pad rows and pad columns
-// are written as zeros so that every GEMM can run on whole tiles without bounds checks.
-// Time step t lives in row block t of every panel (pvae_layout.h).  For t > 0 the current-state
-// columns are left zero here: they are the world model's own prediction of step t-1 (tpv:421),
-// copied in by scatter_state_kernel during the forward pass.  `wm_pred` (L > 1 only) is the
-// input panel of the world-model invocations that take the decoder's action.
-__global__ void __launch_bounds__(256)
-stage_batch_kernel(const float* __restrict__ states, const float* __restrict__ actions,
-                   const int32_t* __restrict__ window_row, long long first_window,
-                   const float* __restrict__ x, const float* __restrict__ y, int rows, int Db, int Da,
-                   float* __restrict__ te_in, int ld_te, float* __restrict__ md_in, int ld_md,
-                   float* __restrict__ wm_in, int ld_wm, float* __restrict__ s2, int ld_s2,
-                   float* __restrict__ act_t, int ld_a, float* __restrict__ wm_pred, int L) {
-    const int r = blockIdx.x;
-    const int t = blockIdx.y;
-    const size_t prow = (size_t)t * gridDim.x + r;        // row inside the stacked panels
-    const bool valid = r < rows;
-    const bool first = t == 0;
-    const float* p1 = nullptr;
-    const float* p2 = nullptr;
-    const float* pa = nullptr;
-    if (valid) {
-        if (window_row) {
-            const long long s = (long long)window_row[first_window + r] + t;
-            p1 = states + s * Db;
-            p2 = p1 + Db;
-            pa = actions + s * Da;
-        } else {
-            p1 = x + ((size_t)r * L + t) * 2 * Db;
-            p2 = p1 + Db;
-            pa = y ? y + ((size_t)r * L + t) * Da : nullptr;
-        }
-    }
-    int ld_max = ld_te;
-    if (ld_md > ld_max) ld_max = ld_md;
-    if (ld_wm > ld_max) ld_max = ld_wm;
-    for (int c = threadIdx.x; c < ld_max; c += 256) {
-        const float v1 = (valid && first && c < Db) ? p1[c] : 0.f;
-        const float v2 = (valid && c < Db) ? p2[c] : 0.f;
-        const float va = (valid && pa && c < Da) ? pa[c] : 0.f;
-        if (c < ld_te) {
-            float u = v1;
-            if (c >= Db) u = (valid && c < 2 * Db) ? p2[c - Db] : 0.f;
-            te_in[prow * ld_te + c] = u;
-        }
-        if (c < ld_md) md_in[prow * ld_md + c] = v1;          // z columns filled by reparam
-        if (c < ld_wm) {
-            float u = v1;
-            if (c >= Db) u = (valid && pa && c < Db + Da) ? pa[c - Db] : 0.f;
-            wm_in[prow * ld_wm + c] = u;
-            if (wm_pred) wm_pred[prow * ld_wm + c] = c < Db ? v1 : 0.f;   // a_hat columns filled by the decoder
-        }
-        if (c < ld_s2) s2[prow * ld_s2 + c] = v2;
-        if (c < ld_a) act_t[prow * ld_a + c] = va;
-    }
+// Minibatch staging as a launch of its own: one block per (padded) batch row and time step
+// (blockIdx.y = t < L); the work is stage_row (pvae_gemm.h).
+__global__ void __launch_bounds__(256) stage_batch_kernel(StageArgs a) {
+    stage_row(a, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // s1 of step t+1 = world-model prediction of step t (tpv:421): copy the first Db columns of the
@@ -582,9 +533,12 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
         const int pw2 = g_prof.begin(2, 2.0 * rowsf * ((double)l1.n_in * l1.n_out + (double)l0.n_in * l0.n_out), st);
         auto go = [&](auto e1, auto e0) -> int {
             if (with_fold) e1.loss = foldv;            // block 0 of the launch belongs to the first problem
+            // the step's LAST launch also gathers the next minibatch into the alternate panels
+            const bool carry = with_fold && c->next_stage.rows_pad > 0;
             HIP_TRY(gemm_wgrad_pair(c->ws + w->dz[1], l1.n_out_pad, c->ws + w->act[0], l1.ld, l1.n_out_pad, l1.ld, e1,
                                     c->ws + w->dz[0], l0.n_out_pad, c->ws + w->in, l0.ld, l0.n_out_pad, l0.ld, e0,
-                                    rows_pad, st));
+                                    rows_pad, st, carry ? &c->next_stage : nullptr));
+            if (carry) c->next_carried = true;
             return 0;
         };
         const int rc = fused ? go(adam_epi(l1), adam_epi(l0)) : go(store_epi(l1), store_epi(l0));
@@ -713,6 +667,7 @@ int pvae_create(const pvae_config* cfg, pvae_ctx** out) {
     if (!c) return fail(-3, "out of host memory");
     c->L = L;
     c->W = make_workspace(L);
+    memset(&c->next_stage, 0, sizeof(c->next_stage));
     const char* pv = getenv("PVAE_PAIR");
     c->pair_launch = !(pv && pv[0] == '0');
     *out = c;
@@ -754,23 +709,37 @@ int pvae_bind_dataset(pvae_ctx* c, const float* states, const float* actions, co
 }
 
 // `steps`: time steps to stage (the ctx's lookahead for training batches, 1 for rollout inference)
+// Arguments of a staging job into the CURRENT (alt == false) or the alternate set of input panels.
+static StageArgs stage_args(const pvae_ctx* c, long long first_window, const float* x, const float* y, int rows,
+                            bool from_set, int steps, bool alt) {
+    const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action;
+    float* w = c->ws;
+    const int ld_wm = c->L.net[PVAE_NET_WM].layers[0].ld;
+    StageArgs a;
+    memset(&a, 0, sizeof(a));
+    a.states = from_set ? c->states : nullptr;
+    a.actions = from_set ? c->actions : nullptr;
+    a.window_row = from_set ? c->window_row : nullptr;
+    a.first_window = first_window;
+    a.x = x; a.y = y;
+    a.rows = rows; a.rows_pad = pad32(rows); a.Db = Db; a.Da = Da; a.L = steps;
+    a.te_in = w + (alt ? c->W.alt_in[PVAE_NET_TE] : c->W.net[PVAE_NET_TE].in); a.ld_te = c->L.net[PVAE_NET_TE].layers[0].ld;
+    a.md_in = w + (alt ? c->W.alt_in[PVAE_NET_MD] : c->W.net[PVAE_NET_MD].in); a.ld_md = c->L.net[PVAE_NET_MD].layers[0].ld;
+    a.wm_in = w + (alt ? c->W.alt_in[PVAE_NET_WM] : c->W.net[PVAE_NET_WM].in); a.ld_wm = ld_wm;
+    a.s2 = w + (alt ? c->W.alt_s2 : c->W.s2); a.ld_s2 = pad64(Db);
+    a.act_t = w + (alt ? c->W.alt_act_t : c->W.act_t); a.ld_a = pad64(Da);
+    a.wm_pred = (steps > 1 && !alt) ? a.wm_in + (int64_t)steps * a.rows_pad * ld_wm : nullptr;
+    return a;
+}
+
+// `steps`: time steps to stage (the ctx's lookahead for training batches, 1 for rollout inference)
 static int stage(pvae_ctx* c, long long first_window, const float* x, const float* y, int rows, bool from_set,
                  hipStream_t st, int steps) {
     int rc = check_ready(c, false);
     if (rc) return rc;
     if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
-    const int rows_pad = pad32(rows);
-    const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action;
-    float* w = c->ws;
-    const int T = steps;
-    const int ld_wm = c->L.net[PVAE_NET_WM].layers[0].ld;
-    hipLaunchKernelGGL(stage_batch_kernel, dim3(rows_pad, T), dim3(256), 0, st,
-                       from_set ? c->states : nullptr, from_set ? c->actions : nullptr,
-                       from_set ? c->window_row : nullptr, first_window, x, y, rows, Db, Da,
-                       w + c->W.net[PVAE_NET_TE].in, c->L.net[PVAE_NET_TE].layers[0].ld,
-                       w + c->W.net[PVAE_NET_MD].in, c->L.net[PVAE_NET_MD].layers[0].ld,
-                       w + c->W.net[PVAE_NET_WM].in, ld_wm, w + c->W.s2, pad64(Db), w + c->W.act_t, pad64(Da),
-                       T > 1 ? w + c->W.net[PVAE_NET_WM].in + (int64_t)T * rows_pad * ld_wm : (float*)nullptr, T);
+    const StageArgs a = stage_args(c, first_window, x, y, rows, from_set, steps, false);
+    hipLaunchKernelGGL(stage_batch_kernel, dim3(a.rows_pad, steps), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     c->staged_rows = rows;
     c->staged_rows_f = rows;
@@ -1402,6 +1371,41 @@ int pvae_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t rows, 
     int rc = pvae_gather(c, first_window, rows, stream);
     if (rc) return rc;
     return pvae_forward_backward(c, phase, rows, sp, eps, loss_out, PVAE_FLAG_FUSED_ADAM, stream);
+}
+
+// swap the roles of the two sets of staging panels
+static void flip_stage_panels(pvae_ctx* c) {
+    for (int n = 0; n < PVAE_NUM_NETS; ++n) std::swap(c->W.net[n].in, c->W.alt_in[n]);
+    std::swap(c->W.s2, c->W.alt_s2);
+    std::swap(c->W.act_t, c->W.alt_act_t);
+}
+
+int pvae_train_step_prefetch(pvae_ctx* c, int phase, int64_t first_window, int32_t rows, const pvae_step_params* sp,
+                             const float* eps, float* loss_out, int64_t next_first, int32_t next_rows, void* stream) {
+    if (!c) return fail(-1, "null ctx");
+    if (!c->states) return fail(-2, "dataset not bound");
+    int rc;
+    const bool can = c->W.L == 1 && c->pair_launch && loss_out != nullptr;   // the carrier is the folding launch
+    if (can && c->pf.valid && c->pf.first == first_window && c->pf.rows == rows && c->pf.states == c->states) {
+        flip_stage_panels(c);                   // this minibatch is already staged
+        c->staged_rows = rows;
+        c->staged_rows_f = rows;
+    } else if ((rc = pvae_gather(c, first_window, rows, stream))) {
+        return rc;
+    }
+    c->pf.valid = false;
+    c->next_stage.rows_pad = 0;
+    c->next_carried = false;
+    if (can && next_rows > 0 && next_rows <= c->L.cfg.max_batch && next_first >= 0 &&
+        next_first + next_rows <= c->n_windows)
+        c->next_stage = stage_args(c, next_first, nullptr, nullptr, next_rows, true, 1, true);
+    rc = pvae_forward_backward(c, phase, rows, sp, eps, loss_out, PVAE_FLAG_FUSED_ADAM, stream);
+    if (!rc && c->next_carried) {
+        c->pf.valid = true; c->pf.first = next_first; c->pf.rows = next_rows; c->pf.states = c->states;
+    }
+    c->next_stage.rows_pad = 0;
+    c->next_carried = false;
+    return rc;
 }
 
 int pvae_read_tensor(pvae_ctx* c, int what, float* dst, int32_t rows, void* stream) {

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 
 namespace pvae {
 
@@ -63,6 +64,80 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 //   Q is always ROW (X or dZ, k-contiguous).  P_ROW: W[p][k] (forward);  !P_ROW: W[k][p] (dgrad).
 // ABL (tools/gemm_ablate.hip only; 0 in production): 1 = no tile staging in the loop, 2 = no LDS
 // fragment reads, 4 = no MFMA, 8 = no barrier.
+// ---------------------------------------------------------------------------------------
+// minibatch staging (device side; launched as stage_batch_kernel or as tail blocks of the step's
+// last weight-gradient launch)
+// ---------------------------------------------------------------------------------------
+// One call = one (padded) batch row r of time step t.  Builds the network input panels and the two
+// target panels from either the HBM-resident demonstration set (window_row != null: step t of
+// window i reads rows s+t and s+t+1 of `states`, row s+t of `actions`; tpv:133-156 windows,
+// tm:52-56 float64->float32, tm:166-175 collate) or explicit x[rows][L][2Db] / y[rows][L][Da]
+// (tpv:365-376).  Pad rows and pad columns are written as zeros so that every GEMM can run on
+// whole tiles without bounds checks.  Time step t lives in row block t of every panel
+// (pvae_layout.h).  For t > 0 the current-state columns are left zero here: they are the world
+// model's own prediction of step t-1 (tpv:421), copied in by scatter_state_kernel during the
+// forward pass.  `wm_pred` (L > 1 only) is the input panel of the world-model invocations that
+// take the decoder's action.
+struct StageArgs {
+    const float* states;
+    const float* actions;
+    const int32_t* window_row;
+    long long first_window;
+    const float* x;
+    const float* y;
+    int rows, rows_pad, Db, Da, L;
+    float* te_in; int ld_te;
+    float* md_in; int ld_md;
+    float* wm_in; int ld_wm;
+    float* s2; int ld_s2;
+    float* act_t; int ld_a;
+    float* wm_pred;
+};
+
+__device__ inline void stage_row(const StageArgs& a, int r, int t, int rows_pad) {
+    const int Db = a.Db, Da = a.Da;
+    const size_t prow = (size_t)t * rows_pad + r;          // row inside the stacked panels
+    const bool valid = r < a.rows;
+    const bool first = t == 0;
+    const float* p1 = nullptr;
+    const float* p2 = nullptr;
+    const float* pa = nullptr;
+    if (valid) {
+        if (a.window_row) {
+            const long long s = (long long)a.window_row[a.first_window + r] + t;
+            p1 = a.states + s * Db;
+            p2 = p1 + Db;
+            pa = a.actions + s * Da;
+        } else {
+            p1 = a.x + ((size_t)r * a.L + t) * 2 * Db;
+            p2 = p1 + Db;
+            pa = a.y ? a.y + ((size_t)r * a.L + t) * Da : nullptr;
+        }
+    }
+    int ld_max = a.ld_te;
+    if (a.ld_md > ld_max) ld_max = a.ld_md;
+    if (a.ld_wm > ld_max) ld_max = a.ld_wm;
+    for (int c = threadIdx.x; c < ld_max; c += 256) {
+        const float v1 = (valid && first && c < Db) ? p1[c] : 0.f;
+        const float v2 = (valid && c < Db) ? p2[c] : 0.f;
+        const float va = (valid && pa && c < Da) ? pa[c] : 0.f;
+        if (c < a.ld_te) {
+            float u = v1;
+            if (c >= Db) u = (valid && c < 2 * Db) ? p2[c - Db] : 0.f;
+            a.te_in[prow * a.ld_te + c] = u;
+        }
+        if (c < a.ld_md) a.md_in[prow * a.ld_md + c] = v1;      // z columns filled by reparam
+        if (c < a.ld_wm) {
+            float u = v1;
+            if (c >= Db) u = (valid && pa && c < Db + Da) ? pa[c - Db] : 0.f;
+            a.wm_in[prow * a.ld_wm + c] = u;
+            if (a.wm_pred) a.wm_pred[prow * a.ld_wm + c] = c < Db ? v1 : 0.f;   // a_hat columns filled by the decoder
+        }
+        if (c < a.ld_s2) a.s2[prow * a.ld_s2 + c] = v2;
+        if (c < a.ld_a) a.act_t[prow * a.ld_a + c] = va;
+    }
+}
+
 // host-side default for GemmArgs::krot: off (measured: no gain); PVAE_KROT=1 enables
 static int g_krot = [] { const char* e = getenv("PVAE_KROT"); return (e && e[0] == '1') ? 1 : 0; }();
 struct GemmArgs {
@@ -669,12 +744,16 @@ gemm_wgrad_reg_kernel(GemmArgs ga, Epi epi) {
 // layer l.  The dgrad blocks are dispatched first (one per CU), the wgrad blocks land beside
 // them (2 waves per SIMD), so one workgroup's load / Adam-traffic phases hide under the other's
 // MFMA phases, and a launch boundary disappears.
+// Blocks past the two problems (n12 .. n12 + sa.rows_pad) stage the NEXT minibatch into the
+// alternate input panels (StageArgs / stage_row below): the gather rides in the last launch of the
+// step that precedes it instead of being a launch of its own.
 template <class EpiW>
 __global__ void __launch_bounds__(256)
-wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2) {
+wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2, int n12, StageArgs sa) {
     __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
     if ((int)blockIdx.x < n1) wgrad_reg_body<EpiW>(lds, blockIdx.x, g1, e1);
-    else wgrad_reg_body<EpiW>(lds, blockIdx.x - n1, g2, e2);
+    else if ((int)blockIdx.x < n12) wgrad_reg_body<EpiW>(lds, blockIdx.x - n1, g2, e2);
+    else stage_row(sa, blockIdx.x - n12, 0, sa.rows_pad);
 }
 
 // (The dgrad half stays on the register-staged body here: with the wave-specialised body the
@@ -945,12 +1024,16 @@ inline hipError_t gemm_wgrad(const float* dZ, int ldz, const float* X, int ldx, 
 template <class EpiW>
 inline hipError_t gemm_wgrad_pair(const float* dZ1, int ldz1, const float* X1, int ldx1, int N1, int Kin1,
                                   const EpiW& e1, const float* dZ2, int ldz2, const float* X2, int ldx2, int N2,
-                                  int Kin2, const EpiW& e2, int M, hipStream_t st) {
+                                  int Kin2, const EpiW& e2, int M, hipStream_t st, const StageArgs* next = nullptr) {
     const GemmGrid g1 = make_grid(N1, Kin1, 64, 64);
     const GemmGrid g2 = make_grid(N2, Kin2, 64, 64);
-    hipLaunchKernelGGL((wgrad_pair_kernel<EpiW>), dim3(g1.grid + g2.grid), dim3(256), 0, st,
+    StageArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    if (next) sa = *next;                     // rows_pad extra blocks gather the next minibatch
+    hipLaunchKernelGGL((wgrad_pair_kernel<EpiW>), dim3(g1.grid + g2.grid + sa.rows_pad), dim3(256), 0, st,
                        GemmArgs{dZ1, ldz1, X1, ldx1, M, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, e1, g1.grid,
-                       GemmArgs{dZ2, ldz2, X2, ldx2, M, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, e2);
+                       GemmArgs{dZ2, ldz2, X2, ldx2, M, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, e2,
+                       g1.grid + g2.grid, sa);
     return hipGetLastError();
 }
 // one launch: dX'[M][Kin'] = (dZ'[M][N'] W'[N'][Kin']) .* mask   ||   G[N][Kin] = dZ[M][N]^T X[M][Kin]

@@ -94,6 +94,10 @@ struct Workspace {
     NetWork net[PVAE_NUM_NETS];
     int64_t s2 = 0, act_t = 0;  // targets: next state [L*Bp][pad64(Db)], action [L*Bp][pad64(Da)]
     int64_t eps = 0;            // eps actually used [L*Bp][Z]
+    // second set of staging panels (lookahead 1 only): the gather of minibatch n+1 is written here
+    // by tail blocks of step n's last launch, then the two sets swap roles (pvae_train_step_prefetch)
+    int64_t alt_in[PVAE_NUM_NETS] = {0, 0, 0};
+    int64_t alt_s2 = 0, alt_act_t = 0;
     int64_t loss_part = 0;      // [5][kLossParts] partial sums
     int64_t total_floats = 0;
 };
@@ -121,6 +125,9 @@ inline Workspace make_workspace(const Layout& L) {
     W.s2 = take(T * W.Bp * pad64(L.cfg.dim_body));
     W.act_t = take(T * W.Bp * pad64(L.cfg.dim_action));
     W.eps = take(T * W.Bp * L.cfg.latent);
+    for (int n = 0; n < PVAE_NUM_NETS; ++n) W.alt_in[n] = take((int64_t)W.Bp * L.net[n].layers[0].ld);
+    W.alt_s2 = take((int64_t)W.Bp * pad64(L.cfg.dim_body));
+    W.alt_act_t = take((int64_t)W.Bp * pad64(L.cfg.dim_action));
     W.loss_part = take(5 * kLossParts);
     W.total_floats = off;
     return W;

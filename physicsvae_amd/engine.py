@@ -215,11 +215,19 @@ class HipEngine:
             mask |= 1 << n
         _lib.check(self.lib.pvae_adam(self.ctx, mask, C.byref(sp), self._stream()), "pvae_adam")
 
-    def train_step(self, phase, first_window, rows, sp, eps=None, loss_out=None):
+    def train_step(self, phase, first_window, rows, sp, eps=None, loss_out=None, next_span=None):
+        """One fused optimizer step; `next_span` = (first_window, rows) of the minibatch that follows
+        lets the library gather it inside this step's last launch (pvae_train_step_prefetch)."""
         self._need_gpu()
         if eps is not None:
             eps = self._eps(eps, rows)
         out = self._loss_scratch if loss_out is None else loss_out
+        if next_span is not None:
+            _lib.check(self.lib.pvae_train_step_prefetch(
+                self.ctx, phase, int(first_window), int(rows), C.byref(sp),
+                eps.data_ptr() if eps is not None else None, out.data_ptr(), int(next_span[0]), int(next_span[1]),
+                self._stream()), "pvae_train_step_prefetch")
+            return out
         _lib.check(self.lib.pvae_train_step(
             self.ctx, phase, int(first_window), int(rows), C.byref(sp),
             eps.data_ptr() if eps is not None else None, out.data_ptr(), self._stream()),

@@ -169,6 +169,7 @@ class TrainModel(tune.Trainable):
         self.dp = parallel.DataParallel.from_env()
         self.dp_bucket_mb = float(config.get("dp_bucket_mb", os.environ.get("PVAE_DP_BUCKET_MB", 0)))
         self.dp.attach(self.engine)
+        self.prefetch_gather = bool(config.get("prefetch_gather", os.environ.get("PVAE_PREFETCH", "1") != "0"))
         self.prepare_data(config)
         self.optimizer = HipAdam(self.model.parameters(), self.engine,
                                  lr=config.get("lr", 1e-3),
@@ -240,7 +241,11 @@ class TrainModel(tune.Trainable):
                     eng.gather(first, rows)
                     eng.forward_backward(phase, rows, sp, eps=eps, backward=False, loss_out=out[g])
             elif not dp.collective:
-                eng.train_step(phase, first, rows, sp, eps=eps, loss_out=out[g])
+                nxt = (first + rows, min(loader.batch_size, len(loader.dataset) - first - rows))
+                if nxt[1] <= 0:                   # epoch boundary: the next epoch starts at window 0
+                    nxt = (0, min(loader.batch_size, len(loader.dataset)))
+                eng.train_step(phase, first, rows, sp, eps=eps, loss_out=out[g],
+                               next_span=nxt if self.prefetch_gather else None)
             else:
                 self.dp_step(phase, nets, first, rows, sp, eps, out[g])
             if train:

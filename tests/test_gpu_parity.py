@@ -383,6 +383,44 @@ def test_fused_adam_equals_separate_adam_and_tracks_oracle(golden):
         assert rel_err(mom[k][1].cpu(), v_ref[k]) < 1e-4, k
 
 
+def test_gather_prefetch_is_bit_identical(golden):
+    """The gather of minibatch n+1 riding in step n's last launch (second set of input panels)
+    changes nothing: three epochs across the phase switch, ragged last minibatch, an evaluation
+    epoch in between -- parameters, moments and losses equal the run that gathers in a launch of
+    its own, bit for bit; a mispredicted next minibatch falls back to a normal gather."""
+    g = golden("train_tiny")
+    arch = arch_from_meta(g["meta"])
+    n_ep, n_steps, batch, m_world, n_epochs, lr_step = [int(v) for v in g["meta"][9:15]]
+    data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
+    runs = []
+    for pre in (False, True):
+        tr = make_trainer(arch, data, batch, m_world=1, device=DEV, eps_fn=R.eps_stream(2, arch["Z"]),
+                          extra={"prefetch_gather": pre})
+        tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3))
+        losses = [tr.train()["mean_train_loss"]]
+        ev = tr.run_epoch(tr.train_loader, train=False)          # forward-only epoch in between
+        losses += [tr.train()["mean_train_loss"] for _ in range(2)]
+        runs.append((losses, ev, tr.engine.params.clone(), tr.engine.exp_avg.clone(), tr.engine.exp_avg_sq.clone()))
+    (la, ea, pa, ma, va), (lb, eb, pb, mb, vb) = runs
+    assert la == lb and torch.equal(ea, eb)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    # misprediction: announce one minibatch, ask for another
+    eng = tr.engine
+    eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
+    phase, nets = tr.phase()
+    out1, out2 = torch.zeros(5, device=DEV), torch.zeros(5, device=DEV)
+    p0, m0, v0 = eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone()
+    sp = tr.step_params(nets, batch, True)
+    e = R.eps_stream(9, arch["Z"])(0, (batch, arch["Z"]))
+    eng.train_step(phase, 0, batch, sp, eps=e, loss_out=out1, next_span=(batch, batch))
+    eng.train_step(phase, 2 * batch, batch, sp, eps=e, loss_out=out1, next_span=(0, batch))
+    p1 = eng.params.clone()
+    eng.params.copy_(p0); eng.exp_avg.copy_(m0); eng.exp_avg_sq.copy_(v0)
+    eng.train_step(phase, 0, batch, sp, eps=e, loss_out=out2)
+    eng.train_step(phase, 2 * batch, batch, sp, eps=e, loss_out=out2)
+    assert torch.equal(p1, eng.params) and torch.equal(out1, out2)
+
+
 def test_step_is_deterministic(golden):
     g, arch, data, x, y, sd, eps, tr = _setup_single(golden, "single_c1")
     eng = tr.engine
