@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (load order matters)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpvae_gfx950.so")
+LIB_PATH = os.environ.get("PVAE_LIB_PATH") or os.path.join(HERE, "libpvae_gfx950.so")   # env: A/B builds
 
 NET_TE, NET_MD, NET_WM = 0, 1, 2
 NET_NAMES = {NET_TE: "_task_encoder", NET_MD: "_motor_decoder", NET_WM: "_world_model"}

@@ -27,6 +27,20 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+// Timeline probe (tools/timeline_probe.hip defines PVAE_TIMELINE): thread `tid_` of each workgroup
+// stores the 100 MHz wall clock at numbered points of the wave-specialised kernel, and GemmArgs::krot
+// values >= 2 switch parts of it off (ablation).  Compiled out of the library.
+#ifdef PVAE_TIMELINE
+extern __device__ unsigned long long* g_timeline;
+#define PVAE_MARK(tid_, id_)                                                                   \
+    do {                                                                                       \
+        if ((int)threadIdx.x == (tid_)) g_timeline[(size_t)blockIdx.x * 8 + (id_)] = wall_clock64(); \
+    } while (0)
+#define PVAE_PROBE(mode_) (ga.krot == (mode_))
+#else
+#define PVAE_MARK(tid_, id_) do { } while (0)
+#define PVAE_PROBE(mode_) false
+#endif
 #include <cstring>
 
 namespace pvae {
@@ -369,6 +383,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lh = lane >> 4;
     const int nk = K / BK;
+    PVAE_MARK(0, 0);                                             // workgroup entered
     v4f acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -398,9 +413,11 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
         const size_t kstep_p = P_ROW ? (size_t)BK : (size_t)BK * ldp;
         const int rot = k_rotation(ga, loc, tile_q, nk);
         auto issue = [&](int t) {
+            if (PVAE_PROBE(6)) return;                    // probe: loaders only keep the barriers
             float* slot = lds + (t % S) * kStage;
             int kt = t + rot;                             // k-tile this workgroup reads at step t
             if (kt >= nk) kt -= nk;
+            if (PVAE_PROBE(2)) kt = 0;                    // probe: every step re-reads tile 0 (cache-resident)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 lds_dma16(sq[u] + (size_t)kt * BK, slot + (u0 + 4 * u) * 256);
@@ -410,7 +427,9 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
 #pragma unroll
         for (int t = 0; t < S - 1; ++t)
             if (t < nk) issue(t);
+        PVAE_MARK(256, 4);                                       // prologue loads issued
         wait_dma_tile(nk - 1 < S - 2 ? nk - 1 : S - 2);          // tile 0 landed
+        PVAE_MARK(256, 5);
         __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nk; ++t) {
             // tile t+1 landed: younger tiles in flight = t+2 .. min(t+S-2, nk-1)
@@ -445,6 +464,10 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
             }
         };
         auto mfmas = [&](const Frag& f) {
+            if (PVAE_PROBE(4)) {                          // probe: no MFMAs (fragments stay live)
+                asm volatile("" ::"v"(f.q[0]), "v"(f.q[1]), "v"(f.p[0]), "v"(f.p[1]));
+                return;
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
@@ -457,6 +480,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
         };
         __builtin_amdgcn_s_barrier();                              // tile 0 landed
         asm volatile("" ::: "memory");
+        PVAE_MARK(0, 1);
         Frag F0, F1;
         fread(lds, F0);
         for (int t0 = 0; t0 < nk; t0 += 2) {
@@ -477,6 +501,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
     }
     // split-K reduction through LDS (fixed order: compute wave 0..3), epilogue on float4s by the
     // 256 compute threads; every wave takes part in the barriers
+    PVAE_MARK(0, 2);                                             // main loop done (compute wave 0)
     __syncthreads();
     constexpr int RS = 36;
     if (wave < 4) {
@@ -501,6 +526,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
         epi(q0 + ql, p0 + pl, v);
     }
     epi.finish(lds, tile_q * tiles_p + tile_p, tid);
+    PVAE_MARK(0, 3);                                             // epilogue stores issued
 }
 
 template <bool P_ROW, class Epi>
