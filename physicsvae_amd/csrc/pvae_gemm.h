@@ -37,7 +37,16 @@ extern __device__ unsigned long long* g_timeline;
         if ((int)threadIdx.x == (tid_)) g_timeline[(size_t)blockIdx.x * 8 + (id_)] = wall_clock64(); \
     } while (0)
 #define PVAE_PROBE(mode_) (ga.krot == (mode_))
+// slot 6: HW_ID (bits 8..11 CU, 12..13 SH, 13..15 SE on gfx9), slot 7: XCC_ID
+#define PVAE_MARK_HW()                                                                         \
+    do {                                                                                       \
+        if (threadIdx.x == 0) {                                                                \
+            g_timeline[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
+            g_timeline[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)); \
+        }                                                                                      \
+    } while (0)
 #else
+#define PVAE_MARK_HW() do { } while (0)
 #define PVAE_MARK(tid_, id_) do { } while (0)
 #define PVAE_PROBE(mode_) false
 #endif
@@ -740,6 +749,7 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
         }
     }
 
+    PVAE_MARK(0, 2);                                             // contraction done, epilogue (Adam) starts
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int q = q0 + wq + 2 * li + a, p = p0 + wp + 8 * lh;
@@ -788,8 +798,11 @@ template <class EpiD, class EpiW>
 __global__ void __launch_bounds__(256)
 bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew) {
     __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
+    PVAE_MARK(0, 0);
+    PVAE_MARK_HW();
     if ((int)blockIdx.x < nd) splitk_reg_body<false, EpiD>(lds, blockIdx.x, gd, ed);
     else wgrad_reg_body<EpiW>(lds, blockIdx.x - nd, gw, ew);
+    PVAE_MARK(0, 3);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1,0 +1,73 @@
+// Timeline of the horizontally fused backward launch (bwd_pair_kernel: blocks [0,256) = input
+// gradient 256x1024x1024 on 32x32 tiles, blocks [256,512) = weight gradient 1024x1024 (K = 256
+// rows) on 64x64 tiles with Adam in the epilogue): when does each kind of workgroup start and end,
+// and on which CU does it run (do a dgrad and a wgrad workgroup really share every CU?).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/pair_probe.hip -o tools/pair_probe.out
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <map>
+#include <vector>
+#define PVAE_TIMELINE 1
+__device__ unsigned long long* g_timeline;
+#include "../physicsvae_amd/csrc/pvae_gemm.h"
+using namespace pvae;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+int main() {
+    const int M = 256, N = 1024, K = 1024;
+    hipStream_t st; CK(hipStreamCreate(&st));
+    float *dZ, *W, *X, *dX, *act, *m, *v; unsigned long long* T;
+    const size_t nw = (size_t)N * K;
+    CK(hipMalloc(&dZ, (size_t)M * N * 4)); CK(hipMalloc(&W, nw * 4 + N * 4)); CK(hipMalloc(&X, (size_t)M * K * 4));
+    CK(hipMalloc(&dX, (size_t)M * K * 4)); CK(hipMalloc(&act, (size_t)M * K * 4));
+    CK(hipMalloc(&m, nw * 4 + N * 4)); CK(hipMalloc(&v, nw * 4 + N * 4));
+    CK(hipMalloc(&T, (size_t)2048 * 8 * 8));
+    CK(hipMemset(dZ, 0, (size_t)M * N * 4)); CK(hipMemset(W, 0, nw * 4 + N * 4)); CK(hipMemset(X, 0, (size_t)M * K * 4));
+    CK(hipMemset(act, 0, (size_t)M * K * 4)); CK(hipMemset(m, 0, nw * 4 + N * 4)); CK(hipMemset(v, 0, nw * 4 + N * 4));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &T, sizeof(T)));
+    AdamScalars as{5e-4f, 1.f, 0.9f, 0.999f, 1e-8f, 0.1f, 0.001f};
+    EpiGradAdam e{W, m, v, K, as};
+    e.b = W + nw; e.bm = m + nw; e.bv = v + nw;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    auto go = [&]() { return gemm_bwd_pair(dZ, N, W, K, act, K, dX, K, M, K, N, dZ, N, X, K, N, K, M, e, st); };
+    for (int i = 0; i < 20; ++i) CK(go());
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(a, st));
+    const int iters = 200;
+    for (int i = 0; i < iters; ++i) CK(go());
+    CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    const int grid = 512;
+    std::vector<unsigned long long> h((size_t)grid * 8);
+    CK(hipMemcpy(h.data(), T, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (int w = 0; w < grid; ++w) t0 = std::min(t0, h[(size_t)w * 8]);
+    printf("bwd_pair launch period %.2f us (back-to-back)\n", ms * 1e3 / iters);
+    auto stat = [&](const char* name, int lo, int hi, int id) {
+        std::vector<double> x;
+        for (int w = lo; w < hi; ++w) x.push_back((double)(h[(size_t)w * 8 + id] - t0) * 0.01);
+        std::sort(x.begin(), x.end());
+        printf("   %-44s min %6.2f  median %6.2f  max %6.2f us\n", name, x.front(), x[x.size() / 2], x.back());
+    };
+    stat("dgrad workgroups: entered", 0, 256, 0);
+    stat("dgrad workgroups: finished", 0, 256, 3);
+    stat("wgrad workgroups: entered", 256, 512, 0);
+    stat("wgrad workgroups: contraction done", 256, 512, 2);
+    stat("wgrad workgroups: finished (Adam stored)", 256, 512, 3);
+    // co-residency: (xcc, hw_id CU/SH/SE bits) of every workgroup
+    std::map<unsigned long long, std::pair<int, int>> cu;
+    for (int w = 0; w < grid; ++w) {
+        const unsigned long long key = (h[(size_t)w * 8 + 7] << 32) | ((h[(size_t)w * 8 + 6] >> 8) & 0xff);
+        if (w < 256) cu[key].first++; else cu[key].second++;
+    }
+    int both = 0, two_d = 0, two_w = 0;
+    for (auto& kv : cu) {
+        if (kv.second.first == 1 && kv.second.second == 1) ++both;
+        if (kv.second.first >= 2) ++two_d;
+        if (kv.second.second >= 2) ++two_w;
+    }
+    printf("   %zu distinct CUs used; %d hold one dgrad + one wgrad workgroup, %d hold >= 2 dgrad, %d hold >= 2 wgrad\n",
+           cu.size(), both, two_d, two_w);
+    return 0;
+}
