@@ -421,6 +421,46 @@ def test_gather_prefetch_is_bit_identical(golden):
     assert torch.equal(p1, eng.params) and torch.equal(out1, out2)
 
 
+def test_argument_errors_are_loud_and_leave_the_ctx_usable(golden):
+    """Every misuse of the C ABI returns a negative code with a message (-> RuntimeError in the
+    binding), launches nothing harmful, and the next correct call still matches the oracle."""
+    g, arch, data, x, y, sd, eps, tr = _setup_single(golden, "single_tiny")
+    eng = tr.engine
+    rows = x.shape[0]
+    sp = make_step_params(lr=5e-4, global_rows=rows)
+    p0 = eng.params.clone()
+    with pytest.raises(RuntimeError, match="staged rows"):          # nothing staged yet for 3 rows
+        eng.forward_backward(_lib.PHASE_JOINT, 3, sp, eps=eps[:3])
+    with pytest.raises(RuntimeError, match="dataset not bound"):
+        eng.gather(0, rows)
+    eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
+    n = len(tr.train_loader.dataset)
+    with pytest.raises(RuntimeError, match="outside"):               # window range past the end
+        eng.gather(n - 2, rows)
+    with pytest.raises(RuntimeError, match="outside"):               # more rows than max_batch
+        eng.gather(0, eng.max_batch + 1)
+    with pytest.raises(RuntimeError, match="outside"):
+        eng.train_step(_lib.PHASE_WORLD, -1, rows, sp)
+    eng.gather(0, rows)
+    with pytest.raises(RuntimeError, match="unknown phase"):
+        eng.forward_backward(7, rows, sp)
+    bad = make_step_params(lr=5e-4, global_rows=rows, s_rec=0.5)
+    with pytest.raises(RuntimeError, match="s_rec"):                 # joint phase + s_rec != 0 is refused
+        eng.forward_backward(_lib.PHASE_JOINT, rows, bad, eps=eps)
+    bad = make_step_params(lr=5e-4, global_rows=rows)
+    bad.loss_kind = 9
+    with pytest.raises(RuntimeError, match="loss_kind"):
+        eng.forward_backward(_lib.PHASE_WORLD, rows, bad)
+    with pytest.raises(RuntimeError, match="communicator"):
+        eng.dp_train_step(_lib.PHASE_WORLD, 0, rows, sp)
+    with pytest.raises(AssertionError):                               # eps of the wrong shape (binding)
+        eng.forward_backward(_lib.PHASE_JOINT, rows, sp, eps=eps[:, :2])
+    assert torch.equal(eng.params, p0)                                # no failed call touched the weights
+    eng.set_batch(x, y)
+    loss = eng.forward_backward(_lib.PHASE_JOINT, rows, sp, eps=eps, fused_adam=False).cpu()
+    assert float(loss[0]) == pytest.approx(float(g["joint_total"]), rel=1e-5)
+
+
 def test_step_is_deterministic(golden):
     g, arch, data, x, y, sd, eps, tr = _setup_single(golden, "single_c1")
     eng = tr.engine
