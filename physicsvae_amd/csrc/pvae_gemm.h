@@ -399,6 +399,32 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
 
+    const size_t kstep_p = P_ROW ? (size_t)BK : (size_t)BK * ldp;
+    const int rot = k_rotation(ga, loc, tile_q, nk);
+#ifndef PVAE_WS_SLOW0
+    // k-tile 0 is fetched by ALL eight waves (one eighth of each operand image per wave, two DMA
+    // instructions each): it is in flight ~0.1 us after the workgroup starts instead of queueing
+    // behind the loaders' three-tile prologue (each global_load_lds holds its wave ~150 cycles, so
+    // the prologue alone took 0.67 us -- tools/timeline_probe.hip).
+    if (!PVAE_PROBE(6)) {
+        const int j = wave * 64 + lane;                   // 16-byte slot inside the 8 KB tile image
+        const float* s0q;
+        const float* s0p;
+        {
+            const int row = j >> 4, c = (j & 15) ^ (row & 15);
+            s0q = Q + (size_t)(q0 + row) * ldq + c * 4;
+        }
+        if (P_ROW) {
+            const int row = j >> 4, c = (j & 15) ^ (row & 15);
+            s0p = P + (size_t)(p0 + row) * ldp + c * 4;
+        } else {
+            const int r = j >> 3, k = r ^ ((r >> 2) & 1);
+            s0p = P + (size_t)k * ldp + p0 + (j & 7) * 4;
+        }
+        lds_dma16(s0q + (size_t)rot * BK, lds + wave * 256);
+        lds_dma16(s0p + (size_t)rot * kstep_p, lds + kTile + wave * 256);
+    }
+#endif
     if (wave >= 4) {
         // ---------------- loader waves ----------------
         const int u0 = wave - 4;
@@ -419,8 +445,6 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
                 sp[u] = P + (size_t)k * ldp + p0 + (j & 7) * 4;
             }
         }
-        const size_t kstep_p = P_ROW ? (size_t)BK : (size_t)BK * ldp;
-        const int rot = k_rotation(ga, loc, tile_q, nk);
         auto issue = [&](int t) {
             if (PVAE_PROBE(6)) return;                    // probe: loaders only keep the barriers
             float* slot = lds + (t % S) * kStage;
@@ -433,6 +457,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
                 lds_dma16(sp[u] + (size_t)kt * kstep_p, slot + kTile + (u0 + 4 * u) * 256);
             }
         };
+#ifdef PVAE_WS_SLOW0
 #pragma unroll
         for (int t = 0; t < S - 1; ++t)
             if (t < nk) issue(t);
@@ -440,6 +465,17 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
         wait_dma_tile(nk - 1 < S - 2 ? nk - 1 : S - 2);          // tile 0 landed
         PVAE_MARK(256, 5);
         __builtin_amdgcn_s_barrier();
+#else
+        if (1 < nk) issue(1);                                    // rides on tile 0's flight time
+        PVAE_MARK(256, 4);
+        if (1 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>();       // this wave's share of tile 0 landed
+        PVAE_MARK(256, 5);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int t = 2; t < S - 1; ++t)
+            if (t < nk) issue(t);
+#endif
         for (int t = 0; t < nk; ++t) {
             // tile t+1 landed: younger tiles in flight = t+2 .. min(t+S-2, nk-1)
             int y = nk - 2 - t;
@@ -459,6 +495,9 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
             oq[a] = row * 64 + (((4 * wave + lh) ^ (row & 15)) << 2);
         }
         const int kq = 16 * wave + 4 * lh;
+#ifndef PVAE_WS_SLOW0
+        wait_vmcnt<0>();                                           // this wave's share of tile 0 landed
+#endif
         struct Frag { v4f q[2], p[2]; v2f c[4]; };
         auto fread = [&](const float* st, Frag& f) {
 #pragma unroll
