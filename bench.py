@@ -126,12 +126,12 @@ def main():
             first, rows, grows = dp.shard(g, n_win, a.batch)
             sp = tr.step_params(nets, grows, True)
             sp.rng_seed, sp.rng_offset = 7, (start + i) * 65536 + dp.rank * 64
+            nfirst, nrows, _ = dp.shard((start + i + 1) % full, n_win, a.batch)
             if not dp.collective:
-                nfirst, nrows, _ = dp.shard((start + i + 1) % full, n_win, a.batch)
                 eng.train_step(phase, first, rows, sp, loss_out=loss_buf,
                                next_span=(nfirst, nrows) if tr.prefetch_gather else None)
             else:
-                tr.dp_step(phase, nets, first, rows, sp, None, loss_buf)
+                tr.dp_step(phase, nets, first, rows, sp, None, loss_buf, next_span=(nfirst, nrows))
             rows_done += grows
         return rows_done
 

@@ -185,7 +185,10 @@ int pvae_adam_segment(pvae_ctx* ctx, int net, int64_t offset, int64_t count, con
  *                         on `stream` like any other launch of this library (no side stream)
  *   pvae_dp_train_step    one data-parallel optimizer step in ONE call: gather + forward +
  *                         backward (gradients scaled by 1/global_rows) + per-net all-reduce +
- *                         Adam; rows may be 0 (empty shard of a ragged last global batch).
+ *                         Adam; rows may be 0 (empty shard of a ragged last global batch);
+ *                         [next_first, +next_rows) = this rank's shard of the following step
+ *                         (0 rows: unknown), gathered inside this step's last launch as in
+ *                         pvae_train_step_prefetch.
  * The RCCL library is resolved at run time (the copy PyTorch already loaded, else the system
  * one); a missing library is an error from these calls only. */
 int pvae_comm_unique_id(void* id128);
@@ -193,7 +196,8 @@ int pvae_comm_init(pvae_ctx* ctx, int rank, int world, const void* id128);
 int pvae_comm_destroy(pvae_ctx* ctx);
 int pvae_allreduce_grads(pvae_ctx* ctx, int64_t offset, int64_t count, void* stream);
 int pvae_dp_train_step(pvae_ctx* ctx, int phase, int64_t first_window, int32_t rows,
-                       const pvae_step_params* sp, const float* eps, float* loss_out, void* stream);
+                       const pvae_step_params* sp, const float* eps, float* loss_out,
+                       int64_t next_first, int32_t next_rows, void* stream);
 
 /* One whole optimizer step on the bound dataset: gather + forward/backward + Adam.
  * This is the body of the `for data in self.train_loader` loop (tm:137-144). */

@@ -70,7 +70,8 @@ _SIGS = {
     "pvae_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "pvae_comm_destroy": (C.c_int, [_P]),
     "pvae_allreduce_grads": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
-    "pvae_dp_train_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P, _P]),
+    "pvae_dp_train_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P,
+                                     C.c_int64, C.c_int32, _P]),
     "pvae_train_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P,
                                   _P]),
     "pvae_train_step_prefetch": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P,

@@ -1275,6 +1275,8 @@ int pvae_adam(pvae_ctx* c, int net_mask, const pvae_step_params* sp, void* strea
     return 0;
 }
 
+static void flip_stage_panels(pvae_ctx* c);
+
 // ---- data-parallel exchange inside the library ---------------------------------------------
 int pvae_comm_unique_id(void* id128) {
     if (!id128) return fail(-1, "null id buffer");
@@ -1323,7 +1325,7 @@ int pvae_allreduce_grads(pvae_ctx* c, int64_t offset, int64_t count, void* strea
 }
 
 int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t rows, const pvae_step_params* sp,
-                       const float* eps, float* loss_out, void* stream) {
+                       const float* eps, float* loss_out, int64_t next_first, int32_t next_rows, void* stream) {
     int rc = check_ready(c, true);
     if (rc) return rc;
     if (!c->comm) return fail(-2, "no communicator (pvae_comm_init)");
@@ -1344,7 +1346,21 @@ int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t row
         }
         return 0;
     }
-    if ((rc = pvae_gather(c, first_window, rows, stream))) return rc;
+    // gather prefetch as in pvae_train_step_prefetch: this rank's next shard rides in the last launch
+    const bool can = c->W.L == 1 && c->pair_launch && loss_out != nullptr && c->states != nullptr;
+    if (can && c->pf.valid && c->pf.first == first_window && c->pf.rows == rows && c->pf.states == c->states) {
+        flip_stage_panels(c);
+        c->staged_rows = rows;
+        c->staged_rows_f = rows;
+    } else if ((rc = pvae_gather(c, first_window, rows, stream))) {
+        return rc;
+    }
+    c->pf.valid = false;
+    c->next_stage.rows_pad = 0;
+    c->next_carried = false;
+    if (can && next_rows > 0 && next_rows <= c->L.cfg.max_batch && next_first >= 0 &&
+        next_first + next_rows <= c->n_windows)
+        c->next_stage = stage_args(c, next_first, nullptr, nullptr, next_rows, true, 1, true);
     if ((rc = check_step(c, phase, rows, sp, true, false))) return rc;
     StepShape S;
     if ((rc = step_shape(c, phase, rows, sp, loss_out, true, S))) return rc;
@@ -1356,14 +1372,19 @@ int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t row
     // (no cross-stream hand-off) and Adam follows.  In the joint phase the decoder's reduction
     // is queued before the encoder's backward launches and runs ahead of them in stream order.
     for (Stage& s : plan) {
-        if ((rc = s.run())) return rc;
+        if ((rc = s.run())) break;
         if (s.ready_cnt > 0 && s.net >= 0 && s.ready_off == c->L.net[s.net].off) {
             const NetLayout& N = c->L.net[s.net];
-            if ((rc = pvae_allreduce_grads(c, N.off, N.count, stream))) return rc;
-            if ((rc = pvae_adam_segment(c, s.net, N.off, N.count, sp, stream))) return rc;
+            if ((rc = pvae_allreduce_grads(c, N.off, N.count, stream))) break;
+            if ((rc = pvae_adam_segment(c, s.net, N.off, N.count, sp, stream))) break;
         }
     }
-    return 0;
+    if (!rc && c->next_carried) {
+        c->pf.valid = true; c->pf.first = next_first; c->pf.rows = next_rows; c->pf.states = c->states;
+    }
+    c->next_stage.rows_pad = 0;
+    c->next_carried = false;
+    return rc;
 }
 
 int pvae_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t rows, const pvae_step_params* sp,

@@ -255,14 +255,15 @@ class HipEngine:
         self._need_gpu()
         _lib.check(self.lib.pvae_allreduce_grads(self.ctx, int(off), int(cnt), self._stream()), "pvae_allreduce_grads")
 
-    def dp_train_step(self, phase, first_window, rows, sp, eps=None, loss_out=None):
+    def dp_train_step(self, phase, first_window, rows, sp, eps=None, loss_out=None, next_span=None):
         self._need_gpu()
+        nf, nr = (int(next_span[0]), int(next_span[1])) if next_span is not None else (0, 0)
         if eps is not None and rows:
             eps = self._eps(eps, rows)
         out = self._loss_scratch if loss_out is None else loss_out
         _lib.check(self.lib.pvae_dp_train_step(
             self.ctx, phase, int(first_window), int(rows), C.byref(sp),
-            eps.data_ptr() if (eps is not None and rows) else None, out.data_ptr(), self._stream()),
+            eps.data_ptr() if (eps is not None and rows) else None, out.data_ptr(), nf, nr, self._stream()),
             "pvae_dp_train_step")
         return out
 

@@ -247,7 +247,9 @@ class TrainModel(tune.Trainable):
                 eng.train_step(phase, first, rows, sp, eps=eps, loss_out=out[g],
                                next_span=nxt if self.prefetch_gather else None)
             else:
-                self.dp_step(phase, nets, first, rows, sp, eps, out[g])
+                g2 = g + 1 if g + 1 < n_glob else 0           # this rank's shard of the following step
+                nfirst, nrows, _ = dp.shard(g2, len(loader.dataset), loader.batch_size)
+                self.dp_step(phase, nets, first, rows, sp, eps, out[g], next_span=(nfirst, nrows))
             if train:
                 self.optimizer.step()             # bookkeeping only (scheduler call order)
             self.global_batch += 1
@@ -255,7 +257,7 @@ class TrainModel(tune.Trainable):
             dp.all_reduce(out)
         return out[:n_glob].cpu()                 # the single host sync of the epoch
 
-    def dp_step(self, phase, nets, first, rows, sp, eps, loss_out):
+    def dp_step(self, phase, nets, first, rows, sp, eps, loss_out, next_span=None):
         """One data-parallel optimizer step.  The backward pass is issued launch by launch; the
         slices of the gradient arena it finishes (one per layer, last layer first, adjacent in the
         arena) are merged into buckets, and each bucket is SUM-all-reduced asynchronously as soon as
@@ -270,7 +272,8 @@ class TrainModel(tune.Trainable):
         one rank through RCCL: 5 collectives per step 206 us, 1 per step see DESIGN.md)."""
         eng, dp = self.engine, self.dp
         if eng.has_comm:                          # whole step inside the library (RCCL, one stream)
-            eng.dp_train_step(phase, first, rows, sp, eps=eps, loss_out=loss_out)
+            eng.dp_train_step(phase, first, rows, sp, eps=eps, loss_out=loss_out,
+                              next_span=next_span if self.prefetch_gather else None)
             return
         if not rows:                              # empty shard of a ragged last global batch
             seg = eng.segment(eng.grads, nets)
