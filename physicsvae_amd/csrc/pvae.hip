@@ -137,6 +137,7 @@ struct pvae_ctx {
     struct { bool valid = false; int64_t first = 0; int rows = 0; const float* states = nullptr; } pf;
     StageArgs next_stage;        // rows_pad > 0: pending for the last launch of this step
     bool next_carried = false;   // set by the launch that took it
+    bool seed_pads_clean = false;  // pad columns of the seed panels zeroed (see plan_backward)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -462,9 +463,32 @@ typedef std::vector<Stage> Plan;
 //     dgrad_L | dgrad_{L-1} + wgrad_L | ... | dgrad_1 + wgrad_2 | [dgrad_0] + wgrad_1 | wgrad_0
 // (without an input gradient the two last weight gradients share a launch).  `fold` (optional)
 // is executed by the blocks of the last launch.
+// What the input-gradient launch of a stack's FIRST layer does with its result (lookahead 1):
+// nothing special (store the panel), or form the gradient seed of the stack that produced those
+// input columns in its epilogue (pvae_gemm.h: EpiActionSeed / EpiSamplerSeed).
+struct InputSeed {
+    int kind = 0;                      // 0 none, 1 action seed (world model -> decoder), 2 sampler seed (decoder -> encoder)
+    EpiActionSeed a;
+    EpiSamplerSeed s;
+};
+// A weight-gradient launch handed from one stack's plan to the next one's first input-gradient
+// launch, so the two go out as ONE horizontally fused launch across the stack boundary.
+struct DgradArgs {
+    const float* dZ; int ldz; const float* W; int ldw; const float* mask; int ldm; float* dX; int ldo;
+    int M, Kin, Nd;
+    double flops;
+};
+struct CarriedWgrad {
+    bool valid = false;
+    std::function<int(const DgradArgs&)> run_with_dgrad;
+    int64_t ready_off = 0, ready_cnt = 0;
+    int net = -1;
+};
+
 static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool input_grad,
                               const pvae_step_params* sp, bool fused, hipStream_t st, const LossFinal* fold,
-                              Plan& plan) {
+                              Plan& plan, const InputSeed* seed = nullptr, CarriedWgrad* carry_out = nullptr,
+                              const CarriedWgrad* carry_in = nullptr) {
     const NetLayout* N = &c->L.net[n];
     const NetWork* w = &c->W.net[n];
     const AdamScalars as = adam_scalars(sp, n);
@@ -475,6 +499,8 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
     LossFinal foldv;
     memset(&foldv, 0, sizeof(foldv));
     if (fold) foldv = *fold;
+    InputSeed seedv;
+    if (seed) seedv = *seed;
 
     auto has_dgrad = [=](int i) { return i > 0 || input_grad; };
     auto seg_of = [=](int lo, int hi, Stage& s) {       // layers lo..hi (lo <= hi) of this net
@@ -487,8 +513,16 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
         const Layer& l = N->layers[i];
         const float* xin = i == 0 ? c->ws + w->in : c->ws + w->act[i - 1];
         const int ps = g_prof.begin(1, 2.0 * rowsf * (i > 0 ? l.n_in : need) * l.n_out, st);
-        HIP_TRY(gemm_dgrad(c->ws + w->dz[i], l.n_out_pad, c->params + l.w_off, l.ld, i > 0 ? xin : nullptr, l.ld,
-                           i > 0 ? c->ws + w->dz[i - 1] : c->ws + w->d_in, l.ld, rows_pad, l.ld, l.n_out_pad, st));
+        if (i == 0 && seedv.kind == 1) {
+            HIP_TRY(gemm_dgrad_epi(c->ws + w->dz[0], l.n_out_pad, c->params + l.w_off, l.ld, rows_pad, l.ld, l.n_out_pad,
+                                   seedv.a, st));
+        } else if (i == 0 && seedv.kind == 2) {
+            HIP_TRY(gemm_dgrad_epi(c->ws + w->dz[0], l.n_out_pad, c->params + l.w_off, l.ld, rows_pad, l.ld, l.n_out_pad,
+                                   seedv.s, st));
+        } else {
+            HIP_TRY(gemm_dgrad(c->ws + w->dz[i], l.n_out_pad, c->params + l.w_off, l.ld, i > 0 ? xin : nullptr, l.ld,
+                               i > 0 ? c->ws + w->dz[i - 1] : c->ws + w->d_in, l.ld, rows_pad, l.ld, l.n_out_pad, st));
+        }
         g_prof.end(ps, st);
         return 0;
     };
@@ -514,9 +548,16 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
                 const float* dx_in = j == 0 ? c->ws + w->in : c->ws + w->act[j - 1];
                 const int pp = g_prof.begin(3, 2.0 * rowsf * ((double)l.n_in * l.n_out +
                                                (double)(j > 0 ? d.n_in : need) * d.n_out), st);
-                HIP_TRY(gemm_bwd_pair(c->ws + w->dz[j], d.n_out_pad, c->params + d.w_off, d.ld, j > 0 ? dx_in : nullptr,
-                                      d.ld, j > 0 ? c->ws + w->dz[j - 1] : c->ws + w->d_in, d.ld, rows_pad, d.ld,
-                                      d.n_out_pad, dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
+                if (j == 0 && seedv.kind == 2) {
+                    HIP_TRY(gemm_bwd_pair_epi(c->ws + w->dz[0], d.n_out_pad, c->params + d.w_off, d.ld, rows_pad, d.ld,
+                                              d.n_out_pad, seedv.s, dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld,
+                                              rows_pad, e, st));
+                } else {
+                    HIP_TRY(gemm_bwd_pair(c->ws + w->dz[j], d.n_out_pad, c->params + d.w_off, d.ld,
+                                          j > 0 ? dx_in : nullptr, d.ld, j > 0 ? c->ws + w->dz[j - 1] : c->ws + w->d_in,
+                                          d.ld, rows_pad, d.ld, d.n_out_pad, dz, l.n_out_pad, xin, l.ld, l.n_out_pad,
+                                          l.ld, rows_pad, e, st));
+                }
                 g_prof.end(pp, st);
             } else {
                 const int pw = g_prof.begin(2, 2.0 * rowsf * l.n_in * l.n_out, st);
@@ -564,7 +605,21 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
         }
         return;
     }
-    if (has_dgrad(last)) push([=] { return dgrad(last); });
+    if (has_dgrad(last)) {
+        if (carry_in && carry_in->valid) {
+            // the previous stack's trailing weight gradient rides with this stack's first input gradient
+            const CarriedWgrad cw = *carry_in;
+            const Layer& l = N->layers[last];
+            DgradArgs da{c->ws + w->dz[last], l.n_out_pad, c->params + l.w_off, l.ld,
+                         last > 0 ? c->ws + w->act[last - 1] : nullptr, l.ld,
+                         last > 0 ? c->ws + w->dz[last - 1] : c->ws + w->d_in, l.ld, rows_pad, l.ld, l.n_out_pad,
+                         2.0 * rowsf * l.n_in * l.n_out};
+            Stage& sref = push([=] { return cw.run_with_dgrad(da); });
+            sref.ready_off = cw.ready_off; sref.ready_cnt = cw.ready_cnt; sref.net = cw.net;
+        } else {
+            push([=] { return dgrad(last); });
+        }
+    }
     for (int i = last; i >= 0; --i) {
         const int j = i - 1;                       // dgrad_{i-1} rides with wgrad_i
         if (j >= 0 && has_dgrad(j)) {
@@ -574,6 +629,29 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
             const bool f = fold != nullptr;
             seg_of(0, 1, push([=] { return wgrad_pair10(f); }));
             return;
+        } else if (i == 0 && carry_out && !fold) {
+            // hand the lone trailing weight gradient to the next stack's plan
+            const Layer& l = N->layers[0];
+            const float* dz = c->ws + w->dz[0];
+            const float* xin = c->ws + w->in;
+            carry_out->valid = true;
+            carry_out->ready_off = l.w_off;
+            carry_out->ready_cnt = l.b_off + l.n_out_pad - l.w_off;
+            carry_out->net = n;
+            carry_out->run_with_dgrad = [=](const DgradArgs& d) -> int {
+                const int pp = g_prof.begin(3, d.flops + 2.0 * rowsf * l.n_in * l.n_out, st);
+                hipError_t he;
+                if (fused) {
+                    he = gemm_bwd_pair(d.dZ, d.ldz, d.W, d.ldw, d.mask, d.ldm, d.dX, d.ldo, d.M, d.Kin, d.Nd, dz,
+                                       l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, adam_epi(l), st);
+                } else {
+                    he = gemm_bwd_pair(d.dZ, d.ldz, d.W, d.ldw, d.mask, d.ldm, d.dX, d.ldo, d.M, d.Kin, d.Nd, dz,
+                                       l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, store_epi(l), st);
+                }
+                g_prof.end(pp, st);
+                if (he != hipSuccess) return fail(-10, "gemm_bwd_pair: %s", hipGetErrorString(he));
+                return 0;
+            };
         } else {
             const bool f = fold && i == 0;
             seg_of(i, i, push([=] { return wgrad(i, -1, f); }));
@@ -694,6 +772,7 @@ int pvae_bind_workspace(pvae_ctx* c, void* workspace, size_t bytes) {
     if (bytes < (size_t)c->W.total_floats * sizeof(float))
         return fail(-1, "workspace too small: %zu < %zu", bytes, (size_t)c->W.total_floats * sizeof(float));
     c->ws = (float*)workspace;
+    c->seed_pads_clean = false;
     return 0;
 }
 
@@ -766,6 +845,7 @@ int pvae_set_batch(pvae_ctx* c, const float* x, const float* y, int32_t rows, vo
 // Everything a step needs that is a pure function of (phase, rows, step params).
 struct StepShape {
     int rows_pad, wm_tiles, gridz, nparts_a;
+    bool seed_action, seed_sampler;   // stack hand-overs fused into input-gradient epilogues (plan_backward)
     int l1;                    // loss_kind of the three reconstruction terms
     float gs;                  // d(mean loss)/d(residual) factor: 2 for MSE, 1 for L1
     float Bg;
@@ -789,6 +869,8 @@ static int step_shape(pvae_ctx* c, int phase, int rows, const pvae_step_params* 
     S.nparts_a = S.rows_pad < 64 ? S.rows_pad : 64;
     S.cyc_grad = backward && phase == PVAE_PHASE_JOINT && sp->cycle_coeff > 0.0f;
     S.kl_active = phase == PVAE_PHASE_JOINT && sp->kl_coeff > 0.0f && sp->a_rec_coeff > 0.0f;   // tpv:381-384
+    S.seed_sampler = backward && phase == PVAE_PHASE_JOINT && c->W.L == 1 && c->pair_launch;
+    S.seed_action = S.seed_sampler && S.cyc_grad;
     float* part = c->ws + c->W.loss_part;
     memset(&S.lf, 0, sizeof(S.lf));
     for (int t = 0; t < 4; ++t) S.lf.part[t] = part + (t + 1) * kLossParts;
@@ -800,7 +882,8 @@ static int step_shape(pvae_ctx* c, int phase, int rows, const pvae_step_params* 
     if (phase == PVAE_PHASE_WORLD) {
         S.lf.nparts[2] = S.wm_tiles * T;
     } else {
-        if (sp->a_rec_coeff > 0.0f) S.lf.nparts[0] = S.nparts_a * T;
+        if (sp->a_rec_coeff > 0.0f)
+            S.lf.nparts[0] = S.seed_action ? (S.rows_pad / 32) * (c->L.net[PVAE_NET_WM].layers[0].ld / 32) : S.nparts_a * T;
         if (S.kl_active) S.lf.nparts[1] = S.gridz * T;
         if (sp->cycle_coeff > 0.0f) S.lf.nparts[3] = S.wm_tiles * T;
     }
@@ -856,6 +939,13 @@ static int run_forward(pvae_ctx* c, int phase, int rows, const pvae_step_params*
         mse.partial = part + 3 * kLossParts;
         return forward_net(c, PVAE_NET_WM, S.rows_pad, st, wm_tail);
     }
+    if (!c->seed_pads_clean) {
+        // the seed epilogues (plan_backward) write only the real columns of these two gradient
+        // panels; their pad columns must be zero and nothing else ever writes them
+        HIP_TRY(hipMemsetAsync(w + wmd.dz.back(), 0, (size_t)c->W.Bp * MD.layers.back().n_out_pad * sizeof(float), st));
+        HIP_TRY(hipMemsetAsync(w + wte.dz.back(), 0, (size_t)c->W.Bp * TE.layers.back().n_out_pad * sizeof(float), st));
+        c->seed_pads_clean = true;
+    }
     // joint forward: TE -> sampler -> MD -> WM (rmt:742-771)
     if ((rc = forward_net(c, PVAE_NET_TE, S.rows_pad, st))) return rc;
     hipLaunchKernelGGL(reparam_kernel, dim3(S.gridz), dim3(256), 0, st, w + wte.act.back(),
@@ -894,11 +984,28 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
     const NetWork* wte = &c->W.net[PVAE_NET_TE];
     const NetWork* wmd = &c->W.net[PVAE_NET_MD];
     const NetWork* wwm = &c->W.net[PVAE_NET_WM];
-    if (S.cyc_grad)                            // gradient through the frozen world model (dgrad only)
-        plan_backward_net(c, PVAE_NET_WM, S.rows_pad, false, true, sp, fused, st, nullptr, plan);
+    const int ldo_md = MD->layers.back().n_out_pad, ldo_te = TE->layers.back().n_out_pad;
+    const float ga = sp->a_rec_coeff * S.gs / (S.Bg * Da);
+    // The two gradient hand-overs between stacks live in the epilogue of the consuming stack's
+    // first-layer input-gradient launch (InputSeed) whenever that launch exists and runs the paired
+    // schedule; otherwise the stand-alone glue kernels do the same arithmetic.
+    const bool seed_action = S.seed_action, seed_sampler = S.seed_sampler;
+    if (S.cyc_grad) {                          // gradient through the frozen world model (dgrad only)
+        InputSeed sd;
+        if (seed_action) {
+            sd.kind = 1;
+            memset(&sd.a, 0, sizeof(sd.a));
+            sd.a.pred = w + wmd->act.back(); sd.a.ldp = ldo_md;
+            sd.a.target = w + c->W.act_t; sd.a.ldt = pad64(Da);
+            sd.a.dz = w + wmd->dz.back(); sd.a.ldz = ldo_md;
+            sd.a.c0 = Db; sd.a.n = Da; sd.a.rows = rows;
+            sd.a.grad_scale = ga; sd.a.l1 = S.l1;
+            sd.a.partial = part + 1 * kLossParts;
+        }
+        plan_backward_net(c, PVAE_NET_WM, S.rows_pad, false, true, sp, fused, st, nullptr, plan, &sd);
+    }
     // action reconstruction (tpv:381-382) + gradient arriving through the world model
-    {
-        const float ga = sp->a_rec_coeff * S.gs / (S.Bg * Da);
+    if (!seed_action) {
         const int nparts = S.nparts_a, rows_pad = S.rows_pad, l1 = S.l1;
         const bool cyc = S.cyc_grad;
         plan.emplace_back();
@@ -913,9 +1020,21 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
         };
     }
     if (!backward) return;
-    plan_backward_net(c, PVAE_NET_MD, S.rows_pad, true, true, sp, fused, st, nullptr, plan);
-    {
-        const float kls = S.kl_active ? sp->kl_coeff / S.Bg : 0.0f;
+    const float kls = S.kl_active ? sp->kl_coeff / S.Bg : 0.0f;
+    InputSeed ss;
+    if (seed_sampler) {
+        ss.kind = 2;
+        memset(&ss.s, 0, sizeof(ss.s));
+        ss.s.te_out = w + wte->act.back(); ss.s.ldte = ldo_te;
+        ss.s.eps = w + c->W.eps;
+        ss.s.dz = w + wte->dz.back(); ss.s.ldz = ldo_te;
+        ss.s.c0 = Db; ss.s.Z = Z; ss.s.rows = rows;
+        ss.s.kl_scale = kls;
+    }
+    CarriedWgrad carry;
+    plan_backward_net(c, PVAE_NET_MD, S.rows_pad, true, true, sp, fused, st, nullptr, plan, &ss,
+                      seed_sampler ? &carry : nullptr);
+    if (!seed_sampler) {
         const int rows_pad = S.rows_pad;
         const int tot = rows_pad * TE->layers.back().n_out_pad;
         plan.emplace_back();
@@ -927,7 +1046,7 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
             return 0;
         };
     }
-    plan_backward_net(c, PVAE_NET_TE, S.rows_pad, true, false, sp, fused, st, fold, plan);
+    plan_backward_net(c, PVAE_NET_TE, S.rows_pad, true, false, sp, fused, st, fold, plan, nullptr, nullptr, &carry);
 }
 
 

@@ -936,6 +936,75 @@ struct EpiMask {              // input gradient: out = acc * (act > 0)
     __device__ inline void finish(float*, int, int) const {}
 };
 
+// Input gradient of the WORLD MODEL's first layer (joint phase): its columns [c0, c0+n) are
+// d(loss)/d(a_hat) arriving through the frozen world model (cycle loss, tpv:417-419).  Instead of
+// storing the panel for a separate kernel, this epilogue forms the motor decoder's output gradient
+// right here (tpv:381-382 + chain rule):
+//     dz[q][c] = grad_scale * f(a_hat[q][c] - a[q][c]) + acc[q][c0+c]        (f: MSE d, L1 sign d)
+// and the action-reconstruction loss partial of its workgroup.  The other columns (gradient wrt the
+// state) have no consumer at lookahead 1 and are not stored.  Rows >= `rows` get zeros.
+struct EpiActionSeed {
+    const float* pred;  int ldp;      // a_hat: motor decoder output
+    const float* target; int ldt;     // demonstrated action
+    float* dz; int ldz;               // -> gradient wrt the decoder's output layer
+    int c0, n, rows;
+    float grad_scale;
+    int l1;
+    float* partial;
+    float sq = 0.f;
+    __device__ inline void operator()(int q, int p, v4f v) {
+        if (p + 3 < c0 || p >= c0 + n) return;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = p + e - c0;
+            if (c < 0 || c >= n) continue;
+            float g = 0.f;
+            if (q < rows) {
+                const float d = pred[(size_t)q * ldp + c] - target[(size_t)q * ldt + c];
+                sq += l1 ? fabsf(d) : d * d;
+                g = grad_scale * (l1 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : d) + v[e];
+            }
+            dz[(size_t)q * ldz + c] = g;
+        }
+    }
+    __device__ inline void finish(float* scratch, int tile, int tid) {
+        const float s = block_sum_256(sq, scratch);
+        if (tid == 0) partial[tile] = s;
+    }
+};
+
+// Input gradient of the MOTOR DECODER's first layer: its columns [c0, c0+Z) are d(loss)/dz.  This
+// epilogue is the backward of the sampler + KL (autograd of rmt:734-740 and tpv:388) and writes the
+// task encoder's output gradient directly:
+//     dmu = dz + (beta/B) mu ;  dlogvar = dz * eps * 0.5 exp(0.5 lv) + (beta/B) 0.5 (exp(lv) - 1)
+// Nothing else of the panel has a consumer at lookahead 1.
+struct EpiSamplerSeed {
+    const float* te_out; int ldte;    // [mu | logvar]
+    const float* eps;                 // [rows_pad][Z] draws actually used
+    float* dz; int ldz;               // -> gradient wrt the encoder's output layer [.. | dmu | dlogvar]
+    int c0, Z, rows;
+    float kl_scale;
+    __device__ inline void operator()(int q, int p, v4f v) const {
+        if (p + 3 < c0 || p >= c0 + Z) return;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = p + e - c0;
+            if (j < 0 || j >= Z) continue;
+            float gm = 0.f, gl = 0.f;
+            if (q < rows) {
+                const float mu = te_out[(size_t)q * ldte + j];
+                const float lv = te_out[(size_t)q * ldte + Z + j];
+                const float ep = eps[(size_t)q * Z + j];
+                gm = v[e] + kl_scale * mu;
+                gl = v[e] * ep * 0.5f * expf(0.5f * lv) + kl_scale * 0.5f * (expf(lv) - 1.0f);
+            }
+            dz[(size_t)q * ldz + j] = gm;
+            dz[(size_t)q * ldz + Z + j] = gl;
+        }
+    }
+    __device__ inline void finish(float*, int, int) const {}
+};
+
 struct AdamScalars {
     float step_size;          // lr / (1 - beta1^t)
     float inv_bc2_sqrt;       // 1 / sqrt(1 - beta2^t)
@@ -1089,6 +1158,16 @@ inline hipError_t gemm_dgrad(const float* dZ, int ldz, const float* W, int ldw, 
                        GemmArgs{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
     return hipGetLastError();
 }
+// same contraction with a caller-supplied epilogue (gradient seeds of the producing stack)
+template <class EpiD>
+inline hipError_t gemm_dgrad_epi(const float* dZ, int ldz, const float* W, int ldw, int M, int Kin, int N,
+                                 const EpiD& e, hipStream_t st) {
+    const GemmGrid g = make_grid(M, Kin, 32, 32);
+    hipLaunchKernelGGL((gemm_splitk_ws_kernel<false, EpiD>), dim3(g.grid), dim3(512), 0, st,
+                       GemmArgs{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+    return hipGetLastError();
+}
+inline int dgrad_tiles(int M, int Kin) { return make_grid(M, Kin, 32, 32).grid; }
 // wgrad: G[N][Kin] = dZ[M][N]^T X[M][Kin]  (+ bias gradient, + optional loss finalisation)
 template <class Epi>
 inline hipError_t gemm_wgrad(const float* dZ, int ldz, const float* X, int ldx, int N, int Kin, int M,
@@ -1115,18 +1194,24 @@ inline hipError_t gemm_wgrad_pair(const float* dZ1, int ldz1, const float* X1, i
     return hipGetLastError();
 }
 // one launch: dX'[M][Kin'] = (dZ'[M][N'] W'[N'][Kin']) .* mask   ||   G[N][Kin] = dZ[M][N]^T X[M][Kin]
+template <class EpiD, class EpiW>
+inline hipError_t gemm_bwd_pair_epi(const float* dZd, int ldzd, const float* Wd, int ldwd, int Md, int Kind, int Nd,
+                                    const EpiD& ed, const float* dZw, int ldzw, const float* Xw, int ldxw, int Nw,
+                                    int Kinw, int Mw, const EpiW& ew, hipStream_t st) {
+    const GemmGrid g1 = make_grid(Md, Kind, 32, 32);
+    const GemmGrid g2 = make_grid(Nw, Kinw, 64, 64);
+    hipLaunchKernelGGL((bwd_pair_kernel<EpiD, EpiW>), dim3(g1.grid + g2.grid), dim3(256), 0, st,
+                       GemmArgs{dZd, ldzd, Wd, ldwd, Nd, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, g1.grid,
+                       GemmArgs{dZw, ldzw, Xw, ldxw, Mw, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, ew);
+    return hipGetLastError();
+}
 template <class EpiW>
 inline hipError_t gemm_bwd_pair(const float* dZd, int ldzd, const float* Wd, int ldwd, const float* mask, int ldm,
                                 float* dXd, int ldod, int Md, int Kind, int Nd,
                                 const float* dZw, int ldzw, const float* Xw, int ldxw, int Nw, int Kinw, int Mw,
                                 const EpiW& ew, hipStream_t st) {
     const EpiMask ed{dXd, ldod, mask, ldm};
-    const GemmGrid g1 = make_grid(Md, Kind, 32, 32);
-    const GemmGrid g2 = make_grid(Nw, Kinw, 64, 64);
-    hipLaunchKernelGGL((bwd_pair_kernel<EpiMask, EpiW>), dim3(g1.grid + g2.grid), dim3(256), 0, st,
-                       GemmArgs{dZd, ldzd, Wd, ldwd, Nd, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, g1.grid,
-                       GemmArgs{dZw, ldzw, Xw, ldxw, Mw, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, ew);
-    return hipGetLastError();
+    return gemm_bwd_pair_epi(dZd, ldzd, Wd, ldwd, Md, Kind, Nd, ed, dZw, ldzw, Xw, ldxw, Nw, Kinw, Mw, ew, st);
 }
 
 }  // namespace pvae

@@ -461,6 +461,30 @@ def test_argument_errors_are_loud_and_leave_the_ctx_usable(golden):
     assert float(loss[0]) == pytest.approx(float(g["joint_total"]), rel=1e-5)
 
 
+def test_unfused_launch_schedule_agrees(golden, monkeypatch):
+    """PVAE_PAIR=0 runs every contraction as its own launch and the stack hand-overs (action-loss
+    gradient, sampler backward) as stand-alone kernels; the default schedule fuses them (paired
+    launches, seed epilogues, cross-stack pair).  Same arithmetic, different launch structure:
+    losses and every gradient agree to fp32 summation-order noise."""
+    g, arch, data, x, y, sd, eps, tr = _setup_single(golden, "single_c1")
+    rows = x.shape[0]
+    monkeypatch.setenv("PVAE_PAIR", "0")
+    tr2 = make_trainer(arch, data, rows, device=DEV)
+    monkeypatch.delenv("PVAE_PAIR")
+    tr2.model.load_state_dict(sd)
+    for phase, world, nets in ((_lib.PHASE_WORLD, True, [_lib.NET_WM]), (_lib.PHASE_JOINT, False, [_lib.NET_TE, _lib.NET_MD])):
+        c = R.phase_coeffs(world)
+        sp = make_step_params(lr=5e-4, a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"], s_rec=c["s_rec_coeff"],
+                              cyc=c["vae_cycle_coeff"], global_rows=rows)
+        out = []
+        for t in (tr, tr2):
+            t.engine.set_batch(x, y)
+            loss = t.engine.forward_backward(phase, rows, sp, eps=eps, fused_adam=False).clone()
+            out.append((loss.cpu(), t.engine.segment(t.engine.grads, nets).clone().cpu()))
+        assert torch.allclose(out[0][0], out[1][0], rtol=2e-6, atol=1e-9)
+        assert max_err_scaled(out[0][1], out[1][1]) < 2e-6
+
+
 def test_step_is_deterministic(golden):
     g, arch, data, x, y, sd, eps, tr = _setup_single(golden, "single_c1")
     eng = tr.engine
