@@ -265,53 +265,63 @@ __device__ inline void splitk_reg_body(float* lds, int bid, const GemmArgs& ga, 
     if (D < nk) gload(D, rg[0]);
     __syncthreads();
 
-    for (int t0 = 0; t0 < nk; t0 += D) {
+    // one k-tile; see wgrad_reg_body for why the full groups are branch-free (exact vmcnt: the
+    // three younger register sets stay in flight across the LDS write of the oldest)
+    auto tile_step = [&](int t, int d, bool guarded) {
+        const float* st = lds + (t & 1) * kStage;
+        v4f fq[2], fp[2];
+        v2f fc[4];
+        if (ABL & 2) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int t = t0 + d;
-            if (t < nk) {
-                const float* st = lds + (t & 1) * kStage;
-                v4f fq[2], fp[2];
-                v2f fc[4];
-                if (ABL & 2) {
+            for (int a = 0; a < 2; ++a) { fq[a] = v4f{1.f, 2.f, 3.f, 4.f} * (float)lane; fp[a] = fq[a] + 1.f; }
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) { fq[a] = v4f{1.f, 2.f, 3.f, 4.f} * (float)lane; fp[a] = fq[a] + 1.f; }
+            for (int s2 = 0; s2 < 4; ++s2) fc[s2] = v2f{1.f + s2, 2.f} * (float)lane;
+            asm volatile("" : "+v"(fq[0]), "+v"(fq[1]), "+v"(fp[0]), "+v"(fp[1]));
+        } else {
 #pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2) fc[s2] = v2f{1.f + s2, 2.f} * (float)lane;
-                    asm volatile("" : "+v"(fq[0]), "+v"(fq[1]), "+v"(fp[0]), "+v"(fp[1]));
-                } else {
+            for (int a = 0; a < 2; ++a) fq[a] = *reinterpret_cast<const v4f*>(st + oq[a]);
+            if (P_ROW) {
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) fq[a] = *reinterpret_cast<const v4f*>(st + oq[a]);
-                    if (P_ROW) {
+                for (int b = 0; b < 2; ++b) fp[b] = *reinterpret_cast<const v4f*>(st + kTile + oq[b]);
+            } else {
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) fp[b] = *reinterpret_cast<const v4f*>(st + kTile + oq[b]);
-                    } else {
-#pragma unroll
-                        for (int s2 = 0; s2 < 4; ++s2)
-                            fc[s2] = *reinterpret_cast<const v2f*>(st + kTile + (((kq + s2) ^ (lh & 1)) * 32) + 2 * li);
-                    }
-                }
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            const float pv = P_ROW ? fp[b][s2] : fc[s2][b];
-                            if (ABL & 4) acc[a][b][0] += pv * fq[a][s2];
-                            else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, fq[a][s2], acc[a][b], 0, 0, 0);
-                        }
-                    if (s2 == 1 && !(ABL & 1) && t + 1 < nk) {
-                        // tile t+1 sits in register set (d+1)%D: park it in the other LDS slot and
-                        // refill the registers with tile t+1+D
-                        lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
-                        if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D]);
-                    }
-                }
-                if (!(ABL & 8)) __syncthreads();
+                for (int s2 = 0; s2 < 4; ++s2)
+                    fc[s2] = *reinterpret_cast<const v2f*>(st + kTile + (((kq + s2) ^ (lh & 1)) * 32) + 2 * li);
             }
         }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float pv = P_ROW ? fp[b][s2] : fc[s2][b];
+                    if (ABL & 4) acc[a][b][0] += pv * fq[a][s2];
+                    else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, fq[a][s2], acc[a][b], 0, 0, 0);
+                }
+            if (s2 == 1 && !(ABL & 1)) {
+                // tile t+1 sits in register set (d+1)%D: park it in the other LDS slot and
+                // refill the registers with tile t+1+D
+                if (!guarded) {
+                    lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
+                    const int tn = t + 1 + D < nk ? t + 1 + D : nk - 1;
+                    gload(tn, rg[(d + 1) % D]);
+                } else if (t + 1 < nk) {
+                    lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
+                    if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D]);
+                }
+            }
+        }
+        if (!(ABL & 8)) __syncthreads();
+    };
+    int t0 = 0;
+    for (; t0 + D <= nk; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) tile_step(t0 + d, d, false);
     }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (t0 + d < nk) tile_step(t0 + d, d, true);
 
     constexpr int RS = 36;
     float* red = lds + wave * (32 * RS);
@@ -634,26 +644,36 @@ __device__ inline void splitk_reg16_body(float* lds, int bid, const GemmArgs& ga
     if (D < nk) gload(D, rg[0]);
     __syncthreads();
 
-    for (int t0 = 0; t0 < nk; t0 += D) {
+    // (full groups of D tiles are branch-free so that the compiler counts the outstanding loads
+    // exactly -- see wgrad_reg_body)
+    auto tile_step = [&](int t, int d, bool guarded) {
+        const float* st = lds + (t & 1) * kStage;
+        const v4f fq = *reinterpret_cast<const v4f*>(st + of);
+        const v4f fp = *reinterpret_cast<const v4f*>(st + kTile + of);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int t = t0 + d;
-            if (t < nk) {
-                const float* st = lds + (t & 1) * kStage;
-                const v4f fq = *reinterpret_cast<const v4f*>(st + of);
-                const v4f fp = *reinterpret_cast<const v4f*>(st + kTile + of);
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-                    acc[s2 & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[s2], fq[s2], acc[s2 & 1], 0, 0, 0);
-                    if (s2 == 1 && t + 1 < nk) {
-                        lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
-                        if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D]);
-                    }
+        for (int s2 = 0; s2 < 4; ++s2) {
+            acc[s2 & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[s2], fq[s2], acc[s2 & 1], 0, 0, 0);
+            if (s2 == 1) {
+                if (!guarded) {
+                    lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
+                    const int tn = t + 1 + D < nk ? t + 1 + D : nk - 1;
+                    gload(tn, rg[(d + 1) % D]);
+                } else if (t + 1 < nk) {
+                    lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
+                    if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D]);
                 }
-                __syncthreads();
             }
         }
+        __syncthreads();
+    };
+    int t0 = 0;
+    for (; t0 + D <= nk; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) tile_step(t0 + d, d, false);
     }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (t0 + d < nk) tile_step(t0 + d, d, true);
 
     // split-K reduction (fixed order) + epilogue: 64 threads x float4 cover the 16x16 tile
     constexpr int RS = 20;
@@ -753,40 +773,54 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
     }
     __syncthreads();
 
-    for (int t0 = 0; t0 < nk; t0 += D) {
+    // one k-tile: 8 steps of (2 fragment reads, 4 MFMAs); after step 3 the next tile moves from its
+    // register set into the other LDS slot and that set is refilled D tiles ahead
+    auto tile_step = [&](int t, int d, bool guarded) {
+        const float* st = lds + (t & 1) * kStage;
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int t = t0 + d;
-            if (t < nk) {
-                const float* st = lds + (t & 1) * kStage;
+        for (int kk = 0; kk < BK; kk += 4) {
+            v2f fq, fp;
+            if (ABL & 2) {
+                fq = v2f{1.f, 2.f} * (float)(lane + kk);
+                fp = v2f{3.f, 4.f} * (float)(lane + kk);
+                asm volatile("" : "+v"(fq), "+v"(fp));
+            } else {
+                fq = *reinterpret_cast<const v2f*>(st + oq + kk * 64);
+                fp = *reinterpret_cast<const v2f*>(st + op + kk * 64);
+            }
+            bsum += fq;
 #pragma unroll
-                for (int kk = 0; kk < BK; kk += 4) {
-                    v2f fq, fp;
-                    if (ABL & 2) {
-                        fq = v2f{1.f, 2.f} * (float)(lane + kk);
-                        fp = v2f{3.f, 4.f} * (float)(lane + kk);
-                        asm volatile("" : "+v"(fq), "+v"(fp));
-                    } else {
-                        fq = *reinterpret_cast<const v2f*>(st + oq + kk * 64);
-                        fp = *reinterpret_cast<const v2f*>(st + op + kk * 64);
-                    }
-                    bsum += fq;
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int a = 0; a < 2; ++a)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            if (ABL & 4) acc[a][b][0] += fp[b] * fq[a];
-                            else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[b], fq[a], acc[a][b], 0, 0, 0);
-                        }
-                    if (kk == 12 && !(ABL & 1) && t + 1 < nk) {
-                        lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
-                        if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D]);
-                    }
+                for (int b = 0; b < 2; ++b) {
+                    if (ABL & 4) acc[a][b][0] += fp[b] * fq[a];
+                    else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[b], fq[a], acc[a][b], 0, 0, 0);
                 }
-                if (!(ABL & 8)) __syncthreads();
+            if (kk == 12 && !(ABL & 1)) {
+                if (!guarded) {
+                    // branch-free: past the end this stores a stale register set into the idle slot
+                    // and re-reads the last tile -- both unused.  Without branches the compiler counts
+                    // the outstanding loads exactly (vmcnt(12): three younger sets stay in flight);
+                    // with the guards it drained the whole prefetch queue before every LDS write.
+                    lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
+                    const int tn = t + 1 + D < nk ? t + 1 + D : nk - 1;
+                    gload(tn, rg[(d + 1) % D]);
+                } else if (t + 1 < nk) {
+                    lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
+                    if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D]);
+                }
             }
         }
+        if (!(ABL & 8)) __syncthreads();
+    };
+    int t0 = 0;
+    for (; t0 + D <= nk; t0 += D) {            // full groups of D tiles: no branch inside
+#pragma unroll
+        for (int d = 0; d < D; ++d) tile_step(t0 + d, d, false);
     }
+#pragma unroll
+    for (int d = 0; d < D; ++d)                // remaining nk % D tiles
+        if (t0 + d < nk) tile_step(t0 + d, d, true);
 
     PVAE_MARK(0, 2);                                             // contraction done, epilogue (Adam) starts
 #pragma unroll
