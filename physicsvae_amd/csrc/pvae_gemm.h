@@ -259,10 +259,9 @@ __device__ inline void splitk_reg_body(float* lds, int bid, const GemmArgs& ga, 
 
     const int nk = K / BK;
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < nk) gload(d, rg[d]);
+    for (int d = 0; d < D; ++d) gload(d < nk ? d : nk - 1, rg[d]);     // (clamped, not guarded: exact vmcnt)
     lwrite(lds, rg[0]);
-    if (D < nk) gload(D, rg[0]);
+    gload(D < nk ? D : nk - 1, rg[0]);
     __syncthreads();
 
     // one k-tile; see wgrad_reg_body for why the full groups are branch-free (exact vmcnt: the
@@ -638,10 +637,9 @@ __device__ inline void splitk_reg16_body(float* lds, int bid, const GemmArgs& ga
 
     const int nk = K / BK;
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < nk) gload(d, rg[d]);
+    for (int d = 0; d < D; ++d) gload(d < nk ? d : nk - 1, rg[d]);     // (clamped, not guarded: exact vmcnt)
     lwrite(lds, rg[0]);
-    if (D < nk) gload(D, rg[0]);
+    gload(D < nk ? D : nk - 1, rg[0]);
     __syncthreads();
 
     // (full groups of D tiles are branch-free so that the compiler counts the outstanding loads
@@ -760,10 +758,9 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
 
     const int nk = K / BK;
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < nk) gload(d, rg[d]);
+    for (int d = 0; d < D; ++d) gload(d < nk ? d : nk - 1, rg[d]);     // (clamped, not guarded: exact vmcnt)
     lwrite(lds, rg[0]);
-    if (D < nk) gload(D, rg[0]);
+    gload(D < nk ? D : nk - 1, rg[0]);
     // epilogue operands: queued behind the first D tiles, they arrive while the loop runs
     typename Epi::Pre pre[2][2];
 #pragma unroll
