@@ -262,6 +262,7 @@ __device__ inline void splitk_reg_body(float* lds, int bid, const GemmArgs& ga, 
     for (int d = 0; d < D; ++d) gload(d < nk ? d : nk - 1, rg[d]);     // (clamped, not guarded: exact vmcnt)
     lwrite(lds, rg[0]);
     gload(D < nk ? D : nk - 1, rg[0]);
+    const typename Epi::Pre epre = epi.preload(q0 + (tid >> 3), p0 + ((tid & 7) << 2));   // arrives under the loop
     __syncthreads();
 
     // one k-tile; see wgrad_reg_body for why the full groups are branch-free (exact vmcnt: the
@@ -340,7 +341,7 @@ __device__ inline void splitk_reg_body(float* lds, int bid, const GemmArgs& ga, 
         v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
 #pragma unroll
         for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (32 * RS) + ql * RS + pl);
-        epi(q0 + ql, p0 + pl, v);
+        epi(q0 + ql, p0 + pl, v, epre);
     }
     epi.finish(lds, tile_q * tiles_p + tile_p, tid);
 }
@@ -402,6 +403,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
     const int li = lane & 15, lh = lane >> 4;
     const int nk = K / BK;
     PVAE_MARK(0, 0);                                             // workgroup entered
+    typename Epi::Pre epre{};
     v4f acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -507,6 +509,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
 #ifndef PVAE_WS_SLOW0
         wait_vmcnt<0>();                                           // this wave's share of tile 0 landed
 #endif
+        epre = epi.preload(q0 + (tid >> 3), p0 + ((tid & 7) << 2));   // epilogue operands: arrive under the loop
         struct Frag { v4f q[2], p[2]; v2f c[4]; };
         auto fread = [&](const float* st, Frag& f) {
 #pragma unroll
@@ -580,7 +583,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
         v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
 #pragma unroll
         for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (32 * RS) + ql * RS + pl);
-        epi(q0 + ql, p0 + pl, v);
+        epi(q0 + ql, p0 + pl, v, epre);
     }
     epi.finish(lds, tile_q * tiles_p + tile_p, tid);
     PVAE_MARK(0, 3);                                             // epilogue stores issued
@@ -685,7 +688,7 @@ __device__ inline void splitk_reg16_body(float* lds, int bid, const GemmArgs& ga
         v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
 #pragma unroll
         for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (16 * RS) + ql * RS + pl);
-        epi(q0 + ql, p0 + pl, v);
+        epi(q0 + ql, p0 + pl, v, epi.preload(q0 + ql, p0 + pl));
     }
     epi.finish(lds, tile_q * tiles_p + tile_p, tid);
 }
@@ -897,8 +900,17 @@ struct EpiBiasAct {           // forward layer: out = act(acc + bias)
     int relu;
     float* out2 = nullptr;    // optional second destination for columns [0, n2): out2[q][off2 + p]
     int ld2 = 0, off2 = 0, n2 = 0;   // (motor-decoder output -> action columns of the world-model input)
-    __device__ inline void operator()(int q, int p, v4f v) const {
-        if (bias) v += *reinterpret_cast<const v4f*>(bias + p);
+    // operands of the epilogue that do not depend on the contraction are fetched BEFORE the main
+    // loop (`preload`) and handed back at the end: their latency hides under the loop instead of
+    // sitting between the last MFMA and the stores
+    struct Pre { v4f b; };
+    __device__ inline Pre preload(int, int p) const {
+        Pre r;
+        r.b = bias ? *reinterpret_cast<const v4f*>(bias + p) : v4f{0.f, 0.f, 0.f, 0.f};
+        return r;
+    }
+    __device__ inline void operator()(int q, int p, v4f v, const Pre& pre) const {
+        v += pre.b;
         if (relu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
             v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -930,10 +942,17 @@ struct EpiMse {
     float* partial;
     int l1;                   // 0: nn.MSELoss (sum d^2, grad 2d/n), 1: nn.L1Loss (sum |d|, grad sign(d)/n)
     float sq = 0.f;
-    __device__ inline void operator()(int q, int p, v4f v) {
-        if (bias) v += *reinterpret_cast<const v4f*>(bias + p);
+    struct Pre { v4f b, t; };
+    __device__ inline Pre preload(int q, int p) const {
+        Pre r;
+        r.b = bias ? *reinterpret_cast<const v4f*>(bias + p) : v4f{0.f, 0.f, 0.f, 0.f};
+        r.t = *reinterpret_cast<const v4f*>(target + (size_t)q * ldt + p);
+        return r;
+    }
+    __device__ inline void operator()(int q, int p, v4f v, const Pre& pre) {
+        v += pre.b;
         *reinterpret_cast<v4f*>(out + (size_t)q * ldo + p) = v;
-        const v4f t = *reinterpret_cast<const v4f*>(target + (size_t)q * ldt + p);
+        const v4f t = pre.t;
         v4f g;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -956,12 +975,16 @@ struct EpiMask {              // input gradient: out = acc * (act > 0)
     int ldo;
     const float* mask;        // post-ReLU activation of the producing layer, or null
     int ldm;
-    __device__ inline void operator()(int q, int p, v4f v) const {
-        if (mask) {
-            const v4f m = *reinterpret_cast<const v4f*>(mask + (size_t)q * ldm + p);
-            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-            v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-        }
+    struct Pre { v4f m; };
+    __device__ inline Pre preload(int q, int p) const {
+        Pre r;
+        r.m = mask ? *reinterpret_cast<const v4f*>(mask + (size_t)q * ldm + p) : v4f{1.f, 1.f, 1.f, 1.f};
+        return r;
+    }
+    __device__ inline void operator()(int q, int p, v4f v, const Pre& pre) const {
+        const v4f m = pre.m;
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         *reinterpret_cast<v4f*>(out + (size_t)q * ldo + p) = v;
     }
     __device__ inline void finish(float*, int, int) const {}
@@ -983,7 +1006,9 @@ struct EpiActionSeed {
     int l1;
     float* partial;
     float sq = 0.f;
-    __device__ inline void operator()(int q, int p, v4f v) {
+    struct Pre {};
+    __device__ inline Pre preload(int, int) const { return Pre(); }
+    __device__ inline void operator()(int q, int p, v4f v, const Pre&) {
         if (p + 3 < c0 || p >= c0 + n) return;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1015,7 +1040,9 @@ struct EpiSamplerSeed {
     float* dz; int ldz;               // -> gradient wrt the encoder's output layer [.. | dmu | dlogvar]
     int c0, Z, rows;
     float kl_scale;
-    __device__ inline void operator()(int q, int p, v4f v) const {
+    struct Pre {};
+    __device__ inline Pre preload(int, int) const { return Pre(); }
+    __device__ inline void operator()(int q, int p, v4f v, const Pre&) const {
         if (p + 3 < c0 || p >= c0 + Z) return;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

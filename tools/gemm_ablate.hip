@@ -9,7 +9,7 @@
 using namespace pvae;
 static int g_pad = 0;   // extra floats of row pitch
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
-struct EpiNop { float* out; int ld; __device__ void operator()(int q, int p, v4f v) const { if (v.x == 123.456f) out[(size_t)q * ld + p] = v.y; } __device__ void finish(float*, int, int) const {} };
+struct EpiNop { float* out; int ld; struct Pre {}; __device__ Pre preload(int, int) const { return Pre(); } __device__ void operator()(int q, int p, v4f v, const Pre&) const { if (v.x == 123.456f) out[(size_t)q * ld + p] = v.y; } __device__ void finish(float*, int, int) const {} };
 
 template <int ABL> float run_fwd(bool prow, const float* X, const float* W, float* out, int M, int N, int K, hipStream_t st, int iters, bool real_epi) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);

@@ -162,7 +162,7 @@ gemm_splitk_kernel(const float* __restrict__ Q, int ldq, const float* __restrict
         v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
 #pragma unroll
         for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (32 * RS) + ql * RS + pl);
-        epi(q0 + ql, p0 + pl, v);
+        epi(q0 + ql, p0 + pl, v, epi.preload(q0 + ql, p0 + pl));
     }
     epi.finish(lds, tile_q * tiles_p + tile_p, tid);
 }
@@ -432,7 +432,7 @@ gemm_splitk_wsN_kernel(GemmArgs ga, Epi epi) {
         v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
 #pragma unroll
         for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (32 * RS) + ql * RS + pl);
-        epi(q0 + ql, p0 + pl, v);
+        epi(q0 + ql, p0 + pl, v, epi.preload(q0 + ql, p0 + pl));
     }
 }
 
