@@ -572,6 +572,46 @@ def test_full_size_training_decreases_loss_and_matches_oracle_trajectory():
             assert rel_err(tr.model.state_dict()[k].cpu(), v) < (0.1 if k.endswith("bias") else 2e-2), k
 
 
+def test_long_run_final_terms_within_one_percent_of_oracle():
+    """SURVEY.md 8c's long-horizon criterion at a size the CPU oracle finishes in seconds: 25 world
+    + 35 joint epochs (780 optimizer steps, StepLR decaying twice) with the same eps stream -- the
+    final world-model MSE and every final ELBO term stay within 1 % of the oracle's loop, and the
+    whole loss curve within 1 %."""
+    arch = R.make_arch(23, 7, latent=8, te=(64, 2), md=(96, 2), wm=(128, 3))
+    data = R.synth_demo(0, 4, 105, 23, 7, kind="dynamics")        # 416 windows, B=32 -> 13 steps / epoch
+    eps_fn = R.eps_stream(3, 8)
+    m_world, n_epochs = 25, 60
+    tr = make_trainer(arch, data, 32, m_world=m_world, device=DEV, eps_fn=eps_fn, lr_step=20)
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=2), seed=5)
+    tr.model.load_state_dict(sd)
+    X, Y = R.build_windows(data)
+    ref = R.RefTrainer(arch, sd, X, Y, 32, m_world, lr_step=20, eps_fn=eps_fn)
+    ours, theirs = [], []
+    for e in range(n_epochs):
+        assert tr.optimizer.lr == pytest.approx(ref.opt.param_groups[0]["lr"], rel=1e-12)
+        ours.append(tr.train()["mean_train_loss"])
+        theirs.append(ref.step()["mean_train_loss"])
+    np.testing.assert_allclose(ours, theirs, rtol=1e-2)
+    assert ours[m_world - 1] < 0.5 * ours[0]                      # the world model actually learns
+    assert ours[-1] < ours[m_world]                               # and so does the VAE
+    # final per-term values on the first minibatch, both phases, vs the oracle's final weights
+    x, y = next(iter(R.make_loader(X, Y, 32)))
+    eps = eps_fn(10 ** 6, (32, 8))
+    sd_ref = {k: v.clone() for k, v in ref.model.state_dict().items()}
+    for world in (True, False):
+        want = R.loss_and_grads(arch, sd_ref, x, y, eps, world)
+        c = R.phase_coeffs(world)
+        sp = make_step_params(lr=5e-4, a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"], s_rec=c["s_rec_coeff"],
+                              cyc=c["vae_cycle_coeff"], global_rows=32)
+        tr.engine.set_batch(x, y)
+        got = tr.engine.forward_backward(_lib.PHASE_WORLD if world else _lib.PHASE_JOINT, 32, sp, eps=eps,
+                                         backward=False).cpu()
+        assert float(got[0]) == pytest.approx(float(want["total"]), rel=1e-2)
+        for i, k in enumerate(("loss_a", "loss_kl", "loss_s", "loss_cyc")):
+            if float(want[k]) != 0.0:
+                assert float(got[1 + i]) == pytest.approx(float(want[k]), rel=1e-2), (world, k)
+
+
 # ------------------------------------------------------------------------------------------
 # sampler, inference surface, checkpoints
 # ------------------------------------------------------------------------------------------
