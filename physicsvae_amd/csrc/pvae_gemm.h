@@ -71,7 +71,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 //   * the 4 waves of a workgroup split K instead of the tile (forward / dgrad): every wave owns
 //     the whole 32x32 output as 2x2 MFMA tiles, so each fragment feeds two MFMAs; partial tiles
 //     are summed through LDS in a fixed order at the end.
-// Tiles travel global -> VGPR (plain global_load_dwordx4, D = 4 register sets per lane) ->
+// Tiles travel global -> VGPR (plain global_load_dwordx4, D register sets per lane, see PVAE_REG_DEPTH_*) ->
 // ds_write_b128 into a 2-slot LDS image.  The image is lane-linear (slot j = 16-byte chunk j of
 // the tile) with the chunk order XOR-permuted on the way in and, identically, on the fragment
 // read (involutions), which removes bank conflicts without padding:
@@ -162,6 +162,17 @@ __device__ inline void stage_row(const StageArgs& a, int r, int t, int rows_pad)
 }
 
 // host-side default for GemmArgs::krot: off (measured: no gain); PVAE_KROT=1 enables
+// register sets in flight per lane in the register-staged kernels (A/B on the whole step: 2 / 2 /
+// 4 beats 4 / 4 / 4 by 1.8 %, 3 and 8 lose; compile-time switches for re-measuring)
+#ifndef PVAE_REG_DEPTH_D
+#define PVAE_REG_DEPTH_D 2
+#endif
+#ifndef PVAE_REG_DEPTH_16
+#define PVAE_REG_DEPTH_16 4
+#endif
+#ifndef PVAE_REG_DEPTH_W
+#define PVAE_REG_DEPTH_W 2
+#endif
 static int g_krot = [] { const char* e = getenv("PVAE_KROT"); return (e && e[0] == '1') ? 1 : 0; }();
 struct GemmArgs {
     const float* Q;
@@ -191,7 +202,7 @@ constexpr int kRegRingFloats = 2 * 2 * 32 * 64;      // 2 LDS slots x (Q tile + 
 
 template <bool P_ROW, class Epi, int ABL = 0>
 __device__ inline void splitk_reg_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
-    constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, D = 4, S = 2;
+    constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, D = PVAE_REG_DEPTH_D, S = 2;
     static_assert(S * kStage >= 4 * 32 * 36, "ring must hold the split-K reduction buffer");
     const float* __restrict__ Q = ga.Q;
     const float* __restrict__ P = ga.P;
@@ -604,7 +615,7 @@ gemm_splitk_ws_kernel(GemmArgs ga, Epi epi) {
 // streaming (16 + 16) rows.  4 flop/B, so it only pays when the grid would otherwise be small.
 template <class Epi>
 __device__ inline void splitk_reg16_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
-    constexpr int BK = 64, kTile = 16 * 64, kStage = 2 * kTile, D = 4;
+    constexpr int BK = 64, kTile = 16 * 64, kStage = 2 * kTile, D = PVAE_REG_DEPTH_16;
     const float* __restrict__ Q = ga.Q;
     const float* __restrict__ P = ga.P;
     const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
@@ -704,7 +715,7 @@ gemm_splitk_reg16_kernel(GemmArgs ga, Epi epi) {
 // waves 2x2 with 32x32 each; the epilogue operands (Adam's p, m, v) are fetched under the loop --
 template <class Epi, int ABL = 0>
 __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
-    constexpr int BK = 32, kTile = 32 * 64, kStage = 2 * kTile, D = 4, S = 2;
+    constexpr int BK = 32, kTile = 32 * 64, kStage = 2 * kTile, D = PVAE_REG_DEPTH_W, S = 2;
     static_assert(S * kStage == kRegRingFloats, "LDS budget");
     const float* __restrict__ Q = ga.Q;
     const float* __restrict__ P = ga.P;
@@ -867,14 +878,14 @@ wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2, int n12, S
 
 // (The dgrad half stays on the register-staged body here: with the wave-specialised body the
 // pair needs 512-thread blocks and 64 KB of LDS per workgroup and measured 15 % slower.)
-template <class EpiD, class EpiW>
+template <class EpiD, class EpiW, int ABL = 0>          // ABL: ablation bits of the two bodies (probes only)
 __global__ void __launch_bounds__(256)
 bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew) {
     __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
     PVAE_MARK(0, 0);
     PVAE_MARK_HW();
-    if ((int)blockIdx.x < nd) splitk_reg_body<false, EpiD>(lds, blockIdx.x, gd, ed);
-    else wgrad_reg_body<EpiW>(lds, blockIdx.x - nd, gw, ew);
+    if ((int)blockIdx.x < nd) splitk_reg_body<false, EpiD, ABL>(lds, blockIdx.x, gd, ed);
+    else wgrad_reg_body<EpiW, ABL>(lds, blockIdx.x - nd, gw, ew);
     PVAE_MARK(0, 3);
 }
 

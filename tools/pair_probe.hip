@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <map>
+#include <type_traits>
 #include <vector>
 #define PVAE_TIMELINE 1
 __device__ unsigned long long* g_timeline;
@@ -69,5 +70,30 @@ int main() {
     }
     printf("   %zu distinct CUs used; %d hold one dgrad + one wgrad workgroup, %d hold >= 2 dgrad, %d hold >= 2 wgrad\n",
            cu.size(), both, two_d, two_w);
+    // ablations of BOTH co-resident bodies: which resource do they fight over?
+    auto run_abl = [&](auto tag, const char* name) {
+        constexpr int A = decltype(tag)::value;
+        const EpiMask ed{dX, K, act, K};
+        const GemmGrid g1 = make_grid(M, K, 32, 32), g2 = make_grid(N, K, 64, 64);
+        auto launch = [&]() {
+            hipLaunchKernelGGL((bwd_pair_kernel<EpiMask, EpiGradAdam, A>), dim3(g1.grid + g2.grid), dim3(256), 0, st,
+                               GemmArgs{dZ, N, W, K, N, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, g1.grid,
+                               GemmArgs{dZ, N, X, K, M, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, e);
+        };
+        for (int i = 0; i < 10; ++i) launch();
+        hipStreamSynchronize(st);
+        hipEventRecord(a, st);
+        for (int i = 0; i < 100; ++i) launch();
+        hipEventRecord(b, st); hipEventSynchronize(b);
+        float t; hipEventElapsedTime(&t, a, b);
+        printf("   %-46s period %6.2f us\n", name, t * 10.0f);
+    };
+    run_abl(std::integral_constant<int, 0>(), "both bodies complete");
+    run_abl(std::integral_constant<int, 1>(), "no global loads / LDS writes");
+    run_abl(std::integral_constant<int, 2>(), "no LDS fragment reads");
+    run_abl(std::integral_constant<int, 4>(), "no MFMA");
+    run_abl(std::integral_constant<int, 8>(), "no barriers");
+    run_abl(std::integral_constant<int, 11>(), "MFMA only (no loads, LDS reads, barriers)");
+    run_abl(std::integral_constant<int, 3>(), "MFMA + barriers (no loads, no LDS reads)");
     return 0;
 }
