@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256)
 reparam_kernel(const float* __restrict__ te_out, int ldte, const float* __restrict__ eps_in,
                float* __restrict__ eps_used, float* __restrict__ md_in, int ld_md, int Db, int Z, int rows,
                int rows_pad, int noise, unsigned long long seed, unsigned long long offset,
-               float* __restrict__ partial) {
+               float* __restrict__ partial, float* __restrict__ z_dense) {
     float acc = 0.f;
     const int total = rows_pad * Z;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
@@ -267,6 +267,7 @@ reparam_kernel(const float* __restrict__ te_out, int ldte, const float* __restri
         }
         md_in[(size_t)r * ld_md + Db + c] = z;
         eps_used[(size_t)r * Z + c] = e;
+        if (z_dense && r < rows) z_dense[(size_t)r * Z + c] = z;      // caller's [rows][Z] copy (rollout path)
     }
     const float s = block_sum_256(acc);
     if (threadIdx.x == 0 && partial) partial[blockIdx.x] = s;
@@ -951,7 +952,7 @@ static int run_forward(pvae_ctx* c, int phase, int rows, const pvae_step_params*
     hipLaunchKernelGGL(reparam_kernel, dim3(S.gridz), dim3(256), 0, st, w + wte.act.back(),
                        TE.layers.back().n_out_pad, eps, w + c->W.eps, w + wmd.in, MD.layers[0].ld, Db, Z, rows,
                        S.rows_pad, 1, (unsigned long long)sp->rng_seed, (unsigned long long)sp->rng_offset,
-                       part + 2 * kLossParts);
+                       part + 2 * kLossParts, (float*)nullptr);
     HIP_TRY(hipGetLastError());
     FwdTail md_tail;                           // a_hat also lands in the action columns of the WM input
     md_tail.out2 = w + wwm.in; md_tail.ld2 = WM.layers[0].ld; md_tail.off2 = Db; md_tail.n2 = Da;
@@ -1095,7 +1096,7 @@ static int run_forward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_ste
                            eps ? eps + (size_t)t * rows * Z : (const float*)nullptr, w + c->W.eps + bt * Z,
                            w + wmd.in + bt * ld_md, ld_md, Db, Z, rows, u.rows_pad, 1,
                            (unsigned long long)sp->rng_seed, (unsigned long long)(sp->rng_offset + t),
-                           part + 2 * kLossParts + t * S.gridz);
+                           part + 2 * kLossParts + t * S.gridz, (float*)nullptr);
         HIP_TRY(hipGetLastError());
         FwdTail md_tail;                       // a_hat -> action columns of the predicted-action WM input
         md_tail.out2 = w + wwm.in + bp * ld_wm; md_tail.ld2 = ld_wm; md_tail.off2 = Db; md_tail.n2 = Da;
@@ -1596,17 +1597,22 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
     hipLaunchKernelGGL(reparam_kernel, dim3(gridz), dim3(256), 0, st, w + c->W.net[PVAE_NET_TE].act.back(),
                        TE.layers.back().n_out_pad, eps, w + c->W.eps, w + c->W.net[PVAE_NET_MD].in, MD.layers[0].ld, Db,
                        Z, rows, rows_pad, noise ? 1 : 0, (unsigned long long)rng_seed, (unsigned long long)rng_offset,
-                       (float*)nullptr);
+                       (float*)nullptr, z_out);                 // z also lands in the caller's buffer
     HIP_TRY(hipGetLastError());
+    // The decoder's output layer can write a second copy of a_hat: into the world model's input
+    // panel when the prediction is wanted, else straight into the caller's buffer (row counts the
+    // GEMV kernel covers exactly -- the control loop's B = 1 -- so no padded row is written).
+    const bool direct = !s2_hat && (rows == 1 || rows == 2 || rows == 4);
     FwdTail md_tail;
-    md_tail.out2 = w + c->W.net[PVAE_NET_WM].in; md_tail.ld2 = WM.layers[0].ld; md_tail.off2 = Db; md_tail.n2 = Da;
+    if (direct) {
+        md_tail.out2 = a_hat; md_tail.ld2 = Da; md_tail.off2 = 0; md_tail.n2 = Da;
+    } else {
+        md_tail.out2 = w + c->W.net[PVAE_NET_WM].in; md_tail.ld2 = WM.layers[0].ld; md_tail.off2 = Db; md_tail.n2 = Da;
+    }
     if ((rc = forward_net(c, PVAE_NET_MD, rows_pad, st, md_tail))) return rc;
-    hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, w + c->W.net[PVAE_NET_MD].act.back(),
-                       MD.layers.back().n_out_pad, 0, a_hat, Da, 0, rows, Da);
-    HIP_TRY(hipGetLastError());
-    if (z_out) {
-        hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, w + c->W.net[PVAE_NET_MD].in, MD.layers[0].ld,
-                           Db, z_out, Z, 0, rows, Z);
+    if (!direct) {
+        hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, w + c->W.net[PVAE_NET_MD].act.back(),
+                           MD.layers.back().n_out_pad, 0, a_hat, Da, 0, rows, Da);
         HIP_TRY(hipGetLastError());
     }
     if (s2_hat) {
@@ -1654,10 +1660,7 @@ int pvae_reparam(pvae_ctx* c, const float* mu_logvar, int32_t rows, const float*
     c->staged_rows = 0;
     hipLaunchKernelGGL(reparam_kernel, dim3(gridz), dim3(256), 0, st, mu_logvar, 2 * Z, eps, c->ws + c->W.eps,
                        c->ws + c->W.net[PVAE_NET_MD].in, ld_md, Db, Z, rows, rows, noise ? 1 : 0,
-                       (unsigned long long)rng_seed, (unsigned long long)rng_offset, (float*)nullptr);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, c->ws + c->W.net[PVAE_NET_MD].in, ld_md, Db, z_out,
-                       Z, 0, rows, Z);
+                       (unsigned long long)rng_seed, (unsigned long long)rng_offset, (float*)nullptr, z_out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -277,14 +277,21 @@ class HipEngine:
                                              self._stream()), "pvae_read_tensor")
         return dst
 
-    def infer(self, obs, eps=None, noise=True, seed=0, offset=0, want_s2=True):
-        """rmt:742-771 forward at rollout batch sizes: returns (a_hat, s2_hat|None, z)."""
+    def infer(self, obs, eps=None, noise=True, seed=0, offset=0, want_s2=True, out=None):
+        """rmt:742-771 forward at rollout batch sizes: returns (a_hat, s2_hat|None, z).
+        `out` = a tuple returned by an earlier call with the same row count: its tensors are
+        overwritten instead of allocating new ones (the 30 Hz control loop calls this every step; at
+        B = 1 the host side of the call costs as much as the GPU side)."""
         self._need_gpu()
-        obs = obs.reshape(obs.shape[0], -1).to(self.device, torch.float32).contiguous()
+        if not (obs.dtype == torch.float32 and obs.device == self.device and obs.dim() == 2 and obs.is_contiguous()):
+            obs = obs.reshape(obs.shape[0], -1).to(self.device, torch.float32).contiguous()
         rows = obs.shape[0]
-        a_hat = torch.empty(rows, self.arch.Da, dtype=torch.float32, device=self.device)
-        s2 = torch.empty(rows, self.arch.Db, dtype=torch.float32, device=self.device) if want_s2 else None
-        z = torch.empty(rows, self.arch.Z, dtype=torch.float32, device=self.device)
+        if out is not None and out[0].shape[0] == rows and (out[1] is not None) == bool(want_s2):
+            a_hat, s2, z = out
+        else:
+            a_hat = torch.empty(rows, self.arch.Da, dtype=torch.float32, device=self.device)
+            s2 = torch.empty(rows, self.arch.Db, dtype=torch.float32, device=self.device) if want_s2 else None
+            z = torch.empty(rows, self.arch.Z, dtype=torch.float32, device=self.device)
         if eps is not None:
             eps = eps.to(self.device, torch.float32).contiguous()
         _lib.check(self.lib.pvae_infer(
