@@ -25,7 +25,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -64,8 +64,8 @@ def main():
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
 
-    from oracle import refpath as R          # synthetic data generator + the CPU-baseline leg only
-    from util import make_trainer
+    from synth_demo import make_trainer, synth_demo      # tools/: inputs only; oracle/ is imported by the
+                                                         # cpu_baseline leg below and nowhere else
 
     import contextlib
     import io
@@ -73,18 +73,17 @@ def main():
     if a.config == "c2":
         Db, Da = 197, 45
         a.batch = a.batch or 256
-        data = R.synth_demo(0, 10, 1000, Db, Da, kind="iid")
+        data = synth_demo(0, 10, 1000, Db, Da)
         workload = "BASELINE configs[1]: synthetic loco demo 10x1000, dim_state_body 197, dim_action 45"
     else:
         Db, Da = 400, 90
         a.batch = a.batch or 512
-        data = R.synth_demo(0, 1, 4, Db, Da, kind="iid")        # placeholder file; the real set is built below
+        data = synth_demo(0, 1, 4, Db, Da)                       # placeholder file; the real set is built below
         workload = "BASELINE configs[4]: synthetic demo 1000x1001 (1e6 transitions), dim_state_body 400, dim_action 90"
-    arch = R.make_arch(Db, Da, latent=Z, te=(W, D), md=(W, D), wm=(W, D))
+    torch.manual_seed(1)                       # normc initialisation of the model's own constructor
     with contextlib.redirect_stdout(io.StringIO()):
-        tr = make_trainer(arch, data, a.batch, m_world=10 ** 9, device=dev)
-    sd = R.init_state_dict(arch, seed=1)
-    tr.model.load_state_dict(sd)
+        tr = make_trainer(data, a.batch, dev, width=W, depth=D, latent=Z)
+    sd = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}     # for the CPU leg
     eng, dp = tr.engine, tr.dp
     ds = tr.train_loader.dataset
     if a.config == "c5":
@@ -231,8 +230,10 @@ def main():
         out["gemm_time_share_of_step"] = sum(c["total_ms"] for c in cats.values()) / n_prof / ms_per_step
 
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
+        from oracle import refpath as R        # the checker, timed as the CPU baseline -- this leg only
+        arch = R.make_arch(Db, Da, latent=Z, te=(W, D), md=(W, D), wm=(W, D))
         if a.config != "c2":
-            data = R.synth_demo(0, 10, 1000, Db, Da, kind="iid")   # bounded CPU sample of the same shape
+            data = synth_demo(0, 10, 1000, Db, Da)                 # bounded CPU sample of the same shape
         X, Y = R.build_windows(data)
         n_b = 3 * 39 if a.config == "c2" else 2 * (len(X) // a.batch)
         t0 = time.perf_counter()

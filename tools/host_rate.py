@@ -2,13 +2,11 @@
 short bursts measure the pure host cost, a long run the back-pressured steady state.
 Usage (GPU box): python tools/host_rate.py"""
 import sys, os, time, io, contextlib, torch
-sys.path[:0]=[os.getcwd(), os.path.join(os.getcwd(),"tests")]
-from oracle import refpath as R
-from util import make_trainer
-arch = R.make_arch(197,45,latent=32,te=(1024,4),md=(1024,4),wm=(1024,4))
-data = R.synth_demo(0,10,1000,197,45,kind="iid")
+sys.path[:0]=[os.getcwd(), os.path.join(os.getcwd(),"tools")]
+from synth_demo import make_trainer, synth_demo
+data = synth_demo(0,10,1000,197,45)
 with contextlib.redirect_stdout(io.StringIO()):
-    tr = make_trainer(arch, data, 256, m_world=10**9, device="cuda")
+    tr = make_trainer(data, 256, "cuda")
 eng=tr.engine; ds=tr.train_loader.dataset
 eng.bind_dataset(*ds.device_arrays(eng.device))
 loss=torch.zeros(5,device="cuda")

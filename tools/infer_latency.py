@@ -1,15 +1,20 @@
 """Rollout-path latency: PhysicsVAE forward at control-loop batch sizes (rmt:742-771)."""
 import contextlib, io, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
-from oracle import refpath as R
-from util import make_trainer
-for name, arch in (("default 256x2/512x3/1024x2", R.make_arch(197, 45)),
-                   ("4x1024", R.make_arch(197, 45, te=(1024, 4), md=(1024, 4), wm=(1024, 4)))):
-    data = R.synth_demo(0, 2, 50, 197, 45)
+from synth_demo import synth_demo, write_demo
+from physicsvae_amd import train_physics_vae as T
+import tempfile
+td = tempfile.mkdtemp(prefix="pvae_infer_")
+write_demo(os.path.join(td, "demo.pkl"), synth_demo(0, 2, 50, 197, 45))
+for name, sizes in (("default 256x2/512x3/1024x2", []),          # the trainer's own defaults (tpv:264-280)
+                    ("4x1024", [a for p in ("TE", "MD", "world_model") for a in ("--%s_width" % p, "1024", "--%s_depth" % p, "4")])):
+    T.args = T.arg_parser().parse_args(["--data_train", os.path.join(td, "demo.pkl"), "--batch_size", "32"] + sizes)
+    cfg = T.get_trainer_config(T.args)
+    cfg["model"]["custom_model_config"]["device"] = "cuda"
     with contextlib.redirect_stdout(io.StringIO()):
-        tr = make_trainer(arch, data, 32, device="cuda")
+        tr = T.TrainModel(cfg)
     eng = tr.engine
     for rows in (1, 4, 32):
         obs = torch.randn(rows, 394, device="cuda")

@@ -12,7 +12,7 @@ import time
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
 
 
 def main():
@@ -21,15 +21,12 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--batch", type=int, default=256)
     a = ap.parse_args()
-    from oracle import refpath as R              # synthetic data generator only
-    from util import make_trainer
-    arch = R.make_arch(197, 45, latent=32, te=(1024, 4), md=(1024, 4), wm=(1024, 4))
-    data = R.synth_demo(0, 10, 1000, 197, 45, kind="iid")
+    from synth_demo import make_trainer, synth_demo
+    data = synth_demo(0, 10, 1000, 197, 45)
     out = {}
     for L in (1, a.lookahead):
         with contextlib.redirect_stdout(io.StringIO()):
-            tr = make_trainer(arch, data, a.batch, m_world=10 ** 9, device="cuda", extra={"lookahead": L})
-        tr.model.load_state_dict(R.init_state_dict(arch, seed=1))
+            tr = make_trainer(data, a.batch, "cuda", extra={"lookahead": L})
         eng = tr.engine
         ds = tr.train_loader.dataset
         eng.bind_dataset(*ds.device_arrays(eng.device))

@@ -1,15 +1,13 @@
 """Step-time decomposition: fused Adam vs gradient store (no Adam) vs store + flat Adam vs staged DP path."""
 import os, sys, time, io, contextlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
-from oracle import refpath as R
 from physicsvae_amd import _lib
-from util import make_trainer
-arch = R.make_arch(197, 45, latent=32, te=(1024, 4), md=(1024, 4), wm=(1024, 4))
-data = R.synth_demo(0, 10, 1000, 197, 45)
+from synth_demo import make_trainer, synth_demo
+data = synth_demo(0, 10, 1000, 197, 45)
 with contextlib.redirect_stdout(io.StringIO()):
-    tr = make_trainer(arch, data, 256, m_world=10**9, device="cuda")
+    tr = make_trainer(data, 256, "cuda")
 eng = tr.engine
 eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
 loss = torch.zeros(5, device="cuda")
