@@ -346,3 +346,14 @@ def test_graft_entry_build_runs_without_gpu():
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "built" in r.stdout
+
+
+def test_bench_algorithmic_flops_match_the_survey():
+    """the per-sample work `roofline.achieved` is priced with."""
+    sys.path.insert(0, ROOT)
+    import bench
+    w, j = bench.algorithmic_flops_per_sample(197, 45, 32, 1024, 4)
+    assert (w, j) == (2 * 10_537_984, 2 * 27_506_688)
+    w5, j5 = bench.algorithmic_flops_per_sample(400, 90, 32, 1024, 4)
+    assert (w5, j5) == (2 * 11_669_504, 2 * 29_607_936)
+    assert bench.PEAK_F32_MFMA_TFLOPS == pytest.approx(256 * 2.4e9 * 256 / 1e12, rel=1e-3)
