@@ -141,7 +141,9 @@ class WindowDataset(torch_models.DatasetBase):
         return ds
 
     def device_arrays(self, device):
-        if self._dev is None or self._dev[0].device != torch.device(device):
+        d = torch.device(device)
+        have = None if self._dev is None else self._dev[0].device
+        if have is None or have.type != d.type or (d.index is not None and d.index != have.index):
             self._dev = tuple(torch.from_numpy(a).to(device)
                               for a in (self.states, self.actions, self.window_row))
         return self._dev
