@@ -93,6 +93,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks: several ranks on ONE GPU (PVAE_LOCAL_DEVICE=0) need the gloo backend
+    # (PVAE_DIST_BACKEND=gloo) -- RCCL refuses two ranks on the same device
+    if os.environ.get("PVAE_LOCAL_DEVICE") is not None:
+        local = int(os.environ["PVAE_LOCAL_DEVICE"])
+    backend = backend or os.environ.get("PVAE_DIST_BACKEND")
     force = os.environ.get("PVAE_DP_ALWAYS_REDUCE", "0") == "1"
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -131,3 +131,26 @@ def test_in_library_exchange_calls(golden):
         assert not torch.equal(got, p0)                             # the moments still move the weights
     eng.comm_destroy()
     assert not eng.has_comm
+
+
+def test_bench_multi_rank_path_runs_end_to_end(tmp_path):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per
+    rank), with both ranks on this box's single GPU through the test hooks (gloo instead of RCCL,
+    which refuses two ranks on one device): the N > 1 branches of the benchmark -- sharding,
+    barrier-bracketed timing with the max over ranks, the instrumented roofline pass, rank-0-only
+    JSON -- run and produce a well-formed line."""
+    import json
+    env = dict(os.environ, PVAE_LOCAL_DEVICE="0", PVAE_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "20", "--warmup", "3"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                     # ONE JSON line, from rank 0 only
+    d = json.loads(lines[0])
+    assert r.stdout.strip().splitlines()[-1] == lines[0]          # and it is the last line on stdout
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] == pytest.approx(512 * 20 / (d["ms_per_step"] * 20 * 1e-3), rel=1e-6)
+    assert "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma" and d["vs_baseline"] is None
