@@ -785,6 +785,7 @@ int pvae_bind_dataset(pvae_ctx* c, const float* states, const float* actions, co
     if (n_rows > 2147483647ll) return fail(-1, "more than 2^31-1 rows");
     c->states = states; c->actions = actions; c->window_row = window_row;
     c->n_rows = n_rows; c->n_windows = n_windows;
+    c->pf.valid = false;         // a minibatch gathered ahead came from the previous binding
     return 0;
 }
 

@@ -131,6 +131,9 @@ class HipEngine:
     # -- data ---------------------------------------------------------------------------
     def bind_dataset(self, states, actions, window_row):
         self._need_gpu()
+        if self.dataset is not None and self.dataset[0] is states and self.dataset[1] is actions \
+                and self.dataset[2] is window_row:
+            return                                # the very same device tensors are already bound
         states = states.to(self.device, torch.float32).contiguous()
         actions = actions.to(self.device, torch.float32).contiguous()
         window_row = window_row.to(self.device, torch.int32).contiguous()

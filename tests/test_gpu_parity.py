@@ -419,6 +419,20 @@ def test_gather_prefetch_is_bit_identical(golden):
     eng.train_step(phase, 0, batch, sp, eps=e, loss_out=out2)
     eng.train_step(phase, 2 * batch, batch, sp, eps=e, loss_out=out2)
     assert torch.equal(p1, eng.params) and torch.equal(out1, out2)
+    # a different demonstration set bound in between: what was gathered ahead must not be used
+    st, ac, wr = eng.dataset
+    other = (st.flip(0).contiguous(), ac.flip(0).contiguous(), wr.clone())
+    eng.params.copy_(p0); eng.exp_avg.copy_(m0); eng.exp_avg_sq.copy_(v0)
+    eng.train_step(phase, 0, batch, sp, eps=e, loss_out=out1, next_span=(batch, batch))   # prefetches set A
+    eng.bind_dataset(*other)
+    eng.train_step(phase, batch, batch, sp, eps=e, loss_out=out1)                         # must read set B
+    p_b = eng.params.clone()
+    eng.bind_dataset(st, ac, wr)
+    eng.params.copy_(p0); eng.exp_avg.copy_(m0); eng.exp_avg_sq.copy_(v0)
+    eng.train_step(phase, 0, batch, sp, eps=e, loss_out=out2)
+    eng.bind_dataset(*other)
+    eng.train_step(phase, batch, batch, sp, eps=e, loss_out=out2)
+    assert torch.equal(p_b, eng.params) and torch.equal(out1, out2)
 
 
 def test_argument_errors_are_loud_and_leave_the_ctx_usable(golden):
