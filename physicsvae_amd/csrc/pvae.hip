@@ -774,6 +774,7 @@ int pvae_bind_workspace(pvae_ctx* c, void* workspace, size_t bytes) {
         return fail(-1, "workspace too small: %zu < %zu", bytes, (size_t)c->W.total_floats * sizeof(float));
     c->ws = (float*)workspace;
     c->seed_pads_clean = false;
+    c->pf.valid = false;
     return 0;
 }
 
