@@ -746,3 +746,35 @@ def test_config5_full_size_dataset_epoch_and_ragged_tail():
             got = eng.forward_backward(_lib.PHASE_WORLD if world else _lib.PHASE_JOINT, rows, sp, eps=eps,
                                        backward=False).cpu()
             assert float(got[0]) == pytest.approx(float(want["total"]), rel=2e-5), (first, world)
+
+
+def test_cli_trains_and_writes_the_five_checkpoint_files(tmp_path):
+    """`python -m physicsvae_amd.train_physics_vae ...` with the reference's flags (tpv:30-56, 469-521):
+    trains across the phase switch, writes a checkpoint directory every `--checkpoint_freq`
+    iterations with the five files of tpv:440-467, and the files load back."""
+    import subprocess
+    import sys
+    pkl = str(tmp_path / "demo.pkl")
+    R.write_demo(pkl, R.synth_demo(0, 3, 120, 23, 7, kind="dynamics"))
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "physicsvae_amd.train_physics_vae", "--data_train", pkl, "--max_iter", "4",
+                        "--max_iter_world_model", "2", "--batch_size", "64", "--checkpoint_freq", "2",
+                        "--local_dir", str(tmp_path / "results"), "--name", "cli"], cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import glob
+    import os
+    cks = sorted(glob.glob(str(tmp_path / "results" / "cli" / "*" / "checkpoint_*")))
+    assert [os.path.basename(c) for c in cks] == ["checkpoint_000002", "checkpoint_000004"]
+    for c in cks:
+        assert sorted(os.listdir(c)) == ["model.pt", "model.pth", "motor_decoder.pt", "task_encoder.pt", "world_model.pt"]
+    full = torch.load(os.path.join(cks[-1], "model.pt"))
+    assert len(full) == 26 and all(v.device.type == "cpu" and v.is_contiguous() for v in full.values())
+    assert list(torch.load(os.path.join(cks[-1], "task_encoder.pt")).keys()) == ["task_encoder"]
+    # the world model stops changing at the switch (after iteration 2)
+    wm2 = torch.load(os.path.join(cks[0], "world_model.pt"))
+    wm4 = torch.load(os.path.join(cks[1], "world_model.pt"))
+    assert all(torch.equal(wm2[k], wm4[k]) for k in wm2)
+    te2 = torch.load(os.path.join(cks[0], "task_encoder.pt"))["task_encoder"]
+    te4 = torch.load(os.path.join(cks[1], "task_encoder.pt"))["task_encoder"]
+    assert any(not torch.equal(te2[k], te4[k]) for k in te2)
