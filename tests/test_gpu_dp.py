@@ -154,3 +154,37 @@ def test_bench_multi_rank_path_runs_end_to_end(tmp_path):
     assert d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp2"
     assert d["value"] == pytest.approx(512 * 20 / (d["ms_per_step"] * 20 * 1e-3), rel=1e-6)
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma" and d["vs_baseline"] is None
+
+
+def test_in_library_exchange_with_lookahead(golden):
+    """The data-parallel step over a lookahead-2 unroll (stacked time steps, one weight-gradient
+    launch per layer, per-net all-reduce, flat Adam) equals the fused single-GPU step bit for bit."""
+    from oracle import refpath as R
+    from physicsvae_amd import _lib
+    from physicsvae_amd.engine import make_step_params
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_trainer
+    arch = R.make_arch(23, 7, latent=8, te=(64, 2), md=(96, 2), wm=(128, 3))
+    data = R.synth_demo(0, 3, 40, 23, 7, kind="dynamics")
+    tr = make_trainer(arch, data, 32, device="cuda", extra={"lookahead": 2})
+    sd = R.perturb_biases(R.init_state_dict(arch, 1), 3)
+    eng = tr.engine
+    eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
+    eng.comm_init(0, 1, eng.comm_unique_id())
+    es = R.eps_stream(2, 8)
+    eps = torch.stack([es(t, (32, 8)) for t in range(2)])
+    for phase, world in ((_lib.PHASE_WORLD, True), (_lib.PHASE_JOINT, False)):
+        c = R.phase_coeffs(world)
+        res = []
+        for dp in (False, True):
+            tr.model.load_state_dict(sd)
+            eng.exp_avg.zero_(); eng.exp_avg_sq.zero_()
+            out = torch.zeros(5, device="cuda")
+            for t in (1, 2):
+                sp = make_step_params(lr=5e-4, adam_t=(t, t, t), a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"],
+                                      s_rec=c["s_rec_coeff"], cyc=c["vae_cycle_coeff"], global_rows=32)
+                (eng.dp_train_step if dp else eng.train_step)(phase, 32 * (t - 1), 32, sp, eps=eps, loss_out=out)
+            res.append((eng.params.clone(), eng.exp_avg.clone(), out.clone()))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+    eng.comm_destroy()
