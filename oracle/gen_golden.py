@@ -263,6 +263,31 @@ def case_training(name, arch, n_ep, n_steps, batch, m_world, n_epochs, full, lr_
     print("wrote", name, "losses", losses, "lrs", lrs)
 
 
+def case_anchor(name):
+    """The reference exactly as a user runs it: its OWN constructor under torch.manual_seed(0) (normc
+    init through the torch RNG), B=64, 2x256 stacks, max_iter_world_model=2.  Records the initial
+    state dict (digests) and the two world-phase epoch losses (which do not depend on the sampler's
+    draws: 1.0004073202989663, 0.9972580170175832 -- the known-answer anchor of SURVEY.md 8c)."""
+    arch = R.make_arch(197, 45, latent=32, te=(256, 2), md=(256, 2), wm=(256, 2))
+    fix = {}
+    with tempfile.TemporaryDirectory() as td:
+        pkl = os.path.join(td, "demo.pkl")
+        R.write_demo(pkl, R.survey_anchor_demo())
+        torch.manual_seed(0)
+        tr = make_reference_trainer(pkl, arch, 64, m_world=2)
+        sd0 = tr.model.state_dict()
+        fix["sd_keys"] = np.array(list(sd0.keys()))
+        for k, v in sd0.items():
+            fix["init_digest::" + k] = R.tensor_digest(v)
+        fix["n_batches"] = np.array(len(tr.train_loader))
+        fix["world_epoch_losses"] = np.array([tr.train()["mean_train_loss"] for _ in range(2)], dtype=np.float64)
+        for k, v in tr.model.state_dict().items():
+            if k.startswith("_world_model"):
+                fix["after_world_digest::" + k] = R.tensor_digest(v)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
+    print("wrote", name, fix["world_epoch_losses"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -282,6 +307,7 @@ def main():
                                             full=True),
         "train_c1": lambda: case_training("train_c1", c1, 4, 200, 64, m_world=2, n_epochs=4,
                                           full=False),
+        "anchor_c1": lambda: case_anchor("anchor_c1"),
         "look3_tiny": lambda: case_lookahead("look3_tiny", tiny, 2, 15, 8, lookahead=3, full=True),
         "look2_c1": lambda: case_lookahead("look2_c1", c1, 2, 200, 64, lookahead=2, full=False),
         "l1_tiny": lambda: case_lookahead("l1_tiny", tiny, 2, 15, 8, lookahead=1, full=True, loss="L1"),

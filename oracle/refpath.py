@@ -149,6 +149,22 @@ def synth_demo(seed, n_episodes, n_steps, dim_body, dim_action, kind="iid", quan
     }
 
 
+def survey_anchor_demo():
+    """SURVEY.md 8(c) anchor inputs: numpy default_rng(0), per episode standard_normal((1000,197))
+    then standard_normal((1000,45)).clip(-3,3), 10 episodes (values NOT rounded)."""
+    rng = np.random.default_rng(0)
+    eps = []
+    for _ in range(10):
+        sb = rng.standard_normal((1000, 197))
+        a = rng.standard_normal((1000, 45)).clip(-3, 3)
+        eps.append({"time": [t / 30.0 for t in range(1000)],
+                    "state": [np.concatenate([sb[t], sb[min(t + 1, 999)]]) for t in range(1000)],
+                    "state_body": [sb[t] for t in range(1000)], "state_task": [sb[min(t + 1, 999)] for t in range(1000)],
+                    "action": [a[t] for t in range(1000)], "reward": [0.0] * 1000})
+    return {"dim_action": 45, "dim_state": 394, "dim_state_body": 197, "dim_state_task": 197, "exp_std": 0.05,
+            "iter_per_episode": 1, "episodes": eps}
+
+
 def write_demo(path, data):
     with open(path, "wb") as f:
         pickle.dump(data, f)

@@ -778,3 +778,26 @@ def test_cli_trains_and_writes_the_five_checkpoint_files(tmp_path):
     te2 = torch.load(os.path.join(cks[0], "task_encoder.pt"))["task_encoder"]
     te4 = torch.load(os.path.join(cks[1], "task_encoder.pt"))["task_encoder"]
     assert any(not torch.equal(te2[k], te4[k]) for k in te2)
+
+
+def test_reference_known_answer_run_world_phase(golden):
+    """The reference run as a user starts it -- torch.manual_seed(0), its own constructor, the
+    SURVEY.md 8(c) demo (10 x 1000 steps, Db=197, Da=45), B=64, 2x256 stacks -- gives epoch losses
+    1.0004073202989663, 0.9972580170175832 in the world-model phase (captured from the reference;
+    they do not depend on the sampler's draws).  Same seed, our constructor, the HIP path: same
+    numbers, and the same world-model weights afterwards."""
+    g = golden("anchor_c1")
+    arch = R.make_arch(197, 45, latent=32, te=(256, 2), md=(256, 2), wm=(256, 2))
+    torch.manual_seed(0)
+    tr = make_trainer(arch, R.survey_anchor_demo(), 64, m_world=2, device=DEV)
+    assert len(tr.train_loader) == int(g["n_batches"]) == 157
+    losses = [tr.train()["mean_train_loss"] for _ in range(2)]
+    # epoch 1 starts from identical weights; by epoch 2 157 Adam steps have amplified fp32 noise
+    assert losses[0] == pytest.approx(float(g["world_epoch_losses"][0]), rel=3e-6)
+    assert losses[1] == pytest.approx(float(g["world_epoch_losses"][1]), rel=5e-5)
+    np.testing.assert_allclose(g["world_epoch_losses"], [1.0004073202989663, 0.9972580170175832], rtol=1e-12)
+    for k, v in tr.model.state_dict().items():
+        if k.startswith("_world_model") and k.endswith("weight") and "._model.2." not in k:
+            # 314 Adam steps from identical weights: the hidden layers' norms agree to 1e-3 (biases and
+            # the 0.01-scaled output layer are pure accumulated Adam updates and amplify fp32 noise)
+            np.testing.assert_allclose(R.tensor_digest(v.cpu())[1:3], g["after_world_digest::" + k][1:3], rtol=1e-3)

@@ -357,3 +357,19 @@ def test_bench_algorithmic_flops_match_the_survey():
     w5, j5 = bench.algorithmic_flops_per_sample(400, 90, 32, 1024, 4)
     assert (w5, j5) == (2 * 11_669_504, 2 * 29_607_936)
     assert bench.PEAK_F32_MFMA_TFLOPS == pytest.approx(256 * 2.4e9 * 256 / 1e12, rel=1e-3)
+
+
+def test_constructor_reproduces_the_reference_initialisation_bit_for_bit(golden):
+    """Same torch seed -> same weights as the reference's own constructor: the stacks are built in the
+    reference's order (task encoder, motor decoder, world model, value branch) and `normc_` consumes
+    the torch RNG exactly like ray's normc_initializer, so a user who seeds torch gets the run they
+    would have got upstream.  (Digests of the reference's state dict under torch.manual_seed(0).)"""
+    g = golden("anchor_c1")
+    arch = R.make_arch(197, 45, latent=32, te=(256, 2), md=(256, 2), wm=(256, 2))
+    data = R.synth_demo(0, 1, 8, 197, 45)                      # dims only; the init does not see the data
+    torch.manual_seed(0)
+    tr = make_trainer(arch, data, 64, m_world=2, device="cpu")
+    sd = tr.model.state_dict()
+    assert list(sd.keys()) == list(g["sd_keys"])
+    for k, v in sd.items():
+        np.testing.assert_array_equal(R.tensor_digest(v.cpu()), g["init_digest::" + k], err_msg=k)
