@@ -284,8 +284,12 @@ def case_anchor(name):
         for k, v in tr.model.state_dict().items():
             if k.startswith("_world_model"):
                 fix["after_world_digest::" + k] = R.tensor_digest(v)
+        # two joint epochs with the sampler drawing from torch's global CPU generator, untouched:
+        # per epoch one int64 draw by the DataLoader iterator (its base seed), then one
+        # randn_like([B, Z]) per minibatch -- in the world epochs above as well (tpv:378)
+        fix["joint_epoch_losses"] = np.array([tr.train()["mean_train_loss"] for _ in range(2)], dtype=np.float64)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
-    print("wrote", name, fix["world_epoch_losses"])
+    print("wrote", name, fix["world_epoch_losses"], fix["joint_epoch_losses"])
 
 
 def main():

@@ -780,7 +780,7 @@ def test_cli_trains_and_writes_the_five_checkpoint_files(tmp_path):
     assert any(not torch.equal(te2[k], te4[k]) for k in te2)
 
 
-def test_reference_known_answer_run_world_phase(golden):
+def test_reference_known_answer_run(golden):
     """The reference run as a user starts it -- torch.manual_seed(0), its own constructor, the
     SURVEY.md 8(c) demo (10 x 1000 steps, Db=197, Da=45), B=64, 2x256 stacks -- gives epoch losses
     1.0004073202989663, 0.9972580170175832 in the world-model phase (captured from the reference;
@@ -796,8 +796,28 @@ def test_reference_known_answer_run_world_phase(golden):
     assert losses[0] == pytest.approx(float(g["world_epoch_losses"][0]), rel=3e-6)
     assert losses[1] == pytest.approx(float(g["world_epoch_losses"][1]), rel=5e-5)
     np.testing.assert_allclose(g["world_epoch_losses"], [1.0004073202989663, 0.9972580170175832], rtol=1e-12)
+    # ... and the two joint epochs that follow.  The reference's sampler draws from torch's global CPU
+    # generator: per epoch one int64 (the DataLoader iterator's base seed), then one randn_like([rows, Z])
+    # per minibatch -- in the world epochs too (tpv:378).  Replaying exactly those draws as our eps
+    # reproduces its joint-phase epoch losses.
+    spans = list(tr.train_loader.spans())
+    wm_after_world = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items() if k.startswith("_world_model")}
+    for _ in range(2):                                            # what the two world epochs consumed
+        torch.empty((), dtype=torch.int64).random_()
+        for _, rows in spans:
+            torch.randn(rows, 32)
+    tr.eps_fn = lambda call, shape: torch.randn(*shape)
+    joint = []
+    for _ in range(2):
+        torch.empty((), dtype=torch.int64).random_()
+        joint.append(tr.train()["mean_train_loss"])
+    print("known-answer run: ours", losses + joint, "reference", list(g["world_epoch_losses"]) + list(g["joint_epoch_losses"]))
+    np.testing.assert_allclose(joint, g["joint_epoch_losses"], rtol=2e-5)    # measured: 1.4e-7, 9e-8
     for k, v in tr.model.state_dict().items():
         if k.startswith("_world_model") and k.endswith("weight") and "._model.2." not in k:
+            assert torch.equal(v.cpu(), wm_after_world[k])        # frozen in the joint phase
+    for k, v in wm_after_world.items():
+        if k.endswith("weight") and "._model.2." not in k:
             # 314 Adam steps from identical weights: the hidden layers' norms agree to 1e-3 (biases and
             # the 0.01-scaled output layer are pure accumulated Adam updates and amplify fp32 noise)
-            np.testing.assert_allclose(R.tensor_digest(v.cpu())[1:3], g["after_world_digest::" + k][1:3], rtol=1e-3)
+            np.testing.assert_allclose(R.tensor_digest(v)[1:3], g["after_world_digest::" + k][1:3], rtol=1e-3)

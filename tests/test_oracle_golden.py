@@ -247,3 +247,24 @@ def test_adam_restatement_matches_torch():
         opt.step()
         q, m, v = R.adam_reference_update(q, gr, m, v, t, 5e-4)
         np.testing.assert_allclose(q.numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_known_answer_run_of_the_reference(golden):
+    """SURVEY.md 8(c) anchor, captured from the reference run untouched (its own constructor under
+    torch.manual_seed(0); sampler draws from torch's global generator): four epoch losses across the
+    phase switch.  The oracle loop started from the same generator state reproduces them."""
+    from util import make_trainer
+    g = golden("anchor_c1")
+    arch = arch_from_meta([197, 45, 32, 256, 2, 256, 2, 256, 2])
+    data = R.survey_anchor_demo()
+    torch.manual_seed(0)
+    mine = make_trainer(arch, data, 64, m_world=2, device="cpu")      # consumes the init draws like the reference
+    state = torch.get_rng_state()
+    sd = {k: v.detach().clone() for k, v in mine.model.state_dict().items()}
+    X, Y = R.build_windows(data)
+    tr = R.RefTrainer(arch, sd, X, Y, 64, 2)                           # (its own nn.Linear init draws are discarded)
+    torch.set_rng_state(state)
+    losses = [tr.step()["mean_train_loss"] for _ in range(4)]
+    np.testing.assert_allclose(losses[:2], g["world_epoch_losses"], rtol=1e-7)
+    np.testing.assert_allclose(losses[2:], g["joint_epoch_losses"], rtol=1e-6)
+    np.testing.assert_allclose(g["world_epoch_losses"], [1.0004073202989663, 0.9972580170175832], rtol=1e-12)
