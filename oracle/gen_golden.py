@@ -292,6 +292,65 @@ def case_anchor(name):
     print("wrote", name, fix["world_epoch_losses"], fix["joint_epoch_losses"])
 
 
+def case_checkpoint_interop(name, arch):
+    """Both directions of the checkpoint drop-in, with the REFERENCE's own classes:
+    (a) the five files written by the reference's save_checkpoint are stored byte for byte (data
+        files), for our loaders to read in tests;
+    (b) the five files written by OUR trainer (CPU device) are loaded through the reference's
+        load_checkpoint / load_weights / load_weights_{task_encoder,motor_decoder,world_model}; the
+        resulting state dicts must equal the weights we saved, and the reference's forward on a
+        fixed observation after loading them is recorded as the expected output."""
+    from physicsvae_amd import train_physics_vae as OT
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_trainer
+    data = R.synth_demo(seed=0, n_episodes=2, n_steps=14, dim_body=arch["Db"], dim_action=arch["Da"], kind="iid")
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    fix = {}
+    with tempfile.TemporaryDirectory() as td:
+        pkl = os.path.join(td, "demo.pkl")
+        R.write_demo(pkl, data)
+        ref = make_reference_trainer(pkl, arch, 8, m_world=2)
+        ref.model.load_state_dict(sd)
+        d_ref = os.path.join(td, "ref_ck")
+        os.makedirs(d_ref)
+        ref.save_checkpoint(d_ref)
+        for f in sorted(os.listdir(d_ref)):
+            fix["ref_file::" + f] = np.frombuffer(open(os.path.join(d_ref, f), "rb").read(), dtype=np.uint8)
+        # (b) our files -> the reference's loaders
+        ours = make_trainer(arch, data, 8, device="cpu")
+        sd2 = R.perturb_biases(R.init_state_dict(arch, seed=7), seed=9)      # different weights than `sd`
+        ours.model.load_state_dict(sd2)
+        d_our = os.path.join(td, "our_ck")
+        os.makedirs(d_our)
+        ret = ours.save_checkpoint(d_our)
+        ok = {}
+        ref.load_checkpoint(ret)                                              # tm:215-216, model.pth
+        ok["load_checkpoint"] = all(torch.equal(v, sd2[k]) for k, v in ref.model.state_dict().items())
+        ref.model.load_state_dict(sd)
+        ref.model.load_weights(os.path.join(d_our, "model.pt"))               # rmt:873-875
+        ok["load_weights"] = all(torch.equal(v, sd2[k]) for k, v in ref.model.state_dict().items())
+        ref.model.load_state_dict(sd)
+        ref.model.load_weights_task_encoder(os.path.join(d_our, "task_encoder.pt"))
+        ref.model.load_weights_motor_decoder(os.path.join(d_our, "motor_decoder.pt"))
+        ref.model.load_weights_world_model(os.path.join(d_our, "world_model.pt"))
+        got = ref.model.state_dict()
+        ok["per_net_loaders"] = all(torch.equal(v, (sd if k.startswith("_value_branch") else sd2)[k])
+                                    for k, v in got.items())
+        for k, v in ok.items():
+            assert v, k
+            fix["reference_accepts::" + k] = np.array(True)
+        obs = torch.from_numpy(np.random.default_rng(5).standard_normal((4, 2 * arch["Db"])).astype(np.float32))
+        ref.model.latent_prior_noise = False if hasattr(ref.model, "latent_prior_noise") else None
+        with EpsPatch(lambda c, shape: torch.zeros(shape)):
+            logits, _ = ref.model(input_dict={"obs": obs, "obs_flat": obs}, state=None, seq_lens=None)
+        fix["obs"] = obs.numpy()
+        fix["reference_logits_after_loading_our_files"] = logits.detach().numpy()
+        fix["reference_future_state"] = ref.model._cur_future_state.detach().numpy()
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"]])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
+    print("wrote", name, "reference accepts our files:", ok)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -312,6 +371,7 @@ def main():
         "train_c1": lambda: case_training("train_c1", c1, 4, 200, 64, m_world=2, n_epochs=4,
                                           full=False),
         "anchor_c1": lambda: case_anchor("anchor_c1"),
+        "ckpt_interop_tiny": lambda: case_checkpoint_interop("ckpt_interop_tiny", tiny),
         "look3_tiny": lambda: case_lookahead("look3_tiny", tiny, 2, 15, 8, lookahead=3, full=True),
         "look2_c1": lambda: case_lookahead("look2_c1", c1, 2, 200, 64, lookahead=2, full=False),
         "l1_tiny": lambda: case_lookahead("l1_tiny", tiny, 2, 15, 8, lookahead=1, full=True, loss="L1"),

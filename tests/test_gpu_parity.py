@@ -821,3 +821,22 @@ def test_reference_known_answer_run(golden):
             # 314 Adam steps from identical weights: the hidden layers' norms agree to 1e-3 (biases and
             # the 0.01-scaled output layer are pure accumulated Adam updates and amplify fp32 noise)
             np.testing.assert_allclose(R.tensor_digest(v)[1:3], g["after_world_digest::" + k][1:3], rtol=1e-3)
+
+
+def test_rollout_forward_from_weights_the_reference_accepted(golden):
+    """End of the drop-in chain on the GPU: the weights whose five files the reference's own loaders
+    accepted (ckpt_interop_tiny.npz) give, through PhysicsVAE.forward on the HIP path (eps = 0), the
+    logits and the predicted next state that the reference itself computed after loading them."""
+    g = golden("ckpt_interop_tiny")
+    arch = arch_from_meta(g["meta"])
+    data = R.synth_demo(0, 2, 14, arch["Db"], arch["Da"], kind="iid")
+    tr = make_trainer(arch, data, 8, device=DEV)
+    tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, seed=7), seed=9))
+    obs = torch.from_numpy(g["obs"]).to(DEV)
+    tr.model.latent_prior_noise = False                               # z = mu, as with eps = 0
+    logits, _ = tr.model(input_dict={"obs": obs, "obs_flat": obs}, state=None, seq_lens=None)
+    assert max_err_scaled(logits.cpu(), g["reference_logits_after_loading_our_files"]) < 2e-5
+    assert max_err_scaled(tr.model._cur_future_state.cpu(), g["reference_future_state"]) < 2e-5
+    a_hat, s2, z = tr.engine.infer(obs, noise=False)
+    assert max_err_scaled(a_hat.cpu(), g["reference_logits_after_loading_our_files"][:, : arch["Da"]]) < 2e-5
+    assert max_err_scaled(s2.cpu(), g["reference_future_state"]) < 2e-5

@@ -373,3 +373,41 @@ def test_constructor_reproduces_the_reference_initialisation_bit_for_bit(golden)
     assert list(sd.keys()) == list(g["sd_keys"])
     for k, v in sd.items():
         np.testing.assert_array_equal(R.tensor_digest(v.cpu()), g["init_digest::" + k], err_msg=k)
+
+
+def test_checkpoint_interop_with_the_reference_both_directions(golden, tmp_path):
+    """(a) The five files the REFERENCE wrote (stored byte for byte in the fixture) load through our
+    restore / load_weights* and give exactly the weights it held.  (b) The fixture was only written
+    after the reference's own load_checkpoint / load_weights / per-net loaders had accepted OUR five
+    files and reproduced our weights (asserted in oracle/gen_golden.py, flags recorded); the forward
+    pass the reference then computed is reproduced by the oracle from those weights."""
+    g = golden("ckpt_interop_tiny")
+    arch = arch_from_meta(g["meta"])
+    data = R.synth_demo(0, 2, 14, arch["Db"], arch["Da"], kind="iid")
+    names = sorted(k.split("::")[1] for k in g.files if k.startswith("ref_file::"))
+    assert names == ["model.pt", "model.pth", "motor_decoder.pt", "task_encoder.pt", "world_model.pt"]
+    for f in names:
+        (tmp_path / f).write_bytes(g["ref_file::" + f].tobytes())
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)           # what the reference held
+    tr = make_trainer(arch, data, 8, device="cpu")
+    tr.restore(str(tmp_path / "model.pth"))
+    assert all(torch.equal(v, sd[k]) for k, v in tr.model.state_dict().items())
+    tr2 = make_trainer(arch, data, 8, device="cpu")
+    tr2.model.load_weights(str(tmp_path / "model.pt"))
+    assert all(torch.equal(v, sd[k]) for k, v in tr2.model.state_dict().items())
+    tr3 = make_trainer(arch, data, 8, device="cpu")
+    tr3.model.load_weights_task_encoder(str(tmp_path / "task_encoder.pt"))
+    tr3.model.load_weights_motor_decoder(str(tmp_path / "motor_decoder.pt"))
+    tr3.model.load_weights_world_model(str(tmp_path / "world_model.pt"))
+    assert all(torch.equal(v, sd[k]) for k, v in tr3.model.state_dict().items() if not k.startswith("_value_branch"))
+    # (b)
+    for k in ("load_checkpoint", "load_weights", "per_net_loaders"):
+        assert bool(g["reference_accepts::" + k])
+    sd2 = R.perturb_biases(R.init_state_dict(arch, seed=7), seed=9)
+    m = R.RefModel(arch)
+    m.load_state_dict(sd2)
+    m.eps_source = lambda shape: torch.zeros(shape)
+    with torch.no_grad():
+        logits = m(torch.from_numpy(g["obs"]))
+    np.testing.assert_allclose(logits.numpy(), g["reference_logits_after_loading_our_files"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(m.cur_future_state.numpy(), g["reference_future_state"], rtol=1e-6, atol=1e-7)
