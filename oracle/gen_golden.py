@@ -292,6 +292,38 @@ def case_anchor(name):
     print("wrote", name, fix["world_epoch_losses"], fix["joint_epoch_losses"])
 
 
+def case_ingest(name, arch):
+    """Dataset ingest variants of the reference (tpv:94-164): two --data_train files merged, and the
+    --num_data cap; window counts, batch counts and digests of the loader's first / last batches."""
+    d1 = R.synth_demo(seed=0, n_episodes=2, n_steps=14, dim_body=arch["Db"], dim_action=arch["Da"], kind="iid")
+    d2 = R.synth_demo(seed=5, n_episodes=3, n_steps=11, dim_body=arch["Db"], dim_action=arch["Da"], kind="iid")
+    fix = {}
+    with tempfile.TemporaryDirectory() as td:
+        p1, p2 = os.path.join(td, "a.pkl"), os.path.join(td, "b.pkl")
+        R.write_demo(p1, d1)
+        R.write_demo(p2, d2)
+        for tag, num in (("all", None), ("cap", 37)):
+            argv = ["--data_train", p1, "--data_train", p2, "--batch_size", "8", "--max_iter", "10",
+                    "--max_iter_world_model", "2", "--latent_dim", str(arch["Z"])]
+            T.args = T.arg_parser().parse_args(argv)
+            T.args.num_data = num
+            cfg = resolve_grid(T.get_trainer_config(T.args))
+            cfg["TE_width"], cfg["TE_depth"] = arch["te"]
+            cfg["MD_width"], cfg["MD_depth"] = arch["md"]
+            cfg["world_model_width"], cfg["world_model_depth"] = arch["wm"]
+            tr = T.TrainModel(cfg)
+            batches = list(tr.train_loader)
+            fix[tag + "_n_windows"] = np.array(len(tr.train_loader.dataset))
+            fix[tag + "_n_batches"] = np.array(len(batches))
+            fix[tag + "_last_batch_size"] = np.array(batches[-1][0].shape[0])
+            for b, nm in ((0, "first"), (len(batches) - 1, "last")):
+                fix["%s_%s_x_digest" % (tag, nm)] = R.tensor_digest(batches[b][0])
+                fix["%s_%s_y_digest" % (tag, nm)] = R.tensor_digest(batches[b][1])
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"]])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
+    print("wrote", name, {k: int(v) for k, v in fix.items() if k.endswith(("n_windows", "n_batches", "last_batch_size"))})
+
+
 def case_checkpoint_interop(name, arch):
     """Both directions of the checkpoint drop-in, with the REFERENCE's own classes:
     (a) the five files written by the reference's save_checkpoint are stored byte for byte (data
@@ -371,6 +403,7 @@ def main():
         "train_c1": lambda: case_training("train_c1", c1, 4, 200, 64, m_world=2, n_epochs=4,
                                           full=False),
         "anchor_c1": lambda: case_anchor("anchor_c1"),
+        "ingest_tiny": lambda: case_ingest("ingest_tiny", tiny),
         "ckpt_interop_tiny": lambda: case_checkpoint_interop("ckpt_interop_tiny", tiny),
         "look3_tiny": lambda: case_lookahead("look3_tiny", tiny, 2, 15, 8, lookahead=3, full=True),
         "look2_c1": lambda: case_lookahead("look2_c1", c1, 2, 200, 64, lookahead=2, full=False),

@@ -411,3 +411,34 @@ def test_checkpoint_interop_with_the_reference_both_directions(golden, tmp_path)
         logits = m(torch.from_numpy(g["obs"]))
     np.testing.assert_allclose(logits.numpy(), g["reference_logits_after_loading_our_files"], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(m.cur_future_state.numpy(), g["reference_future_state"], rtol=1e-6, atol=1e-7)
+
+
+def test_multi_file_merge_and_num_data_cap_match_the_reference(golden, tmp_path):
+    """Two --data_train files (tpv:94-114) and the --num_data cap (tpv:137-138), captured from the
+    reference: window / batch counts and the loader's first and last minibatches -- for the pickle
+    path and for packed .pvd files."""
+    g = golden("ingest_tiny")
+    arch = arch_from_meta(g["meta"])
+    d1 = R.synth_demo(0, 2, 14, arch["Db"], arch["Da"], kind="iid")
+    d2 = R.synth_demo(5, 3, 11, arch["Db"], arch["Da"], kind="iid")
+    p1, p2 = str(tmp_path / "a.pkl"), str(tmp_path / "b.pkl")
+    R.write_demo(p1, d1)
+    R.write_demo(p2, d2)
+    q1, q2 = str(tmp_path / "a.pvd"), str(tmp_path / "b.pvd")
+    T.save_packed(T.load_dataset_for_PhysicsVAE([p1]), q1, meta={k: d1[k] for k in T.META_KEYS})
+    T.save_packed(T.load_dataset_for_PhysicsVAE([p2]), q2, meta={k: d2[k] for k in T.META_KEYS})
+    for files in ([p1, p2], [q1, q2]):
+        for tag, num in (("all", None), ("cap", 37)):
+            ds = T.load_dataset_for_PhysicsVAE(files, num_samples=num)
+            loader = TM.WindowLoader(ds, 8)
+            batches = list(loader)
+            assert len(ds) == int(g[tag + "_n_windows"]) and len(loader) == int(g[tag + "_n_batches"])
+            assert batches[-1][0].shape[0] == int(g[tag + "_last_batch_size"])
+            for b, nm in ((0, "first"), (len(batches) - 1, "last")):
+                np.testing.assert_array_equal(R.tensor_digest(batches[b][0]), g["%s_%s_x_digest" % (tag, nm)])
+                np.testing.assert_array_equal(R.tensor_digest(batches[b][1]), g["%s_%s_y_digest" % (tag, nm)])
+    d3 = dict(d2, dim_action=arch["Da"] + 1)                          # meta mismatch is refused like upstream
+    p3 = str(tmp_path / "c.pkl")
+    R.write_demo(p3, d3)
+    with pytest.raises(AssertionError):
+        T.load_dataset_for_PhysicsVAE([p1, p3])
