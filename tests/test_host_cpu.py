@@ -442,3 +442,34 @@ def test_multi_file_merge_and_num_data_cap_match_the_reference(golden, tmp_path)
     R.write_demo(p3, d3)
     with pytest.raises(AssertionError):
         T.load_dataset_for_PhysicsVAE([p1, p3])
+
+
+def test_pretrained_weight_options_of_the_constructor(tmp_path):
+    """rmt:709-727: `load_weights`, `*_load_weights` keys of custom_model_config (the trainer's
+    --world_model flag feeds world_model_load_weights, tpv:247) load at construction."""
+    arch = R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2))
+    data = R.synth_demo(0, 2, 14, 7, 3)
+    src = make_trainer(arch, data, 8, device="cpu")
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=11), seed=12)
+    src.model.load_state_dict(sd)
+    src.save_checkpoint(str(tmp_path))
+    # --world_model: only the world model comes from the file
+    td = str(tmp_path / "d.pkl")
+    R.write_demo(td, data)
+    argv = ["--data_train", td, "--batch_size", "8", "--max_iter_world_model", "0", "--latent_dim", "4",
+            "--TE_width", "16", "--TE_depth", "2", "--MD_width", "24", "--MD_depth", "2",
+            "--world_model_width", "32", "--world_model_depth", "2", "--world_model", str(tmp_path / "world_model.pt")]
+    T.args = T.arg_parser().parse_args(argv)
+    cfg = T.get_trainer_config(T.args)
+    cfg["model"]["custom_model_config"]["device"] = "cpu"
+    tr = T.TrainModel(cfg)
+    got = tr.model.state_dict()
+    assert all(torch.equal(got[k], sd[k]) for k in got if k.startswith("_world_model"))
+    assert not all(torch.equal(got[k], sd[k]) for k in got if k.startswith("_task_encoder"))
+    # load_weights: everything; per-net keys with their learnable flags
+    cfg2 = T.get_trainer_config(T.args)
+    cmc = cfg2["model"]["custom_model_config"]
+    cmc.update(device="cpu", world_model_load_weights=None, load_weights=str(tmp_path / "model.pt"),
+               task_encoder_load_weights=str(tmp_path / "task_encoder.pt"), task_encoder_learnable=False)
+    tr2 = T.TrainModel(cfg2)
+    assert all(torch.equal(v, sd[k]) for k, v in tr2.model.state_dict().items())
