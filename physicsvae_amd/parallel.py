@@ -12,6 +12,7 @@ moments are replicated and every rank applies the identical update to the identi
 reduced gradient, so replicas stay bit-identical.
 """
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -60,12 +61,31 @@ class DataParallel:
             return engine.has_comm
         if os.environ.get("PVAE_DP_TRANSPORT", "rccl") != "rccl" or dist.get_backend(self.group) != "nccl":
             return False
-        try:
-            box = [engine.comm_unique_id() if self.rank == 0 else None]
-            dist.broadcast_object_list(box, src=0, group=self.group)
-            engine.comm_init(self.rank, self.world, box[0])
-        except Exception as exc:                                   # noqa: BLE001
-            print("[physicsvae_amd] in-library RCCL exchange unavailable (%s); using torch.distributed" % exc)
+        # Every step below is collective: a rank that hits an error must still take part, then all
+        # ranks agree (MIN over a success flag) on ONE transport -- a rank raising on its own would
+        # leave the others waiting in the broadcast, or later in mismatched collectives.
+        uid, err = None, None
+        if self.rank == 0:
+            try:
+                uid = engine.comm_unique_id()
+            except Exception as exc:                               # noqa: BLE001
+                err = str(exc)
+        box = [uid]
+        dist.broadcast_object_list(box, src=0, group=self.group)
+        ok = box[0] is not None
+        if ok:
+            try:
+                engine.comm_init(self.rank, self.world, box[0])
+            except Exception as exc:                               # noqa: BLE001
+                ok, err = False, str(exc)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=engine.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) != 1:
+            if engine.has_comm:
+                engine.comm_destroy()
+            if self.rank == 0 or err:
+                print("[physicsvae_amd] in-library RCCL exchange unavailable (%s); using torch.distributed"
+                      % (err or "another rank failed"), file=sys.stderr)
             return False
         return True
 
