@@ -18,11 +18,15 @@
 // L2 locality only); each XCD is given a contiguous range of p-tiles and all q-tiles of it, so
 // the P panel it streams is fetched once per XCD and the (small) Q operand stays in that L2.
 //
-// What bounds these kernels (tools/gemm_ablate.hip on MI355X, profiles/): a 32x32 output tile
-// per CU is 8 flop per operand byte, and the per-CU load path sustains ~27 B/clk for this
-// pattern (~14 TB/s over 256 CUs, L2-resident): 250-330 ns per 16 KB k-tile against 213 ns of
-// MFMA work, so forward/dgrad are load-path bound at B = 256; wgrad (64x64 tiles, 16 flop/B)
-// is matrix-pipe bound in its main loop and HBM-bound in its Adam epilogue.
+// What bounds these kernels (tools/timeline_probe.hip, pair_probe.hip, wgrad_probe.hip, mfma_rate.hip
+// on MI355X): v_mfma_f32_16x16x4_f32 issues every 32 cycles at 2.35-2.39 GHz,
+// i.e. 218 ns for the 16 MFMAs a compute wave spends on a 32x32x64 k-tile.  A forward / dgrad
+// launch is ~1.7 us of launch + drain, ~1 us until the first k-tile is in LDS, 272 ns per k-tile
+// (the per-CU load path delivers a 16 KB tile in 170-240 ns when nothing else runs) and ~0.5 us of
+// split-K reduction + epilogue; the weight-gradient body runs at ~63 % of the matrix pipe's issue
+// rate (one LDS round trip in front of every 8 MFMAs) and its Adam epilogue moves 24 B per
+// parameter.  hipcc's wait-count pass only stays exact in branch-free loop bodies, which is why the
+// register-staged loops are written as full groups plus a guarded tail.
 #pragma once
 #include <hip/hip_runtime.h>
 
