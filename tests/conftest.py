@@ -14,6 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
 
 
+def pytest_sessionstart(session):
+    """Make sure libpvae_gfx950.so exists and is not older than its sources (hipcc cross-compiles
+    without a GPU, ~40 s).  A missing compiler is only an error if there is no library at all."""
+    from physicsvae_amd import build
+    try:
+        build.build(force=False)
+    except Exception as exc:                                       # noqa: BLE001
+        if not os.path.exists(build.LIB):
+            raise pytest.UsageError("libpvae_gfx950.so is missing and could not be built: %s" % exc)
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():
