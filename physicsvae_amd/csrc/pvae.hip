@@ -57,13 +57,12 @@ struct Profiler {
         }
         cat[n] = category;
         flops[n] = fl;
-        hipEventRecord(ev[n][0], st);
+        if (hipEventRecord(ev[n][0], st) != hipSuccess) return -1;
         return n;
     }
     void end(int slot, hipStream_t st) {
         if (slot < 0) return;
-        hipEventRecord(ev[slot][1], st);
-        n = slot + 1;
+        if (hipEventRecord(ev[slot][1], st) == hipSuccess) n = slot + 1;
     }
 };
 static Profiler g_prof;
