@@ -1272,8 +1272,13 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
         const int krows = blocks * u.rows_pad;
         const AdamScalars as = adam_scalars(sp, n);
         const bool last_net = k + 1 == train_nets.size();
-        for (int i = (int)N->layers.size() - 1; i >= 0; --i) {
-            const bool with_fold = fold && last_net && i == 0;
+        // two layers per launch (wgrad_pair_kernel), last layer first; an odd layer count leaves layer 0
+        // on its own.  The launch that contains layer 0 of the last net also finalises the losses.
+        const bool pairs = c->pair_launch && krows > 0;
+        for (int i = (int)N->layers.size() - 1; i >= 0;) {
+            const int j = (pairs && i >= 1) ? i - 1 : -1;             // second layer of this launch
+            const int lo = j >= 0 ? j : i;
+            const bool with_fold = fold && last_net && lo == 0;
             LossFinal foldv;
             memset(&foldv, 0, sizeof(foldv));
             if (with_fold) foldv = *fold;
@@ -1281,29 +1286,41 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
                 const Layer& l = N->layers[i];
                 const float* dz = w + nw->dz[i];
                 const float* xin = i == 0 ? w + nw->in : w + nw->act[i - 1];
-                const int pw = g_prof.begin(2, 2.0 * rowsf * blocks * l.n_in * l.n_out, st);
+                double fl = 2.0 * rowsf * blocks * l.n_in * l.n_out;
+                if (j >= 0) fl += 2.0 * rowsf * blocks * N->layers[j].n_in * N->layers[j].n_out;
+                const int pw = g_prof.begin(2, fl, st);
                 int rc2 = 0;
-                if (krows == 0) {
-                    rc2 = 0;                   // nothing reached this net: gradient stays as it is
-                } else if (fused) {
-                    EpiGradAdam e{c->params + l.w_off, c->m + l.w_off, c->v + l.w_off, l.ld, as};
-                    e.b = c->params + l.b_off; e.bm = c->m + l.b_off; e.bv = c->v + l.b_off;
-                    if (with_fold) e.loss = foldv;
-                    hipError_t he = gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, krows, e, st);
-                    if (he != hipSuccess) rc2 = fail(-10, "gemm_wgrad: %s", hipGetErrorString(he));
-                } else {
-                    EpiGradStore e{c->grads + l.w_off, l.ld};
-                    e.gb = c->grads + l.b_off;
-                    if (with_fold) e.loss = foldv;
-                    hipError_t he = gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, krows, e, st);
-                    if (he != hipSuccess) rc2 = fail(-10, "gemm_wgrad: %s", hipGetErrorString(he));
+                auto adam_of = [&](const Layer& y) {
+                    EpiGradAdam e{c->params + y.w_off, c->m + y.w_off, c->v + y.w_off, y.ld, as};
+                    e.b = c->params + y.b_off; e.bm = c->m + y.b_off; e.bv = c->v + y.b_off;
+                    return e;
+                };
+                auto store_of = [&](const Layer& y) {
+                    EpiGradStore e{c->grads + y.w_off, y.ld};
+                    e.gb = c->grads + y.b_off;
+                    return e;
+                };
+                auto go = [&](auto e1, auto e2) -> hipError_t {
+                    if (with_fold) e1.loss = foldv;                   // block 0 of the launch runs e1's problem
+                    if (j < 0) return gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, krows, e1, st);
+                    const Layer& l2 = N->layers[j];
+                    const float* dz2 = w + nw->dz[j];
+                    const float* xin2 = j == 0 ? w + nw->in : w + nw->act[j - 1];
+                    return gemm_wgrad_pair(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, e1, dz2, l2.n_out_pad, xin2, l2.ld,
+                                           l2.n_out_pad, l2.ld, e2, krows, st);
+                };
+                if (krows > 0) {                   // (0: nothing reached this net, its gradient stays as it is)
+                    const Layer& l2 = N->layers[j >= 0 ? j : i];
+                    const hipError_t he = fused ? go(adam_of(l), adam_of(l2)) : go(store_of(l), store_of(l2));
+                    if (he != hipSuccess) rc2 = fail(-10, "weight-gradient launch: %s", hipGetErrorString(he));
                 }
                 g_prof.end(pw, st);
                 return rc2;
             });
-            sref.ready_off = N->layers[i].w_off;
-            sref.ready_cnt = N->layers[i].b_off + N->layers[i].n_out_pad - N->layers[i].w_off;
+            sref.ready_off = N->layers[lo].w_off;
+            sref.ready_cnt = N->layers[i].b_off + N->layers[i].n_out_pad - N->layers[lo].w_off;
             sref.net = n;
+            i = lo - 1;
         }
     }
 }
