@@ -241,8 +241,10 @@ int pvae_reparam(pvae_ctx* ctx, const float* mu_logvar, int32_t rows, const floa
                  uint64_t rng_seed, uint64_t rng_offset, float* z_out, void* stream);
 
 /* Per-kernel timing with HIP events on the launch stream (bench.py's `roofline` object).
- * While enabled every contraction launch is bracketed by an event pair (this serialises the
- * host a little, so it is used in a separate instrumented pass, never in a timed region).
+ * While enabled every contraction launch carries an event pair stamped by the device at the
+ * kernel's own start and end (hipExtLaunchKernelGGL), i.e. the duration rocprofv3 --kernel-trace
+ * reports, without the launch seam (this serialises the host a little, so it is used in a
+ * separate instrumented pass, never in a timed region).
  * category: 0 = forward kernel, 1 = input-gradient kernel (alone), 2 = weight-gradient(+Adam)
  * launches (single or the two trailing layers in one launch), 3 = fused input-gradient +
  * weight-gradient(+Adam) launch.

@@ -49,7 +49,10 @@ struct Profiler {
     int cat[kMax];
     double flops[kMax];
     int n = 0, created = 0;
-    int begin(int category, double fl, hipStream_t st) {
+    // begin() arms the slot's event pair; the launch wrapper (PVAE_LAUNCH, pvae_gemm.h) hands it to
+    // hipExtLaunchKernelGGL, so the pair brackets the kernel itself and not the launch seam.  Every
+    // profiled range holds exactly one launch; a range that launched nothing is dropped.
+    int begin(int category, double fl, hipStream_t) {
         if (!on || n >= kMax) return -1;
         if (n >= created) {
             if (hipEventCreate(&ev[n][0]) != hipSuccess || hipEventCreate(&ev[n][1]) != hipSuccess) return -1;
@@ -57,12 +60,14 @@ struct Profiler {
         }
         cat[n] = category;
         flops[n] = fl;
-        if (hipEventRecord(ev[n][0], st) != hipSuccess) return -1;
+        g_kernel_ev[0] = ev[n][0];
+        g_kernel_ev[1] = ev[n][1];
         return n;
     }
-    void end(int slot, hipStream_t st) {
+    void end(int slot, hipStream_t) {
         if (slot < 0) return;
-        if (hipEventRecord(ev[slot][1], st) == hipSuccess) n = slot + 1;
+        if (!g_kernel_ev[0]) n = slot + 1;          // consumed by a launch
+        g_kernel_ev[0] = g_kernel_ev[1] = nullptr;
     }
 };
 static Profiler g_prof;
@@ -423,7 +428,7 @@ static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st, const F
             float* o2 = (l.last && tail.out2) ? tail.out2 : nullptr;
             const dim3 grid(l.n_out_pad / 4), block(256);
 #define PVAE_GEMV(R)                                                                                        \
-    hipLaunchKernelGGL((gemv_rows_kernel<R>), grid, block, 0, st, x, ldx, c->params + l.w_off, l.ld,           \
+    PVAE_LAUNCH((gemv_rows_kernel<R>), grid, block, st, x, ldx, c->params + l.w_off, l.ld,           \
                        c->params + l.b_off, out, l.n_out_pad, l.ld, l.last ? 0 : 1, o2, tail.ld2, tail.off2, tail.n2)
             if (rows == 1) PVAE_GEMV(1);
             else if (rows == 2) PVAE_GEMV(2);

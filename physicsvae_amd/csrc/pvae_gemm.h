@@ -29,6 +29,7 @@
 // register-staged loops are written as full groups plus a guarded tail.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdlib>
 // Timeline probe (tools/timeline_probe.hip defines PVAE_TIMELINE): thread `tid_` of each workgroup
@@ -1184,6 +1185,18 @@ struct EpiGradAdam {          // weight gradient consumed in registers by Adam (
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+// When the profiler arms a pair of events, the next launch goes through hipExtLaunchKernelGGL, which
+// stamps them with the kernel's own start and end on the device (what rocprofv3 reports as the kernel
+// duration); events recorded around a plain launch would include the launch seam.
+static hipEvent_t g_kernel_ev[2] = {nullptr, nullptr};
+#define PVAE_LAUNCH(kernel, grid, block, st, ...)                                                          \
+    do {                                                                                                   \
+        if (g_kernel_ev[0]) {                                                                              \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, st, g_kernel_ev[0], g_kernel_ev[1], 0, __VA_ARGS__); \
+            g_kernel_ev[0] = g_kernel_ev[1] = nullptr;                                                     \
+        } else                                                                                               \
+            hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                   \
+    } while (0)
 struct GemmGrid {
     int tiles_q, tiles_p, p_per_xcd, grid;
 };
@@ -1208,12 +1221,12 @@ inline hipError_t gemm_forward_epi(const float* X, int ldx, const float* W, int 
                                    const Epi& e, hipStream_t st) {
     if (forward_uses_16x16(M, N)) {
         const GemmGrid g = make_grid(M, N, 16, 16);
-        hipLaunchKernelGGL((gemm_splitk_reg16_kernel<Epi>), dim3(g.grid), dim3(256), 0, st,
+        PVAE_LAUNCH((gemm_splitk_reg16_kernel<Epi>), dim3(g.grid), dim3(256), st,
                            GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
         return hipGetLastError();
     }
     const GemmGrid g = make_grid(M, N, 32, 32);
-    hipLaunchKernelGGL((gemm_splitk_ws_kernel<true, Epi>), dim3(g.grid), dim3(512), 0, st,
+    PVAE_LAUNCH((gemm_splitk_ws_kernel<true, Epi>), dim3(g.grid), dim3(512), st,
                        GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
     return hipGetLastError();
 }
@@ -1227,7 +1240,7 @@ inline hipError_t gemm_dgrad(const float* dZ, int ldz, const float* W, int ldw, 
                              int ldm, float* dX, int ldo, int M, int Kin, int N, hipStream_t st) {
     const EpiMask e{dX, ldo, mask, ldm};
     const GemmGrid g = make_grid(M, Kin, 32, 32);
-    hipLaunchKernelGGL((gemm_splitk_ws_kernel<false, EpiMask>), dim3(g.grid), dim3(512), 0, st,
+    PVAE_LAUNCH((gemm_splitk_ws_kernel<false, EpiMask>), dim3(g.grid), dim3(512), st,
                        GemmArgs{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
     return hipGetLastError();
 }
@@ -1236,7 +1249,7 @@ template <class EpiD>
 inline hipError_t gemm_dgrad_epi(const float* dZ, int ldz, const float* W, int ldw, int M, int Kin, int N,
                                  const EpiD& e, hipStream_t st) {
     const GemmGrid g = make_grid(M, Kin, 32, 32);
-    hipLaunchKernelGGL((gemm_splitk_ws_kernel<false, EpiD>), dim3(g.grid), dim3(512), 0, st,
+    PVAE_LAUNCH((gemm_splitk_ws_kernel<false, EpiD>), dim3(g.grid), dim3(512), st,
                        GemmArgs{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
     return hipGetLastError();
 }
@@ -1246,7 +1259,7 @@ template <class Epi>
 inline hipError_t gemm_wgrad(const float* dZ, int ldz, const float* X, int ldx, int N, int Kin, int M,
                              const Epi& e, hipStream_t st) {
     const GemmGrid g = make_grid(N, Kin, 64, 64);
-    hipLaunchKernelGGL((gemm_wgrad_reg_kernel<Epi>), dim3(g.grid), dim3(256), 0, st,
+    PVAE_LAUNCH((gemm_wgrad_reg_kernel<Epi>), dim3(g.grid), dim3(256), st,
                        GemmArgs{dZ, ldz, X, ldx, M, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
     return hipGetLastError();
 }
@@ -1260,7 +1273,7 @@ inline hipError_t gemm_wgrad_pair(const float* dZ1, int ldz1, const float* X1, i
     StageArgs sa;
     memset(&sa, 0, sizeof(sa));
     if (next) sa = *next;                     // rows_pad extra blocks gather the next minibatch
-    hipLaunchKernelGGL((wgrad_pair_kernel<EpiW>), dim3(g1.grid + g2.grid + sa.rows_pad), dim3(256), 0, st,
+    PVAE_LAUNCH((wgrad_pair_kernel<EpiW>), dim3(g1.grid + g2.grid + sa.rows_pad), dim3(256), st,
                        GemmArgs{dZ1, ldz1, X1, ldx1, M, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, e1, g1.grid,
                        GemmArgs{dZ2, ldz2, X2, ldx2, M, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, e2,
                        g1.grid + g2.grid, sa);
@@ -1273,7 +1286,7 @@ inline hipError_t gemm_bwd_pair_epi(const float* dZd, int ldzd, const float* Wd,
                                     int Kinw, int Mw, const EpiW& ew, hipStream_t st) {
     const GemmGrid g1 = make_grid(Md, Kind, 32, 32);
     const GemmGrid g2 = make_grid(Nw, Kinw, 64, 64);
-    hipLaunchKernelGGL((bwd_pair_kernel<EpiD, EpiW>), dim3(g1.grid + g2.grid), dim3(256), 0, st,
+    PVAE_LAUNCH((bwd_pair_kernel<EpiD, EpiW>), dim3(g1.grid + g2.grid), dim3(256), st,
                        GemmArgs{dZd, ldzd, Wd, ldwd, Nd, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, g1.grid,
                        GemmArgs{dZw, ldzw, Xw, ldxw, Mw, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, ew);
     return hipGetLastError();
