@@ -187,8 +187,19 @@ int pvae_adam_segment(pvae_ctx* ctx, int net, int64_t offset, int64_t count, con
  *   pvae_allreduce_grads  in-place SUM all-reduce of a slice of the gradient arena, stream-ordered
  *                         on `stream` like any other launch of this library (no side stream)
  *   pvae_dp_train_step    one data-parallel optimizer step in ONE call: gather + forward +
- *                         backward (gradients scaled by 1/global_rows) + per-net all-reduce +
- *                         Adam; rows may be 0 (empty shard of a ragged last global batch);
+ *                         backward (gradients scaled by 1/global_rows) + all-reduce + Adam.
+ *                         Default: one reduction per stack, in line on `stream` as soon as the
+ *                         stack's gradient is final (no cross-stream hand-off: one costs
+ *                         ~18 us of idle GPU each way on this runtime).
+ *                         With bucket_bytes > 0 (pvae_comm_config) the exchange is bucketed
+ *                         and overlapped instead: a stack's gradient becomes final last layer
+ *                         first, and every time whole layers worth bucket_bytes are done
+ *                         that bucket is reduced and Adam-applied on the library's own
+ *                         high-priority exchange stream while `stream` keeps launching the
+ *                         rest of the backward pass; `stream` rejoins (event wait) before the
+ *                         call returns.  Bucket boundaries depend on the layout and
+ *                         bucket_bytes only -- identical on every rank.  rows may be 0 (empty
+ *                         shard of a ragged last global batch);
  *                         [next_first, +next_rows) = this rank's shard of the following step
  *                         (0 rows: unknown), gathered inside this step's last launch as in
  *                         pvae_train_step_prefetch.
@@ -197,6 +208,15 @@ int pvae_adam_segment(pvae_ctx* ctx, int net, int64_t offset, int64_t count, con
 int pvae_comm_unique_id(void* id128);
 int pvae_comm_init(pvae_ctx* ctx, int rank, int world, const void* id128);
 int pvae_comm_destroy(pvae_ctx* ctx);
+/* Exchange settings of pvae_dp_train_step (same values on every rank): bucket_bytes (default 0 =
+ * one bucket per stack, reduced in line on the caller's stream; PVAE_DP_BUCKET_MB at
+ * pvae_comm_init overrides the default); test_delay_us > 0 puts a spin kernel of that length in
+ * front of every reduction (ordering tests).  Overlap pays when the backward work still to be
+ * launched after a bucket closes exceeds the two hand-offs (long stacks, lookahead > 1, slow
+ * links); with the caller on the NULL stream also set GPU_MAX_HW_QUEUES=8 before HIP starts --
+ * with the default 4 hardware queues the exchange stream can share one with the NULL stream and
+ * every hand-off then stalls ~250 us. */
+int pvae_comm_config(pvae_ctx* ctx, int64_t bucket_bytes, int32_t test_delay_us);
 int pvae_allreduce_grads(pvae_ctx* ctx, int64_t offset, int64_t count, void* stream);
 int pvae_dp_train_step(pvae_ctx* ctx, int phase, int64_t first_window, int32_t rows,
                        const pvae_step_params* sp, const float* eps, float* loss_out,

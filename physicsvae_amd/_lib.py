@@ -8,6 +8,9 @@ import os
 # ROCm 7 defaults to device kernargs on this GPU; pin it so the behaviour does not depend on that.
 # (Read by the HIP runtime when it initialises, i.e. at the first CUDA/HIP call of the process.)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+if os.environ.get("PVAE_DP_BUCKET_MB", "0") not in ("", "0", "0.0"):
+    # overlapped gradient exchange asked for: keep its stream off the NULL stream's hardware queue
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be the first one
 # the process loads: our library then binds to the SAME runtime instance (same soname), which is
@@ -75,6 +78,7 @@ _SIGS = {
     "pvae_comm_unique_id": (C.c_int, [_P]),
     "pvae_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "pvae_comm_destroy": (C.c_int, [_P]),
+    "pvae_comm_config": (C.c_int, [_P, C.c_int64, C.c_int32]),
     "pvae_allreduce_grads": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     "pvae_dp_train_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P,
                                      C.c_int64, C.c_int32, _P]),

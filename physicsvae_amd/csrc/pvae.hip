@@ -122,6 +122,14 @@ static int rccl_load() {
 struct pvae_ctx {
     void* comm = nullptr;        // ncclComm_t of the data-parallel group (pvae_comm_init)
     int comm_rank = 0, comm_world = 1;
+    // overlapped gradient exchange (pvae_dp_train_step): the buckets of a stack are reduced and
+    // applied on comm_stream while the compute stream keeps producing the next ones
+    hipStream_t comm_stream = nullptr;
+    static constexpr int kMaxBuckets = 64;
+    hipEvent_t bucket_ready[kMaxBuckets] = {};
+    hipEvent_t comm_done = nullptr;
+    int64_t bucket_bytes = 0;          // 0: one bucket per stack, reduced in line on the compute stream
+    int comm_test_delay_us = 0;        // tests: a spin kernel in front of every reduction
     Layout L;
     Workspace W;
     float* params = nullptr;
@@ -1442,6 +1450,22 @@ int pvae_comm_init(pvae_ctx* c, int rank, int world, const void* id128) {
     void* comm = nullptr;
     RCCL_TRY(g_rccl.CommInitRank(&comm, world, id, rank));
     c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+    if (!c->comm_stream) {
+        int lo = 0, hi = 0;                                   // hi = numerically lowest = most urgent
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, hi));
+        for (hipEvent_t& e : c->bucket_ready) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->comm_done, hipEventDisableTiming));
+    }
+    if (const char* e = getenv("PVAE_DP_BUCKET_MB")) c->bucket_bytes = (int64_t)(atof(e) * (1 << 20));
+    return 0;
+}
+
+int pvae_comm_config(pvae_ctx* c, int64_t bucket_bytes, int32_t test_delay_us) {
+    if (!c) return fail(-1, "null ctx");
+    if (bucket_bytes < 0 || test_delay_us < 0 || test_delay_us > 100000) return fail(-1, "bad exchange settings");
+    c->bucket_bytes = bucket_bytes;
+    c->comm_test_delay_us = test_delay_us;
     return 0;
 }
 
@@ -1451,7 +1475,59 @@ int pvae_comm_destroy(pvae_ctx* c) {
         RCCL_TRY(g_rccl.CommDestroy(c->comm));
         c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0;
     }
+    if (c->comm_stream) {
+        HIP_TRY(hipStreamSynchronize(c->comm_stream));
+        HIP_TRY(hipStreamDestroy(c->comm_stream));
+        c->comm_stream = nullptr;
+        for (hipEvent_t& e : c->bucket_ready) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        if (c->comm_done) (void)hipEventDestroy(c->comm_done);
+        c->comm_done = nullptr;
+    }
     return 0;
+}
+
+// Exchange buckets of one stack: whole layers, last layer first (the order the backward pass
+// finishes them), closed as soon as they hold bucket_bytes.  A function of the layout and the
+// bucket size only, so every rank -- also one whose shard of a ragged last batch is empty --
+// issues the same sequence of reductions.
+struct Bucket { int64_t off, cnt; };
+static std::vector<Bucket> exchange_buckets(const pvae_ctx* c, int net) {
+    const NetLayout& N = c->L.net[net];
+    std::vector<Bucket> out;
+    if (c->bucket_bytes <= 0) { out.push_back({N.off, N.count}); return out; }
+    int64_t end = N.off + N.count;
+    for (int i = (int)N.layers.size() - 1; i >= 0; --i) {
+        const int64_t lo = i == 0 ? N.off : N.layers[i].w_off;
+        if ((end - lo) * (int64_t)sizeof(float) >= c->bucket_bytes || i == 0) {
+            out.push_back({lo, end - lo});
+            end = lo;
+        }
+    }
+    return out;
+}
+
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// Reduce one bucket over the ranks and apply Adam to it.  `cs` == `st`: in line.  Otherwise the
+// bucket is handed to the exchange stream behind an event, and the compute stream carries on.
+static int exchange_bucket(pvae_ctx* c, int net, const Bucket& b, const pvae_step_params* sp, hipStream_t st,
+                           hipStream_t cs, int& n_events) {
+    int rc;
+    if (cs != st) {
+        if (n_events >= pvae_ctx::kMaxBuckets) return fail(-2, "more than %d exchange buckets in a step", pvae_ctx::kMaxBuckets);
+        hipEvent_t e = c->bucket_ready[n_events++];
+        HIP_TRY(hipEventRecord(e, st));
+        HIP_TRY(hipStreamWaitEvent(cs, e, 0));
+    }
+    if (c->comm_test_delay_us > 0) {
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, cs, (long long)c->comm_test_delay_us * 100);   // 100 MHz
+        HIP_TRY(hipGetLastError());
+    }
+    if ((rc = pvae_allreduce_grads(c, b.off, b.cnt, cs))) return rc;
+    return pvae_adam_segment(c, net, b.off, b.cnt, sp, cs);
 }
 
 int pvae_allreduce_grads(pvae_ctx* c, int64_t offset, int64_t count, void* stream) {
@@ -1478,16 +1554,24 @@ int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t row
     hipStream_t st = (hipStream_t)stream;
     const int nets[2] = {phase == PVAE_PHASE_WORLD ? PVAE_NET_WM : PVAE_NET_MD,
                          phase == PVAE_PHASE_WORLD ? -1 : PVAE_NET_TE};      // backward order
+    hipStream_t cs = (c->bucket_bytes > 0 && c->comm_stream) ? c->comm_stream : st;
+    int n_events = 0;
+    auto join = [&]() -> int {                 // later work on the caller's stream sees the updated parameters
+        if (cs == st) return 0;
+        HIP_TRY(hipEventRecord(c->comm_done, cs));
+        HIP_TRY(hipStreamWaitEvent(st, c->comm_done, 0));
+        return 0;
+    };
     if (rows == 0) {
         // empty shard of a ragged last global batch: contribute zeros, apply the same update
         for (int n : nets) {
             if (n < 0) continue;
             const NetLayout& N = c->L.net[n];
             HIP_TRY(hipMemsetAsync(c->grads + N.off, 0, (size_t)N.count * sizeof(float), st));
-            if ((rc = pvae_allreduce_grads(c, N.off, N.count, stream))) return rc;
-            if ((rc = pvae_adam_segment(c, n, N.off, N.count, sp, stream))) return rc;
+            for (const Bucket& b : exchange_buckets(c, n))
+                if ((rc = exchange_bucket(c, n, b, sp, st, cs, n_events))) return rc;
         }
-        return 0;
+        return join();
     }
     // gather prefetch as in pvae_train_step_prefetch: this rank's next shard rides in the last launch
     const bool can = c->W.L == 1 && c->pair_launch && loss_out != nullptr && c->states != nullptr;
@@ -1510,18 +1594,35 @@ int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t row
     if ((rc = run_forward(c, phase, rows, sp, eps, true, S, st))) return rc;
     Plan plan;
     plan_backward(c, phase, rows, sp, true, false, S, st, plan);
-    // One bucket per net: the net's slices become final last layer first; when the slice that
-    // starts at the net's offset is done, the whole segment is reduced in place on THIS stream
-    // (no cross-stream hand-off) and Adam follows.  In the joint phase the decoder's reduction
-    // is queued before the encoder's backward launches and runs ahead of them in stream order.
+    // A stack's slices become final last layer first.  Each time the finished region reaches down
+    // to the start of the next exchange bucket, that bucket goes to the exchange stream (reduce over
+    // the ranks, then Adam on it) while this stream keeps launching the rest of the backward pass;
+    // the parameters a bucket's Adam rewrites are not read again in this step (the fused path
+    // rewrites them in the same launches).  The caller's stream rejoins at the end.
+    std::vector<Bucket> bk[PVAE_NUM_NETS];
+    size_t next_bk[PVAE_NUM_NETS] = {};
+    int64_t low[PVAE_NUM_NETS];
+    for (int n : nets)
+        if (n >= 0) { bk[n] = exchange_buckets(c, n); low[n] = c->L.net[n].off + c->L.net[n].count; }
     for (Stage& s : plan) {
         if ((rc = s.run())) break;
-        if (s.ready_cnt > 0 && s.net >= 0 && s.ready_off == c->L.net[s.net].off) {
-            const NetLayout& N = c->L.net[s.net];
-            if ((rc = pvae_allreduce_grads(c, N.off, N.count, stream))) break;
-            if ((rc = pvae_adam_segment(c, s.net, N.off, N.count, sp, stream))) break;
+        if (s.ready_cnt <= 0 || s.net < 0) continue;
+        const int n = s.net;
+        if (s.ready_off + s.ready_cnt != low[n]) {
+            rc = fail(-2, "backward plan finished [%lld, +%lld) of stack %d out of order", (long long)s.ready_off,
+                      (long long)s.ready_cnt, n);
+            break;
         }
+        low[n] = s.ready_off;
+        while (!rc && next_bk[n] < bk[n].size() && bk[n][next_bk[n]].off >= low[n])
+            rc = exchange_bucket(c, n, bk[n][next_bk[n]++], sp, st, cs, n_events);
+        if (rc) break;
     }
+    if (!rc)
+        for (int n : nets)
+            if (n >= 0 && next_bk[n] != bk[n].size()) rc = fail(-2, "stack %d left the backward pass unfinished", n);
+    const int jrc = join();
+    if (!rc) rc = jrc;
     if (!rc && c->next_carried) {
         c->pf.valid = true; c->pf.first = next_first; c->pf.rows = next_rows; c->pf.states = c->states;
     }

@@ -254,6 +254,12 @@ class HipEngine:
             _lib.check(self.lib.pvae_comm_destroy(self.ctx), "pvae_comm_destroy")
             self.has_comm = False
 
+    def comm_config(self, bucket_mb=0.0, test_delay_us=0):
+        """Exchange settings of dp_train_step: bucket size in MiB (0, the default: one in-line
+        reduction per stack; > 0: bucketed and overlapped on the library's exchange stream, see
+        include/pvae.h) and, for ordering tests, a delay in front of every reduction."""
+        _lib.check(self.lib.pvae_comm_config(self.ctx, int(bucket_mb * (1 << 20)), int(test_delay_us)), "pvae_comm_config")
+
     def allreduce_grads(self, off, cnt):
         self._need_gpu()
         _lib.check(self.lib.pvae_allreduce_grads(self.ctx, int(off), int(cnt), self._stream()), "pvae_allreduce_grads")

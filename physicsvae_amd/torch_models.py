@@ -169,6 +169,8 @@ class TrainModel(tune.Trainable):
         self.dp = parallel.DataParallel.from_env()
         self.dp_bucket_mb = float(config.get("dp_bucket_mb", os.environ.get("PVAE_DP_BUCKET_MB", 0)))
         self.dp.attach(self.engine)
+        if self.engine.has_comm and ("dp_bucket_mb" in config or "PVAE_DP_BUCKET_MB" in os.environ):
+            self.engine.comm_config(self.dp_bucket_mb)
         self.prefetch_gather = bool(config.get("prefetch_gather", os.environ.get("PVAE_PREFETCH", "1") != "0"))
         self.prepare_data(config)
         self.optimizer = HipAdam(self.model.parameters(), self.engine,
@@ -271,7 +273,7 @@ class TrainModel(tune.Trainable):
         which at ~120 us per step outweighs what finer-grained overlap could hide (measured with
         one rank through RCCL: 5 collectives per step 206 us, 1 per step see DESIGN.md)."""
         eng, dp = self.engine, self.dp
-        if eng.has_comm:                          # whole step inside the library (RCCL, one stream)
+        if eng.has_comm:       # whole step inside the library (RCCL; in line, or bucketed + overlapped)
             eng.dp_train_step(phase, first, rows, sp, eps=eps, loss_out=loss_out,
                               next_span=next_span if self.prefetch_gather else None)
             return

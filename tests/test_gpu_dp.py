@@ -188,3 +188,110 @@ def test_in_library_exchange_with_lookahead(golden):
         for a, b in zip(*res):
             assert torch.equal(a, b)
     eng.comm_destroy()
+
+
+@pytest.mark.parametrize("lookahead", [1, 2])
+@pytest.mark.parametrize("bucket_mb,delay_us", [(0.0, 0), (0.01, 0), (0.01, 400), (0.05, 150), (6.0, 400)])
+def test_overlapped_exchange_ordering(golden, lookahead, bucket_mb, delay_us):
+    """The bucketed exchange of pvae_dp_train_step runs on the library's own stream.  With every
+    bucket size (per layer ... per stack ... in line) and with the reductions artificially slowed
+    down by a spin kernel (so a missing event wait would let Adam or the next forward pass run on
+    half-finished data), several consecutive steps -- including an empty shard -- give the same
+    parameters and moments, bit for bit, as the single-stream fused step."""
+    from oracle import refpath as R
+    from physicsvae_amd import _lib
+    from physicsvae_amd.engine import make_step_params
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_trainer
+    arch = R.make_arch(23, 7, latent=8, te=(64, 2), md=(96, 3), wm=(128, 3))
+    data = R.synth_demo(0, 3, 60, 23, 7, kind="dynamics")
+    tr = make_trainer(arch, data, 32, device="cuda", extra={"lookahead": lookahead})
+    sd = R.perturb_biases(R.init_state_dict(arch, 1), 3)
+    eng = tr.engine
+    eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
+    eng.comm_init(0, 1, eng.comm_unique_id())
+    eng.comm_config(bucket_mb, delay_us)
+    es = R.eps_stream(2, 8)
+    eps = torch.stack([es(t, (32, 8)) for t in range(lookahead)]) if lookahead > 1 else es(0, (32, 8))
+    for phase, world, nets in ((_lib.PHASE_WORLD, True, [_lib.NET_WM]), (_lib.PHASE_JOINT, False, [_lib.NET_TE, _lib.NET_MD])):
+        c = R.phase_coeffs(world)
+        res = []
+        for dp in (False, True):
+            tr.model.load_state_dict(sd)
+            eng.exp_avg.zero_(); eng.exp_avg_sq.zero_()
+            out = torch.zeros(5, device="cuda")
+            for t in range(1, 6):
+                sp = make_step_params(lr=5e-4, adam_t=(t, t, t), a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"],
+                                      s_rec=c["s_rec_coeff"], cyc=c["vae_cycle_coeff"], global_rows=32)
+                if t == 3:                         # an empty shard in the middle of the run
+                    if dp:
+                        eng.dp_train_step(phase, 0, 0, sp)
+                    else:
+                        eng.segment(eng.grads, nets).zero_()
+                        eng.adam(nets, sp)
+                    continue
+                first = 32 * ((t - 1) % 3)
+                if dp:
+                    eng.dp_train_step(phase, first, 32, sp, eps=eps, loss_out=out, next_span=(32 * (t % 3), 32))
+                else:
+                    eng.train_step(phase, first, 32, sp, eps=eps, loss_out=out)
+            res.append((eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(), out.clone()))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+    eng.comm_destroy()
+
+
+def test_exchange_buckets_at_bench_sizes():
+    """BASELINE configs[1] sizes (4x1024 stacks, batch 256): 6 MiB buckets split every stack's
+    exchange in two; the overlapped run and the in-line run both equal the fused single-stream step
+    bit for bit.  (Prints the one-rank step times: what the hand-offs cost with nothing to hide.)"""
+    import contextlib, io, time
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from synth_demo import make_trainer as mk, synth_demo
+    from physicsvae_amd.engine import make_step_params
+    data = synth_demo(0, 4, 400, 197, 45)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr = mk(data, 256, "cuda")
+    eng = tr.engine
+    eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
+    eng.comm_init(0, 1, eng.comm_unique_id())
+    p0 = eng.params.clone()
+    out = torch.zeros(5, device="cuda")
+    side = torch.cuda.Stream()                 # not the NULL stream (see pvae_comm_config)
+    side.wait_stream(torch.cuda.current_stream())
+    for name in ("world", "joint"):
+        w = name == "world"
+        tr.model.set_learnable_task_encoder(not w); tr.model.set_learnable_motor_decoder(not w)
+        tr.model.set_learnable_world_model(w)
+        tr.read_loss_fn_coeff(world=w)
+        phase, nets = tr.phase()
+        res, rate = [], {}
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(side)
+        for mode in ("fused", "overlap", "inline"):
+            eng.params.copy_(p0); eng.exp_avg.zero_(); eng.exp_avg_sq.zero_()
+            if mode != "fused":
+                eng.comm_config(6.0 if mode == "overlap" else 0.0, 0)
+            n = 60
+            for rep in range(2):                   # second pass is the timed one
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n):
+                    sp = make_step_params(lr=1e-3, adam_t=(i + 1, i + 1, i + 1), a_rec=tr.a_rec_coeff, kl=tr.vae_kl_coeff,
+                                          s_rec=tr.s_rec_coeff, cyc=tr.vae_cycle_coeff, global_rows=256, seed=7,
+                                          offset=i * 65536)
+                    first = 256 * (i % 5)
+                    if mode == "fused":
+                        eng.train_step(phase, first, 256, sp, loss_out=out)
+                    else:
+                        eng.dp_train_step(phase, first, 256, sp, loss_out=out, next_span=(256 * ((i + 1) % 5), 256))
+                torch.cuda.synchronize()
+                rate[mode] = (time.perf_counter() - t0) / n * 1e6
+                if rep == 0:
+                    res.append((eng.params.clone(), eng.exp_avg.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1])
+        print("%s: fused %.1f us/step, dp overlapped %.1f, dp in line %.1f" % (name, rate["fused"], rate["overlap"], rate["inline"]))
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    eng.comm_destroy()
