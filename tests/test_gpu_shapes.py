@@ -1,0 +1,95 @@
+"""Randomised-shape sweep of the HIP path against the oracle: stack widths that are not multiples
+of any tile, depths 1..4 that differ per stack, tiny and odd observation / action / latent sizes,
+minibatches from 1 row up, lookahead 1..3, MSE and L1.  Every case: loss terms rel 1e-5, every
+gradient 1e-4 (samples on a ReLU kink excluded, see oracle.refpath.relu_kink_margin), the pad
+entries of the arena stay zero, and three optimizer steps with Adam fused into the weight-gradient
+launches equal gradient-store + flat Adam bit for bit.  Seeds are fixed: the sweep is deterministic."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import refpath as R
+from physicsvae_amd import _lib
+from physicsvae_amd.engine import make_step_params
+from util import make_trainer, max_err_scaled, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    r = np.random.default_rng(1000 + seed)
+    Db = int(r.integers(2, 72))
+    Da = int(r.integers(1, 34))
+    Z = int(r.integers(1, 24))
+    nets = [(int(r.choice([5, 17, 31, 64, 100, 129, 200, 257, 320])), int(r.integers(1, 5))) for _ in range(3)]
+    L = int(r.choice([1, 1, 1, 2, 3]))
+    rows = int(r.choice([1, 2, 7, 31, 32, 33, 64, 97, 130]))
+    loss = str(r.choice(["MSE", "MSE", "L1"]))
+    return dict(Db=Db, Da=Da, Z=Z, te=nets[0], md=nets[1], wm=nets[2], L=L, rows=rows, loss=loss)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_shapes_match_oracle(seed):
+    c = _case(seed)
+    L, rows, lk = c["L"], c["rows"], c["loss"]
+    arch = R.make_arch(c["Db"], c["Da"], latent=c["Z"], te=c["te"], md=c["md"], wm=c["wm"])
+    n_steps = rows + L + 3
+    data = R.synth_demo(seed, 2, n_steps, c["Db"], c["Da"], kind="dynamics")
+    X, Y = R.build_windows(data, lookahead=L)
+    x, y = next(iter(R.make_loader(X, Y, rows)))
+    assert x.shape[0] == rows
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=seed + 1), seed=seed + 3)
+    es = R.eps_stream(seed + 2, c["Z"])
+    eps = torch.stack([es(t, (rows, c["Z"])) for t in range(L)])
+    tr = make_trainer(arch, data, rows, device="cuda", extra={"lookahead": L, "loss": lk})
+    tr.model.load_state_dict(sd)
+    eng = tr.engine
+    for world in (True, False):
+        phase = _lib.PHASE_WORLD if world else _lib.PHASE_JOINT
+        co = R.phase_coeffs(world)
+        keep = R.relu_kink_margin(arch, sd, x, y, eps, world) > 4e-6
+        if int(keep.sum()) == 0:
+            continue
+        xk, yk, ek = x[keep], y[keep], eps[:, keep]
+        n = xk.shape[0]
+        want = R.loss_and_grads(arch, sd, xk, yk, ek if L > 1 else ek[0], world, loss=lk)
+        sp = make_step_params(lr=5e-4, a_rec=co["a_rec_coeff"], kl=co["vae_kl_coeff"], s_rec=co["s_rec_coeff"],
+                              cyc=co["vae_cycle_coeff"], global_rows=n, loss=lk)
+        eng.set_batch(xk, yk)
+        eng.grads.fill_(float("nan"))
+        e_in = (ek if L > 1 else ek[0]) if (not world or L > 1) else None
+        loss = eng.forward_backward(phase, n, sp, eps=e_in, fused_adam=False).cpu()
+        assert float(loss[0]) == pytest.approx(float(want["total"]), rel=1e-5, abs=1e-9), (c, world)
+        for i, k in enumerate(("loss_a", "loss_kl", "loss_s", "loss_cyc")):
+            assert float(loss[1 + i]) == pytest.approx(float(want[k]), rel=1e-5, abs=1e-9), (c, world, k)
+        gv = eng.named_views(eng.grads)
+        for k, gr in want["grads"].items():
+            ours = gv[k].cpu()
+            assert torch.isfinite(ours).all(), (c, world, k)
+            assert max_err_scaled(ours, gr) < 1e-4, (c, world, k)
+            assert rel_err(ours, gr) < 1e-4, (c, world, k)
+        nets = [_lib.NET_WM] if world else [_lib.NET_TE, _lib.NET_MD]
+        seg = eng.segment(eng.grads, nets)
+        real = sum(gv[k].abs().double().sum().item() for k in want["grads"])
+        assert seg.abs().double().sum().item() == pytest.approx(real, rel=1e-9), (c, world)   # pads stay zero
+
+        def run(fused):
+            tr.model.load_state_dict(sd)
+            eng.exp_avg.zero_()
+            eng.exp_avg_sq.zero_()
+            for t in (1, 2, 3):
+                spt = make_step_params(lr=5e-4, adam_t=(t, t, t), a_rec=co["a_rec_coeff"], kl=co["vae_kl_coeff"],
+                                       s_rec=co["s_rec_coeff"], cyc=co["vae_cycle_coeff"], global_rows=n, loss=lk)
+                eng.set_batch(xk, yk)
+                eng.forward_backward(phase, n, spt, eps=e_in, fused_adam=fused)
+                if not fused:
+                    eng.adam(nets, spt)
+            return eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone()
+        p0 = eng.params.clone()
+        a = run(True)
+        eng.params.copy_(p0)
+        b = run(False)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v), (c, world)
+        assert not torch.equal(a[0], p0)
+        tr.model.load_state_dict(sd)
