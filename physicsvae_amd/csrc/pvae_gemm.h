@@ -768,7 +768,6 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
-    v2f bsum = v2f{0.f, 0.f};
 
     const int sw = (lh & 1) << 3;
     const int cq = wq + 2 * li, cp = wp + 2 * li;
@@ -804,7 +803,6 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
                 fq = *reinterpret_cast<const v2f*>(st + oq + kk * 64);
                 fp = *reinterpret_cast<const v2f*>(st + op + kk * 64);
             }
-            bsum += fq;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -845,23 +843,44 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
         epi.apply(q, p, v4f{acc[a][0][0], acc[a][1][0], acc[a][0][1], acc[a][1][1]}, pre[a][0]);
         epi.apply(q, p + 4, v4f{acc[a][0][2], acc[a][1][2], acc[a][0][3], acc[a][1][3]}, pre[a][1]);
     }
-    if (epi.has_bias() && tile_p == 0 && (wave & 1) == 0) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float v = bsum[e];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (lh == 0) epi.bias(q0 + wq + 2 * li + e, v);
-        }
-    }
     if (epi.loss.out && bid == 0 && wave == 3) finalize_loss_wave(epi.loss, lane);
+}
+
+// Bias gradient of a weight-gradient problem, db[q] = sum over the K rows of Q[k][q], for 64
+// columns per workgroup (fixed summation order), handed to the epilogue's bias() (store, or Adam on
+// the bias).  These few light workgroups are appended to every weight-gradient launch: summing the
+// fragments inside the contraction loop instead put two VALU adds beside every four MFMAs of EVERY
+// wave (only 1 tile column in 16 needs them) and cost 2 % of the step.
+template <class Epi>
+__device__ inline void bias_grad_body(float* lds, int tile, const GemmArgs& ga, Epi& epi) {
+    if (!epi.has_bias() || tile >= ga.tiles_q) return;
+    const int tid = threadIdx.x, c4 = (tid & 15) * 4, r0 = tid >> 4;      // 16 rows x 64 columns per pass
+    const float* __restrict__ src = ga.Q + (size_t)r0 * ga.ldq + tile * 64 + c4;
+    const size_t step = (size_t)16 * ga.ldq;
+    v4f s0 = v4f{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int k = r0;
+    for (; k + 16 < ga.K; k += 32) {
+        s0 += *reinterpret_cast<const v4f*>(src);
+        s1 += *reinterpret_cast<const v4f*>(src + step);
+        src += 2 * step;
+    }
+    if (k < ga.K) s0 += *reinterpret_cast<const v4f*>(src);
+    *reinterpret_cast<v4f*>(lds + r0 * 64 + c4) = s0 + s1;
+    __syncthreads();
+    if (tid < 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v += lds[r * 64 + tid];
+        epi.bias(tile * 64 + tid, v);
+    }
 }
 
 template <class Epi, int ABL = 0>
 __global__ void __launch_bounds__(256)
-gemm_wgrad_reg_kernel(GemmArgs ga, Epi epi) {
+gemm_wgrad_reg_kernel(GemmArgs ga, Epi epi, int nw) {
     __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
-    wgrad_reg_body<Epi, ABL>(lds, blockIdx.x, ga, epi);
+    if ((int)blockIdx.x < nw) wgrad_reg_body<Epi, ABL>(lds, blockIdx.x, ga, epi);
+    else bias_grad_body(lds, blockIdx.x - nw, ga, epi);
 }
 
 // Horizontal fusion of two independent backward contractions in ONE launch: blocks [0, nd) run
@@ -869,28 +888,34 @@ gemm_wgrad_reg_kernel(GemmArgs ga, Epi epi) {
 // layer l.  The dgrad blocks are dispatched first (one per CU), the wgrad blocks land beside
 // them (2 waves per SIMD), so one workgroup's load / Adam-traffic phases hide under the other's
 // MFMA phases, and a launch boundary disappears.
-// Blocks past the two problems (n12 .. n12 + sa.rows_pad) stage the NEXT minibatch into the
+// The next tiles_q blocks of each problem sum its bias gradient (bias_grad_body); the blocks past
+// those (sa.rows_pad of them) stage the NEXT minibatch into the
 // alternate input panels (StageArgs / stage_row below): the gather rides in the last launch of the
 // step that precedes it instead of being a launch of its own.
 template <class EpiW>
 __global__ void __launch_bounds__(256)
 wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2, int n12, StageArgs sa) {
     __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
-    if ((int)blockIdx.x < n1) wgrad_reg_body<EpiW>(lds, blockIdx.x, g1, e1);
-    else if ((int)blockIdx.x < n12) wgrad_reg_body<EpiW>(lds, blockIdx.x - n1, g2, e2);
-    else stage_row(sa, blockIdx.x - n12, 0, sa.rows_pad);
+    const int b = blockIdx.x;
+    if (b < n1) wgrad_reg_body<EpiW>(lds, b, g1, e1);
+    else if (b < n12) wgrad_reg_body<EpiW>(lds, b - n1, g2, e2);
+    else if (b < n12 + g1.tiles_q) bias_grad_body(lds, b - n12, g1, e1);
+    else if (b < n12 + g1.tiles_q + g2.tiles_q) bias_grad_body(lds, b - n12 - g1.tiles_q, g2, e2);
+    else stage_row(sa, b - n12 - g1.tiles_q - g2.tiles_q, 0, sa.rows_pad);
 }
 
 // (The dgrad half stays on the register-staged body here: with the wave-specialised body the
 // pair needs 512-thread blocks and 64 KB of LDS per workgroup and measured 15 % slower.)
 template <class EpiD, class EpiW, int ABL = 0>          // ABL: ablation bits of the two bodies (probes only)
 __global__ void __launch_bounds__(256)
-bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew) {
+bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw) {
     __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
     PVAE_MARK(0, 0);
     PVAE_MARK_HW();
-    if ((int)blockIdx.x < nd) splitk_reg_body<false, EpiD, ABL>(lds, blockIdx.x, gd, ed);
-    else wgrad_reg_body<EpiW, ABL>(lds, blockIdx.x - nd, gw, ew);
+    const int b = blockIdx.x;
+    if (b < nd) splitk_reg_body<false, EpiD, ABL>(lds, b, gd, ed);
+    else if (b < nd + nw) wgrad_reg_body<EpiW, ABL>(lds, b - nd, gw, ew);
+    else bias_grad_body(lds, b - nd - nw, gw, ew);
     PVAE_MARK(0, 3);
 }
 
@@ -1259,8 +1284,8 @@ template <class Epi>
 inline hipError_t gemm_wgrad(const float* dZ, int ldz, const float* X, int ldx, int N, int Kin, int M,
                              const Epi& e, hipStream_t st) {
     const GemmGrid g = make_grid(N, Kin, 64, 64);
-    PVAE_LAUNCH((gemm_wgrad_reg_kernel<Epi>), dim3(g.grid), dim3(256), st,
-                       GemmArgs{dZ, ldz, X, ldx, M, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+    PVAE_LAUNCH((gemm_wgrad_reg_kernel<Epi>), dim3(g.grid + g.tiles_q), dim3(256), st,
+                       GemmArgs{dZ, ldz, X, ldx, M, g.tiles_q, g.tiles_p, g.p_per_xcd}, e, g.grid);
     return hipGetLastError();
 }
 // one launch, two independent weight gradients (the two last layers of a backward pass)
@@ -1273,7 +1298,7 @@ inline hipError_t gemm_wgrad_pair(const float* dZ1, int ldz1, const float* X1, i
     StageArgs sa;
     memset(&sa, 0, sizeof(sa));
     if (next) sa = *next;                     // rows_pad extra blocks gather the next minibatch
-    PVAE_LAUNCH((wgrad_pair_kernel<EpiW>), dim3(g1.grid + g2.grid + sa.rows_pad), dim3(256), st,
+    PVAE_LAUNCH((wgrad_pair_kernel<EpiW>), dim3(g1.grid + g2.grid + g1.tiles_q + g2.tiles_q + sa.rows_pad), dim3(256), st,
                        GemmArgs{dZ1, ldz1, X1, ldx1, M, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, e1, g1.grid,
                        GemmArgs{dZ2, ldz2, X2, ldx2, M, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, e2,
                        g1.grid + g2.grid, sa);
@@ -1286,9 +1311,9 @@ inline hipError_t gemm_bwd_pair_epi(const float* dZd, int ldzd, const float* Wd,
                                     int Kinw, int Mw, const EpiW& ew, hipStream_t st) {
     const GemmGrid g1 = make_grid(Md, Kind, 32, 32);
     const GemmGrid g2 = make_grid(Nw, Kinw, 64, 64);
-    PVAE_LAUNCH((bwd_pair_kernel<EpiD, EpiW>), dim3(g1.grid + g2.grid), dim3(256), st,
+    PVAE_LAUNCH((bwd_pair_kernel<EpiD, EpiW>), dim3(g1.grid + g2.grid + g2.tiles_q), dim3(256), st,
                        GemmArgs{dZd, ldzd, Wd, ldwd, Nd, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, g1.grid,
-                       GemmArgs{dZw, ldzw, Xw, ldxw, Mw, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, ew);
+                       GemmArgs{dZw, ldzw, Xw, ldxw, Mw, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, ew, g2.grid);
     return hipGetLastError();
 }
 template <class EpiW>

@@ -15,6 +15,7 @@ __device__ unsigned long long* g_timeline;
 using namespace pvae;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
+#define CK2(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) printf("%s: %s\n", #x, hipGetErrorString(e_)); } while (0)
 int main() {
     const int M = 256, N = 1024, K = 1024;
     hipStream_t st; CK(hipStreamCreate(&st));
@@ -71,14 +72,16 @@ int main() {
     printf("   %zu distinct CUs used; %d hold one dgrad + one wgrad workgroup, %d hold >= 2 dgrad, %d hold >= 2 wgrad\n",
            cu.size(), both, two_d, two_w);
     // ablations of BOTH co-resident bodies: which resource do they fight over?
+    int part = 3;                       // bit 0: dgrad workgroups present, bit 1: wgrad workgroups present
     auto run_abl = [&](auto tag, const char* name) {
         constexpr int A = decltype(tag)::value;
         const EpiMask ed{dX, K, act, K};
         const GemmGrid g1 = make_grid(M, K, 32, 32), g2 = make_grid(N, K, 64, 64);
         auto launch = [&]() {
-            hipLaunchKernelGGL((bwd_pair_kernel<EpiMask, EpiGradAdam, A>), dim3(g1.grid + g2.grid), dim3(256), 0, st,
-                               GemmArgs{dZ, N, W, K, N, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, g1.grid,
-                               GemmArgs{dZ, N, X, K, M, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, e);
+            const int nd = (part & 1) ? g1.grid : 0, nw2 = (part & 2) ? g2.grid : 0;
+            hipLaunchKernelGGL((bwd_pair_kernel<EpiMask, EpiGradAdam, A>), dim3(nd + nw2), dim3(256), 0, st,
+                               GemmArgs{dZ, N, W, K, N, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, nd,
+                               GemmArgs{dZ, N, X, K, M, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, e, nw2);
         };
         for (int i = 0; i < 10; ++i) launch();
         hipStreamSynchronize(st);
@@ -87,6 +90,15 @@ int main() {
         hipEventRecord(b, st); hipEventSynchronize(b);
         float t; hipEventElapsedTime(&t, a, b);
         printf("   %-46s period %6.2f us\n", name, t * 10.0f);
+        CK2(hipMemcpy(h.data(), T, h.size() * 8, hipMemcpyDeviceToHost));
+        t0 = ~0ull;
+        for (int w = 0; w < grid; ++w) t0 = std::min(t0, h[(size_t)w * 8]);
+        const int nd = (part & 1) ? 256 : 0;
+        t0 = ~0ull;
+        for (int w = 0; w < nd + ((part & 2) ? 256 : 0); ++w) t0 = std::min(t0, h[(size_t)w * 8]);
+        if (part & 1) stat("      dgrad finished", 0, 256, 3);
+        if (part & 2) stat("      wgrad contraction done", nd, nd + 256, 2);
+        if (part & 2) stat("      wgrad finished", nd, nd + 256, 3);
     };
     run_abl(std::integral_constant<int, 0>(), "both bodies complete");
     run_abl(std::integral_constant<int, 1>(), "no global loads / LDS writes");
@@ -95,5 +107,60 @@ int main() {
     run_abl(std::integral_constant<int, 8>(), "no barriers");
     run_abl(std::integral_constant<int, 11>(), "MFMA only (no loads, LDS reads, barriers)");
     run_abl(std::integral_constant<int, 3>(), "MFMA + barriers (no loads, no LDS reads)");
+    {
+        // More waves per SIMD?  Same flops, same operand bytes, but every workgroup contracts over half
+        // the length (twice as many workgroups, 4 co-resident per CU if registers allow).  Results
+        // would need a cross-workgroup reduction; this only times the loops.
+        float *gw, *big;
+        CK(hipMalloc(&gw, (size_t)2048 * 1024 * 4)); CK(hipMalloc(&big, (size_t)2048 * 1024 * 4));
+        CK(hipMemset(big, 0, (size_t)2048 * 1024 * 4));
+        EpiGradStore es{gw, K};
+        auto timeit = [&](const char* name, int dM, int dN, int wN, int wM) {
+            const EpiMask ed{dX, K, act, K};
+            const GemmGrid g1 = make_grid(dM, K, 32, 32), g2 = make_grid(wN, K, 64, 64);
+            auto launch = [&]() {
+                hipLaunchKernelGGL((bwd_pair_kernel<EpiMask, EpiGradStore, 0>), dim3(g1.grid + g2.grid), dim3(256), 0, st,
+                                   GemmArgs{big, dN, W, K, dN, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, g1.grid,
+                                   GemmArgs{big, wN, X, K, wM, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, es, g2.grid);
+            };
+            for (int i = 0; i < 10; ++i) launch();
+            hipStreamSynchronize(st);
+            hipEventRecord(a, st);
+            for (int i = 0; i < 100; ++i) launch();
+            hipEventRecord(b, st); hipEventSynchronize(b);
+            float t; hipEventElapsedTime(&t, a, b);
+            printf("   %-60s %4d workgroups, period %6.2f us\n", name, g1.grid + g2.grid, t * 10.0f);
+            std::vector<unsigned long long> hh((size_t)(g1.grid + g2.grid) * 8);
+            CK2(hipMemcpy(hh.data(), T, hh.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long tt = ~0ull;
+            for (int w = 0; w < g1.grid + g2.grid; ++w) tt = std::min(tt, hh[(size_t)w * 8]);
+            auto st2 = [&](const char* nm, int lo, int hi, int id) {
+                std::vector<double> x;
+                for (int w = lo; w < hi; ++w) x.push_back((double)(hh[(size_t)w * 8 + id] - tt) * 0.01);
+                std::sort(x.begin(), x.end());
+                printf("         %-36s min %6.2f  median %6.2f  max %6.2f us\n", nm, x.front(), x[x.size() / 2], x.back());
+            };
+            st2("dgrad entered", 0, g1.grid, 0);
+            st2("dgrad finished", 0, g1.grid, 3);
+            st2("wgrad entered", g1.grid, g1.grid + g2.grid, 0);
+            st2("wgrad contraction done", g1.grid, g1.grid + g2.grid, 2);
+            st2("wgrad finished", g1.grid, g1.grid + g2.grid, 3);
+        };
+        float* dX2; CK(hipMalloc(&dX2, (size_t)512 * K * 4));
+        timeit("gradient store: 256x1024 (k 1024) | 1024x1024 (k 256)", 256, 1024, 1024, 256);
+        float* keep = dX; dX = dX2;
+        float* keepa = act; act = big;
+        timeit("half contraction: 512x1024 (k 512) | 2048x1024 (k 128)", 512, 512, 2048, 128);
+        dX = keep; act = keepa;
+    }
+    for (int pp : {1, 2}) {
+        part = pp;
+        printf("--- only the %s workgroups\n", pp == 1 ? "dgrad" : "wgrad");
+        run_abl(std::integral_constant<int, 0>(), "complete");
+        run_abl(std::integral_constant<int, 4>(), "no MFMA");
+        run_abl(std::integral_constant<int, 11>(), "MFMA only (no loads, LDS reads, barriers)");
+        run_abl(std::integral_constant<int, 3>(), "MFMA + barriers (no loads, no LDS reads)");
+        run_abl(std::integral_constant<int, 1>(), "no global loads / LDS writes");
+    }
     return 0;
 }
