@@ -718,6 +718,9 @@ gemm_splitk_reg16_kernel(GemmArgs ga, Epi epi) {
 
 // ---- wgrad: G[64 q][64 p] per workgroup, reduction over batch rows (BK = 32), both operands COL,
 // waves 2x2 with 32x32 each; the epilogue operands (Adam's p, m, v) are fetched under the loop --
+#ifndef PVAE_WGRAD_PIPE
+#define PVAE_WGRAD_PIPE 1      // 0: the plain loop (also what the ablation probes run)
+#endif
 template <class Epi, int ABL = 0>
 __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
     constexpr int BK = 32, kTile = 32 * 64, kStage = 2 * kTile, D = PVAE_REG_DEPTH_W, S = 2;
@@ -790,7 +793,42 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
 
     // one k-tile: 8 steps of (2 fragment reads, 4 MFMAs); after step 3 the next tile moves from its
     // register set into the other LDS slot and that set is refilled D tiles ahead
-    auto tile_step = [&](int t, int d, bool guarded) {
+    // fragments of k-step kk+4 are requested before the MFMAs of k-step kk are issued: inside a tile
+    // only the first read's latency is exposed (left to itself hipcc reads two k-steps with one
+    // ds_read2st64_b64, waits for them, issues 8 MFMAs, and repeats: 4 exposed waits per tile;
+    // fused backward launch 15.1 -> 14.8 us)
+    auto tile_step_piped = [&](int t, int d, bool guarded) {
+        const float* st = lds + (t & 1) * kStage;
+        v2f fq[2], fp[2];
+        fq[0] = *reinterpret_cast<const v2f*>(st + oq);
+        fp[0] = *reinterpret_cast<const v2f*>(st + op);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            const int c = (kk >> 2) & 1, n = c ^ 1;
+            if (kk + 4 < BK) {
+                fq[n] = *reinterpret_cast<const v2f*>(st + oq + (kk + 4) * 64);
+                fp[n] = *reinterpret_cast<const v2f*>(st + op + (kk + 4) * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[c][b], fq[c][a], acc[a][b], 0, 0, 0);
+            if (kk == 12) {
+                if (!guarded) {
+                    lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
+                    const int tn = t + 1 + D < nk ? t + 1 + D : nk - 1;
+                    gload(tn, rg[(d + 1) % D]);
+                } else if (t + 1 < nk) {
+                    lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
+                    if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D]);
+                }
+            }
+        }
+        __syncthreads();
+    };
+    auto tile_step_plain = [&](int t, int d, bool guarded) {
         const float* st = lds + (t & 1) * kStage;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
@@ -826,6 +864,10 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
             }
         }
         if (!(ABL & 8)) __syncthreads();
+    };
+    auto tile_step = [&](int t, int d, bool guarded) {
+        if constexpr (ABL == 0 && PVAE_WGRAD_PIPE) tile_step_piped(t, d, guarded);
+        else tile_step_plain(t, d, guarded);
     };
     int t0 = 0;
     for (; t0 + D <= nk; t0 += D) {            // full groups of D tiles: no branch inside
