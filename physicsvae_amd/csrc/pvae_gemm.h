@@ -186,6 +186,7 @@ struct GemmArgs {
     int ldp;
     int K, tiles_q, tiles_p, p_per_xcd;
     int krot = g_krot;        // rotate each workgroup's K order (see k_rotation)
+    int tile32 = 0;           // weight gradient on 32x32 output tiles (wgrad32_body) instead of 64x64
 };
 
 // Experiment (off by default): start each workgroup at a different k-tile and wrap around, so that
@@ -888,14 +889,152 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
     if (epi.loss.out && bid == 0 && wave == 3) finalize_loss_wave(epi.loss, lane);
 }
 
+// ---- weight gradient, 32x32 output tile per workgroup ------------------------------------------
+// A weight matrix with few 64x64 tiles (first / last layers: 1024x256 -> 64 tiles) occupies a
+// quarter of the CUs with workgroups that run as long as those of a full 1024x1024 layer; in a fused
+// launch they decide its length (layer-1 + layer-0 gradients: 16.7 us, layer 1 alone 11.2).  On 32x32
+// tiles the same matrix gives four times the workgroups, each a quarter as long: the four waves
+// split every 64-row k-tile (16 rows = 4 MFMA k-steps each) over the whole tile and reduce through
+// LDS at the end, like the input-gradient body.  Needs K % 64 == 0 (wgrad_uses_32x32).
+template <class Epi>
+__device__ inline void wgrad32_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
+    constexpr int BK = 64, kTile = 64 * 32, kStage = 2 * kTile, D = PVAE_REG_DEPTH_W, S = 2;
+    static_assert(S * kStage == kRegRingFloats, "LDS budget");
+    static_assert(S * kStage >= 4 * 32 * 36, "ring must hold the split-K reduction buffer");
+    const float* __restrict__ Q = ga.Q;
+    const float* __restrict__ P = ga.P;
+    const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
+
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int tile_p = xcd * ga.p_per_xcd + loc / tiles_q;
+    const int tile_q = loc % tiles_q;
+    if (tile_p >= tiles_p) return;
+    const int q0 = tile_q * 32, p0 = tile_p * 32;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15, lh = lane >> 4;
+
+    // operand images in LDS: [64 k-rows][32 columns], row-major (fragment reads and 16-byte writes
+    // are conflict-free as they are); 512 16-byte chunks per operand, two per thread
+    const float* sq[2];
+    const float* sp[2];
+    int slot_off[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = tid + 256 * u;
+        const int row = j >> 3, c = j & 7;
+        slot_off[u] = j * 4;
+        sq[u] = Q + (size_t)row * ldq + q0 + c * 4;
+        sp[u] = P + (size_t)row * ldp + p0 + c * 4;
+    }
+    v4f rg[D][4];
+    auto gload = [&](int t, v4f(&r)[4]) {
+        r[0] = *reinterpret_cast<const v4f*>(sq[0] + (size_t)t * BK * ldq);
+        r[1] = *reinterpret_cast<const v4f*>(sp[0] + (size_t)t * BK * ldp);
+        r[2] = *reinterpret_cast<const v4f*>(sq[1] + (size_t)t * BK * ldq);
+        r[3] = *reinterpret_cast<const v4f*>(sp[1] + (size_t)t * BK * ldp);
+    };
+    auto lwrite = [&](float* slot, const v4f(&r)[4]) {
+        *reinterpret_cast<v4f*>(slot + slot_off[0]) = r[0];
+        *reinterpret_cast<v4f*>(slot + kTile + slot_off[0]) = r[1];
+        *reinterpret_cast<v4f*>(slot + slot_off[1]) = r[2];
+        *reinterpret_cast<v4f*>(slot + kTile + slot_off[1]) = r[3];
+    };
+
+    v4f acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    const int of = (16 * wave + lh) * 32 + 2 * li;       // this lane's fragment pair at k-step 0 of its slice
+
+    const int nk = K / BK;
+#pragma unroll
+    for (int d = 0; d < D; ++d) gload(d < nk ? d : nk - 1, rg[d]);     // (clamped, not guarded: exact vmcnt)
+    lwrite(lds, rg[0]);
+    gload(D < nk ? D : nk - 1, rg[0]);
+    const typename Epi::Pre pre = epi.load(q0 + (tid >> 3), p0 + ((tid & 7) << 2));   // arrives under the loop
+    __syncthreads();
+
+    auto tile_step = [&](int t, int d, bool guarded) {
+        const float* st = lds + (t & 1) * kStage;
+        v2f fq[2], fp[2];
+        fq[0] = *reinterpret_cast<const v2f*>(st + of);
+        fp[0] = *reinterpret_cast<const v2f*>(st + kTile + of);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int c = s2 & 1, n = c ^ 1;
+            if (s2 + 1 < 4) {
+                fq[n] = *reinterpret_cast<const v2f*>(st + of + (s2 + 1) * 128);
+                fp[n] = *reinterpret_cast<const v2f*>(st + kTile + of + (s2 + 1) * 128);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[c][b], fq[c][a], acc[a][b], 0, 0, 0);
+            if (s2 == 1) {
+                if (!guarded) {
+                    lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
+                    const int tn = t + 1 + D < nk ? t + 1 + D : nk - 1;
+                    gload(tn, rg[(d + 1) % D]);
+                } else if (t + 1 < nk) {
+                    lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
+                    if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D]);
+                }
+            }
+        }
+        __syncthreads();
+    };
+    int t0 = 0;
+    for (; t0 + D <= nk; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) tile_step(t0 + d, d, false);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (t0 + d < nk) tile_step(t0 + d, d, true);
+
+    // split-K reduction over the four waves (fixed order), epilogue on float4s by all 256 threads
+    constexpr int RS = 36;
+    float* red = lds + wave * (32 * RS);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(2 * li + a) * RS + 8 * lh + 2 * r + b] = acc[a][b][r];
+    __syncthreads();
+    {
+        const int ql = tid >> 3, pl = (tid & 7) << 2;
+        v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (32 * RS) + ql * RS + pl);
+        epi.apply(q0 + ql, p0 + pl, v, pre);
+    }
+    if (epi.loss.out && bid == 0 && wave == 3) finalize_loss_wave(epi.loss, lane);
+}
+
+// either geometry, chosen per problem on the host
+template <class Epi, int ABL = 0>
+__device__ inline void wgrad_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
+    if (ga.tile32) wgrad32_body<Epi>(lds, bid, ga, epi);
+    else wgrad_reg_body<Epi, ABL>(lds, bid, ga, epi);
+}
+
 // Bias gradient of a weight-gradient problem, db[q] = sum over the K rows of Q[k][q], for 64
 // columns per workgroup (fixed summation order), handed to the epilogue's bias() (store, or Adam on
 // the bias).  These few light workgroups are appended to every weight-gradient launch: summing the
 // fragments inside the contraction loop instead put two VALU adds beside every four MFMAs of EVERY
 // wave (only 1 tile column in 16 needs them) and cost 2 % of the step.
+__host__ __device__ inline int bias_tiles(const GemmArgs& ga) { return ga.tile32 ? ga.tiles_q / 2 : ga.tiles_q; }
 template <class Epi>
 __device__ inline void bias_grad_body(float* lds, int tile, const GemmArgs& ga, Epi& epi) {
-    if (!epi.has_bias() || tile >= ga.tiles_q) return;
+    if (!epi.has_bias() || tile >= bias_tiles(ga)) return;
     const int tid = threadIdx.x, c4 = (tid & 15) * 4, r0 = tid >> 4;      // 16 rows x 64 columns per pass
     const float* __restrict__ src = ga.Q + (size_t)r0 * ga.ldq + tile * 64 + c4;
     const size_t step = (size_t)16 * ga.ldq;
@@ -921,7 +1060,7 @@ template <class Epi, int ABL = 0>
 __global__ void __launch_bounds__(256)
 gemm_wgrad_reg_kernel(GemmArgs ga, Epi epi, int nw) {
     __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
-    if ((int)blockIdx.x < nw) wgrad_reg_body<Epi, ABL>(lds, blockIdx.x, ga, epi);
+    if ((int)blockIdx.x < nw) wgrad_body<Epi, ABL>(lds, blockIdx.x, ga, epi);
     else bias_grad_body(lds, blockIdx.x - nw, ga, epi);
 }
 
@@ -939,11 +1078,12 @@ __global__ void __launch_bounds__(256)
 wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2, int n12, StageArgs sa) {
     __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
     const int b = blockIdx.x;
-    if (b < n1) wgrad_reg_body<EpiW>(lds, b, g1, e1);
-    else if (b < n12) wgrad_reg_body<EpiW>(lds, b - n1, g2, e2);
-    else if (b < n12 + g1.tiles_q) bias_grad_body(lds, b - n12, g1, e1);
-    else if (b < n12 + g1.tiles_q + g2.tiles_q) bias_grad_body(lds, b - n12 - g1.tiles_q, g2, e2);
-    else stage_row(sa, b - n12 - g1.tiles_q - g2.tiles_q, 0, sa.rows_pad);
+    const int nb1 = bias_tiles(g1), nb2 = bias_tiles(g2);
+    if (b < n1) wgrad_body<EpiW>(lds, b, g1, e1);
+    else if (b < n12) wgrad_body<EpiW>(lds, b - n1, g2, e2);
+    else if (b < n12 + nb1) bias_grad_body(lds, b - n12, g1, e1);
+    else if (b < n12 + nb1 + nb2) bias_grad_body(lds, b - n12 - nb1, g2, e2);
+    else stage_row(sa, b - n12 - nb1 - nb2, 0, sa.rows_pad);
 }
 
 // (The dgrad half stays on the register-staged body here: with the wave-specialised body the
@@ -956,7 +1096,7 @@ bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw) {
     PVAE_MARK_HW();
     const int b = blockIdx.x;
     if (b < nd) splitk_reg_body<false, EpiD, ABL>(lds, b, gd, ed);
-    else if (b < nd + nw) wgrad_reg_body<EpiW, ABL>(lds, b - nd, gw, ew);
+    else if (b < nd + nw) wgrad_body<EpiW, ABL>(lds, b - nd, gw, ew);
     else bias_grad_body(lds, b - nd - nw, gw, ew);
     PVAE_MARK(0, 3);
 }
@@ -1322,12 +1462,28 @@ inline hipError_t gemm_dgrad_epi(const float* dZ, int ldz, const float* W, int l
 }
 inline int dgrad_tiles(int M, int Kin) { return make_grid(M, Kin, 32, 32).grid; }
 // wgrad: G[N][Kin] = dZ[M][N]^T X[M][Kin]  (+ bias gradient, + optional loss finalisation)
+// Tile geometry per problem: 64x64, or 32x32 when that leaves at most half the CUs with a tile
+// (PVAE_WGRAD32=0 switches the small geometry off: A/B).
+static int g_wgrad32 = [] { const char* e = getenv("PVAE_WGRAD32"); return (e && e[0] == '0') ? 0 : 1; }();
+inline bool wgrad_uses_32x32(int N, int Kin, int M) {
+    return g_wgrad32 && (N / 64) * (Kin / 64) <= 128 && M % 64 == 0;
+}
+struct WgradPlan {
+    GemmArgs ga;
+    int grid, nbias;          // contraction workgroups, bias-gradient workgroups (64 columns each)
+};
+inline WgradPlan plan_wgrad(const float* dZ, int ldz, const float* X, int ldx, int N, int Kin, int M) {
+    const bool t32 = wgrad_uses_32x32(N, Kin, M);
+    const GemmGrid g = t32 ? make_grid(N, Kin, 32, 32) : make_grid(N, Kin, 64, 64);
+    WgradPlan p{GemmArgs{dZ, ldz, X, ldx, M, g.tiles_q, g.tiles_p, g.p_per_xcd}, g.grid, N / 64};
+    p.ga.tile32 = t32 ? 1 : 0;
+    return p;
+}
 template <class Epi>
 inline hipError_t gemm_wgrad(const float* dZ, int ldz, const float* X, int ldx, int N, int Kin, int M,
                              const Epi& e, hipStream_t st) {
-    const GemmGrid g = make_grid(N, Kin, 64, 64);
-    PVAE_LAUNCH((gemm_wgrad_reg_kernel<Epi>), dim3(g.grid + g.tiles_q), dim3(256), st,
-                       GemmArgs{dZ, ldz, X, ldx, M, g.tiles_q, g.tiles_p, g.p_per_xcd}, e, g.grid);
+    const WgradPlan w = plan_wgrad(dZ, ldz, X, ldx, N, Kin, M);
+    PVAE_LAUNCH((gemm_wgrad_reg_kernel<Epi>), dim3(w.grid + w.nbias), dim3(256), st, w.ga, e, w.grid);
     return hipGetLastError();
 }
 // one launch, two independent weight gradients (the two last layers of a backward pass)
@@ -1335,15 +1491,13 @@ template <class EpiW>
 inline hipError_t gemm_wgrad_pair(const float* dZ1, int ldz1, const float* X1, int ldx1, int N1, int Kin1,
                                   const EpiW& e1, const float* dZ2, int ldz2, const float* X2, int ldx2, int N2,
                                   int Kin2, const EpiW& e2, int M, hipStream_t st, const StageArgs* next = nullptr) {
-    const GemmGrid g1 = make_grid(N1, Kin1, 64, 64);
-    const GemmGrid g2 = make_grid(N2, Kin2, 64, 64);
+    const WgradPlan w1 = plan_wgrad(dZ1, ldz1, X1, ldx1, N1, Kin1, M);
+    const WgradPlan w2 = plan_wgrad(dZ2, ldz2, X2, ldx2, N2, Kin2, M);
     StageArgs sa;
     memset(&sa, 0, sizeof(sa));
     if (next) sa = *next;                     // rows_pad extra blocks gather the next minibatch
-    PVAE_LAUNCH((wgrad_pair_kernel<EpiW>), dim3(g1.grid + g2.grid + g1.tiles_q + g2.tiles_q + sa.rows_pad), dim3(256), st,
-                       GemmArgs{dZ1, ldz1, X1, ldx1, M, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, e1, g1.grid,
-                       GemmArgs{dZ2, ldz2, X2, ldx2, M, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, e2,
-                       g1.grid + g2.grid, sa);
+    PVAE_LAUNCH((wgrad_pair_kernel<EpiW>), dim3(w1.grid + w2.grid + w1.nbias + w2.nbias + sa.rows_pad), dim3(256), st,
+                       w1.ga, e1, w1.grid, w2.ga, e2, w1.grid + w2.grid, sa);
     return hipGetLastError();
 }
 // one launch: dX'[M][Kin'] = (dZ'[M][N'] W'[N'][Kin']) .* mask   ||   G[N][Kin] = dZ[M][N]^T X[M][Kin]
@@ -1352,10 +1506,10 @@ inline hipError_t gemm_bwd_pair_epi(const float* dZd, int ldzd, const float* Wd,
                                     const EpiD& ed, const float* dZw, int ldzw, const float* Xw, int ldxw, int Nw,
                                     int Kinw, int Mw, const EpiW& ew, hipStream_t st) {
     const GemmGrid g1 = make_grid(Md, Kind, 32, 32);
-    const GemmGrid g2 = make_grid(Nw, Kinw, 64, 64);
-    PVAE_LAUNCH((bwd_pair_kernel<EpiD, EpiW>), dim3(g1.grid + g2.grid + g2.tiles_q), dim3(256), st,
+    const WgradPlan w = plan_wgrad(dZw, ldzw, Xw, ldxw, Nw, Kinw, Mw);
+    PVAE_LAUNCH((bwd_pair_kernel<EpiD, EpiW>), dim3(g1.grid + w.grid + w.nbias), dim3(256), st,
                        GemmArgs{dZd, ldzd, Wd, ldwd, Nd, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, g1.grid,
-                       GemmArgs{dZw, ldzw, Xw, ldxw, Mw, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, ew, g2.grid);
+                       w.ga, ew, w.grid);
     return hipGetLastError();
 }
 template <class EpiW>
