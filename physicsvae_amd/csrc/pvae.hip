@@ -898,7 +898,7 @@ static int step_shape(pvae_ctx* c, int phase, int rows, const pvae_step_params* 
         S.lf.nparts[2] = S.wm_tiles * T;
     } else {
         if (sp->a_rec_coeff > 0.0f)
-            S.lf.nparts[0] = S.seed_action ? (S.rows_pad / 32) * (c->L.net[PVAE_NET_WM].layers[0].ld / 32) : S.nparts_a * T;
+            S.lf.nparts[0] = S.seed_action ? dgrad_tiles(S.rows_pad, c->L.net[PVAE_NET_WM].layers[0].ld) : S.nparts_a * T;
         if (S.kl_active) S.lf.nparts[1] = S.gridz * T;
         if (sp->cycle_coeff > 0.0f) S.lf.nparts[3] = S.wm_tiles * T;
     }

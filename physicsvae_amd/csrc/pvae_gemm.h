@@ -187,6 +187,7 @@ struct GemmArgs {
     int K, tiles_q, tiles_p, p_per_xcd;
     int krot = g_krot;        // rotate each workgroup's K order (see k_rotation)
     int tile32 = 0;           // weight gradient on 32x32 output tiles (wgrad32_body) instead of 64x64
+    int tile16 = 0;           // input gradient on 16x16 output tiles (splitk_reg16_body<false>) instead of 32x32
 };
 
 // Experiment (off by default): start each workgroup at a different k-tile and wrap around, so that
@@ -619,7 +620,10 @@ gemm_splitk_ws_kernel(GemmArgs ga, Epi epi) {
 // 16x16 tile (one MFMA tile per wave, two accumulators alternating over the k-steps so the
 // dependent-issue latency is covered; the 4 waves still split K): 4x the workgroups, each
 // streaming (16 + 16) rows.  4 flop/B, so it only pays when the grid would otherwise be small.
-template <class Epi>
+// P_ROW = false is the input-gradient form (P = W[k][p], p contiguous) for first-layer gradients:
+// 256 x 256 outputs are 64 tiles of 32x32 that run a full K = 1024 pass on a quarter of the CUs
+// (9.5 us), 256 of these.  Its P image is [64 k][16 p] row-major, read one dword per k-step.
+template <bool P_ROW, class Epi>
 __device__ inline void splitk_reg16_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
     constexpr int BK = 64, kTile = 16 * 64, kStage = 2 * kTile, D = PVAE_REG_DEPTH_16;
     const float* __restrict__ Q = ga.Q;
@@ -640,13 +644,15 @@ __device__ inline void splitk_reg16_body(float* lds, int bid, const GemmArgs& ga
     // one 16-byte chunk of each operand tile per thread: slot j = tid, row j>>4, chunk (j&15)^row
     const int srow = tid >> 4, schunk = (tid & 15) ^ srow;
     const float* sq = Q + (size_t)(q0 + srow) * ldq + schunk * 4;
-    const float* sp = P + (size_t)(p0 + srow) * ldp + schunk * 4;
+    const float* sp = P_ROW ? P + (size_t)(p0 + srow) * ldp + schunk * 4
+                            : P + (size_t)(tid >> 2) * ldp + p0 + (tid & 3) * 4;      // k = tid/4, 4 chunks per row
+    const size_t kstep_p = P_ROW ? (size_t)BK : (size_t)BK * ldp;
     const int slot_off = tid * 4;
 
     v4f rg[D][2];
     auto gload = [&](int t, v4f(&r)[2]) {
         r[0] = *reinterpret_cast<const v4f*>(sq + (size_t)t * BK);
-        r[1] = *reinterpret_cast<const v4f*>(sp + (size_t)t * BK);
+        r[1] = *reinterpret_cast<const v4f*>(sp + (size_t)t * kstep_p);
     };
     auto lwrite = [&](float* slot, const v4f(&r)[2]) {
         *reinterpret_cast<v4f*>(slot + slot_off) = r[0];
@@ -667,7 +673,13 @@ __device__ inline void splitk_reg16_body(float* lds, int bid, const GemmArgs& ga
     auto tile_step = [&](int t, int d, bool guarded) {
         const float* st = lds + (t & 1) * kStage;
         const v4f fq = *reinterpret_cast<const v4f*>(st + of);
-        const v4f fp = *reinterpret_cast<const v4f*>(st + kTile + of);
+        v4f fp;
+        if (P_ROW) {
+            fp = *reinterpret_cast<const v4f*>(st + kTile + of);
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) fp[s2] = st[kTile + (16 * wave + 4 * lh + s2) * 16 + li];
+        }
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
             acc[s2 & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[s2], fq[s2], acc[s2 & 1], 0, 0, 0);
@@ -710,11 +722,11 @@ __device__ inline void splitk_reg16_body(float* lds, int bid, const GemmArgs& ga
     epi.finish(lds, tile_q * tiles_p + tile_p, tid);
 }
 
-template <class Epi>
+template <bool P_ROW, class Epi>
 __global__ void __launch_bounds__(256)
 gemm_splitk_reg16_kernel(GemmArgs ga, Epi epi) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * 16 * 64];
-    splitk_reg16_body<Epi>(lds, blockIdx.x, ga, epi);
+    splitk_reg16_body<P_ROW, Epi>(lds, blockIdx.x, ga, epi);
 }
 
 // ---- wgrad: G[64 q][64 p] per workgroup, reduction over batch rows (BK = 32), both operands COL,
@@ -1095,8 +1107,10 @@ bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw) {
     PVAE_MARK(0, 0);
     PVAE_MARK_HW();
     const int b = blockIdx.x;
-    if (b < nd) splitk_reg_body<false, EpiD, ABL>(lds, b, gd, ed);
-    else if (b < nd + nw) wgrad_body<EpiW, ABL>(lds, b - nd, gw, ew);
+    if (b < nd) {
+        if (gd.tile16) splitk_reg16_body<false, EpiD>(lds, b, gd, ed);
+        else splitk_reg_body<false, EpiD, ABL>(lds, b, gd, ed);
+    } else if (b < nd + nw) wgrad_body<EpiW, ABL>(lds, b - nd, gw, ew);
     else bias_grad_body(lds, b - nd - nw, gw, ew);
     PVAE_MARK(0, 3);
 }
@@ -1428,7 +1442,7 @@ inline hipError_t gemm_forward_epi(const float* X, int ldx, const float* W, int 
                                    const Epi& e, hipStream_t st) {
     if (forward_uses_16x16(M, N)) {
         const GemmGrid g = make_grid(M, N, 16, 16);
-        PVAE_LAUNCH((gemm_splitk_reg16_kernel<Epi>), dim3(g.grid), dim3(256), st,
+        PVAE_LAUNCH((gemm_splitk_reg16_kernel<true, Epi>), dim3(g.grid), dim3(256), st,
                            GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
         return hipGetLastError();
     }
@@ -1443,24 +1457,39 @@ inline hipError_t gemm_forward(const float* X, int ldx, const float* W, int ldw,
     return gemm_forward_epi(X, ldx, W, ldw, M, N, K, e, st);
 }
 // dgrad: dX[M][Kin] = (dZ[M][N] W[N][Kin]) .* (mask > 0)
-inline hipError_t gemm_dgrad(const float* dZ, int ldz, const float* W, int ldw, const float* mask,
-                             int ldm, float* dX, int ldo, int M, int Kin, int N, hipStream_t st) {
-    const EpiMask e{dX, ldo, mask, ldm};
-    const GemmGrid g = make_grid(M, Kin, 32, 32);
-    PVAE_LAUNCH((gemm_splitk_ws_kernel<false, EpiMask>), dim3(g.grid), dim3(512), st,
-                       GemmArgs{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
-    return hipGetLastError();
+// Tile geometry: 32x32, or 16x16 when that leaves fewer than 128 workgroups (narrow first layers;
+// PVAE_DGRAD16=0 switches it off: A/B).
+static int g_dgrad16 = [] { const char* e = getenv("PVAE_DGRAD16"); return (e && e[0] == '0') ? 0 : 1; }();
+inline bool dgrad_uses_16x16(int M, int Kin) { return g_dgrad16 && (M / 32) * (Kin / 32) < 128; }
+// workgroups whose epilogue sees a tile (= loss partials a seed epilogue writes)
+inline int dgrad_tiles(int M, int Kin) {
+    return dgrad_uses_16x16(M, Kin) ? (M / 16) * (Kin / 16) : (M / 32) * (Kin / 32);
+}
+struct DgradPlan {
+    GemmArgs ga;
+    int grid;
+};
+inline DgradPlan plan_dgrad(const float* dZ, int ldz, const float* W, int ldw, int M, int Kin, int N) {
+    const bool t16 = dgrad_uses_16x16(M, Kin);
+    const GemmGrid g = t16 ? make_grid(M, Kin, 16, 16) : make_grid(M, Kin, 32, 32);
+    DgradPlan d{GemmArgs{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd}, g.grid};
+    d.ga.tile16 = t16 ? 1 : 0;
+    return d;
 }
 // same contraction with a caller-supplied epilogue (gradient seeds of the producing stack)
 template <class EpiD>
 inline hipError_t gemm_dgrad_epi(const float* dZ, int ldz, const float* W, int ldw, int M, int Kin, int N,
                                  const EpiD& e, hipStream_t st) {
-    const GemmGrid g = make_grid(M, Kin, 32, 32);
-    PVAE_LAUNCH((gemm_splitk_ws_kernel<false, EpiD>), dim3(g.grid), dim3(512), st,
-                       GemmArgs{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+    const DgradPlan d = plan_dgrad(dZ, ldz, W, ldw, M, Kin, N);
+    if (d.ga.tile16) PVAE_LAUNCH((gemm_splitk_reg16_kernel<false, EpiD>), dim3(d.grid), dim3(256), st, d.ga, e);
+    else PVAE_LAUNCH((gemm_splitk_ws_kernel<false, EpiD>), dim3(d.grid), dim3(512), st, d.ga, e);
     return hipGetLastError();
 }
-inline int dgrad_tiles(int M, int Kin) { return make_grid(M, Kin, 32, 32).grid; }
+inline hipError_t gemm_dgrad(const float* dZ, int ldz, const float* W, int ldw, const float* mask,
+                             int ldm, float* dX, int ldo, int M, int Kin, int N, hipStream_t st) {
+    const EpiMask e{dX, ldo, mask, ldm};
+    return gemm_dgrad_epi(dZ, ldz, W, ldw, M, Kin, N, e, st);
+}
 // wgrad: G[N][Kin] = dZ[M][N]^T X[M][Kin]  (+ bias gradient, + optional loss finalisation)
 // Tile geometry per problem: 64x64, or 32x32 when that leaves at most half the CUs with a tile
 // (PVAE_WGRAD32=0 switches the small geometry off: A/B).
@@ -1505,11 +1534,10 @@ template <class EpiD, class EpiW>
 inline hipError_t gemm_bwd_pair_epi(const float* dZd, int ldzd, const float* Wd, int ldwd, int Md, int Kind, int Nd,
                                     const EpiD& ed, const float* dZw, int ldzw, const float* Xw, int ldxw, int Nw,
                                     int Kinw, int Mw, const EpiW& ew, hipStream_t st) {
-    const GemmGrid g1 = make_grid(Md, Kind, 32, 32);
+    const DgradPlan d = plan_dgrad(dZd, ldzd, Wd, ldwd, Md, Kind, Nd);
     const WgradPlan w = plan_wgrad(dZw, ldzw, Xw, ldxw, Nw, Kinw, Mw);
-    PVAE_LAUNCH((bwd_pair_kernel<EpiD, EpiW>), dim3(g1.grid + w.grid + w.nbias), dim3(256), st,
-                       GemmArgs{dZd, ldzd, Wd, ldwd, Nd, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, g1.grid,
-                       w.ga, ew, w.grid);
+    PVAE_LAUNCH((bwd_pair_kernel<EpiD, EpiW>), dim3(d.grid + w.grid + w.nbias), dim3(256), st,
+                       d.ga, ed, d.grid, w.ga, ew, w.grid);
     return hipGetLastError();
 }
 template <class EpiW>
