@@ -479,6 +479,13 @@ typedef std::vector<Stage> Plan;
 // What the input-gradient launch of a stack's FIRST layer does with its result (lookahead 1):
 // nothing special (store the panel), or form the gradient seed of the stack that produced those
 // input columns in its epilogue (pvae_gemm.h: EpiActionSeed / EpiSamplerSeed).
+// Columns [c0, c0 + n) of a first-layer input gradient, widened to whole 32-column tiles: the only
+// part of that panel a gradient seed reads, so the only part its launch contracts.
+struct SeedWindow { int lo, width; };
+static inline SeedWindow seed_window(int c0, int n) {
+    const int lo = c0 & ~31;
+    return SeedWindow{lo, pad32(c0 + n) - lo};
+}
 struct InputSeed {
     int kind = 0;                      // 0 none, 1 action seed (world model -> decoder), 2 sampler seed (decoder -> encoder)
     EpiActionSeed a;
@@ -527,11 +534,18 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
         const float* xin = i == 0 ? c->ws + w->in : c->ws + w->act[i - 1];
         const int ps = g_prof.begin(1, 2.0 * rowsf * (i > 0 ? l.n_in : need) * l.n_out, st);
         if (i == 0 && seedv.kind == 1) {
-            HIP_TRY(gemm_dgrad_epi(c->ws + w->dz[0], l.n_out_pad, c->params + l.w_off, l.ld, rows_pad, l.ld, l.n_out_pad,
-                                   seedv.a, st));
+            // only the input columns the seed consumes are contracted (a 32-aligned window of W_0)
+            const SeedWindow sw = seed_window(seedv.a.c0, seedv.a.n);
+            EpiActionSeed e = seedv.a;
+            e.c0 -= sw.lo;
+            HIP_TRY(gemm_dgrad_epi(c->ws + w->dz[0], l.n_out_pad, c->params + l.w_off + sw.lo, l.ld, rows_pad, sw.width,
+                                   l.n_out_pad, e, st));
         } else if (i == 0 && seedv.kind == 2) {
-            HIP_TRY(gemm_dgrad_epi(c->ws + w->dz[0], l.n_out_pad, c->params + l.w_off, l.ld, rows_pad, l.ld, l.n_out_pad,
-                                   seedv.s, st));
+            const SeedWindow sw = seed_window(seedv.s.c0, seedv.s.Z);
+            EpiSamplerSeed e = seedv.s;
+            e.c0 -= sw.lo;
+            HIP_TRY(gemm_dgrad_epi(c->ws + w->dz[0], l.n_out_pad, c->params + l.w_off + sw.lo, l.ld, rows_pad, sw.width,
+                                   l.n_out_pad, e, st));
         } else {
             HIP_TRY(gemm_dgrad(c->ws + w->dz[i], l.n_out_pad, c->params + l.w_off, l.ld, i > 0 ? xin : nullptr, l.ld,
                                i > 0 ? c->ws + w->dz[i - 1] : c->ws + w->d_in, l.ld, rows_pad, l.ld, l.n_out_pad, st));
@@ -562,8 +576,11 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
                 const int pp = g_prof.begin(3, 2.0 * rowsf * ((double)l.n_in * l.n_out +
                                                (double)(j > 0 ? d.n_in : need) * d.n_out), st);
                 if (j == 0 && seedv.kind == 2) {
-                    HIP_TRY(gemm_bwd_pair_epi(c->ws + w->dz[0], d.n_out_pad, c->params + d.w_off, d.ld, rows_pad, d.ld,
-                                              d.n_out_pad, seedv.s, dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld,
+                    const SeedWindow sw = seed_window(seedv.s.c0, seedv.s.Z);
+                    EpiSamplerSeed es = seedv.s;
+                    es.c0 -= sw.lo;
+                    HIP_TRY(gemm_bwd_pair_epi(c->ws + w->dz[0], d.n_out_pad, c->params + d.w_off + sw.lo, d.ld, rows_pad,
+                                              sw.width, d.n_out_pad, es, dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld,
                                               rows_pad, e, st));
                 } else {
                     HIP_TRY(gemm_bwd_pair(c->ws + w->dz[j], d.n_out_pad, c->params + d.w_off, d.ld,
@@ -898,7 +915,7 @@ static int step_shape(pvae_ctx* c, int phase, int rows, const pvae_step_params* 
         S.lf.nparts[2] = S.wm_tiles * T;
     } else {
         if (sp->a_rec_coeff > 0.0f)
-            S.lf.nparts[0] = S.seed_action ? dgrad_tiles(S.rows_pad, c->L.net[PVAE_NET_WM].layers[0].ld) : S.nparts_a * T;
+            S.lf.nparts[0] = S.seed_action ? dgrad_tiles(S.rows_pad, seed_window(Db, Da).width) : S.nparts_a * T;
         if (S.kl_active) S.lf.nparts[1] = S.gridz * T;
         if (sp->cycle_coeff > 0.0f) S.lf.nparts[3] = S.wm_tiles * T;
     }
