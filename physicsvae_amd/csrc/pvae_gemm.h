@@ -1493,7 +1493,7 @@ inline hipError_t gemm_dgrad(const float* dZ, int ldz, const float* W, int ldw, 
 // wgrad: G[N][Kin] = dZ[M][N]^T X[M][Kin]  (+ bias gradient, + optional loss finalisation)
 // Tile geometry per problem: 64x64, or 32x32 when that leaves at most half the CUs with a tile
 // (PVAE_WGRAD32=0 switches the small geometry off: A/B).
-static int g_wgrad32 = [] { const char* e = getenv("PVAE_WGRAD32"); return e ? atoi(e) : 1; }();   // 2: always (A/B)
+static int g_wgrad32 = [] { const char* e = getenv("PVAE_WGRAD32"); return e ? atoi(e) : 1; }();   // 0: never, 2: always (A/B)
 inline bool wgrad_uses_32x32(int N, int Kin, int M) {
     return g_wgrad32 && ((N / 64) * (Kin / 64) <= 128 || g_wgrad32 == 2) && M % 64 == 0;
 }
