@@ -93,3 +93,21 @@ def test_random_shapes_match_oracle(seed):
             assert torch.equal(u, v), (c, world)
         assert not torch.equal(a[0], p0)
         tr.model.load_state_dict(sd)
+
+
+def test_tile_geometry_switches_keep_parity():
+    """The narrow-layer geometries (32x32 weight-gradient tiles, 16x16 first-layer input-gradient
+    tiles) are chosen per problem at launch time; PVAE_WGRAD32=0 / PVAE_DGRAD16=0 force the wide
+    tiles everywhere and PVAE_WGRAD32=2 the narrow weight-gradient tiles everywhere.  The switches
+    are read when the library is loaded, so the sweep above runs again in fresh processes: every
+    geometry meets the same oracle tolerances."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env in ({"PVAE_WGRAD32": "0", "PVAE_DGRAD16": "0"}, {"PVAE_WGRAD32": "2"}):
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_shapes.py"), "-q", "-x",
+                            "-m", "gpu", "-k", "random_shapes", "-p", "no:cacheprovider"],
+                           env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (env, r.stdout[-2000:], r.stderr[-1000:])
+        assert "40 passed" in r.stdout, (env, r.stdout[-500:])
