@@ -150,6 +150,10 @@ struct pvae_ctx {
     StageArgs next_stage;        // rows_pad > 0: pending for the last launch of this step
     bool next_carried = false;   // set by the launch that took it
     bool seed_pads_clean = false;  // pad columns of the seed panels zeroed (see plan_backward)
+    // deferred Adam (AdamSeg, pvae_gemm.h): the layer whose gradient the last launch stored; the next
+    // weight-gradient launch of the step updates it with extra workgroups (PVAE_DEFER_ADAM=0: off)
+    AdamSeg pending_adam;
+    bool defer_adam = true;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -479,6 +483,23 @@ typedef std::vector<Stage> Plan;
 // What the input-gradient launch of a stack's FIRST layer does with its result (lookahead 1):
 // nothing special (store the panel), or form the gradient seed of the stack that produced those
 // input columns in its epilogue (pvae_gemm.h: EpiActionSeed / EpiSamplerSeed).
+// the pending deferred-Adam segment, handed to the launch that is about to go out
+static AdamSeg take_pending_adam(pvae_ctx* c) {
+    const AdamSeg a = c->pending_adam;
+    c->pending_adam = AdamSeg();
+    return a;
+}
+// nothing left to carry it: its own launch
+static int flush_pending_adam(pvae_ctx* c, hipStream_t st) {
+    const AdamSeg a = take_pending_adam(c);
+    if (a.n4 <= 0) return 0;
+    int grid = (int)((a.n4 + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, st, a.p, a.g, a.m, a.v, a.n4, a.s);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // Columns [c0, c0 + n) of a first-layer input gradient, widened to whole 32-column tiles: the only
 // part of that panel a gradient seed reads, so the only part its launch contracts.
 struct SeedWindow { int lo, width; };
@@ -563,13 +584,18 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
         e.gb = c->grads + l.b_off;
         return e;
     };
-    // wgrad of layer i, optionally fused with the dgrad of layer j (j < 0: alone)
+    // wgrad of layer i, optionally fused with the dgrad of layer j (j < 0: alone).  In a fused pair
+    // that is not the step's last launch the gradient is stored and Adam deferred to workgroups of
+    // the next weight-gradient launch (AdamSeg); every launch carries whatever is pending.
+    const bool can_defer = fused && c->defer_adam && c->grads != nullptr;
     auto wgrad = [=](int i, int j, bool with_fold) -> int {
         const Layer& l = N->layers[i];
         const float* dz = c->ws + w->dz[i];
         const float* xin = i == 0 ? c->ws + w->in : c->ws + w->act[i - 1];
+        const bool defer = can_defer && j >= 0 && !with_fold;
         auto go = [&](auto e) -> int {
             if (with_fold) e.loss = foldv;
+            const AdamSeg ad = take_pending_adam(c);
             if (j >= 0) {
                 const Layer& d = N->layers[j];
                 const float* dx_in = j == 0 ? c->ws + w->in : c->ws + w->act[j - 1];
@@ -581,22 +607,32 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
                     es.c0 -= sw.lo;
                     HIP_TRY(gemm_bwd_pair_epi(c->ws + w->dz[0], d.n_out_pad, c->params + d.w_off + sw.lo, d.ld, rows_pad,
                                               sw.width, d.n_out_pad, es, dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld,
-                                              rows_pad, e, st));
+                                              rows_pad, e, st, &ad));
                 } else {
                     HIP_TRY(gemm_bwd_pair(c->ws + w->dz[j], d.n_out_pad, c->params + d.w_off, d.ld,
                                           j > 0 ? dx_in : nullptr, d.ld, j > 0 ? c->ws + w->dz[j - 1] : c->ws + w->d_in,
                                           d.ld, rows_pad, d.ld, d.n_out_pad, dz, l.n_out_pad, xin, l.ld, l.n_out_pad,
-                                          l.ld, rows_pad, e, st));
+                                          l.ld, rows_pad, e, st, &ad));
                 }
                 g_prof.end(pp, st);
             } else {
                 const int pw = g_prof.begin(2, 2.0 * rowsf * l.n_in * l.n_out, st);
-                HIP_TRY(gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st));
+                HIP_TRY(gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, e, st, &ad));
                 g_prof.end(pw, st);
             }
             return 0;
         };
-        return fused ? go(adam_epi(l)) : go(store_epi(l));
+        if (!fused) return go(store_epi(l));
+        if (!defer) return go(adam_epi(l));
+        const int rc = go(store_epi(l));
+        if (rc == 0) {
+            AdamSeg a;
+            a.p = c->params + l.w_off; a.g = c->grads + l.w_off; a.m = c->m + l.w_off; a.v = c->v + l.w_off;
+            a.n4 = (l.b_off + l.n_out_pad - l.w_off) / 4;
+            a.s = as;
+            c->pending_adam = a;
+        }
+        return rc;
     };
     auto wgrad_pair10 = [=](bool with_fold) -> int {    // layers 1 and 0 in one launch
         const Layer& l1 = N->layers[1];
@@ -606,9 +642,10 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
             if (with_fold) e1.loss = foldv;            // block 0 of the launch belongs to the first problem
             // the step's LAST launch also gathers the next minibatch into the alternate panels
             const bool carry = with_fold && c->next_stage.rows_pad > 0;
+            const AdamSeg ad = take_pending_adam(c);
             HIP_TRY(gemm_wgrad_pair(c->ws + w->dz[1], l1.n_out_pad, c->ws + w->act[0], l1.ld, l1.n_out_pad, l1.ld, e1,
                                     c->ws + w->dz[0], l0.n_out_pad, c->ws + w->in, l0.ld, l0.n_out_pad, l0.ld, e0,
-                                    rows_pad, st, carry ? &c->next_stage : nullptr));
+                                    rows_pad, st, carry ? &c->next_stage : nullptr, &ad));
             if (carry) c->next_carried = true;
             return 0;
         };
@@ -671,12 +708,13 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
             carry_out->run_with_dgrad = [=](const DgradArgs& d) -> int {
                 const int pp = g_prof.begin(3, d.flops + 2.0 * rowsf * l.n_in * l.n_out, st);
                 hipError_t he;
+                const AdamSeg ad = take_pending_adam(c);
                 if (fused) {
                     he = gemm_bwd_pair(d.dZ, d.ldz, d.W, d.ldw, d.mask, d.ldm, d.dX, d.ldo, d.M, d.Kin, d.Nd, dz,
-                                       l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, adam_epi(l), st);
+                                       l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, adam_epi(l), st, &ad);
                 } else {
                     he = gemm_bwd_pair(d.dZ, d.ldz, d.W, d.ldw, d.mask, d.ldm, d.dX, d.ldo, d.M, d.Kin, d.Nd, dz,
-                                       l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, store_epi(l), st);
+                                       l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, store_epi(l), st, &ad);
                 }
                 g_prof.end(pp, st);
                 if (he != hipSuccess) return fail(-10, "gemm_bwd_pair: %s", hipGetErrorString(he));
@@ -778,6 +816,8 @@ int pvae_create(const pvae_config* cfg, pvae_ctx** out) {
     memset(&c->next_stage, 0, sizeof(c->next_stage));
     const char* pv = getenv("PVAE_PAIR");
     c->pair_launch = !(pv && pv[0] == '0');
+    const char* da = getenv("PVAE_DEFER_ADAM");
+    c->defer_adam = !(da && da[0] == '0');
     *out = c;
     return 0;
 }
@@ -1369,8 +1409,10 @@ int pvae_forward_backward(pvae_ctx* c, int phase, int32_t rows, const pvae_step_
     if ((rc = run_forward(c, phase, rows, sp, eps, backward, S, st))) return rc;
     Plan plan;
     plan_backward(c, phase, rows, sp, backward, fused, S, st, plan);
+    c->pending_adam = AdamSeg();
     for (Stage& s : plan)
-        if ((rc = s.run())) return rc;
+        if ((rc = s.run())) { c->pending_adam = AdamSeg(); return rc; }
+    if ((rc = flush_pending_adam(c, st))) return rc;
     if (loss_out && !backward) {
         hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(64), 0, st, S.lf);
         HIP_TRY(hipGetLastError());

@@ -1038,6 +1038,64 @@ __device__ inline void wgrad_body(float* lds, int bid, const GemmArgs& ga, Epi& 
     else wgrad_reg_body<Epi, ABL>(lds, bid, ga, epi);
 }
 
+struct AdamScalars {
+    float step_size;          // lr / (1 - beta1^t)
+    float inv_bc2_sqrt;       // 1 / sqrt(1 - beta2^t)
+    float beta1, beta2, eps;
+    float one_minus_beta1, one_minus_beta2;   // computed in double on the host, as torch does
+};
+
+// torch.optim.Adam single-tensor update (amsgrad False, weight_decay 0), tm:119-122,143:
+//   m <- m + (g - m)(1 - b1) ; v <- v b2 + (1 - b2) g g ; p <- p - step_size * m / (sqrt(v)/bc2_sqrt + eps)
+__device__ inline void adam_update(float g, float& p, float& m, float& v, const AdamScalars& s) {
+    // Moments: every operation pinned (no context-dependent fma contraction), so the fused
+    // epilogue and the flat multi-tensor kernel stay bit-identical.  Step: v_sqrt_f32 / v_rcp_f32
+    // (1 ulp) instead of the correctly rounded sequences (~10x the instructions); the term they
+    // feed is scaled by lr/(1-b1^t) ~ 5e-4 before it meets p, so p moves by < 0.1 ulp of itself.
+    m = __fmaf_rn(__fsub_rn(g, m), s.one_minus_beta1, m);
+    v = __fmaf_rn(v, s.beta2, __fmul_rn(__fmul_rn(s.one_minus_beta2, g), g));
+    const float denom = __fmaf_rn(__builtin_amdgcn_sqrtf(v), s.inv_bc2_sqrt, s.eps);
+    p = __fmaf_rn(-s.step_size, __fmul_rn(m, __builtin_amdgcn_rcpf(denom)), p);
+}
+
+__device__ inline void adam_update4(const v4f& g, v4f& p, v4f& m, v4f& v, const AdamScalars& s) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float pe = p[e], me = m[e], ve = v[e];
+        adam_update(g[e], pe, me, ve, s);
+        p[e] = pe; m[e] = me; v[e] = ve;
+    }
+}
+
+// Deferred Adam: a layer whose weight gradient went to the gradient arena in the PREVIOUS launch is
+// updated by `kAdamBlocks` extra workgroups of the current one (p, g, m, v streamed while the other
+// workgroups contract).  With Adam in the weight-gradient epilogue every workgroup of the launch does
+// its update at the same moment, after the matrix pipe has gone idle: 15.7 us for the fused pair
+// against 12.7 with a plain gradient store; store + 256 co-resident update workgroups: 14.2
+// (tools/pair_probe.hip).  Same arithmetic as the epilogue and as adam_flat_kernel: bit-identical.
+struct AdamSeg {
+    float* p = nullptr;
+    const float* g = nullptr;
+    float* m = nullptr;
+    float* v = nullptr;
+    long long n4 = 0;          // float4 count (0: nothing pending)
+    AdamScalars s{};
+};
+constexpr int kAdamBlocks = 256;
+__device__ inline void adam_seg_body(const AdamSeg& a, int blk) {
+    for (long long i = blk * 256ll + threadIdx.x; i < a.n4; i += kAdamBlocks * 256ll) {
+        v4f pp = reinterpret_cast<v4f*>(a.p)[i];
+        const v4f gg = reinterpret_cast<const v4f*>(a.g)[i];
+        v4f mm = reinterpret_cast<v4f*>(a.m)[i];
+        v4f vv = reinterpret_cast<v4f*>(a.v)[i];
+        adam_update4(gg, pp, mm, vv, a.s);
+        reinterpret_cast<v4f*>(a.p)[i] = pp;
+        reinterpret_cast<v4f*>(a.m)[i] = mm;
+        reinterpret_cast<v4f*>(a.v)[i] = vv;
+    }
+}
+inline int adam_blocks(const AdamSeg* a) { return a && a->n4 > 0 ? kAdamBlocks : 0; }
+
 // Bias gradient of a weight-gradient problem, db[q] = sum over the K rows of Q[k][q], for 64
 // columns per workgroup (fixed summation order), handed to the epilogue's bias() (store, or Adam on
 // the bias).  These few light workgroups are appended to every weight-gradient launch: summing the
@@ -1070,10 +1128,12 @@ __device__ inline void bias_grad_body(float* lds, int tile, const GemmArgs& ga, 
 
 template <class Epi, int ABL = 0>
 __global__ void __launch_bounds__(256)
-gemm_wgrad_reg_kernel(GemmArgs ga, Epi epi, int nw) {
+gemm_wgrad_reg_kernel(GemmArgs ga, Epi epi, int nw, AdamSeg ad) {
     __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
-    if ((int)blockIdx.x < nw) wgrad_body<Epi, ABL>(lds, blockIdx.x, ga, epi);
-    else bias_grad_body(lds, blockIdx.x - nw, ga, epi);
+    const int b = blockIdx.x, nb = bias_tiles(ga);
+    if (b < nw) wgrad_body<Epi, ABL>(lds, b, ga, epi);
+    else if (b < nw + nb) bias_grad_body(lds, b - nw, ga, epi);
+    else adam_seg_body(ad, b - nw - nb);
 }
 
 // Horizontal fusion of two independent backward contractions in ONE launch: blocks [0, nd) run
@@ -1087,7 +1147,7 @@ gemm_wgrad_reg_kernel(GemmArgs ga, Epi epi, int nw) {
 // step that precedes it instead of being a launch of its own.
 template <class EpiW>
 __global__ void __launch_bounds__(256)
-wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2, int n12, StageArgs sa) {
+wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2, int n12, StageArgs sa, AdamSeg ad, int na) {
     __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
     const int b = blockIdx.x;
     const int nb1 = bias_tiles(g1), nb2 = bias_tiles(g2);
@@ -1095,14 +1155,15 @@ wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2, int n12, S
     else if (b < n12) wgrad_body<EpiW>(lds, b - n1, g2, e2);
     else if (b < n12 + nb1) bias_grad_body(lds, b - n12, g1, e1);
     else if (b < n12 + nb1 + nb2) bias_grad_body(lds, b - n12 - nb1, g2, e2);
-    else stage_row(sa, b - n12 - nb1 - nb2, 0, sa.rows_pad);
+    else if (b < n12 + nb1 + nb2 + na) adam_seg_body(ad, b - n12 - nb1 - nb2);
+    else stage_row(sa, b - n12 - nb1 - nb2 - na, 0, sa.rows_pad);
 }
 
 // (The dgrad half stays on the register-staged body here: with the wave-specialised body the
 // pair needs 512-thread blocks and 64 KB of LDS per workgroup and measured 15 % slower.)
 template <class EpiD, class EpiW, int ABL = 0>          // ABL: ablation bits of the two bodies (probes only)
 __global__ void __launch_bounds__(256)
-bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw) {
+bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, AdamSeg ad) {
     __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
     PVAE_MARK(0, 0);
     PVAE_MARK_HW();
@@ -1111,7 +1172,8 @@ bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw) {
         if (gd.tile16) splitk_reg16_body<false, EpiD>(lds, b, gd, ed);
         else splitk_reg_body<false, EpiD, ABL>(lds, b, gd, ed);
     } else if (b < nd + nw) wgrad_body<EpiW, ABL>(lds, b - nd, gw, ew);
-    else bias_grad_body(lds, b - nd - nw, gw, ew);
+    else if (b < nd + nw + bias_tiles(gw)) bias_grad_body(lds, b - nd - nw, gw, ew);
+    else adam_seg_body(ad, b - nd - nw - bias_tiles(gw));
     PVAE_MARK(0, 3);
 }
 
@@ -1300,35 +1362,6 @@ struct EpiSamplerSeed {
     __device__ inline void finish(float*, int, int) const {}
 };
 
-struct AdamScalars {
-    float step_size;          // lr / (1 - beta1^t)
-    float inv_bc2_sqrt;       // 1 / sqrt(1 - beta2^t)
-    float beta1, beta2, eps;
-    float one_minus_beta1, one_minus_beta2;   // computed in double on the host, as torch does
-};
-
-// torch.optim.Adam single-tensor update (amsgrad False, weight_decay 0), tm:119-122,143:
-//   m <- m + (g - m)(1 - b1) ; v <- v b2 + (1 - b2) g g ; p <- p - step_size * m / (sqrt(v)/bc2_sqrt + eps)
-__device__ inline void adam_update(float g, float& p, float& m, float& v, const AdamScalars& s) {
-    // Moments: every operation pinned (no context-dependent fma contraction), so the fused
-    // epilogue and the flat multi-tensor kernel stay bit-identical.  Step: v_sqrt_f32 / v_rcp_f32
-    // (1 ulp) instead of the correctly rounded sequences (~10x the instructions); the term they
-    // feed is scaled by lr/(1-b1^t) ~ 5e-4 before it meets p, so p moves by < 0.1 ulp of itself.
-    m = __fmaf_rn(__fsub_rn(g, m), s.one_minus_beta1, m);
-    v = __fmaf_rn(v, s.beta2, __fmul_rn(__fmul_rn(s.one_minus_beta2, g), g));
-    const float denom = __fmaf_rn(__builtin_amdgcn_sqrtf(v), s.inv_bc2_sqrt, s.eps);
-    p = __fmaf_rn(-s.step_size, __fmul_rn(m, __builtin_amdgcn_rcpf(denom)), p);
-}
-
-__device__ inline void adam_update4(const v4f& g, v4f& p, v4f& m, v4f& v, const AdamScalars& s) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float pe = p[e], me = m[e], ve = v[e];
-        adam_update(g[e], pe, me, ve, s);
-        p[e] = pe; m[e] = me; v[e] = ve;
-    }
-}
-
 // Fixed-order sum of the per-workgroup loss partials -> {total, loss_a, loss_kl, loss_s,
 // loss_cyc} (tpv:430-435 weighting).  Runs in one wave: as the tail of the step's last
 // weight-gradient launch (training) or as its own tiny kernel (evaluation).
@@ -1510,43 +1543,45 @@ inline WgradPlan plan_wgrad(const float* dZ, int ldz, const float* X, int ldx, i
 }
 template <class Epi>
 inline hipError_t gemm_wgrad(const float* dZ, int ldz, const float* X, int ldx, int N, int Kin, int M,
-                             const Epi& e, hipStream_t st) {
+                             const Epi& e, hipStream_t st, const AdamSeg* ad = nullptr) {
     const WgradPlan w = plan_wgrad(dZ, ldz, X, ldx, N, Kin, M);
-    PVAE_LAUNCH((gemm_wgrad_reg_kernel<Epi>), dim3(w.grid + w.nbias), dim3(256), st, w.ga, e, w.grid);
+    PVAE_LAUNCH((gemm_wgrad_reg_kernel<Epi>), dim3(w.grid + w.nbias + adam_blocks(ad)), dim3(256), st, w.ga, e, w.grid,
+                ad ? *ad : AdamSeg());
     return hipGetLastError();
 }
 // one launch, two independent weight gradients (the two last layers of a backward pass)
 template <class EpiW>
 inline hipError_t gemm_wgrad_pair(const float* dZ1, int ldz1, const float* X1, int ldx1, int N1, int Kin1,
                                   const EpiW& e1, const float* dZ2, int ldz2, const float* X2, int ldx2, int N2,
-                                  int Kin2, const EpiW& e2, int M, hipStream_t st, const StageArgs* next = nullptr) {
+                                  int Kin2, const EpiW& e2, int M, hipStream_t st, const StageArgs* next = nullptr,
+                                  const AdamSeg* ad = nullptr) {
     const WgradPlan w1 = plan_wgrad(dZ1, ldz1, X1, ldx1, N1, Kin1, M);
     const WgradPlan w2 = plan_wgrad(dZ2, ldz2, X2, ldx2, N2, Kin2, M);
     StageArgs sa;
     memset(&sa, 0, sizeof(sa));
     if (next) sa = *next;                     // rows_pad extra blocks gather the next minibatch
-    PVAE_LAUNCH((wgrad_pair_kernel<EpiW>), dim3(w1.grid + w2.grid + w1.nbias + w2.nbias + sa.rows_pad), dim3(256), st,
-                       w1.ga, e1, w1.grid, w2.ga, e2, w1.grid + w2.grid, sa);
+    PVAE_LAUNCH((wgrad_pair_kernel<EpiW>), dim3(w1.grid + w2.grid + w1.nbias + w2.nbias + adam_blocks(ad) + sa.rows_pad),
+                dim3(256), st, w1.ga, e1, w1.grid, w2.ga, e2, w1.grid + w2.grid, sa, ad ? *ad : AdamSeg(), adam_blocks(ad));
     return hipGetLastError();
 }
 // one launch: dX'[M][Kin'] = (dZ'[M][N'] W'[N'][Kin']) .* mask   ||   G[N][Kin] = dZ[M][N]^T X[M][Kin]
 template <class EpiD, class EpiW>
 inline hipError_t gemm_bwd_pair_epi(const float* dZd, int ldzd, const float* Wd, int ldwd, int Md, int Kind, int Nd,
                                     const EpiD& ed, const float* dZw, int ldzw, const float* Xw, int ldxw, int Nw,
-                                    int Kinw, int Mw, const EpiW& ew, hipStream_t st) {
+                                    int Kinw, int Mw, const EpiW& ew, hipStream_t st, const AdamSeg* ad = nullptr) {
     const DgradPlan d = plan_dgrad(dZd, ldzd, Wd, ldwd, Md, Kind, Nd);
     const WgradPlan w = plan_wgrad(dZw, ldzw, Xw, ldxw, Nw, Kinw, Mw);
-    PVAE_LAUNCH((bwd_pair_kernel<EpiD, EpiW>), dim3(d.grid + w.grid + w.nbias), dim3(256), st,
-                       d.ga, ed, d.grid, w.ga, ew, w.grid);
+    PVAE_LAUNCH((bwd_pair_kernel<EpiD, EpiW>), dim3(d.grid + w.grid + w.nbias + adam_blocks(ad)), dim3(256), st,
+                       d.ga, ed, d.grid, w.ga, ew, w.grid, ad ? *ad : AdamSeg());
     return hipGetLastError();
 }
 template <class EpiW>
 inline hipError_t gemm_bwd_pair(const float* dZd, int ldzd, const float* Wd, int ldwd, const float* mask, int ldm,
                                 float* dXd, int ldod, int Md, int Kind, int Nd,
                                 const float* dZw, int ldzw, const float* Xw, int ldxw, int Nw, int Kinw, int Mw,
-                                const EpiW& ew, hipStream_t st) {
+                                const EpiW& ew, hipStream_t st, const AdamSeg* ad = nullptr) {
     const EpiMask ed{dXd, ldod, mask, ldm};
-    return gemm_bwd_pair_epi(dZd, ldzd, Wd, ldwd, Md, Kind, Nd, ed, dZw, ldzw, Xw, ldxw, Nw, Kinw, Mw, ew, st);
+    return gemm_bwd_pair_epi(dZd, ldzd, Wd, ldwd, Md, Kind, Nd, ed, dZw, ldzw, Xw, ldxw, Nw, Kinw, Mw, ew, st, ad);
 }
 
 }  // namespace pvae

@@ -13,6 +13,31 @@
 __device__ unsigned long long* g_timeline;
 #include "../physicsvae_amd/csrc/pvae_gemm.h"
 using namespace pvae;
+// bwd_pair with gradient store, plus `na` extra workgroups that apply Adam to ANOTHER layer's
+// stored gradient (p, m, v, g streamed from memory) while the contractions run
+template <class EpiD, class EpiW>
+__global__ void __launch_bounds__(256)
+pair_plus_adam(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, float* p, const float* g, float* m, float* v,
+               long long n4, AdamScalars as, int na) {
+    __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
+    const int b = blockIdx.x;
+    if (b < nd) splitk_reg_body<false, EpiD, 0>(lds, b, gd, ed);
+    else if (b < nd + nw) wgrad_body<EpiW, 0>(lds, b - nd, gw, ew);
+    else if (b < nd + nw + bias_tiles(gw)) bias_grad_body(lds, b - nd - nw, gw, ew);
+    else {
+        const int a = b - nd - nw - bias_tiles(gw);
+        for (long long i = a * 256ll + threadIdx.x; i < n4; i += na * 256ll) {
+            v4f pp = reinterpret_cast<v4f*>(p)[i];
+            const v4f gg = reinterpret_cast<const v4f*>(g)[i];
+            v4f mm = reinterpret_cast<v4f*>(m)[i];
+            v4f vv = reinterpret_cast<v4f*>(v)[i];
+            adam_update4(gg, pp, mm, vv, as);
+            reinterpret_cast<v4f*>(p)[i] = pp;
+            reinterpret_cast<v4f*>(m)[i] = mm;
+            reinterpret_cast<v4f*>(v)[i] = vv;
+        }
+    }
+}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 #define CK2(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) printf("%s: %s\n", #x, hipGetErrorString(e_)); } while (0)
@@ -81,7 +106,7 @@ int main() {
             const int nd = (part & 1) ? g1.grid : 0, nw2 = (part & 2) ? g2.grid : 0;
             hipLaunchKernelGGL((bwd_pair_kernel<EpiMask, EpiGradAdam, A>), dim3(nd + nw2), dim3(256), 0, st,
                                GemmArgs{dZ, N, W, K, N, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, nd,
-                               GemmArgs{dZ, N, X, K, M, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, e, nw2);
+                               GemmArgs{dZ, N, X, K, M, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, e, nw2, AdamSeg());
         };
         for (int i = 0; i < 10; ++i) launch();
         hipStreamSynchronize(st);
@@ -121,7 +146,7 @@ int main() {
             auto launch = [&]() {
                 hipLaunchKernelGGL((bwd_pair_kernel<EpiMask, EpiGradStore, 0>), dim3(g1.grid + g2.grid), dim3(256), 0, st,
                                    GemmArgs{big, dN, W, K, dN, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, g1.grid,
-                                   GemmArgs{big, wN, X, K, wM, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, es, g2.grid);
+                                   GemmArgs{big, wN, X, K, wM, g2.tiles_q, g2.tiles_p, g2.p_per_xcd}, es, g2.grid, AdamSeg());
             };
             for (int i = 0; i < 10; ++i) launch();
             hipStreamSynchronize(st);
@@ -146,6 +171,29 @@ int main() {
             st2("wgrad contraction done", g1.grid, g1.grid + g2.grid, 2);
             st2("wgrad finished", g1.grid, g1.grid + g2.grid, 3);
         };
+        {
+            // deferred Adam: a second layer's p/m/v/g (same size), updated by extra workgroups
+            float *p2, *g2, *m2, *v2;
+            CK(hipMalloc(&p2, nw * 4)); CK(hipMalloc(&g2, nw * 4)); CK(hipMalloc(&m2, nw * 4)); CK(hipMalloc(&v2, nw * 4));
+            CK(hipMemset(p2, 0, nw * 4)); CK(hipMemset(g2, 0, nw * 4)); CK(hipMemset(m2, 0, nw * 4)); CK(hipMemset(v2, 0, nw * 4));
+            const EpiMask ed{dX, K, act, K};
+            const GemmGrid g1 = make_grid(M, K, 32, 32), gg2 = make_grid(N, K, 64, 64);
+            for (int na : {0, 32, 64, 128, 256, 512}) {
+                auto launch = [&]() {
+                    hipLaunchKernelGGL((pair_plus_adam<EpiMask, EpiGradStore>), dim3(g1.grid + gg2.grid + gg2.tiles_q + na), dim3(256), 0, st,
+                                       GemmArgs{dZ, N, W, K, N, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, g1.grid,
+                                       GemmArgs{dZ, N, X, K, M, gg2.tiles_q, gg2.tiles_p, gg2.p_per_xcd}, es, gg2.grid,
+                                       p2, g2, m2, v2, (long long)(nw / 4), as, na);
+                };
+                for (int i = 0; i < 10; ++i) launch();
+                hipStreamSynchronize(st);
+                hipEventRecord(a, st);
+                for (int i = 0; i < 100; ++i) launch();
+                hipEventRecord(b, st); hipEventSynchronize(b);
+                float t; hipEventElapsedTime(&t, a, b);
+                printf("   gradient-store pair + %3d Adam workgroups on another layer: period %6.2f us\n", na, t * 10.0f);
+            }
+        }
         float* dX2; CK(hipMalloc(&dX2, (size_t)512 * K * 4));
         timeit("gradient store: 256x1024 (k 1024) | 1024x1024 (k 256)", 256, 1024, 1024, 256);
         float* keep = dX; dX = dX2;
