@@ -154,6 +154,7 @@ struct pvae_ctx {
     // weight-gradient launch of the step updates it with extra workgroups (PVAE_DEFER_ADAM=0: off)
     AdamSeg pending_adam;
     bool defer_adam = true;
+    bool same_layer_pairs = true;  // PVAE_SAME_LAYER=0: wgrad_i rides with dgrad_{i-1} as before (A/B)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -592,7 +593,8 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
         const Layer& l = N->layers[i];
         const float* dz = c->ws + w->dz[i];
         const float* xin = i == 0 ? c->ws + w->in : c->ws + w->act[i - 1];
-        const bool defer = can_defer && j >= 0 && !with_fold;
+        // (j == i: the launch also reads W_i, so the update MUST wait for the next one)
+        const bool defer = can_defer && j >= 0 && (!with_fold || j == i);
         auto go = [&](auto e) -> int {
             if (with_fold) e.loss = foldv;
             const AdamSeg ad = take_pending_adam(c);
@@ -654,6 +656,26 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
         return rc;
     };
 
+    // layer 0 alone (same-layer schedule): the step's last launch of a stack without input gradient;
+    // carries the loss finalisation, the pending update and the gather of the next minibatch
+    auto wgrad_last0 = [=](bool with_fold) -> int {
+        const Layer& l0 = N->layers[0];
+        const int pw = g_prof.begin(2, 2.0 * rowsf * l0.n_in * l0.n_out, st);
+        auto go = [&](auto e0) -> int {
+            if (with_fold) e0.loss = foldv;
+            const bool carry = with_fold && c->next_stage.rows_pad > 0;
+            const AdamSeg ad = take_pending_adam(c);
+            HIP_TRY(gemm_wgrad_pair(c->ws + w->dz[0], l0.n_out_pad, c->ws + w->in, l0.ld, l0.n_out_pad, l0.ld, e0,
+                                    (const float*)nullptr, 0, (const float*)nullptr, 0, 0, l0.ld, e0,
+                                    rows_pad, st, carry ? &c->next_stage : nullptr, &ad));
+            if (carry) c->next_carried = true;
+            return 0;
+        };
+        const int rc = fused ? go(adam_epi(l0)) : go(store_epi(l0));
+        g_prof.end(pw, st);
+        return rc;
+    };
+
     auto push = [&](std::function<int()> f) -> Stage& {
         plan.emplace_back();
         plan.back().run = std::move(f);
@@ -669,6 +691,21 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
             if (has_dgrad(i)) push([=] { return dgrad(i); });
             const bool f = fold && i == 0;
             seg_of(i, i, push([=] { return wgrad(i, -1, f); }));
+        }
+        return;
+    }
+    if ((!fused || can_defer) && c->same_layer_pairs) {
+        // Same-layer schedule: with the update deferred (or no update at all: gradient store for the
+        // data-parallel exchange) wgrad_i no longer writes W_i, so it shares a launch with dgrad_i
+        // instead of trailing one launch behind it:
+        //     dgrad_L + wgrad_L | dgrad_{L-1} + wgrad_{L-1} [+ Adam_L] | ... | wgrad_0 [+ Adam_1]
+        // The short first launch (K = output width) and the short last one (narrow layer 0) each get
+        // a partner of their own size, instead of a lone short launch at one end and two narrow
+        // problems in one launch at the other.
+        for (int i = last; i >= 0; --i) {
+            const bool f = fold && i == 0;
+            if (has_dgrad(i)) seg_of(i, i, push([=] { return wgrad(i, i, f); }));
+            else seg_of(0, 0, push([=] { return wgrad_last0(f); }));
         }
         return;
     }
@@ -818,6 +855,8 @@ int pvae_create(const pvae_config* cfg, pvae_ctx** out) {
     c->pair_launch = !(pv && pv[0] == '0');
     const char* da = getenv("PVAE_DEFER_ADAM");
     c->defer_adam = !(da && da[0] == '0');
+    const char* sl = getenv("PVAE_SAME_LAYER");
+    c->same_layer_pairs = !(sl && sl[0] == '0');
     *out = c;
     return 0;
 }
