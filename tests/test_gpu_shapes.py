@@ -95,17 +95,20 @@ def test_random_shapes_match_oracle(seed):
         tr.model.load_state_dict(sd)
 
 
-def test_tile_geometry_switches_keep_parity():
+def test_schedule_and_geometry_switches_keep_parity():
     """The narrow-layer geometries (32x32 weight-gradient tiles, 16x16 first-layer input-gradient
     tiles) are chosen per problem at launch time; PVAE_WGRAD32=0 / PVAE_DGRAD16=0 force the wide
-    tiles everywhere and PVAE_WGRAD32=2 the narrow weight-gradient tiles everywhere.  The switches
-    are read when the library is loaded, so the sweep above runs again in fresh processes: every
-    geometry meets the same oracle tolerances."""
+    tiles everywhere and PVAE_WGRAD32=2 the narrow weight-gradient tiles everywhere.
+    PVAE_SAME_LAYER=0 pairs wgrad_i with dgrad_{i-1} (the schedule used when the update cannot be
+    deferred), PVAE_DEFER_ADAM=0 keeps Adam in every weight-gradient epilogue.  The switches are
+    read when the library / context is created, so the sweep above runs again in fresh processes:
+    every variant meets the same oracle tolerances and the same fused == flat Adam identity."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for env in ({"PVAE_WGRAD32": "0", "PVAE_DGRAD16": "0"}, {"PVAE_WGRAD32": "2"}):
+    for env in ({"PVAE_WGRAD32": "0", "PVAE_DGRAD16": "0"}, {"PVAE_WGRAD32": "2"}, {"PVAE_SAME_LAYER": "0"},
+                {"PVAE_DEFER_ADAM": "0"}):
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_shapes.py"), "-q", "-x",
                             "-m", "gpu", "-k", "random_shapes", "-p", "no:cacheprovider"],
                            env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=900)

@@ -18,9 +18,10 @@ using namespace pvae;
 template <class EpiD, class EpiW>
 __global__ void __launch_bounds__(256)
 pair_plus_adam(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, float* p, const float* g, float* m, float* v,
-               long long n4, AdamScalars as, int na) {
+               long long n4, AdamScalars as, int na, int adam_first) {
     __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+    if (adam_first) b = b < na ? nd + nw + bias_tiles(gw) + b : b - na;
     if (b < nd) splitk_reg_body<false, EpiD, 0>(lds, b, gd, ed);
     else if (b < nd + nw) wgrad_body<EpiW, 0>(lds, b - nd, gw, ew);
     else if (b < nd + nw + bias_tiles(gw)) bias_grad_body(lds, b - nd - nw, gw, ew);
@@ -178,12 +179,13 @@ int main() {
             CK(hipMemset(p2, 0, nw * 4)); CK(hipMemset(g2, 0, nw * 4)); CK(hipMemset(m2, 0, nw * 4)); CK(hipMemset(v2, 0, nw * 4));
             const EpiMask ed{dX, K, act, K};
             const GemmGrid g1 = make_grid(M, K, 32, 32), gg2 = make_grid(N, K, 64, 64);
-            for (int na : {0, 32, 64, 128, 256, 512}) {
+            for (int first : {0, 1})
+            for (int na : {0, 128, 256, 512}) {
                 auto launch = [&]() {
                     hipLaunchKernelGGL((pair_plus_adam<EpiMask, EpiGradStore>), dim3(g1.grid + gg2.grid + gg2.tiles_q + na), dim3(256), 0, st,
                                        GemmArgs{dZ, N, W, K, N, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, g1.grid,
                                        GemmArgs{dZ, N, X, K, M, gg2.tiles_q, gg2.tiles_p, gg2.p_per_xcd}, es, gg2.grid,
-                                       p2, g2, m2, v2, (long long)(nw / 4), as, na);
+                                       p2, g2, m2, v2, (long long)(nw / 4), as, na, first);
                 };
                 for (int i = 0; i < 10; ++i) launch();
                 hipStreamSynchronize(st);
@@ -191,7 +193,7 @@ int main() {
                 for (int i = 0; i < 100; ++i) launch();
                 hipEventRecord(b, st); hipEventSynchronize(b);
                 float t; hipEventElapsedTime(&t, a, b);
-                printf("   gradient-store pair + %3d Adam workgroups on another layer: period %6.2f us\n", na, t * 10.0f);
+                printf("   gradient-store pair + %3d Adam workgroups on another layer (%s): period %6.2f us\n", na, first ? "dispatched first" : "dispatched last", t * 10.0f);
             }
         }
         float* dX2; CK(hipMalloc(&dX2, (size_t)512 * K * 4));
