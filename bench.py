@@ -193,8 +193,9 @@ def main():
         adam = "+Adam" if dp.world == 1 else ""
         names = {0: "gemm_splitk_ws_kernel<P_ROW> / gemm_splitk_reg16_kernel (forward layer)",
                  1: "gemm_splitk_ws_kernel<P_COL> (input gradient, 32x32 tile)",
-                 2: "gemm_wgrad_reg_kernel / wgrad_pair_kernel (weight gradient%s, 64x64 tiles)" % adam,
-                 3: "bwd_pair_kernel (input gradient of layer l-1 || weight gradient%s of layer l)" % adam}
+                 2: "wgrad_pair_kernel / gemm_wgrad_reg_kernel (trailing weight gradient%s + deferred Adam of the layer before)" % adam,
+                 3: "bwd_pair_kernel (input gradient || weight gradient of one layer%s)" %
+                    (", gradient stored; Adam of the previous layer in extra workgroups" if dp.world == 1 else "")}
         cats = {}
         for c in (0, 1, 2, 3):
             ms, cnt, fls = C.c_double(), C.c_int64(), C.c_double()
@@ -213,7 +214,7 @@ def main():
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))[::-1]:
                 summ = json.load(open(f))
-                key = {3: "bwd_pair_kernel<EpiMask,EpiGradAdam>", 2: "wgrad_pair_kernel<EpiGradAdam>",
+                key = {3: "bwd_pair_kernel<EpiMask,EpiGradStore>", 2: "wgrad_pair_kernel<EpiGradAdam>",
                        0: "gemm_splitk_ws_kernel<P_ROW,EpiBiasAct>", 1: "gemm_splitk_ws_kernel<P_COL,EpiMask>"}[dom]
                 if key in summ and "hbm_traffic_MB" in summ[key] and dp.world == 1 and a.phase == "world" and a.config == "c2":
                     traffic, traffic_src = summ[key]["hbm_traffic_MB"] * 1e6, os.path.relpath(f, ROOT)

@@ -10,9 +10,10 @@ import numpy as np
 
 
 def short(n):
-    if "wgrad_pair" in n: return "wgrad_pair_kernel<EpiGradAdam>"
-    if "bwd_pair" in n: return "bwd_pair_kernel<EpiMask,EpiGradAdam>"
-    if "wgrad_reg" in n: return "gemm_wgrad_reg_kernel<EpiGradAdam>"
+    epi = "EpiGradStore" if "EpiGradStore" in n else "EpiGradAdam"
+    if "wgrad_pair" in n: return "wgrad_pair_kernel<%s>" % epi
+    if "bwd_pair" in n: return "bwd_pair_kernel<%s,%s>" % ("EpiSamplerSeed" if "SamplerSeed" in n else "EpiMask", epi)
+    if "wgrad_reg" in n: return "gemm_wgrad_reg_kernel<%s>" % epi
     if "reg16" in n and "EpiMse" in n: return "gemm_splitk_reg16_kernel<EpiMse>"
     if "reg16" in n: return "gemm_splitk_reg16_kernel<EpiBiasAct>"
     if "splitk_ws" in n and "EpiMse" in n: return "gemm_splitk_ws_kernel<P_ROW,EpiMse>"
