@@ -47,7 +47,10 @@ enum { PVAE_LOSS_MSE = 0, PVAE_LOSS_L1 = 1 };
 
 /* flags for pvae_forward_backward */
 enum {
-    PVAE_FLAG_FUSED_ADAM = 1, /* apply Adam inside the weight-gradient kernels (1 GPU)       */
+    PVAE_FLAG_FUSED_ADAM = 1, /* apply Adam inside the backward launches (1 GPU): in the weight-
+                               * gradient epilogue, or -- when a gradient arena is bound -- deferred by
+                               * one launch to extra workgroups, the arena serving as scratch (its
+                               * contents are unspecified afterwards); same arithmetic either way  */
     PVAE_FLAG_NO_BACKWARD = 2 /* forward + losses only (tm:147-156 test loop, parity probes) */
 };
 
