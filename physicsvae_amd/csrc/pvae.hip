@@ -474,16 +474,6 @@ struct Stage {
 };
 typedef std::vector<Stage> Plan;
 
-// dz[last] must be filled.  Layer by layer, last to first: the input gradient of layer i reads
-// W_i, then the weight gradient of layer i (+bias gradient, +Adam) may overwrite it.  When both
-// exist, dgrad_{i-1} (needs dz_{i-1}, W_{i-1}) and wgrad_i (needs dz_i, x_i; writes W_i) are
-// independent and go out as ONE horizontally fused launch:
-//     dgrad_L | dgrad_{L-1} + wgrad_L | ... | dgrad_1 + wgrad_2 | [dgrad_0] + wgrad_1 | wgrad_0
-// (without an input gradient the two last weight gradients share a launch).  `fold` (optional)
-// is executed by the blocks of the last launch.
-// What the input-gradient launch of a stack's FIRST layer does with its result (lookahead 1):
-// nothing special (store the panel), or form the gradient seed of the stack that produced those
-// input columns in its epilogue (pvae_gemm.h: EpiActionSeed / EpiSamplerSeed).
 // the pending deferred-Adam segment, handed to the launch that is about to go out
 static AdamSeg take_pending_adam(pvae_ctx* c) {
     const AdamSeg a = c->pending_adam;
@@ -501,6 +491,20 @@ static int flush_pending_adam(pvae_ctx* c, hipStream_t st) {
     return 0;
 }
 
+// dz[last] must be filled.  Layer by layer, last to first: the input gradient of layer i reads
+// W_i; a weight gradient of layer i with Adam in its epilogue overwrites W_i.  Two schedules:
+//  * same layer (the default whenever the update can be deferred, and for the gradient-store path
+//    of the data-parallel exchange): wgrad_i only stores its gradient, shares ONE horizontally
+//    fused launch with dgrad_i, and Adam_i runs as extra workgroups of the next launch:
+//        dgrad_L + wgrad_L | dgrad_{L-1} + wgrad_{L-1} + Adam_L | ... | wgrad_0 + Adam_1
+//  * one behind (Adam in the epilogue; no gradient arena, PVAE_SAME_LAYER=0 / PVAE_DEFER_ADAM=0):
+//    dgrad_{i-1} (needs dz_{i-1}, W_{i-1}) and wgrad_i (needs dz_i, x_i; writes W_i) are independent:
+//        dgrad_L | dgrad_{L-1} + wgrad_L | ... | dgrad_1 + wgrad_2 | [dgrad_0] + wgrad_1 | wgrad_0
+//    (without an input gradient the two last weight gradients share a launch).
+// `fold` (optional) is executed by the blocks of the last launch.
+// What the input-gradient launch of a stack's FIRST layer does with its result (lookahead 1):
+// nothing special (store the panel), or form the gradient seed of the stack that produced those
+// input columns in its epilogue (pvae_gemm.h: EpiActionSeed / EpiSamplerSeed).
 // Columns [c0, c0 + n) of a first-layer input gradient, widened to whole 32-column tiles: the only
 // part of that panel a gradient seed reads, so the only part its launch contracts.
 struct SeedWindow { int lo, width; };
