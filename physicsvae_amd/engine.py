@@ -28,6 +28,41 @@ class Arch:
         return (self.Db, self.Da, self.Z, self.te, self.md, self.wm)
 
 
+class GraphedInfer:
+    """`HipEngine.infer` captured once into a HIP graph.  The rollout forward at B = 1 is 8-10 tiny
+    launches and host-bound (~33 us of Python + launch calls for ~15 us of GPU work); replaying the
+    captured sequence is one host call.  Inputs and outputs live in static tensors: `__call__` copies
+    the observation (and the draws, when the sampler is on) in and returns the static outputs
+    (a_hat, s2_hat|None, z) -- valid until the next call.  The graph reads the parameter arena in
+    place, so optimizer steps or load_state_dict between calls are seen by the next replay."""
+
+    def __init__(self, engine, rows, want_s2=True, noise=False):
+        engine._need_gpu()
+        self.engine, self.rows, self.noise = engine, int(rows), bool(noise)
+        dev = engine.device
+        self.obs = torch.zeros(self.rows, 2 * engine.arch.Db, dtype=torch.float32, device=dev)
+        self.eps = torch.zeros(self.rows, engine.arch.Z, dtype=torch.float32, device=dev) if noise else None
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                      # warm-up outside the capture (allocations, lazy init)
+            self.out = engine.infer(self.obs, eps=self.eps, noise=self.noise, want_s2=want_s2)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self.out = engine.infer(self.obs, eps=self.eps, noise=self.noise, want_s2=want_s2, out=self.out)
+
+    def __call__(self, obs, eps=None):
+        self.obs.copy_(obs.reshape(self.rows, -1), non_blocking=True)
+        if self.noise:
+            if eps is not None:
+                self.eps.copy_(eps, non_blocking=True)
+            else:
+                self.eps.normal_()
+        self.graph.replay()
+        return self.out
+
+
 def make_step_params(lr, adam_t=(1, 1, 1), a_rec=1.0, kl=1.0, s_rec=0.0, cyc=1e-3,
                      global_rows=0, seed=0, offset=0, beta1=0.9, beta2=0.999, eps=1e-8, loss="MSE"):
     sp = _lib.StepParams()
@@ -308,6 +343,10 @@ class HipEngine:
             1 if noise else 0, int(seed), int(offset), a_hat.data_ptr(),
             s2.data_ptr() if s2 is not None else None, z.data_ptr(), self._stream()), "pvae_infer")
         return a_hat, s2, z
+
+    def graphed_infer(self, rows, want_s2=True, noise=False):
+        """The rollout forward for a fixed row count as ONE replayable HIP graph (see GraphedInfer)."""
+        return GraphedInfer(self, rows, want_s2=want_s2, noise=noise)
 
     def panel(self, kind, net=0, layer=0):
         """Workspace panel as a [Bp, width] view (inspection / tests).  kind: 'in', 'd_in',

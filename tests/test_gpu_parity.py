@@ -840,3 +840,28 @@ def test_rollout_forward_from_weights_the_reference_accepted(golden):
     a_hat, s2, z = tr.engine.infer(obs, noise=False)
     assert max_err_scaled(a_hat.cpu(), g["reference_logits_after_loading_our_files"][:, : arch["Da"]]) < 2e-5
     assert max_err_scaled(s2.cpu(), g["reference_future_state"]) < 2e-5
+
+
+@pytest.mark.parametrize("rows", [1, 4, 32])
+def test_graphed_rollout_forward_equals_eager(golden, rows):
+    """HipEngine.graphed_infer replays the rollout forward as one HIP graph: same outputs as the
+    eager call bit for bit (deterministic z = mu, and with supplied draws), and it follows the
+    parameters -- an optimizer step between two replays changes the second one's result."""
+    g, arch, data, x, y, sd, eps, tr = _setup_single(golden, "single_c1")
+    eng = tr.engine
+    obs = x[:rows, 0, :].contiguous().to(DEV)
+    for noise in (False, True):
+        e = eps[:rows].to(DEV) if noise else None
+        want = [t.clone() if t is not None else None for t in eng.infer(obs, eps=e, noise=noise, want_s2=True)]
+        gi = eng.graphed_infer(rows, want_s2=True, noise=noise)
+        for _ in range(3):
+            got = gi(obs, eps=e)
+            for a, b in zip(got, want):
+                assert torch.equal(a, b)
+    # parameters are read in place (the first epoch trains the world model: s2_hat moves)
+    gi = eng.graphed_infer(rows, want_s2=True, noise=False)
+    before = gi(obs)[1].clone()
+    tr.train()
+    after = gi(obs)[1].clone()
+    assert not torch.equal(before, after)
+    assert torch.equal(after, eng.infer(obs, noise=False, want_s2=True)[1])

@@ -40,5 +40,25 @@ for name, sizes in (("default 256x2/512x3/1024x2", []),          # the trainer's
                 torch.cuda.synchronize()
                 lat.append((time.perf_counter() - t2) * 1e6)
             lat.sort()
-            print("%-28s rows %2d  %s : %6.1f us / call back to back (host %5.1f), %6.1f us single-call latency"
-                  % (name, rows, "TE+MD+WM" if want_s2 else "TE+MD   ", wall, (t1 - t0) / n * 1e6, lat[len(lat) // 2]))
+            # the same forward as one replayable HIP graph (static input/output tensors)
+            gi = eng.graphed_infer(rows, want_s2=want_s2, noise=False)
+            for _ in range(20):
+                gi(obs)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(n):
+                gi(obs)
+            torch.cuda.synchronize()
+            gwall = (time.perf_counter() - t3) / n * 1e6
+            glat = []
+            for _ in range(50):
+                torch.cuda.synchronize()
+                t4 = time.perf_counter()
+                gi(obs)
+                torch.cuda.synchronize()
+                glat.append((time.perf_counter() - t4) * 1e6)
+            glat.sort()
+            print("%-28s rows %2d  %s : %6.1f us / call back to back (host %5.1f), %6.1f us single-call latency | "
+                  "as a HIP graph: %6.1f us back to back, %6.1f us single call"
+                  % (name, rows, "TE+MD+WM" if want_s2 else "TE+MD   ", wall, (t1 - t0) / n * 1e6, lat[len(lat) // 2],
+                     gwall, glat[len(glat) // 2]))
