@@ -161,7 +161,7 @@ def main():
         "config": {"workload": "%s, batch %d/GPU, TE/MD/WM 4x1024, %s phase" % (workload, a.batch, a.phase),
                    "phase": a.phase, "global_batch": a.batch * a.gpus,
                    "parallelism": "dp%d" % a.gpus,
-                   "optimizer": "Adam fused in wgrad" if not dp.collective else
+                   "optimizer": "Adam inside the backward launches (deferred one launch behind each weight gradient)" if not dp.collective else
                    ("in-library RCCL all-reduce per net (same stream) + Adam" if eng.has_comm else
                     "torch.distributed bucketed async all-reduce + per-bucket Adam")},
         "last_loss": last_loss,
