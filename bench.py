@@ -1,36 +1,69 @@
 """bench.py -- training samples/s of the PhysicsVAE hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--phase world|joint]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--phase joint|world] [--config c2|c5]
+
+Launched plainly with --gpus N > 1 it starts the N ranks itself (one process per GPU, RCCL over
+xGMI; on a box with fewer GPUs than ranks the ranks share a GPU over gloo -- a functional check
+of the same code path, reported as such).  Launched by `python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N` it is one of the ranks (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* from the environment).
 
 One "step" = one optimizer step over one minibatch of synthetic demonstrations: minibatch
 gather from the HBM-resident demo set -> MLP forward -> losses -> backward -> Adam.
-Workload = BASELINE.json configs[1]: synthetic loco demo (10 episodes x 1000 steps,
-dim_state_body 197, dim_action 45), batch 256 per GPU, TE/MD/WM = 4x1024, world-model-only
-phase.  (`--phase joint` times the joint world-model + CVAE step of configs[2]; the default
-run also reports it as `joint_value`.)  N > 1: data-parallel, 256 rows per GPU (global batch
-N*256, weak scaling), gradient SUM all-reduce over RCCL, replicated Adam.
+Workload = BASELINE.json configs[1..2] sizes: synthetic loco demo (10 episodes x 1000 steps,
+dim_state_body 197, dim_action 45), batch 256 per GPU, TE/MD/WM = 4x1024.  The headline `value`
+is the JOINT phase (world-model + CVAE step: encoder -> sampler -> decoder -> frozen world model,
+ELBO + cycle loss, TE and MD learn), the step BASELINE.json's metric names; the world-model-only
+phase of configs[1] is reported beside it as `world_value` with its own `world_roofline`.
+N > 1: data-parallel, 256 rows per GPU (global batch N*256, weak scaling), gradient SUM
+all-reduce over RCCL, replicated Adam.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch
-stream in an instrumented pass after the timed region; `cpu_baseline` is the oracle's
-restatement of the reference loop (oracle/refpath.py: the checker, timed here, never the
-product path) on this host's cores over a bounded sample.
+Timing protocol: W warm-up steps, then R = 3 timed regions of max(K, 200) steps each, every
+region bracketed by barrier + torch.cuda.synchronize() on both sides, MAX over ranks per region;
+`value` / `ms_per_step` are the MEDIAN region (>= 200 steps, median of 3).
+
+`roofline` (dominant kernel of the timed phase): algorithmic flops per launch / average launch
+duration.  Two clocks are reported: HIP events stamped at the kernel's own start / end on the
+launch stream in an instrumented pass (`avg_launch_us`), and -- at N = 1 -- rocprofv3
+--kernel-trace of this same command run as a child process (`avg_launch_us_rocprof`); `frac` uses
+the rocprofv3 duration when it is available (the larger of the two).  `traffic` = HBM bytes per
+launch from separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md HBM
+section), collected live by the same child runs.  `cpu_baseline` is the oracle's restatement of
+the reference loop (oracle/refpath.py: the checker, timed here, never the product path) on this
+host's cores over a bounded sample, swept over thread counts.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk
+MIN_TIMED_STEPS, REPEATS = 200, 3
+METRIC = "train samples/sec (world-model+VAE step), loco demo, batch 256, 1/2/4/8 GPU"
+
+# profiler categories of the library (include/pvae.h) and the kernels rocprofv3 files under them
+CAT_NAMES = {
+    0: "forward layer (gemm_splitk_ws_kernel<P_ROW> / gemm_splitk_reg16_kernel<P_ROW>)",
+    1: "input gradient alone (gemm_splitk_ws_kernel<P_COL> / gemm_splitk_reg16_kernel<P_COL>)",
+    2: "trailing weight gradient (wgrad_pair_kernel / gemm_wgrad_reg_kernel)",
+    3: "bwd_pair_kernel (input gradient || weight gradient of one layer, + deferred Adam of the layer before)",
+}
+CAT_MATCH = {
+    0: ("gemm_splitk_ws_kernel<true", "gemm_splitk_reg16_kernel<true", "gemm_splitk_reg_kernel<true"),
+    1: ("gemm_splitk_ws_kernel<false", "gemm_splitk_reg16_kernel<false", "gemm_splitk_reg_kernel<false"),
+    2: ("wgrad_pair_kernel", "gemm_wgrad_reg_kernel"),
+    3: ("bwd_pair_kernel",),
+}
 
 
 def algorithmic_flops_per_sample(Db, Da, Z, W, d):
@@ -44,28 +77,223 @@ def algorithmic_flops_per_sample(Db, Da, Z, W, d):
     return 2 * world, 2 * joint
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--phase", choices=["world", "joint"], default="world")
+    ap.add_argument("--phase", choices=["world", "joint"], default="joint",
+                    help="phase timed as `value` (default joint: the world-model + VAE step)")
     ap.add_argument("--batch", type=int, default=None, help="rows per GPU (default 256; 512 for --config c5)")
     ap.add_argument("--config", choices=["c2", "c5"], default="c2",
                     help="c2 = BASELINE configs[1..3] sizes (default); c5 = configs[4]: 1e6 transitions, "
                          "dim_state_body 400, dim_action 90, 512 rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary-phase and roofline passes")
-    a = ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary-phase, roofline and rocprofv3 passes")
+    ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 child runs (kernel trace + PMC)")
+    ap.add_argument("--inner", action="store_true",
+                    help="(internal) the child run that rocprofv3 wraps: one timed region of exactly --steps steps "
+                         "of --phase, nothing else")
+    return ap.parse_args(argv)
 
+
+# ---------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with no rendezvous in the environment
+# ---------------------------------------------------------------------------------------------
+def self_launch(a):
+    import torch
+    ndev = torch.cuda.device_count()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    shared = ndev < a.gpus
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_RANK=str(r),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if shared:
+            # fewer GPUs than ranks (a 1-GPU box): the ranks share devices and exchange over gloo -- RCCL
+            # refuses two ranks on one device.  Same sharding / reduction / Adam code, not a scaling number.
+            env.update(PVAE_LOCAL_DEVICE=str(r % max(ndev, 1)), PVAE_DIST_BACKEND="gloo", PVAE_BENCH_SHARED_GPU="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
+# rocprofv3 child runs (N = 1): kernel durations + HBM traffic + MFMA busy for the timed phase
+# ---------------------------------------------------------------------------------------------
+def _csv_rows(path):
+    import csv
+    with open(path, newline="") as f:
+        return list(csv.DictReader(f))
+
+
+def _find(d, suffix):
+    for root, _, files in os.walk(d):
+        for f in files:
+            if f.endswith(suffix):
+                return os.path.join(root, f)
+    return None
+
+
+def _cat_of(name):
+    for c, pats in CAT_MATCH.items():
+        if any(p in name for p in pats):
+            return c
+    return None
+
+
+def rocprof_passes(a, phase, budget_s=150):
+    """-> {cat: {"avg_us", "calls", "hbm_fetch_bytes", "hbm_write_bytes", "mfma_busy"}} or {"error": ...}.
+    One `rocprofv3 --kernel-trace --stats` pass and three `--pmc` passes (never combined with the
+    hip/hsa trace domains) over `python bench.py --inner --phase <phase>`."""
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    tmp = tempfile.mkdtemp(prefix="pvae_rocprof_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--inner", "--phase", phase, "--config", a.config,
+             "--steps", "100", "--warmup", "20", "--no-cpu-baseline", "--no-extra"]
+    if a.batch:
+        child += ["--batch", str(a.batch)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    passes = [("trace", ["--kernel-trace", "--stats"]),
+              ("fetch", ["--pmc", "FETCH_SIZE", "--kernel-trace"]),
+              ("write", ["--pmc", "WRITE_SIZE", "--kernel-trace"]),
+              ("mfma", ["--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "--kernel-trace"])]
+    out, t_end, notes = {}, time.time() + budget_s, []
+    for tag, flags in passes:
+        left = t_end - time.time()
+        if left < 20:
+            notes.append("%s pass skipped (time budget)" % tag)
+            continue
+        d = os.path.join(tmp, tag)
+        try:
+            subprocess.run([exe] + flags + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + child, cwd="/tmp",
+                           env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=left, check=True)
+        except Exception as exc:                                   # noqa: BLE001
+            notes.append("%s pass failed: %s" % (tag, type(exc).__name__))
+            continue
+        if tag == "trace":
+            f = _find(d, "kernel_stats.csv")
+            if not f:
+                notes.append("trace pass wrote no kernel_stats.csv")
+                continue
+            for r in _csv_rows(f):
+                c = _cat_of(r["Name"])
+                if c is None:
+                    continue
+                e = out.setdefault(c, {"calls": 0, "total_ns": 0.0})
+                e["calls"] += int(r["Calls"])
+                e["total_ns"] += float(r["TotalDurationNs"])
+        else:
+            f = _find(d, "counter_collection.csv")
+            if not f:
+                notes.append("%s pass wrote no counter_collection.csv" % tag)
+                continue
+            acc = {}
+            for r in _csv_rows(f):
+                c = _cat_of(r["Kernel_Name"])
+                if c is None:
+                    continue
+                k = (c, r["Counter_Name"])
+                s = acc.setdefault(k, [0.0, 0])
+                s[0] += float(r["Counter_Value"])
+                s[1] += 1
+            for (c, name), (tot, n) in acc.items():
+                out.setdefault(c, {})[name] = tot / max(n, 1)
+    shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for c, e in out.items():
+        r = {}
+        if e.get("calls"):
+            r["avg_us"] = e["total_ns"] / e["calls"] / 1e3
+            r["calls"] = e["calls"]
+        # MI355X_MICROARCH.md, HBM: FETCH_SIZE (KiB) reports half the bytes of wide coalesced reads on gfx950
+        if "FETCH_SIZE" in e:
+            r["hbm_fetch_bytes"] = e["FETCH_SIZE"] * 1024 * 2
+        if "WRITE_SIZE" in e:
+            r["hbm_write_bytes"] = e["WRITE_SIZE"] * 1024
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in e and r.get("avg_us"):
+            # busy cycles summed over the 1024 SIMDs; launch duration at the 2.4 GHz peak clock
+            r["mfma_busy"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (r["avg_us"] * 1e-6 * 2.4e9)
+        res[c] = r
+    if notes:
+        res["notes"] = notes
+    return res
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: thread sweep of the oracle's restatement of the reference loop
+# ---------------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(a, sd, Db, Da, Z, W, D, phase, synth_demo):
+    import torch
+    from oracle import refpath as R        # the checker, timed as the CPU baseline -- this leg only
+    arch = R.make_arch(Db, Da, latent=Z, te=(W, D), md=(W, D), wm=(W, D))
+    data = synth_demo(0, 10, 1000, Db, Da)                       # bounded CPU sample of the workload's shape
+    X, Y = R.build_windows(data)
+    default_threads = torch.get_num_threads()
+    sweep = sorted({t for t in (1, 8, 16, 32, 64, default_threads) if 1 <= t <= max(default_threads, 1)})
+    per_setting_s = 4.0
+    results = {}
+    t_all = time.perf_counter()
+    for t in sweep:
+        torch.set_num_threads(t)
+        trc = R.RefTrainer(arch, sd, X, Y, a.batch, max_iter_world_model=(10 ** 9 if phase == "world" else 0))
+        trc.step(max_batches=1)                                   # warm-up (allocator, thread pool)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            trc.step(max_batches=2)
+            n += 2
+            dt = time.perf_counter() - t0
+            if dt > per_setting_s or n >= 60:
+                break
+        results[t] = n * a.batch / dt
+    torch.set_num_threads(default_threads)
+    best = max(results, key=results.get)
+    return {"value": results[best], "unit": "samples/s", "cores": best, "threads_best": best,
+            "value_1thread": results.get(1), "value_default_threads": results.get(default_threads),
+            "default_threads": default_threads, "sweep": {str(k): v for k, v in results.items()},
+            "kind": "port", "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
+            "sample": "%s phase, minibatches of %d from a 10x1000 synthetic demo of the same dims, "
+                      "oracle/refpath.RefTrainer (stock torch CPU ops in the reference's op order: per-sample "
+                      "Dataset + collate, full forward incl. value branch, torch.optim.Adam, per-batch .item()); "
+                      "per thread count 1 warm-up minibatch then up to %.0f s / 60 minibatches; %.1f s in total"
+                      % (phase, a.batch, per_setting_s, time.perf_counter() - t_all)}
+
+
+# ---------------------------------------------------------------------------------------------
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(a))
+
+    import torch
+    import torch.distributed as dist
     from physicsvae_amd import _lib, parallel
     rank, world, local = parallel.init_from_env()
-    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (a.gpus, world))
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
 
     from synth_demo import make_trainer, synth_demo      # tools/: inputs only; oracle/ is imported by the
-                                                         # cpu_baseline leg below and nowhere else
+                                                         # cpu_baseline leg and nowhere else
 
     import contextlib
     import io
@@ -74,7 +302,7 @@ def main():
         Db, Da = 197, 45
         a.batch = a.batch or 256
         data = synth_demo(0, 10, 1000, Db, Da)
-        workload = "BASELINE configs[1]: synthetic loco demo 10x1000, dim_state_body 197, dim_action 45"
+        workload = "BASELINE configs[1-2]: synthetic loco demo 10x1000, dim_state_body 197, dim_action 45"
     else:
         Db, Da = 400, 90
         a.batch = a.batch or 512
@@ -102,7 +330,6 @@ def main():
         tr.train_loader.dataset = ds
     eng.bind_dataset(*ds.device_arrays(eng.device))
     n_win = len(ds)
-    steps_per_epoch = dp.global_steps(n_win, a.batch)
     lib = _lib.load()
 
     def set_phase(name):
@@ -134,14 +361,12 @@ def main():
             rows_done += grows
         return rows_done
 
-    def timed(name, steps, warmup):
-        phase, nets = set_phase(name)
-        run_steps(phase, nets, warmup, 0)
+    def region(phase, nets, steps, start):
         if dp.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        samples = run_steps(phase, nets, steps, warmup)
+        samples = run_steps(phase, nets, steps, start)
         torch.cuda.synchronize()
         if dp.world > 1:
             dist.barrier()
@@ -150,108 +375,141 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return samples / dt, dt / steps * 1e3, float(loss_buf[0].item())
+        return samples, dt
 
-    value, ms_per_step, last_loss = timed(a.phase, a.steps, a.warmup)
+    def timed(name, steps, warmup, repeats):
+        """-> (samples/s, ms/step, last loss, per-region samples/s): `repeats` regions of `steps` steps."""
+        phase, nets = set_phase(name)
+        run_steps(phase, nets, warmup, 0)
+        rates, mss, start = [], [], warmup
+        for _ in range(repeats):
+            samples, dt = region(phase, nets, steps, start)
+            start += steps
+            rates.append(samples / dt)
+            mss.append(dt / steps * 1e3)
+        return statistics.median(rates), statistics.median(mss), float(loss_buf[0].item()), rates
+
+    if a.inner:                                # the command rocprofv3 wraps: one region, one line, done
+        v, ms, loss, _ = timed(a.phase, a.steps, a.warmup, 1)
+        print(json.dumps({"inner": True, "phase": a.phase, "value": v, "ms_per_step": ms, "last_loss": loss}), flush=True)
+        return
+
+    timed_steps = max(a.steps, MIN_TIMED_STEPS)
+    value, ms_per_step, last_loss, rates = timed(a.phase, timed_steps, a.warmup, REPEATS)
+    comm_rank, comm_ranks = eng.comm_info()
+    shared_gpu = os.environ.get("PVAE_BENCH_SHARED_GPU") == "1"
+    if not dp.collective:
+        transport = "none (single rank: Adam inside the backward launches, deferred one launch behind each weight gradient)"
+    elif eng.has_comm:
+        transport = "in-library RCCL all-reduce per net on the compute stream + flat Adam"
+    else:
+        transport = "torch.distributed (%s) bucketed async all-reduce + per-bucket Adam" % dist.get_backend()
     out = {
-        "metric": "train samples/sec (world-model+VAE step), loco demo, batch 256, 1/2/4/8 GPU",
+        "metric": METRIC,
         "value": value, "unit": "samples/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s, batch %d/GPU, TE/MD/WM 4x1024, %s phase" % (workload, a.batch, a.phase),
-                   "phase": a.phase, "global_batch": a.batch * a.gpus,
-                   "parallelism": "dp%d" % a.gpus,
-                   "optimizer": "Adam inside the backward launches (deferred one launch behind each weight gradient)" if not dp.collective else
-                   ("in-library RCCL all-reduce per net (same stream) + Adam" if eng.has_comm else
-                    "torch.distributed bucketed async all-reduce + per-bucket Adam")},
+                   "phase": a.phase, "global_batch": a.batch * a.gpus, "parallelism": "dp%d" % a.gpus,
+                   "exchange": transport},
+        "timing": {"timed_steps_per_region": timed_steps, "regions": REPEATS, "statistic": "median",
+                   "region_values": rates},
+        "rccl_ranks": comm_ranks, "rccl_rank": comm_rank,
+        "ranks_share_a_gpu": shared_gpu,
         "last_loss": last_loss,
     }
     fl_world, fl_joint = algorithmic_flops_per_sample(Db, Da, Z, W, D)
-    fl = fl_world if a.phase == "world" else fl_joint
-    out["step_mfma_frac"] = value / a.gpus * fl / (PEAK_F32_MFMA_TFLOPS * 1e12)
+    fl = {"world": fl_world, "joint": fl_joint}
+    out["step_mfma_frac"] = value / a.gpus * fl[a.phase] / (PEAK_F32_MFMA_TFLOPS * 1e12)
+    out["algorithmic_mflop_per_sample"] = {"world": fl_world / 1e6, "joint": fl_joint / 1e6}
 
-    if not a.no_extra:
-        other = "joint" if a.phase == "world" else "world"
-        v2, ms2, _ = timed(other, max(a.steps // 4, 20), max(a.warmup // 4, 5))
-        out[other + "_value"] = v2
-        out[other + "_ms_per_step"] = ms2
-        # ---- roofline: instrumented pass (HIP events on the launch stream around every
-        # contraction launch), same workload/phase as `value`
-        phase, nets = set_phase(a.phase)
-        torch.cuda.synchronize()
-        lib.pvae_profile_enable(1)
-        n_prof = 50
-        run_steps(phase, nets, n_prof, 0) if dp.world == 1 else None
-        if dp.world > 1:
-            for i in range(n_prof):
-                first, rows, grows = dp.shard(i % (n_win // (a.batch * dp.world)), n_win, a.batch)
-                sp = tr.step_params(nets, grows, True)
-                eng.gather(first, rows)
-                eng.forward_backward(phase, rows, sp, fused_adam=False, loss_out=loss_buf)
-        torch.cuda.synchronize()
-        lib.pvae_profile_enable(0)
-        adam = "+Adam" if dp.world == 1 else ""
-        names = {0: "gemm_splitk_ws_kernel<P_ROW> / gemm_splitk_reg16_kernel (forward layer)",
-                 1: "gemm_splitk_ws_kernel<P_COL> (input gradient, 32x32 tile)",
-                 2: "wgrad_pair_kernel / gemm_wgrad_reg_kernel (trailing weight gradient%s + deferred Adam of the layer before)" % adam,
-                 3: "bwd_pair_kernel (input gradient || weight gradient of one layer%s)" %
-                    (", gradient stored; Adam of the previous layer in extra workgroups" if dp.world == 1 else "")}
+    def read_cats():
         cats = {}
-        for c in (0, 1, 2, 3):
+        for c in (0, 1, 2, 3, 4):
             ms, cnt, fls = C.c_double(), C.c_int64(), C.c_double()
             _lib.check(lib.pvae_profile_read(c, C.byref(ms), C.byref(cnt), C.byref(fls)))
             if cnt.value:
-                cats[c] = dict(kernel=names[c], total_ms=ms.value, launches=cnt.value,
-                               avg_us=ms.value / cnt.value * 1e3,
-                               algo_gflop_per_launch=fls.value / cnt.value / 1e9,
-                               tflops=fls.value / (ms.value * 1e-3) / 1e12)
+                cats[c] = dict(total_ms=ms.value, launches=cnt.value, avg_us=ms.value / cnt.value * 1e3,
+                               per_launch=fls.value / cnt.value)
+        return cats
+
+    def roofline_block(name, ms_step, rp):
+        """Instrumented pass of phase `name` (HIP events around every contraction launch and the RCCL
+        collective) + the rocprofv3 figures `rp` of the same phase -> (roofline, kernels, collective)."""
+        phase, nets = set_phase(name)
+        n_prof = 50
+        torch.cuda.synchronize()
+        lib.pvae_profile_enable(1)
+        run_steps(phase, nets, n_prof, 0)
+        torch.cuda.synchronize()
+        lib.pvae_profile_enable(0)
+        cats = read_cats()
+        coll = cats.pop(4, None)
+        if not cats:
+            return None, None, coll
         dom = max(cats, key=lambda c: cats[c]["total_ms"])
         d = cats[dom]
-        # HBM traffic per launch of that kernel: PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE,
-        # MI355X_MICROARCH.md HBM section) of this same command, summarised under profiles/
-        traffic, traffic_src = None, None
-        try:
-            import glob
-            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))[::-1]:
-                summ = json.load(open(f))
-                key = {3: "bwd_pair_kernel<EpiMask,EpiGradStore>", 2: "wgrad_pair_kernel<EpiGradAdam>",
-                       0: "gemm_splitk_ws_kernel<P_ROW,EpiBiasAct>", 1: "gemm_splitk_ws_kernel<P_COL,EpiMask>"}[dom]
-                if key in summ and "hbm_traffic_MB" in summ[key] and dp.world == 1 and a.phase == "world" and a.config == "c2":
-                    traffic, traffic_src = summ[key]["hbm_traffic_MB"] * 1e6, os.path.relpath(f, ROOT)
-                    break
-        except Exception:
-            pass
-        out["roofline"] = {"bound": "mfma", "achieved": d["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": d["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                           "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC)", "traffic_source": traffic_src,
-                           "kernel": d["kernel"], "avg_launch_us": d["avg_us"],
-                           "algorithmic_gflop_per_launch": d["algo_gflop_per_launch"],
-                           "launches_per_step": d["launches"] / n_prof}
-        out["kernels"] = {cats[c]["kernel"]: {k: v for k, v in cats[c].items() if k != "kernel"} for c in cats}
-        out["gemm_time_share_of_step"] = sum(c["total_ms"] for c in cats.values()) / n_prof / ms_per_step
+        r = (rp or {}).get(dom, {})
+        us_ev, us_rp = d["avg_us"], r.get("avg_us")
+        us = max(us_ev, us_rp) if us_rp else us_ev
+        tflops = d["per_launch"] / (us * 1e-6) / 1e12
+        traffic = None
+        if "hbm_fetch_bytes" in r and "hbm_write_bytes" in r:
+            traffic = r["hbm_fetch_bytes"] + r["hbm_write_bytes"]
+        roof = {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                "traffic_unit": "HBM bytes/launch: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, child runs of this command",
+                "kernel": CAT_NAMES[dom], "phase": name,
+                "clock": "rocprofv3 --kernel-trace (child run)" if us_rp and us_rp >= us_ev else "HIP events at kernel start/end",
+                "avg_launch_us": us_ev, "avg_launch_us_rocprof": us_rp,
+                "frac_hip_events": d["per_launch"] / (us_ev * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "frac_rocprof": (d["per_launch"] / (us_rp * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS) if us_rp else None,
+                "mfma_busy": r.get("mfma_busy"),
+                "algorithmic_gflop_per_launch": d["per_launch"] / 1e9,
+                "launches_per_step": d["launches"] / n_prof}
+        kernels = {}
+        for c, v in cats.items():
+            k = {"launches_per_step": v["launches"] / n_prof, "avg_us": v["avg_us"],
+                 "algo_gflop_per_launch": v["per_launch"] / 1e9,
+                 "tflops": v["per_launch"] / (v["avg_us"] * 1e-6) / 1e12}
+            for key in ("avg_us", "hbm_fetch_bytes", "hbm_write_bytes", "mfma_busy"):
+                if key in (rp or {}).get(c, {}):
+                    k["rocprof_" + key] = rp[c][key]
+            kernels[CAT_NAMES[c]] = k
+        kernels["gemm_time_share_of_step"] = sum(v["total_ms"] for v in cats.values()) / n_prof / ms_step
+        return roof, kernels, coll
+
+    if not a.no_extra:
+        other = "joint" if a.phase == "world" else "world"
+        v2, ms2, _, _ = timed(other, MIN_TIMED_STEPS, max(a.warmup // 2, 5), REPEATS)
+        out[other + "_value"] = v2
+        out[other + "_ms_per_step"] = ms2
+        out[other + "_step_mfma_frac"] = v2 / a.gpus * fl[other] / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        rp_main = rp_other = None
+        if a.gpus == 1 and not a.no_rocprof:
+            t0 = time.time()
+            rp_main = rocprof_passes(a, a.phase)
+            rp_other = rocprof_passes(a, other, budget_s=60)       # kernel trace (+ what fits)
+            out["rocprof_child_runs_s"] = time.time() - t0
+            for tag, rp in ((a.phase, rp_main), (other, rp_other)):
+                if rp.get("error") or rp.get("notes"):
+                    out.setdefault("rocprof_notes", {})[tag] = rp.get("error") or rp.get("notes")
+        roof, kernels, coll = roofline_block(a.phase, ms_per_step, rp_main)
+        if roof:
+            out["roofline"], out["kernels"] = roof, kernels
+        roof2, kernels2, _ = roofline_block(other, ms2, rp_other)
+        if roof2:
+            out[other + "_roofline"], out[other + "_kernels"] = roof2, kernels2
+        if coll:
+            n_prof = 50
+            out["allreduce_us_per_step"] = coll["total_ms"] / n_prof * 1e3
+            out["allreduce_calls_per_step"] = coll["launches"] / n_prof
+            out["allreduce_bytes_per_step"] = coll["per_launch"] * coll["launches"] / n_prof
+        elif dp.collective:
+            out["allreduce_us_per_step"] = None                   # torch.distributed transport: not instrumented
 
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
-        from oracle import refpath as R        # the checker, timed as the CPU baseline -- this leg only
-        arch = R.make_arch(Db, Da, latent=Z, te=(W, D), md=(W, D), wm=(W, D))
-        if a.config != "c2":
-            data = synth_demo(0, 10, 1000, Db, Da)                 # bounded CPU sample of the same shape
-        X, Y = R.build_windows(data)
-        n_b = 3 * 39 if a.config == "c2" else 2 * (len(X) // a.batch)
-        t0 = time.perf_counter()
-        trc = R.RefTrainer(arch, sd, X, Y, a.batch, max_iter_world_model=(10 ** 9 if a.phase == "world" else 0))
-        trc.step(max_batches=2)
-        t1 = time.perf_counter()
-        done, per = 0, min(39, len(X) // a.batch)
-        while done < n_b:
-            trc.step(max_batches=min(per, n_b - done))
-            done += per
-        dt = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": n_b * a.batch / dt, "unit": "samples/s",
-                               "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": "%d minibatches of %d (passes over the full minibatches of a 10x1000 "
-                                         "synthetic demo of the same dims), %s phase, oracle/refpath.RefTrainer (stock "
-                                         "torch CPU ops in the reference's op order), %.1f s" % (n_b, a.batch, a.phase, dt),
-                               "host_cpus": os.cpu_count()}
+        out["cpu_baseline"] = cpu_baseline(a, sd, Db, Da, Z, W, D, a.phase, synth_demo)
     if dist.is_initialized():
         torch.cuda.synchronize()
         dist.barrier()
@@ -259,9 +517,8 @@ def main():
         dist.destroy_process_group()
     # RCCL writes an init banner through C stdio, which a pipe would otherwise deliver AFTER
     # Python's output: drain it first so that the JSON object is the last line on stdout.
-    import ctypes
     sys.stdout.flush()
-    ctypes.CDLL(None).fflush(None)
+    C.CDLL(None).fflush(None)
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -138,6 +138,13 @@ int pvae_bind_dataset(pvae_ctx* ctx, const float* states, const float* actions,
 /* Minibatch gather: windows [first_window, first_window+rows) -> network input panels.
  * Replaces DataLoader + default collate over DatasetBase (tm:166-175, 137-139). */
 int pvae_gather(pvae_ctx* ctx, int64_t first_window, int32_t rows, void* stream);
+/* Declare the staging panels dirty: the staged training minibatch and a minibatch gathered ahead
+ * (pvae_train_step_prefetch) are forgotten, so the next training call gathers again and
+ * pvae_forward_backward without a new gather fails with "staged rows" instead of running on
+ * overwritten panels.  Needed by callers that replay a captured HIP graph of pvae_infer: the graph
+ * writes the panels that were current when it was captured, and the host-side bookkeeping of
+ * pvae_infer does not run on replay.  Host-side only; launches nothing. */
+int pvae_invalidate_staging(pvae_ctx* ctx);
 /* Same, from explicit device tensors x[rows][L][2*Db], y[rows][L][Da] (dense fp32, L =
  * lookahead): the compute_loss(y, x) entry of tpv:361 for callers that bring their own batch. */
 int pvae_set_batch(pvae_ctx* ctx, const float* x, const float* y, int32_t rows, void* stream);
@@ -211,6 +218,10 @@ int pvae_adam_segment(pvae_ctx* ctx, int net, int64_t offset, int64_t count, con
 int pvae_comm_unique_id(void* id128);
 int pvae_comm_init(pvae_ctx* ctx, int rank, int world, const void* id128);
 int pvae_comm_destroy(pvae_ctx* ctx);
+/* What the ctx's communicator itself reports (ncclCommUserRank / ncclCommCount): *nranks = 0 when
+ * the ctx has no communicator.  bench.py prints this as `rccl_ranks`, so that the number of ranks
+ * in the JSON line comes from RCCL and not from a command-line flag. */
+int pvae_comm_info(pvae_ctx* ctx, int* rank, int* nranks);
 /* Exchange settings of pvae_dp_train_step (same values on every rank): bucket_bytes (default 0 =
  * one bucket per stack, reduced in line on the caller's stream; PVAE_DP_BUCKET_MB at
  * pvae_comm_init overrides the default); test_delay_us > 0 puts a spin kernel of that length in
@@ -270,7 +281,9 @@ int pvae_reparam(pvae_ctx* ctx, const float* mu_logvar, int32_t rows, const floa
  * separate instrumented pass, never in a timed region).
  * category: 0 = forward kernel, 1 = input-gradient kernel (alone), 2 = weight-gradient(+Adam)
  * launches (single or the two trailing layers in one launch), 3 = fused input-gradient +
- * weight-gradient(+Adam) launch.
+ * weight-gradient(+Adam) launch, 4 = the RCCL all-reduce of pvae_allreduce_grads /
+ * pvae_dp_train_step (events recorded on the stream around the collective; total_flops then
+ * carries the payload BYTES).
  * pvae_profile_read synchronises on the recorded events and returns the summed duration
  * (ms), launch count and ALGORITHMIC flops (2*rows*n_in*n_out on the unpadded dims). */
 int pvae_profile_enable(int on);

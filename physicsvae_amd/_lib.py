@@ -65,6 +65,7 @@ _SIGS = {
     "pvae_bind_arenas": (C.c_int, [_P, _P, _P, _P, _P]),
     "pvae_bind_workspace": (C.c_int, [_P, _P, C.c_size_t]),
     "pvae_bind_dataset": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64]),
+    "pvae_invalidate_staging": (C.c_int, [_P]),
     "pvae_gather": (C.c_int, [_P, C.c_int64, C.c_int32, _P]),
     "pvae_set_batch": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "pvae_forward_backward": (C.c_int, [_P, C.c_int, C.c_int32, C.POINTER(StepParams), _P, _P,
@@ -78,6 +79,7 @@ _SIGS = {
     "pvae_comm_unique_id": (C.c_int, [_P]),
     "pvae_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "pvae_comm_destroy": (C.c_int, [_P]),
+    "pvae_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pvae_comm_config": (C.c_int, [_P, C.c_int64, C.c_int32]),
     "pvae_allreduce_grads": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     "pvae_dp_train_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P,

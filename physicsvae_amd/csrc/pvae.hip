@@ -69,6 +69,23 @@ struct Profiler {
         if (!g_kernel_ev[0]) n = slot + 1;          // consumed by a launch
         g_kernel_ev[0] = g_kernel_ev[1] = nullptr;
     }
+    // a range that is not one of our launches (the RCCL collective): events recorded on the stream
+    // around the call; `fl` carries the payload bytes instead of flops
+    int begin_range(int category, double fl, hipStream_t st) {
+        if (!on || n >= kMax) return -1;
+        if (n >= created) {
+            if (hipEventCreate(&ev[n][0]) != hipSuccess || hipEventCreate(&ev[n][1]) != hipSuccess) return -1;
+            created = n + 1;
+        }
+        cat[n] = category;
+        flops[n] = fl;
+        if (hipEventRecord(ev[n][0], st) != hipSuccess) return -1;
+        return n;
+    }
+    void end_range(int slot, hipStream_t st) {
+        if (slot < 0) return;
+        if (hipEventRecord(ev[slot][1], st) == hipSuccess) n = slot + 1;
+    }
 };
 static Profiler g_prof;
 
@@ -85,6 +102,8 @@ struct Rccl {
     int (*CommInitRank)(void**, int, RcclId, int) = nullptr;          // id is passed BY VALUE
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok() const { return h && GetUniqueId && CommInitRank && AllReduce && CommDestroy && GetErrorString; }
 };
@@ -106,6 +125,8 @@ static int rccl_load() {
     g_rccl.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(h, "ncclCommInitRank");
     g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    g_rccl.CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");           // optional (pvae_comm_info)
+    g_rccl.CommUserRank = (int (*)(void*, int*))dlsym(h, "ncclCommUserRank");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
     if (!g_rccl.ok()) {
         g_rccl = Rccl();
@@ -940,6 +961,13 @@ static int stage(pvae_ctx* c, long long first_window, const float* x, const floa
     return 0;
 }
 
+int pvae_invalidate_staging(pvae_ctx* c) {
+    if (!c) return fail(-1, "null ctx");
+    c->pf.valid = false;
+    c->staged_rows = 0;
+    return 0;
+}
+
 int pvae_gather(pvae_ctx* c, int64_t first_window, int32_t rows, void* stream) {
     if (!c) return fail(-1, "null ctx");
     if (!c->states) return fail(-2, "dataset not bound");
@@ -1563,6 +1591,16 @@ int pvae_comm_init(pvae_ctx* c, int rank, int world, const void* id128) {
     return 0;
 }
 
+int pvae_comm_info(pvae_ctx* c, int* rank, int* nranks) {
+    if (!c || !rank || !nranks) return fail(-1, "null argument");
+    *rank = 0; *nranks = 0;
+    if (!c->comm) return 0;                    // no communicator: 0 ranks
+    if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(-20, "RCCL lacks ncclCommCount / ncclCommUserRank");
+    RCCL_TRY(g_rccl.CommCount(c->comm, nranks));
+    RCCL_TRY(g_rccl.CommUserRank(c->comm, rank));
+    return 0;
+}
+
 int pvae_comm_config(pvae_ctx* c, int64_t bucket_bytes, int32_t test_delay_us) {
     if (!c) return fail(-1, "null ctx");
     if (bucket_bytes < 0 || test_delay_us < 0 || test_delay_us > 100000) return fail(-1, "bad exchange settings");
@@ -1640,8 +1678,10 @@ int pvae_allreduce_grads(pvae_ctx* c, int64_t offset, int64_t count, void* strea
     if (offset < 0 || count < 0 || offset + count > c->L.arena_floats)
         return fail(-1, "slice [%lld, +%lld) outside the arena", (long long)offset, (long long)count);
     if (count == 0) return 0;
+    const int ps = g_prof.begin_range(4, (double)count * sizeof(float), (hipStream_t)stream);
     RCCL_TRY(g_rccl.AllReduce(c->grads + offset, c->grads + offset, (size_t)count, kNcclFloat32, kNcclSum, c->comm,
                               (hipStream_t)stream));
+    g_prof.end_range(ps, (hipStream_t)stream);
     return 0;
 }
 

@@ -53,6 +53,12 @@ class GraphedInfer:
             self.out = engine.infer(self.obs, eps=self.eps, noise=self.noise, want_s2=want_s2, out=self.out)
 
     def __call__(self, obs, eps=None):
+        # The captured launches write the staging panels that were current at capture time.  A
+        # prefetched train step swaps the current and alternate panels, so after an odd number of them
+        # those panels hold the NEXT training minibatch: tell the ctx that whatever is staged or
+        # prefetched is gone (the next train step gathers again; pvae_infer does the same on the eager
+        # path).  Host-side bookkeeping only, nothing is launched.
+        self.engine.invalidate_staging()
         self.obs.copy_(obs.reshape(self.rows, -1), non_blocking=True)
         if self.noise:
             if eps is not None:
@@ -83,6 +89,9 @@ class HipEngine:
         self.max_batch = int(max_batch)
         self.lookahead = int(lookahead)          # steps unrolled per sample (tpv:277, 367-428)
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            # an indexed device, so that comparisons with tensor.device (always indexed) are exact
+            self.device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
         self.cfg = arch.config(max_batch, self.lookahead)
         n = self.lib.pvae_arena_floats(C.byref(self.cfg))
         _lib.check(int(n), "pvae_arena_floats")
@@ -178,6 +187,11 @@ class HipEngine:
         _lib.check(self.lib.pvae_bind_dataset(self.ctx, states.data_ptr(), actions.data_ptr(),
                                               window_row.data_ptr(), states.shape[0],
                                               window_row.shape[0]), "pvae_bind_dataset")
+
+    def invalidate_staging(self):
+        """Forget the staged / prefetched minibatch (something else is about to overwrite the panels)."""
+        if self.ctx is not None:
+            _lib.check(self.lib.pvae_invalidate_staging(self.ctx), "pvae_invalidate_staging")
 
     def gather(self, first_window, rows):
         self._need_gpu()
@@ -288,6 +302,14 @@ class HipEngine:
         if self.ctx is not None and self.has_comm:
             _lib.check(self.lib.pvae_comm_destroy(self.ctx), "pvae_comm_destroy")
             self.has_comm = False
+
+    def comm_info(self):
+        """(rank, nranks) as the ctx's RCCL communicator reports them; (0, 0) without one."""
+        r, n = C.c_int(), C.c_int()
+        if self.ctx is None:
+            return 0, 0
+        _lib.check(self.lib.pvae_comm_info(self.ctx, C.byref(r), C.byref(n)), "pvae_comm_info")
+        return r.value, n.value
 
     def comm_config(self, bucket_mb=0.0, test_delay_us=0):
         """Exchange settings of dp_train_step: bucket size in MiB (0, the default: one in-line

@@ -264,8 +264,17 @@ class PhysicsVAE(nn.Module):
     def _apply(self, fn, recurse=True):
         """`.to()/.cuda()/.float()` would re-allocate the arena-backed parameters and break
         the aliasing; the device is chosen at construction (custom_model_config['device'])."""
-        probe = fn(torch.zeros(1, device=self.engine.device))
-        if probe.device != self.engine.device or probe.dtype != torch.float32:
+        want = self.engine.device
+        probe = fn(torch.zeros(1, device=want))
+
+        def same_device(a, b):                     # 'cuda' == 'cuda:<current>'
+            if a.type != b.type:
+                return False
+            if a.type != "cuda":
+                return True
+            cur = torch.cuda.current_device() if torch.cuda.is_available() else 0
+            return (cur if a.index is None else a.index) == (cur if b.index is None else b.index)
+        if not same_device(probe.device, want) or probe.dtype != torch.float32:
             raise RuntimeError("PhysicsVAE lives on %s/float32 (chosen at construction); "
                                "rebuild it with custom_model_config['device'] instead of .to()"
                                % self.engine.device)

@@ -47,11 +47,16 @@ def arg_parser():
     p.add_argument("--world_model", type=str, default=None)
     p.add_argument("--latent_dim", type=int, default=32)
     # NB (reference quirk kept): action='append' on a list default
-    # APPENDS to the default, so `--vae_kl_coeff 0.1` means a sweep over [1.0, 0.1].
+    # APPENDS to the default, so `--vae_kl_coeff 0.1` means a sweep over [1.0, 0.1]: two trials,
+    # which tune.run executes one after the other (tune.expand_grid).
     p.add_argument("--vae_kl_coeff", type=float, action="append", default=[1.0])
     p.add_argument("--vae_cycle_coeff", type=float, action="append", default=[1e-3])
     p.add_argument("--latent_prior_type", type=str, action="append",
                    default=["normal_zero_mean_one_std"])
+    # ours: the same three settings as SINGLE values (one trial, no sweep over the default)
+    p.add_argument("--kl_coeff", type=float, default=None, help="single vae_kl_coeff (replaces the sweep list)")
+    p.add_argument("--cycle_coeff", type=float, default=None, help="single vae_cycle_coeff")
+    p.add_argument("--prior", type=str, default=None, help="single latent_prior_type")
     # ours: MLP sizes are dict-only in the reference (tpv:263-280)
     p.add_argument("--TE_width", type=int, default=256)
     p.add_argument("--TE_depth", type=int, default=2)
@@ -284,6 +289,10 @@ def get_trainer_config(a):
     def box(n, scale):
         return Box(low=-scale * np.ones(n), high=scale * np.ones(n), dtype=np.float64)
 
+    # argparse appends to the very list object given as default: work on copies
+    kl_list = [a.kl_coeff] if getattr(a, "kl_coeff", None) is not None else list(a.vae_kl_coeff)
+    cyc_list = [a.cycle_coeff] if getattr(a, "cycle_coeff", None) is not None else list(a.vae_cycle_coeff)
+    prior_list = [a.prior] if getattr(a, "prior", None) is not None else list(a.latent_prior_type)
     cmc = copy.deepcopy(MODEL_CONFIG)
     cmc.update(observation_space=box(dim_state, 1000.0), observation_space_body=box(dim_body, 1000.0),
                observation_space_task=box(dim_task, 1000.0), action_space=box(dim_action, 3.0),
@@ -303,7 +312,7 @@ def get_trainer_config(a):
         "batch_size": a.batch_size,
         "suffle_data": True,            # sic -- the key the reference sets; nothing reads it
         "latent_dim": a.latent_dim,
-        "latent_prior_type": tune.grid_search(a.latent_prior_type),
+        "latent_prior_type": tune.grid_search(prior_list),
         "act_fn": "relu",
         "MD_width": tune.grid_search([getattr(a, "MD_width", 512)]),
         "MD_depth": tune.grid_search([getattr(a, "MD_depth", 3)]),
@@ -312,10 +321,10 @@ def get_trainer_config(a):
         "lookahead": getattr(a, "lookahead", 1),       # tpv:277 hard-wires 1; --lookahead exposes it
         "world_model_width": tune.grid_search([getattr(a, "world_model_width", 1024)]),
         "world_model_depth": tune.grid_search([getattr(a, "world_model_depth", 2)]),
-        "vae_kl_coeff": tune.grid_search(a.vae_kl_coeff),
+        "vae_kl_coeff": tune.grid_search(kl_list),
         "motor_decoder_a_rec_coeff": 1.0,
         "world_model_s_rec_coeff": 0.0,
-        "vae_cycle_coeff": tune.grid_search(a.vae_cycle_coeff),
+        "vae_cycle_coeff": tune.grid_search(cyc_list),
         "seed": getattr(a, "seed", 0),
     }
 
@@ -419,13 +428,16 @@ def main(argv=None):
         analysis = tune.run(TrainModel, stop={"training_iteration": args.max_iter},
                             checkpoint_freq=args.checkpoint_freq, checkpoint_at_end=True,
                             config=trainer_config, local_dir=args.local_dir, name=args.name)
-        checkpoint = analysis.get_best_checkpoint()
+        best = analysis.get_best_logdir(metric="mean_train_loss", mode="min")
+        checkpoint = analysis.get_best_checkpoint(logdir=best)
+        best_config = next(t.config for t in analysis.trials if t.logdir == best)
     else:
         checkpoint = args.checkpoint
+        best_config = tune.expand_grid(trainer_config)[0]
     if args.output is not None:
         # the reference's --output branch instantiates the abstract base and cannot work
         # (SURVEY.md App. C-3); here it exports the full state_dict as intended
-        trainer = TrainModel(trainer_config)
+        trainer = TrainModel(best_config)
         trainer.restore(checkpoint)
         torch.save(trainer.model.portable_state_dict(), args.output)
         print("Model Saved:", args.output)

@@ -1,10 +1,47 @@
 """A small stand-in for the slice of Ray Tune the reference uses (tpv:484-502): the
 Trainable protocol (setup / step / save_checkpoint / load_checkpoint, train() bookkeeping)
-and a single-trial `run` loop with periodic checkpoints.  Trial scheduling, actors and
-search are out of scope (control plane)."""
+and a `run` loop with periodic checkpoints that executes the trials of a `grid_search` config
+one after the other (the cartesian product of the grid leaves, as Ray expands it; the reference's
+`--vae_kl_coeff 0.1` means the two trials [1.0, 0.1]).  Actors, trial
+schedulers and search algorithms are out of scope (control plane).
+
+Under a multi-rank launch every rank runs the same trials (the data-parallel step needs all of
+them); logs and checkpoints are written by rank 0 only and the other ranks wait for them."""
+import itertools
 import json
 import os
 import time
+
+
+def _rank_world():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except Exception:                                              # noqa: BLE001
+        pass
+    return 0, 1
+
+
+def _barrier():
+    rank, world = _rank_world()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def expand_grid(config):
+    """All trial configs of `config`: one per element of the cartesian product of its
+    `{"grid_search": [...]}` leaves (top level, as tpv:263-285 uses them), first key slowest."""
+    keys = [k for k, v in config.items() if isinstance(v, dict) and set(v.keys()) == {"grid_search"}]
+    if not keys:
+        return [dict(config)]
+    out = []
+    for combo in itertools.product(*[config[k]["grid_search"] for k in keys]):
+        c = dict(config)
+        c.update(dict(zip(keys, combo)))
+        out.append(c)
+    return out
 
 
 def grid_search(values):
@@ -70,37 +107,82 @@ class Trainable:
         pass
 
 
+class Trial:
+    def __init__(self, logdir, config):
+        self.logdir, self.config = logdir, config
+        self.checkpoints, self.results = [], []
+
+
 class Analysis:
-    def __init__(self, logdir, checkpoints, results):
-        self.logdir, self.checkpoints, self.results = logdir, checkpoints, results
+    """What the reference reads back from `tune.run` (tpv:503-509): the best trial's logdir and
+    its last checkpoint.  Single-trial attributes (`logdir`, `checkpoints`, `results`) refer to the
+    last trial run."""
+
+    def __init__(self, trials):
+        self.trials = trials
+        last = trials[-1]
+        self.logdir, self.checkpoints, self.results = last.logdir, last.checkpoints, last.results
+
+    def _best(self, metric, mode):
+        if metric is None or len(self.trials) == 1:
+            return self.trials[-1]
+        scored = [(t.results[-1].get(metric), t) for t in self.trials if t.results and metric in t.results[-1]]
+        if not scored:
+            return self.trials[-1]
+        pick = min if (mode or "min") == "min" else max
+        return pick(scored, key=lambda kv: kv[0])[1]
 
     def get_best_logdir(self, metric=None, mode=None):
-        return self.logdir
+        return self._best(metric, mode).logdir
 
     def get_best_checkpoint(self, logdir=None, metric=None, mode=None):
-        return self.checkpoints[-1] if self.checkpoints else None
+        t = next((t for t in self.trials if t.logdir == logdir), None) or self._best(metric, mode)
+        return t.checkpoints[-1] if t.checkpoints else None
 
 
 def run(trainable_cls, config=None, stop=None, checkpoint_freq=0, checkpoint_at_end=False,
         local_dir="~/ray_results", name=None, verbose=1, **_ignored):
     max_iter = int((stop or {}).get("training_iteration", 1))
-    logdir = os.path.join(os.path.expanduser(local_dir), name or trainable_cls.__name__,
-                          time.strftime("trial_%Y%m%d_%H%M%S"))
-    os.makedirs(logdir, exist_ok=True)
-    trial = trainable_cls(config, logdir=logdir)
-    ckpts, results = [], []
-    with open(os.path.join(logdir, "result.json"), "w") as log:
-        while trial.training_iteration < max_iter:
-            res = trial.train()
-            results.append(res)
-            log.write(json.dumps({k: v for k, v in res.items() if isinstance(v, (int, float, str))}) + "\n")
-            log.flush()
-            if verbose:
-                print("iter %d  train %.6f  test %.6f  (%.2fs)" % (
-                    res["training_iteration"], res.get("mean_train_loss", float("nan")),
-                    res.get("mean_test_loss", float("nan")), res["time_this_iter_s"]))
-            it = trial.training_iteration
-            if (checkpoint_freq and it % checkpoint_freq == 0) or (checkpoint_at_end and it == max_iter):
-                ckpts.append(trial.save())
-    trial.stop()
-    return Analysis(logdir, ckpts, results)
+    rank, world = _rank_world()
+    stamp = time.strftime("%Y%m%d_%H%M%S")
+    if world > 1:                                  # one directory name for the whole job
+        import torch.distributed as dist
+        box = [stamp]
+        dist.broadcast_object_list(box, src=0)
+        stamp = box[0]
+    variants = expand_grid(config or {})
+    trials = []
+    for ti, cfg in enumerate(variants):
+        tag = "trial_%s" % stamp if len(variants) == 1 else "trial_%s_%02d" % (stamp, ti)
+        logdir = os.path.join(os.path.expanduser(local_dir), name or trainable_cls.__name__, tag)
+        if rank == 0:
+            os.makedirs(logdir, exist_ok=True)
+        _barrier()
+        trial = trainable_cls(cfg, logdir=logdir)
+        rec = Trial(logdir, cfg)
+        log = open(os.path.join(logdir, "result.json"), "w") if rank == 0 else None
+        try:
+            while trial.training_iteration < max_iter:
+                res = trial.train()
+                rec.results.append(res)
+                if log:
+                    log.write(json.dumps({k: v for k, v in res.items() if isinstance(v, (int, float, str))}) + "\n")
+                    log.flush()
+                if verbose and rank == 0:
+                    print("iter %d  train %.6f  test %.6f  (%.2fs)" % (
+                        res["training_iteration"], res.get("mean_train_loss", float("nan")),
+                        res.get("mean_test_loss", float("nan")), res["time_this_iter_s"]))
+                it = trial.training_iteration
+                if (checkpoint_freq and it % checkpoint_freq == 0) or (checkpoint_at_end and it == max_iter):
+                    base = os.path.join(logdir, "checkpoint_%06d" % it)
+                    if rank == 0:                  # replicas are bit-identical: one writer is enough
+                        rec.checkpoints.append(trial.save(base))
+                    else:
+                        rec.checkpoints.append(os.path.join(base, "model.pth"))
+                    _barrier()                     # the files exist before any rank may read them
+        finally:
+            if log:
+                log.close()
+        trial.stop()
+        trials.append(rec)
+    return Analysis(trials)

@@ -1,0 +1,155 @@
+"""Round-2 GPU tests: bench.py launched plainly (N = 1 and N = 2 self-launch), HIP-graph rollout
+replays interleaved with prefetched training steps, identity device moves of the module, and the
+gather kernel on a demonstration set whose byte offsets cross 2^31."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import refpath as R
+from physicsvae_amd import _lib
+from util import arch_from_meta, make_trainer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*flags, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_plain_two_ranks_self_launch():
+    """`python bench.py --gpus 2`, launched plainly, starts its two ranks itself and prints ONE line.
+    On a 1-GPU box the ranks share the device and exchange over gloo (RCCL refuses two ranks on one
+    device): same sharding / reduction / Adam path, flagged in the line."""
+    d = _bench("--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-rocprof")
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5
+    assert d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp2"
+    assert d["timing"]["timed_steps_per_region"] >= 200 and d["timing"]["regions"] == 3
+    assert d["value"] > 0 and np.isfinite(d["last_loss"])
+    if torch.cuda.device_count() < 2:
+        assert d["ranks_share_a_gpu"] is True and d["rccl_ranks"] == 0
+    else:
+        assert d["ranks_share_a_gpu"] is False and d["rccl_ranks"] == 2
+        assert d["allreduce_us_per_step"] > 0
+    assert "roofline" in d and 0 < d["roofline"]["frac"] < 1
+
+
+def test_bench_plain_single_gpu_line():
+    d = _bench("--steps", "20", "--warmup", "5", "--no-rocprof")
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 0 and d["config"]["phase"] == "joint"
+    assert d["metric"].startswith("train samples/sec (world-model+VAE step)")
+    for key in ("roofline", "world_roofline", "cpu_baseline", "world_value"):
+        assert key in d, key
+    for roof in (d["roofline"], d["world_roofline"]):
+        assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["peak"] == 157.3
+    cb = d["cpu_baseline"]
+    assert cb["value"] >= cb["value_1thread"] > 0 and cb["threads_best"] in [int(k) for k in cb["sweep"]]
+    assert len(d["timing"]["region_values"]) == 3
+
+
+def test_graph_replays_between_prefetched_train_steps_do_not_touch_the_training_batch(golden):
+    """GraphedInfer writes the staging panels that were current when it was captured; a prefetched
+    train step swaps current and alternate panels.  Replays interleaved with prefetched steps (odd
+    and even counts in between) must leave training bit-identical to an engine that never
+    prefetches and never replays, and a replay must not leave a stale 'staged' minibatch behind."""
+    g = golden("train_tiny")
+    arch = arch_from_meta(g["meta"])
+    n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
+    data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    obs = torch.randn(1, 2 * arch["Db"], generator=torch.Generator().manual_seed(5)).to(DEV)
+    res = []
+    for replay in (False, True):
+        tr = make_trainer(arch, data, batch, m_world=1, device=DEV, extra={"prefetch_gather": replay})
+        tr.model.load_state_dict(sd)
+        eng = tr.engine
+        eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
+        gi = eng.graphed_infer(1, want_s2=True, noise=False) if replay else None
+        tr.model.set_learnable_task_encoder(True); tr.model.set_learnable_motor_decoder(True)
+        tr.model.set_learnable_world_model(False); tr.read_loss_fn_coeff(world=False)
+        phase, nets = tr.phase()
+        spans = list(tr.train_loader.spans())
+        out = torch.zeros(len(spans), 5, device=DEV)
+        for i, (first, rows) in enumerate(spans):
+            sp = tr.step_params(nets, rows, True)
+            e = R.eps_stream(7, arch["Z"])(i, (rows, arch["Z"]))
+            nxt = spans[(i + 1) % len(spans)]
+            eng.train_step(phase, first, rows, sp, eps=e, loss_out=out[i], next_span=nxt if replay else None)
+            if replay and i % 3 != 2:               # 1, then 2 prefetched steps between replays: both parities
+                a_hat = gi(obs)[0].clone()
+                assert torch.equal(a_hat, eng.infer(obs, noise=False, want_s2=True)[0])
+        res.append((out.clone(), eng.params.clone(), eng.exp_avg.clone()))
+        if replay:
+            # gather -> replay -> forward_backward must fail loudly, not run on overwritten panels
+            eng.gather(0, batch)
+            gi(obs)
+            with pytest.raises(RuntimeError, match="staged"):
+                eng.forward_backward(phase, batch, tr.step_params(nets, batch, False), backward=False)
+    (la, pa, ma), (lb, pb, mb) = res
+    assert torch.equal(la, lb) and torch.equal(pa, pb) and torch.equal(ma, mb)
+
+
+def test_identity_device_moves_of_the_module(golden):
+    """`model.to(device)` with the device it already lives on (what the reference's trainer and
+    RLlib call), `.cuda()` and `.float()` are no-ops; a real move is refused."""
+    g = golden("single_tiny")
+    arch = arch_from_meta(g["meta"])
+    data = R.synth_demo(0, 2, 20, arch["Db"], arch["Da"], kind="iid")
+    tr = make_trainer(arch, data, 8, device=DEV)          # "cuda" without an index
+    m = tr.model
+    ptr = m.engine.params.data_ptr()
+    assert m.to("cuda") is m and m.cuda() is m and m.float() is m
+    assert m.to(torch.device("cuda", torch.cuda.current_device())) is m and m.to(m.engine.device) is m
+    assert m.engine.params.data_ptr() == ptr
+    assert next(m._world_model.parameters()).data_ptr() >= ptr         # still views of the arena
+    with pytest.raises(RuntimeError):
+        m.to("cpu")
+    with pytest.raises(RuntimeError):
+        m.double()
+
+
+def test_gather_windows_across_the_2GiB_byte_boundary():
+    """A demonstration set of 1.5e6 state rows x 400 floats = 2.4 GB: byte offsets of the rows a
+    window reads cross 2^31 (row 1 342 177).  The panels the gather kernel fills for windows at the
+    start, straddling the boundary and at the very end equal the oracle's definition of a window
+    (x = [s_t | s_{t+1}], y = a_t; tpv:133-156) bit for bit."""
+    from physicsvae_amd.engine import Arch, HipEngine
+    Db, Da, B = 400, 90, 512
+    rows_total = 1_500_000
+    eng = HipEngine(Arch(Db, Da, 32, (64, 1), (64, 1), (64, 1)), B, device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    states = torch.randn(rows_total, Db, generator=gen, device=DEV)
+    actions = torch.randn(rows_total, Da, generator=gen, device=DEV)
+    assert states.numel() * 4 > 2 ** 31
+    # windows: every row but the last of each 1000-row "episode" (episode boundaries are skipped)
+    idx = torch.arange(rows_total, device=DEV)
+    window_row = idx[(idx % 1000) != 999].to(torch.int32)
+    eng.bind_dataset(states, actions, window_row)
+    n = window_row.numel()
+    boundary_row = 2 ** 31 // (Db * 4)                   # first row whose bytes start beyond 2^31
+    first_over = int(torch.searchsorted(window_row, torch.tensor(boundary_row, device=DEV, dtype=torch.int32)))
+    for first, rows in ((0, B), (first_over - B // 2, B), (n - B, B), (n - 37, 37)):
+        eng.gather(first, rows)
+        torch.cuda.synchronize()
+        r = window_row[first: first + rows].long()
+        te_in = eng.panel("in", _lib.NET_TE)[:rows]
+        wm_in = eng.panel("in", _lib.NET_WM)[:rows]
+        md_in = eng.panel("in", _lib.NET_MD)[:rows]
+        assert torch.equal(te_in[:, :Db], states[r]) and torch.equal(te_in[:, Db: 2 * Db], states[r + 1])
+        assert torch.equal(wm_in[:, :Db], states[r]) and torch.equal(wm_in[:, Db: Db + Da], actions[r])
+        assert torch.equal(md_in[:, :Db], states[r])
+        assert torch.equal(eng.panel("s2")[:rows, :Db], states[r + 1])
+        assert torch.equal(eng.panel("act_t")[:rows, :Da], actions[r])
+        assert float(te_in[:, 2 * Db:].abs().max()) == 0.0            # pad columns are zeros
+        if rows < B:
+            assert float(eng.panel("in", _lib.NET_TE)[rows: (rows + 31) // 32 * 32].abs().max()) == 0.0

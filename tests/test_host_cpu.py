@@ -473,3 +473,100 @@ def test_pretrained_weight_options_of_the_constructor(tmp_path):
                task_encoder_load_weights=str(tmp_path / "task_encoder.pt"), task_encoder_learnable=False)
     tr2 = T.TrainModel(cfg2)
     assert all(torch.equal(v, sd[k]) for k, v in tr2.model.state_dict().items())
+
+
+# ------------------------------------------------------------------------------------------
+# tune stand-in: grid trials, rank-gated logs / checkpoints
+# ------------------------------------------------------------------------------------------
+class _CountingTrainable(__import__("physicsvae_amd.tune", fromlist=["Trainable"]).Trainable):
+    def setup(self, config):
+        self.scale = config["scale"] * config["shift"]
+
+    def step(self):
+        return {"mean_train_loss": self.scale / (self.training_iteration + 1), "mean_test_loss": 0.0}
+
+    def save_checkpoint(self, checkpoint_dir):
+        path = os.path.join(checkpoint_dir, "model.pth")
+        torch.save({"scale": self.scale}, path)
+        return path
+
+
+def test_tune_run_executes_every_grid_trial(tmp_path):
+    """`--vae_kl_coeff 0.1` in the reference sweeps [1.0, 0.1] (tpv:51-53): tune.run executes the
+    cartesian product of the grid leaves as consecutive trials and the analysis picks the best."""
+    from physicsvae_amd import tune
+    cfg = {"scale": tune.grid_search([3.0, 1.0]), "shift": tune.grid_search([2.0]), "plain": 7}
+    assert [(c["scale"], c["shift"]) for c in tune.expand_grid(cfg)] == [(3.0, 2.0), (1.0, 2.0)]
+    an = tune.run(_CountingTrainable, config=cfg, stop={"training_iteration": 3}, checkpoint_freq=2,
+                  checkpoint_at_end=True, local_dir=str(tmp_path), name="t", verbose=0)
+    assert len(an.trials) == 2 and all(len(t.results) == 3 for t in an.trials)
+    assert [len(t.checkpoints) for t in an.trials] == [2, 2]          # iteration 2 and the end (3)
+    best = an.get_best_logdir(metric="mean_train_loss", mode="min")
+    assert best == an.trials[1].logdir
+    ck = an.get_best_checkpoint(logdir=best)
+    assert torch.load(ck)["scale"] == 2.0
+    assert len(open(os.path.join(best, "result.json")).read().splitlines()) == 3
+
+
+def test_cli_coefficient_flags(tmp_path):
+    """The reference's append-to-default flags keep their sweep meaning; the single-value flags
+    (ours) run one trial with the value given."""
+    from physicsvae_amd import tune
+    pkl = str(tmp_path / "d.pkl")
+    R.write_demo(pkl, R.synth_demo(0, 2, 14, 7, 3))
+    a = T.arg_parser().parse_args(["--data_train", pkl, "--vae_kl_coeff", "0.1"])
+    cfg = T.get_trainer_config(a)
+    assert cfg["vae_kl_coeff"] == {"grid_search": [1.0, 0.1]} and cfg["vae_cycle_coeff"] == {"grid_search": [1e-3]}
+    assert len(tune.expand_grid(cfg)) == 2
+    a = T.arg_parser().parse_args(["--data_train", pkl, "--kl_coeff", "0.1", "--cycle_coeff", "0.01"])
+    cfg = T.get_trainer_config(a)
+    assert cfg["vae_kl_coeff"] == {"grid_search": [0.1]} and cfg["vae_cycle_coeff"] == {"grid_search": [0.01]}
+    assert len(tune.expand_grid(cfg)) == 1
+    # a fresh parser still has the reference's defaults (argparse must not have mutated them)
+    a = T.arg_parser().parse_args(["--data_train", pkl])
+    assert a.vae_kl_coeff == [1.0] and a.vae_cycle_coeff == [1e-3]
+
+
+TUNE_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from physicsvae_amd import parallel, tune
+rank, world, _ = parallel.init_from_env(backend="gloo")
+class Tr(tune.Trainable):
+    def setup(self, config): self.k = config["k"]
+    def step(self): return {"mean_train_loss": float(self.k), "mean_test_loss": 0.0}
+    def save_checkpoint(self, d):
+        p = os.path.join(d, "model.pth"); torch.save({"k": self.k, "writer": dist.get_rank()}, p); return p
+an = tune.run(Tr, config={"k": tune.grid_search([2, 5])}, stop={"training_iteration": 2}, checkpoint_at_end=True,
+              local_dir=sys.argv[2], name="job", verbose=0)
+ck = an.get_best_checkpoint(logdir=an.get_best_logdir("mean_train_loss", "min"))
+got = torch.load(ck)
+assert got == {"k": 2, "writer": 0}, got
+print("CKPT", rank, ck)
+dist.barrier()
+'''
+
+
+def test_tune_run_under_two_ranks_writes_once(tmp_path):
+    script = tmp_path / "tune_worker.py"
+    script.write_text(TUNE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path / "out")],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    paths = {o.strip().splitlines()[-1].split(" ", 2)[2] for o in outs}
+    assert len(paths) == 1                                        # both ranks agree on ONE checkpoint
+    dirs = os.listdir(tmp_path / "out" / "job")
+    assert len(dirs) == 2, dirs                                   # one directory per trial, not per rank
+
+
+def test_module_identity_moves_on_cpu():
+    data = R.synth_demo(0, 2, 14, 7, 3)
+    arch = R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2))
+    m = make_trainer(arch, data, 8, device="cpu").model
+    assert m.to("cpu") is m and m.float() is m and m.cpu() is m
+    with pytest.raises(RuntimeError):
+        m.double()
