@@ -34,16 +34,53 @@ import torch.nn as nn
 
 NETS = ("_task_encoder", "_motor_decoder", "_world_model", "_value_branch")
 
+# --------------------------------------------------------------------------------------
+# Latent priors other than N(0, I): OUR SPECIFICATION, not a capture.
+#
+# The reference sketches two more `latent_prior_type`s (rmt:614-635, 795-819; tpv:390-409) and both
+# crash before the first loss value exists, so no golden vector can be recorded ("parity unpinned"
+# for these two options only; everything they share with the default prior is pinned):
+#   * "normal_state_mean_one_std": the constructor passes `layers=latent_prior_type` (a string) to
+#     create_layer (rmt:632), and the loss reads `self.model._cur_vae_prior_mu`, an attribute that is
+#     never set (the model stores `_cur_latent_prior_mu`, rmt:808; tpv:395-396);
+#   * "hypersphere_uniform": the same missing attribute (tpv:406).
+# What we build is the evident intent of that code, with the two slips fixed and nothing else changed:
+#
+#   normal_state_mean_one_std -- a learned prior mean.  `_latent_prior` = MLP(Db -> Z) over the body
+#     state, layers = `latent_prior_layers` (ours: the task encoder's width/depth when None), registered
+#     BEFORE the task encoder (rmt:627-635), so its keys lead the state_dict.  The encoder still emits
+#     (mu, logvar) and z = mu + eps*exp(logvar/2).  KL term = KL(N(mu, sigma^2) || N(mu_p, 1)) summed over
+#     the latent dims and averaged over the minibatch:
+#         loss_kl = mean_i sum_j 0.5 * (exp(logvar) + (mu - mu_p)^2 - 1 - logvar)
+#     (the closed form of the torch.distributions call of tpv:397-402 with logvar_p = 0, rmt:809).  The
+#     sketch sums over the rows and averages over the dims (`kl_div += ...; kl_div.mean()`), i.e. B/Z
+#     times this; we keep the normalisation of the default prior so that mu_p = 0 reproduces
+#     "normal_zero_mean_one_std" exactly and vae_kl_coeff keeps its meaning.  The prior net receives
+#     gradient only through this term and trains with the encoder/decoder in the joint phase (it is never
+#     frozen upstream either: rmt:930-950 has no switch for it).
+#
+#   hypersphere_uniform -- a deterministic encoder on the unit sphere.  The encoder emits Z values
+#     (rmt:620-621), mu = e/|e| (F.normalize, eps 1e-12; rmt:811); the decoder receives z = mu (the
+#     sketch passes the un-normalised e on, which makes "one radius" meaningless -- fixed).  The prior
+#     sample of that forward is u = n/|n| with n = randn_like(mu) (rmt:813-814) and
+#         loss_kl = mean_i <mu_i, u_i>                                     (tpv:404-407)
+#     `latent_prior_noise` only gates n (False: u = 0, the term vanishes).
+# --------------------------------------------------------------------------------------
+PRIORS = ("normal_zero_mean_one_std", "normal_state_mean_one_std", "hypersphere_uniform")
+
 
 # --------------------------------------------------------------------------------------
 # architecture description
 # --------------------------------------------------------------------------------------
 def make_arch(dim_body, dim_action, latent=32, te=(256, 2), md=(512, 3), wm=(1024, 2),
-              vb=(256, 2)):
+              vb=(256, 2), prior="normal_zero_mean_one_std", pr=None):
     """Widths/depths as `gen_layers(width, depth)` expands them (tpv:180-192, 290-311);
-    defaults are PhysicsVAE.DEFAULT_CONFIG (rmt:462-510)."""
+    defaults are PhysicsVAE.DEFAULT_CONFIG (rmt:462-510).  `prior` / `pr`: see PRIORS above
+    (`pr` = (width, depth) of the learned prior, default = the task encoder's)."""
+    assert prior in PRIORS, prior
     return dict(Db=int(dim_body), Da=int(dim_action), Z=int(latent),
-                te=tuple(te), md=tuple(md), wm=tuple(wm), vb=tuple(vb))
+                te=tuple(te), md=tuple(md), wm=tuple(wm), vb=tuple(vb), prior=prior,
+                pr=tuple(pr) if pr is not None else tuple(te))
 
 
 def net_layer_dims(arch):
@@ -59,8 +96,11 @@ def net_layer_dims(arch):
         dims.append((prev, n_out))
         return dims
 
-    return OrderedDict([
-        ("_task_encoder", chain(2 * Db, arch["te"], 2 * Z)),       # rmt:638-644, 612-613
+    prior = arch.get("prior", PRIORS[0])
+    te_out = Z if prior == "hypersphere_uniform" else 2 * Z                    # rmt:618-621
+    learned = [("_latent_prior", chain(Db, arch.get("pr", arch["te"]), Z))] if prior == PRIORS[1] else []
+    return OrderedDict(learned + [                                             # rmt:627-635 comes first
+        ("_task_encoder", chain(2 * Db, arch["te"], te_out)),      # rmt:638-644, 612-613
         ("_motor_decoder", chain(Db + Z, arch["md"], Da)),         # rmt:646-668
         ("_world_model", chain(Db + Da, arch["wm"], Db)),          # rmt:682-689
         ("_value_branch", chain(2 * Db, arch["vb"], 1)),           # rmt:693-699
@@ -258,6 +298,9 @@ class RefModel(nn.Module):
         super().__init__()
         self.arch = arch
         dims = net_layer_dims(arch)
+        self.prior = arch.get("prior", PRIORS[0])
+        if "_latent_prior" in dims:                                   # rmt:627-635: registered first
+            self._latent_prior = _Stack(dims["_latent_prior"])
         self._task_encoder = _Stack(dims["_task_encoder"])
         self._motor_decoder = _Stack(dims["_motor_decoder"])
         self._world_model = _Stack(dims["_world_model"])
@@ -281,15 +324,28 @@ class RefModel(nn.Module):
         Db, Da, Z = self.arch["Db"], self.arch["Da"], self.arch["Z"]
         obs = obs.float()
         h = self._task_encoder(obs)                                   # rmt:788-793
-        self.cur_mu, self.cur_logvar = h[..., :Z], h[..., Z:]         # rmt:795-800
-        z = self.reparameterize(self.cur_mu, self.cur_logvar)
+        if self.prior == "hypersphere_uniform":                       # rmt:810-814, fixed as specified above
+            self.cur_mu, self.cur_logvar = nn.functional.normalize(h), None
+            z = self.cur_mu
+            if self.latent_prior_noise:
+                n = self.eps_source(h.shape) if self.eps_source is not None else torch.randn_like(h)
+                self.cur_eps = n
+                self.cur_prior_mu = nn.functional.normalize(n)
+            else:
+                self.cur_prior_mu = torch.zeros_like(h)
+        else:
+            self.cur_mu, self.cur_logvar = h[..., :Z], h[..., Z:]     # rmt:795-800
+            z = self.reparameterize(self.cur_mu, self.cur_logvar)
+            if self.prior == "normal_state_mean_one_std":             # rmt:801-809
+                self.cur_prior_mu = self._latent_prior(obs[..., :Db])
         self.cur_z = z
         a_hat = self._motor_decoder(torch.cat([obs[..., :Db], z], dim=-1))     # rmt:822-831
         logits = torch.cat([a_hat, torch.full_like(a_hat, self.log_std)], dim=-1)
         self.cur_future_state = self.forward_world(obs, logits)       # rmt:758
         self.cur_value = self._value_branch(obs).squeeze(1)           # rmt:760-769
         if self.trace is not None:
-            self.trace.append(dict(mu=self.cur_mu.detach(), logvar=self.cur_logvar.detach(), z=z.detach(),
+            lv = self.cur_logvar if self.cur_logvar is not None else torch.zeros_like(self.cur_mu)
+            self.trace.append(dict(mu=self.cur_mu.detach(), logvar=lv.detach(), z=z.detach(),
                                    a_hat=a_hat.detach(), future_state=self.cur_future_state.detach()))
         return logits
 
@@ -337,7 +393,14 @@ def compute_loss(model, x, y, coeffs, loss="MSE"):
             loss_a = loss_a + mse(y_t, a_hat)                         # tpv:381-382
             if coeffs["vae_kl_coeff"] > 0.0:
                 mu, lv = model.cur_mu, model.cur_logvar
-                loss_kl = loss_kl + torch.mean(-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp(), dim=1), dim=0)
+                prior = getattr(model, "prior", PRIORS[0])
+                if prior == PRIORS[0]:                                # tpv:385-389
+                    loss_kl = loss_kl + torch.mean(-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp(), dim=1), dim=0)
+                elif prior == PRIORS[1]:                              # tpv:390-403 as specified above
+                    d = mu - model.cur_prior_mu
+                    loss_kl = loss_kl + torch.mean(0.5 * torch.sum(lv.exp() + d.pow(2) - 1 - lv, dim=1), dim=0)
+                else:                                                 # tpv:404-407
+                    loss_kl = loss_kl + (mu * model.cur_prior_mu).sum(-1).mean()
         if coeffs["s_rec_coeff"] > 0:
             s2_gt_act = model.forward_world(s1, y_t)                  # tpv:411-414
             loss_s = loss_s + mse(s2, s2_gt_act)
@@ -372,6 +435,8 @@ def loss_and_grads(arch, sd, x, y, eps, world, coeff_cfg=None, loss="MSE"):
     model.set_learnable("_task_encoder", not world)
     model.set_learnable("_motor_decoder", not world)
     model.set_learnable("_world_model", world)
+    if hasattr(model, "_latent_prior"):
+        model.set_learnable("_latent_prior", not world)
     coeffs = phase_coeffs(world, coeff_cfg)
     model.trace = []
     total, terms = compute_loss(model, x, y, coeffs, loss)
@@ -379,9 +444,12 @@ def loss_and_grads(arch, sd, x, y, eps, world, coeff_cfg=None, loss="MSE"):
     grads = OrderedDict((k, p.grad.detach().clone()) for k, p in model.named_parameters()
                         if p.grad is not None)
     Da = arch["Da"]
-    out = dict(total=total.detach(), mu=model.cur_mu.detach(), logvar=model.cur_logvar.detach(),
+    lv = model.cur_logvar if model.cur_logvar is not None else torch.zeros_like(model.cur_mu)
+    out = dict(total=total.detach(), mu=model.cur_mu.detach(), logvar=lv.detach(),
                z=model.cur_z.detach(), future_state=model.cur_future_state.detach(),
                grads=grads, steps=model.trace)
+    if getattr(model, "cur_prior_mu", None) is not None:
+        out["prior_mu"] = model.cur_prior_mu.detach()
     model.trace = None
     out.update({k: v.detach() for k, v in terms.items()})
     with torch.no_grad():
@@ -474,6 +542,8 @@ class RefTrainer:
         self.model.set_learnable("_task_encoder", not self.world)
         self.model.set_learnable("_motor_decoder", not self.world)
         self.model.set_learnable("_world_model", self.world)
+        if hasattr(self.model, "_latent_prior"):                  # trains with the encoder (spec above)
+            self.model.set_learnable("_latent_prior", not self.world)
         self.coeffs = phase_coeffs(self.world, self.coeff_cfg)
 
     def _next_eps(self, shape):

@@ -2,9 +2,11 @@
 # A/B of runtime switches: bash tools/ab_env.sh "PVAE_WGRAD32=0" "PVAE_KROT=1" ...  ("" = defaults)
 for v in "" "$@" ""; do
   echo "== ${v:-defaults}"
-  env $v python bench.py --no-cpu-baseline --steps 600 --warmup 60 2>/dev/null | python -c "
+  env $v python bench.py --no-cpu-baseline --no-rocprof --steps 400 --warmup 40 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-k = d['kernels']
-print('world %.2f us  joint %.2f us | ' % (d['ms_per_step']*1e3, d['joint_ms_per_step']*1e3) + '  '.join('%s %.2f' % (n.split(' ')[0][:22], v['avg_us']) for n, v in k.items()))"
+def row(k):
+    return '  '.join('%s %.2f' % (n.split(' (')[0][:18], v['avg_us']) for n, v in k.items() if isinstance(v, dict))
+print('joint %.2f us | %s' % (d['ms_per_step']*1e3, row(d['kernels'])))
+print('world %.2f us | %s' % (d['world_ms_per_step']*1e3, row(d['world_kernels'])))"
 done
