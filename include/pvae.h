@@ -36,11 +36,21 @@
 extern "C" {
 #endif
 
-#define PVAE_ABI_VERSION 2
+#define PVAE_ABI_VERSION 3
 
 typedef struct pvae_ctx pvae_ctx;
 
-enum { PVAE_NET_TE = 0, PVAE_NET_MD = 1, PVAE_NET_WM = 2, PVAE_NUM_NETS = 3 };
+/* PVAE_NET_PR: the learned prior mean `_latent_prior` (rmt:627-635), present only with
+ * PVAE_PRIOR_STATE_MEAN.  Arena order is TE | MD | PR | WM, so that the stacks trained together in
+ * the joint phase (TE, MD, PR) form one contiguous segment. */
+enum { PVAE_NET_TE = 0, PVAE_NET_MD = 1, PVAE_NET_WM = 2, PVAE_NET_PR = 3, PVAE_NUM_NETS = 4 };
+/* latent_prior_type (rmt:614-635, 795-819; tpv:384-409).  Only the first runs upstream; the other two
+ * follow the specification in oracle/refpath.py (the reference sketches them and crashes):
+ *   ZERO_MEAN   "normal_zero_mean_one_std"  KL(N(mu,s^2) || N(0,1))
+ *   STATE_MEAN  "normal_state_mean_one_std" KL(N(mu,s^2) || N(mu_p(s_body),1)), mu_p = PR stack (Db -> Z)
+ *   HYPERSPHERE "hypersphere_uniform"       encoder emits Z values, z = e/|e|, loss_kl = mean <z, n/|n|>
+ * The two non-default kinds need lookahead == 1. */
+enum { PVAE_PRIOR_ZERO_MEAN = 0, PVAE_PRIOR_STATE_MEAN = 1, PVAE_PRIOR_HYPERSPHERE = 2 };
 enum { PVAE_PHASE_WORLD = 0, PVAE_PHASE_JOINT = 1 };
 /* loss_fn of the three reconstruction terms (get_loss_fn tm:97-107; trainer key "loss", tpv:257) */
 enum { PVAE_LOSS_MSE = 0, PVAE_LOSS_L1 = 1 };
@@ -55,7 +65,8 @@ enum {
 };
 
 /* Architecture.  Mirrors the dict keys of tpv:247-286 / gen_layers tpv:180-192:
- * TE: 2*Db -> te_width x te_depth -> 2*Z ; MD: Db+Z -> ... -> Da ; WM: Db+Da -> ... -> Db.
+ * TE: 2*Db -> te_width x te_depth -> 2*Z (Z with PVAE_PRIOR_HYPERSPHERE) ; MD: Db+Z -> ... -> Da ;
+ * WM: Db+Da -> ... -> Db ; PR (PVAE_PRIOR_STATE_MEAN): Db -> pr_width x pr_depth -> Z.
  * ReLU after every hidden layer, linear output layer. */
 typedef struct pvae_config {
     int32_t dim_body;   /* Db */
@@ -67,6 +78,8 @@ typedef struct pvae_config {
     int32_t max_batch;  /* largest minibatch (rows) this ctx will be asked to process */
     int32_t lookahead;  /* L >= 1: steps unrolled through the world model per sample (tpv:277,
                            367-428); sizes the workspace (L blocks per panel) */
+    int32_t prior_kind; /* PVAE_PRIOR_* (0 = the reference's working default)                 */
+    int32_t pr_width, pr_depth; /* learned prior stack (PVAE_PRIOR_STATE_MEAN only; else ignored) */
 } pvae_config;
 
 typedef struct pvae_layer_info {
@@ -231,6 +244,19 @@ int pvae_comm_info(pvae_ctx* ctx, int* rank, int* nranks);
  * with the default 4 hardware queues the exchange stream can share one with the NULL stream and
  * every hand-off then stalls ~250 us. */
 int pvae_comm_config(pvae_ctx* ctx, int64_t bucket_bytes, int32_t test_delay_us);
+/* How pvae_dp_train_step exchanges a bucket (same value on every rank, chosen before the first step
+ * and not changed afterwards):
+ *   PVAE_EXCHANGE_ALLREDUCE (default)  ncclAllReduce of the gradient, then every rank applies the same
+ *                                      Adam update to the whole bucket (replicated moments);
+ *   PVAE_EXCHANGE_SHARDED              ncclReduceScatter (rank r ends with the summed gradient of ITS
+ *                                      1/N slice), Adam on that slice only (1/N of the p, g, m, v
+ *                                      traffic per rank), ncclAllGather of the updated parameter
+ *                                      slices.  Each rank then holds valid Adam moments for its own
+ *                                      slice only (ZeRO-1 shaped).  Buckets whose length is not a
+ *                                      multiple of 4*N floats fall back to the all-reduce form.
+ * PVAE_DP_SHARDED=1 in the environment selects the sharded form at pvae_comm_init. */
+enum { PVAE_EXCHANGE_ALLREDUCE = 0, PVAE_EXCHANGE_SHARDED = 1 };
+int pvae_comm_mode(pvae_ctx* ctx, int mode);
 int pvae_allreduce_grads(pvae_ctx* ctx, int64_t offset, int64_t count, void* stream);
 int pvae_dp_train_step(pvae_ctx* ctx, int phase, int64_t first_window, int32_t rows,
                        const pvae_step_params* sp, const float* eps, float* loss_out,
@@ -254,7 +280,10 @@ int pvae_train_step_prefetch(pvae_ctx* ctx, int phase, int64_t first_window, int
 /* Copy a forward intermediate of the last pvae_forward_backward into dst (dense
  * [rows][width] fp32, device).  what: 0 = mu, 1 = logvar, 2 = z, 3 = a_hat (MD output),
  * 4 = s2_hat (WM output; with lookahead > 1 the prediction that feeds the next step), 5 = eps
- * actually used.  Add 8*t to read time step t of a lookahead > 1 batch. */
+ * actually used (PVAE_PRIOR_HYPERSPHERE: the unit prior sample u), 6 = prior mean mu_p
+ * (PVAE_PRIOR_STATE_MEAN).  With PVAE_PRIOR_HYPERSPHERE 0 reads the raw encoder output e, 2 the
+ * unit vector z = e/|e|, and 1 is not available.  Add 8*t to read time step t of a
+ * lookahead > 1 batch. */
 int pvae_read_tensor(pvae_ctx* ctx, int what, float* dst, int32_t rows, void* stream);
 
 /* Rollout inference (rmt:742-771 at small batch): obs[rows][2*Db] -> a_hat[rows][Da]

@@ -558,19 +558,23 @@ class RefTrainer:
         self.iter += 1
         self.model.train()
         acc, n = 0.0, 0
+        tacc = dict(loss_a=0.0, loss_kl=0.0, loss_s=0.0, loss_cyc=0.0)
         for x, y in self.loader:
             if self.eps_fn is not None:
                 self.model.eps_source = self._next_eps
             self.opt.zero_grad()
-            loss, _ = compute_loss(self.model, x, y, self.coeffs, self.loss)
+            loss, terms = compute_loss(self.model, x, y, self.coeffs, self.loss)
             loss.backward()
             self.opt.step()
             acc += loss.item()
+            for k in tacc:                        # (test bookkeeping: per-term epoch means)
+                tacc[k] += float(terms[k].detach()) if torch.is_tensor(terms[k]) else float(terms[k])
             n += 1
             self.global_batch += 1
             if max_batches is not None and n >= max_batches:
                 break
         self.sched.step()
+        self.last_terms = {k: v / max(n, 1) for k, v in tacc.items()}
         return {"mean_train_loss": acc / (len(self.loader) if max_batches is None else n),
                 "mean_test_loss": 0.0}
 

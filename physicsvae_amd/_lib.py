@@ -21,18 +21,22 @@ import torch  # noqa: F401  (load order matters)
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PVAE_LIB_PATH") or os.path.join(HERE, "libpvae_gfx950.so")   # env: A/B builds
 
-NET_TE, NET_MD, NET_WM = 0, 1, 2
-NET_NAMES = {NET_TE: "_task_encoder", NET_MD: "_motor_decoder", NET_WM: "_world_model"}
+NET_TE, NET_MD, NET_WM, NET_PR = 0, 1, 2, 3
+NUM_NETS = 4
+NET_NAMES = {NET_TE: "_task_encoder", NET_MD: "_motor_decoder", NET_WM: "_world_model", NET_PR: "_latent_prior"}
+# latent_prior_type (rmt:614-635) -> pvae_config.prior_kind
+PRIOR_KINDS = {"normal_zero_mean_one_std": 0, "normal_state_mean_one_std": 1, "hypersphere_uniform": 2}
 PHASE_WORLD, PHASE_JOINT = 0, 1
 FLAG_FUSED_ADAM, FLAG_NO_BACKWARD = 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 LOSS_MSE, LOSS_L1 = 0, 1
+EXCHANGE_ALLREDUCE, EXCHANGE_SHARDED = 0, 1
 
 
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dim_body", "dim_action", "latent", "te_width", "te_depth", "md_width", "md_depth",
-        "wm_width", "wm_depth", "max_batch", "lookahead")]
+        "wm_width", "wm_depth", "max_batch", "lookahead", "prior_kind", "pr_width", "pr_depth")]
 
 
 class LayerInfo(C.Structure):
@@ -44,7 +48,7 @@ class LayerInfo(C.Structure):
 class StepParams(C.Structure):
     _fields_ = [("a_rec_coeff", C.c_float), ("kl_coeff", C.c_float), ("s_rec_coeff", C.c_float),
                 ("cycle_coeff", C.c_float), ("lr", C.c_double), ("beta1", C.c_double),
-                ("beta2", C.c_double), ("adam_eps", C.c_double), ("adam_t", C.c_int32 * 3),
+                ("beta2", C.c_double), ("adam_eps", C.c_double), ("adam_t", C.c_int32 * NUM_NETS),
                 ("global_rows", C.c_int32), ("rng_seed", C.c_uint64), ("rng_offset", C.c_uint64),
                 ("loss_kind", C.c_int32), ("reserved", C.c_int32)]
 
@@ -81,6 +85,7 @@ _SIGS = {
     "pvae_comm_destroy": (C.c_int, [_P]),
     "pvae_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pvae_comm_config": (C.c_int, [_P, C.c_int64, C.c_int32]),
+    "pvae_comm_mode": (C.c_int, [_P, C.c_int]),
     "pvae_allreduce_grads": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     "pvae_dp_train_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P,
                                      C.c_int64, C.c_int32, _P]),

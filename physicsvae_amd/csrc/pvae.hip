@@ -101,6 +101,8 @@ struct Rccl {
     int (*GetUniqueId)(RcclId*) = nullptr;
     int (*CommInitRank)(void**, int, RcclId, int) = nullptr;          // id is passed BY VALUE
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;   // optional
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;            // optional
     int (*CommDestroy)(void*) = nullptr;
     int (*CommCount)(void*, int*) = nullptr;
     int (*CommUserRank)(void*, int*) = nullptr;
@@ -124,6 +126,8 @@ static int rccl_load() {
     g_rccl.GetUniqueId = (int (*)(RcclId*))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(h, "ncclCommInitRank");
     g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+    g_rccl.ReduceScatter = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclReduceScatter");
+    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
     g_rccl.CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");           // optional (pvae_comm_info)
     g_rccl.CommUserRank = (int (*)(void*, int*))dlsym(h, "ncclCommUserRank");
@@ -149,6 +153,7 @@ struct pvae_ctx {
     static constexpr int kMaxBuckets = 64;
     hipEvent_t bucket_ready[kMaxBuckets] = {};
     hipEvent_t comm_done = nullptr;
+    int exchange_mode = 0;             // PVAE_EXCHANGE_*: all-reduce + replicated Adam, or sharded (ZeRO-1 shaped)
     int64_t bucket_bytes = 0;          // 0: one bucket per stack, reduced in line on the compute stream
     int comm_test_delay_us = 0;        // tests: a spin kernel in front of every reduction
     Layout L;
@@ -290,7 +295,8 @@ __global__ void __launch_bounds__(256)
 reparam_kernel(const float* __restrict__ te_out, int ldte, const float* __restrict__ eps_in,
                float* __restrict__ eps_used, float* __restrict__ md_in, int ld_md, int Db, int Z, int rows,
                int rows_pad, int noise, unsigned long long seed, unsigned long long offset,
-               float* __restrict__ partial, float* __restrict__ z_dense) {
+               float* __restrict__ partial, float* __restrict__ z_dense,
+               const float* __restrict__ mu_p = nullptr, int ldmp = 0) {
     float acc = 0.f;
     const int total = rows_pad * Z;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
@@ -301,7 +307,12 @@ reparam_kernel(const float* __restrict__ te_out, int ldte, const float* __restri
             const float lv = te_out[(size_t)r * ldte + Z + c];
             if (noise) e = eps_in ? eps_in[(size_t)r * Z + c] : philox_normal(seed, offset, r, c);
             z = mu + e * expf(0.5f * lv);
-            acc += -0.5f * (1.0f + lv - mu * mu - expf(lv));
+            if (mu_p) {               // KL(N(mu, s^2) || N(mu_p, 1)), oracle/refpath.py PRIORS
+                const float d = mu - mu_p[(size_t)r * ldmp + c];
+                acc += 0.5f * (expf(lv) + d * d - 1.0f - lv);
+            } else {
+                acc += -0.5f * (1.0f + lv - mu * mu - expf(lv));
+            }
         }
         md_in[(size_t)r * ld_md + Db + c] = z;
         eps_used[(size_t)r * Z + c] = e;
@@ -316,7 +327,8 @@ reparam_kernel(const float* __restrict__ te_out, int ldte, const float* __restri
 __global__ void __launch_bounds__(256)
 reparam_bwd_kernel(const float* __restrict__ d_md_in, int ld_md, int Db, const float* __restrict__ te_out,
                    int ldte, const float* __restrict__ eps_used, float* __restrict__ dz_te, int ld_dz,
-                   int rows, int rows_pad, int Z, float kl_scale) {
+                   int rows, int rows_pad, int Z, float kl_scale, const float* __restrict__ mu_p = nullptr,
+                   int ldmp = 0, float* __restrict__ dz_p = nullptr, int ldzp = 0) {
     const int total = rows_pad * ld_dz;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
         const int r = idx / ld_dz, c = idx - r * ld_dz;
@@ -327,13 +339,102 @@ reparam_bwd_kernel(const float* __restrict__ d_md_in, int ld_md, int Db, const f
             const float mu = te_out[(size_t)r * ldte + cz];
             const float lv = te_out[(size_t)r * ldte + Z + cz];
             if (c < Z) {
-                g = dzv + kl_scale * mu;
+                if (mu_p) {
+                    const float gp = kl_scale * (mu - mu_p[(size_t)r * ldmp + cz]);
+                    g = dzv + gp;
+                    if (dz_p) dz_p[(size_t)r * ldzp + cz] = -gp;
+                } else {
+                    g = dzv + kl_scale * mu;
+                }
             } else {
                 const float e = eps_used[(size_t)r * Z + cz];
                 g = dzv * e * 0.5f * expf(0.5f * lv) + kl_scale * 0.5f * (expf(lv) - 1.0f);
             }
         }
         dz_te[idx] = g;
+        if (dz_p && c < Z && r >= rows) dz_p[(size_t)r * ldzp + c] = 0.f;
+    }
+}
+
+// PVAE_PRIOR_HYPERSPHERE (oracle/refpath.py PRIORS; rmt:810-814, tpv:404-407): the encoder's Z outputs
+// e are projected onto the unit sphere, z = e / max(|e|, 1e-12) (F.normalize), z goes to the decoder;
+// the prior sample of this forward is u = n / max(|n|, 1e-12), n ~ N(0, I) (the supplied eps, or Philox),
+// and the KL slot of the loss is mean_i <z_i, u_i>.  One wave per row.
+//   md_in[:, Db:Db+Z] = z     eps_used = u (zeros without noise)     partial[b] = sum over its rows of <z, u>
+__global__ void __launch_bounds__(256)
+sphere_kernel(const float* __restrict__ te_out, int ldte, const float* __restrict__ eps_in,
+              float* __restrict__ eps_used, float* __restrict__ md_in, int ld_md, int Db, int Z, int rows,
+              int rows_pad, int noise, unsigned long long seed, unsigned long long offset,
+              float* __restrict__ partial, float* __restrict__ z_dense) {
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    float dot = 0.f;
+    if (r < rows_pad) {
+        float e2 = 0.f, n2 = 0.f;
+        for (int c = lane; c < Z; c += 64) {
+            if (r < rows) {
+                const float e = te_out[(size_t)r * ldte + c];
+                e2 += e * e;
+                if (noise) {
+                    const float nz = eps_in ? eps_in[(size_t)r * Z + c] : philox_normal(seed, offset, r, c);
+                    n2 += nz * nz;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { e2 += __shfl_xor(e2, o, 64); n2 += __shfl_xor(n2, o, 64); }
+        const float ie = 1.0f / fmaxf(sqrtf(e2), 1e-12f), in_ = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+        for (int c = lane; c < Z; c += 64) {
+            float z = 0.f, u = 0.f;
+            if (r < rows) {
+                z = te_out[(size_t)r * ldte + c] * ie;
+                if (noise) u = (eps_in ? eps_in[(size_t)r * Z + c] : philox_normal(seed, offset, r, c)) * in_;
+                dot += z * u;
+                if (z_dense) z_dense[(size_t)r * Z + c] = z;
+            }
+            md_in[(size_t)r * ld_md + Db + c] = z;
+            eps_used[(size_t)r * Z + c] = u;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    }
+    if (lane == 0) part[wave] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0 && partial) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// its backward: g = dL/dz = (what came back through the decoder) + (beta/B) u;  dL/de = (g - z <z, g>) / |e|
+__global__ void __launch_bounds__(256)
+sphere_bwd_kernel(const float* __restrict__ d_md_in, int ld_md, int Db, const float* __restrict__ te_out, int ldte,
+                  const float* __restrict__ u_used, float* __restrict__ dz_te, int ld_dz, int rows, int rows_pad,
+                  int Z, float kl_scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= rows_pad) return;
+    float e2 = 0.f, zg = 0.f;
+    if (r < rows)
+        for (int c = lane; c < Z; c += 64) {
+            const float e = te_out[(size_t)r * ldte + c];
+            e2 += e * e;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o, 64);
+    const float ie = 1.0f / fmaxf(sqrtf(e2), 1e-12f);
+    if (r < rows)
+        for (int c = lane; c < Z; c += 64) {
+            const float g = d_md_in[(size_t)r * ld_md + Db + c] + kl_scale * u_used[(size_t)r * Z + c];
+            zg += te_out[(size_t)r * ldte + c] * ie * g;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) zg += __shfl_xor(zg, o, 64);
+    for (int c = lane; c < ld_dz; c += 64) {
+        float d = 0.f;
+        if (r < rows && c < Z) {
+            const float g = d_md_in[(size_t)r * ld_md + Db + c] + kl_scale * u_used[(size_t)r * Z + c];
+            d = (g - te_out[(size_t)r * ldte + c] * ie * zg) * ie;
+        }
+        dz_te[(size_t)r * ld_dz + c] = d;
     }
 }
 
@@ -810,7 +911,8 @@ int pvae_layer(const pvae_config* cfg, int i, pvae_layer_info* out) {
     if (!cfg || !out) return fail(-1, "null argument");
     Layout L = make_layout(*cfg);
     if (!L.ok) return fail(-1, "bad config: %s", L.why);
-    for (auto& N : L.net) {
+    for (int n : kArenaOrder) {
+        const NetLayout& N = L.net[n];
         if (i < (int)N.layers.size()) {
             const Layer& l = N.layers[i];
             out->net = l.net; out->index = l.index; out->n_in = l.n_in; out->n_out = l.n_out;
@@ -852,7 +954,7 @@ int64_t pvae_workspace_offset(const pvae_config* cfg, int kind, int net, int lay
     if (!L.ok) return fail(-1, "bad config: %s", L.why);
     Workspace W = make_workspace(L);
     if (kind >= 0 && kind <= 3) {
-        if (net < 0 || net >= PVAE_NUM_NETS) return fail(-1, "bad net id %d", net);
+        if (net < 0 || net >= PVAE_NUM_NETS || L.net[net].layers.empty()) return fail(-1, "bad net id %d", net);
         if (kind >= 2 && (layer < 0 || layer >= (int)L.net[net].layers.size())) return fail(-1, "bad layer %d", layer);
     }
     switch (kind) {
@@ -944,6 +1046,10 @@ static StageArgs stage_args(const pvae_ctx* c, long long first_window, const flo
     a.s2 = w + (alt ? c->W.alt_s2 : c->W.s2); a.ld_s2 = pad64(Db);
     a.act_t = w + (alt ? c->W.alt_act_t : c->W.act_t); a.ld_a = pad64(Da);
     a.wm_pred = (steps > 1 && !alt) ? a.wm_in + (int64_t)steps * a.rows_pad * ld_wm : nullptr;
+    if (!c->L.net[PVAE_NET_PR].layers.empty()) {
+        a.pr_in = w + (alt ? c->W.alt_in[PVAE_NET_PR] : c->W.net[PVAE_NET_PR].in);
+        a.ld_pr = c->L.net[PVAE_NET_PR].layers[0].ld;
+    }
     return a;
 }
 
@@ -985,6 +1091,29 @@ int pvae_set_batch(pvae_ctx* c, const float* x, const float* y, int32_t rows, vo
 
 }  // extern "C"
 
+// The sampler of the configured prior kind (rmt:795-819): reparam_kernel (N(mu, s^2); KL to N(0, I) or to
+// the learned prior mean mu_p) or sphere_kernel (unit-sphere encoder).  `partial` may be null (rollout).
+static int sampler_grid(const pvae_ctx* c, int rows_pad) {
+    if (c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE) return rows_pad / 4;
+    const int Z = c->L.cfg.latent;
+    return (rows_pad * Z + 255) / 256 < 64 ? (rows_pad * Z + 255) / 256 : 64;
+}
+static int launch_sampler(pvae_ctx* c, const float* te_out, int ldte, const float* eps, float* eps_used, float* md_in,
+                          int ld_md, int rows, int rows_pad, int noise, unsigned long long seed,
+                          unsigned long long offset, float* partial, float* z_dense, const float* mu_p, int ldmp,
+                          hipStream_t st) {
+    const int Db = c->L.cfg.dim_body, Z = c->L.cfg.latent;
+    if (c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE) {
+        hipLaunchKernelGGL(sphere_kernel, dim3((rows_pad + 3) / 4), dim3(256), 0, st, te_out, ldte, eps, eps_used, md_in,
+                           ld_md, Db, Z, rows, rows_pad, noise, seed, offset, partial, z_dense);
+    } else {
+        hipLaunchKernelGGL(reparam_kernel, dim3(sampler_grid(c, rows_pad)), dim3(256), 0, st, te_out, ldte, eps, eps_used,
+                           md_in, ld_md, Db, Z, rows, rows_pad, noise, seed, offset, partial, z_dense, mu_p, ldmp);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // Everything a step needs that is a pure function of (phase, rows, step params).
 struct StepShape {
     int rows_pad, wm_tiles, gridz, nparts_a;
@@ -1008,11 +1137,14 @@ static int step_shape(pvae_ctx* c, int phase, int rows, const pvae_step_params* 
     if ((int64_t)S.wm_tiles * T > kLossParts)
         return fail(-1, "batch x dim_body x lookahead too large for the loss partial buffer");
     S.Bg *= (float)T;                          // every term is the mean over the L steps (tpv:423-428)
-    S.gridz = (S.rows_pad * Z + 255) / 256 < 64 ? (S.rows_pad * Z + 255) / 256 : 64;
+    S.gridz = sampler_grid(c, S.rows_pad);
+    (void)Z;
     S.nparts_a = S.rows_pad < 64 ? S.rows_pad : 64;
     S.cyc_grad = backward && phase == PVAE_PHASE_JOINT && sp->cycle_coeff > 0.0f;
     S.kl_active = phase == PVAE_PHASE_JOINT && sp->kl_coeff > 0.0f && sp->a_rec_coeff > 0.0f;   // tpv:381-384
-    S.seed_sampler = backward && phase == PVAE_PHASE_JOINT && c->W.L == 1 && c->pair_launch;
+    // (the sphere's backward needs a dot product over a whole latent row, which no tile epilogue sees)
+    S.seed_sampler = backward && phase == PVAE_PHASE_JOINT && c->W.L == 1 && c->pair_launch &&
+                     c->L.cfg.prior_kind != PVAE_PRIOR_HYPERSPHERE;
     S.seed_action = S.seed_sampler && S.cyc_grad;
     float* part = c->ws + c->W.loss_part;
     memset(&S.lf, 0, sizeof(S.lf));
@@ -1082,20 +1214,28 @@ static int run_forward(pvae_ctx* c, int phase, int rows, const pvae_step_params*
         mse.partial = part + 3 * kLossParts;
         return forward_net(c, PVAE_NET_WM, S.rows_pad, st, wm_tail);
     }
+    const NetLayout& PR = c->L.net[PVAE_NET_PR];
+    const NetWork& wpr = c->W.net[PVAE_NET_PR];
+    const bool learned_prior = !PR.layers.empty();
     if (!c->seed_pads_clean) {
-        // the seed epilogues (plan_backward) write only the real columns of these two gradient
+        // the seed epilogues (plan_backward) write only the real columns of these gradient
         // panels; their pad columns must be zero and nothing else ever writes them
         HIP_TRY(hipMemsetAsync(w + wmd.dz.back(), 0, (size_t)c->W.Bp * MD.layers.back().n_out_pad * sizeof(float), st));
         HIP_TRY(hipMemsetAsync(w + wte.dz.back(), 0, (size_t)c->W.Bp * TE.layers.back().n_out_pad * sizeof(float), st));
+        if (learned_prior)
+            HIP_TRY(hipMemsetAsync(w + wpr.dz.back(), 0, (size_t)c->W.Bp * PR.layers.back().n_out_pad * sizeof(float), st));
         c->seed_pads_clean = true;
     }
-    // joint forward: TE -> sampler -> MD -> WM (rmt:742-771)
+    // joint forward: [prior mean ->] TE -> sampler -> MD -> WM (rmt:742-771, 801-809)
+    if (learned_prior && (rc = forward_net(c, PVAE_NET_PR, S.rows_pad, st))) return rc;
     if ((rc = forward_net(c, PVAE_NET_TE, S.rows_pad, st))) return rc;
-    hipLaunchKernelGGL(reparam_kernel, dim3(S.gridz), dim3(256), 0, st, w + wte.act.back(),
-                       TE.layers.back().n_out_pad, eps, w + c->W.eps, w + wmd.in, MD.layers[0].ld, Db, Z, rows,
-                       S.rows_pad, 1, (unsigned long long)sp->rng_seed, (unsigned long long)sp->rng_offset,
-                       part + 2 * kLossParts, (float*)nullptr);
-    HIP_TRY(hipGetLastError());
+    if ((rc = launch_sampler(c, w + wte.act.back(), TE.layers.back().n_out_pad, eps, w + c->W.eps, w + wmd.in,
+                             MD.layers[0].ld, rows, S.rows_pad, 1, (unsigned long long)sp->rng_seed,
+                             (unsigned long long)sp->rng_offset, part + 2 * kLossParts, (float*)nullptr,
+                             learned_prior ? w + wpr.act.back() : (const float*)nullptr,
+                             learned_prior ? PR.layers.back().n_out_pad : 0, st)))
+        return rc;
+    (void)Z;
     FwdTail md_tail;                           // a_hat also lands in the action columns of the WM input
     md_tail.out2 = w + wwm.in; md_tail.ld2 = WM.layers[0].ld; md_tail.off2 = Db; md_tail.n2 = Da;
     if ((rc = forward_net(c, PVAE_NET_MD, S.rows_pad, st, md_tail))) return rc;
@@ -1127,6 +1267,10 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
     const NetWork* wte = &c->W.net[PVAE_NET_TE];
     const NetWork* wmd = &c->W.net[PVAE_NET_MD];
     const NetWork* wwm = &c->W.net[PVAE_NET_WM];
+    const NetLayout* PR = &c->L.net[PVAE_NET_PR];
+    const NetWork* wpr = &c->W.net[PVAE_NET_PR];
+    const bool learned_prior = !PR->layers.empty();
+    const bool sphere = c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE;
     const int ldo_md = MD->layers.back().n_out_pad, ldo_te = TE->layers.back().n_out_pad;
     const float ga = sp->a_rec_coeff * S.gs / (S.Bg * Da);
     // The two gradient hand-overs between stacks live in the epilogue of the consuming stack's
@@ -1173,6 +1317,10 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
         ss.s.dz = w + wte->dz.back(); ss.s.ldz = ldo_te;
         ss.s.c0 = Db; ss.s.Z = Z; ss.s.rows = rows;
         ss.s.kl_scale = kls;
+        if (learned_prior) {
+            ss.s.mu_p = w + wpr->act.back(); ss.s.ldmp = PR->layers.back().n_out_pad;
+            ss.s.dz_p = w + wpr->dz.back(); ss.s.ldzp = PR->layers.back().n_out_pad;
+        }
     }
     CarriedWgrad carry;
     plan_backward_net(c, PVAE_NET_MD, S.rows_pad, true, true, sp, fused, st, nullptr, plan, &ss,
@@ -1182,13 +1330,26 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
         const int tot = rows_pad * TE->layers.back().n_out_pad;
         plan.emplace_back();
         plan.back().run = [=]() -> int {
-            hipLaunchKernelGGL(reparam_bwd_kernel, dim3((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256), dim3(256), 0,
-                               st, w + wmd->d_in, MD->layers[0].ld, Db, w + wte->act.back(), TE->layers.back().n_out_pad,
-                               w + c->W.eps, w + wte->dz.back(), TE->layers.back().n_out_pad, rows, rows_pad, Z, kls);
+            if (sphere) {
+                hipLaunchKernelGGL(sphere_bwd_kernel, dim3((rows_pad + 3) / 4), dim3(256), 0, st, w + wmd->d_in,
+                                   MD->layers[0].ld, Db, w + wte->act.back(), TE->layers.back().n_out_pad, w + c->W.eps,
+                                   w + wte->dz.back(), TE->layers.back().n_out_pad, rows, rows_pad, Z, kls);
+            } else {
+                hipLaunchKernelGGL(reparam_bwd_kernel, dim3((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256), dim3(256), 0,
+                                   st, w + wmd->d_in, MD->layers[0].ld, Db, w + wte->act.back(), TE->layers.back().n_out_pad,
+                                   w + c->W.eps, w + wte->dz.back(), TE->layers.back().n_out_pad, rows, rows_pad, Z, kls,
+                                   learned_prior ? w + wpr->act.back() : (const float*)nullptr,
+                                   learned_prior ? PR->layers.back().n_out_pad : 0,
+                                   learned_prior ? w + wpr->dz.back() : (float*)nullptr,
+                                   learned_prior ? PR->layers.back().n_out_pad : 0);
+            }
             HIP_TRY(hipGetLastError());
             return 0;
         };
     }
+    // the learned prior mean trains through the KL term only (its output gradient was written beside the
+    // encoder's by the sampler backward above); no input gradient
+    if (learned_prior) plan_backward_net(c, PVAE_NET_PR, S.rows_pad, true, false, sp, fused, st, nullptr, plan);
     plan_backward_net(c, PVAE_NET_TE, S.rows_pad, true, false, sp, fused, st, fold, plan, nullptr, nullptr, &carry);
 }
 
@@ -1546,6 +1707,7 @@ int pvae_adam(pvae_ctx* c, int net_mask, const pvae_step_params* sp, void* strea
     for (int n = 0; n < PVAE_NUM_NETS; ++n) {
         if (!(net_mask & (1 << n))) continue;
         const NetLayout& N = c->L.net[n];
+        if (N.count == 0) continue;
         const long long n4 = N.count / 4;      // segments are multiples of 64 floats
         int grid = (int)((n4 + 255) / 256);
         if (grid > 2048) grid = 2048;
@@ -1588,6 +1750,19 @@ int pvae_comm_init(pvae_ctx* c, int rank, int world, const void* id128) {
         HIP_TRY(hipEventCreateWithFlags(&c->comm_done, hipEventDisableTiming));
     }
     if (const char* e = getenv("PVAE_DP_BUCKET_MB")) c->bucket_bytes = (int64_t)(atof(e) * (1 << 20));
+    if (const char* e = getenv("PVAE_DP_SHARDED")) c->exchange_mode = e[0] == '1' ? PVAE_EXCHANGE_SHARDED : PVAE_EXCHANGE_ALLREDUCE;
+    return 0;
+}
+
+int pvae_comm_mode(pvae_ctx* c, int mode) {
+    if (!c) return fail(-1, "null ctx");
+    if (mode != PVAE_EXCHANGE_ALLREDUCE && mode != PVAE_EXCHANGE_SHARDED) return fail(-1, "unknown exchange mode %d", mode);
+    if (mode == PVAE_EXCHANGE_SHARDED) {
+        int rc = rccl_load();
+        if (rc) return rc;
+        if (!g_rccl.ReduceScatter || !g_rccl.AllGather) return fail(-20, "RCCL lacks ncclReduceScatter / ncclAllGather");
+    }
+    c->exchange_mode = mode;
     return 0;
 }
 
@@ -1666,6 +1841,23 @@ static int exchange_bucket(pvae_ctx* c, int net, const Bucket& b, const pvae_ste
         hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, cs, (long long)c->comm_test_delay_us * 100);   // 100 MHz
         HIP_TRY(hipGetLastError());
     }
+    // Sharded exchange (PVAE_EXCHANGE_SHARDED, ZeRO-1 shaped): every rank reduces only ITS 1/N slice of the
+    // bucket (reduce-scatter, in place), applies Adam to that slice (1/N of the p, g, m, v traffic) and the
+    // updated parameter slices are all-gathered in place.  Same bytes on the links as a ring all-reduce;
+    // the moments of the other ranks' slices are never touched here (they stay at whatever they were).
+    const int64_t N = c->comm_world;
+    if (c->exchange_mode == PVAE_EXCHANGE_SHARDED && g_rccl.ReduceScatter && g_rccl.AllGather &&
+        b.cnt % (N * 4) == 0 && b.cnt > 0) {
+        const int64_t slice = b.cnt / N, mine = b.off + c->comm_rank * slice;
+        int ps = g_prof.begin_range(4, (double)b.cnt * sizeof(float), cs);
+        RCCL_TRY(g_rccl.ReduceScatter(c->grads + b.off, c->grads + mine, (size_t)slice, kNcclFloat32, kNcclSum, c->comm, cs));
+        g_prof.end_range(ps, cs);
+        if ((rc = pvae_adam_segment(c, net, mine, slice, sp, cs))) return rc;
+        ps = g_prof.begin_range(4, (double)b.cnt * sizeof(float), cs);
+        RCCL_TRY(g_rccl.AllGather(c->params + mine, c->params + b.off, (size_t)slice, kNcclFloat32, c->comm, cs));
+        g_prof.end_range(ps, cs);
+        return 0;
+    }
     if ((rc = pvae_allreduce_grads(c, b.off, b.cnt, cs))) return rc;
     return pvae_adam_segment(c, net, b.off, b.cnt, sp, cs);
 }
@@ -1694,8 +1886,10 @@ int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t row
     if (!c->grads || !c->m || !c->v) return fail(-2, "grads / Adam moment arenas not bound");
     if (phase != PVAE_PHASE_WORLD && phase != PVAE_PHASE_JOINT) return fail(-1, "unknown phase %d", phase);
     hipStream_t st = (hipStream_t)stream;
-    const int nets[2] = {phase == PVAE_PHASE_WORLD ? PVAE_NET_WM : PVAE_NET_MD,
-                         phase == PVAE_PHASE_WORLD ? -1 : PVAE_NET_TE};      // backward order
+    const bool learned_prior = !c->L.net[PVAE_NET_PR].layers.empty();
+    const int nets[3] = {phase == PVAE_PHASE_WORLD ? PVAE_NET_WM : PVAE_NET_MD,
+                         phase == PVAE_PHASE_WORLD ? -1 : (learned_prior ? PVAE_NET_PR : PVAE_NET_TE),
+                         phase == PVAE_PHASE_WORLD || !learned_prior ? -1 : PVAE_NET_TE};      // backward order
     hipStream_t cs = (c->bucket_bytes > 0 && c->comm_stream) ? c->comm_stream : st;
     int n_events = 0;
     auto join = [&]() -> int {                 // later work on the caller's stream sees the updated parameters
@@ -1829,13 +2023,19 @@ int pvae_read_tensor(pvae_ctx* c, int what, float* dst, int32_t rows, void* stre
     const NetWork& wte = c->W.net[PVAE_NET_TE];
     switch (what) {
         case 0: src = c->ws + wte.act.back(); ld = c->L.net[PVAE_NET_TE].layers.back().n_out_pad; col0 = 0; nc = Z; break;
-        case 1: src = c->ws + wte.act.back(); ld = c->L.net[PVAE_NET_TE].layers.back().n_out_pad; col0 = Z; nc = Z; break;
+        case 1:
+            if (c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE) return fail(-1, "the hypersphere encoder has no logvar");
+            src = c->ws + wte.act.back(); ld = c->L.net[PVAE_NET_TE].layers.back().n_out_pad; col0 = Z; nc = Z; break;
         case 2: src = c->ws + c->W.net[PVAE_NET_MD].in; ld = c->L.net[PVAE_NET_MD].layers[0].ld; col0 = Db; nc = Z; break;
         case 3: src = c->ws + c->W.net[PVAE_NET_MD].act.back(); ld = c->L.net[PVAE_NET_MD].layers.back().n_out_pad; col0 = 0; nc = Da; break;
         case 4: src = c->ws + c->W.net[PVAE_NET_WM].act.back(); ld = c->L.net[PVAE_NET_WM].layers.back().n_out_pad; col0 = 0; nc = Db;
                 if (c->W.L > 1) blk += (int64_t)c->W.L * rows_pad;      // the predicted-action invocation
                 break;
         case 5: src = c->ws + c->W.eps; ld = Z; col0 = 0; nc = Z; break;
+        case 6:
+            if (c->L.net[PVAE_NET_PR].layers.empty()) return fail(-1, "no learned prior in this configuration");
+            src = c->ws + c->W.net[PVAE_NET_PR].act.back(); ld = c->L.net[PVAE_NET_PR].layers.back().n_out_pad; col0 = 0; nc = Z;
+            break;
         default: return fail(-1, "unknown tensor id %d", what);
     }
     src += blk * ld;
@@ -1859,12 +2059,13 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
     const NetLayout& MD = c->L.net[PVAE_NET_MD];
     const NetLayout& WM = c->L.net[PVAE_NET_WM];
     if ((rc = forward_net(c, PVAE_NET_TE, rows_pad, st))) return rc;
-    const int gridz = (rows_pad * Z + 255) / 256 < 64 ? (rows_pad * Z + 255) / 256 : 64;
-    hipLaunchKernelGGL(reparam_kernel, dim3(gridz), dim3(256), 0, st, w + c->W.net[PVAE_NET_TE].act.back(),
-                       TE.layers.back().n_out_pad, eps, w + c->W.eps, w + c->W.net[PVAE_NET_MD].in, MD.layers[0].ld, Db,
-                       Z, rows, rows_pad, noise ? 1 : 0, (unsigned long long)rng_seed, (unsigned long long)rng_offset,
-                       (float*)nullptr, z_out);                 // z also lands in the caller's buffer
-    HIP_TRY(hipGetLastError());
+    // (the learned prior mean plays no part in the action: rmt:801-809 only records it)
+    if ((rc = launch_sampler(c, w + c->W.net[PVAE_NET_TE].act.back(), TE.layers.back().n_out_pad, eps, w + c->W.eps,
+                             w + c->W.net[PVAE_NET_MD].in, MD.layers[0].ld, rows, rows_pad, noise ? 1 : 0,
+                             (unsigned long long)rng_seed, (unsigned long long)rng_offset, (float*)nullptr, z_out,
+                             (const float*)nullptr, 0, st)))                 // z also lands in the caller's buffer
+        return rc;
+    (void)Z;
     // The decoder's output layer can write a second copy of a_hat: into the world model's input
     // panel when the prediction is wanted, else straight into the caller's buffer (row counts the
     // GEMV kernel covers exactly -- the control loop's B = 1 -- so no padded row is written).
@@ -1920,15 +2121,14 @@ int pvae_reparam(pvae_ctx* c, const float* mu_logvar, int32_t rows, const float*
     if (!mu_logvar || !z_out) return fail(-1, "mu_logvar / z_out is null");
     if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
     hipStream_t st = (hipStream_t)stream;
-    const int Db = c->L.cfg.dim_body, Z = c->L.cfg.latent;
+    const int Z = c->L.cfg.latent;
     const int ld_md = c->L.net[PVAE_NET_MD].layers[0].ld;
-    const int gridz = (rows * Z + 255) / 256 < 64 ? (rows * Z + 255) / 256 : 64;
     c->staged_rows = 0;
-    hipLaunchKernelGGL(reparam_kernel, dim3(gridz), dim3(256), 0, st, mu_logvar, 2 * Z, eps, c->ws + c->W.eps,
-                       c->ws + c->W.net[PVAE_NET_MD].in, ld_md, Db, Z, rows, rows, noise ? 1 : 0,
-                       (unsigned long long)rng_seed, (unsigned long long)rng_offset, (float*)nullptr, z_out);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    const int ldte = c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE ? Z : 2 * Z;       // dense [rows][n_out of the encoder]
+    // pad rows are not touched: `rows` doubles as rows_pad (the sphere kernel rounds its grid up itself)
+    return launch_sampler(c, mu_logvar, ldte, eps, c->ws + c->W.eps, c->ws + c->W.net[PVAE_NET_MD].in, ld_md, rows, rows,
+                          noise ? 1 : 0, (unsigned long long)rng_seed, (unsigned long long)rng_offset, (float*)nullptr,
+                          z_out, (const float*)nullptr, 0, st);
 }
 
 int pvae_profile_enable(int on) {

@@ -139,6 +139,7 @@ struct StageArgs {
     float* s2; int ld_s2;
     float* act_t; int ld_a;
     float* wm_pred;
+    float* pr_in; int ld_pr;      // input panel of the learned prior stack [s1 | 0] (null: no such stack)
 };
 
 __device__ inline void stage_row(const StageArgs& a, int r, int t, int rows_pad) {
@@ -165,6 +166,7 @@ __device__ inline void stage_row(const StageArgs& a, int r, int t, int rows_pad)
     if (a.ld_md > ld_max) ld_max = a.ld_md;
     if (a.ld_wm > ld_max) ld_max = a.ld_wm;
     for (int c = threadIdx.x; c < ld_max; c += 256) {
+        if (a.pr_in && c < a.ld_pr) a.pr_in[prow * a.ld_pr + c] = (valid && first && c < Db) ? p1[c] : 0.f;
         const float v1 = (valid && first && c < Db) ? p1[c] : 0.f;
         const float v2 = (valid && c < Db) ? p2[c] : 0.f;
         const float va = (valid && pa && c < Da) ? pa[c] : 0.f;
@@ -1701,6 +1703,10 @@ struct EpiSamplerSeed {
     float* dz; int ldz;               // -> gradient wrt the encoder's output layer [.. | dmu | dlogvar]
     int c0, Z, rows;
     float kl_scale;
+    // learned prior mean (PVAE_PRIOR_STATE_MEAN; null otherwise): KL(N(mu,s^2) || N(mu_p,1)) pulls mu and
+    // mu_p together -- dmu gets +kl (mu - mu_p), the prior stack's output gradient is the negative of it
+    const float* mu_p = nullptr; int ldmp = 0;
+    float* dz_p = nullptr; int ldzp = 0;
     struct Pre {};
     __device__ inline Pre preload(int, int) const { return Pre(); }
     __device__ inline void operator()(int q, int p, v4f v, const Pre&) const {
@@ -1709,16 +1715,22 @@ struct EpiSamplerSeed {
         for (int e = 0; e < 4; ++e) {
             const int j = p + e - c0;
             if (j < 0 || j >= Z) continue;
-            float gm = 0.f, gl = 0.f;
+            float gm = 0.f, gl = 0.f, gp = 0.f;
             if (q < rows) {
                 const float mu = te_out[(size_t)q * ldte + j];
                 const float lv = te_out[(size_t)q * ldte + Z + j];
                 const float ep = eps[(size_t)q * Z + j];
-                gm = v[e] + kl_scale * mu;
+                if (mu_p) {
+                    gp = kl_scale * (mu - mu_p[(size_t)q * ldmp + j]);
+                    gm = v[e] + gp;
+                } else {
+                    gm = v[e] + kl_scale * mu;
+                }
                 gl = v[e] * ep * 0.5f * expf(0.5f * lv) + kl_scale * 0.5f * (expf(lv) - 1.0f);
             }
             dz[(size_t)q * ldz + j] = gm;
             dz[(size_t)q * ldz + Z + j] = gl;
+            if (dz_p) dz_p[(size_t)q * ldzp + j] = -gp;
         }
     }
     __device__ inline void finish(float*, int, int) const {}

@@ -33,6 +33,9 @@ struct Layout {
     const char* why = "";
 };
 
+// order of the stacks in the arena (and of pvae_layer's enumeration)
+constexpr int kArenaOrder[PVAE_NUM_NETS] = {PVAE_NET_TE, PVAE_NET_MD, PVAE_NET_PR, PVAE_NET_WM};
+
 inline Layout make_layout(const pvae_config& c) {
     Layout L;
     L.cfg = c;
@@ -42,15 +45,24 @@ inline Layout make_layout(const pvae_config& c) {
     if (c.te_depth > 15 || c.md_depth > 15 || c.wm_depth > 15) { L.why = "depth > 15 unsupported"; return L; }
     if (c.max_batch <= 0 || c.max_batch > 65536) { L.why = "max_batch out of range"; return L; }
     if (c.lookahead < 1 || c.lookahead > 64) { L.why = "lookahead must be in [1, 64]"; return L; }
+    if (c.prior_kind < 0 || c.prior_kind > PVAE_PRIOR_HYPERSPHERE) { L.why = "unknown prior_kind"; return L; }
+    if (c.prior_kind != PVAE_PRIOR_ZERO_MEAN && c.lookahead != 1) {
+        L.why = "latent priors other than normal_zero_mean_one_std need lookahead == 1";
+        return L;
+    }
+    const bool learned = c.prior_kind == PVAE_PRIOR_STATE_MEAN;
+    if (learned && (c.pr_width <= 0 || c.pr_depth <= 0 || c.pr_depth > 15)) { L.why = "prior stack width/depth out of range"; return L; }
     const int Db = c.dim_body, Da = c.dim_action, Z = c.latent;
-    const int ins[3] = {2 * Db, Db + Z, Db + Da};        // rmt:638-644, 646-668, 682-689
-    const int outs[3] = {2 * Z, Da, Db};
-    const int widths[3] = {c.te_width, c.md_width, c.wm_width};
-    const int depths[3] = {c.te_depth, c.md_depth, c.wm_depth};
+    // rmt:638-644 (618-621: Z outputs on the hypersphere), 646-668, 682-689, 627-635
+    const int ins[PVAE_NUM_NETS] = {2 * Db, Db + Z, Db + Da, Db};
+    const int outs[PVAE_NUM_NETS] = {c.prior_kind == PVAE_PRIOR_HYPERSPHERE ? Z : 2 * Z, Da, Db, Z};
+    const int widths[PVAE_NUM_NETS] = {c.te_width, c.md_width, c.wm_width, c.pr_width};
+    const int depths[PVAE_NUM_NETS] = {c.te_depth, c.md_depth, c.wm_depth, c.pr_depth};
     int64_t off = 0;
-    for (int n = 0; n < PVAE_NUM_NETS; ++n) {
+    for (int n : kArenaOrder) {
         NetLayout& N = L.net[n];
         N.off = off;
+        if (n == PVAE_NET_PR && !learned) continue;          // no such stack: an empty segment
         N.n_in = ins[n];
         N.n_out = outs[n];
         int prev = ins[n];
@@ -96,7 +108,7 @@ struct Workspace {
     int64_t eps = 0;            // eps actually used [L*Bp][Z]
     // second set of staging panels (lookahead 1 only): the gather of minibatch n+1 is written here
     // by tail blocks of step n's last launch, then the two sets swap roles (pvae_train_step_prefetch)
-    int64_t alt_in[PVAE_NUM_NETS] = {0, 0, 0};
+    int64_t alt_in[PVAE_NUM_NETS] = {0, 0, 0, 0};
     int64_t alt_s2 = 0, alt_act_t = 0;
     int64_t loss_part = 0;      // [5][kLossParts] partial sums
     int64_t total_floats = 0;
@@ -113,6 +125,7 @@ inline Workspace make_workspace(const Layout& L) {
     auto take = [&](int64_t n) { int64_t o = off; off += (n + 63) / 64 * 64; return o; };
     for (int n = 0; n < PVAE_NUM_NETS; ++n) {
         const NetLayout& N = L.net[n];
+        if (N.layers.empty()) continue;
         const int64_t slots = (T > 1 && n == PVAE_NET_WM) ? 2 * T : T;
         W.net[n].slots = (int)slots;
         W.net[n].in = take(slots * W.Bp * N.layers[0].ld);
@@ -125,7 +138,8 @@ inline Workspace make_workspace(const Layout& L) {
     W.s2 = take(T * W.Bp * pad64(L.cfg.dim_body));
     W.act_t = take(T * W.Bp * pad64(L.cfg.dim_action));
     W.eps = take(T * W.Bp * L.cfg.latent);
-    for (int n = 0; n < PVAE_NUM_NETS; ++n) W.alt_in[n] = take((int64_t)W.Bp * L.net[n].layers[0].ld);
+    for (int n = 0; n < PVAE_NUM_NETS; ++n)
+        if (!L.net[n].layers.empty()) W.alt_in[n] = take((int64_t)W.Bp * L.net[n].layers[0].ld);
     W.alt_s2 = take((int64_t)W.Bp * pad64(L.cfg.dim_body));
     W.alt_act_t = take((int64_t)W.Bp * pad64(L.cfg.dim_action));
     W.loss_part = take(5 * kLossParts);

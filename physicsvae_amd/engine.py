@@ -8,24 +8,33 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import FLAG_FUSED_ADAM, FLAG_NO_BACKWARD, NET_MD, NET_NAMES, NET_TE, NET_WM
+from ._lib import FLAG_FUSED_ADAM, FLAG_NO_BACKWARD, NET_MD, NET_NAMES, NET_PR, NET_TE, NET_WM, NUM_NETS, PRIOR_KINDS
 
-TENSOR_IDS = {"mu": 0, "logvar": 1, "z": 2, "a_hat": 3, "s2_hat": 4, "eps": 5}
+TENSOR_IDS = {"mu": 0, "logvar": 1, "z": 2, "a_hat": 3, "s2_hat": 4, "eps": 5, "prior_mu": 6}
 
 
 class Arch:
     """Dims of the three trainable stacks (tpv:247-286 keys, gen_layers tpv:180-192)."""
 
-    def __init__(self, dim_body, dim_action, latent, te, md, wm):
+    def __init__(self, dim_body, dim_action, latent, te, md, wm, prior="normal_zero_mean_one_std", pr=None):
         self.Db, self.Da, self.Z = int(dim_body), int(dim_action), int(latent)
         self.te, self.md, self.wm = tuple(te), tuple(md), tuple(wm)
+        if prior not in PRIOR_KINDS:
+            raise NotImplementedError("Unknown latent_prior_type:%s" % (prior,))      # rmt:624-625
+        self.prior = prior                       # latent_prior_type (rmt:614-635; oracle/refpath.py PRIORS)
+        self.pr = tuple(pr) if pr is not None else tuple(te)      # learned prior stack (width, depth)
+
+    @property
+    def te_out(self):
+        return self.Z if self.prior == "hypersphere_uniform" else 2 * self.Z           # rmt:618-621
 
     def config(self, max_batch, lookahead=1):
         return _lib.Config(self.Db, self.Da, self.Z, self.te[0], self.te[1], self.md[0],
-                           self.md[1], self.wm[0], self.wm[1], int(max_batch), int(lookahead))
+                           self.md[1], self.wm[0], self.wm[1], int(max_batch), int(lookahead),
+                           PRIOR_KINDS[self.prior], self.pr[0], self.pr[1])
 
     def key(self):
-        return (self.Db, self.Da, self.Z, self.te, self.md, self.wm)
+        return (self.Db, self.Da, self.Z, self.te, self.md, self.wm, self.prior, self.pr)
 
 
 class GraphedInfer:
@@ -75,8 +84,8 @@ def make_step_params(lr, adam_t=(1, 1, 1), a_rec=1.0, kl=1.0, s_rec=0.0, cyc=1e-
     sp.loss_kind = {"MSE": _lib.LOSS_MSE, "L1": _lib.LOSS_L1, "MAE": _lib.LOSS_L1}[loss]
     sp.a_rec_coeff, sp.kl_coeff, sp.s_rec_coeff, sp.cycle_coeff = a_rec, kl, s_rec, cyc
     sp.lr, sp.beta1, sp.beta2, sp.adam_eps = lr, beta1, beta2, eps
-    for i in range(3):
-        sp.adam_t[i] = int(adam_t[i])
+    for i in range(NUM_NETS):                      # (TE, MD, WM[, PR]); a missing entry counts as step 1
+        sp.adam_t[i] = int(adam_t[i]) if i < len(adam_t) else 1
     sp.global_rows = int(global_rows)
     sp.rng_seed, sp.rng_offset = int(seed), int(offset)
     return sp
@@ -102,7 +111,7 @@ class HipEngine:
             _lib.check(self.lib.pvae_layer(C.byref(self.cfg), i, C.byref(info)))
             self.layers.append({f: getattr(info, f) for f, _ in _lib.LayerInfo._fields_})
         self.segments = {}
-        for net in (NET_TE, NET_MD, NET_WM):
+        for net in (NET_TE, NET_MD, NET_WM, NET_PR):
             off, cnt = C.c_int64(), C.c_int64()
             _lib.check(self.lib.pvae_net_segment(C.byref(self.cfg), net, C.byref(off), C.byref(cnt)))
             self.segments[net] = (off.value, cnt.value)
@@ -165,8 +174,9 @@ class HipEngine:
         return out
 
     def segment(self, arena, nets):
-        """Contiguous slice of `arena` covering the given nets (TE+MD are adjacent)."""
-        offs = [self.segments[n] for n in sorted(nets)]
+        """Contiguous slice of `arena` covering the given nets (arena order TE | MD | PR | WM: the stacks
+        trained together in the joint phase are adjacent)."""
+        offs = sorted(self.segments[n] for n in nets if self.segments[n][1] > 0)
         lo = offs[0][0]
         hi = offs[-1][0] + offs[-1][1]
         assert sum(c for _, c in offs) == hi - lo, "nets are not adjacent in the arena"
@@ -317,6 +327,12 @@ class HipEngine:
         include/pvae.h) and, for ordering tests, a delay in front of every reduction."""
         _lib.check(self.lib.pvae_comm_config(self.ctx, int(bucket_mb * (1 << 20)), int(test_delay_us)), "pvae_comm_config")
 
+    def comm_mode(self, sharded):
+        """Exchange form of dp_train_step: all-reduce + replicated Adam (default) or reduce-scatter ->
+        Adam on the owned 1/N slice -> all-gather of the parameters (include/pvae.h)."""
+        _lib.check(self.lib.pvae_comm_mode(self.ctx, _lib.EXCHANGE_SHARDED if sharded else _lib.EXCHANGE_ALLREDUCE),
+                   "pvae_comm_mode")
+
     def allreduce_grads(self, off, cnt):
         self._need_gpu()
         _lib.check(self.lib.pvae_allreduce_grads(self.ctx, int(off), int(cnt), self._stream()), "pvae_allreduce_grads")
@@ -337,7 +353,7 @@ class HipEngine:
         """Forward intermediate of time step `step` of the last batch."""
         self._need_gpu()
         width = {"mu": self.arch.Z, "logvar": self.arch.Z, "z": self.arch.Z, "eps": self.arch.Z,
-                 "a_hat": self.arch.Da, "s2_hat": self.arch.Db}[name]
+                 "prior_mu": self.arch.Z, "a_hat": self.arch.Da, "s2_hat": self.arch.Db}[name]
         dst = torch.empty(rows, width, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.pvae_read_tensor(self.ctx, TENSOR_IDS[name] + 8 * int(step), dst.data_ptr(), rows,
                                              self._stream()), "pvae_read_tensor")

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ._lib import NET_MD, NET_NAMES, NET_TE, NET_WM
+from ._lib import NET_MD, NET_NAMES, NET_PR, NET_TE, NET_WM, PRIOR_KINDS
 from .engine import Arch, HipEngine
 
 
@@ -91,15 +91,24 @@ class SlimFC(nn.Module):
 
 
 class AppendLogStd(nn.Module):
-    """rmt:160-206 with type "constant": log_std is a plain tensor (NOT a parameter or buffer,
-    so it is absent from state_dict) appended to the decoder output."""
+    """rmt:160-206.  "constant": log_std is a plain tensor (NOT a parameter or buffer, so it is absent
+    from state_dict) appended to the decoder output; "state_independent": an nn.Parameter (key
+    `..._model.<n>.log_std`).  The supervised loss reads the action half of the logits only
+    (tpv:356-359), so the parameter never receives a gradient there -- upstream or here."""
 
-    def __init__(self, init_val, dim):
+    def __init__(self, init_val, dim, type="constant", device=None):
         super().__init__()
-        self.type = "constant"
-        self.log_std = torch.full((dim,), float(init_val), dtype=torch.float32)
+        self.type = type
+        val = torch.full((dim,), float(init_val), dtype=torch.float32)
+        if type == "constant":
+            self.log_std = val
+        elif type == "state_independent":
+            self.log_std = nn.Parameter(val.to(device) if device is not None else val)
+        else:
+            raise NotImplementedError(type)
 
     def set_val(self, val):
+        assert self.type == "constant", "Change value is only allowed in constant logstd"
         assert np.isscalar(val), "Only scalar is currently supported"
         self.log_std[:] = float(val)
 
@@ -111,7 +120,8 @@ class AppendLogStd(nn.Module):
 class FC(nn.Module):
     """rmt:234-283: `self._model = nn.Sequential(SlimFC..., [AppendLogStd])`."""
 
-    def __init__(self, dims, views=None, append_log_std=False, sample_std=1.0):
+    def __init__(self, dims, views=None, append_log_std=False, sample_std=1.0, log_std_type="constant",
+                 device=None):
         super().__init__()
         mods = []
         for i, (n_in, n_out) in enumerate(dims):
@@ -120,7 +130,7 @@ class FC(nn.Module):
             mods.append(SlimFC(n_in, n_out, relu=not last, init_std=0.01 if last else 1.0,
                                weight=w, bias=b))
         if append_log_std:
-            mods.append(AppendLogStd(math.log(sample_std), dims[-1][1]))
+            mods.append(AppendLogStd(math.log(sample_std), dims[-1][1], type=log_std_type, device=device))
         self._model = nn.Sequential(*mods)
 
     def forward(self, x):
@@ -180,11 +190,11 @@ class PhysicsVAE(nn.Module):
         self.num_outputs = num_outputs
         cfg = copy.deepcopy(PhysicsVAE.DEFAULT_CONFIG)
         cfg.update(model_config.get("custom_model_config") or {})
-        if cfg["log_std_type"] != "constant":
-            raise NotImplementedError("only log_std_type 'constant' (the trainer's setting, rmt:466)")
-        if cfg["latent_prior_type"] != "normal_zero_mean_one_std":
-            # the other two priors crash in the reference itself
-            raise NotImplementedError("latent_prior_type %r" % (cfg["latent_prior_type"],))
+        if cfg["log_std_type"] not in ("constant", "state_independent"):
+            raise NotImplementedError(cfg["log_std_type"])                      # rmt:182-183
+        if cfg["latent_prior_type"] not in PRIOR_KINDS:
+            # (`False` = no prior, rmt:622-623, is never set by the trainer and is not built)
+            raise NotImplementedError("Unknown latent_prior_type:%s" % (cfg["latent_prior_type"],))    # rmt:624-625
         if cfg["task_encoder_inputs"] != ["body", "task"] or cfg["motor_decoder_inputs"] != ["body", "task"]:
             raise NotImplementedError("task-encoder / motor-decoder inputs must be ['body','task']")
         if cfg.get("motor_decoder_helper_enable"):
@@ -199,21 +209,24 @@ class PhysicsVAE(nn.Module):
         assert num_outputs // 2 == self.dim_action
         Z = int(cfg["task_encoder_output_dim"])
         self._task_encoder_output_dim = Z
+        # "normal_state_mean_one_std" / "hypersphere_uniform": the reference sketches them and crashes
+        # (rmt:632, tpv:395-396, 406); built here to the specification in oracle/refpath.py (PRIORS)
         self._latent_prior_type = cfg["latent_prior_type"]
-        self._latent_prior = None
         self._motor_decoder_helper = None
 
         te = _uniform_relu_stack(cfg["task_encoder_layers"], "task_encoder_layers")
         md = _uniform_relu_stack(cfg["motor_decoder_layers"], "motor_decoder_layers")
         wm = _uniform_relu_stack(cfg["world_model_layers"], "world_model_layers")
         vb = _uniform_relu_stack(cfg["value_fn_layers"], "value_fn_layers")
-        self.arch = Arch(self.dim_state_body, self.dim_action, Z, te, md, wm)
+        learned_prior = self._latent_prior_type == "normal_state_mean_one_std"
+        pr = _uniform_relu_stack(cfg.get("latent_prior_layers") or cfg["task_encoder_layers"], "latent_prior_layers")
+        self.arch = Arch(self.dim_state_body, self.dim_action, Z, te, md, wm, prior=self._latent_prior_type, pr=pr)
         device = cfg["device"] or ("cuda" if torch.cuda.is_available() else "cpu")
         self.engine = HipEngine(self.arch, int(cfg["max_batch"]), device=device,
                                 lookahead=int(cfg.get("lookahead", 1) or 1))
 
         views = self.engine.named_views()
-        per_net = {n: [] for n in (NET_TE, NET_MD, NET_WM)}
+        per_net = {n: [] for n in (NET_TE, NET_MD, NET_WM, NET_PR)}
         for info in self.engine.layers:
             base = "%s._model.%d._model.0." % (NET_NAMES[info["net"]], info["index"])
             per_net[info["net"]].append(((info["n_in"], info["n_out"]),
@@ -224,9 +237,11 @@ class PhysicsVAE(nn.Module):
             vws = [v for _, v in per_net[net]]
             return FC(dims, views=vws, **kw)
 
-        # registration order fixes the state_dict order: TE, MD, WM, VB (rmt:638-699)
+        # registration order fixes the state_dict order: [prior,] TE, MD, WM, VB (rmt:627-699)
+        self._latent_prior = build(NET_PR) if learned_prior else None
         self._task_encoder = build(NET_TE)
-        self._motor_decoder = build(NET_MD, append_log_std=True, sample_std=cfg["sample_std"])
+        self._motor_decoder = build(NET_MD, append_log_std=True, sample_std=cfg["sample_std"],
+                                    log_std_type=cfg["log_std_type"], device=self.engine.device)
         self._world_model = build(NET_WM)
         vb_dims, prev = [], self.dim_state
         for _ in range(vb[1]):
@@ -236,10 +251,14 @@ class PhysicsVAE(nn.Module):
         self._value_branch = FC(vb_dims).to(self.engine.device)
 
         self._cur_value = None
+        self._lazy, self._mu, self._logvar = None, None, None
+        self._graphs = {}                        # (rows, noise) -> GraphedInfer of the rollout forward
         self._cur_task_encoder_variable = None
         self._cur_body_encoder_variable = None
         self._cur_task_encoder_mu = None
         self._cur_task_encoder_logvar = None
+        self._cur_latent_prior_mu = None
+        self._cur_latent_prior_logvar = None
         self._cur_future_state = None
         self.latent_prior_noise = True
         self._rng_seed, self._rng_calls = 0, 0
@@ -295,8 +314,46 @@ class PhysicsVAE(nn.Module):
         out, st = self.forward(d, state or [], seq_lens)
         return out, st
 
+    # rollout batches (the 30 Hz control loop calls forward at B = 1, envs/rllib_env_imitation.py:215-266):
+    # up to this many rows the whole forward is ONE replayed HIP graph (HipEngine.graphed_infer)
+    GRAPH_ROWS = 4
+
     def forward(self, input_dict, state, seq_lens, eps=None):
+        """rmt:742-771.  One library call for the whole chain (stage -> TE -> sampler -> MD -> WM,
+        `pvae_infer`); at <= GRAPH_ROWS rows that call is a captured HIP graph, replayed.  The encoder's
+        mu / logvar and the value estimate are produced on demand (`_cur_task_encoder_mu`,
+        `value_function()`): the rollout loop reads neither."""
         obs = input_dict["obs_flat"].float()
+        eng = self.engine
+        if obs.dim() != 2 or obs.shape[0] > eng.max_batch or self._latent_prior is not None or eng.lookahead != 1:
+            return self._forward_staged(obs, state, seq_lens, eps)
+        rows = obs.shape[0]
+        obs = obs.to(eng.device)
+        noise = bool(self.latent_prior_noise)
+        self._rng_calls += 1
+        if rows <= self.GRAPH_ROWS and (eps is not None or not noise):
+            key = (rows, noise)
+            gi = self._graphs.get(key)
+            if gi is None:
+                gi = self._graphs[key] = eng.graphed_infer(rows, want_s2=True, noise=noise)
+            a_hat, s2, z = gi(obs, eps=eps if noise else None)
+        else:                                      # on-chip Philox draws are keyed per call: not replayable
+            a_hat, s2, z = eng.infer(obs, eps=eps if noise else None, noise=noise, seed=self._rng_seed,
+                                     offset=self._rng_calls, want_s2=True)
+        logits = self._motor_decoder._model[-1](a_hat)
+        self._cur_future_state = s2
+        self._cur_body_encoder_variable = obs[..., : self.dim_state_body]
+        self._cur_task_encoder_variable = z
+        self._lazy = (obs, rows)                   # mu / logvar / value: computed when somebody asks
+        self._mu = self._logvar = self._cur_value = None
+        self._cur_latent_prior_mu = (eng.read("eps", rows) if self._latent_prior_type == "hypersphere_uniform"
+                                     else None)                # rmt:813-814: the unit prior sample of this forward
+        return logits, state
+
+    def _forward_staged(self, obs, state, seq_lens, eps=None):
+        """The same forward stage by stage (forward_encoder / forward_decoder / forward_world): batches
+        beyond the engine's panel size, the learned-prior configuration, lookahead engines."""
+        self._lazy = None
         z_body, z_task, _ = self.forward_encoder(obs, state, seq_lens, 0, eps=eps)
         logits, _ = self.forward_decoder(z_body, z_task, state, seq_lens, 0)
         self._cur_future_state = self.forward_world(obs, logits)
@@ -306,12 +363,44 @@ class PhysicsVAE(nn.Module):
         self._cur_value = val.squeeze(1)
         return logits, state
 
+    def _encoder_stat(self, name):
+        """mu / logvar of the last fused forward, read back from the engine's panels on first use."""
+        if getattr(self, "_lazy", None) is not None and self._mu is None:
+            rows = self._lazy[1]
+            self._mu = self.engine.read("z" if self._latent_prior_type == "hypersphere_uniform" else "mu", rows)
+            self._logvar = None if self._latent_prior_type == "hypersphere_uniform" else self.engine.read("logvar", rows)
+        return self._mu if name == "mu" else self._logvar
+
+    @property
+    def _cur_task_encoder_mu(self):
+        return self._encoder_stat("mu")
+
+    @_cur_task_encoder_mu.setter
+    def _cur_task_encoder_mu(self, v):
+        self._mu = v
+
+    @property
+    def _cur_task_encoder_logvar(self):
+        return self._encoder_stat("logvar")
+
+    @_cur_task_encoder_logvar.setter
+    def _cur_task_encoder_logvar(self, v):
+        self._logvar = v
+
     def forward_encoder(self, obs, state=None, seq_lens=None, state_cnt=0, eps=None):
         Z = self._task_encoder_output_dim
         obs = obs.to(self.engine.device)
         h = self.engine.net_forward(NET_TE, obs)
+        if self._latent_prior_type == "hypersphere_uniform":        # rmt:810-814 (z = mu: oracle PRIORS)
+            z_task = self._reparameterize(h, eps)                   # e / |e|; the unit prior sample lands in "eps"
+            self._cur_task_encoder_mu, self._cur_task_encoder_logvar = z_task, None
+            self._cur_latent_prior_mu = self.engine.read("eps", h.shape[0])
+            return obs[..., : self.dim_state_body], z_task, state_cnt
         self._cur_task_encoder_mu, self._cur_task_encoder_logvar = h[:, :Z], h[:, Z:]
         z_task = self._reparameterize(h, eps)
+        if self._latent_prior is not None:                          # rmt:801-809
+            self._cur_latent_prior_mu = self.engine.net_forward(NET_PR, obs[..., : self.dim_state_body].contiguous())
+            self._cur_latent_prior_logvar = torch.zeros_like(self._cur_latent_prior_mu)
         return obs[..., : self.dim_state_body], z_task, state_cnt
 
     def _reparameterize(self, mu_logvar, eps=None):
@@ -334,6 +423,9 @@ class PhysicsVAE(nn.Module):
             return self._value_branch(obs.to(self.engine.device).float()), state_cnt
 
     def value_function(self):
+        if self._cur_value is None and getattr(self, "_lazy", None) is not None:
+            val, _ = self.forward_value_branch(self._lazy[0])      # deferred by the fused forward
+            self._cur_value = val.squeeze(1)
         assert self._cur_value is not None, "must call forward() first"
         return self._cur_value
 
@@ -383,27 +475,37 @@ class PhysicsVAE(nn.Module):
         self._world_model.load_state_dict(torch.load(file, map_location="cpu"))
         self._world_model.eval()
 
-    def save_weights_latent_prior(self, file):
-        pass                                     # no learnable prior (see __init__)
+    def save_weights_latent_prior(self, file):                       # rmt:921-923
+        if self._latent_prior is not None:
+            torch.save(_portable(self._latent_prior.state_dict()), file)
 
-    def load_weights_latent_prior(self, file):
-        pass
+    def load_weights_latent_prior(self, file):                       # rmt:925-928
+        if self._latent_prior is not None:
+            self._latent_prior.load_state_dict(torch.load(file, map_location="cpu"))
+            self._latent_prior.eval()
 
     # -- freezing (rmt:930-950) -----------------------------------------------------------
     def set_learnable_task_encoder(self, learnable):
         for p in self._task_encoder.parameters():
             p.requires_grad = learnable
 
-    def set_learnable_motor_decoder(self, learnable, free_log_std=True):
-        for p in self._motor_decoder.parameters():
-            p.requires_grad = learnable
+    def set_learnable_motor_decoder(self, learnable, free_log_std=True):       # rmt:936-941
+        for name, p in self._motor_decoder.named_parameters():
+            p.requires_grad = free_log_std if "log_std" in name else learnable
 
     def set_learnable_world_model(self, learnable):
         for p in self._world_model.parameters():
             p.requires_grad = learnable
 
+    def set_learnable_latent_prior(self, learnable):
+        """Ours (rmt:930-950 has no switch for it): the learned prior mean only ever receives gradient
+        through the KL term, i.e. together with the task encoder; the trainer flips both together."""
+        if self._latent_prior is not None:
+            for p in self._latent_prior.parameters():
+                p.requires_grad = learnable
+
     def learnable_nets(self):
-        def on(m):
-            return all(p.requires_grad for p in m.parameters())
+        def on(m):      # (a state_independent log_std follows `free_log_std`, not the stack: rmt:939-941)
+            return m is not None and all(p.requires_grad for n, p in m.named_parameters() if "log_std" not in n)
         return [n for n, m in ((NET_TE, self._task_encoder), (NET_MD, self._motor_decoder),
-                               (NET_WM, self._world_model)) if on(m)]
+                               (NET_WM, self._world_model), (NET_PR, self._latent_prior)) if on(m)]

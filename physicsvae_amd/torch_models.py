@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from . import parallel, tune
-from ._lib import NET_MD, NET_TE, NET_WM, PHASE_JOINT, PHASE_WORLD
+from ._lib import NET_MD, NET_PR, NET_TE, NET_WM, PHASE_JOINT, PHASE_WORLD
 
 EPSILON = np.finfo(np.float32).eps
 
@@ -133,7 +133,7 @@ class HipAdam(optim.Optimizer):
             raise NotImplementedError("weight_decay != 0 (the trainer uses 0.0, tpv:253)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.engine = engine
-        self.net_steps = {NET_TE: 0, NET_MD: 0, NET_WM: 0}
+        self.net_steps = {NET_TE: 0, NET_MD: 0, NET_WM: 0, NET_PR: 0}
 
     @property
     def lr(self):
@@ -143,7 +143,7 @@ class HipAdam(optim.Optimizer):
         """Advance and return adam_t for the nets updated by the coming step."""
         for n in nets:
             self.net_steps[n] += 1
-        return [max(self.net_steps[n], 1) for n in (NET_TE, NET_MD, NET_WM)]
+        return [max(self.net_steps[n], 1) for n in (NET_TE, NET_MD, NET_WM, NET_PR)]
 
     def step(self, closure=None):
         # the update itself is issued by TrainModel (fused or after the all-reduce)
@@ -171,6 +171,11 @@ class TrainModel(tune.Trainable):
         self.dp.attach(self.engine)
         if self.engine.has_comm and ("dp_bucket_mb" in config or "PVAE_DP_BUCKET_MB" in os.environ):
             self.engine.comm_config(self.dp_bucket_mb)
+        # sharded exchange (default off): reduce-scatter -> Adam on the owned 1/N slice -> all-gather of the
+        # parameters (include/pvae.h PVAE_EXCHANGE_SHARDED); every rank must choose the same
+        self.dp_sharded = bool(config.get("dp_sharded", os.environ.get("PVAE_DP_SHARDED", "0") == "1"))
+        if self.engine.has_comm:
+            self.engine.comm_mode(self.dp_sharded)
         self.prefetch_gather = bool(config.get("prefetch_gather", os.environ.get("PVAE_PREFETCH", "1") != "0"))
         self.prepare_data(config)
         self.optimizer = HipAdam(self.model.parameters(), self.engine,
@@ -210,7 +215,7 @@ class TrainModel(tune.Trainable):
         nets = self.model.learnable_nets()
         if nets == [NET_WM]:
             return PHASE_WORLD, nets
-        if nets == [NET_TE, NET_MD]:
+        if nets in ([NET_TE, NET_MD], [NET_TE, NET_MD, NET_PR]):     # (+ the learned prior mean, when configured)
             return PHASE_JOINT, nets
         raise NotImplementedError("learnable nets %s: the trainer only uses {WM} or {TE, MD}" % nets)
 
@@ -281,7 +286,8 @@ class TrainModel(tune.Trainable):
             seg = eng.segment(eng.grads, nets)
             seg.zero_()
             dp.all_reduce(seg)
-            eng.adam(nets, sp)
+            for net in nets:
+                self._apply_update(net, eng.segments[net][0], eng.segments[net][1], sp)
             return
         limit = int(self.dp_bucket_mb * (1 << 20) / 4) if self.dp_bucket_mb > 0 else None
         eng.gather(first, rows)
@@ -310,7 +316,23 @@ class TrainModel(tune.Trainable):
         for net, off, cnt, work in pending:
             if work is not None:
                 work.wait()
+            self._apply_update(net, off, cnt, sp)
+
+    def _apply_update(self, net, off, cnt, sp):
+        """Adam on a reduced slice [off, off+cnt) of the gradient arena.  Sharded exchange over
+        torch.distributed: this rank updates only its 1/N of the slice and the updated parameters are
+        all-gathered (the gradient itself was all-reduced: this transport has no stream-ordered
+        reduce-scatter on every backend; the in-library RCCL path does the true reduce-scatter)."""
+        eng, dp = self.engine, self.dp
+        if not (self.dp_sharded and dp.world > 1 and cnt % (dp.world * 4) == 0):
             eng.adam_segment(net, off, cnt, sp)
+            return
+        import torch.distributed as dist
+        sl = cnt // dp.world
+        mine = off + dp.rank * sl
+        eng.adam_segment(net, mine, sl, sp)
+        outs = [eng.params[off + r * sl: off + (r + 1) * sl] for r in range(dp.world)]
+        dist.all_gather(outs, outs[dp.rank].clone(), group=dp.group)
 
     # -- overridables, reference names ----------------------------------------------------
     def load_dataset(self, file):
@@ -331,21 +353,66 @@ class TrainModel(tune.Trainable):
     def create_model(self, config):
         return config.get("model")
 
-    def compute_model(self, x):
-        raise NotImplementedError
+    def compute_model(self, x):                   # tm:198-199
+        return self.model(x)
 
-    def compute_loss(self, y, x):
-        raise NotImplementedError
+    def compute_loss(self, y, x):                 # tm:201-203
+        y_recon = self.compute_model(x)
+        return self.loss_fn(y_recon, y)
 
-    def compute_test_loss(self, y, x):
-        return self.compute_loss(y, x)
+    def compute_test_loss(self, y, x):            # tm:205-207
+        y_recon = self.compute_model(x)
+        return self.loss_fn(y_recon, y)
 
     def save_checkpoint(self, checkpoint_dir):
         print(checkpoint_dir)
         path = os.path.join(checkpoint_dir, "model.pth")
         torch.save(self.model.portable_state_dict(), path)
+        if self.config_flag("save_trainer_state"):        # ours, opt-in: the directory otherwise holds exactly
+            self.save_trainer_state(os.path.join(checkpoint_dir, "trainer_state.pt"))   # the reference's files
         return path
 
     def load_checkpoint(self, checkpoint_path):
-        # weights only -- optimizer, scheduler, iter are not restored (tm:215-216, App. C-7)
+        # weights only -- optimizer, scheduler, iter are not restored (tm:215-216, App. C-7), unless the
+        # config asks for it with "resume_trainer_state" (ours) and the checkpoint directory has the file
         self.model.load_state_dict(torch.load(checkpoint_path, map_location="cpu"))
+        extra = os.path.join(os.path.dirname(checkpoint_path), "trainer_state.pt")
+        if self.config_flag("resume_trainer_state") and os.path.exists(extra):
+            self.load_trainer_state(extra)
+
+    def config_flag(self, name):
+        return bool(getattr(self, "config", {}).get(name, False))
+
+    # -- ours: everything a bit-exact resume needs beyond the weights -----------------
+    def save_trainer_state(self, path):
+        """Adam moments (checkpoint key naming, CPU), per-stack Adam step counts, epoch counter, minibatch
+        counter (keys the eps / Philox stream) and the lr scheduler.  Not written under the sharded
+        exchange: there every rank holds valid moments for its own slices only."""
+        if getattr(self, "dp_sharded", False) and self.dp.world > 1:
+            return None
+        mom = self.optimizer.moments()
+        state = {
+            "exp_avg": {k: m.detach().cpu().contiguous().clone() for k, (m, _) in mom.items()},
+            "exp_avg_sq": {k: v.detach().cpu().contiguous().clone() for k, (_, v) in mom.items()},
+            "net_steps": dict(self.optimizer.net_steps), "iter": self.iter, "global_batch": self.global_batch,
+            "training_iteration": self.training_iteration, "lr": self.optimizer.lr,
+            "lr_scheduler": self.lr_scheduler.state_dict() if self.lr_scheduler else None,
+            "learnable_nets": self.model.learnable_nets(),
+        }
+        torch.save(state, path)
+        return path
+
+    def load_trainer_state(self, path):
+        state = torch.load(path, map_location="cpu")
+        mom = self.optimizer.moments()
+        with torch.no_grad():
+            for k, (m, v) in mom.items():
+                m.copy_(state["exp_avg"][k])
+                v.copy_(state["exp_avg_sq"][k])
+        self.optimizer.net_steps.update(state["net_steps"])
+        self.iter, self.global_batch = int(state["iter"]), int(state["global_batch"])
+        self._iteration = int(state.get("training_iteration", self._iteration))
+        if self.lr_scheduler and state.get("lr_scheduler"):
+            self.lr_scheduler.load_state_dict(state["lr_scheduler"])
+        self.optimizer.param_groups[0]["lr"] = state["lr"]
+        return state

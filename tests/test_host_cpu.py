@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pvae_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.pvae_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_layout_queries_without_gpu():
@@ -258,7 +258,7 @@ def test_phase_machine_and_adam_counters():
     assert tr.phase() == (_lib.PHASE_WORLD, [_lib.NET_WM])
     assert (tr.s_rec_coeff, tr.a_rec_coeff, tr.vae_kl_coeff, tr.vae_cycle_coeff) == (1.0, 0.0, 0.0, 0.0)
     sp = tr.step_params([_lib.NET_WM], 8, True)
-    assert list(sp.adam_t) == [1, 1, 1] and tr.optimizer.net_steps[_lib.NET_WM] == 1
+    assert list(sp.adam_t)[:3] == [1, 1, 1] and tr.optimizer.net_steps[_lib.NET_WM] == 1
     tr.iter = 2                                   # as if two world epochs had run
     tr.model.set_learnable_task_encoder(True)
     tr.model.set_learnable_motor_decoder(True)
@@ -267,9 +267,9 @@ def test_phase_machine_and_adam_counters():
     assert tr.phase() == (_lib.PHASE_JOINT, [_lib.NET_TE, _lib.NET_MD])
     assert (tr.s_rec_coeff, tr.a_rec_coeff, tr.vae_kl_coeff, tr.vae_cycle_coeff) == (0.0, 1.0, 1.0, 1e-3)
     sp = tr.step_params([_lib.NET_TE, _lib.NET_MD], 8, True)
-    assert list(sp.adam_t) == [1, 1, 1]           # TE/MD start at t = 1, WM stays where it was
+    assert list(sp.adam_t)[:3] == [1, 1, 1]       # TE/MD start at t = 1, WM stays where it was
     sp = tr.step_params([_lib.NET_TE, _lib.NET_MD], 8, True)
-    assert list(sp.adam_t) == [2, 2, 1]
+    assert list(sp.adam_t)[:3] == [2, 2, 1]
     # StepLR drives HipAdam through param_groups, once per epoch
     sched = TM.get_lr_scheduler(tr.optimizer, "step", {"step_size": 2, "gamma": 0.7})
     lrs = []
@@ -285,7 +285,7 @@ def test_unsupported_configs_are_refused():
     data = R.synth_demo(0, 2, 14, 7, 3)
     arch = R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2))
     with pytest.raises(NotImplementedError):
-        make_trainer(arch, data, 8, device="cpu", extra={"latent_prior_type": "hypersphere_uniform"})
+        make_trainer(arch, data, 8, device="cpu", extra={"latent_prior_type": "von_mises_fisher"})     # rmt:624-625
     with pytest.raises(NotImplementedError):
         make_trainer(arch, data, 8, device="cpu", extra={"loss": "CrossEntropy"})
     assert make_trainer(arch, data, 8, device="cpu", extra={"loss": "L1"}).loss_name == "L1"
@@ -570,3 +570,46 @@ def test_module_identity_moves_on_cpu():
     assert m.to("cpu") is m and m.float() is m and m.cpu() is m
     with pytest.raises(RuntimeError):
         m.double()
+
+
+# ------------------------------------------------------------------------------------------
+# latent priors other than N(0, I) (specified in oracle/refpath.py: the reference crashes on them)
+# ------------------------------------------------------------------------------------------
+def test_prior_kinds_layout_and_state_dict():
+    lib = _lib.load()
+    base = (7, 3, 4, 16, 2, 24, 2, 32, 2, 8, 1)
+    n0 = lib.pvae_num_layers(C.byref(_lib.Config(*base, 0, 0, 0)))
+    assert lib.pvae_num_layers(C.byref(_lib.Config(*base, 1, 12, 1))) == n0 + 2          # + prior stack 7 -> 12 -> 4
+    assert lib.pvae_num_layers(C.byref(_lib.Config(*base, 2, 0, 0))) == n0
+    assert lib.pvae_num_layers(C.byref(_lib.Config(*base, 3, 0, 0))) < 0                 # unknown kind
+    assert lib.pvae_num_layers(C.byref(_lib.Config(7, 3, 4, 16, 2, 24, 2, 32, 2, 8, 2, 1, 12, 1))) < 0   # needs lookahead 1
+    assert b"lookahead" in lib.pvae_last_error()
+    # arena order TE | MD | PR | WM, densely packed; the hypersphere encoder emits Z values, not 2Z
+    cfg = _lib.Config(*base, 1, 12, 1)
+    info, end, nets = _lib.LayerInfo(), 0, []
+    for i in range(n0 + 2):
+        assert lib.pvae_layer(C.byref(cfg), i, C.byref(info)) == 0
+        assert info.w_offset == end
+        end = info.b_offset + info.n_out_pad
+        nets.append(info.net)
+    assert nets == [0] * 3 + [1] * 3 + [3] * 2 + [2] * 3
+    cfg2 = _lib.Config(*base, 2, 0, 0)
+    assert lib.pvae_layer(C.byref(cfg2), 2, C.byref(info)) == 0 and (info.net, info.n_out) == (0, 4)
+    data = R.synth_demo(0, 2, 14, 7, 3)
+    for prior in R.PRIORS[1:]:
+        arch = R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2), prior=prior, pr=(12, 1))
+        tr = make_trainer(arch, data, 8, device="cpu")
+        sd = tr.model.state_dict()
+        assert [(k, tuple(v.shape)) for k, v in sd.items()] == R.state_dict_spec(arch)
+        # the reference-shaped state dict round-trips through the arena views
+        ref_sd = R.perturb_biases(R.init_state_dict(arch, 1), 3)
+        tr.model.load_state_dict(ref_sd)
+        for k, v in tr.model.state_dict().items():
+            assert torch.equal(v.cpu(), ref_sd[k]), k
+        # phase machine: the learned prior follows the encoder
+        want_joint = [_lib.NET_TE, _lib.NET_MD] + ([_lib.NET_PR] if prior == R.PRIORS[1] else [])
+        assert tr.phase() == (_lib.PHASE_WORLD, [_lib.NET_WM])
+        tr.iter = tr.max_iter_world_model = 0
+        tr.model.set_learnable_task_encoder(True); tr.model.set_learnable_motor_decoder(True)
+        tr.model.set_learnable_world_model(False); tr.model.set_learnable_latent_prior(True)
+        assert tr.phase() == (_lib.PHASE_JOINT, want_joint)
