@@ -28,7 +28,8 @@ def short(n):
 def main(src, dst):
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     out = collections.defaultdict(dict)
-    stats = list(csv.DictReader(open(src + "_trace/t_kernel_stats.csv")))
+    import glob
+    stats = list(csv.DictReader(open(glob.glob(src + "_trace/**/*kernel_stats.csv", recursive=True)[0])))
     for r in stats:
         k = short(r["Name"])
         if k.startswith(("void at::", "__amd", "at::")):
@@ -37,9 +38,10 @@ def main(src, dst):
                       min_us=float(r["MinNs"]) / 1e3, max_us=float(r["MaxNs"]) / 1e3,
                       pct_of_gpu_time=float(r["Percentage"]))
     for tag, f in (("fetch", "_fetch/f"), ("write", "_write/w"), ("mfma", "_mfma/m"), ("lds", "_lds/l")):
-        path = src + f + "_counter_collection.csv"
-        if not os.path.exists(path):
+        found = glob.glob(src + f.split("/")[0] + "/**/*counter_collection.csv", recursive=True)
+        if not found:
             continue
+        path = found[0]
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(path)):
             agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -59,6 +61,9 @@ def main(src, dst):
             per_simd = d["SQ_VALU_MFMA_BUSY_CYCLES_median_per_launch"] / 1024.0
             d["mfma_busy_cycles_per_simd"] = per_simd
             d["mfma_util_at_2.4GHz"] = per_simd / (d["avg_us"] * 1e-6 * 2.4e9)
+            if d.get("GRBM_GUI_ACTIVE_median_per_launch"):
+                d["clock_ghz"] = d["GRBM_GUI_ACTIVE_median_per_launch"] / (d["avg_us"] * 1e3)
+                d["mfma_busy_of_active_cycles"] = per_simd / d["GRBM_GUI_ACTIVE_median_per_launch"]
         if "SQ_LDS_BANK_CONFLICT_median_per_launch" in d and d.get("SQ_LDS_IDX_ACTIVE_median_per_launch"):
             d["lds_conflict_frac"] = d["SQ_LDS_BANK_CONFLICT_median_per_launch"] / d["SQ_LDS_IDX_ACTIVE_median_per_launch"]
     json.dump(out, open(dst + "_summary.json", "w"), indent=1, sort_keys=True)
