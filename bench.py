@@ -165,7 +165,7 @@ def rocprof_passes(a, phase, budget_s=150):
     passes = [("trace", ["--kernel-trace", "--stats"]),
               ("fetch", ["--pmc", "FETCH_SIZE", "--kernel-trace"]),
               ("write", ["--pmc", "WRITE_SIZE", "--kernel-trace"]),
-              ("mfma", ["--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "--kernel-trace"])]
+              ("mfma", ["--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "--kernel-trace"])]
     out, t_end, notes = {}, time.time() + budget_s, []
     for tag, flags in passes:
         left = t_end - time.time()
@@ -219,14 +219,9 @@ def rocprof_passes(a, phase, budget_s=150):
             r["hbm_fetch_bytes"] = e["FETCH_SIZE"] * 1024 * 2
         if "WRITE_SIZE" in e:
             r["hbm_write_bytes"] = e["WRITE_SIZE"] * 1024
-        if "GRBM_GUI_ACTIVE" in e and r.get("avg_us"):
-            # GPU-active cycles of the launch / its duration = the clock the chip actually ran at (DVFS)
-            r["clock_ghz"] = e["GRBM_GUI_ACTIVE"] / (r["avg_us"] * 1e3)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in e and r.get("avg_us"):
             # busy cycles summed over the 1024 SIMDs; launch duration at the 2.4 GHz peak clock
             r["mfma_busy"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (r["avg_us"] * 1e-6 * 2.4e9)
-            if e.get("GRBM_GUI_ACTIVE"):
-                r["mfma_busy_of_active_cycles"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / e["GRBM_GUI_ACTIVE"]
         res[c] = r
     if notes:
         res["notes"] = notes
@@ -469,7 +464,7 @@ def main():
                 "avg_launch_us": us_ev, "avg_launch_us_rocprof": us_rp,
                 "frac_hip_events": d["per_launch"] / (us_ev * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                 "frac_rocprof": (d["per_launch"] / (us_rp * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS) if us_rp else None,
-                "mfma_busy": r.get("mfma_busy"), "clock_ghz": r.get("clock_ghz"),
+                "mfma_busy": r.get("mfma_busy"),
                 "algorithmic_gflop_per_launch": d["per_launch"] / 1e9,
                 "launches_per_step": d["launches"] / n_prof}
         kernels = {}
@@ -477,7 +472,7 @@ def main():
             k = {"launches_per_step": v["launches"] / n_prof, "avg_us": v["avg_us"],
                  "algo_gflop_per_launch": v["per_launch"] / 1e9,
                  "tflops": v["per_launch"] / (v["avg_us"] * 1e-6) / 1e12}
-            for key in ("avg_us", "hbm_fetch_bytes", "hbm_write_bytes", "mfma_busy", "clock_ghz", "mfma_busy_of_active_cycles"):
+            for key in ("avg_us", "hbm_fetch_bytes", "hbm_write_bytes", "mfma_busy"):
                 if key in (rp or {}).get(c, {}):
                     k["rocprof_" + key] = rp[c][key]
             kernels[CAT_NAMES[c]] = k

@@ -146,6 +146,13 @@ int pvae_bind_workspace(pvae_ctx* ctx, void* workspace, size_t bytes);
  * (tpv:117-164) and DatasetBase.__getitem__ (tm:52-56). */
 int pvae_bind_dataset(pvae_ctx* ctx, const float* states, const float* actions,
                       const int32_t* window_row, int64_t n_rows, int64_t n_windows);
+/* Optional, after pvae_bind_dataset: `next_states` [n_rows][Db] fp32, row-aligned with `states`; row r
+ * holds what follows state r in a window -- the second half of x and the state-reconstruction target
+ * are then read from next_states[row] instead of states[row + 1].  This is how cond = "rel" of
+ * load_dataset_for_PhysicsVAE (tpv:149-150: x = [s_t | s_{t+1} - s_t]) reaches the gather kernel: the
+ * differences are formed once in float64 on the host, as the reference does.  NULL restores the
+ * default; a new pvae_bind_dataset resets it. */
+int pvae_bind_dataset_next(pvae_ctx* ctx, const float* next_states);
 
 /* ---- hot path ------------------------------------------------------------------------ */
 /* Minibatch gather: windows [first_window, first_window+rows) -> network input panels.

@@ -324,6 +324,30 @@ def case_ingest(name, arch):
     print("wrote", name, {k: int(v) for k, v in fix.items() if k.endswith(("n_windows", "n_batches", "last_batch_size"))})
 
 
+def case_ingest_rel(name, arch):
+    """`load_dataset_for_PhysicsVAE(cond="rel")` of the reference itself (tpv:149-150: the second half of
+    x is s_{t+1} - s_t; the trainer never asks for it, so it is called directly): digests of the whole X / Y
+    and of the first and last windows as the reference's DatasetBase yields them, lookahead 1 and 2."""
+    data = R.synth_demo(seed=3, n_episodes=3, n_steps=12, dim_body=arch["Db"], dim_action=arch["Da"], kind="iid",
+                        quantum=0.0)                      # un-rounded values: the float64 subtraction matters
+    fix = {}
+    with tempfile.TemporaryDirectory() as td:
+        p1 = os.path.join(td, "a.pkl")
+        R.write_demo(p1, data)
+        for L in (1, 2):
+            ds = T.load_dataset_for_PhysicsVAE([p1], lookahead=L, cond="rel")
+            fix["L%d_n_windows" % L] = np.array(len(ds))
+            fix["L%d_X_digest" % L] = R.tensor_digest(torch.from_numpy(np.asarray(ds.X)))
+            fix["L%d_Y_digest" % L] = R.tensor_digest(torch.from_numpy(np.asarray(ds.Y)))
+            for i, nm in ((0, "first"), (len(ds) - 1, "last")):
+                x, y = ds[i]
+                fix["L%d_%s_x" % (L, nm)] = x.numpy()
+                fix["L%d_%s_y" % (L, nm)] = y.numpy()
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"]])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
+    print("wrote", name, {k: int(v) for k, v in fix.items() if k.endswith("n_windows")})
+
+
 def case_checkpoint_interop(name, arch):
     """Both directions of the checkpoint drop-in, with the REFERENCE's own classes:
     (a) the five files written by the reference's save_checkpoint are stored byte for byte (data
@@ -404,6 +428,7 @@ def main():
                                           full=False),
         "anchor_c1": lambda: case_anchor("anchor_c1"),
         "ingest_tiny": lambda: case_ingest("ingest_tiny", tiny),
+        "ingest_rel_tiny": lambda: case_ingest_rel("ingest_rel_tiny", tiny),
         "ckpt_interop_tiny": lambda: case_checkpoint_interop("ckpt_interop_tiny", tiny),
         "look3_tiny": lambda: case_lookahead("look3_tiny", tiny, 2, 15, 8, lookahead=3, full=True),
         "look2_c1": lambda: case_lookahead("look2_c1", c1, 2, 200, 64, lookahead=2, full=False),

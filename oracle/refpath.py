@@ -227,11 +227,12 @@ def merge_demo_files(files):
     return merged
 
 
-def build_windows(data, lookahead=1, num_samples=None):
-    """tpv:117-164 with cond="abs", use_a_gt=False.  Returns float64
-    X[N, L, 2*Db] = [sb[i+j] | sb[i+j+1]], Y[N, L, Da] = a[i+j]; episode order, i ascending;
-    the `num_samples` cap stops at exactly that many windows (tpv:137-138)."""
-    assert lookahead >= 1
+def build_windows(data, lookahead=1, num_samples=None, cond="abs"):
+    """tpv:117-164 with use_a_gt=False.  Returns float64
+    X[N, L, 2*Db] = [sb[i+j] | sb[i+j+1]] (cond "abs") or [sb[i+j] | sb[i+j+1] - sb[i+j]] (cond "rel",
+    tpv:149-150), Y[N, L, Da] = a[i+j]; episode order, i ascending; the `num_samples` cap stops at
+    exactly that many windows (tpv:137-138)."""
+    assert lookahead >= 1 and cond in ("abs", "rel")
     X, Y = [], []
     for ep in data["episodes"]:
         T = len(ep["time"])
@@ -239,7 +240,8 @@ def build_windows(data, lookahead=1, num_samples=None):
         for i in range(T - lookahead):
             if num_samples is not None and len(X) >= num_samples:
                 break
-            X.append(np.vstack([np.hstack([ep["state_body"][i + j], ep["state_body"][i + j + 1]])
+            X.append(np.vstack([np.hstack([ep["state_body"][i + j],
+                                           ep["state_body"][i + j + 1] - (ep["state_body"][i + j] if cond == "rel" else 0.0)])
                                 for j in range(lookahead)]))
             Y.append(np.vstack([ep["action"][i + j] for j in range(lookahead)]))
     return np.array(X), np.array(Y)

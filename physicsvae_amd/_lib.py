@@ -69,6 +69,7 @@ _SIGS = {
     "pvae_bind_arenas": (C.c_int, [_P, _P, _P, _P, _P]),
     "pvae_bind_workspace": (C.c_int, [_P, _P, C.c_size_t]),
     "pvae_bind_dataset": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64]),
+    "pvae_bind_dataset_next": (C.c_int, [_P, _P]),
     "pvae_invalidate_staging": (C.c_int, [_P]),
     "pvae_gather": (C.c_int, [_P, C.c_int64, C.c_int32, _P]),
     "pvae_set_batch": (C.c_int, [_P, _P, _P, C.c_int32, _P]),

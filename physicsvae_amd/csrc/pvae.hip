@@ -164,6 +164,7 @@ struct pvae_ctx {
     float* v = nullptr;
     float* ws = nullptr;
     const float* states = nullptr;
+    const float* next_states = nullptr;      // pvae_bind_dataset_next (null: next row of `states`)
     const float* actions = nullptr;
     const int32_t* window_row = nullptr;
     int64_t n_rows = 0, n_windows = 0;
@@ -539,6 +540,86 @@ gemv_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__
             if (relu) v = fmaxf(v, 0.f);
             out[(size_t)r * ldo + n] = v;
             if (out2 && n < n2) out2[(size_t)r * ld2 + off2 + n] = v;
+        }
+    }
+}
+
+// Rollout forward with fewer launches (pvae_infer at <= 4 rows): the layer kernel assembles its R input
+// rows in LDS itself, so the staging launch, the sampler launch and the copy-out launches disappear --
+// 7 launches for observation -> action (TE 3, MD 4 at the trainer's default sizes) instead of 9, 10 with
+// the world model's prediction instead of 14.  The input of a layer is
+//   kind 0: rows of a padded activation panel (hidden layers)
+//   kind 1: the caller's dense observation rows obs[r][0:Ka]                       (first encoder layer)
+//   kind 2: [obs[r][0:Ka] | z_r],  z = mu + eps * exp(logvar / 2) from the encoder's output   (first decoder layer:
+//           the sampler of rmt:734-740 runs here; workgroup 0 also records z and the draws)
+//   kind 3: [obs[r][0:Ka] | src_b[r][0:Kb]]                                        (first world-model layer: a_hat)
+// One wave per output feature streams its weight row once (as gemv_rows_kernel); rows >= `rows` of the
+// R-row template are computed on zeros and never stored.
+struct RolloutIn {
+    int kind;
+    const float* a; int lda, Ka;      // panel (kind 0: Ka = padded width) or dense observation
+    const float* b; int ldb, Kb;      // kind 2: encoder output [mu | logvar] (Kb = Z); kind 3: second source
+    const float* eps; int noise;      // kind 2: supplied draws [rows][Z] or null (Philox) / noise off
+    unsigned long long seed, offset;
+    float* z_out; float* eps_used;    // kind 2, written by workgroup 0 (z_out may be null)
+};
+template <int R>
+__global__ void __launch_bounds__(256)
+gemv_rollout_kernel(RolloutIn in, int rows, const float* __restrict__ W, int ldw, const float* __restrict__ bias,
+                    float* __restrict__ out, int ldo, int K, int relu, float* __restrict__ out2, int ld2, int n2) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];         // [R][K], K = ld of the layer (multiple of 64)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < R * K; i += 256) {
+        const int r = i / K, k = i - r * K;
+        float v = 0.f;
+        if (r < rows) {
+            if (in.kind == 0) {
+                v = in.a[(size_t)r * in.lda + k];
+            } else if (k < in.Ka) {
+                v = in.a[(size_t)r * in.lda + k];
+            } else if (k < in.Ka + in.Kb) {
+                const int j = k - in.Ka;
+                if (in.kind == 2) {
+                    const float mu = in.b[(size_t)r * in.ldb + j], lv = in.b[(size_t)r * in.ldb + in.Kb + j];
+                    float e = 0.f;
+                    if (in.noise) e = in.eps ? in.eps[(size_t)r * in.Kb + j] : philox_normal(in.seed, in.offset, r, j);
+                    v = mu + e * expf(0.5f * lv);
+                    if (blockIdx.x == 0) {
+                        if (in.z_out) in.z_out[(size_t)r * in.Kb + j] = v;
+                        in.eps_used[(size_t)r * in.Kb + j] = e;
+                    }
+                } else if (in.kind == 3) {
+                    v = in.b[(size_t)r * in.ldb + j];
+                }
+            }
+        }
+        xs[i] = v;
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 4 + (tid >> 6);
+    const int lane = tid & 63;
+    const float* wrow = W + (size_t)n * ldw;
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const v4f wv = *reinterpret_cast<const v4f*>(wrow + k);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const v4f xv = *reinterpret_cast<const v4f*>(xs + r * K + k);
+            acc[r] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[r]))));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float v = acc[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0 && r < rows) {
+            v += bias[n];
+            if (relu) v = fmaxf(v, 0.f);
+            out[(size_t)r * ldo + n] = v;
+            if (out2 && n < n2) out2[(size_t)r * ld2 + n] = v;
         }
     }
 }
@@ -1020,8 +1101,17 @@ int pvae_bind_dataset(pvae_ctx* c, const float* states, const float* actions, co
     if (n_rows < 2 || n_windows < 1) return fail(-1, "empty dataset");
     if (n_rows > 2147483647ll) return fail(-1, "more than 2^31-1 rows");
     c->states = states; c->actions = actions; c->window_row = window_row;
+    c->next_states = nullptr;
     c->n_rows = n_rows; c->n_windows = n_windows;
     c->pf.valid = false;         // a minibatch gathered ahead came from the previous binding
+    return 0;
+}
+
+int pvae_bind_dataset_next(pvae_ctx* c, const float* next_states) {
+    if (!c) return fail(-1, "null ctx");
+    if (!c->states) return fail(-2, "dataset not bound");
+    c->next_states = next_states;
+    c->pf.valid = false;
     return 0;
 }
 
@@ -1035,6 +1125,7 @@ static StageArgs stage_args(const pvae_ctx* c, long long first_window, const flo
     StageArgs a;
     memset(&a, 0, sizeof(a));
     a.states = from_set ? c->states : nullptr;
+    a.next_states = from_set ? c->next_states : nullptr;
     a.actions = from_set ? c->actions : nullptr;
     a.window_row = from_set ? c->window_row : nullptr;
     a.first_window = first_window;
@@ -2050,6 +2141,57 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
     if (rc) return rc;
     if (!obs || !a_hat) return fail(-1, "obs / a_hat is null");
     hipStream_t st = (hipStream_t)stream;
+    if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
+    static const bool fused_rollout = [] { const char* e = getenv("PVAE_ROLLOUT_FUSED"); return !(e && e[0] == '0'); }();
+    if (rows <= 4 && fused_rollout && c->L.cfg.prior_kind != PVAE_PRIOR_HYPERSPHERE) {
+        // latency path of the control loop (rmt:742-771 at B = 1): no staging / sampler / copy launches, the
+        // input panels of a staged training minibatch are not touched
+        const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
+        float* w = c->ws;
+        c->staged_rows_f = rows;
+        auto run_net = [&](int n, RolloutIn first, float* out2, int ld2, int n2) -> int {
+            const NetLayout& N = c->L.net[n];
+            RolloutIn in = first;
+            for (const Layer& l : N.layers) {
+                float* out = w + c->W.net[n].act[l.index];
+                const dim3 grid(l.n_out_pad / 4), block(256);
+                const size_t shm = (size_t)(rows <= 1 ? 1 : rows == 2 ? 2 : 4) * l.ld * sizeof(float);
+                float* o2 = l.last ? out2 : nullptr;
+                const int ps = g_prof.begin(0, 2.0 * rows * l.n_in * l.n_out, st);
+#define PVAE_ROLL(R)                                                                                                  \
+    hipLaunchKernelGGL((gemv_rollout_kernel<R>), grid, block, shm, st, in, (int)rows, c->params + l.w_off, l.ld,      \
+                       c->params + l.b_off, out, l.n_out_pad, l.ld, l.last ? 0 : 1, o2, ld2, n2)
+                if (rows == 1) PVAE_ROLL(1);
+                else if (rows == 2) PVAE_ROLL(2);
+                else PVAE_ROLL(4);
+#undef PVAE_ROLL
+                g_prof.end(ps, st);
+                HIP_TRY(hipGetLastError());
+                memset(&in, 0, sizeof(in));
+                in.kind = 0; in.a = out; in.lda = l.n_out_pad; in.Ka = l.n_out_pad;
+            }
+            return 0;
+        };
+        RolloutIn te;
+        memset(&te, 0, sizeof(te));
+        te.kind = 1; te.a = obs; te.lda = 2 * Db; te.Ka = 2 * Db;
+        if ((rc = run_net(PVAE_NET_TE, te, nullptr, 0, 0))) return rc;
+        RolloutIn md;
+        memset(&md, 0, sizeof(md));
+        md.kind = 2; md.a = obs; md.lda = 2 * Db; md.Ka = Db;
+        md.b = w + c->W.net[PVAE_NET_TE].act.back(); md.ldb = c->L.net[PVAE_NET_TE].layers.back().n_out_pad; md.Kb = Z;
+        md.eps = eps; md.noise = noise ? 1 : 0; md.seed = rng_seed; md.offset = rng_offset;
+        md.z_out = z_out; md.eps_used = w + c->W.eps;
+        if ((rc = run_net(PVAE_NET_MD, md, a_hat, Da, Da))) return rc;
+        if (s2_hat) {
+            RolloutIn wm;
+            memset(&wm, 0, sizeof(wm));
+            wm.kind = 3; wm.a = obs; wm.lda = 2 * Db; wm.Ka = Db;
+            wm.b = w + c->W.net[PVAE_NET_MD].act.back(); wm.ldb = c->L.net[PVAE_NET_MD].layers.back().n_out_pad; wm.Kb = Da;
+            if ((rc = run_net(PVAE_NET_WM, wm, s2_hat, Db, Db))) return rc;
+        }
+        return 0;
+    }
     if ((rc = stage(c, 0, obs, nullptr, rows, false, st, 1))) return rc;
     c->staged_rows = 0;      // not a training batch
     const int rows_pad = pad32(rows);

@@ -127,6 +127,8 @@ __device__ inline void store_stream(float* p, const v4f& v) {
 // take the decoder's action.
 struct StageArgs {
     const float* states;
+    const float* next_states;     // null: the second half of x / the target s2 is the NEXT row of `states`;
+                                  // else row-aligned with `states` (cond "rel": s_{t+1} - s_t, tpv:149-150)
     const float* actions;
     const int32_t* window_row;
     long long first_window;
@@ -154,7 +156,7 @@ __device__ inline void stage_row(const StageArgs& a, int r, int t, int rows_pad)
         if (a.window_row) {
             const long long s = (long long)a.window_row[a.first_window + r] + t;
             p1 = a.states + s * Db;
-            p2 = p1 + Db;
+            p2 = a.next_states ? a.next_states + s * Db : p1 + Db;
             pa = a.actions + s * Da;
         } else {
             p1 = a.x + ((size_t)r * a.L + t) * 2 * Db;

@@ -183,20 +183,27 @@ class HipEngine:
         return arena[lo:hi]
 
     # -- data ---------------------------------------------------------------------------
-    def bind_dataset(self, states, actions, window_row):
+    def bind_dataset(self, states, actions, window_row, next_states=None):
+        """`next_states` (optional, row-aligned with `states`): what the second half of x / the target s2
+        is read from instead of the next state row (cond "rel", tpv:149-150)."""
         self._need_gpu()
         if self.dataset is not None and self.dataset[0] is states and self.dataset[1] is actions \
-                and self.dataset[2] is window_row:
+                and self.dataset[2] is window_row and self.dataset[3] is next_states:
             return                                # the very same device tensors are already bound
         states = states.to(self.device, torch.float32).contiguous()
         actions = actions.to(self.device, torch.float32).contiguous()
         window_row = window_row.to(self.device, torch.int32).contiguous()
         assert states.shape[1] == self.arch.Db and actions.shape[1] == self.arch.Da
-        assert int(window_row.max()) + self.lookahead < states.shape[0]
-        self.dataset = (states, actions, window_row)
+        assert int(window_row.max()) + self.lookahead < states.shape[0] + (1 if next_states is not None else 0)
+        if next_states is not None:
+            next_states = next_states.to(self.device, torch.float32).contiguous()
+            assert next_states.shape == states.shape
+        self.dataset = (states, actions, window_row, next_states)
         _lib.check(self.lib.pvae_bind_dataset(self.ctx, states.data_ptr(), actions.data_ptr(),
                                               window_row.data_ptr(), states.shape[0],
                                               window_row.shape[0]), "pvae_bind_dataset")
+        if next_states is not None:
+            _lib.check(self.lib.pvae_bind_dataset_next(self.ctx, next_states.data_ptr()), "pvae_bind_dataset_next")
 
     def invalidate_staging(self):
         """Forget the staged / prefetched minibatch (something else is about to overwrite the panels)."""

@@ -99,8 +99,10 @@ class WindowDataset(torch_models.DatasetBase):
     is the next row) -- the layout the gather kernel reads from HBM.  `__getitem__`, `X`, `Y`
     reproduce the reference's tensors on demand."""
 
-    def __init__(self, states, actions, window_row, lookahead=1):
+    def __init__(self, states, actions, window_row, lookahead=1, next_states=None):
         self.states = np.ascontiguousarray(states, dtype=np.float32)
+        # cond "rel" (tpv:149-150): row r holds fp32(s_{r+1} - s_r), formed in float64 like the reference
+        self.next_states = None if next_states is None else np.ascontiguousarray(next_states, dtype=np.float32)
         self.actions = np.ascontiguousarray(actions, dtype=np.float32)
         self.window_row = np.ascontiguousarray(window_row, dtype=np.int32)
         self.lookahead = int(lookahead)          # steps per window: rows r .. r+L of one episode
@@ -113,15 +115,18 @@ class WindowDataset(torch_models.DatasetBase):
     def _steps(self, rows):
         return np.asarray(rows)[..., None] + np.arange(self.lookahead)
 
+    def _second(self, r):
+        return self.states[r + 1] if self.next_states is None else self.next_states[r]
+
     def __getitem__(self, index):
         r = self._steps(int(self.window_row[index]))                      # [L]
-        x = np.concatenate([self.states[r], self.states[r + 1]], axis=1)  # tpv:141-154
+        x = np.concatenate([self.states[r], self._second(r)], axis=1)     # tpv:141-154
         return torch.from_numpy(x.copy()), torch.from_numpy(self.actions[r].copy())
 
     @property
     def X(self):
         r = self._steps(self.window_row)                                   # [N, L]
-        return np.concatenate([self.states[r], self.states[r + 1]], axis=2).astype(np.float64)
+        return np.concatenate([self.states[r], self._second(r)], axis=2).astype(np.float64)
 
     @property
     def Y(self):
@@ -141,7 +146,7 @@ class WindowDataset(torch_models.DatasetBase):
         keep = np.ones(len(starts), dtype=bool)
         for j in range(1, lookahead):
             keep &= have[starts + j]
-        ds = WindowDataset(self.states, self.actions, starts[keep].astype(np.int32), lookahead)
+        ds = WindowDataset(self.states, self.actions, starts[keep].astype(np.int32), lookahead, self.next_states)
         ds.meta = getattr(self, "meta", {})
         return ds
 
@@ -151,6 +156,8 @@ class WindowDataset(torch_models.DatasetBase):
         if have is None or have.type != d.type or (d.index is not None and d.index != have.index):
             self._dev = tuple(torch.from_numpy(a).to(device)
                               for a in (self.states, self.actions, self.window_row))
+            if self.next_states is not None:
+                self._dev = self._dev + (torch.from_numpy(self.next_states).to(device),)
         return self._dev
 
 
@@ -164,6 +171,8 @@ def save_packed(dataset, path, meta=None):
     layout the gather kernel reads from HBM, so loading is a straight copy (no float64 blow-up:
     config 5's 6.4 GB of X/Y becomes 1.96 GB)."""
     import json
+    if dataset.next_states is not None:
+        raise NotImplementedError("packed files hold cond='abs' windows (states stored once)")
     arrays = [("states", dataset.states), ("actions", dataset.actions), ("window_row", dataset.window_row)]
     header = {"version": 1, "dim_state_body": int(dataset.states.shape[1]),
               "dim_action": int(dataset.actions.shape[1]), "n_rows": int(dataset.states.shape[0]),
@@ -207,7 +216,11 @@ def load_dataset_for_PhysicsVAE(files, num_samples=None, lookahead=1, cond="abs"
     files (save_packed); anything else is the reference's pickle."""
     assert files and len(files) > 0
     assert lookahead >= 1
+    if cond not in ("abs", "rel"):
+        raise NotImplementedError(cond)                                       # tpv:151-152
     if all(str(f).endswith(".pvd") for f in files):
+        if cond != "abs":
+            raise NotImplementedError("packed files hold cond='abs' windows; cond='rel' needs the float64 pickle")
         parts = [load_packed(f).with_lookahead(lookahead) for f in files]
         for p_ in parts[1:]:                     # same compatibility rule as merge_dataset
             assert p_.states.shape[1] == parts[0].states.shape[1] and p_.actions.shape[1] == parts[0].actions.shape[1]
@@ -224,11 +237,9 @@ def load_dataset_for_PhysicsVAE(files, num_samples=None, lookahead=1, cond="abs"
                                np.concatenate([p_.actions for p_ in parts]), rows.astype(np.int32), lookahead)
         print("Packed demonstrations:", files, "windows:", len(ds))
         return ds
-    if cond != "abs":
-        raise NotImplementedError("cond=%r (the trainer uses 'abs')" % cond)
     data = merge_dataset(files)
     episodes = data["episodes"]
-    states, actions, rows = [], [], []
+    states, actions, rows, deltas = [], [], [], []
     base = 0
     for ep in episodes:
         T = len(ep["time"])
@@ -240,9 +251,12 @@ def load_dataset_for_PhysicsVAE(files, num_samples=None, lookahead=1, cond="abs"
             n = max(0, min(n, num_samples - len(rows)))
         states.append(sb.astype(np.float32))
         actions.append(ac.astype(np.float32))
+        if cond == "rel":                        # tpv:149-150, in float64 as upstream; the last row has no successor
+            deltas.append(np.concatenate([sb[1:] - sb[:-1], np.zeros((1, sb.shape[1]))]).astype(np.float32))
         rows.extend(range(base, base + n))
         base += T
-    ds = WindowDataset(np.concatenate(states), np.concatenate(actions), np.asarray(rows, dtype=np.int32), lookahead)
+    ds = WindowDataset(np.concatenate(states), np.concatenate(actions), np.asarray(rows, dtype=np.int32), lookahead,
+                       np.concatenate(deltas) if cond == "rel" else None)
     ds.meta = {k: data.get(k) for k in META_KEYS}
     print("------------------Data Loaded------------------")
     print("File:", files)

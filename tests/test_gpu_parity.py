@@ -420,7 +420,7 @@ def test_gather_prefetch_is_bit_identical(golden):
     eng.train_step(phase, 2 * batch, batch, sp, eps=e, loss_out=out2)
     assert torch.equal(p1, eng.params) and torch.equal(out1, out2)
     # a different demonstration set bound in between: what was gathered ahead must not be used
-    st, ac, wr = eng.dataset
+    st, ac, wr = eng.dataset[:3]
     other = (st.flip(0).contiguous(), ac.flip(0).contiguous(), wr.clone())
     eng.params.copy_(p0); eng.exp_avg.copy_(m0); eng.exp_avg_sq.copy_(v0)
     eng.train_step(phase, 0, batch, sp, eps=e, loss_out=out1, next_span=(batch, batch))   # prefetches set A

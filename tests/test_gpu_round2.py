@@ -207,3 +207,90 @@ def test_state_independent_log_std_is_a_parameter_the_loss_never_touches(golden)
         tr.model.set_exploration_std(0.05)     # rmt:191-193
     logits, _ = tr.model({"obs": torch.zeros(2, 2 * arch["Db"], device=DEV)})
     assert torch.allclose(logits[:, arch["Da"]:].cpu(), before.cpu().expand(2, -1))
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3, 4])
+def test_fused_rollout_path_equals_the_staged_forward(golden, rows):
+    """pvae_infer at <= 4 rows (input assembly, sampler and output copies inside the layer launches: 7
+    launches instead of 9, 10 instead of 14 with the world model) against the stage-by-stage module
+    forward (forward_encoder / forward_decoder / forward_world over padded panels), with supplied draws,
+    Philox draws and noise off; the staged training minibatch survives a rollout call."""
+    g = golden("single_default")
+    arch = arch_from_meta(g["meta"])
+    data = R.synth_demo(0, 2, 40, arch["Db"], arch["Da"], kind="dynamics")
+    tr = make_trainer(arch, data, 32, device=DEV)
+    tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3))
+    m, eng = tr.model, tr.engine
+    obs = torch.randn(rows, 2 * arch["Db"], generator=torch.Generator().manual_seed(rows)).to(DEV)
+    eps = torch.randn(rows, arch["Z"], generator=torch.Generator().manual_seed(9)).to(DEV)
+    for noise, e in ((True, eps), (False, None)):
+        m.latent_prior_noise = noise
+        want, _ = m._forward_staged(obs, [], None, eps=e)
+        want_s2, want_z = m._cur_future_state.clone(), m.task_encoder_variable().clone()
+        a_hat, s2, z = eng.infer(obs, eps=e, noise=noise, want_s2=True)
+        assert float((a_hat - want[:, : arch["Da"]]).abs().max()) < 1e-6
+        assert float((s2 - want_s2).abs().max()) < 1e-6 and float((z - want_z).abs().max()) < 1e-6
+        a2, none, z2 = eng.infer(obs, eps=e, noise=noise, want_s2=False)
+        assert none is None and torch.equal(a2, a_hat) and torch.equal(z2, z)
+        logits, _ = m.forward({"obs_flat": obs}, [], None, eps=e)            # graph replay of the same launches
+        assert torch.equal(logits[:, : arch["Da"]], a_hat)
+        assert float((m._cur_task_encoder_mu - eng.read("mu", rows)).abs().max()) == 0.0
+    # Philox draws: keyed by (seed, offset), reproducible, standard-normal sized
+    m.latent_prior_noise = True
+    z1 = eng.infer(obs, noise=True, seed=5, offset=11)[2].clone()
+    z2 = eng.infer(obs, noise=True, seed=5, offset=11)[2].clone()
+    z3 = eng.infer(obs, noise=True, seed=5, offset=12)[2].clone()
+    assert torch.equal(z1, z2) and not torch.equal(z1, z3)
+    # a rollout call between gather and forward_backward leaves the staged minibatch alone
+    eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
+    c = R.phase_coeffs(True)
+    from physicsvae_amd.engine import make_step_params
+    sp = make_step_params(lr=5e-4, a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"], s_rec=c["s_rec_coeff"],
+                          cyc=c["vae_cycle_coeff"], global_rows=32)
+    eng.gather(0, 32)
+    l0 = eng.forward_backward(_lib.PHASE_WORLD, 32, sp, backward=False).clone()
+    eng.gather(0, 32)
+    eng.infer(obs, noise=False)
+    l1 = eng.forward_backward(_lib.PHASE_WORLD, 32, sp, backward=False).clone()
+    assert torch.equal(l0, l1)
+
+
+def test_gather_of_cond_rel_windows_is_bit_exact(golden, tmp_path):
+    """cond = "rel" datasets on the device: the gather kernel reads the second half of x and the target
+    s2 from the row-aligned `next_states` array; the panels equal the dataset's windows bit for bit and
+    a training epoch over them runs (the world model then learns state DIFFERENCES)."""
+    from physicsvae_amd import train_physics_vae as T
+    g = golden("ingest_rel_tiny")
+    arch = arch_from_meta(g["meta"])
+    Db, Da = arch["Db"], arch["Da"]
+    data = R.synth_demo(3, 3, 12, Db, Da, kind="iid", quantum=0.0)
+    pkl = str(tmp_path / "a.pkl")
+    R.write_demo(pkl, data)
+    tr = make_trainer(arch, data, 8, m_world=1, device=DEV)
+    ds = T.load_dataset_for_PhysicsVAE([pkl], cond="rel")
+    tr.train_loader.dataset = ds
+    eng = tr.engine
+    eng.bind_dataset(*ds.device_arrays(eng.device))
+    for first, rows in ((0, 8), (25, 8), (32, 1)):
+        eng.gather(first, rows)
+        torch.cuda.synchronize()
+        xs = torch.stack([ds[i][0][0] for i in range(first, first + rows)]).to(DEV)      # [rows, 2Db]
+        ys = torch.stack([ds[i][1][0] for i in range(first, first + rows)]).to(DEV)
+        assert torch.equal(eng.panel("in", _lib.NET_TE)[:rows, : 2 * Db], xs)
+        assert torch.equal(eng.panel("s2")[:rows, :Db], xs[:, Db:])
+        assert torch.equal(eng.panel("in", _lib.NET_WM)[:rows, :Db], xs[:, :Db])
+        assert torch.equal(eng.panel("in", _lib.NET_WM)[:rows, Db: Db + Da], ys)
+    r1, r2 = tr.train(), tr.train()
+    assert np.isfinite(r1["mean_train_loss"]) and np.isfinite(r2["mean_train_loss"])
+    # against the oracle on the same windows
+    X, Y = R.build_windows(data, cond="rel")
+    x, y = next(iter(R.make_loader(X, Y, 8)))
+    sd = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    want = R.loss_and_grads(arch, sd, x, y, None, world=True)
+    c = R.phase_coeffs(True)
+    from physicsvae_amd.engine import make_step_params
+    sp = make_step_params(lr=5e-4, a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"], s_rec=c["s_rec_coeff"],
+                          cyc=c["vae_cycle_coeff"], global_rows=8)
+    eng.gather(0, 8)
+    got = eng.forward_backward(_lib.PHASE_WORLD, 8, sp, backward=False).cpu()
+    assert float(got[0]) == pytest.approx(float(want["total"]), rel=1e-5)

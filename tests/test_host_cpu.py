@@ -613,3 +613,31 @@ def test_prior_kinds_layout_and_state_dict():
         tr.model.set_learnable_task_encoder(True); tr.model.set_learnable_motor_decoder(True)
         tr.model.set_learnable_world_model(False); tr.model.set_learnable_latent_prior(True)
         assert tr.phase() == (_lib.PHASE_JOINT, want_joint)
+
+
+def test_cond_rel_windows_match_the_reference_capture(golden, tmp_path):
+    """load_dataset_for_PhysicsVAE(cond="rel") (tpv:149-150: x = [s_t | s_{t+1} - s_t], float64 subtraction,
+    then the Dataset's float32 copy): our packed-once dataset (states + a row-aligned `next_states` array)
+    yields the reference's own windows bit for bit, at lookahead 1 and 2; the oracle's build_windows too."""
+    g = golden("ingest_rel_tiny")
+    arch = arch_from_meta(g["meta"])
+    data = R.synth_demo(3, 3, 12, arch["Db"], arch["Da"], kind="iid", quantum=0.0)
+    pkl = str(tmp_path / "a.pkl")
+    R.write_demo(pkl, data)
+    for L in (1, 2):
+        ds = T.load_dataset_for_PhysicsVAE([pkl], lookahead=L, cond="rel")
+        assert len(ds) == int(g["L%d_n_windows" % L])
+        for i, nm in ((0, "first"), (len(ds) - 1, "last")):
+            x, y = ds[i]
+            np.testing.assert_array_equal(x.numpy(), g["L%d_%s_x" % (L, nm)])
+            np.testing.assert_array_equal(y.numpy(), g["L%d_%s_y" % (L, nm)])
+        X, Y = R.build_windows(data, lookahead=L, cond="rel")
+        np.testing.assert_array_equal(R.tensor_digest(torch.from_numpy(X)), g["L%d_X_digest" % L])
+        np.testing.assert_array_equal(R.tensor_digest(torch.from_numpy(Y)), g["L%d_Y_digest" % L])
+        np.testing.assert_array_equal(torch.from_numpy(X).float().numpy(), ds.X.astype(np.float32))
+        # the states themselves are still stored once; only the differences are an extra array
+        assert ds.states.shape == ds.next_states.shape == (36, arch["Db"])
+    with pytest.raises(NotImplementedError):
+        T.load_dataset_for_PhysicsVAE([pkl], cond="delta")
+    with pytest.raises(NotImplementedError):
+        T.save_packed(ds, str(tmp_path / "a.pvd"))

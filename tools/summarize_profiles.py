@@ -61,9 +61,6 @@ def main(src, dst):
             per_simd = d["SQ_VALU_MFMA_BUSY_CYCLES_median_per_launch"] / 1024.0
             d["mfma_busy_cycles_per_simd"] = per_simd
             d["mfma_util_at_2.4GHz"] = per_simd / (d["avg_us"] * 1e-6 * 2.4e9)
-            if d.get("GRBM_GUI_ACTIVE_median_per_launch"):
-                d["clock_ghz"] = d["GRBM_GUI_ACTIVE_median_per_launch"] / (d["avg_us"] * 1e3)
-                d["mfma_busy_of_active_cycles"] = per_simd / d["GRBM_GUI_ACTIVE_median_per_launch"]
         if "SQ_LDS_BANK_CONFLICT_median_per_launch" in d and d.get("SQ_LDS_IDX_ACTIVE_median_per_launch"):
             d["lds_conflict_frac"] = d["SQ_LDS_BANK_CONFLICT_median_per_launch"] / d["SQ_LDS_IDX_ACTIVE_median_per_launch"]
     json.dump(out, open(dst + "_summary.json", "w"), indent=1, sort_keys=True)
