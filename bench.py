@@ -418,6 +418,14 @@ def main():
         "ranks_share_a_gpu": shared_gpu,
         "last_loss": last_loss,
     }
+    # context for every fraction below: the clock the chip sustains under fp32-MFMA load on THESE weights
+    ghz, peak_now = C.c_double(), C.c_double()
+    scratch = torch.zeros(1024, dtype=torch.float32, device=dev)
+    _lib.check(lib.pvae_mfma_clock_probe(eng.params.data_ptr(), eng.params.numel(), scratch.data_ptr(), C.byref(ghz),
+                                         C.byref(peak_now), torch.cuda.current_stream().cuda_stream), "clock probe")
+    out["mfma_clock_under_load"] = {"ghz": ghz.value, "fp32_mfma_peak_at_that_clock_tflops": peak_now.value,
+                                    "note": "all SIMDs issuing v_mfma_f32_16x16x4_f32 back to back on the parameter "
+                                            "arena's values; roofline.peak stays the 2.4 GHz spec figure"}
     fl_world, fl_joint = algorithmic_flops_per_sample(Db, Da, Z, W, D)
     fl = {"world": fl_world, "joint": fl_joint}
     out["step_mfma_frac"] = value / a.gpus * fl[a.phase] / (PEAK_F32_MFMA_TFLOPS * 1e12)
@@ -464,7 +472,7 @@ def main():
                 "avg_launch_us": us_ev, "avg_launch_us_rocprof": us_rp,
                 "frac_hip_events": d["per_launch"] / (us_ev * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                 "frac_rocprof": (d["per_launch"] / (us_rp * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS) if us_rp else None,
-                "mfma_busy": r.get("mfma_busy"),
+                "mfma_busy": r.get("mfma_busy"), "frac_of_sustained_clock_peak": tflops / peak_now.value,
                 "algorithmic_gflop_per_launch": d["per_launch"] / 1e9,
                 "launches_per_step": d["launches"] / n_prof}
         kernels = {}

@@ -323,6 +323,13 @@ int pvae_reparam(pvae_ctx* ctx, const float* mu_logvar, int32_t rows, const floa
  * pvae_profile_read synchronises on the recorded events and returns the summed duration
  * (ms), launch count and ALGORITHMIC flops (2*rows*n_in*n_out on the unpadded dims). */
 int pvae_profile_enable(int on);
+/* Shader clock the chip sustains while every SIMD issues fp32 MFMAs back to back on `operands` (>= 8192
+ * floats of representative data, e.g. the parameter arena; DVFS makes this depend on the data: zeros run at
+ * the 2.4 GHz spec clock, trained weights ~10 % lower) and the fp32-MFMA peak that clock allows
+ * (CUs x 256 FLOP/clk x clock).  `scratch` = 512 device floats.  Synchronises `stream` (measurement aid for
+ * bench.py: context for `roofline.frac`, which is quoted against the 2.4 GHz spec peak). */
+int pvae_mfma_clock_probe(const float* operands, int64_t n_operands, float* scratch, double* ghz,
+                          double* tflops_peak, void* stream);
 int pvae_profile_read(int category, double* total_ms, int64_t* launches, double* total_flops);
 
 /* GEMM micro-entry for kernel-level parity/roofline probes:

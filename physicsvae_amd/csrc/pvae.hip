@@ -569,6 +569,17 @@ gemv_rollout_kernel(RolloutIn in, int rows, const float* __restrict__ W, int ldw
                     float* __restrict__ out, int ldo, int K, int relu, float* __restrict__ out2, int ld2, int n2) {
     extern __shared__ __attribute__((aligned(16))) float xs[];         // [R][K], K = ld of the layer (multiple of 64)
     const int tid = threadIdx.x;
+    // this wave's weight row: the first 1024 columns are requested BEFORE the input rows are assembled,
+    // so that the two memory latencies of a layer (inputs, weights) overlap instead of adding up
+    const int n = blockIdx.x * 4 + (tid >> 6);
+    const int lane = tid & 63;
+    const float* wrow = W + (size_t)n * ldw;
+    v4f wpre[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane * 4 + 256 * j;
+        wpre[j] = k < K ? *reinterpret_cast<const v4f*>(wrow + k) : v4f{0.f, 0.f, 0.f, 0.f};
+    }
     for (int i = tid; i < R * K; i += 256) {
         const int r = i / K, k = i - r * K;
         float v = 0.f;
@@ -596,13 +607,21 @@ gemv_rollout_kernel(RolloutIn in, int rows, const float* __restrict__ W, int ldw
         xs[i] = v;
     }
     __syncthreads();
-    const int n = blockIdx.x * 4 + (tid >> 6);
-    const int lane = tid & 63;
-    const float* wrow = W + (size_t)n * ldw;
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.f;
-    for (int k = lane * 4; k < K; k += 256) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane * 4 + 256 * j;
+        if (k < K) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const v4f xv = *reinterpret_cast<const v4f*>(xs + r * K + k);
+                acc[r] = fmaf(wpre[j].x, xv.x, fmaf(wpre[j].y, xv.y, fmaf(wpre[j].z, xv.z, fmaf(wpre[j].w, xv.w, acc[r]))));
+            }
+        }
+    }
+    for (int k = lane * 4 + 1024; k < K; k += 256) {
         const v4f wv = *reinterpret_cast<const v4f*>(wrow + k);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -2271,6 +2290,46 @@ int pvae_reparam(pvae_ctx* c, const float* mu_logvar, int32_t rows, const float*
     return launch_sampler(c, mu_logvar, ldte, eps, c->ws + c->W.eps, c->ws + c->W.net[PVAE_NET_MD].in, ld_md, rows, rows,
                           noise ? 1 : 0, (unsigned long long)rng_seed, (unsigned long long)rng_offset, (float*)nullptr,
                           z_out, (const float*)nullptr, 0, st);
+}
+
+// Shader clock sustained while every SIMD issues fp32 MFMAs back to back on the caller's operands (DVFS:
+// the chip clocks to its power budget, and MFMA power depends on how much the operands toggle -- zeros
+// run at the 2.4 GHz spec clock, real weights ~10 % lower).  One workgroup reports shader cycles
+// (s_memtime) against the 100 MHz wall clock.
+__global__ void __launch_bounds__(256)
+mfma_clock_kernel(const float* __restrict__ src, int n_src, float* __restrict__ sink, int n, unsigned long long* out) {
+    const float a = src[(threadIdx.x + 256 * blockIdx.x) % n_src], b = src[(4099 + threadIdx.x + 17 * blockIdx.x) % n_src];
+    v4f acc[4] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+    const unsigned long long w0 = wall_clock64(), c0 = clock64();
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[u], 0, 0, 0);
+    }
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    const v4f s4 = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    if (s4[0] == 123.456f) sink[threadIdx.x] = s4[1];              // keeps the MFMAs alive; never true in practice
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
+}
+
+int pvae_mfma_clock_probe(const float* operands, int64_t n_operands, float* scratch, double* ghz, double* tflops_peak,
+                          void* stream) {
+    if (!operands || n_operands < 8192 || !scratch || !ghz || !tflops_peak) return fail(-1, "bad probe arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int cus = 0, dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    unsigned long long* d_out = reinterpret_cast<unsigned long long*>(scratch);      // 16 bytes, then the sink
+    const int n_src = (int)(n_operands > (1 << 30) ? (1 << 30) : n_operands);
+    for (int rep = 0; rep < 2; ++rep)          // the second run is measured with the clock already settled
+        hipLaunchKernelGGL(mfma_clock_kernel, dim3(4 * cus), dim3(256), 0, st, operands, n_src, scratch + 64, 2048, d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost));
+    if (!h[1]) return fail(-10, "clock probe measured nothing");
+    *ghz = (double)h[0] / ((double)h[1] * 10.0);                    // cycles / ns
+    *tflops_peak = (double)cus * 256.0 * *ghz * 1e9 / 1e12;         // 256 FLOP / clk / CU (MI355X_MICROARCH.md)
+    return 0;
 }
 
 int pvae_profile_enable(int on) {

@@ -306,17 +306,19 @@ __device__ inline void splitk_reg_body(float* lds, int bid, const GemmArgs& ga, 
     const typename Epi::Pre epre = epi.preload(q0 + (tid >> 3), p0 + ((tid & 7) << 2));   // arrives under the loop
     __syncthreads();
 
+    v4f abl_q = v4f{1.f, 2.f, 3.f, 4.f} * (float)(lane + 1);
+    asm volatile("" : "+v"(abl_q));
     // one k-tile; see wgrad_reg_body for why the full groups are branch-free (exact vmcnt: the
     // three younger register sets stay in flight across the LDS write of the oldest)
     auto tile_step = [&](int t, int d, bool guarded) {
         const float* st = lds + (t & 1) * kStage;
         v4f fq[2], fp[2];
         v2f fc[4];
-        if (ABL & 2) {
+        if (ABL & 2) {            // (probes) loop-invariant fragments the compiler cannot see through
 #pragma unroll
-            for (int a = 0; a < 2; ++a) { fq[a] = v4f{1.f, 2.f, 3.f, 4.f} * (float)lane; fp[a] = fq[a] + 1.f; }
+            for (int a = 0; a < 2; ++a) { fq[a] = abl_q; fp[a] = abl_q; }
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) fc[s2] = v2f{1.f + s2, 2.f} * (float)lane;
+            for (int s2 = 0; s2 < 4; ++s2) fc[s2] = v2f{abl_q[0], abl_q[1]};
             asm volatile("" : "+v"(fq[0]), "+v"(fq[1]), "+v"(fp[0]), "+v"(fp[1]));
         } else {
 #pragma unroll
@@ -363,165 +365,6 @@ __device__ inline void splitk_reg_body(float* lds, int bid, const GemmArgs& ga, 
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (t0 + d < nk) tile_step(t0 + d, d, true);
-
-    constexpr int RS = 36;
-    float* red = lds + wave * (32 * RS);
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ql = 16 * a + li;
-                const int pl = P_ROW ? (16 * b + 4 * lh + r) : (8 * lh + 2 * r + b);
-                red[ql * RS + pl] = acc[a][b][r];
-            }
-    __syncthreads();
-    {
-        const int ql = tid >> 3, pl = (tid & 7) << 2;
-        v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
-#pragma unroll
-        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (32 * RS) + ql * RS + pl);
-        epi(q0 + ql, p0 + pl, v, epre);
-    }
-    epi.finish(lds, tile_q * tiles_p + tile_p, tid);
-}
-
-// The same contraction with the fragments of tile t+1 requested BEFORE the MFMAs of tile t issue
-// (second fragment register set), so that no LDS latency sits behind the barrier.  Because a tile's
-// fragments are then read one tile ahead, its LDS slot is free again as soon as the barrier that ends
-// the PREVIOUS tile has passed: tile t+2 is parked in slot t&1 while tile t is contracted (two slots
-// carry a write-ahead distance of two tiles).  Same LDS image, same split-K layout and summation order
-// as splitk_reg_body: results are bit-identical.
-#ifndef PVAE_DGRAD_PIPE
-#define PVAE_DGRAD_PIPE 0      // 1: splitk_reg2_body in the fused backward launches (measured slower)
-#endif
-template <bool P_ROW, class Epi>
-__device__ inline void splitk_reg2_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
-    constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile;
-    const float* __restrict__ Q = ga.Q;
-    const float* __restrict__ P = ga.P;
-    const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
-
-    const int xcd = bid & 7, loc = bid >> 3;
-    const int tile_p = xcd * ga.p_per_xcd + loc / tiles_q;
-    const int tile_q = loc % tiles_q;
-    if (tile_p >= tiles_p) return;
-    const int q0 = tile_q * 32, p0 = tile_p * 32;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lh = lane >> 4;
-
-    const float* sq[2];
-    const float* sp[2];
-    int slot_off[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int j = (wave + 4 * u) * 64 + lane;
-        slot_off[u] = j * 4;
-        {
-            const int row = j >> 4, c = (j & 15) ^ (row & 15);
-            sq[u] = Q + (size_t)(q0 + row) * ldq + c * 4;
-        }
-        if (P_ROW) {
-            const int row = j >> 4, c = (j & 15) ^ (row & 15);
-            sp[u] = P + (size_t)(p0 + row) * ldp + c * 4;
-        } else {
-            const int r = j >> 3, k = r ^ ((r >> 2) & 1);
-            sp[u] = P + (size_t)k * ldp + p0 + (j & 7) * 4;
-        }
-    }
-    const size_t kstep_p = P_ROW ? (size_t)BK : (size_t)BK * ldp;
-
-    v4f rg[2][4];
-    auto gload = [&](int t, v4f(&r)[4]) {
-        r[0] = *reinterpret_cast<const v4f*>(sq[0] + (size_t)t * BK);
-        r[1] = *reinterpret_cast<const v4f*>(sp[0] + (size_t)t * kstep_p);
-        r[2] = *reinterpret_cast<const v4f*>(sq[1] + (size_t)t * BK);
-        r[3] = *reinterpret_cast<const v4f*>(sp[1] + (size_t)t * kstep_p);
-    };
-    auto lwrite = [&](float* slot, const v4f(&r)[4]) {
-        *reinterpret_cast<v4f*>(slot + slot_off[0]) = r[0];
-        *reinterpret_cast<v4f*>(slot + kTile + slot_off[0]) = r[1];
-        *reinterpret_cast<v4f*>(slot + slot_off[1]) = r[2];
-        *reinterpret_cast<v4f*>(slot + kTile + slot_off[1]) = r[3];
-    };
-
-    v4f acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
-
-    int oq[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int row = 16 * a + li;
-        oq[a] = row * 64 + (((4 * wave + lh) ^ (row & 15)) << 2);
-    }
-    const int kq = 16 * wave + 4 * lh;
-    struct Frag { v4f q[2], p[2]; v2f c[4]; };
-    auto fread = [&](const float* st, Frag& f) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a) f.q[a] = *reinterpret_cast<const v4f*>(st + oq[a]);
-        if (P_ROW) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b) f.p[b] = *reinterpret_cast<const v4f*>(st + kTile + oq[b]);
-        } else {
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)
-                f.c[s2] = *reinterpret_cast<const v2f*>(st + kTile + (((kq + s2) ^ (lh & 1)) * 32) + 2 * li);
-        }
-    };
-    auto mfmas = [&](const Frag& f, int s_lo, int s_hi) {
-#pragma unroll
-        for (int s2 = s_lo; s2 < s_hi; ++s2)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const float pv = P_ROW ? f.p[b][s2] : f.c[s2][b];
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, f.q[a][s2], acc[a][b], 0, 0, 0);
-                }
-    };
-
-    const int nk = K / BK;
-    // prologue: tiles 0, 1 -> slots 0, 1; register sets refilled with tiles 2, 3 (clamped, not
-    // guarded: exact vmcnt, see wgrad_reg_body)
-    gload(0, rg[0]);
-    gload(1 < nk ? 1 : nk - 1, rg[1]);
-    lwrite(lds, rg[0]);
-    gload(2 < nk ? 2 : nk - 1, rg[0]);
-    lwrite(lds + kStage, rg[1]);
-    gload(3 < nk ? 3 : nk - 1, rg[1]);
-    const typename Epi::Pre epre = epi.preload(q0 + (tid >> 3), p0 + ((tid & 7) << 2));   // arrives under the loop
-    __syncthreads();
-
-    Frag F0, F1;
-    fread(lds, F0);
-    auto tile_step = [&](int t, int d, Frag& F, Frag& G) {
-        fread(lds + (d ^ 1) * kStage, G);               // tile t+1 (past the end: a stale slot, never used)
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(F, 0, 2);
-        __builtin_amdgcn_sched_barrier(0);               // (pinned: left alone hipcc hoists the LDS writes and the
-        lwrite(lds + d * kStage, rg[d]);                 //  barrier above the MFMAs) tile t+2; past the end: stale
-        {
-            const int tn = t + 4 < nk ? t + 4 : nk - 1;
-            gload(tn, rg[d]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(F, 2, 4);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-    };
-    int t = 0;
-    for (; t + 2 <= nk; t += 2) {
-        tile_step(t, 0, F0, F1);
-        tile_step(t + 1, 1, F1, F0);
-    }
-    if (t < nk) tile_step(t, 0, F0, F1);
 
     constexpr int RS = 36;
     float* red = lds + wave * (32 * RS);
@@ -1023,14 +866,16 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
         }
         __syncthreads();
     };
+    v2f abl_f = v2f{1.f, 2.f} * (float)(lane + 1);
+    asm volatile("" : "+v"(abl_f));
     auto tile_step_plain = [&](int t, int d, bool guarded) {
         const float* st = lds + (t & 1) * kStage;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             v2f fq, fp;
-            if (ABL & 2) {
-                fq = v2f{1.f, 2.f} * (float)(lane + kk);
-                fp = v2f{3.f, 4.f} * (float)(lane + kk);
+            if (ABL & 2) {        // (probes) loop-invariant fragments the compiler cannot see through
+                fq = abl_f;
+                fp = abl_f;
                 asm volatile("" : "+v"(fq), "+v"(fp));
             } else {
                 fq = *reinterpret_cast<const v2f*>(st + oq + kk * 64);
@@ -1213,193 +1058,11 @@ __device__ inline void wgrad32_body(float* lds, int bid, const GemmArgs& ga, Epi
     if (epi.loss.out && bid == 0 && wave == 3) finalize_loss_wave(epi.loss, lane);
 }
 
-// ---- weight gradient, 64x64 tile per workgroup, EVERY WAVE owns the whole tile (in-workgroup split-K) ----
-// The 2x2-waves body above gives each wave a 32x32 quarter, so every k-step needs one ds_read_b64 per
-// operand per wave and each LDS byte is read twice (256 B of fragment reads per MFMA).  Here the four
-// waves split the 32 batch rows of a k-tile instead (8 rows = 2 MFMA k-steps each) and every wave
-// accumulates all 64x64 outputs as 4x4 MFMA tiles (64 accumulator registers):
-//   * ONE ds_read_b128 per operand per k-step feeds 16 MFMAs: lane (i, kk) reads outputs 4i..4i+3 of
-//     batch row kk, i.e. MFMA tile u owns outputs {4i + u} -- 128 B of fragment reads per MFMA, each LDS
-//     byte read once, on the read instruction that runs at full LDS rate from one wave per SIMD
-//     (MI355X_MICROARCH.md LDS table); the row-major [32 k][64] image is conflict-free as it is;
-//   * 16 independent accumulators: no dependent-issue gaps;
-//   * a 3-slot ring: tile t+2 is written while tile t is contracted, so the fragments of tile t+1 are
-//     requested BEFORE the barrier that ends tile t and no LDS latency is exposed behind a barrier;
-//   * at the end the four partial tiles are reduce-scattered through LDS in ONE round: wave w keeps
-//     the tiles of output rows q = 4i + w, writes the other 12 KB, reads the three other waves' 4 KB
-//     each and sums in wave order (fixed: deterministic); every lane ends with ONE output row x 16
-//     consecutive columns = 4 float4 for the epilogue.
-constexpr int kWgradRing3Floats = 3 * 2 * 32 * 64;      // 48 KB: 3 slots x (Q tile + P tile); also the reduction buffer
-template <class Epi>
-__device__ inline void wgrad64k_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
-    constexpr int BK = 32, kTile = 32 * 64, kStage = 2 * kTile, D = PVAE_REG_DEPTH_W, S = 3;
-    static_assert(S * kStage == kWgradRing3Floats, "LDS budget");
-    static_assert(4 * 12 * 256 <= kWgradRing3Floats, "ring must hold the reduction buffer");
-    const float* __restrict__ Q = ga.Q;
-    const float* __restrict__ P = ga.P;
-    const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
-
-    const int xcd = bid & 7, loc = bid >> 3;
-    const int tile_p = xcd * ga.p_per_xcd + loc / tiles_q;
-    const int tile_q = loc % tiles_q;
-    if (tile_p >= tiles_p) return;
-    const int q0 = tile_q * 64, p0 = tile_p * 64;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lh = lane >> 4;
-
-    // staging: 512 16-byte chunks per operand image, two per thread, image row-major [32 k][64]
-    const float* sq[2];
-    const float* sp[2];
-    int slot_off[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int j = tid + 256 * u;
-        const int row = j >> 4, c = j & 15;
-        slot_off[u] = j * 4;
-        sq[u] = Q + (size_t)row * ldq + q0 + c * 4;
-        sp[u] = P + (size_t)row * ldp + p0 + c * 4;
-    }
-    v4f rg[D][4];
-    auto gload = [&](int t, v4f(&r)[4]) {
-        r[0] = *reinterpret_cast<const v4f*>(sq[0] + (size_t)t * BK * ldq);
-        r[1] = *reinterpret_cast<const v4f*>(sp[0] + (size_t)t * BK * ldp);
-        r[2] = *reinterpret_cast<const v4f*>(sq[1] + (size_t)t * BK * ldq);
-        r[3] = *reinterpret_cast<const v4f*>(sp[1] + (size_t)t * BK * ldp);
-    };
-    auto lwrite = [&](float* slot, const v4f(&r)[4]) {
-        *reinterpret_cast<v4f*>(slot + slot_off[0]) = r[0];
-        *reinterpret_cast<v4f*>(slot + kTile + slot_off[0]) = r[1];
-        *reinterpret_cast<v4f*>(slot + slot_off[1]) = r[2];
-        *reinterpret_cast<v4f*>(slot + kTile + slot_off[1]) = r[3];
-    };
-
-    v4f acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
-
-    // this lane's fragment at k-step s of its wave's 8-row slice: row 8*wave + 4*s + lh, columns 4*li..
-    const int of = (8 * wave + lh) * 64 + 4 * li;
-    struct Frag { v4f q[2], p[2]; };
-    auto fread = [&](const float* st, Frag& f) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            f.q[s2] = *reinterpret_cast<const v4f*>(st + of + s2 * 256);
-            f.p[s2] = *reinterpret_cast<const v4f*>(st + kTile + of + s2 * 256);
-        }
-    };
-    auto mfmas = [&](const Frag& f, int s2) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.p[s2][b], f.q[s2][a], acc[a][b], 0, 0, 0);
-    };
-
-    const int nk = K / BK;
-    // prologue: tiles 0 and 1 into slots 0 and 1, register sets refilled with tiles 2.. (clamped, not
-    // guarded: exact vmcnt, see wgrad_reg_body)
-#pragma unroll
-    for (int d = 0; d < D; ++d) gload(d < nk ? d : nk - 1, rg[d]);
-    static_assert(D == 2, "the ring schedule below is written for two register sets");
-    lwrite(lds, rg[0]);
-    gload(2 < nk ? 2 : nk - 1, rg[0]);
-    lwrite(lds + kStage, rg[1]);
-    gload(3 < nk ? 3 : nk - 1, rg[1]);
-    __syncthreads();
-
-    // tile t: contract slot t%3 (fragments already in registers), park tile t+2 in slot (t+2)%3 (idle
-    // since tile t-1) and refill that register set with tile t+4; the fragments of tile t+1 (slot
-    // (t+1)%3, written during tile t-1) are requested as soon as the MFMAs that read the current ones
-    // have issued -- step 0's right behind step 0, i.e. half a tile before the barrier.
-    Frag F;
-    fread(lds, F);
-    const float* st_next = lds + kStage;             // slot of tile t+1
-    float* st_w = lds + 2 * kStage;                  // slot tile t+2 goes to
-    auto tile_step = [&](int t, int d) {
-        mfmas(F, 0);
-        __builtin_amdgcn_sched_barrier(0);               // (the order below is pinned: hipcc otherwise moves the
-        F.q[0] = *reinterpret_cast<const v4f*>(st_next + of);            //  barrier into the MFMA stream)
-        F.p[0] = *reinterpret_cast<const v4f*>(st_next + kTile + of);    // (past the end: stale, never used)
-        lwrite(st_w, rg[d]);                             // (past the end: a stale register set into an idle slot)
-        {
-            const int tn = t + 4 < nk ? t + 4 : nk - 1;
-            gload(tn, rg[d]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(F, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        F.q[1] = *reinterpret_cast<const v4f*>(st_next + of + 256);
-        F.p[1] = *reinterpret_cast<const v4f*>(st_next + kTile + of + 256);
-        __syncthreads();
-        const float* nn = st_w;                          // rotate: next <- written, written <- the slot just read
-        st_w = const_cast<float*>(st_next) - kStage;
-        if (st_w < lds) st_w += S * kStage;
-        st_next = nn;
-    };
-    int t = 0;
-    for (; t + 2 <= nk; t += 2) {
-        tile_step(t, 0);
-        tile_step(t + 1, 1);
-    }
-    if (t < nk) tile_step(t, 0);
-
-    PVAE_MARK(0, 2);
-    // reduce-scatter over the four waves: wave w owns the tiles acc[w][*].  Region w' of the buffer
-    // holds wave w' partials of the 12 tiles it does not own, tile (a, b) at rank a - (a > w').
-    // (the barrier that ended the last tile also ended every read of the ring)
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        if (a == wave) continue;
-        const int rank = a - (a > wave ? 1 : 0);
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-            *reinterpret_cast<v4f*>(lds + ((wave * 12 + rank * 4 + b) * 64 + lane) * 4) = acc[a][b];
-    }
-    __syncthreads();
-    v4f mine[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        v4f own = acc[0][b];
-#pragma unroll
-        for (int a = 1; a < 4; ++a)
-            if (a == wave) own = acc[a][b];
-        v4f sum = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2) {                 // fixed order: wave 0, 1, 2, 3
-            if (w2 == wave) {
-                sum = w2 == 0 ? own : sum + own;
-            } else {
-                const int rank = wave - (wave > w2 ? 1 : 0);
-                const v4f part = *reinterpret_cast<const v4f*>(lds + ((w2 * 12 + rank * 4 + b) * 64 + lane) * 4);
-                sum = w2 == 0 ? part : sum + part;
-            }
-        }
-        mine[b] = sum;
-    }
-    // lane (li, lh) of wave w holds G[q0 + 4 li + w][p0 + 16 lh + 4 r + b] in mine[b][r]
-    const int q = q0 + 4 * li + wave;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int pc = p0 + 16 * lh + 4 * r;
-        epi.apply(q, pc, v4f{mine[0][r], mine[1][r], mine[2][r], mine[3][r]}, epi.load(q, pc));
-    }
-    if (epi.loss.out && bid == 0 && wave == 3) finalize_loss_wave(epi.loss, lane);
-}
-
 // either geometry, chosen per problem on the host
-#ifndef PVAE_WGRAD_K64
-#define PVAE_WGRAD_K64 0       // 1: wgrad64k_body for the 64x64 geometry (measured slower)
-#endif
-constexpr int kPairLdsFloats = PVAE_WGRAD_K64 ? kWgradRing3Floats : kRegRingFloats;
-template <class Epi, int ABL = 0, int WV = PVAE_WGRAD_K64>
+constexpr int kPairLdsFloats = kRegRingFloats;
+template <class Epi, int ABL = 0>
 __device__ inline void wgrad_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
     if (ga.tile32) wgrad32_body<Epi>(lds, bid, ga, epi);
-    else if constexpr (WV == 1 && ABL == 0) wgrad64k_body<Epi>(lds, bid, ga, epi);
     else wgrad_reg_body<Epi, ABL>(lds, bid, ga, epi);
 }
 
@@ -1447,8 +1110,32 @@ struct AdamSeg {
     AdamScalars s{};
 };
 constexpr int kAdamBlocks = 256;
+#ifndef PVAE_ADAM_UNROLL
+#define PVAE_ADAM_UNROLL 1     // float4 elements per thread in flight (A/B: 2 issues both trips' loads up front)
+#endif
 __device__ inline void adam_seg_body(const AdamSeg& a, int blk) {
-    for (long long i = blk * 256ll + threadIdx.x; i < a.n4; i += kAdamBlocks * 256ll) {
+    long long i = blk * 256ll + threadIdx.x;
+#if PVAE_ADAM_UNROLL == 2
+    constexpr long long kStride = kAdamBlocks * 256ll;
+    for (; i + kStride < a.n4; i += 2 * kStride) {
+        v4f pp[2], gg[2], mm[2], vv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            pp[u] = reinterpret_cast<v4f*>(a.p)[i + u * kStride];
+            gg[u] = reinterpret_cast<const v4f*>(a.g)[i + u * kStride];
+            mm[u] = reinterpret_cast<v4f*>(a.m)[i + u * kStride];
+            vv[u] = reinterpret_cast<v4f*>(a.v)[i + u * kStride];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            adam_update4(gg[u], pp[u], mm[u], vv[u], a.s);
+            store_stream(a.p + 4 * (i + u * kStride), pp[u]);
+            store_stream(a.m + 4 * (i + u * kStride), mm[u]);
+            store_stream(a.v + 4 * (i + u * kStride), vv[u]);
+        }
+    }
+#endif
+    for (; i < a.n4; i += kAdamBlocks * 256ll) {
         v4f pp = reinterpret_cast<v4f*>(a.p)[i];
         const v4f gg = reinterpret_cast<const v4f*>(a.g)[i];
         v4f mm = reinterpret_cast<v4f*>(a.m)[i];
@@ -1461,33 +1148,43 @@ __device__ inline void adam_seg_body(const AdamSeg& a, int blk) {
 }
 inline int adam_blocks(const AdamSeg* a) { return a && a->n4 > 0 ? kAdamBlocks : 0; }
 
-// Bias gradient of a weight-gradient problem, db[q] = sum over the K rows of Q[k][q], for 64
+// Bias gradient of a weight-gradient problem, db[q] = sum over the K rows of Q[k][q], for 32
 // columns per workgroup (fixed summation order), handed to the epilogue's bias() (store, or Adam on
 // the bias).  These few light workgroups are appended to every weight-gradient launch: summing the
 // fragments inside the contraction loop instead put two VALU adds beside every four MFMAs of EVERY
 // wave (only 1 tile column in 16 needs them) and cost 2 % of the step.
-__host__ __device__ inline int bias_tiles(const GemmArgs& ga) { return ga.tile32 ? ga.tiles_q / 2 : ga.tiles_q; }
+// Shape: a launch ends with its last workgroup, and these are latency chains sharing their CU with two
+// contraction workgroups -- 16 workgroups of 64 columns x 16 row groups walked K = 256 rows in 8
+// dependent round trips and kept the fused backward launch open 0.8 us longer (tools/pair_lab.hip:
+// 14.28 vs 13.47 us).  32 columns x 32 row groups with all K / 32 loads of a thread in flight at once
+// (full 128-byte lines per row) is ONE round trip for batches up to 256 rows.
+__host__ __device__ inline int bias_tiles(const GemmArgs& ga) { return ga.tile32 ? ga.tiles_q : 2 * ga.tiles_q; }
 template <class Epi>
 __device__ inline void bias_grad_body(float* lds, int tile, const GemmArgs& ga, Epi& epi) {
     if (!epi.has_bias() || tile >= bias_tiles(ga)) return;
-    const int tid = threadIdx.x, c4 = (tid & 15) * 4, r0 = tid >> 4;      // 16 rows x 64 columns per pass
-    const float* __restrict__ src = ga.Q + (size_t)r0 * ga.ldq + tile * 64 + c4;
-    const size_t step = (size_t)16 * ga.ldq;
-    v4f s0 = v4f{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    const int tid = threadIdx.x, c4 = (tid & 7) * 4, r0 = tid >> 3;       // 32 rows x 32 columns per pass
+    const float* __restrict__ src = ga.Q + (size_t)r0 * ga.ldq + tile * 32 + c4;
+    const size_t step = (size_t)32 * ga.ldq;
+    v4f s = v4f{0.f, 0.f, 0.f, 0.f};
     int k = r0;
-    for (; k + 16 < ga.K; k += 32) {
-        s0 += *reinterpret_cast<const v4f*>(src);
-        s1 += *reinterpret_cast<const v4f*>(src + step);
-        src += 2 * step;
+    for (; k + 7 * 32 < ga.K; k += 8 * 32) {      // 8 rows per thread in flight (256 batch rows per trip)
+        v4f t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = *reinterpret_cast<const v4f*>(src + i * step);
+        s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        src += 8 * step;
     }
-    if (k < ga.K) s0 += *reinterpret_cast<const v4f*>(src);
-    *reinterpret_cast<v4f*>(lds + r0 * 64 + c4) = s0 + s1;
+    for (; k < ga.K; k += 32) {
+        s += *reinterpret_cast<const v4f*>(src);
+        src += step;
+    }
+    *reinterpret_cast<v4f*>(lds + r0 * 32 + c4) = s;
     __syncthreads();
-    if (tid < 64) {
+    if (tid < 32) {
         float v = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v += lds[r * 64 + tid];
-        epi.bias(tile * 64 + tid, v);
+        for (int r = 0; r < 32; ++r) v += lds[r * 32 + tid];
+        epi.bias(tile * 32 + tid, v);
     }
 }
 
@@ -1535,7 +1232,6 @@ bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, Adam
     const int b = blockIdx.x;
     if (b < nd) {
         if (gd.tile16) splitk_reg16_body<false, EpiD>(lds, b, gd, ed);
-        else if constexpr (PVAE_DGRAD_PIPE && ABL == 0) splitk_reg2_body<false, EpiD>(lds, b, gd, ed);
         else splitk_reg_body<false, EpiD, ABL>(lds, b, gd, ed);
     } else if (b < nd + nw) wgrad_body<EpiW, ABL>(lds, b - nd, gw, ew);
     else if (b < nd + nw + bias_tiles(gw)) bias_grad_body(lds, b - nd - nw, gw, ew);
@@ -1906,12 +1602,12 @@ inline bool wgrad_uses_32x32(int N, int Kin, int M) {
 }
 struct WgradPlan {
     GemmArgs ga;
-    int grid, nbias;          // contraction workgroups, bias-gradient workgroups (64 columns each)
+    int grid, nbias;          // contraction workgroups, bias-gradient workgroups (32 columns each)
 };
 inline WgradPlan plan_wgrad(const float* dZ, int ldz, const float* X, int ldx, int N, int Kin, int M) {
     const bool t32 = wgrad_uses_32x32(N, Kin, M);
     const GemmGrid g = t32 ? make_grid(N, Kin, 32, 32) : make_grid(N, Kin, 64, 64);
-    WgradPlan p{GemmArgs{dZ, ldz, X, ldx, M, g.tiles_q, g.tiles_p, g.p_per_xcd}, g.grid, N / 64};
+    WgradPlan p{GemmArgs{dZ, ldz, X, ldx, M, g.tiles_q, g.tiles_p, g.p_per_xcd}, g.grid, N / 32};
     p.ga.tile32 = t32 ? 1 : 0;
     return p;
 }

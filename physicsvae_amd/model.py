@@ -252,7 +252,6 @@ class PhysicsVAE(nn.Module):
 
         self._cur_value = None
         self._lazy, self._mu, self._logvar = None, None, None
-        self._graphs = {}                        # (rows, noise) -> GraphedInfer of the rollout forward
         self._cur_task_encoder_variable = None
         self._cur_body_encoder_variable = None
         self._cur_task_encoder_mu = None
@@ -314,15 +313,14 @@ class PhysicsVAE(nn.Module):
         out, st = self.forward(d, state or [], seq_lens)
         return out, st
 
-    # rollout batches (the 30 Hz control loop calls forward at B = 1, envs/rllib_env_imitation.py:215-266):
-    # up to this many rows the whole forward is ONE replayed HIP graph (HipEngine.graphed_infer)
-    GRAPH_ROWS = 4
+    # The 30 Hz control loop calls forward at B = 1 (envs/rllib_env_imitation.py:215-266) and reads the
+    # action only; set False to skip the world model's prediction `_cur_future_state` (3 launches less).
+    rollout_predicts_state = True
 
     def forward(self, input_dict, state, seq_lens, eps=None):
-        """rmt:742-771.  One library call for the whole chain (stage -> TE -> sampler -> MD -> WM,
-        `pvae_infer`); at <= GRAPH_ROWS rows that call is a captured HIP graph, replayed.  The encoder's
-        mu / logvar and the value estimate are produced on demand (`_cur_task_encoder_mu`,
-        `value_function()`): the rollout loop reads neither."""
+        """rmt:742-771.  One library call for the whole chain (TE -> sampler -> MD -> WM, `pvae_infer`).
+        The encoder's mu / logvar and the value estimate are produced on demand
+        (`_cur_task_encoder_mu`, `value_function()`): the rollout loop reads neither."""
         obs = input_dict["obs_flat"].float()
         eng = self.engine
         if obs.dim() != 2 or obs.shape[0] > eng.max_batch or self._latent_prior is not None or eng.lookahead != 1:
@@ -331,15 +329,12 @@ class PhysicsVAE(nn.Module):
         obs = obs.to(eng.device)
         noise = bool(self.latent_prior_noise)
         self._rng_calls += 1
-        if rows <= self.GRAPH_ROWS and (eps is not None or not noise):
-            key = (rows, noise)
-            gi = self._graphs.get(key)
-            if gi is None:
-                gi = self._graphs[key] = eng.graphed_infer(rows, want_s2=True, noise=noise)
-            a_hat, s2, z = gi(obs, eps=eps if noise else None)
-        else:                                      # on-chip Philox draws are keyed per call: not replayable
-            a_hat, s2, z = eng.infer(obs, eps=eps if noise else None, noise=noise, seed=self._rng_seed,
-                                     offset=self._rng_calls, want_s2=True)
+        # (eager on purpose: with the input assembly, the sampler and the output copies inside the layer
+        #  launches the call is 10 launches, and issue -> result at B = 1 measures 37 us eager against 44 us
+        #  for a replay of the same launches as a HIP graph, whose fixed cost is higher; `graphed_infer`
+        #  stays available for callers that replay many forwards back to back)
+        a_hat, s2, z = eng.infer(obs, eps=eps if noise else None, noise=noise, seed=self._rng_seed,
+                                 offset=self._rng_calls, want_s2=self.rollout_predicts_state)
         logits = self._motor_decoder._model[-1](a_hat)
         self._cur_future_state = s2
         self._cur_body_encoder_variable = obs[..., : self.dim_state_body]

@@ -232,7 +232,7 @@ def test_fused_rollout_path_equals_the_staged_forward(golden, rows):
         assert float((s2 - want_s2).abs().max()) < 1e-6 and float((z - want_z).abs().max()) < 1e-6
         a2, none, z2 = eng.infer(obs, eps=e, noise=noise, want_s2=False)
         assert none is None and torch.equal(a2, a_hat) and torch.equal(z2, z)
-        logits, _ = m.forward({"obs_flat": obs}, [], None, eps=e)            # graph replay of the same launches
+        logits, _ = m.forward({"obs_flat": obs}, [], None, eps=e)            # the module's forward is the same call
         assert torch.equal(logits[:, : arch["Da"]], a_hat)
         assert float((m._cur_task_encoder_mu - eng.read("mu", rows)).abs().max()) == 0.0
     # Philox draws: keyed by (seed, offset), reproducible, standard-normal sized
