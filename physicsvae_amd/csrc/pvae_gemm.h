@@ -105,11 +105,11 @@ __device__ inline void store_stream(float* p, const v4f& v) {
 //   COL tile [32 k][64] b64 reads  : chunk ^= (row & 1) << 3        (rows k, k+1 likewise)
 // (An LDS-DMA ring variant of the same kernels -- global_load_lds, 8 stages, counted vmcnt --
 // measured ~12 % slower because a DMA instruction costs ~150 issue cycles on the wave that also
-// feeds the matrix pipe; it lives in tools/gemm_dma_ring.h with the ablation harness.)
+// feeds the matrix pipe; it was dropped after round 1, the measurement is in DESIGN.md section 4.)
 // ---------------------------------------------------------------------------------------
 // ---- forward / dgrad: C[32 q][32 p] per workgroup, BK = 64, the 4 waves split K -------------
 //   Q is always ROW (X or dZ, k-contiguous).  P_ROW: W[p][k] (forward);  !P_ROW: W[k][p] (dgrad).
-// ABL (tools/gemm_ablate.hip only; 0 in production): 1 = no tile staging in the loop, 2 = no LDS
+// ABL (tools/pair_lab.hip, tools/pair_probe.hip only; 0 in production): 1 = no tile staging in the loop, 2 = no LDS
 // fragment reads, 4 = no MFMA, 8 = no barrier.
 // ---------------------------------------------------------------------------------------
 // minibatch staging (device side; launched as stage_batch_kernel or as tail blocks of the step's
