@@ -401,7 +401,8 @@ def main():
     if not dp.collective:
         transport = "none (single rank: Adam inside the backward launches, deferred one launch behind each weight gradient)"
     elif eng.has_comm:
-        transport = "in-library RCCL all-reduce per net on the compute stream + flat Adam"
+        transport = ("in-library RCCL all-reduce + flat Adam; default schedule: in line on the compute stream in the "
+                     "world phase, 6 MiB buckets overlapped on the exchange stream in the joint phase")
     else:
         transport = "torch.distributed (%s) bucketed async all-reduce + per-bucket Adam" % dist.get_backend()
     out = {

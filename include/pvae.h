@@ -242,9 +242,12 @@ int pvae_comm_destroy(pvae_ctx* ctx);
  * the ctx has no communicator.  bench.py prints this as `rccl_ranks`, so that the number of ranks
  * in the JSON line comes from RCCL and not from a command-line flag. */
 int pvae_comm_info(pvae_ctx* ctx, int* rank, int* nranks);
-/* Exchange settings of pvae_dp_train_step (same values on every rank): bucket_bytes (default 0 =
- * one bucket per stack, reduced in line on the caller's stream; PVAE_DP_BUCKET_MB at
- * pvae_comm_init overrides the default); test_delay_us > 0 puts a spin kernel of that length in
+/* Exchange settings of pvae_dp_train_step (same values on every rank): bucket_bytes = 0: one bucket per
+ * stack, reduced in line on the caller's stream; > 0: buckets of that size, reduced and applied on the
+ * library's exchange stream while the backward pass continues.  Until this is called (or
+ * PVAE_DP_BUCKET_MB is set at pvae_comm_init) the library chooses per step: in line with one rank and in
+ * the world phase, 6 MiB overlapped buckets in the joint phase with more than one rank (the decoder's
+ * reduction then hides behind the encoder's backward pass); test_delay_us > 0 puts a spin kernel of that length in
  * front of every reduction (ordering tests).  Overlap pays when the backward work still to be
  * launched after a bucket closes exceeds the two hand-offs (long stacks, lookahead > 1, slow
  * links); with the caller on the NULL stream also set GPU_MAX_HW_QUEUES=8 before HIP starts --

@@ -8,8 +8,9 @@ import os
 # ROCm 7 defaults to device kernargs on this GPU; pin it so the behaviour does not depend on that.
 # (Read by the HIP runtime when it initialises, i.e. at the first CUDA/HIP call of the process.)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
-if os.environ.get("PVAE_DP_BUCKET_MB", "0") not in ("", "0", "0.0"):
-    # overlapped gradient exchange asked for: keep its stream off the NULL stream's hardware queue
+if os.environ.get("PVAE_DP_BUCKET_MB", "0") not in ("", "0", "0.0") or int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+    # overlapped gradient exchange (asked for, or the multi-rank default in the joint phase): keep the
+    # library's exchange stream off the NULL stream's hardware queue
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be the first one

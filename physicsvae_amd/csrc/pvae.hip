@@ -154,7 +154,9 @@ struct pvae_ctx {
     hipEvent_t bucket_ready[kMaxBuckets] = {};
     hipEvent_t comm_done = nullptr;
     int exchange_mode = 0;             // PVAE_EXCHANGE_*: all-reduce + replicated Adam, or sharded (ZeRO-1 shaped)
-    int64_t bucket_bytes = 0;          // 0: one bucket per stack, reduced in line on the compute stream
+    int64_t bucket_bytes = -1;         // > 0: bucketed + overlapped; 0: one bucket per stack, in line on the compute
+                                       // stream; -1 (default): chosen per step by auto_bucket_bytes()
+    int64_t bucket_bytes_now = 0;      // what the step in flight uses (exchange_buckets / dp_train_step)
     int comm_test_delay_us = 0;        // tests: a spin kernel in front of every reduction
     Layout L;
     Workspace W;
@@ -1916,14 +1918,24 @@ int pvae_comm_destroy(pvae_ctx* c) {
 // bucket size only, so every rank -- also one whose shard of a ragged last batch is empty --
 // issues the same sequence of reductions.
 struct Bucket { int64_t off, cnt; };
+// Default exchange schedule.  With one rank there is nothing to hide: in line.  With several ranks the
+// all-reduce of a stack (14 MB) takes about as long over xGMI as the backward pass of a stack (~100 us), so
+// in the JOINT phase the decoder's reduction is worth hiding behind the encoder's backward pass even at the
+// ~27 us the two stream hand-offs cost (section 5 of DESIGN.md): 6 MiB buckets on the exchange stream.  The
+// world phase has one stack and ~36 us of backward left after its first bucket closes: in line.
+// A function of (communicator size, phase) only, so every rank chooses the same.
+static int64_t auto_bucket_bytes(const pvae_ctx* c, int phase) {
+    if (c->bucket_bytes >= 0) return c->bucket_bytes;
+    return (c->comm_world > 1 && phase == PVAE_PHASE_JOINT && c->comm_stream) ? (int64_t)6 << 20 : 0;
+}
 static std::vector<Bucket> exchange_buckets(const pvae_ctx* c, int net) {
     const NetLayout& N = c->L.net[net];
     std::vector<Bucket> out;
-    if (c->bucket_bytes <= 0) { out.push_back({N.off, N.count}); return out; }
+    if (c->bucket_bytes_now <= 0) { out.push_back({N.off, N.count}); return out; }
     int64_t end = N.off + N.count;
     for (int i = (int)N.layers.size() - 1; i >= 0; --i) {
         const int64_t lo = i == 0 ? N.off : N.layers[i].w_off;
-        if ((end - lo) * (int64_t)sizeof(float) >= c->bucket_bytes || i == 0) {
+        if ((end - lo) * (int64_t)sizeof(float) >= c->bucket_bytes_now || i == 0) {
             out.push_back({lo, end - lo});
             end = lo;
         }
@@ -2000,7 +2012,8 @@ int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t row
     const int nets[3] = {phase == PVAE_PHASE_WORLD ? PVAE_NET_WM : PVAE_NET_MD,
                          phase == PVAE_PHASE_WORLD ? -1 : (learned_prior ? PVAE_NET_PR : PVAE_NET_TE),
                          phase == PVAE_PHASE_WORLD || !learned_prior ? -1 : PVAE_NET_TE};      // backward order
-    hipStream_t cs = (c->bucket_bytes > 0 && c->comm_stream) ? c->comm_stream : st;
+    c->bucket_bytes_now = auto_bucket_bytes(c, phase);
+    hipStream_t cs = (c->bucket_bytes_now > 0 && c->comm_stream) ? c->comm_stream : st;
     int n_events = 0;
     auto join = [&]() -> int {                 // later work on the caller's stream sees the updated parameters
         if (cs == st) return 0;
