@@ -517,6 +517,31 @@ def main():
         elif dp.collective:
             out["allreduce_us_per_step"] = None                   # torch.distributed transport: not instrumented
 
+    if not a.no_extra:
+        # the minibatch gather on its own (HBM-bound by nature; SURVEY.md 8d: (2 Db + Da) * 4 bytes read and the
+        # same written per sample).  In the training step it rides in the last launch (prefetch), so this
+        # stand-alone launch only ever runs for the first minibatch of a loader: reported for the roofline.
+        n_g = 200
+        first, rows, _ = dp.shard(0, n_win, a.batch)
+        for _ in range(10):
+            eng.gather(first, rows)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(n_g):
+            f_i, r_i, _ = dp.shard(i % max(n_win // (a.batch * dp.world), 1), n_win, a.batch)
+            eng.gather(f_i, r_i)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n_g
+        gbytes = 2.0 * rows * (2 * Db + Da) * 4
+        out["gather_roofline"] = {"bound": "hbm", "achieved": gbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                  "frac": gbytes / (us * 1e-6) / 1e9 / 8000.0, "kernel": "stage_batch_kernel (stand-alone gather)",
+                                  "avg_launch_us": us, "algorithmic_bytes_per_launch": gbytes, "rows": rows,
+                                  "note": "launch-latency bound at this size (%.2f MB per launch); inside the step the "
+                                          "gather of the next minibatch rides in the trailing launch" % (gbytes / 1e6)}
+        eng.invalidate_staging()
+
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, sd, Db, Da, Z, W, D, a.phase, synth_demo)
     if dist.is_initialized():
