@@ -2311,12 +2311,19 @@ int pvae_reparam(pvae_ctx* c, const float* mu_logvar, int32_t rows, const float*
 // (s_memtime) against the 100 MHz wall clock.
 __global__ void __launch_bounds__(256)
 mfma_clock_kernel(const float* __restrict__ src, int n_src, float* __restrict__ sink, int n, unsigned long long* out) {
-    const float a = src[(threadIdx.x + 256 * blockIdx.x) % n_src], b = src[(4099 + threadIdx.x + 17 * blockIdx.x) % n_src];
+    // eight different operand pairs per lane, cycled: consecutive MFMAs see different values, as in a real
+    // contraction (with ONE constant pair the multiplier array hardly switches and the probe reads high)
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        a[u] = src[(threadIdx.x + 256 * blockIdx.x + 4099 * u) % n_src];
+        b[u] = src[(7919 + threadIdx.x + 17 * blockIdx.x + 6151 * u) % n_src];
+    }
     v4f acc[4] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
     const unsigned long long w0 = wall_clock64(), c0 = clock64();
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; i += 2) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[u], 0, 0, 0);
+        for (int u = 0; u < 8; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc[u & 3], 0, 0, 0);
     }
     const unsigned long long c1 = clock64(), w1 = wall_clock64();
     const v4f s4 = (acc[0] + acc[1]) + (acc[2] + acc[3]);
@@ -2333,7 +2340,9 @@ int pvae_mfma_clock_probe(const float* operands, int64_t n_operands, float* scra
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     unsigned long long* d_out = reinterpret_cast<unsigned long long*>(scratch);      // 16 bytes, then the sink
     const int n_src = (int)(n_operands > (1 << 30) ? (1 << 30) : n_operands);
-    for (int rep = 0; rep < 2; ++rep)          // the second run is measured with the clock already settled
+    // the power-management loop reacts over milliseconds: ~10 ms of this load before the launch that is read
+    // (two launches still report the 2.38 GHz the chip starts at; after 2 ms it has settled near 2.17)
+    for (int rep = 0; rep < 30; ++rep)
         hipLaunchKernelGGL(mfma_clock_kernel, dim3(4 * cus), dim3(256), 0, st, operands, n_src, scratch + 64, 2048, d_out);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));

@@ -53,12 +53,17 @@ __global__ void empty_kernel(int) {}
 // and workgroup 0 reports shader cycles (s_memtime) against the 100 MHz wall clock.
 __global__ void __launch_bounds__(256) clock_kernel(const float* __restrict__ src, float* __restrict__ sink, int n,
                                                     unsigned long long* out) {
-    const float a = src[threadIdx.x + 256 * (blockIdx.x & 255)], b = src[4096 + threadIdx.x];
+    float a[8], b[8];              // eight operand pairs per lane, cycled (consecutive MFMAs see different values)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        a[u] = src[(threadIdx.x + 256 * (blockIdx.x & 255) + 4099 * u) & 65535];
+        b[u] = src[(7919 + threadIdx.x + 6151 * u) & 65535];
+    }
     v4f acc[4] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
     const unsigned long long w0 = wall_clock64(), c0 = clock64();
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; i += 2) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[u], 0, 0, 0);
+        for (int u = 0; u < 8; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc[u & 3], 0, 0, 0);
     }
     const unsigned long long c1 = clock64(), w1 = wall_clock64();
     const v4f s4 = (acc[0] + acc[1]) + (acc[2] + acc[3]);
@@ -96,7 +101,7 @@ int main() {
         float* zeros; CK(hipMalloc(&zeros, 65536 * 4)); CK(hipMemset(zeros, 0, 65536 * 4));
         for (int pass = 0; pass < 2; ++pass) {
             const float* src = pass ? zeros : W;
-            for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(clock_kernel, dim3(1024), dim3(256), 0, st, src, dX, 4096, d_out);
+            for (int rep = 0; rep < 12; ++rep) hipLaunchKernelGGL(clock_kernel, dim3(1024), dim3(256), 0, st, src, dX, 4096, d_out);
             CK(hipStreamSynchronize(st));
             unsigned long long h[2]; CK(hipMemcpy(h, d_out, 16, hipMemcpyDeviceToHost));
             const double us = h[1] / 100.0, ghz = h[0] / (us * 1e3), per = (double)h[0] / (4096.0 * 4);
