@@ -641,3 +641,30 @@ def test_cond_rel_windows_match_the_reference_capture(golden, tmp_path):
         T.load_dataset_for_PhysicsVAE([pkl], cond="delta")
     with pytest.raises(NotImplementedError):
         T.save_packed(ds, str(tmp_path / "a.pvd"))
+
+
+def test_bench_classifies_the_kernels_of_a_committed_trace():
+    """bench.py files rocprofv3 kernel names under the library's profiler categories by name; the committed
+    round-2 kernel stats must all land where the HIP-event pass puts them (a renamed kernel would silently
+    drop out of `roofline`)."""
+    import csv
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+    with open(os.path.join(ROOT, "profiles", "r02_kernel_stats_joint.csv"), newline="") as f:
+        for r in csv.DictReader(f):
+            if "pvae::" in r["Name"]:
+                seen[r["Name"].split("(")[0]] = bench._cat_of(r["Name"])
+    assert any(c == 3 for c in seen.values()) and any(c == 0 for c in seen.values())
+    for name, c in seen.items():
+        if "bwd_pair_kernel" in name:
+            assert c == 3, name
+        elif "wgrad_pair_kernel" in name or "gemm_wgrad_reg_kernel" in name:
+            assert c == 2, name
+        elif "<true," in name:
+            assert c == 0, name
+        elif "<false," in name:
+            assert c == 1, name
+    assert bench._cat_of("reparam_kernel(float const*, int)") is None
+    a = bench.parse_args(["--gpus", "2", "--steps", "7"])
+    assert (a.gpus, a.steps, a.phase, a.config) == (2, 7, "joint", "c2")
