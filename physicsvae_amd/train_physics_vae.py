@@ -443,8 +443,8 @@ def main(argv=None):
     if args.checkpoint is None:
         analysis = tune.run(TrainModel, stop={"training_iteration": args.max_iter},
                             checkpoint_freq=args.checkpoint_freq, checkpoint_at_end=True,
-                            config=trainer_config, local_dir=args.local_dir, name=args.name)
-        best = analysis.get_best_logdir(metric="mean_train_loss", mode="min")
+                            config=trainer_config, local_dir=args.local_dir, name=args.name, resume=args.resume)
+        best = analysis.get_best_logdir(metric="training_iteration", mode="max")          # tpv:503-506
         checkpoint = analysis.get_best_checkpoint(logdir=best)
         best_config = next(t.config for t in analysis.trials if t.logdir == best)
     else:

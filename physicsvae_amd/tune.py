@@ -140,8 +140,24 @@ class Analysis:
         return t.checkpoints[-1] if t.checkpoints else None
 
 
+def _latest_checkpoint(logdir):
+    """(iteration, path of model.pth) of the newest checkpoint_<iter> directory under `logdir`, or None."""
+    best = None
+    if os.path.isdir(logdir):
+        for d in os.listdir(logdir):
+            path = os.path.join(logdir, d, "model.pth")
+            if d.startswith("checkpoint_") and d[len("checkpoint_"):].isdigit() and os.path.exists(path):
+                it = int(d[len("checkpoint_"):])
+                if best is None or it > best[0]:
+                    best = (it, path)
+    return best
+
+
 def run(trainable_cls, config=None, stop=None, checkpoint_freq=0, checkpoint_at_end=False,
-        local_dir="~/ray_results", name=None, verbose=1, **_ignored):
+        local_dir="~/ray_results", name=None, verbose=1, resume=False, **_ignored):
+    """`resume=True` (tpv:500, `--resume`): continue the experiment `name` under `local_dir` -- trial i picks
+    up the i-th existing trial directory at its newest checkpoint (weights through `restore`, the
+    iteration counter from the directory name, as Ray does) and runs on to the stop criterion."""
     max_iter = int((stop or {}).get("training_iteration", 1))
     rank, world = _rank_world()
     stamp = time.strftime("%Y%m%d_%H%M%S")
@@ -152,15 +168,26 @@ def run(trainable_cls, config=None, stop=None, checkpoint_freq=0, checkpoint_at_
         stamp = box[0]
     variants = expand_grid(config or {})
     trials = []
+    exp_dir = os.path.join(os.path.expanduser(local_dir), name or trainable_cls.__name__)
+    old = sorted(d for d in os.listdir(exp_dir) if d.startswith("trial_")) if (resume and os.path.isdir(exp_dir)) else []
     for ti, cfg in enumerate(variants):
         tag = "trial_%s" % stamp if len(variants) == 1 else "trial_%s_%02d" % (stamp, ti)
-        logdir = os.path.join(os.path.expanduser(local_dir), name or trainable_cls.__name__, tag)
+        if ti < len(old):
+            tag = old[ti]
+        logdir = os.path.join(exp_dir, tag)
         if rank == 0:
             os.makedirs(logdir, exist_ok=True)
         _barrier()
         trial = trainable_cls(cfg, logdir=logdir)
         rec = Trial(logdir, cfg)
-        log = open(os.path.join(logdir, "result.json"), "w") if rank == 0 else None
+        last = _latest_checkpoint(logdir) if ti < len(old) else None
+        if last is not None:
+            trial.restore(last[1])
+            trial._iteration = max(trial._iteration, last[0])
+            rec.checkpoints.append(last[1])
+            if verbose and rank == 0:
+                print("resumed %s at iteration %d" % (logdir, trial._iteration))
+        log = open(os.path.join(logdir, "result.json"), "a" if last is not None else "w") if rank == 0 else None
         try:
             while trial.training_iteration < max_iter:
                 res = trial.train()

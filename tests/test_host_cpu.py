@@ -668,3 +668,25 @@ def test_bench_classifies_the_kernels_of_a_committed_trace():
     assert bench._cat_of("reparam_kernel(float const*, int)") is None
     a = bench.parse_args(["--gpus", "2", "--steps", "7"])
     assert (a.gpus, a.steps, a.phase, a.config) == (2, 7, "joint", "c2")
+
+
+def test_tune_run_resume_continues_from_the_newest_checkpoint(tmp_path):
+    """`--resume` (tpv:500): a second tune.run on the same experiment name picks the trial directory up at
+    its newest checkpoint -- weights through `restore`, the iteration counter from the directory name --
+    and runs on to the stop criterion, appending to result.json."""
+    from physicsvae_amd import tune
+
+    class Tr(_CountingTrainable):
+        def load_checkpoint(self, path):
+            self.scale = torch.load(path)["scale"] + 100.0         # visible proof that restore ran
+
+    cfg = {"scale": 3.0, "shift": 2.0}
+    a1 = tune.run(Tr, config=cfg, stop={"training_iteration": 2}, checkpoint_at_end=True, local_dir=str(tmp_path),
+                  name="exp", verbose=0)
+    assert len(a1.results) == 2 and a1.checkpoints[-1].endswith(os.path.join("checkpoint_000002", "model.pth"))
+    a2 = tune.run(Tr, config=cfg, stop={"training_iteration": 5}, checkpoint_at_end=True, local_dir=str(tmp_path),
+                  name="exp", verbose=0, resume=True)
+    assert a2.logdir == a1.logdir and [r["training_iteration"] for r in a2.results] == [3, 4, 5]
+    assert a2.results[0]["mean_train_loss"] == pytest.approx(106.0 / 3)          # restored scale 6 + 100, iteration 3
+    assert len(open(os.path.join(a2.logdir, "result.json")).read().splitlines()) == 5
+    assert os.listdir(tmp_path / "exp") == [os.path.basename(a1.logdir)]
