@@ -1223,21 +1223,16 @@ wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2, int n12, S
 
 // (The dgrad half stays on the register-staged body here: with the wave-specialised body the
 // pair needs 512-thread blocks and 64 KB of LDS per workgroup and measured 15 % slower.)
-#ifndef PVAE_PAIR_ORDER
-#define PVAE_PAIR_ORDER 0
-#endif
 template <class EpiD, class EpiW, int ABL = 0>          // ABL: ablation bits of the two bodies (probes only)
 __global__ void __launch_bounds__(256)
 bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, AdamSeg ad) {
     __shared__ __attribute__((aligned(16))) float lds[kPairLdsFloats];
     PVAE_MARK(0, 0);
     PVAE_MARK_HW();
-    int b = blockIdx.x;
-#if PVAE_PAIR_ORDER == 1       // (A/B) weight-gradient workgroups dispatched first: their 4 MB store tail ends earlier
-    if (b < nd + nw) b = b < nw ? nd + b : b - nw;
-#elif PVAE_PAIR_ORDER == 2     // (A/B) the two kinds interleaved in dispatch order
-    if (nd == nw && b < nd + nw) b = (b & 1) ? nd + (b >> 1) : (b >> 1);
-#endif
+    // (dispatch order matters: input-gradient workgroups first.  Weight-gradient workgroups first: world step
+    //  90.0 -> 93.5 us; the two kinds interleaved: 91.8 us -- the older waves of a SIMD win issue arbitration,
+    //  and it is the input gradient whose reduction + store epilogue can hide under the partner's MFMAs)
+    const int b = blockIdx.x;
     if (b < nd) {
         if (gd.tile16) splitk_reg16_body<false, EpiD>(lds, b, gd, ed);
         else splitk_reg_body<false, EpiD, ABL>(lds, b, gd, ed);
