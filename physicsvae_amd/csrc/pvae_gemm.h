@@ -480,7 +480,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
     }
 #endif
     if (wave >= 4) {
-        // ---------------- loader waves ----------------
+        // ---------------- loader waves ----------------  (s_setprio 1 here, or on the compute waves: +-0)
         const int u0 = wave - 4;
         const float* sq[2];
         const float* sp[2];
