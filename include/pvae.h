@@ -49,8 +49,10 @@ enum { PVAE_NET_TE = 0, PVAE_NET_MD = 1, PVAE_NET_WM = 2, PVAE_NET_PR = 3, PVAE_
  *   ZERO_MEAN   "normal_zero_mean_one_std"  KL(N(mu,s^2) || N(0,1))
  *   STATE_MEAN  "normal_state_mean_one_std" KL(N(mu,s^2) || N(mu_p(s_body),1)), mu_p = PR stack (Db -> Z)
  *   HYPERSPHERE "hypersphere_uniform"       encoder emits Z values, z = e/|e|, loss_kl = mean <z, n/|n|>
- * The two non-default kinds need lookahead == 1. */
-enum { PVAE_PRIOR_ZERO_MEAN = 0, PVAE_PRIOR_STATE_MEAN = 1, PVAE_PRIOR_HYPERSPHERE = 2 };
+ *   NONE        latent_prior_type = False   encoder emits Z values that ARE the code: no sampling, no KL term
+ *                                           (rmt:622-623, 815-816; a mode the reference runs: pinned by a capture)
+ * The non-default kinds need lookahead == 1. */
+enum { PVAE_PRIOR_ZERO_MEAN = 0, PVAE_PRIOR_STATE_MEAN = 1, PVAE_PRIOR_HYPERSPHERE = 2, PVAE_PRIOR_NONE = 3 };
 enum { PVAE_PHASE_WORLD = 0, PVAE_PHASE_JOINT = 1 };
 /* loss_fn of the three reconstruction terms (get_loss_fn tm:97-107; trainer key "loss", tpv:257) */
 enum { PVAE_LOSS_MSE = 0, PVAE_LOSS_L1 = 1 };

@@ -40,7 +40,7 @@ def resolve_grid(cfg):
     return cfg
 
 
-def make_reference_trainer(pkl, arch, batch, m_world, num_data=None, lookahead=1, loss="MSE"):
+def make_reference_trainer(pkl, arch, batch, m_world, num_data=None, lookahead=1, loss="MSE", prior=None):
     argv = ["--data_train", pkl, "--batch_size", str(batch), "--max_iter", "1000",
             "--max_iter_world_model", str(m_world), "--latent_dim", str(arch["Z"])]
     T.args = T.arg_parser().parse_args(argv)
@@ -51,6 +51,8 @@ def make_reference_trainer(pkl, arch, batch, m_world, num_data=None, lookahead=1
     cfg["world_model_width"], cfg["world_model_depth"] = arch["wm"]
     cfg["lookahead"] = lookahead              # tpv:277 hard-wires 1; users edit the dict
     cfg["loss"] = loss                        # tpv:257 -> get_loss_fn (tm:97-107)
+    if prior is not None:
+        cfg["latent_prior_type"] = prior      # tpv:262 (a grid leaf upstream; users edit the dict)
     return T.TrainModel(cfg)
 
 
@@ -324,6 +326,45 @@ def case_ingest(name, arch):
     print("wrote", name, {k: int(v) for k, v in fix.items() if k.endswith(("n_windows", "n_batches", "last_batch_size"))})
 
 
+def case_noprior(name, arch, n_ep, n_steps, batch):
+    """`latent_prior_type = False` (rmt:622-623, 815-816): a mode the reference runs -- the encoder's Z outputs
+    are the decoder's code, nothing is sampled, no KL term.  One minibatch, both phases: total, internals, every
+    gradient, plus the state-dict layout (the encoder's last layer has Z rows, not 2Z)."""
+    data = R.synth_demo(seed=0, n_episodes=n_ep, n_steps=n_steps, dim_body=arch["Db"], dim_action=arch["Da"], kind="iid")
+    fix = {}
+    with tempfile.TemporaryDirectory() as td:
+        pkl = os.path.join(td, "demo.pkl")
+        R.write_demo(pkl, data)
+        tr = make_reference_trainer(pkl, arch, batch, m_world=2, prior=False)
+        ref_sd = tr.model.state_dict()
+        fix["sd_keys"] = np.array(list(ref_sd.keys()))
+        fix["sd_shapes"] = np.array([list(v.shape) + [0] * (2 - v.dim()) for v in ref_sd.values()])
+        sd = R.perturb_biases(R.init_state_dict(dict(arch, prior=False), seed=1), seed=3)
+        tr.model.load_state_dict(sd)
+        x, y = next(iter(tr.train_loader))
+        for world in (True, False):
+            tag = "world" if world else "joint"
+            m = tr.model
+            m.set_learnable_task_encoder(not world)
+            m.set_learnable_motor_decoder(not world)
+            m.set_learnable_world_model(world)
+            tr.read_loss_fn_coeff(world=world)
+            m.train()
+            tr.optimizer.zero_grad()
+            loss = tr.compute_loss(y, x)
+            loss.backward()
+            fix[tag + "_total"] = loss.detach().numpy()
+            fix[tag + "_z"] = m._cur_task_encoder_variable.detach().numpy()
+            fix[tag + "_future_state"] = m._cur_future_state.detach().numpy()
+            grads = grads_of(m)
+            fix[tag + "_grad_keys"] = np.array(list(grads.keys()))
+            for k, g in grads.items():
+                fix["%s_grad::%s" % (tag, k)] = g.numpy()
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"], n_ep, n_steps, batch])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
+    print("wrote", name, "world", fix["world_total"], "joint", fix["joint_total"])
+
+
 def case_ingest_rel(name, arch):
     """`load_dataset_for_PhysicsVAE(cond="rel")` of the reference itself (tpv:149-150: the second half of
     x is s_{t+1} - s_t; the trainer never asks for it, so it is called directly): digests of the whole X / Y
@@ -429,6 +470,7 @@ def main():
         "anchor_c1": lambda: case_anchor("anchor_c1"),
         "ingest_tiny": lambda: case_ingest("ingest_tiny", tiny),
         "ingest_rel_tiny": lambda: case_ingest_rel("ingest_rel_tiny", tiny),
+        "noprior_tiny": lambda: case_noprior("noprior_tiny", tiny, 2, 14, 8),
         "ckpt_interop_tiny": lambda: case_checkpoint_interop("ckpt_interop_tiny", tiny),
         "look3_tiny": lambda: case_lookahead("look3_tiny", tiny, 2, 15, 8, lookahead=3, full=True),
         "look2_c1": lambda: case_lookahead("look2_c1", c1, 2, 200, 64, lookahead=2, full=False),

@@ -67,6 +67,9 @@ NETS = ("_task_encoder", "_motor_decoder", "_world_model", "_value_branch")
 #     `latent_prior_noise` only gates n (False: u = 0, the term vanishes).
 # --------------------------------------------------------------------------------------
 PRIORS = ("normal_zero_mean_one_std", "normal_state_mean_one_std", "hypersphere_uniform")
+# `latent_prior_type = False` (rmt:622-623, 815-816; tpv:384 `if self.latent_prior_type and ...`) is a mode the
+# reference DOES run: the encoder emits Z values that go to the decoder as they are, no sampling, no KL term.
+# It is restated below and pinned by a capture of the reference (tests/golden/noprior_tiny.npz).
 
 
 # --------------------------------------------------------------------------------------
@@ -77,7 +80,7 @@ def make_arch(dim_body, dim_action, latent=32, te=(256, 2), md=(512, 3), wm=(102
     """Widths/depths as `gen_layers(width, depth)` expands them (tpv:180-192, 290-311);
     defaults are PhysicsVAE.DEFAULT_CONFIG (rmt:462-510).  `prior` / `pr`: see PRIORS above
     (`pr` = (width, depth) of the learned prior, default = the task encoder's)."""
-    assert prior in PRIORS, prior
+    assert prior in PRIORS or prior is False, prior
     return dict(Db=int(dim_body), Da=int(dim_action), Z=int(latent),
                 te=tuple(te), md=tuple(md), wm=tuple(wm), vb=tuple(vb), prior=prior,
                 pr=tuple(pr) if pr is not None else tuple(te))
@@ -97,7 +100,7 @@ def net_layer_dims(arch):
         return dims
 
     prior = arch.get("prior", PRIORS[0])
-    te_out = Z if prior == "hypersphere_uniform" else 2 * Z                    # rmt:618-621
+    te_out = Z if (prior == "hypersphere_uniform" or prior is False) else 2 * Z   # rmt:618-623
     learned = [("_latent_prior", chain(Db, arch.get("pr", arch["te"]), Z))] if prior == PRIORS[1] else []
     return OrderedDict(learned + [                                             # rmt:627-635 comes first
         ("_task_encoder", chain(2 * Db, arch["te"], te_out)),      # rmt:638-644, 612-613
@@ -326,7 +329,10 @@ class RefModel(nn.Module):
         Db, Da, Z = self.arch["Db"], self.arch["Da"], self.arch["Z"]
         obs = obs.float()
         h = self._task_encoder(obs)                                   # rmt:788-793
-        if self.prior == "hypersphere_uniform":                       # rmt:810-814, fixed as specified above
+        if self.prior is False:                                       # rmt:815-816: the code is the encoder output
+            self.cur_mu, self.cur_logvar, self.cur_prior_mu = h, None, None
+            z = h
+        elif self.prior == "hypersphere_uniform":                       # rmt:810-814, fixed as specified above
             self.cur_mu, self.cur_logvar = nn.functional.normalize(h), None
             z = self.cur_mu
             if self.latent_prior_noise:
@@ -396,7 +402,9 @@ def compute_loss(model, x, y, coeffs, loss="MSE"):
             if coeffs["vae_kl_coeff"] > 0.0:
                 mu, lv = model.cur_mu, model.cur_logvar
                 prior = getattr(model, "prior", PRIORS[0])
-                if prior == PRIORS[0]:                                # tpv:385-389
+                if prior is False:                                    # tpv:384: `if self.latent_prior_type and ...`
+                    pass
+                elif prior == PRIORS[0]:                              # tpv:385-389
                     loss_kl = loss_kl + torch.mean(-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp(), dim=1), dim=0)
                 elif prior == PRIORS[1]:                              # tpv:390-403 as specified above
                     d = mu - model.cur_prior_mu

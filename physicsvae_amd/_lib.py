@@ -26,7 +26,7 @@ NET_TE, NET_MD, NET_WM, NET_PR = 0, 1, 2, 3
 NUM_NETS = 4
 NET_NAMES = {NET_TE: "_task_encoder", NET_MD: "_motor_decoder", NET_WM: "_world_model", NET_PR: "_latent_prior"}
 # latent_prior_type (rmt:614-635) -> pvae_config.prior_kind
-PRIOR_KINDS = {"normal_zero_mean_one_std": 0, "normal_state_mean_one_std": 1, "hypersphere_uniform": 2}
+PRIOR_KINDS = {"normal_zero_mean_one_std": 0, "normal_state_mean_one_std": 1, "hypersphere_uniform": 2, False: 3}
 PHASE_WORLD, PHASE_JOINT = 0, 1
 FLAG_FUSED_ADAM, FLAG_NO_BACKWARD = 1, 2
 ABI_VERSION = 3

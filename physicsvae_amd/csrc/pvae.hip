@@ -368,7 +368,9 @@ __global__ void __launch_bounds__(256)
 sphere_kernel(const float* __restrict__ te_out, int ldte, const float* __restrict__ eps_in,
               float* __restrict__ eps_used, float* __restrict__ md_in, int ld_md, int Db, int Z, int rows,
               int rows_pad, int noise, unsigned long long seed, unsigned long long offset,
-              float* __restrict__ partial, float* __restrict__ z_dense) {
+              float* __restrict__ partial, float* __restrict__ z_dense, int normalize) {
+    // normalize == 0: latent_prior_type = False (rmt:815-816) -- z = e, nothing sampled, no loss term
+    if (!normalize) noise = 0;
     __shared__ float part[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + wave;
@@ -387,7 +389,7 @@ sphere_kernel(const float* __restrict__ te_out, int ldte, const float* __restric
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { e2 += __shfl_xor(e2, o, 64); n2 += __shfl_xor(n2, o, 64); }
-        const float ie = 1.0f / fmaxf(sqrtf(e2), 1e-12f), in_ = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+        const float ie = normalize ? 1.0f / fmaxf(sqrtf(e2), 1e-12f) : 1.0f, in_ = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
         for (int c = lane; c < Z; c += 64) {
             float z = 0.f, u = 0.f;
             if (r < rows) {
@@ -411,7 +413,7 @@ sphere_kernel(const float* __restrict__ te_out, int ldte, const float* __restric
 __global__ void __launch_bounds__(256)
 sphere_bwd_kernel(const float* __restrict__ d_md_in, int ld_md, int Db, const float* __restrict__ te_out, int ldte,
                   const float* __restrict__ u_used, float* __restrict__ dz_te, int ld_dz, int rows, int rows_pad,
-                  int Z, float kl_scale) {
+                  int Z, float kl_scale, int normalize) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + wave;
     if (r >= rows_pad) return;
@@ -424,6 +426,11 @@ sphere_bwd_kernel(const float* __restrict__ d_md_in, int ld_md, int Db, const fl
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o, 64);
     const float ie = 1.0f / fmaxf(sqrtf(e2), 1e-12f);
+    if (!normalize) {                          // z = e: the decoder's input gradient is the encoder's output gradient
+        for (int c = lane; c < ld_dz; c += 64)
+            dz_te[(size_t)r * ld_dz + c] = (r < rows && c < Z) ? d_md_in[(size_t)r * ld_md + Db + c] : 0.f;
+        return;
+    }
     if (r < rows)
         for (int c = lane; c < Z; c += 64) {
             const float g = d_md_in[(size_t)r * ld_md + Db + c] + kl_scale * u_used[(size_t)r * Z + c];
@@ -1206,7 +1213,7 @@ int pvae_set_batch(pvae_ctx* c, const float* x, const float* y, int32_t rows, vo
 // The sampler of the configured prior kind (rmt:795-819): reparam_kernel (N(mu, s^2); KL to N(0, I) or to
 // the learned prior mean mu_p) or sphere_kernel (unit-sphere encoder).  `partial` may be null (rollout).
 static int sampler_grid(const pvae_ctx* c, int rows_pad) {
-    if (c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE) return rows_pad / 4;
+    if (c->L.cfg.prior_kind >= PVAE_PRIOR_HYPERSPHERE) return rows_pad / 4;
     const int Z = c->L.cfg.latent;
     return (rows_pad * Z + 255) / 256 < 64 ? (rows_pad * Z + 255) / 256 : 64;
 }
@@ -1215,9 +1222,10 @@ static int launch_sampler(pvae_ctx* c, const float* te_out, int ldte, const floa
                           unsigned long long offset, float* partial, float* z_dense, const float* mu_p, int ldmp,
                           hipStream_t st) {
     const int Db = c->L.cfg.dim_body, Z = c->L.cfg.latent;
-    if (c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE) {
+    if (c->L.cfg.prior_kind >= PVAE_PRIOR_HYPERSPHERE) {
         hipLaunchKernelGGL(sphere_kernel, dim3((rows_pad + 3) / 4), dim3(256), 0, st, te_out, ldte, eps, eps_used, md_in,
-                           ld_md, Db, Z, rows, rows_pad, noise, seed, offset, partial, z_dense);
+                           ld_md, Db, Z, rows, rows_pad, noise, seed, offset, partial, z_dense,
+                           c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE ? 1 : 0);
     } else {
         hipLaunchKernelGGL(reparam_kernel, dim3(sampler_grid(c, rows_pad)), dim3(256), 0, st, te_out, ldte, eps, eps_used,
                            md_in, ld_md, Db, Z, rows, rows_pad, noise, seed, offset, partial, z_dense, mu_p, ldmp);
@@ -1253,10 +1261,11 @@ static int step_shape(pvae_ctx* c, int phase, int rows, const pvae_step_params* 
     (void)Z;
     S.nparts_a = S.rows_pad < 64 ? S.rows_pad : 64;
     S.cyc_grad = backward && phase == PVAE_PHASE_JOINT && sp->cycle_coeff > 0.0f;
-    S.kl_active = phase == PVAE_PHASE_JOINT && sp->kl_coeff > 0.0f && sp->a_rec_coeff > 0.0f;   // tpv:381-384
+    S.kl_active = phase == PVAE_PHASE_JOINT && sp->kl_coeff > 0.0f && sp->a_rec_coeff > 0.0f &&   // tpv:381-384
+                  c->L.cfg.prior_kind != PVAE_PRIOR_NONE;                 // (`if self.latent_prior_type and ...`)
     // (the sphere's backward needs a dot product over a whole latent row, which no tile epilogue sees)
     S.seed_sampler = backward && phase == PVAE_PHASE_JOINT && c->W.L == 1 && c->pair_launch &&
-                     c->L.cfg.prior_kind != PVAE_PRIOR_HYPERSPHERE;
+                     c->L.cfg.prior_kind < PVAE_PRIOR_HYPERSPHERE;
     S.seed_action = S.seed_sampler && S.cyc_grad;
     float* part = c->ws + c->W.loss_part;
     memset(&S.lf, 0, sizeof(S.lf));
@@ -1382,7 +1391,8 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
     const NetLayout* PR = &c->L.net[PVAE_NET_PR];
     const NetWork* wpr = &c->W.net[PVAE_NET_PR];
     const bool learned_prior = !PR->layers.empty();
-    const bool sphere = c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE;
+    const bool sphere = c->L.cfg.prior_kind >= PVAE_PRIOR_HYPERSPHERE;     // (incl. NONE: the same kernel, not normalising)
+    const int sphere_norm = c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE ? 1 : 0;
     const int ldo_md = MD->layers.back().n_out_pad, ldo_te = TE->layers.back().n_out_pad;
     const float ga = sp->a_rec_coeff * S.gs / (S.Bg * Da);
     // The two gradient hand-overs between stacks live in the epilogue of the consuming stack's
@@ -1445,7 +1455,7 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
             if (sphere) {
                 hipLaunchKernelGGL(sphere_bwd_kernel, dim3((rows_pad + 3) / 4), dim3(256), 0, st, w + wmd->d_in,
                                    MD->layers[0].ld, Db, w + wte->act.back(), TE->layers.back().n_out_pad, w + c->W.eps,
-                                   w + wte->dz.back(), TE->layers.back().n_out_pad, rows, rows_pad, Z, kls);
+                                   w + wte->dz.back(), TE->layers.back().n_out_pad, rows, rows_pad, Z, kls, sphere_norm);
             } else {
                 hipLaunchKernelGGL(reparam_bwd_kernel, dim3((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256), dim3(256), 0,
                                    st, w + wmd->d_in, MD->layers[0].ld, Db, w + wte->act.back(), TE->layers.back().n_out_pad,
@@ -2147,7 +2157,7 @@ int pvae_read_tensor(pvae_ctx* c, int what, float* dst, int32_t rows, void* stre
     switch (what) {
         case 0: src = c->ws + wte.act.back(); ld = c->L.net[PVAE_NET_TE].layers.back().n_out_pad; col0 = 0; nc = Z; break;
         case 1:
-            if (c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE) return fail(-1, "the hypersphere encoder has no logvar");
+            if (c->L.cfg.prior_kind >= PVAE_PRIOR_HYPERSPHERE) return fail(-1, "this encoder has no logvar");
             src = c->ws + wte.act.back(); ld = c->L.net[PVAE_NET_TE].layers.back().n_out_pad; col0 = Z; nc = Z; break;
         case 2: src = c->ws + c->W.net[PVAE_NET_MD].in; ld = c->L.net[PVAE_NET_MD].layers[0].ld; col0 = Db; nc = Z; break;
         case 3: src = c->ws + c->W.net[PVAE_NET_MD].act.back(); ld = c->L.net[PVAE_NET_MD].layers.back().n_out_pad; col0 = 0; nc = Da; break;
@@ -2175,7 +2185,7 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
     hipStream_t st = (hipStream_t)stream;
     if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
     static const bool fused_rollout = [] { const char* e = getenv("PVAE_ROLLOUT_FUSED"); return !(e && e[0] == '0'); }();
-    if (rows <= 4 && fused_rollout && c->L.cfg.prior_kind != PVAE_PRIOR_HYPERSPHERE) {
+    if (rows <= 4 && fused_rollout && c->L.cfg.prior_kind < PVAE_PRIOR_HYPERSPHERE) {
         // latency path of the control loop (rmt:742-771 at B = 1): no staging / sampler / copy launches, the
         // input panels of a staged training minibatch are not touched
         const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
@@ -2298,7 +2308,7 @@ int pvae_reparam(pvae_ctx* c, const float* mu_logvar, int32_t rows, const float*
     const int Z = c->L.cfg.latent;
     const int ld_md = c->L.net[PVAE_NET_MD].layers[0].ld;
     c->staged_rows = 0;
-    const int ldte = c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE ? Z : 2 * Z;       // dense [rows][n_out of the encoder]
+    const int ldte = c->L.cfg.prior_kind >= PVAE_PRIOR_HYPERSPHERE ? Z : 2 * Z;       // dense [rows][n_out of the encoder]
     // pad rows are not touched: `rows` doubles as rows_pad (the sphere kernel rounds its grid up itself)
     return launch_sampler(c, mu_logvar, ldte, eps, c->ws + c->W.eps, c->ws + c->W.net[PVAE_NET_MD].in, ld_md, rows, rows,
                           noise ? 1 : 0, (unsigned long long)rng_seed, (unsigned long long)rng_offset, (float*)nullptr,

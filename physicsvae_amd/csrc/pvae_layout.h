@@ -45,7 +45,7 @@ inline Layout make_layout(const pvae_config& c) {
     if (c.te_depth > 15 || c.md_depth > 15 || c.wm_depth > 15) { L.why = "depth > 15 unsupported"; return L; }
     if (c.max_batch <= 0 || c.max_batch > 65536) { L.why = "max_batch out of range"; return L; }
     if (c.lookahead < 1 || c.lookahead > 64) { L.why = "lookahead must be in [1, 64]"; return L; }
-    if (c.prior_kind < 0 || c.prior_kind > PVAE_PRIOR_HYPERSPHERE) { L.why = "unknown prior_kind"; return L; }
+    if (c.prior_kind < 0 || c.prior_kind > PVAE_PRIOR_NONE) { L.why = "unknown prior_kind"; return L; }
     if (c.prior_kind != PVAE_PRIOR_ZERO_MEAN && c.lookahead != 1) {
         L.why = "latent priors other than normal_zero_mean_one_std need lookahead == 1";
         return L;
@@ -55,7 +55,7 @@ inline Layout make_layout(const pvae_config& c) {
     const int Db = c.dim_body, Da = c.dim_action, Z = c.latent;
     // rmt:638-644 (618-621: Z outputs on the hypersphere), 646-668, 682-689, 627-635
     const int ins[PVAE_NUM_NETS] = {2 * Db, Db + Z, Db + Da, Db};
-    const int outs[PVAE_NUM_NETS] = {c.prior_kind == PVAE_PRIOR_HYPERSPHERE ? Z : 2 * Z, Da, Db, Z};
+    const int outs[PVAE_NUM_NETS] = {c.prior_kind >= PVAE_PRIOR_HYPERSPHERE ? Z : 2 * Z, Da, Db, Z};
     const int widths[PVAE_NUM_NETS] = {c.te_width, c.md_width, c.wm_width, c.pr_width};
     const int depths[PVAE_NUM_NETS] = {c.te_depth, c.md_depth, c.wm_depth, c.pr_depth};
     int64_t off = 0;

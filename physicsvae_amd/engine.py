@@ -26,7 +26,7 @@ class Arch:
 
     @property
     def te_out(self):
-        return self.Z if self.prior == "hypersphere_uniform" else 2 * self.Z           # rmt:618-621
+        return self.Z if (self.prior == "hypersphere_uniform" or self.prior is False) else 2 * self.Z   # rmt:618-623
 
     def config(self, max_batch, lookahead=1):
         return _lib.Config(self.Db, self.Da, self.Z, self.te[0], self.te[1], self.md[0],

@@ -193,7 +193,6 @@ class PhysicsVAE(nn.Module):
         if cfg["log_std_type"] not in ("constant", "state_independent"):
             raise NotImplementedError(cfg["log_std_type"])                      # rmt:182-183
         if cfg["latent_prior_type"] not in PRIOR_KINDS:
-            # (`False` = no prior, rmt:622-623, is never set by the trainer and is not built)
             raise NotImplementedError("Unknown latent_prior_type:%s" % (cfg["latent_prior_type"],))    # rmt:624-625
         if cfg["task_encoder_inputs"] != ["body", "task"] or cfg["motor_decoder_inputs"] != ["body", "task"]:
             raise NotImplementedError("task-encoder / motor-decoder inputs must be ['body','task']")
@@ -362,8 +361,9 @@ class PhysicsVAE(nn.Module):
         """mu / logvar of the last fused forward, read back from the engine's panels on first use."""
         if getattr(self, "_lazy", None) is not None and self._mu is None:
             rows = self._lazy[1]
-            self._mu = self.engine.read("z" if self._latent_prior_type == "hypersphere_uniform" else "mu", rows)
-            self._logvar = None if self._latent_prior_type == "hypersphere_uniform" else self.engine.read("logvar", rows)
+            no_logvar = self._latent_prior_type in ("hypersphere_uniform", False)
+            self._mu = self.engine.read("z" if no_logvar else "mu", rows)
+            self._logvar = None if no_logvar else self.engine.read("logvar", rows)
         return self._mu if name == "mu" else self._logvar
 
     @property
@@ -386,6 +386,9 @@ class PhysicsVAE(nn.Module):
         Z = self._task_encoder_output_dim
         obs = obs.to(self.engine.device)
         h = self.engine.net_forward(NET_TE, obs)
+        if self._latent_prior_type is False:                        # rmt:815-816: the encoder output is the code
+            z_task = self._reparameterize(h, None)                  # (a copy through the sampler kernel, not normalised)
+            return obs[..., : self.dim_state_body], z_task, state_cnt
         if self._latent_prior_type == "hypersphere_uniform":        # rmt:810-814 (z = mu: oracle PRIORS)
             z_task = self._reparameterize(h, eps)                   # e / |e|; the unit prior sample lands in "eps"
             self._cur_task_encoder_mu, self._cur_task_encoder_logvar = z_task, None

@@ -199,3 +199,54 @@ def test_module_forward_matches_the_specification(prior, rows):
     assert max_err_scaled(m._cur_latent_prior_mu.cpu(), ref.cur_prior_mu) < 2e-5
     a_hat, s2, z = tr.engine.infer(obs.to(DEV), eps=e.to(DEV), noise=True, want_s2=True)
     assert max_err_scaled(a_hat.cpu(), want[:, : arch["Da"]]) < 2e-5 and max_err_scaled(z.cpu(), ref.cur_z) < 2e-5
+
+
+@pytest.mark.parametrize("paired", ["1", "0"])
+def test_no_prior_mode_matches_the_reference_capture(golden, paired, monkeypatch):
+    """latent_prior_type = False -- a mode the reference runs (rmt:622-623, 815-816): the encoder's Z outputs go
+    to the decoder as they are, no sampling, no KL term.  Total, internals and every gradient of one minibatch
+    against the capture of the reference itself (`noprior_tiny.npz`) and against the oracle, both phases."""
+    from util import arch_from_meta
+    monkeypatch.setenv("PVAE_PAIR", paired)
+    g = golden("noprior_tiny")
+    arch = dict(arch_from_meta(g["meta"]), prior=False)
+    n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
+    data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="iid")
+    X, Y = R.build_windows(data)
+    x, y = next(iter(R.make_loader(X, Y, batch)))
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    tr = make_trainer(arch, data, batch, device=DEV)
+    tr.model.load_state_dict(sd)
+    eng = tr.engine
+    for world in (True, False):
+        tag = "world" if world else "joint"
+        c = R.phase_coeffs(world)
+        sp = make_step_params(lr=5e-4, a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"], s_rec=c["s_rec_coeff"],
+                              cyc=c["vae_cycle_coeff"], global_rows=batch)
+        eng.set_batch(x, y)
+        eng.grads.fill_(float("nan"))
+        loss = eng.forward_backward(_lib.PHASE_WORLD if world else _lib.PHASE_JOINT, batch, sp, fused_adam=False).cpu()
+        assert float(loss[0]) == pytest.approx(float(g[tag + "_total"]), rel=1e-5)
+        assert float(loss[2]) == 0.0                                           # no KL term
+        want = R.loss_and_grads(arch, sd, x, y, None, world)
+        assert float(loss[0]) == pytest.approx(float(want["total"]), rel=1e-5)
+        if not world:
+            assert max_err_scaled(eng.read("z", batch).cpu(), g["joint_z"]) < 2e-5
+            assert max_err_scaled(eng.read("s2_hat", batch).cpu(), g["joint_future_state"]) < 2e-5
+        gv = eng.named_views(eng.grads)
+        assert sorted(str(k) for k in g[tag + "_grad_keys"]) == sorted(want["grads"].keys())
+        for k in g[tag + "_grad_keys"]:
+            k = str(k)
+            ref = torch.from_numpy(g["%s_grad::%s" % (tag, k)])
+            assert max_err_scaled(gv[k].cpu(), ref) < 1e-4, k
+    # module forward: the code is the encoder output
+    ref_m = R.RefModel(arch)
+    ref_m.load_state_dict(sd)
+    obs = x[:3, 0, :]
+    with torch.no_grad():
+        want_logits = ref_m(obs)
+    logits, _ = tr.model.forward({"obs_flat": obs.to(DEV)}, [], None)
+    assert max_err_scaled(logits.cpu(), want_logits) < 2e-5
+    assert max_err_scaled(tr.model.task_encoder_variable().cpu(), ref_m.cur_z) < 2e-5
+    r1, r2 = tr.train(), tr.train()
+    assert np.isfinite(r1["mean_train_loss"]) and np.isfinite(r2["mean_train_loss"])

@@ -581,7 +581,8 @@ def test_prior_kinds_layout_and_state_dict():
     n0 = lib.pvae_num_layers(C.byref(_lib.Config(*base, 0, 0, 0)))
     assert lib.pvae_num_layers(C.byref(_lib.Config(*base, 1, 12, 1))) == n0 + 2          # + prior stack 7 -> 12 -> 4
     assert lib.pvae_num_layers(C.byref(_lib.Config(*base, 2, 0, 0))) == n0
-    assert lib.pvae_num_layers(C.byref(_lib.Config(*base, 3, 0, 0))) < 0                 # unknown kind
+    assert lib.pvae_num_layers(C.byref(_lib.Config(*base, 3, 0, 0))) == n0               # no prior (rmt:622-623)
+    assert lib.pvae_num_layers(C.byref(_lib.Config(*base, 4, 0, 0))) < 0                 # unknown kind
     assert lib.pvae_num_layers(C.byref(_lib.Config(7, 3, 4, 16, 2, 24, 2, 32, 2, 8, 2, 1, 12, 1))) < 0   # needs lookahead 1
     assert b"lookahead" in lib.pvae_last_error()
     # arena order TE | MD | PR | WM, densely packed; the hypersphere encoder emits Z values, not 2Z
@@ -690,3 +691,19 @@ def test_tune_run_resume_continues_from_the_newest_checkpoint(tmp_path):
     assert a2.results[0]["mean_train_loss"] == pytest.approx(106.0 / 3)          # restored scale 6 + 100, iteration 3
     assert len(open(os.path.join(a2.logdir, "result.json")).read().splitlines()) == 5
     assert os.listdir(tmp_path / "exp") == [os.path.basename(a1.logdir)]
+
+
+def test_no_prior_mode_layout_matches_the_reference_capture(golden):
+    """latent_prior_type = False (rmt:622-623): the reference builds an encoder with Z outputs; same keys and
+    shapes here, and its state dict round-trips through the arena views."""
+    g = golden("noprior_tiny")
+    arch = dict(arch_from_meta(g["meta"]), prior=False)
+    n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
+    data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="iid")
+    tr = make_trainer(arch, data, batch, device="cpu")
+    sd = tr.model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["sd_keys"]]
+    for (k, v), shp in zip(sd.items(), g["sd_shapes"]):
+        assert list(v.shape) == [int(x) for x in shp[: v.dim()]], k
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == R.state_dict_spec(arch)
+    assert tr.latent_prior_type is False

@@ -6,6 +6,7 @@ import torch
 
 from oracle import refpath as R
 from physicsvae_amd import train_physics_vae as T
+from physicsvae_amd.tune import grid_search as tune_grid
 
 
 def arch_from_meta(meta):
@@ -24,10 +25,12 @@ def make_trainer(arch, data, batch, m_world=2, device=None, eps_fn=None, lr_step
             "--TE_width", str(arch["te"][0]), "--TE_depth", str(arch["te"][1]),
             "--MD_width", str(arch["md"][0]), "--MD_depth", str(arch["md"][1]),
             "--world_model_width", str(arch["wm"][0]), "--world_model_depth", str(arch["wm"][1])]
-    if arch.get("prior", R.PRIORS[0]) != R.PRIORS[0]:
+    if arch.get("prior", R.PRIORS[0]) not in (R.PRIORS[0], False):
         argv += ["--prior", arch["prior"]]
     T.args = T.arg_parser().parse_args(argv)
     cfg = T.get_trainer_config(T.args)
+    if arch.get("prior", R.PRIORS[0]) is False:           # (not reachable from the CLI, upstream neither: a dict edit)
+        cfg["latent_prior_type"] = tune_grid([False])
     if arch.get("prior") == R.PRIORS[1] and tuple(arch["pr"]) != tuple(arch["te"]):
         cfg["model"]["custom_model_config"]["latent_prior_layers"] = T.gen_layers(arch["pr"][0], arch["pr"][1])
     cfg["lr_schedule_params"] = {"step_size": lr_step, "gamma": 0.7}
