@@ -589,13 +589,19 @@ gemv_rollout_kernel(RolloutIn in, int rows, const float* __restrict__ W, int ldw
         const int k = lane * 4 + 256 * j;
         wpre[j] = k < K ? *reinterpret_cast<const v4f*>(wrow + k) : v4f{0.f, 0.f, 0.f, 0.f};
     }
-    for (int i = tid; i < R * K; i += 256) {
+    if (in.kind == 0) {                   // hidden layers: whole padded panel rows, 16 bytes per load
+        const int kq = K >> 2;
+        for (int i = tid; i < R * kq; i += 256) {
+            const int r = i / kq, k = (i - r * kq) * 4;
+            *reinterpret_cast<v4f*>(xs + r * K + k) =
+                r < rows ? *reinterpret_cast<const v4f*>(in.a + (size_t)r * in.lda + k) : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    for (int i = tid; in.kind != 0 && i < R * K; i += 256) {
         const int r = i / K, k = i - r * K;
         float v = 0.f;
         if (r < rows) {
-            if (in.kind == 0) {
-                v = in.a[(size_t)r * in.lda + k];
-            } else if (k < in.Ka) {
+            if (k < in.Ka) {
                 v = in.a[(size_t)r * in.lda + k];
             } else if (k < in.Ka + in.Kb) {
                 const int j = k - in.Ka;
