@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PVAE_ABI_VERSION 3
+#define PVAE_ABI_VERSION 4
 
 typedef struct pvae_ctx pvae_ctx;
 
@@ -57,6 +57,10 @@ enum { PVAE_PHASE_WORLD = 0, PVAE_PHASE_JOINT = 1 };
 /* loss_fn of the three reconstruction terms (get_loss_fn tm:97-107; trainer key "loss", tpv:257) */
 enum { PVAE_LOSS_MSE = 0, PVAE_LOSS_L1 = 1 };
 
+/* hidden-layer activations (pvae_config.act_kind); "swish" needs the pre-activation in the backward
+ * pass and is not offered */
+enum { PVAE_ACT_RELU = 0, PVAE_ACT_TANH = 1, PVAE_ACT_SIGMOID = 2, PVAE_ACT_ELU = 3 };
+
 /* flags for pvae_forward_backward */
 enum {
     PVAE_FLAG_FUSED_ADAM = 1, /* apply Adam inside the backward launches (1 GPU): in the weight-
@@ -69,7 +73,7 @@ enum {
 /* Architecture.  Mirrors the dict keys of tpv:247-286 / gen_layers tpv:180-192:
  * TE: 2*Db -> te_width x te_depth -> 2*Z (Z with PVAE_PRIOR_HYPERSPHERE) ; MD: Db+Z -> ... -> Da ;
  * WM: Db+Da -> ... -> Db ; PR (PVAE_PRIOR_STATE_MEAN): Db -> pr_width x pr_depth -> Z.
- * ReLU after every hidden layer, linear output layer. */
+ * act_kind after every hidden layer (ReLU unless set), linear output layer. */
 typedef struct pvae_config {
     int32_t dim_body;   /* Db */
     int32_t dim_action; /* Da */
@@ -82,6 +86,8 @@ typedef struct pvae_config {
                            367-428); sizes the workspace (L blocks per panel) */
     int32_t prior_kind; /* PVAE_PRIOR_* (0 = the reference's working default)                 */
     int32_t pr_width, pr_depth; /* learned prior stack (PVAE_PRIOR_STATE_MEAN only; else ignored) */
+    int32_t act_kind;   /* PVAE_ACT_*: hidden activation of every stack = the trainer's "act_fn" (tpv:262;
+                           get_activation_fn rmt:30-46).  0 = relu, so a zeroed field keeps the default */
 } pvae_config;
 
 typedef struct pvae_layer_info {
@@ -112,7 +118,8 @@ typedef struct pvae_step_params {
     uint64_t rng_seed;     /* Philox key when eps == NULL      */
     uint64_t rng_offset;   /* (global step, first global row) -> counter */
     int32_t loss_kind;     /* PVAE_LOSS_MSE (nn.MSELoss, the trainer's setting) or PVAE_LOSS_L1 */
-    int32_t reserved;
+    float weight_decay;    /* torch.optim.Adam's L2 term: g <- g + weight_decay * p before the moments
+                              (tm:119-122; the trainer's config holds 0.0, tpv:253) */
 } pvae_step_params;
 
 /* ---- layout queries (pure host arithmetic, no GPU needed) --------------------------- */

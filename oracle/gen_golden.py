@@ -40,7 +40,8 @@ def resolve_grid(cfg):
     return cfg
 
 
-def make_reference_trainer(pkl, arch, batch, m_world, num_data=None, lookahead=1, loss="MSE", prior=None):
+def make_reference_trainer(pkl, arch, batch, m_world, num_data=None, lookahead=1, loss="MSE", prior=None,
+                           weight_decay=None):
     argv = ["--data_train", pkl, "--batch_size", str(batch), "--max_iter", "1000",
             "--max_iter_world_model", str(m_world), "--latent_dim", str(arch["Z"])]
     T.args = T.arg_parser().parse_args(argv)
@@ -53,6 +54,9 @@ def make_reference_trainer(pkl, arch, batch, m_world, num_data=None, lookahead=1
     cfg["loss"] = loss                        # tpv:257 -> get_loss_fn (tm:97-107)
     if prior is not None:
         cfg["latent_prior_type"] = prior      # tpv:262 (a grid leaf upstream; users edit the dict)
+    cfg["act_fn"] = arch.get("act", "relu")   # tpv:262 -> gen_layers(act_hidden=...) for every stack
+    if weight_decay is not None:
+        cfg["weight_decay"] = weight_decay    # tpv:253 -> torch.optim.Adam(weight_decay=...) (tm:119-122)
     return T.TrainModel(cfg)
 
 
@@ -74,6 +78,12 @@ class EpsPatch:
 
     def __exit__(self, *exc):
         torch.randn_like = self.orig
+
+
+def act_meta(arch):
+    """Extra entry of fixtures captured with an edited "act_fn" (files of the relu default stay as they were)."""
+    act = arch.get("act", "relu")
+    return {"act_fn": np.array(act)} if act != "relu" else {}
 
 
 def grads_of(model):
@@ -172,6 +182,7 @@ def case_single(name, arch, n_ep, n_steps, batch, full):
             fix["ckpt_keys::" + f] = np.array(list(obj.keys()))
     fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"],
                             n_ep, n_steps, batch])
+    fix.update(act_meta(arch))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
     print("wrote", name, "keys:", len(fix))
 
@@ -217,7 +228,8 @@ def case_lookahead(name, arch, n_ep, n_steps, batch, lookahead, full, loss="MSE"
     print("wrote", name, "keys:", len(fix), "world", fix["world_total"], "joint", fix["joint_total"])
 
 
-def case_training(name, arch, n_ep, n_steps, batch, m_world, n_epochs, full, lr_step=2, lookahead=1):
+def case_training(name, arch, n_ep, n_steps, batch, m_world, n_epochs, full, lr_step=2, lookahead=1,
+                  weight_decay=None):
     """Multi-epoch run crossing the phase switch, eps keyed by global minibatch index."""
     data = R.synth_demo(seed=0, n_episodes=n_ep, n_steps=n_steps, dim_body=arch["Db"],
                         dim_action=arch["Da"], kind="dynamics")
@@ -225,7 +237,7 @@ def case_training(name, arch, n_ep, n_steps, batch, m_world, n_epochs, full, lr_
     with tempfile.TemporaryDirectory() as td:
         pkl = os.path.join(td, "demo.pkl")
         R.write_demo(pkl, data)
-        tr = make_reference_trainer(pkl, arch, batch, m_world=m_world, lookahead=lookahead)
+        tr = make_reference_trainer(pkl, arch, batch, m_world=m_world, lookahead=lookahead, weight_decay=weight_decay)
         # shorten StepLR so that the decay is exercised inside the captured run
         tr.lr_scheduler = torch.optim.lr_scheduler.StepLR(tr.optimizer, step_size=lr_step, gamma=0.7)
         sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
@@ -261,6 +273,9 @@ def case_training(name, arch, n_ep, n_steps, batch, m_world, n_epochs, full, lr_
         fix["adam_steps"] = np.array(steps)
     fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"],
                             n_ep, n_steps, batch, m_world, n_epochs, lr_step, lookahead])
+    fix.update(act_meta(arch))
+    if weight_decay:
+        fix["weight_decay"] = np.array(float(weight_decay))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
     print("wrote", name, "losses", losses, "lrs", lrs)
 
@@ -471,6 +486,13 @@ def main():
         "ingest_tiny": lambda: case_ingest("ingest_tiny", tiny),
         "ingest_rel_tiny": lambda: case_ingest_rel("ingest_rel_tiny", tiny),
         "noprior_tiny": lambda: case_noprior("noprior_tiny", tiny, 2, 14, 8),
+        # the trainer's "act_fn" (hidden activation of every stack) and Adam's weight_decay: config keys a user edits
+        "single_tiny_tanh": lambda: case_single("single_tiny_tanh", dict(tiny, act="tanh"), 2, 14, 8, full=True),
+        "single_tiny_sigmoid": lambda: case_single("single_tiny_sigmoid", dict(tiny, act="sigmoid"), 2, 14, 8, full=True),
+        "single_tiny_elu": lambda: case_single("single_tiny_elu", dict(tiny, act="elu"), 2, 14, 8, full=True),
+        "single_c1_tanh": lambda: case_single("single_c1_tanh", dict(c1, act="tanh"), 2, 200, 64, full=False),
+        "train_tiny_elu_wd": lambda: case_training("train_tiny_elu_wd", dict(tiny, act="elu"), 3, 21, 8, m_world=2,
+                                                   n_epochs=5, full=True, weight_decay=0.01),
         "ckpt_interop_tiny": lambda: case_checkpoint_interop("ckpt_interop_tiny", tiny),
         "look3_tiny": lambda: case_lookahead("look3_tiny", tiny, 2, 15, 8, lookahead=3, full=True),
         "look2_c1": lambda: case_lookahead("look2_c1", c1, 2, 200, 64, lookahead=2, full=False),

@@ -76,14 +76,19 @@ PRIORS = ("normal_zero_mean_one_std", "normal_state_mean_one_std", "hypersphere_
 # architecture description
 # --------------------------------------------------------------------------------------
 def make_arch(dim_body, dim_action, latent=32, te=(256, 2), md=(512, 3), wm=(1024, 2),
-              vb=(256, 2), prior="normal_zero_mean_one_std", pr=None):
+              vb=(256, 2), prior="normal_zero_mean_one_std", pr=None, act="relu"):
     """Widths/depths as `gen_layers(width, depth)` expands them (tpv:180-192, 290-311);
     defaults are PhysicsVAE.DEFAULT_CONFIG (rmt:462-510).  `prior` / `pr`: see PRIORS above
-    (`pr` = (width, depth) of the learned prior, default = the task encoder's)."""
+    (`pr` = (width, depth) of the learned prior, default = the task encoder's).  `act`: the trainer's
+    "act_fn" (tpv:262 -> gen_layers' act_hidden -> get_activation_fn rmt:30-46), one for every stack."""
     assert prior in PRIORS or prior is False, prior
+    assert act in ACTIVATIONS, act
     return dict(Db=int(dim_body), Da=int(dim_action), Z=int(latent),
                 te=tuple(te), md=tuple(md), wm=tuple(wm), vb=tuple(vb), prior=prior,
-                pr=tuple(pr) if pr is not None else tuple(te))
+                pr=tuple(pr) if pr is not None else tuple(te), act=act)
+
+
+ACTIVATIONS = {"relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "elu": nn.ELU}      # rmt:37-44
 
 
 def net_layer_dims(arch):
@@ -274,11 +279,11 @@ def make_loader(X, Y, batch_size):
 # model (own nn.Module reproducing the state_dict layout)
 # --------------------------------------------------------------------------------------
 class _Slim(nn.Module):
-    def __init__(self, n_in, n_out, relu):
+    def __init__(self, n_in, n_out, relu, act="relu"):
         super().__init__()
         mods = [nn.Linear(n_in, n_out)]
         if relu:
-            mods.append(nn.ReLU())
+            mods.append(ACTIVATIONS[act]())
         self._model = nn.Sequential(*mods)
 
     def forward(self, x):
@@ -286,9 +291,9 @@ class _Slim(nn.Module):
 
 
 class _Stack(nn.Module):
-    def __init__(self, dims):
+    def __init__(self, dims, act="relu"):
         super().__init__()
-        self._model = nn.Sequential(*[_Slim(i, o, relu=(n < len(dims) - 1))
+        self._model = nn.Sequential(*[_Slim(i, o, relu=(n < len(dims) - 1), act=act)
                                       for n, (i, o) in enumerate(dims)])
 
     def forward(self, x):
@@ -304,12 +309,13 @@ class RefModel(nn.Module):
         self.arch = arch
         dims = net_layer_dims(arch)
         self.prior = arch.get("prior", PRIORS[0])
+        act = arch.get("act", "relu")
         if "_latent_prior" in dims:                                   # rmt:627-635: registered first
-            self._latent_prior = _Stack(dims["_latent_prior"])
-        self._task_encoder = _Stack(dims["_task_encoder"])
-        self._motor_decoder = _Stack(dims["_motor_decoder"])
-        self._world_model = _Stack(dims["_world_model"])
-        self._value_branch = _Stack(dims["_value_branch"])
+            self._latent_prior = _Stack(dims["_latent_prior"], act)
+        self._task_encoder = _Stack(dims["_task_encoder"], act)
+        self._motor_decoder = _Stack(dims["_motor_decoder"], act)
+        self._world_model = _Stack(dims["_world_model"], act)
+        self._value_branch = _Stack(dims["_value_branch"])                # value_fn_layers keep their own relu (rmt:500)
         self.log_std = math.log(0.1)            # AppendLogStd constant (rmt:160-206, 466)
         self.latent_prior_noise = True          # rmt:705
         self.eps_source = None                  # callable(shape) -> eps, else torch.randn
@@ -477,6 +483,8 @@ def relu_kink_margin(arch, sd, x, y, eps, world):
     sample's gradient path in ANY two fp32 implementations (MKL vs MFMA, CPU vs GPU).  Parity
     tests drop such samples (margin below a few ulps of the activation scale) before comparing
     gradients tightly."""
+    if arch.get("act", "relu") != "relu":              # tanh / sigmoid / elu are differentiable everywhere
+        return torch.full((x.shape[0],), float("inf"))
     model = RefModel(arch)
     model.load_state_dict(sd)
     margins = []
@@ -531,13 +539,13 @@ class RefTrainer:
     flip when `iter == max_iter_world_model` is seen *before* the increment."""
 
     def __init__(self, arch, sd, X, Y, batch_size, max_iter_world_model, lr=5e-4,
-                 lr_step=50, lr_gamma=0.7, coeff_cfg=None, eps_fn=None, loss="MSE"):
+                 lr_step=50, lr_gamma=0.7, coeff_cfg=None, eps_fn=None, loss="MSE", weight_decay=0.0):
         self.arch = arch
         self.loss = loss
         self.model = RefModel(arch)
         self.model.load_state_dict(sd)
         self.loader = make_loader(X, Y, batch_size)
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=0.0)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)   # tm:119-122
         self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=lr_step, gamma=lr_gamma)
         self.max_iter_world_model = max_iter_world_model
         self.coeff_cfg = coeff_cfg

@@ -26,10 +26,11 @@ NET_TE, NET_MD, NET_WM, NET_PR = 0, 1, 2, 3
 NUM_NETS = 4
 NET_NAMES = {NET_TE: "_task_encoder", NET_MD: "_motor_decoder", NET_WM: "_world_model", NET_PR: "_latent_prior"}
 # latent_prior_type (rmt:614-635) -> pvae_config.prior_kind
+ACT_KINDS = {"relu": 0, "tanh": 1, "sigmoid": 2, "elu": 3}      # pvae_config.act_kind (get_activation_fn rmt:30-46)
 PRIOR_KINDS = {"normal_zero_mean_one_std": 0, "normal_state_mean_one_std": 1, "hypersphere_uniform": 2, False: 3}
 PHASE_WORLD, PHASE_JOINT = 0, 1
 FLAG_FUSED_ADAM, FLAG_NO_BACKWARD = 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 LOSS_MSE, LOSS_L1 = 0, 1
 EXCHANGE_ALLREDUCE, EXCHANGE_SHARDED = 0, 1
 
@@ -37,7 +38,7 @@ EXCHANGE_ALLREDUCE, EXCHANGE_SHARDED = 0, 1
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dim_body", "dim_action", "latent", "te_width", "te_depth", "md_width", "md_depth",
-        "wm_width", "wm_depth", "max_batch", "lookahead", "prior_kind", "pr_width", "pr_depth")]
+        "wm_width", "wm_depth", "max_batch", "lookahead", "prior_kind", "pr_width", "pr_depth", "act_kind")]
 
 
 class LayerInfo(C.Structure):
@@ -51,7 +52,7 @@ class StepParams(C.Structure):
                 ("cycle_coeff", C.c_float), ("lr", C.c_double), ("beta1", C.c_double),
                 ("beta2", C.c_double), ("adam_eps", C.c_double), ("adam_t", C.c_int32 * NUM_NETS),
                 ("global_rows", C.c_int32), ("rng_seed", C.c_uint64), ("rng_offset", C.c_uint64),
-                ("loss_kind", C.c_int32), ("reserved", C.c_int32)]
+                ("loss_kind", C.c_int32), ("weight_decay", C.c_float)]
 
 
 _P = C.c_void_p

@@ -505,6 +505,7 @@ static AdamScalars adam_scalars(const pvae_step_params* sp, int net) {
     s.eps = (float)sp->adam_eps;
     s.one_minus_beta1 = (float)(1.0 - sp->beta1);
     s.one_minus_beta2 = (float)(1.0 - sp->beta2);
+    s.weight_decay = sp->weight_decay;
     return s;
 }
 
@@ -524,7 +525,7 @@ template <int R>
 __global__ void __launch_bounds__(256)
 gemv_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W, int ldw,
                  const float* __restrict__ bias, float* __restrict__ out, int ldo, int K, int relu,
-                 float* __restrict__ out2, int ld2, int off2, int n2) {
+                 float* __restrict__ out2, int ld2, int off2, int n2, int n_valid) {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const float* wrow = W + (size_t)n * ldw;
@@ -546,7 +547,7 @@ gemv_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         if (lane == 0) {
             v += bias[n];
-            if (relu) v = fmaxf(v, 0.f);
+            v = (relu > 1 && n >= n_valid) ? 0.f : act_apply(v, relu);
             out[(size_t)r * ldo + n] = v;
             if (out2 && n < n2) out2[(size_t)r * ld2 + off2 + n] = v;
         }
@@ -575,7 +576,8 @@ struct RolloutIn {
 template <int R>
 __global__ void __launch_bounds__(256)
 gemv_rollout_kernel(RolloutIn in, int rows, const float* __restrict__ W, int ldw, const float* __restrict__ bias,
-                    float* __restrict__ out, int ldo, int K, int relu, float* __restrict__ out2, int ld2, int n2) {
+                    float* __restrict__ out, int ldo, int K, int relu, float* __restrict__ out2, int ld2, int n2,
+                    int n_valid) {
     extern __shared__ __attribute__((aligned(16))) float xs[];         // [R][K], K = ld of the layer (multiple of 64)
     const int tid = threadIdx.x;
     // this wave's weight row: the first 1024 columns are requested BEFORE the input rows are assembled,
@@ -651,7 +653,7 @@ gemv_rollout_kernel(RolloutIn in, int rows, const float* __restrict__ W, int ldw
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         if (lane == 0 && r < rows) {
             v += bias[n];
-            if (relu) v = fmaxf(v, 0.f);
+            v = (relu > 1 && n >= n_valid) ? 0.f : act_apply(v, relu);
             out[(size_t)r * ldo + n] = v;
             if (out2 && n < n2) out2[(size_t)r * ld2 + n] = v;
         }
@@ -679,7 +681,7 @@ static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st, const F
             const dim3 grid(l.n_out_pad / 4), block(256);
 #define PVAE_GEMV(R)                                                                                        \
     PVAE_LAUNCH((gemv_rows_kernel<R>), grid, block, st, x, ldx, c->params + l.w_off, l.ld,           \
-                       c->params + l.b_off, out, l.n_out_pad, l.ld, l.last ? 0 : 1, o2, tail.ld2, tail.off2, tail.n2)
+                       c->params + l.b_off, out, l.n_out_pad, l.ld, l.last ? 0 : c->L.cfg.act_kind + 1, o2, tail.ld2, tail.off2, tail.n2, l.n_out)
             if (rows == 1) PVAE_GEMV(1);
             else if (rows == 2) PVAE_GEMV(2);
             else PVAE_GEMV(4);
@@ -690,7 +692,8 @@ static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st, const F
             e.out = out; e.ldo = l.n_out_pad; e.bias = c->params + l.b_off;
             HIP_TRY(gemm_forward_epi(x, ldx, c->params + l.w_off, l.ld, rows_pad, l.n_out_pad, l.ld, e, st));
         } else {
-            EpiBiasAct e{out, l.n_out_pad, c->params + l.b_off, l.last ? 0 : 1};
+            EpiBiasAct e{out, l.n_out_pad, c->params + l.b_off, l.last ? 0 : c->L.cfg.act_kind + 1};
+            e.n_valid = l.n_out;
             if (l.last && tail.out2) { e.out2 = tail.out2; e.ld2 = tail.ld2; e.off2 = tail.off2; e.n2 = tail.n2; }
             HIP_TRY(gemm_forward_epi(x, ldx, c->params + l.w_off, l.ld, rows_pad, l.n_out_pad, l.ld, e, st));
         }
@@ -778,6 +781,7 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
     const int last = (int)N->layers.size() - 1;
     const bool pair = train && c->pair_launch;
     const double rowsf = c->staged_rows_f;
+    const int act = c->L.cfg.act_kind + 1;          // act_grad code of the hidden layers
     const int need = n == PVAE_NET_WM ? c->L.cfg.dim_action : c->L.cfg.latent;
     LossFinal foldv;
     memset(&foldv, 0, sizeof(foldv));
@@ -811,7 +815,7 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
                                    l.n_out_pad, e, st));
         } else {
             HIP_TRY(gemm_dgrad(c->ws + w->dz[i], l.n_out_pad, c->params + l.w_off, l.ld, i > 0 ? xin : nullptr, l.ld,
-                               i > 0 ? c->ws + w->dz[i - 1] : c->ws + w->d_in, l.ld, rows_pad, l.ld, l.n_out_pad, st));
+                               i > 0 ? c->ws + w->dz[i - 1] : c->ws + w->d_in, l.ld, rows_pad, l.ld, l.n_out_pad, st, act));
         }
         g_prof.end(ps, st);
         return 0;
@@ -855,7 +859,7 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
                     HIP_TRY(gemm_bwd_pair(c->ws + w->dz[j], d.n_out_pad, c->params + d.w_off, d.ld,
                                           j > 0 ? dx_in : nullptr, d.ld, j > 0 ? c->ws + w->dz[j - 1] : c->ws + w->d_in,
                                           d.ld, rows_pad, d.ld, d.n_out_pad, dz, l.n_out_pad, xin, l.ld, l.n_out_pad,
-                                          l.ld, rows_pad, e, st, &ad));
+                                          l.ld, rows_pad, e, st, &ad, act));
                 }
                 g_prof.end(pp, st);
             } else {
@@ -989,10 +993,10 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
                 const AdamSeg ad = take_pending_adam(c);
                 if (fused) {
                     he = gemm_bwd_pair(d.dZ, d.ldz, d.W, d.ldw, d.mask, d.ldm, d.dX, d.ldo, d.M, d.Kin, d.Nd, dz,
-                                       l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, adam_epi(l), st, &ad);
+                                       l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, adam_epi(l), st, &ad, act);
                 } else {
                     he = gemm_bwd_pair(d.dZ, d.ldz, d.W, d.ldw, d.mask, d.ldm, d.dX, d.ldo, d.M, d.Kin, d.Nd, dz,
-                                       l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, store_epi(l), st, &ad);
+                                       l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, store_epi(l), st, &ad, act);
                 }
                 g_prof.end(pp, st);
                 if (he != hipSuccess) return fail(-10, "gemm_bwd_pair: %s", hipGetErrorString(he));
@@ -1603,7 +1607,7 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
                 float* out = i > 0 ? w + nw->dz[i - 1] + b * l.ld : w + nw->d_in + b * l.ld;
                 const int ps = g_prof.begin(1, 2.0 * rowsf * l.n_in * l.n_out, st);
                 HIP_TRY(gemm_dgrad(w + nw->dz[i] + b * l.n_out_pad, l.n_out_pad, c->params + l.w_off, l.ld, mask, l.ld,
-                                   out, l.ld, rows_pad, l.ld, l.n_out_pad, st));
+                                   out, l.ld, rows_pad, l.ld, l.n_out_pad, st, c->L.cfg.act_kind + 1));
                 g_prof.end(ps, st);
                 return 0;
             });
@@ -2208,7 +2212,7 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
                 const int ps = g_prof.begin(0, 2.0 * rows * l.n_in * l.n_out, st);
 #define PVAE_ROLL(R)                                                                                                  \
     hipLaunchKernelGGL((gemv_rollout_kernel<R>), grid, block, shm, st, in, (int)rows, c->params + l.w_off, l.ld,      \
-                       c->params + l.b_off, out, l.n_out_pad, l.ld, l.last ? 0 : 1, o2, ld2, n2)
+                       c->params + l.b_off, out, l.n_out_pad, l.ld, l.last ? 0 : c->L.cfg.act_kind + 1, o2, ld2, n2, l.n_out)
                 if (rows == 1) PVAE_ROLL(1);
                 else if (rows == 2) PVAE_ROLL(2);
                 else PVAE_ROLL(4);

@@ -1071,15 +1071,17 @@ struct AdamScalars {
     float inv_bc2_sqrt;       // 1 / sqrt(1 - beta2^t)
     float beta1, beta2, eps;
     float one_minus_beta1, one_minus_beta2;   // computed in double on the host, as torch does
+    float weight_decay = 0.f;                 // L2 term folded into the gradient (0: the trainer's setting)
 };
 
-// torch.optim.Adam single-tensor update (amsgrad False, weight_decay 0), tm:119-122,143:
-//   m <- m + (g - m)(1 - b1) ; v <- v b2 + (1 - b2) g g ; p <- p - step_size * m / (sqrt(v)/bc2_sqrt + eps)
+// torch.optim.Adam single-tensor update (amsgrad False), tm:119-122,143:
+//   g <- g + weight_decay p (when set) ; m <- m + (g - m)(1 - b1) ; v <- v b2 + (1 - b2) g g ; p <- p - step_size * m / (sqrt(v)/bc2_sqrt + eps)
 __device__ inline void adam_update(float g, float& p, float& m, float& v, const AdamScalars& s) {
     // Moments: every operation pinned (no context-dependent fma contraction), so the fused
     // epilogue and the flat multi-tensor kernel stay bit-identical.  Step: v_sqrt_f32 / v_rcp_f32
     // (1 ulp) instead of the correctly rounded sequences (~10x the instructions); the term they
     // feed is scaled by lr/(1-b1^t) ~ 5e-4 before it meets p, so p moves by < 0.1 ulp of itself.
+    if (s.weight_decay != 0.f) g = __fmaf_rn(s.weight_decay, p, g);
     m = __fmaf_rn(__fsub_rn(g, m), s.one_minus_beta1, m);
     v = __fmaf_rn(v, s.beta2, __fmul_rn(__fmul_rn(s.one_minus_beta2, g), g));
     const float denom = __fmaf_rn(__builtin_amdgcn_sqrtf(v), s.inv_bc2_sqrt, s.eps);
@@ -1257,13 +1259,36 @@ __device__ inline float block_sum_256(float v, float* scratch) {
     return s;
 }
 
+// Hidden-layer activation (get_activation_fn rmt:30-46 via gen_layers' act_hidden, tpv:180-192):
+// internal codes 0 linear, 1 relu (the trainer's "act_fn"), 2 tanh, 3 sigmoid, 4 elu (alpha 1).  The backward
+// pass needs only the layer's OUTPUT a: relu' = [a > 0], tanh' = 1 - a^2, sigmoid' = a (1 - a), elu' = a > 0 ? 1 : a + 1.
+__device__ inline float act_apply(float x, int act) {
+    switch (act) {
+        case 1: return fmaxf(x, 0.f);
+        case 2: return tanhf(x);
+        case 3: return 1.f / (1.f + expf(-x));
+        case 4: return x > 0.f ? x : expm1f(x);
+        default: return x;
+    }
+}
+__device__ inline float act_grad(float a, int act) {
+    switch (act) {
+        case 2: return 1.f - a * a;
+        case 3: return a * (1.f - a);
+        case 4: return a > 0.f ? 1.f : a + 1.f;
+        default: return 1.f;
+    }
+}
+
 struct EpiBiasAct {           // forward layer: out = act(acc + bias)
     float* out;
     int ldo;
     const float* bias;        // may be null
-    int relu;
+    int act;                  // act_apply code (0: linear output layer)
     float* out2 = nullptr;    // optional second destination for columns [0, n2): out2[q][off2 + p]
     int ld2 = 0, off2 = 0, n2 = 0;   // (motor-decoder output -> action columns of the world-model input)
+    int n_valid = 1 << 30;    // real width of the layer: pad columns stay 0 also where act(0) != 0 (sigmoid),
+                              // so that padding never reaches a weight gradient
     // operands of the epilogue that do not depend on the contraction are fetched BEFORE the main
     // loop (`preload`) and handed back at the end: their latency hides under the loop instead of
     // sitting between the last MFMA and the stores
@@ -1275,9 +1300,12 @@ struct EpiBiasAct {           // forward layer: out = act(acc + bias)
     }
     __device__ inline void operator()(int q, int p, v4f v, const Pre& pre) const {
         v += pre.b;
-        if (relu) {
+        if (act == 1) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
             v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        } else if (act > 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = p + e < n_valid ? act_apply(v[e], act) : 0.f;
         }
         store_stream(out + (size_t)q * ldo + p, v);
         if (out2) {
@@ -1334,11 +1362,12 @@ struct EpiMse {
     }
 };
 
-struct EpiMask {              // input gradient: out = acc * (act > 0)
+struct EpiMask {              // input gradient: out = acc * act'(a)   (relu: acc where a > 0, else 0)
     float* out;
     int ldo;
-    const float* mask;        // post-ReLU activation of the producing layer, or null
+    const float* mask;        // activation a of the producing layer (its output), or null
     int ldm;
+    int act = 1;              // act_grad code of that layer
     struct Pre { v4f m; };
     __device__ inline Pre preload(int q, int p) const {
         Pre r;
@@ -1347,8 +1376,13 @@ struct EpiMask {              // input gradient: out = acc * (act > 0)
     }
     __device__ inline void operator()(int q, int p, v4f v, const Pre& pre) const {
         const v4f m = pre.m;
-        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        if (act <= 1 || !mask) {
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+            v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        } else {
+            v.x *= act_grad(m.x, act); v.y *= act_grad(m.y, act);
+            v.z *= act_grad(m.z, act); v.w *= act_grad(m.w, act);
+        }
         store_stream(out + (size_t)q * ldo + p, v);
     }
     __device__ inline void finish(float*, int, int) const {}
@@ -1558,8 +1592,8 @@ inline hipError_t gemm_forward_epi(const float* X, int ldx, const float* W, int 
     return hipGetLastError();
 }
 inline hipError_t gemm_forward(const float* X, int ldx, const float* W, int ldw, const float* bias,
-                               float* out, int ldo, int M, int N, int K, int relu, hipStream_t st) {
-    EpiBiasAct e{out, ldo, bias, relu};
+                               float* out, int ldo, int M, int N, int K, int act, hipStream_t st) {
+    EpiBiasAct e{out, ldo, bias, act};
     return gemm_forward_epi(X, ldx, W, ldw, M, N, K, e, st);
 }
 // dgrad: dX[M][Kin] = (dZ[M][N] W[N][Kin]) .* (mask > 0)
@@ -1592,8 +1626,8 @@ inline hipError_t gemm_dgrad_epi(const float* dZ, int ldz, const float* W, int l
     return hipGetLastError();
 }
 inline hipError_t gemm_dgrad(const float* dZ, int ldz, const float* W, int ldw, const float* mask,
-                             int ldm, float* dX, int ldo, int M, int Kin, int N, hipStream_t st) {
-    const EpiMask e{dX, ldo, mask, ldm};
+                             int ldm, float* dX, int ldo, int M, int Kin, int N, hipStream_t st, int act = 1) {
+    const EpiMask e{dX, ldo, mask, ldm, act};
     return gemm_dgrad_epi(dZ, ldz, W, ldw, M, Kin, N, e, st);
 }
 // wgrad: G[N][Kin] = dZ[M][N]^T X[M][Kin]  (+ bias gradient, + optional loss finalisation)
@@ -1652,8 +1686,8 @@ template <class EpiW>
 inline hipError_t gemm_bwd_pair(const float* dZd, int ldzd, const float* Wd, int ldwd, const float* mask, int ldm,
                                 float* dXd, int ldod, int Md, int Kind, int Nd,
                                 const float* dZw, int ldzw, const float* Xw, int ldxw, int Nw, int Kinw, int Mw,
-                                const EpiW& ew, hipStream_t st, const AdamSeg* ad = nullptr) {
-    const EpiMask ed{dXd, ldod, mask, ldm};
+                                const EpiW& ew, hipStream_t st, const AdamSeg* ad = nullptr, int act = 1) {
+    const EpiMask ed{dXd, ldod, mask, ldm, act};
     return gemm_bwd_pair_epi(dZd, ldzd, Wd, ldwd, Md, Kind, Nd, ed, dZw, ldzw, Xw, ldxw, Nw, Kinw, Mw, ew, st, ad);
 }
 

@@ -46,6 +46,7 @@ inline Layout make_layout(const pvae_config& c) {
     if (c.max_batch <= 0 || c.max_batch > 65536) { L.why = "max_batch out of range"; return L; }
     if (c.lookahead < 1 || c.lookahead > 64) { L.why = "lookahead must be in [1, 64]"; return L; }
     if (c.prior_kind < 0 || c.prior_kind > PVAE_PRIOR_NONE) { L.why = "unknown prior_kind"; return L; }
+    if (c.act_kind < 0 || c.act_kind > PVAE_ACT_ELU) { L.why = "unknown act_kind"; return L; }
     if (c.prior_kind != PVAE_PRIOR_ZERO_MEAN && c.lookahead != 1) {
         L.why = "latent priors other than normal_zero_mean_one_std need lookahead == 1";
         return L;

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import FLAG_FUSED_ADAM, FLAG_NO_BACKWARD, NET_MD, NET_NAMES, NET_PR, NET_TE, NET_WM, NUM_NETS, PRIOR_KINDS
+from ._lib import ACT_KINDS, FLAG_FUSED_ADAM, FLAG_NO_BACKWARD, NET_MD, NET_NAMES, NET_PR, NET_TE, NET_WM, NUM_NETS, PRIOR_KINDS
 
 TENSOR_IDS = {"mu": 0, "logvar": 1, "z": 2, "a_hat": 3, "s2_hat": 4, "eps": 5, "prior_mu": 6}
 
@@ -16,13 +16,17 @@ TENSOR_IDS = {"mu": 0, "logvar": 1, "z": 2, "a_hat": 3, "s2_hat": 4, "eps": 5, "
 class Arch:
     """Dims of the three trainable stacks (tpv:247-286 keys, gen_layers tpv:180-192)."""
 
-    def __init__(self, dim_body, dim_action, latent, te, md, wm, prior="normal_zero_mean_one_std", pr=None):
+    def __init__(self, dim_body, dim_action, latent, te, md, wm, prior="normal_zero_mean_one_std", pr=None,
+                 act="relu"):
         self.Db, self.Da, self.Z = int(dim_body), int(dim_action), int(latent)
         self.te, self.md, self.wm = tuple(te), tuple(md), tuple(wm)
         if prior not in PRIOR_KINDS:
             raise NotImplementedError("Unknown latent_prior_type:%s" % (prior,))      # rmt:624-625
         self.prior = prior                       # latent_prior_type (rmt:614-635; oracle/refpath.py PRIORS)
         self.pr = tuple(pr) if pr is not None else tuple(te)      # learned prior stack (width, depth)
+        if act not in ACT_KINDS:                 # "swish"/"silu" need the pre-activation in the backward pass
+            raise NotImplementedError("hidden activation %r: the HIP path offers %s" % (act, sorted(ACT_KINDS)))
+        self.act = act                           # the trainer's "act_fn" (tpv:262), one for all stacks
 
     @property
     def te_out(self):
@@ -31,10 +35,10 @@ class Arch:
     def config(self, max_batch, lookahead=1):
         return _lib.Config(self.Db, self.Da, self.Z, self.te[0], self.te[1], self.md[0],
                            self.md[1], self.wm[0], self.wm[1], int(max_batch), int(lookahead),
-                           PRIOR_KINDS[self.prior], self.pr[0], self.pr[1])
+                           PRIOR_KINDS[self.prior], self.pr[0], self.pr[1], ACT_KINDS[self.act])
 
     def key(self):
-        return (self.Db, self.Da, self.Z, self.te, self.md, self.wm, self.prior, self.pr)
+        return (self.Db, self.Da, self.Z, self.te, self.md, self.wm, self.prior, self.pr, self.act)
 
 
 class GraphedInfer:
@@ -79,7 +83,8 @@ class GraphedInfer:
 
 
 def make_step_params(lr, adam_t=(1, 1, 1), a_rec=1.0, kl=1.0, s_rec=0.0, cyc=1e-3,
-                     global_rows=0, seed=0, offset=0, beta1=0.9, beta2=0.999, eps=1e-8, loss="MSE"):
+                     global_rows=0, seed=0, offset=0, beta1=0.9, beta2=0.999, eps=1e-8, loss="MSE",
+                     weight_decay=0.0):
     sp = _lib.StepParams()
     sp.loss_kind = {"MSE": _lib.LOSS_MSE, "L1": _lib.LOSS_L1, "MAE": _lib.LOSS_L1}[loss]
     sp.a_rec_coeff, sp.kl_coeff, sp.s_rec_coeff, sp.cycle_coeff = a_rec, kl, s_rec, cyc
@@ -88,6 +93,7 @@ def make_step_params(lr, adam_t=(1, 1, 1), a_rec=1.0, kl=1.0, s_rec=0.0, cyc=1e-
         sp.adam_t[i] = int(adam_t[i]) if i < len(adam_t) else 1
     sp.global_rows = int(global_rows)
     sp.rng_seed, sp.rng_offset = int(seed), int(offset)
+    sp.weight_decay = float(weight_decay)
     return sp
 
 

@@ -53,9 +53,13 @@ def normc_(tensor, std=1.0):
     return tensor
 
 
-def _uniform_relu_stack(layers, what):
-    """The HIP path covers what train_physics_vae.py can generate: fc layers of one width with
-    ReLU, then a linear fc output layer.  Anything else is refused loudly."""
+ACTIVATIONS = {"relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "elu": nn.ELU}     # rmt:30-46 minus swish
+
+
+def _uniform_stack(layers, what):
+    """The HIP path covers what train_physics_vae.py can generate (gen_layers, tpv:180-192): fc layers of
+    one width with one activation (the trainer's "act_fn": relu unless changed), then a linear fc output
+    layer.  Anything else is refused loudly.  Returns (width, depth, activation)."""
     if not layers or any(l.get("type") != "fc" for l in layers):
         raise NotImplementedError("%s: only 'fc' layers are supported on the HIP path" % what)
     *hidden, last = layers
@@ -64,18 +68,20 @@ def _uniform_relu_stack(layers, what):
     widths = {l["hidden_size"] for l in hidden}
     if len(widths) != 1 or not isinstance(next(iter(widths)), int):
         raise NotImplementedError("%s: hidden layers must share one integer width, got %s" % (what, widths))
-    if any(l.get("activation") != "relu" for l in hidden) or last.get("activation") not in ("linear", None):
-        raise NotImplementedError("%s: hidden activation must be relu and the output linear" % what)
+    acts = {l.get("activation") for l in hidden}
+    if len(acts) != 1 or next(iter(acts)) not in ACTIVATIONS or last.get("activation") not in ("linear", None):
+        raise NotImplementedError("%s: hidden layers must share one activation out of %s and the output be linear, got %s"
+                                  % (what, sorted(ACTIVATIONS), sorted(map(str, acts))))
     if last["hidden_size"] != "output":
         raise NotImplementedError("%s: last layer must have hidden_size 'output'" % what)
-    return next(iter(widths)), len(hidden)
+    return next(iter(widths)), len(hidden), next(iter(acts))
 
 
 class SlimFC(nn.Module):
     """Linear (+ReLU) held as `self._model = nn.Sequential(...)` -- the ray SlimFC shape that
     gives the `._model.0.weight` key suffix."""
 
-    def __init__(self, in_size, out_size, relu, init_std, weight=None, bias=None):
+    def __init__(self, in_size, out_size, relu, init_std, weight=None, bias=None, act="relu"):
         super().__init__()
         lin = nn.Linear(in_size, out_size)
         if weight is not None:                 # alias the engine arena instead of own storage
@@ -84,7 +90,7 @@ class SlimFC(nn.Module):
         normc_(lin.weight.data, init_std)
         with torch.no_grad():
             lin.bias.zero_()
-        self._model = nn.Sequential(*([lin, nn.ReLU()] if relu else [lin]))
+        self._model = nn.Sequential(*([lin, ACTIVATIONS[act]()] if relu else [lin]))
 
     def forward(self, x):
         return self._model(x)
@@ -121,14 +127,14 @@ class FC(nn.Module):
     """rmt:234-283: `self._model = nn.Sequential(SlimFC..., [AppendLogStd])`."""
 
     def __init__(self, dims, views=None, append_log_std=False, sample_std=1.0, log_std_type="constant",
-                 device=None):
+                 device=None, act="relu"):
         super().__init__()
         mods = []
         for i, (n_in, n_out) in enumerate(dims):
             last = i == len(dims) - 1
             w, b = (views[i] if views is not None else (None, None))
             mods.append(SlimFC(n_in, n_out, relu=not last, init_std=0.01 if last else 1.0,
-                               weight=w, bias=b))
+                               weight=w, bias=b, act=act))
         if append_log_std:
             mods.append(AppendLogStd(math.log(sample_std), dims[-1][1], type=log_std_type, device=device))
         self._model = nn.Sequential(*mods)
@@ -213,13 +219,18 @@ class PhysicsVAE(nn.Module):
         self._latent_prior_type = cfg["latent_prior_type"]
         self._motor_decoder_helper = None
 
-        te = _uniform_relu_stack(cfg["task_encoder_layers"], "task_encoder_layers")
-        md = _uniform_relu_stack(cfg["motor_decoder_layers"], "motor_decoder_layers")
-        wm = _uniform_relu_stack(cfg["world_model_layers"], "world_model_layers")
-        vb = _uniform_relu_stack(cfg["value_fn_layers"], "value_fn_layers")
+        te = _uniform_stack(cfg["task_encoder_layers"], "task_encoder_layers")
+        md = _uniform_stack(cfg["motor_decoder_layers"], "motor_decoder_layers")
+        wm = _uniform_stack(cfg["world_model_layers"], "world_model_layers")
+        vb = _uniform_stack(cfg["value_fn_layers"], "value_fn_layers")
         learned_prior = self._latent_prior_type == "normal_state_mean_one_std"
-        pr = _uniform_relu_stack(cfg.get("latent_prior_layers") or cfg["task_encoder_layers"], "latent_prior_layers")
-        self.arch = Arch(self.dim_state_body, self.dim_action, Z, te, md, wm, prior=self._latent_prior_type, pr=pr)
+        pr = _uniform_stack(cfg.get("latent_prior_layers") or cfg["task_encoder_layers"], "latent_prior_layers")
+        acts = {s[2] for s in ((te, md, wm, pr) if learned_prior else (te, md, wm))}
+        if len(acts) != 1:                      # gen_layers gives every stack the trainer's one "act_fn" (tpv:290-311)
+            raise NotImplementedError("the stacks on the HIP path share one hidden activation, got %s" % sorted(acts))
+        act = next(iter(acts))
+        self.arch = Arch(self.dim_state_body, self.dim_action, Z, te[:2], md[:2], wm[:2], prior=self._latent_prior_type,
+                         pr=pr[:2], act=act)
         device = cfg["device"] or ("cuda" if torch.cuda.is_available() else "cpu")
         self.engine = HipEngine(self.arch, int(cfg["max_batch"]), device=device,
                                 lookahead=int(cfg.get("lookahead", 1) or 1))
@@ -234,7 +245,7 @@ class PhysicsVAE(nn.Module):
         def build(net, **kw):
             dims = [d for d, _ in per_net[net]]
             vws = [v for _, v in per_net[net]]
-            return FC(dims, views=vws, **kw)
+            return FC(dims, views=vws, act=act, **kw)
 
         # registration order fixes the state_dict order: [prior,] TE, MD, WM, VB (rmt:627-699)
         self._latent_prior = build(NET_PR) if learned_prior else None
@@ -247,7 +258,7 @@ class PhysicsVAE(nn.Module):
             vb_dims.append((prev, vb[0]))
             prev = vb[0]
         vb_dims.append((prev, 1))
-        self._value_branch = FC(vb_dims).to(self.engine.device)
+        self._value_branch = FC(vb_dims, act=vb[2]).to(self.engine.device)
 
         self._cur_value = None
         self._lazy, self._mu, self._logvar = None, None, None

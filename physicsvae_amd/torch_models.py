@@ -122,15 +122,13 @@ class WindowLoader:
 
 
 class HipAdam(optim.Optimizer):
-    """Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) as tm:119-122 constructs it, with
+    """Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay) as tm:119-122 constructs it, with
     the update executed by the HIP kernels.  Holds what torch's schedulers and callers look
     at (`param_groups[0]['lr']`) plus the per-net 1-based step counters: state is created
     lazily per parameter in torch, so a net's counter starts when it first receives a
     gradient (TE/MD start at 1 at the phase switch; SURVEY.md section 7 hard part 7)."""
 
     def __init__(self, params, engine, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        if weight_decay != 0.0:
-            raise NotImplementedError("weight_decay != 0 (the trainer uses 0.0, tpv:253)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.engine = engine
         self.net_steps = {NET_TE: 0, NET_MD: 0, NET_WM: 0, NET_PR: 0}

@@ -401,7 +401,8 @@ class TrainModel(torch_models.TrainModel):
         t = self.optimizer.next_counts(nets) if train else [1, 1, 1]
         return make_step_params(lr=self.optimizer.lr, adam_t=t, a_rec=self.a_rec_coeff,
                                 kl=self.vae_kl_coeff, s_rec=self.s_rec_coeff, cyc=self.vae_cycle_coeff,
-                                global_rows=global_rows, loss=self.loss_name)
+                                global_rows=global_rows, loss=self.loss_name,
+                                weight_decay=self.optimizer.param_groups[0]["weight_decay"])
 
     # explicit-batch entry points with the reference's signatures (tpv:356-435) -------------
     def compute_model(self, x, eps=None):

@@ -78,7 +78,7 @@ def test_gemm_wgrad(m, n, k):
 # ------------------------------------------------------------------------------------------
 def _setup_single(golden, name):
     g = golden(name)
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
     data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="iid")
     X, Y = R.build_windows(data)
@@ -90,7 +90,9 @@ def _setup_single(golden, name):
     return g, arch, data, x, y, sd, eps, tr
 
 
-@pytest.mark.parametrize("name", ["single_tiny", "single_c1", "single_c2", "single_default"])
+@pytest.mark.parametrize("name", ["single_tiny", "single_c1", "single_c2", "single_default",
+                                  # the trainer's "act_fn" edited (hidden activation of every stack)
+                                  "single_tiny_tanh", "single_tiny_sigmoid", "single_tiny_elu", "single_c1_tanh"])
 @pytest.mark.parametrize("world", [True, False])
 def test_single_batch_matches_oracle_and_golden(golden, name, world):
     g, arch, data, x, y, sd, eps, tr = _setup_single(golden, name)
@@ -389,7 +391,7 @@ def test_gather_prefetch_is_bit_identical(golden):
     epoch in between -- parameters, moments and losses equal the run that gathers in a launch of
     its own, bit for bit; a mispredicted next minibatch falls back to a normal gather."""
     g = golden("train_tiny")
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     n_ep, n_steps, batch, m_world, n_epochs, lr_step = [int(v) for v in g["meta"][9:15]]
     data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
     runs = []
@@ -517,14 +519,15 @@ def test_step_is_deterministic(golden):
 # ------------------------------------------------------------------------------------------
 # the whole loop against the reference's captured training runs
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["train_tiny", "train_c1"])
+@pytest.mark.parametrize("name", ["train_tiny", "train_c1", "train_tiny_elu_wd"])     # last: act_fn elu, weight_decay 0.01
 def test_training_run_matches_reference_capture(golden, name):
     g = golden(name)
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     n_ep, n_steps, batch, m_world, n_epochs, lr_step = [int(v) for v in g["meta"][9:15]]
     data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
+    wd = float(g["weight_decay"]) if "weight_decay" in g.files else 0.0
     tr = make_trainer(arch, data, batch, m_world=m_world, device=DEV, lr_step=lr_step,
-                      eps_fn=R.eps_stream(2, arch["Z"]))
+                      eps_fn=R.eps_stream(2, arch["Z"]), extra={"weight_decay": wd})
     tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3))
     losses = []
     for e in range(n_epochs):
@@ -828,7 +831,7 @@ def test_rollout_forward_from_weights_the_reference_accepted(golden):
     accepted (ckpt_interop_tiny.npz) give, through PhysicsVAE.forward on the HIP path (eps = 0), the
     logits and the predicted next state that the reference itself computed after loading them."""
     g = golden("ckpt_interop_tiny")
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     data = R.synth_demo(0, 2, 14, arch["Db"], arch["Da"], kind="iid")
     tr = make_trainer(arch, data, 8, device=DEV)
     tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, seed=7), seed=9))

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pvae_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.pvae_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_layout_queries_without_gpu():
@@ -76,7 +76,7 @@ def test_compute_without_gpu_fails_loudly():
 @pytest.mark.parametrize("name", ["single_tiny", "single_c1", "single_c2", "single_default"])
 def test_module_state_dict_matches_reference_layout(golden, name):
     g = golden(name)
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
     data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"])
     tr = make_trainer(arch, data, batch, device="cpu")
@@ -112,7 +112,7 @@ def test_module_state_dict_matches_reference_layout(golden, name):
 
 def test_checkpoint_files_match_reference_and_roundtrip(golden, tmp_path):
     g = golden("single_default")
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     data = R.synth_demo(0, 2, 100, arch["Db"], arch["Da"])
     tr = make_trainer(arch, data, 32, device="cpu")
     ref = R.perturb_biases(R.init_state_dict(arch, 1), 3)
@@ -382,7 +382,7 @@ def test_checkpoint_interop_with_the_reference_both_directions(golden, tmp_path)
     files and reproduced our weights (asserted in oracle/gen_golden.py, flags recorded); the forward
     pass the reference then computed is reproduced by the oracle from those weights."""
     g = golden("ckpt_interop_tiny")
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     data = R.synth_demo(0, 2, 14, arch["Db"], arch["Da"], kind="iid")
     names = sorted(k.split("::")[1] for k in g.files if k.startswith("ref_file::"))
     assert names == ["model.pt", "model.pth", "motor_decoder.pt", "task_encoder.pt", "world_model.pt"]
@@ -418,7 +418,7 @@ def test_multi_file_merge_and_num_data_cap_match_the_reference(golden, tmp_path)
     reference: window / batch counts and the loader's first and last minibatches -- for the pickle
     path and for packed .pvd files."""
     g = golden("ingest_tiny")
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     d1 = R.synth_demo(0, 2, 14, arch["Db"], arch["Da"], kind="iid")
     d2 = R.synth_demo(5, 3, 11, arch["Db"], arch["Da"], kind="iid")
     p1, p2 = str(tmp_path / "a.pkl"), str(tmp_path / "b.pkl")
@@ -621,7 +621,7 @@ def test_cond_rel_windows_match_the_reference_capture(golden, tmp_path):
     then the Dataset's float32 copy): our packed-once dataset (states + a row-aligned `next_states` array)
     yields the reference's own windows bit for bit, at lookahead 1 and 2; the oracle's build_windows too."""
     g = golden("ingest_rel_tiny")
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     data = R.synth_demo(3, 3, 12, arch["Db"], arch["Da"], kind="iid", quantum=0.0)
     pkl = str(tmp_path / "a.pkl")
     R.write_demo(pkl, data)
@@ -697,7 +697,7 @@ def test_no_prior_mode_layout_matches_the_reference_capture(golden):
     """latent_prior_type = False (rmt:622-623): the reference builds an encoder with Z outputs; same keys and
     shapes here, and its state dict round-trips through the arena views."""
     g = golden("noprior_tiny")
-    arch = dict(arch_from_meta(g["meta"]), prior=False)
+    arch = dict(arch_from_meta(g), prior=False)
     n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
     data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="iid")
     tr = make_trainer(arch, data, batch, device="cpu")
@@ -707,3 +707,35 @@ def test_no_prior_mode_layout_matches_the_reference_capture(golden):
         assert list(v.shape) == [int(x) for x in shp[: v.dim()]], k
     assert [(k, tuple(v.shape)) for k, v in sd.items()] == R.state_dict_spec(arch)
     assert tr.latent_prior_type is False
+
+
+# ------------------------------------------------------------------------------------------
+# trainer-config keys a user edits in the dict: "act_fn" (tpv:262) and "weight_decay" (tpv:253)
+# ------------------------------------------------------------------------------------------
+def test_act_fn_and_weight_decay_reach_the_model_and_the_step_params():
+    lib = _lib.load()
+    base = (7, 3, 4, 16, 2, 24, 2, 32, 2, 8, 1, 0, 0, 0)
+    n0 = lib.pvae_num_layers(C.byref(_lib.Config(*base)))                      # a zeroed act_kind = relu
+    for kind in _lib.ACT_KINDS.values():
+        assert lib.pvae_num_layers(C.byref(_lib.Config(*base, kind))) == n0
+    assert lib.pvae_num_layers(C.byref(_lib.Config(*base, 4))) < 0 and b"act_kind" in lib.pvae_last_error()
+    data = R.synth_demo(0, 2, 14, 7, 3)
+    for act, mod in (("tanh", torch.nn.Tanh), ("sigmoid", torch.nn.Sigmoid), ("elu", torch.nn.ELU)):
+        arch = R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2), act=act)
+        tr = make_trainer(arch, data, 8, device="cpu", extra={"weight_decay": 0.01})
+        assert tr.engine.cfg.act_kind == _lib.ACT_KINDS[act]
+        for net in (tr.model._task_encoder, tr.model._motor_decoder, tr.model._world_model):
+            assert isinstance(net._model[0]._model[1], mod) and len(net._model[2]._model) == 1     # linear output layer
+        assert isinstance(tr.model._value_branch._model[0]._model[1], torch.nn.ReLU)               # value_fn_layers: untouched
+        assert [(k, tuple(v.shape)) for k, v in tr.model.state_dict().items()] == R.state_dict_spec(arch)
+        assert tr.step_params([_lib.NET_WM], 8, True).weight_decay == pytest.approx(0.01)
+    with pytest.raises(NotImplementedError):                                   # needs the pre-activation backward
+        make_trainer(R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2)), data, 8, device="cpu",
+                     extra={"act_fn": "swish"})
+    from physicsvae_amd.model import PhysicsVAE
+    from physicsvae_amd import train_physics_vae as T
+    tr = make_trainer(R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2)), data, 8, device="cpu")
+    cfg = dict(tr.config["model"]["custom_model_config"])
+    cfg["world_model_layers"] = T.gen_layers(32, 2, act_hidden="tanh")          # stacks must agree on the HIP path
+    with pytest.raises(NotImplementedError):
+        PhysicsVAE(cfg["observation_space"], cfg["action_space"], 6, {"custom_model_config": cfg}, "m")

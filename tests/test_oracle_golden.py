@@ -9,17 +9,23 @@ from oracle import refpath as R
 
 
 def arch_from_meta(meta):
+    """`meta` of a fixture, or the fixture itself (then an edited "act_fn" recorded in it is honoured)."""
+    act = "relu"
+    if hasattr(meta, "files"):
+        act = str(meta["act_fn"]) if "act_fn" in meta.files else "relu"
+        meta = meta["meta"]
     Db, Da, Z, tw, td, mw, md_, ww, wd = [int(v) for v in meta[:9]]
-    return R.make_arch(Db, Da, latent=Z, te=(tw, td), md=(mw, md_), wm=(ww, wd))
+    return R.make_arch(Db, Da, latent=Z, te=(tw, td), md=(mw, md_), wm=(ww, wd), act=act)
 
 
-SINGLE = ["single_tiny", "single_c1", "single_c2", "single_default"]
+SINGLE = ["single_tiny", "single_c1", "single_c2", "single_default",
+          "single_tiny_tanh", "single_tiny_sigmoid", "single_tiny_elu", "single_c1_tanh"]      # last four: "act_fn" edited
 
 
 @pytest.mark.parametrize("name", SINGLE)
 def test_state_dict_layout_matches_reference(golden, name):
     g = golden(name)
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     spec = R.state_dict_spec(arch)
     assert [k for k, _ in spec] == list(g["sd_keys"])
     shapes = [list(s) + [0] * (2 - len(s)) for _, s in spec]
@@ -48,7 +54,7 @@ def test_tensor_counts_26_24_36(golden):
 @pytest.mark.parametrize("name", SINGLE)
 def test_windows_and_loader_match_reference(golden, name):
     g = golden(name)
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
     data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="iid")
     X, Y = R.build_windows(data)
@@ -79,7 +85,7 @@ def test_num_samples_cap_is_exact():
 @pytest.mark.parametrize("name", SINGLE)
 def test_single_batch_losses_and_grads_match_reference(golden, name):
     g = golden(name)
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
     data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="iid")
     X, Y = R.build_windows(data)
@@ -121,7 +127,7 @@ def test_lookahead_unroll_matches_reference(golden, name):
     were captured with trainer key "loss" = "L1" (nn.L1Loss for the three reconstruction terms)."""
     g = golden(name)
     loss = "L1" if name.startswith("l1_") else "MSE"
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     n_ep, n_steps, batch, L = [int(v) for v in g["meta"][9:13]]
     data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
     X, Y = R.build_windows(data, lookahead=L)
@@ -166,7 +172,7 @@ def test_frozen_nets_get_no_grad(golden):
 
 def test_checkpoint_layout_matches_reference(golden):
     g = golden("single_default")
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     sd = R.init_state_dict(arch, 1)
     files = R.checkpoint_files(sd)
     assert sorted(files) == list(g["ckpt_files"])
@@ -178,17 +184,18 @@ def test_checkpoint_layout_matches_reference(golden):
         assert list(obj.keys()) == list(g["ckpt_keys::" + f]), f
 
 
-@pytest.mark.parametrize("name", ["train_tiny", "train_c1", "train_tiny_look2"])
+@pytest.mark.parametrize("name", ["train_tiny", "train_c1", "train_tiny_look2", "train_tiny_elu_wd"])
 def test_training_run_matches_reference(golden, name):
     g = golden(name)
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     n_ep, n_steps, batch, m_world, n_epochs, lr_step = [int(v) for v in g["meta"][9:15]]
     L = int(g["meta"][15]) if len(g["meta"]) > 15 else 1
+    wd = float(g["weight_decay"]) if "weight_decay" in g.files else 0.0       # "weight_decay" edited (tpv:253)
     data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
     X, Y = R.build_windows(data, lookahead=L)
     sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
     tr = R.RefTrainer(arch, sd, X, Y, batch, m_world, lr_step=lr_step,
-                      eps_fn=R.eps_stream(2, arch["Z"]))
+                      eps_fn=R.eps_stream(2, arch["Z"]), weight_decay=wd)
     losses = []
     for e in range(n_epochs):
         lr = tr.opt.param_groups[0]["lr"]

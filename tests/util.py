@@ -10,8 +10,13 @@ from physicsvae_amd.tune import grid_search as tune_grid
 
 
 def arch_from_meta(meta):
+    """`meta` of a fixture, or the fixture itself (then an edited "act_fn" recorded in it is honoured)."""
+    act = "relu"
+    if hasattr(meta, "files"):
+        act = str(meta["act_fn"]) if "act_fn" in meta.files else "relu"
+        meta = meta["meta"]
     Db, Da, Z, tw, td, mw, md_, ww, wd = [int(v) for v in meta[:9]]
-    return R.make_arch(Db, Da, latent=Z, te=(tw, td), md=(mw, md_), wm=(ww, wd))
+    return R.make_arch(Db, Da, latent=Z, te=(tw, td), md=(mw, md_), wm=(ww, wd), act=act)
 
 
 def make_trainer(arch, data, batch, m_world=2, device=None, eps_fn=None, lr_step=50, extra=None):
@@ -31,6 +36,7 @@ def make_trainer(arch, data, batch, m_world=2, device=None, eps_fn=None, lr_step
     cfg = T.get_trainer_config(T.args)
     if arch.get("prior", R.PRIORS[0]) is False:           # (not reachable from the CLI, upstream neither: a dict edit)
         cfg["latent_prior_type"] = tune_grid([False])
+    cfg["act_fn"] = arch.get("act", "relu")               # tpv:262, a dict edit as well
     if arch.get("prior") == R.PRIORS[1] and tuple(arch["pr"]) != tuple(arch["te"]):
         cfg["model"]["custom_model_config"]["latent_prior_layers"] = T.gen_layers(arch["pr"][0], arch["pr"][1])
     cfg["lr_schedule_params"] = {"step_size": lr_step, "gamma": 0.7}
