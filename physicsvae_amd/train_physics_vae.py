@@ -65,6 +65,10 @@ def arg_parser():
     p.add_argument("--world_model_width", type=int, default=1024)
     p.add_argument("--world_model_depth", type=int, default=2)
     p.add_argument("--seed", type=int, default=0)
+    # ours: two more dict-only keys of the reference (tpv:262 "act_fn", tpv:253 "weight_decay")
+    p.add_argument("--act_fn", type=str, default="relu", choices=["relu", "tanh", "sigmoid", "elu"],
+                   help="hidden activation of the task encoder, motor decoder and world model")
+    p.add_argument("--weight_decay", type=float, default=0.0, help="Adam's L2 term")
     p.add_argument("--lookahead", type=int, default=1,
                    help="steps unrolled through the world model per sample (config key tpv:277)")
     return p
@@ -317,7 +321,7 @@ def get_trainer_config(a):
         "lr": a.lr,
         "lr_schedule_params": {"step_size": 50, "gamma": 0.70},
         "lr_schedule": a.lr_schedule,
-        "weight_decay": 0.0,
+        "weight_decay": getattr(a, "weight_decay", 0.0),
         "dataset_train": a.data_train,
         "dataset_test": a.data_test,
         "use_gpu": False,
@@ -327,7 +331,7 @@ def get_trainer_config(a):
         "suffle_data": True,            # sic -- the key the reference sets; nothing reads it
         "latent_dim": a.latent_dim,
         "latent_prior_type": tune.grid_search(prior_list),
-        "act_fn": "relu",
+        "act_fn": getattr(a, "act_fn", "relu"),
         "MD_width": tune.grid_search([getattr(a, "MD_width", 512)]),
         "MD_depth": tune.grid_search([getattr(a, "MD_depth", 3)]),
         "TE_width": tune.grid_search([getattr(a, "TE_width", 256)]),

@@ -739,3 +739,15 @@ def test_act_fn_and_weight_decay_reach_the_model_and_the_step_params():
     cfg["world_model_layers"] = T.gen_layers(32, 2, act_hidden="tanh")          # stacks must agree on the HIP path
     with pytest.raises(NotImplementedError):
         PhysicsVAE(cfg["observation_space"], cfg["action_space"], 6, {"custom_model_config": cfg}, "m")
+
+
+def test_cli_flags_for_act_fn_and_weight_decay(tmp_path):
+    from physicsvae_amd import train_physics_vae as T
+    pkl = str(tmp_path / "d.pkl")
+    R.write_demo(pkl, R.synth_demo(0, 2, 14, 7, 3))
+    a = T.arg_parser().parse_args(["--data_train", pkl, "--act_fn", "elu", "--weight_decay", "0.01"])
+    cfg = T.get_trainer_config(a)
+    assert cfg["act_fn"] == "elu" and cfg["weight_decay"] == 0.01
+    a = T.arg_parser().parse_args(["--data_train", pkl])
+    cfg = T.get_trainer_config(a)
+    assert cfg["act_fn"] == "relu" and cfg["weight_decay"] == 0.0              # tpv:262, 253
