@@ -20,7 +20,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(16))
 def test_random_call_sequences_leave_identical_state(seed):
     rng = np.random.default_rng(500 + seed)
-    arch = R.make_arch(23, 7, latent=8, te=(64, 2), md=(96, 3), wm=(128, 2))
+    act = ("relu", "relu", "tanh", "sigmoid", "elu")[seed % 5]          # the trainer's "act_fn"
+    wd = 0.01 if seed % 3 == 0 else 0.0                                 # ... and "weight_decay"
+    arch = R.make_arch(23, 7, latent=8, te=(64, 2), md=(96, 3), wm=(128, 2), act=act)
     data = R.synth_demo(seed, 3, 120, 23, 7, kind="dynamics")
     data2 = R.synth_demo(seed + 50, 2, 90, 23, 7, kind="dynamics")
     sd = R.perturb_biases(R.init_state_dict(arch, seed + 1), seed + 3)
@@ -52,7 +54,7 @@ def test_random_call_sequences_leave_identical_state(seed):
                 t_adam[n] += 1
             return make_step_params(lr=1e-3, adam_t=tuple(max(t, 1) for t in t_adam), a_rec=co["a_rec_coeff"],
                                     kl=co["vae_kl_coeff"], s_rec=co["s_rec_coeff"], cyc=co["vae_cycle_coeff"],
-                                    global_rows=rows, seed=11, offset=step * 65536)
+                                    global_rows=rows, seed=11, offset=step * 65536, weight_decay=wd)
         if op in ("train", "train_pf"):
             sp = params()
             nxt = (int(rng.integers(0, n_win - rows)), rows) if op == "train_pf" else None
