@@ -1113,31 +1113,38 @@ struct AdamSeg {
 };
 constexpr int kAdamBlocks = 256;
 #ifndef PVAE_ADAM_UNROLL
-#define PVAE_ADAM_UNROLL 1     // float4 elements per thread in flight (A/B: 2 issues both trips' loads up front)
+#define PVAE_ADAM_UNROLL 1     // float4 elements per thread in flight (A/B: >1 issues all trips' loads up front)
+#endif
+#ifndef PVAE_ADAM_DELAY
+#define PVAE_ADAM_DELAY 0      // s_sleep argument (x64 clocks) before the first load (A/B: let the contractions' cold fetches go first)
 #endif
 __device__ inline void adam_seg_body(const AdamSeg& a, int blk) {
     long long i = blk * 256ll + threadIdx.x;
-#if PVAE_ADAM_UNROLL == 2
     constexpr long long kStride = kAdamBlocks * 256ll;
-    for (; i + kStride < a.n4; i += 2 * kStride) {
-        v4f pp[2], gg[2], mm[2], vv[2];
+    constexpr int U = PVAE_ADAM_UNROLL;
+#if PVAE_ADAM_DELAY > 0
+    __builtin_amdgcn_s_sleep(PVAE_ADAM_DELAY);
+#endif
+    if (U > 1) {
+        for (; i + (U - 1) * kStride < a.n4; i += U * kStride) {
+            v4f pp[U], gg[U], mm[U], vv[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            pp[u] = reinterpret_cast<v4f*>(a.p)[i + u * kStride];
-            gg[u] = reinterpret_cast<const v4f*>(a.g)[i + u * kStride];
-            mm[u] = reinterpret_cast<v4f*>(a.m)[i + u * kStride];
-            vv[u] = reinterpret_cast<v4f*>(a.v)[i + u * kStride];
-        }
+            for (int u = 0; u < U; ++u) {
+                pp[u] = reinterpret_cast<v4f*>(a.p)[i + u * kStride];
+                gg[u] = reinterpret_cast<const v4f*>(a.g)[i + u * kStride];
+                mm[u] = reinterpret_cast<v4f*>(a.m)[i + u * kStride];
+                vv[u] = reinterpret_cast<v4f*>(a.v)[i + u * kStride];
+            }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            adam_update4(gg[u], pp[u], mm[u], vv[u], a.s);
-            store_stream(a.p + 4 * (i + u * kStride), pp[u]);
-            store_stream(a.m + 4 * (i + u * kStride), mm[u]);
-            store_stream(a.v + 4 * (i + u * kStride), vv[u]);
+            for (int u = 0; u < U; ++u) {
+                adam_update4(gg[u], pp[u], mm[u], vv[u], a.s);
+                store_stream(a.p + 4 * (i + u * kStride), pp[u]);
+                store_stream(a.m + 4 * (i + u * kStride), mm[u]);
+                store_stream(a.v + 4 * (i + u * kStride), vv[u]);
+            }
         }
     }
-#endif
-    for (; i < a.n4; i += kAdamBlocks * 256ll) {
+    for (; i < a.n4; i += kStride) {
         v4f pp = reinterpret_cast<v4f*>(a.p)[i];
         const v4f gg = reinterpret_cast<const v4f*>(a.g)[i];
         v4f mm = reinterpret_cast<v4f*>(a.m)[i];
