@@ -220,3 +220,26 @@ def test_unrolled_full_size_step_tracks_oracle():
     tr.eps_fn = None                               # Philox draws, L consecutive offsets per step
     res = tr.train()
     assert np.isfinite(res["mean_train_loss"])
+
+
+@pytest.mark.parametrize("act", ["tanh", "sigmoid", "elu"])
+def test_unrolled_training_with_other_activations_tracks_oracle(act):
+    """The trainer's "act_fn" through the multi-step unroll (every launch of the unrolled plan carries the
+    activation and its derivative): a lookahead-2 run with Adam weight decay crossing the phase switch follows
+    the oracle's loop epoch by epoch."""
+    arch = R.make_arch(23, 7, latent=8, te=(64, 2), md=(96, 2), wm=(128, 3), act=act)
+    L = 2
+    data = R.synth_demo(0, 3, 80, 23, 7, kind="dynamics")
+    X, Y = R.build_windows(data, lookahead=L)
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    es = R.eps_stream(2, 8)
+    ref = R.RefTrainer(arch, sd, X, Y, 32, max_iter_world_model=2, eps_fn=es, weight_decay=0.01)
+    tr = make_trainer(arch, data, 32, m_world=2, device=DEV, eps_fn=es, extra={"lookahead": L, "weight_decay": 0.01})
+    tr.model.load_state_dict(sd)
+    for epoch in range(4):
+        want = ref.step()["mean_train_loss"]
+        got = tr.train()["mean_train_loss"]
+        assert got == pytest.approx(want, rel=1e-3), (act, epoch)
+    for k, v in ref.model.state_dict().items():
+        if not k.startswith("_value_branch"):
+            assert rel_err(tr.model.state_dict()[k].cpu(), v) < (0.1 if k.endswith("bias") else 2e-2), k
