@@ -563,6 +563,8 @@ gemv_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__
 //   kind 2: [obs[r][0:Ka] | z_r],  z = mu + eps * exp(logvar / 2) from the encoder's output   (first decoder layer:
 //           the sampler of rmt:734-740 runs here; workgroup 0 also records z and the draws)
 //   kind 3: [obs[r][0:Ka] | src_b[r][0:Kb]]                                        (first world-model layer: a_hat)
+//   kinds 4 / 5: [obs[r][0:Ka] | e_r] resp. [obs | e_r / |e_r|], e = the encoder's Z outputs (latent_prior_type False /
+//           hypersphere_uniform: what sphere_kernel computes on the training path)
 // One wave per output feature streams its weight row once (as gemv_rows_kernel); rows >= `rows` of the
 // R-row template are computed on zeros and never stored.
 struct RolloutIn {
@@ -618,6 +620,30 @@ gemv_rollout_kernel(RolloutIn in, int rows, const float* __restrict__ W, int ldw
                     }
                 } else if (in.kind == 3) {
                     v = in.b[(size_t)r * in.ldb + j];
+                } else if (in.kind == 4) {          // latent_prior_type False: the encoder's outputs are the code
+                    v = in.b[(size_t)r * in.ldb + j];
+                    if (blockIdx.x == 0) {
+                        if (in.z_out) in.z_out[(size_t)r * in.Kb + j] = v;
+                        in.eps_used[(size_t)r * in.Kb + j] = 0.f;
+                    }
+                } else if (in.kind == 5) {          // hypersphere: z = e / max(|e|, 1e-12) (sphere_kernel)
+                    float e2 = 0.f;
+                    for (int q = 0; q < in.Kb; ++q) { const float e = in.b[(size_t)r * in.ldb + q]; e2 += e * e; }
+                    v = in.b[(size_t)r * in.ldb + j] * (1.0f / fmaxf(sqrtf(e2), 1e-12f));
+                    if (blockIdx.x == 0) {
+                        float u = 0.f;
+                        if (in.noise) {             // the prior sample of this forward, recorded only
+                            float n2 = 0.f, mine = 0.f;
+                            for (int q = 0; q < in.Kb; ++q) {
+                                const float nz = in.eps ? in.eps[(size_t)r * in.Kb + q] : philox_normal(in.seed, in.offset, r, q);
+                                n2 += nz * nz;
+                                if (q == j) mine = nz;
+                            }
+                            u = mine * (1.0f / fmaxf(sqrtf(n2), 1e-12f));
+                        }
+                        if (in.z_out) in.z_out[(size_t)r * in.Kb + j] = v;
+                        in.eps_used[(size_t)r * in.Kb + j] = u;
+                    }
                 }
             }
         }
@@ -2195,7 +2221,7 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
     hipStream_t st = (hipStream_t)stream;
     if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
     static const bool fused_rollout = [] { const char* e = getenv("PVAE_ROLLOUT_FUSED"); return !(e && e[0] == '0'); }();
-    if (rows <= 4 && fused_rollout && c->L.cfg.prior_kind < PVAE_PRIOR_HYPERSPHERE) {
+    if (rows <= 4 && fused_rollout) {
         // latency path of the control loop (rmt:742-771 at B = 1): no staging / sampler / copy launches, the
         // input panels of a staged training minibatch are not touched
         const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
@@ -2230,7 +2256,8 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
         if ((rc = run_net(PVAE_NET_TE, te, nullptr, 0, 0))) return rc;
         RolloutIn md;
         memset(&md, 0, sizeof(md));
-        md.kind = 2; md.a = obs; md.lda = 2 * Db; md.Ka = Db;
+        md.kind = c->L.cfg.prior_kind == PVAE_PRIOR_NONE ? 4 : c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE ? 5 : 2;
+        md.a = obs; md.lda = 2 * Db; md.Ka = Db;
         md.b = w + c->W.net[PVAE_NET_TE].act.back(); md.ldb = c->L.net[PVAE_NET_TE].layers.back().n_out_pad; md.Kb = Z;
         md.eps = eps; md.noise = noise ? 1 : 0; md.seed = rng_seed; md.offset = rng_offset;
         md.z_out = z_out; md.eps_used = w + c->W.eps;

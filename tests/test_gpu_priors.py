@@ -250,3 +250,28 @@ def test_no_prior_mode_matches_the_reference_capture(golden, paired, monkeypatch
     assert max_err_scaled(tr.model.task_encoder_variable().cpu(), ref_m.cur_z) < 2e-5
     r1, r2 = tr.train(), tr.train()
     assert np.isfinite(r1["mean_train_loss"]) and np.isfinite(r2["mean_train_loss"])
+
+
+@pytest.mark.parametrize("prior", [False, R.PRIORS[2]])
+@pytest.mark.parametrize("rows", [1, 3, 4, 6])
+def test_rollout_forward_of_the_sample_free_priors(prior, rows):
+    """The rollout path (<= 4 rows: input assembly inside the layer launches, 7 launches) for the two priors
+    whose code is a function of the encoder output alone -- `False`: z = e; hypersphere: z = e / |e| -- against
+    the oracle's module forward, and against the staged path the larger batches take (6 rows)."""
+    arch = R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2), prior=prior)
+    data = R.synth_demo(0, 2, 14, 7, 3, kind="iid")
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    tr = make_trainer(arch, data, 8, device=DEV)
+    tr.model.load_state_dict(sd)
+    ref = R.RefModel(arch)
+    ref.load_state_dict(sd)
+    obs = torch.randn(rows, 14, generator=torch.Generator().manual_seed(rows))
+    e = torch.randn(rows, 4, generator=torch.Generator().manual_seed(7))
+    ref.eps_source = lambda shape: e
+    with torch.no_grad():
+        want = ref(obs)
+    a_hat, s2, z = tr.engine.infer(obs.to(DEV), eps=e.to(DEV), noise=True, want_s2=True)
+    assert max_err_scaled(a_hat.cpu(), want[:, :3]) < 2e-5 and max_err_scaled(z.cpu(), ref.cur_z) < 2e-5
+    assert max_err_scaled(s2.cpu(), ref.cur_future_state) < 2e-5
+    a2, none, z2 = tr.engine.infer(obs.to(DEV), noise=False, want_s2=False)
+    assert none is None and max_err_scaled(a2.cpu(), want[:, :3]) < 2e-5
