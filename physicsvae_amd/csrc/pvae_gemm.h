@@ -202,6 +202,10 @@ __device__ inline void stage_row(const StageArgs& a, int r, int t, int rows_pad)
 #define PVAE_REG_DEPTH_W 2
 #endif
 static int g_krot = [] { const char* e = getenv("PVAE_KROT"); return (e && e[0] == '1') ? 1 : 0; }();
+// Experiment (off by default): XCD x takes q-tile (row block) x of a 256-row layer and ALL its p-tiles, instead of
+// all q-tiles of an eighth of the p-tiles -- the operand traffic a row-block-stationary multi-layer kernel would
+// have (every XCD streams the whole weight matrix through its L2).  Same tiles, same results.
+static int g_rowxcd = [] { const char* e = getenv("PVAE_ROWXCD"); return (e && e[0] == '1') ? 1 : 0; }();
 struct GemmArgs {
     const float* Q;
     int ldq;
@@ -211,6 +215,7 @@ struct GemmArgs {
     int krot = g_krot;        // rotate each workgroup's K order (see k_rotation)
     int tile32 = 0;           // weight gradient on 32x32 output tiles (wgrad32_body) instead of 64x64
     int tile16 = 0;           // input gradient on 16x16 output tiles (splitk_reg16_body<false>) instead of 32x32
+    int rowxcd = g_rowxcd;    // see g_rowxcd
 };
 
 // Experiment (off by default): start each workgroup at a different k-tile and wrap around, so that
@@ -435,8 +440,9 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
     const float* __restrict__ P = ga.P;
     const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
     const int xcd = bid & 7, loc = bid >> 3;
-    const int tile_p = xcd * ga.p_per_xcd + loc / tiles_q;
-    const int tile_q = loc % tiles_q;
+    int tile_p = xcd * ga.p_per_xcd + loc / tiles_q;
+    int tile_q = loc % tiles_q;
+    if (ga.rowxcd && tiles_q == 8 && tiles_p == 8 * ga.p_per_xcd) { tile_q = xcd; tile_p = loc; }
     if (tile_p >= tiles_p) return;
     const int q0 = tile_q * 32, p0 = tile_p * 32;
 
