@@ -19,12 +19,13 @@ barrier_kernel(unsigned* counters, float* slab, int rounds, int words, unsigned*
     __shared__ int s_spun;
     const int xcd = blockIdx.x & 7, rank = blockIdx.x >> 3;            // 32 ranks per XCD
     unsigned* ctr = counters + xcd * 64;                               // one 256-byte line per XCD
-    float* mine = slab + ((size_t)xcd * 32 + rank) * words;
     unsigned errors = 0;
     float acc = 0.f;
     const unsigned long long t0 = wall_clock64();
     for (int r = 1; r <= rounds; ++r) {
         if (mode & 1) {
+            // two slabs by round parity: a neighbour that is already a round ahead writes the OTHER one
+            float* mine = slab + (size_t)(r & 1) * 8 * 32 * 4096 + ((size_t)xcd * 32 + rank) * words;
             for (int i = threadIdx.x; i < words; i += 256) mine[i] = (float)(r * 1000 + rank);      // plain stores
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -44,9 +45,9 @@ barrier_kernel(unsigned* counters, float* slab, int rounds, int words, unsigned*
         if (mode & 1) {
             // read one word of every neighbour's payload (sc1: past the L1)
             if (threadIdx.x < 32) {
-                const float* theirs = slab + ((size_t)xcd * 32 + threadIdx.x) * words + (r % words);
+                const float* theirs = slab + (size_t)(r & 1) * 8 * 32 * 4096 + ((size_t)xcd * 32 + threadIdx.x) * words + (r % words);
                 const float v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v != (float)(r * 1000 + (int)threadIdx.x)) ++errors;
+                if (v != (float)(r * 1000 + (int)threadIdx.x)) { ++errors; if (v < (float)(r * 1000)) errors += 0x10000; }   // high half: words from an EARLIER round
                 acc += v;
             }
         }
@@ -60,7 +61,7 @@ barrier_kernel(unsigned* counters, float* slab, int rounds, int words, unsigned*
 int main() {
     unsigned *d_census, *counters, *bad; float* slab; unsigned long long* t;
     CK(hipMalloc(&d_census, 256 * 4)); CK(hipMalloc(&counters, 8 * 256)); CK(hipMalloc(&bad, 4));
-    CK(hipMalloc(&slab, (size_t)8 * 32 * 4096 * 4)); CK(hipMalloc(&t, 256 * 8));
+    CK(hipMalloc(&slab, (size_t)2 * 8 * 32 * 4096 * 4)); CK(hipMalloc(&t, 256 * 8));
     hipLaunchKernelGGL(census, dim3(256), dim3(64), 0, 0, d_census);
     unsigned h[256];
     CK(hipMemcpy(h, d_census, sizeof(h), hipMemcpyDeviceToHost));
@@ -73,7 +74,7 @@ int main() {
     for (int mode = 0; mode < 2; ++mode)
         for (int words : {256, 1024, 4096}) {
             if (!mode && words != 256) continue;
-            CK(hipMemset(counters, 0, 8 * 256)); CK(hipMemset(bad, 0, 4)); CK(hipMemset(slab, 0, (size_t)8 * 32 * 4096 * 4));
+            CK(hipMemset(counters, 0, 8 * 256)); CK(hipMemset(bad, 0, 4)); CK(hipMemset(slab, 0, (size_t)2 * 8 * 32 * 4096 * 4));
             hipLaunchKernelGGL(barrier_kernel, dim3(256), dim3(256), 0, 0, counters, slab, rounds, words, bad, t, mode);
             CK(hipDeviceSynchronize());
             unsigned long long ht[256]; unsigned hb;
