@@ -14,7 +14,8 @@ __global__ void census(unsigned* out) {
 
 // payload: each workgroup publishes `words` floats per round into slab[xcd][rank][words]
 __global__ void __launch_bounds__(256)
-barrier_kernel(unsigned* counters, float* slab, int rounds, int words, unsigned* bad, unsigned long long* t, int mode) {
+barrier_kernel(unsigned* counters, float* slab, int rounds, int words, unsigned* bad, unsigned long long* t, int mode,
+               const float4* stream, size_t stream_n4) {
     __shared__ float sink[256];
     __shared__ int s_spun;
     const int xcd = blockIdx.x & 7, rank = blockIdx.x >> 3;            // 32 ranks per XCD
@@ -22,7 +23,19 @@ barrier_kernel(unsigned* counters, float* slab, int rounds, int words, unsigned*
     unsigned errors = 0;
     float acc = 0.f;
     const unsigned long long t0 = wall_clock64();
+    float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int r = 1; r <= rounds; ++r) {
+        if (mode & 2) {
+            // what a layer's main loop does to the memory system: 256 KB of operand loads per workgroup and round
+            // (mode & 4: the same loads WITHOUT the barrier = the control)
+            size_t base = ((size_t)blockIdx.x * 16384 + (size_t)r * 1048576 * 3) % (stream_n4 - 16384);
+#pragma unroll 8
+            for (int i = 0; i < 64; ++i) {
+                const float4 v = stream[base + (size_t)i * 256 + threadIdx.x];
+                sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
+            }
+        }
+        if (mode & 4) continue;
         if (mode & 1) {
             // two slabs by round parity: a neighbour that is already a round ahead writes the OTHER one
             float* mine = slab + (size_t)(r & 1) * 8 * 32 * 4096 + ((size_t)xcd * 32 + rank) * words;
@@ -53,7 +66,8 @@ barrier_kernel(unsigned* counters, float* slab, int rounds, int words, unsigned*
         }
     }
     const unsigned long long t1 = wall_clock64();
-    sink[threadIdx.x] = acc;
+    sink[threadIdx.x] = acc + sacc.x + sacc.y + sacc.z + sacc.w;
+    if (sink[threadIdx.x] == 12345.678f) bad[0] = 1;
     if (errors) atomicAdd(bad, errors);
     if (threadIdx.x == 0) t[blockIdx.x] = t1 - t0;
 }
@@ -71,18 +85,21 @@ int main() {
            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     if (!ok) return 0;
     const int rounds = 2000;
-    for (int mode = 0; mode < 2; ++mode)
+    float4* stream; const size_t stream_n4 = (size_t)64 * 1024 * 1024 / 16;
+    CK(hipMalloc(&stream, stream_n4 * 16)); CK(hipMemset(stream, 0, stream_n4 * 16));
+    for (int mode : {0, 1, 6, 2, 3})
         for (int words : {256, 1024, 4096}) {
-            if (!mode && words != 256) continue;
+            if (mode != 1 && mode != 3 && words != 1024) continue;
             CK(hipMemset(counters, 0, 8 * 256)); CK(hipMemset(bad, 0, 4)); CK(hipMemset(slab, 0, (size_t)2 * 8 * 32 * 4096 * 4));
-            hipLaunchKernelGGL(barrier_kernel, dim3(256), dim3(256), 0, 0, counters, slab, rounds, words, bad, t, mode);
+            hipLaunchKernelGGL(barrier_kernel, dim3(256), dim3(256), 0, 0, counters, slab, rounds, words, bad, t, mode, stream, stream_n4);
             CK(hipDeviceSynchronize());
             unsigned long long ht[256]; unsigned hb;
             CK(hipMemcpy(ht, t, sizeof(ht), hipMemcpyDeviceToHost)); CK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost));
             unsigned long long mx = 0;
             for (int i = 0; i < 256; ++i) mx = ht[i] > mx ? ht[i] : mx;
-            if (mode) printf("barrier + %5d-byte payload per workgroup (plain stores, drained; one word of each neighbour checked): ", words * 4);
-            else printf("barrier alone:                                                                                         ");
+            const char* what[8] = {"barrier alone", "barrier + payload", "256 KB of loads per workgroup + barrier", "256 KB of loads + barrier + payload", "", "",
+                                   "256 KB of loads per workgroup, NO barrier (control)", ""};
+            printf("%-52s payload %5d B: ", what[mode], (mode & 1) ? words * 4 : 0);
             printf("%.2f us per round, %s\n", mx / 100.0 / rounds, hb == 0 ? "all words fresh" : (hb & 0x80000000u ? "TIMED OUT" : "STALE WORDS SEEN"));
             if (hb) printf("   (error word 0x%x)\n", hb);
         }
