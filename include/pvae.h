@@ -311,6 +311,21 @@ int pvae_read_tensor(pvae_ctx* ctx, int what, float* dst, int32_t rows, void* st
 int pvae_infer(pvae_ctx* ctx, const float* obs, int32_t rows, const float* eps, int noise,
                uint64_t rng_seed, uint64_t rng_offset, float* a_hat, float* s2_hat, float* z_out,
                void* stream);
+/* pvae_infer with the module's output layout (rmt:742-771 + AppendLogStd rmt:160-206): the action lands in
+ * logits[r * ld_logits + 0 .. Da) and, when log_std (device, [Da]) is given, log_std behind it --
+ * logits = [a_hat | log_std], what PhysicsVAE.forward returns to RLlib's action distribution. */
+int pvae_infer_logits(pvae_ctx* ctx, const float* obs, int32_t rows, const float* eps, int noise,
+                      uint64_t rng_seed, uint64_t rng_offset, float* logits, int32_t ld_logits,
+                      const float* log_std, float* s2_hat, float* z_out, void* stream);
+/* A stack of Linear layers on CALLER-owned dense row-major weights (W[i]: [n_out[i]][n_in[i]], row stride
+ * ldw[i], no alignment needed; bias may be NULL), hidden activation PVAE_ACT_*, linear output layer.
+ * scratch: 2 * rows * (widest hidden layer) floats (device).  No context: this is the value branch of
+ * the rollout model (rmt:846-853, value_fn_layers 2*Db -> 256 -> 256 -> 1), whose parameters stay plain
+ * torch tensors because the supervised loss never touches them. */
+int pvae_mlp_forward(const float* x, int32_t rows, int32_t ldx, int32_t n_layers, const float* const* W,
+                     const float* const* bias, const int32_t* n_in, const int32_t* n_out,
+                     const int32_t* ldw, int32_t act_kind, float* scratch, float* out, int32_t ld_out,
+                     void* stream);
 
 /* One stack on its own: in[rows][n_in] (dense) -> out[rows][n_out] (dense).  The building
  * block behind forward_encoder / forward_decoder / forward_world (rmt:773-844) when a caller

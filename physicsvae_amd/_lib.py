@@ -98,6 +98,8 @@ _SIGS = {
                                            C.c_int64, C.c_int32, _P]),
     "pvae_read_tensor": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P]),
     "pvae_infer": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
+    "pvae_infer_logits": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int, C.c_uint64, C.c_uint64, _P, C.c_int32, _P, _P, _P, _P]),
+    "pvae_mlp_forward": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, _P]),
     "pvae_net_forward": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P, _P]),
     "pvae_reparam": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int, C.c_uint64, C.c_uint64, _P, _P]),
     "pvae_mfma_clock_probe": (C.c_int, [_P, C.c_int64, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),

@@ -579,7 +579,7 @@ template <int R>
 __global__ void __launch_bounds__(256)
 gemv_rollout_kernel(RolloutIn in, int rows, const float* __restrict__ W, int ldw, const float* __restrict__ bias,
                     float* __restrict__ out, int ldo, int K, int relu, float* __restrict__ out2, int ld2, int n2,
-                    int n_valid) {
+                    int n_valid, const float* __restrict__ ls) {
     extern __shared__ __attribute__((aligned(16))) float xs[];         // [R][K], K = ld of the layer (multiple of 64)
     const int tid = threadIdx.x;
     // this wave's weight row: the first 1024 columns are requested BEFORE the input rows are assembled,
@@ -681,8 +681,47 @@ gemv_rollout_kernel(RolloutIn in, int rows, const float* __restrict__ W, int ldw
             v += bias[n];
             v = (relu > 1 && n >= n_valid) ? 0.f : act_apply(v, relu);
             out[(size_t)r * ldo + n] = v;
-            if (out2 && n < n2) out2[(size_t)r * ld2 + n] = v;
+            if (out2 && n < n2) {
+                out2[(size_t)r * ld2 + n] = v;
+                if (ls) out2[(size_t)r * ld2 + n2 + n] = ls[n];       // AppendLogStd (rmt:160-206): [a_hat | log_std]
+            }
         }
+    }
+}
+
+// logits[r][n .. 2n) = log_std[0 .. n) for the staged inference path (AppendLogStd, rmt:160-206)
+__global__ void __launch_bounds__(256)
+append_logstd_kernel(float* __restrict__ logits, int ld, int n, int rows, const float* __restrict__ ls) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rows * n; idx += gridDim.x * 256) {
+        const int r = idx / n, c = idx - r * n;
+        logits[(size_t)r * ld + n + c] = ls[c];
+    }
+}
+
+// A stack of dense Linear layers on caller-owned row-major weights W_i[n_out][n_in] (any row stride, any
+// alignment), hidden activation act_apply(code), linear output: pvae_mlp_forward.  One wave per output feature
+// and chunk of R rows; made for the value branch at rollout batch sizes (rmt:846-853: 2*Db -> 256 -> 256 -> 1).
+template <int R>
+__global__ void __launch_bounds__(256)
+gemv_dense_kernel(const float* __restrict__ x, int ldx, int rows, const float* __restrict__ W, int ldw,
+                  const float* __restrict__ bias, int K, int N, int act, float* __restrict__ out, int ldo) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, r0 = blockIdx.y * R;
+    if (n >= N) return;
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = W[(size_t)n * ldw + k];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (r0 + r < rows) acc[r] = fmaf(w, x[(size_t)(r0 + r) * ldx + k], acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float v = acc[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0 && r0 + r < rows) out[(size_t)(r0 + r) * ldo + n] = act_apply(v + (bias ? bias[n] : 0.f), act);
     }
 }
 
@@ -2213,11 +2252,15 @@ int pvae_read_tensor(pvae_ctx* c, int what, float* dst, int32_t rows, void* stre
     return 0;
 }
 
-int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, int noise, uint64_t rng_seed,
-               uint64_t rng_offset, float* a_hat, float* s2_hat, float* z_out, void* stream) {
+// pvae_infer / pvae_infer_logits: the action lands in a_hat[r * ld_a + 0 .. Da) and, when `log_std` is given, the
+// decoder's log-std vector behind it (AppendLogStd rmt:160-206: logits = [a_hat | log_std]).
+static int infer_impl(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, int noise, uint64_t rng_seed,
+                      uint64_t rng_offset, float* a_hat, int ld_a, const float* log_std, float* s2_hat, float* z_out,
+                      void* stream) {
     int rc = check_ready(c, true);
     if (rc) return rc;
     if (!obs || !a_hat) return fail(-1, "obs / a_hat is null");
+    if (ld_a < c->L.cfg.dim_action * (log_std ? 2 : 1)) return fail(-1, "row stride %d of the action buffer is too small", ld_a);
     hipStream_t st = (hipStream_t)stream;
     if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
     static const bool fused_rollout = [] { const char* e = getenv("PVAE_ROLLOUT_FUSED"); return !(e && e[0] == '0'); }();
@@ -2227,7 +2270,7 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
         const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
         float* w = c->ws;
         c->staged_rows_f = rows;
-        auto run_net = [&](int n, RolloutIn first, float* out2, int ld2, int n2) -> int {
+        auto run_net = [&](int n, RolloutIn first, float* out2, int ld2, int n2, const float* ls) -> int {
             const NetLayout& N = c->L.net[n];
             RolloutIn in = first;
             for (const Layer& l : N.layers) {
@@ -2238,7 +2281,7 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
                 const int ps = g_prof.begin(0, 2.0 * rows * l.n_in * l.n_out, st);
 #define PVAE_ROLL(R)                                                                                                  \
     hipLaunchKernelGGL((gemv_rollout_kernel<R>), grid, block, shm, st, in, (int)rows, c->params + l.w_off, l.ld,      \
-                       c->params + l.b_off, out, l.n_out_pad, l.ld, l.last ? 0 : c->L.cfg.act_kind + 1, o2, ld2, n2, l.n_out)
+                       c->params + l.b_off, out, l.n_out_pad, l.ld, l.last ? 0 : c->L.cfg.act_kind + 1, o2, ld2, n2, l.n_out, l.last ? ls : nullptr)
                 if (rows == 1) PVAE_ROLL(1);
                 else if (rows == 2) PVAE_ROLL(2);
                 else PVAE_ROLL(4);
@@ -2253,7 +2296,7 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
         RolloutIn te;
         memset(&te, 0, sizeof(te));
         te.kind = 1; te.a = obs; te.lda = 2 * Db; te.Ka = 2 * Db;
-        if ((rc = run_net(PVAE_NET_TE, te, nullptr, 0, 0))) return rc;
+        if ((rc = run_net(PVAE_NET_TE, te, nullptr, 0, 0, nullptr))) return rc;
         RolloutIn md;
         memset(&md, 0, sizeof(md));
         md.kind = c->L.cfg.prior_kind == PVAE_PRIOR_NONE ? 4 : c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE ? 5 : 2;
@@ -2261,13 +2304,13 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
         md.b = w + c->W.net[PVAE_NET_TE].act.back(); md.ldb = c->L.net[PVAE_NET_TE].layers.back().n_out_pad; md.Kb = Z;
         md.eps = eps; md.noise = noise ? 1 : 0; md.seed = rng_seed; md.offset = rng_offset;
         md.z_out = z_out; md.eps_used = w + c->W.eps;
-        if ((rc = run_net(PVAE_NET_MD, md, a_hat, Da, Da))) return rc;
+        if ((rc = run_net(PVAE_NET_MD, md, a_hat, ld_a, Da, log_std))) return rc;
         if (s2_hat) {
             RolloutIn wm;
             memset(&wm, 0, sizeof(wm));
             wm.kind = 3; wm.a = obs; wm.lda = 2 * Db; wm.Ka = Db;
             wm.b = w + c->W.net[PVAE_NET_MD].act.back(); wm.ldb = c->L.net[PVAE_NET_MD].layers.back().n_out_pad; wm.Kb = Da;
-            if ((rc = run_net(PVAE_NET_WM, wm, s2_hat, Db, Db))) return rc;
+            if ((rc = run_net(PVAE_NET_WM, wm, s2_hat, Db, Db, nullptr))) return rc;
         }
         return 0;
     }
@@ -2293,14 +2336,18 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
     const bool direct = !s2_hat && (rows == 1 || rows == 2 || rows == 4);
     FwdTail md_tail;
     if (direct) {
-        md_tail.out2 = a_hat; md_tail.ld2 = Da; md_tail.off2 = 0; md_tail.n2 = Da;
+        md_tail.out2 = a_hat; md_tail.ld2 = ld_a; md_tail.off2 = 0; md_tail.n2 = Da;
     } else {
         md_tail.out2 = w + c->W.net[PVAE_NET_WM].in; md_tail.ld2 = WM.layers[0].ld; md_tail.off2 = Db; md_tail.n2 = Da;
     }
     if ((rc = forward_net(c, PVAE_NET_MD, rows_pad, st, md_tail))) return rc;
     if (!direct) {
         hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, w + c->W.net[PVAE_NET_MD].act.back(),
-                           MD.layers.back().n_out_pad, 0, a_hat, Da, 0, rows, Da);
+                           MD.layers.back().n_out_pad, 0, a_hat, ld_a, 0, rows, Da);
+        HIP_TRY(hipGetLastError());
+    }
+    if (log_std) {
+        hipLaunchKernelGGL(append_logstd_kernel, dim3(8), dim3(256), 0, st, a_hat, ld_a, Da, rows, log_std);
         HIP_TRY(hipGetLastError());
     }
     if (s2_hat) {
@@ -2308,6 +2355,46 @@ int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, in
         hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, w + c->W.net[PVAE_NET_WM].act.back(),
                            WM.layers.back().n_out_pad, 0, s2_hat, Db, 0, rows, Db);
         HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, int noise, uint64_t rng_seed,
+               uint64_t rng_offset, float* a_hat, float* s2_hat, float* z_out, void* stream) {
+    return infer_impl(c, obs, rows, eps, noise, rng_seed, rng_offset, a_hat, c ? c->L.cfg.dim_action : 0, nullptr, s2_hat,
+                      z_out, stream);
+}
+
+int pvae_infer_logits(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, int noise, uint64_t rng_seed,
+                      uint64_t rng_offset, float* logits, int32_t ld_logits, const float* log_std, float* s2_hat,
+                      float* z_out, void* stream) {
+    return infer_impl(c, obs, rows, eps, noise, rng_seed, rng_offset, logits, ld_logits, log_std, s2_hat, z_out, stream);
+}
+
+int pvae_mlp_forward(const float* x, int32_t rows, int32_t ldx, int32_t n_layers, const float* const* W,
+                     const float* const* bias, const int32_t* n_in, const int32_t* n_out, const int32_t* ldw,
+                     int32_t act_kind, float* scratch, float* out, int32_t ld_out, void* stream) {
+    if (!x || !W || !n_in || !n_out || !ldw || !out) return fail(-1, "null argument");
+    if (rows < 1 || n_layers < 1 || n_layers > 16) return fail(-1, "rows %d / layers %d out of range", rows, n_layers);
+    if (act_kind < 0 || act_kind > PVAE_ACT_ELU) return fail(-1, "unknown act_kind %d", act_kind);
+    int wmax = 0;
+    for (int i = 0; i + 1 < n_layers; ++i) wmax = n_out[i] > wmax ? n_out[i] : wmax;
+    if (n_layers > 1 && !scratch) return fail(-1, "scratch (2 * rows * widest hidden layer floats) is null");
+    hipStream_t st = (hipStream_t)stream;
+    const float* in = x;
+    int ldi = ldx;
+    for (int i = 0; i < n_layers; ++i) {
+        if (n_in[i] < 1 || n_out[i] < 1 || ldw[i] < n_in[i] || !W[i]) return fail(-1, "bad layer %d", i);
+        if (i > 0 && n_in[i] != n_out[i - 1]) return fail(-1, "layer %d reads %d features, layer %d emits %d", i, n_in[i], i - 1, n_out[i - 1]);
+        const bool last = i == n_layers - 1;
+        float* o = last ? out : scratch + (size_t)(i & 1) * rows * wmax;
+        const int ldo = last ? ld_out : wmax;
+        const dim3 grid((n_out[i] + 3) / 4, (rows + 3) / 4);
+        hipLaunchKernelGGL((gemv_dense_kernel<4>), grid, dim3(256), 0, st, in, ldi, (int)rows, W[i], (int)ldw[i],
+                           bias ? bias[i] : (const float*)nullptr, (int)n_in[i], (int)n_out[i], last ? 0 : act_kind + 1, o, ldo);
+        HIP_TRY(hipGetLastError());
+        in = o;
+        ldi = ldo;
     }
     return 0;
 }

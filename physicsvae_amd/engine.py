@@ -395,6 +395,52 @@ class HipEngine:
             s2.data_ptr() if s2 is not None else None, z.data_ptr(), self._stream()), "pvae_infer")
         return a_hat, s2, z
 
+    def infer_logits(self, obs, log_std, eps=None, noise=True, seed=0, offset=0, want_s2=True):
+        """`infer` with the module's output layout: returns (logits [rows, 2 Da] = [a_hat | log_std], s2_hat|None, z)
+        -- the decoder's log-std vector (device tensor [Da]) is appended by the launch that writes the action
+        (AppendLogStd, rmt:160-206), so `PhysicsVAE.forward` needs no concatenation of its own."""
+        self._need_gpu()
+        if not (obs.dtype == torch.float32 and obs.device == self.device and obs.dim() == 2 and obs.is_contiguous()):
+            obs = obs.reshape(obs.shape[0], -1).to(self.device, torch.float32).contiguous()
+        rows, Da = obs.shape[0], self.arch.Da
+        logits = torch.empty(rows, 2 * Da, dtype=torch.float32, device=self.device)
+        s2 = torch.empty(rows, self.arch.Db, dtype=torch.float32, device=self.device) if want_s2 else None
+        z = torch.empty(rows, self.arch.Z, dtype=torch.float32, device=self.device)
+        if eps is not None:
+            eps = eps.to(self.device, torch.float32).contiguous()
+        _lib.check(self.lib.pvae_infer_logits(
+            self.ctx, obs.data_ptr(), rows, eps.data_ptr() if eps is not None else None,
+            1 if noise else 0, int(seed), int(offset), logits.data_ptr(), 2 * Da, log_std.data_ptr(),
+            s2.data_ptr() if s2 is not None else None, z.data_ptr(), self._stream()), "pvae_infer_logits")
+        return logits, s2, z
+
+    def mlp_forward(self, x, layers, act="relu"):
+        """A stack of Linear layers on caller-owned dense weights: `layers` = [(weight [n_out, n_in], bias)], hidden
+        activation `act`, linear output (`pvae_mlp_forward`; the rollout model's value branch, rmt:846-853)."""
+        self._need_gpu()
+        x = x.reshape(x.shape[0], -1).to(self.device, torch.float32)
+        if x.stride(-1) != 1:
+            x = x.contiguous()
+        n = len(layers)
+        key = tuple((w.data_ptr(), b.data_ptr(), w.stride(0)) for w, b in layers)
+        plan = getattr(self, "_mlp_plan", None)
+        if plan is None or plan[0] != key:              # pointer tables are rebuilt only when a tensor moved
+            Pf = C.c_void_p * n
+            Ii = C.c_int32 * n
+            for w, b in layers:
+                assert w.dtype == torch.float32 and w.device == self.device and w.stride(1) == 1 and b.is_contiguous()
+            plan = (key, Pf(*[w.data_ptr() for w, _ in layers]), Pf(*[b.data_ptr() for _, b in layers]),
+                    Ii(*[w.shape[1] for w, _ in layers]), Ii(*[w.shape[0] for w, _ in layers]),
+                    Ii(*[w.stride(0) for w, _ in layers]), max([w.shape[0] for w, _ in layers[:-1]] or [1]))
+            self._mlp_plan = plan
+        rows = x.shape[0]
+        scratch = torch.empty(2 * rows * plan[6], dtype=torch.float32, device=self.device)
+        out = torch.empty(rows, layers[-1][0].shape[0], dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.pvae_mlp_forward(x.data_ptr(), rows, x.stride(0), n, plan[1], plan[2], plan[3], plan[4], plan[5],
+                                             ACT_KINDS[act], scratch.data_ptr(), out.data_ptr(), out.shape[1],
+                                             self._stream()), "pvae_mlp_forward")
+        return out
+
     def graphed_infer(self, rows, want_s2=True, noise=False):
         """The rollout forward for a fixed row count as ONE replayable HIP graph (see GraphedInfer)."""
         return GraphedInfer(self, rows, want_s2=want_s2, noise=noise)

@@ -117,6 +117,16 @@ class AppendLogStd(nn.Module):
         assert self.type == "constant", "Change value is only allowed in constant logstd"
         assert np.isscalar(val), "Only scalar is currently supported"
         self.log_std[:] = float(val)
+        self._dev = None
+
+    def on_device(self, device):
+        """The vector as a device tensor for the inference launches (a constant log_std lives on the host, as
+        upstream; its device copy is refreshed whenever set_val changes it)."""
+        if self.type != "constant":
+            return self.log_std.detach()
+        if getattr(self, "_dev", None) is None or self._dev.device != device:
+            self._dev = self.log_std.to(device)
+        return self._dev
 
     def forward(self, x):
         ls = self.log_std.to(x.device).reshape([1] * (x.dim() - 1) + [-1])
@@ -154,6 +164,23 @@ def _portable(sd):
     """Contiguous CPU copies: checkpoints must not carry the arena's strides or device
     (the reference saves whatever device the model is on, rmt:870-871)."""
     return OrderedDict((k, v.detach().to("cpu").contiguous().clone()) for k, v in sd.items())
+
+
+class _Cur:
+    """What the last forward left behind (`_cur_*` of rmt:742-771 and the bookkeeping of the lazy read-backs).
+    Kept in a plain object: every attribute write on an nn.Module goes through Module.__setattr__, microseconds
+    each, and the rollout forward sets eight of them per call."""
+    __slots__ = ("_cur_value", "_lazy", "_mu", "_logvar", "_cur_task_encoder_variable", "_cur_body_encoder_variable",
+                 "_cur_latent_prior_mu", "_cur_latent_prior_logvar", "_cur_future_state", "_rng_calls")
+
+    def __init__(self):
+        for k in self.__slots__:
+            setattr(self, k, None)
+        self._rng_calls = 0
+
+
+def _cur_property(name):
+    return property(lambda self: getattr(self._st, name), lambda self, v: setattr(self._st, name, v))
 
 
 class PhysicsVAE(nn.Module):
@@ -253,13 +280,16 @@ class PhysicsVAE(nn.Module):
         self._motor_decoder = build(NET_MD, append_log_std=True, sample_std=cfg["sample_std"],
                                     log_std_type=cfg["log_std_type"], device=self.engine.device)
         self._world_model = build(NET_WM)
+        self.__dict__["_als"] = self._motor_decoder._model[-1]      # (a plain reference: module lookups cost microseconds per forward)
         vb_dims, prev = [], self.dim_state
         for _ in range(vb[1]):
             vb_dims.append((prev, vb[0]))
             prev = vb[0]
         vb_dims.append((prev, 1))
         self._value_branch = FC(vb_dims, act=vb[2]).to(self.engine.device)
+        self._vb_act = vb[2]
 
+        self._st = _Cur()
         self._cur_value = None
         self._lazy, self._mu, self._logvar = None, None, None
         self._cur_task_encoder_variable = None
@@ -327,6 +357,10 @@ class PhysicsVAE(nn.Module):
     # action only; set False to skip the world model's prediction `_cur_future_state` (3 launches less).
     rollout_predicts_state = True
 
+    for _name in _Cur.__slots__:                      # `model._cur_future_state` etc. keep working, reads and writes
+        locals()[_name] = _cur_property(_name)
+    del _name
+
     def forward(self, input_dict, state, seq_lens, eps=None):
         """rmt:742-771.  One library call for the whole chain (TE -> sampler -> MD -> WM, `pvae_infer`).
         The encoder's mu / logvar and the value estimate are produced on demand
@@ -338,21 +372,22 @@ class PhysicsVAE(nn.Module):
         rows = obs.shape[0]
         obs = obs.to(eng.device)
         noise = bool(self.latent_prior_noise)
-        self._rng_calls += 1
+        st = self._st
+        st._rng_calls += 1
         # (eager on purpose: with the input assembly, the sampler and the output copies inside the layer
         #  launches the call is 10 launches, and issue -> result at B = 1 measures 37 us eager against 44 us
         #  for a replay of the same launches as a HIP graph, whose fixed cost is higher; `graphed_infer`
         #  stays available for callers that replay many forwards back to back)
-        a_hat, s2, z = eng.infer(obs, eps=eps if noise else None, noise=noise, seed=self._rng_seed,
-                                 offset=self._rng_calls, want_s2=self.rollout_predicts_state)
-        logits = self._motor_decoder._model[-1](a_hat)
-        self._cur_future_state = s2
-        self._cur_body_encoder_variable = obs[..., : self.dim_state_body]
-        self._cur_task_encoder_variable = z
-        self._lazy = (obs, rows)                   # mu / logvar / value: computed when somebody asks
-        self._mu = self._logvar = self._cur_value = None
-        self._cur_latent_prior_mu = (eng.read("eps", rows) if self._latent_prior_type == "hypersphere_uniform"
-                                     else None)                # rmt:813-814: the unit prior sample of this forward
+        logits, s2, z = eng.infer_logits(obs, self.__dict__["_als"].on_device(eng.device),
+                                         eps=eps if noise else None, noise=noise, seed=self._rng_seed,
+                                         offset=st._rng_calls, want_s2=self.rollout_predicts_state)
+        st._cur_future_state = s2
+        st._cur_body_encoder_variable = obs[..., : self.dim_state_body]
+        st._cur_task_encoder_variable = z
+        st._lazy = (obs, rows)                     # mu / logvar / value: computed when somebody asks
+        st._mu = st._logvar = st._cur_value = None
+        st._cur_latent_prior_mu = (eng.read("eps", rows) if self._latent_prior_type == "hypersphere_uniform"
+                                   else None)                  # rmt:813-814: the unit prior sample of this forward
         return logits, state
 
     def _forward_staged(self, obs, state, seq_lens, eps=None):
@@ -370,7 +405,7 @@ class PhysicsVAE(nn.Module):
 
     def _encoder_stat(self, name):
         """mu / logvar of the last fused forward, read back from the engine's panels on first use."""
-        if getattr(self, "_lazy", None) is not None and self._mu is None:
+        if self._lazy is not None and self._mu is None:
             rows = self._lazy[1]
             no_logvar = self._latent_prior_type in ("hypersphere_uniform", False)
             self._mu = self.engine.read("z" if no_logvar else "mu", rows)
@@ -428,11 +463,18 @@ class PhysicsVAE(nn.Module):
         return self.engine.net_forward(NET_WM, x)
 
     def forward_value_branch(self, obs, state=None, seq_lens=None, state_cnt=0):
-        with torch.no_grad():
-            return self._value_branch(obs.to(self.engine.device).float()), state_cnt
+        """rmt:846-853.  Sampling (no autograd: RLlib's rollout workers) runs the three small Linear layers as one
+        chain of GEMV launches on the parameters where they are (`pvae_mlp_forward`); with autograd on it is the
+        plain torch module, so that a policy-gradient learner can train the branch as upstream."""
+        obs = obs.to(self.engine.device).float()
+        vb = self._value_branch
+        if torch.is_grad_enabled() or self.engine.ctx is None or obs.dim() != 2:
+            return vb(obs), state_cnt
+        layers = [(m._model[0].weight, m._model[0].bias) for m in vb._model]
+        return self.engine.mlp_forward(obs, layers, act=self._vb_act), state_cnt
 
     def value_function(self):
-        if self._cur_value is None and getattr(self, "_lazy", None) is not None:
+        if self._cur_value is None and self._lazy is not None:
             val, _ = self.forward_value_branch(self._lazy[0])      # deferred by the fused forward
             self._cur_value = val.squeeze(1)
         assert self._cur_value is not None, "must call forward() first"

@@ -294,3 +294,54 @@ def test_gather_of_cond_rel_windows_is_bit_exact(golden, tmp_path):
     eng.gather(0, 8)
     got = eng.forward_backward(_lib.PHASE_WORLD, 8, sp, backward=False).cpu()
     assert float(got[0]) == pytest.approx(float(want["total"]), rel=1e-5)
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3, 4, 6, 33])
+def test_module_forward_writes_logits_in_one_call_and_value_branch_runs_on_the_gemv_chain(golden, rows):
+    """`PhysicsVAE.forward` = one `pvae_infer_logits` call: [a_hat | log_std] written by the launch that produces
+    the action (no concatenation, no host -> device copy of a constant log_std per call), `set_exploration_std`
+    seen by the next call; `value_function()` under no_grad = `pvae_mlp_forward` on the value branch's own torch
+    parameters, equal to the torch module (which still serves autograd callers)."""
+    g = golden("single_default")
+    arch = arch_from_meta(g["meta"])
+    data = R.synth_demo(0, 2, 40, arch["Db"], arch["Da"], kind="dynamics")
+    tr = make_trainer(arch, data, 64, device=DEV)
+    tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3))
+    m, eng, Da = tr.model, tr.engine, arch["Da"]
+    m.latent_prior_noise = False
+    obs = torch.randn(rows, 2 * arch["Db"], generator=torch.Generator().manual_seed(rows)).to(DEV)
+    a_hat, s2, z = eng.infer(obs, noise=False, want_s2=True)
+    for std in (0.1, 0.05):
+        m.set_exploration_std(std)
+        with torch.no_grad():
+            logits, _ = m.forward({"obs_flat": obs}, [], None)
+            val = m.value_function()
+        assert logits.shape == (rows, 2 * Da) and torch.equal(logits[:, :Da], a_hat)
+        assert torch.allclose(logits[:, Da:], torch.full((rows, Da), float(np.log(std)), device=DEV), rtol=0, atol=1e-7)
+        assert torch.equal(m._cur_future_state, s2) and torch.equal(m.task_encoder_variable(), z)
+        want = m._value_branch(obs).squeeze(1)                       # torch path (autograd on)
+        assert val.shape == (rows,) and not val.requires_grad and want.requires_grad
+        assert float((val - want.detach()).abs().max()) < 1e-6 * max(1.0, float(want.abs().max()))
+    # any stack of dense layers, any row stride: a transposed-storage weight and a strided input
+    w1 = torch.randn(19, 40, device=DEV)[:, :37]                     # rows 40 floats apart, 37 used
+    b1 = torch.randn(19, device=DEV)
+    w2, b2 = torch.randn(5, 19, device=DEV), torch.randn(5, device=DEV)
+    x = torch.randn(rows, 50, device=DEV)[:, :37]
+    for act, fn in (("relu", torch.relu), ("tanh", torch.tanh), ("elu", torch.nn.functional.elu), ("sigmoid", torch.sigmoid)):
+        got = eng.mlp_forward(x, [(w1, b1), (w2, b2)], act=act)
+        want = fn(x @ w1.t() + b1) @ w2.t() + b2
+        assert float((got - want).abs().max()) < 2e-5
+
+
+def test_state_independent_log_std_reaches_the_logits(golden):
+    g = golden("single_tiny")
+    arch = arch_from_meta(g["meta"])
+    data = R.synth_demo(0, 2, 14, arch["Db"], arch["Da"], kind="iid")
+    tr = make_trainer(arch, data, 8, device=DEV, extra={})
+    cfg = dict(tr.config["model"]["custom_model_config"], log_std_type="state_independent", device=DEV)
+    from physicsvae_amd.model import PhysicsVAE
+    m = PhysicsVAE(cfg["observation_space"], cfg["action_space"], 2 * arch["Da"], {"custom_model_config": cfg}, "m")
+    with torch.no_grad():
+        m._motor_decoder._model[-1].log_std.copy_(torch.arange(arch["Da"], dtype=torch.float32) * 0.1 - 1.0)
+        logits, _ = m.forward({"obs_flat": torch.zeros(1, 2 * arch["Db"], device=DEV)}, [], None)
+    assert torch.allclose(logits[0, arch["Da"]:].cpu(), torch.arange(arch["Da"], dtype=torch.float32) * 0.1 - 1.0)

@@ -62,3 +62,26 @@ for name, sizes in (("default 256x2/512x3/1024x2", []),          # the trainer's
                   "as a HIP graph: %6.1f us back to back, %6.1f us single call"
                   % (name, rows, "TE+MD+WM" if want_s2 else "TE+MD   ", wall, (t1 - t0) / n * 1e6, lat[len(lat) // 2],
                      gwall, glat[len(glat) // 2]))
+    # the module surface RLlib drives (rmt:742-771 + value_function): forward alone, and forward + the lazily
+    # evaluated value branch (plain torch Linear layers: it takes no part in the supervised path)
+    m = tr.model
+    m.latent_prior_noise = False
+    obs1 = torch.randn(1, 394, device="cuda")
+    for with_value in (False, True):
+        lat = []
+        with torch.no_grad():                      # as RLlib's sampler calls it
+            for _ in range(20):
+                m.forward({"obs_flat": obs1}, [], None)
+                if with_value:
+                    m.value_function()
+            for _ in range(100):
+                torch.cuda.synchronize()
+                t5 = time.perf_counter()
+                logits, _ = m.forward({"obs_flat": obs1}, [], None)
+                if with_value:
+                    v = m.value_function()
+                torch.cuda.synchronize()
+                lat.append((time.perf_counter() - t5) * 1e6)
+        lat.sort()
+        print("%-28s rows  1  PhysicsVAE.forward%s : %6.1f us single-call latency"
+              % (name, " + value_function()" if with_value else "                   ", lat[len(lat) // 2]))
