@@ -354,12 +354,23 @@ class PhysicsVAE(nn.Module):
         return out, st
 
     # The 30 Hz control loop calls forward at B = 1 (envs/rllib_env_imitation.py:215-266) and reads the
-    # action only; set False to skip the world model's prediction `_cur_future_state` (3 launches less).
-    rollout_predicts_state = True
+    # action only.  "lazy" (default): the world model's prediction `_cur_future_state` (rmt:758) is computed
+    # when somebody reads it -- 3 launches less per forward; True: with every forward, as upstream; False: never.
+    rollout_predicts_state = "lazy"
 
     for _name in _Cur.__slots__:                      # `model._cur_future_state` etc. keep working, reads and writes
         locals()[_name] = _cur_property(_name)
     del _name
+
+    def _get_future_state(self):
+        st = self._st
+        if st._cur_future_state is None and st._lazy is not None and len(st._lazy) > 2 and self._world_model is not None:
+            obs, rows, eps, noise, offset = st._lazy        # the same call again, now with the prediction: same
+            st._cur_future_state = self.engine.infer(obs, eps=eps, noise=noise, seed=self._rng_seed, offset=offset,
+                                                     want_s2=True)[1]           # kernels, same draws -> same action
+        return st._cur_future_state
+
+    _cur_future_state = property(_get_future_state, lambda self, v: setattr(self._st, "_cur_future_state", v))
 
     def forward(self, input_dict, state, seq_lens, eps=None):
         """rmt:742-771.  One library call for the whole chain (TE -> sampler -> MD -> WM, `pvae_infer`).
@@ -380,11 +391,13 @@ class PhysicsVAE(nn.Module):
         #  stays available for callers that replay many forwards back to back)
         logits, s2, z = eng.infer_logits(obs, self.__dict__["_als"].on_device(eng.device),
                                          eps=eps if noise else None, noise=noise, seed=self._rng_seed,
-                                         offset=st._rng_calls, want_s2=self.rollout_predicts_state)
+                                         offset=st._rng_calls, want_s2=self.rollout_predicts_state is True)
         st._cur_future_state = s2
         st._cur_body_encoder_variable = obs[..., : self.dim_state_body]
         st._cur_task_encoder_variable = z
-        st._lazy = (obs, rows)                     # mu / logvar / value: computed when somebody asks
+        # mu / logvar / value (and the prediction, when lazy): computed when somebody asks
+        st._lazy = ((obs, rows, eps if noise else None, noise, st._rng_calls) if self.rollout_predicts_state == "lazy"
+                    else (obs, rows))
         st._mu = st._logvar = st._cur_value = None
         st._cur_latent_prior_mu = (eng.read("eps", rows) if self._latent_prior_type == "hypersphere_uniform"
                                    else None)                  # rmt:813-814: the unit prior sample of this forward

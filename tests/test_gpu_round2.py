@@ -318,7 +318,18 @@ def test_module_forward_writes_logits_in_one_call_and_value_branch_runs_on_the_g
             val = m.value_function()
         assert logits.shape == (rows, 2 * Da) and torch.equal(logits[:, :Da], a_hat)
         assert torch.allclose(logits[:, Da:], torch.full((rows, Da), float(np.log(std)), device=DEV), rtol=0, atol=1e-7)
-        assert torch.equal(m._cur_future_state, s2) and torch.equal(m.task_encoder_variable(), z)
+        assert m._st._cur_future_state is None                        # the prediction is lazy by default ...
+        assert torch.equal(m._cur_future_state, s2) and torch.equal(m.task_encoder_variable(), z)     # ... and exact when read
+        assert torch.equal(m.forward({"obs_flat": obs}, [], None)[0], logits)
+        m.rollout_predicts_state = True                               # as upstream: with every forward
+        with torch.no_grad():
+            m.forward({"obs_flat": obs}, [], None)
+        assert torch.equal(m._st._cur_future_state, s2)
+        m.rollout_predicts_state = False
+        with torch.no_grad():
+            m.forward({"obs_flat": obs}, [], None)
+        assert m._cur_future_state is None
+        m.rollout_predicts_state = "lazy"
         want = m._value_branch(obs).squeeze(1)                       # torch path (autograd on)
         assert val.shape == (rows,) and not val.requires_grad and want.requires_grad
         assert float((val - want.detach()).abs().max()) < 1e-6 * max(1.0, float(want.abs().max()))
