@@ -483,7 +483,9 @@ class PhysicsVAE(nn.Module):
         vb = self._value_branch
         if torch.is_grad_enabled() or self.engine.ctx is None or obs.dim() != 2:
             return vb(obs), state_cnt
-        layers = [(m._model[0].weight, m._model[0].bias) for m in vb._model]
+        layers = self.__dict__.get("_vb_layers")          # (Parameter objects, looked up once: module attribute reads
+        if layers is None:                                #  cost microseconds each)
+            layers = self.__dict__["_vb_layers"] = [(m._model[0].weight, m._model[0].bias) for m in vb._model]
         return self.engine.mlp_forward(obs, layers, act=self._vb_act), state_cnt
 
     def value_function(self):
