@@ -256,8 +256,11 @@ class TrainModel(tune.Trainable):
                 g2 = g + 1 if g + 1 < n_glob else 0           # this rank's shard of the following step
                 nfirst, nrows, _ = dp.shard(g2, len(loader.dataset), loader.batch_size)
                 self.dp_step(phase, nets, first, rows, sp, eps, out[g], next_span=(nfirst, nrows))
-            if train:
-                self.optimizer.step()             # bookkeeping only (scheduler call order)
+            if train and g == 0:
+                # bookkeeping only (torch's schedulers want an optimizer.step() before their own); once per
+                # epoch: the hooks and profiler ranges torch wraps around Optimizer.step cost ~10 us of host
+                # time per call, which small models cannot hide behind a 30-40 us step
+                self.optimizer.step()
             self.global_batch += 1
         if dp.collective:
             dp.all_reduce(out)

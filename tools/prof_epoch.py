@@ -6,10 +6,11 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 from synth_demo import make_trainer, synth_demo
 data = synth_demo(0, 10, 1000, 197, 45)
+SMALL = "--small" in sys.argv          # 2 x 512 stacks (about the trainer's own defaults) instead of BASELINE's 4 x 1024
 for m_world, name in ((1000, "world"), (0, "joint")):
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
-        tr = make_trainer(data, 256, "cuda", m_world=m_world)
+        tr = make_trainer(data, 256, "cuda", m_world=m_world, **(dict(width=512, depth=2) if SMALL else {}))
     for _ in range(3):
         tr.train()
     torch.cuda.synchronize()
