@@ -396,8 +396,10 @@ class PhysicsVAE(nn.Module):
         st._cur_body_encoder_variable = obs[..., : self.dim_state_body]
         st._cur_task_encoder_variable = z
         # mu / logvar / value (and the prediction, when lazy): computed when somebody asks
-        st._lazy = ((obs, rows, eps if noise else None, noise, st._rng_calls) if self.rollout_predicts_state == "lazy"
-                    else (obs, rows))
+        # (supplied draws are copied: the deferred call must see what this one saw even if the caller reuses its buffer;
+        #  the rollout loop supplies none -- Philox draws are a function of (seed, offset))
+        st._lazy = ((obs, rows, eps.clone() if (noise and eps is not None) else None, noise, st._rng_calls)
+                    if self.rollout_predicts_state == "lazy" else (obs, rows))
         st._mu = st._logvar = st._cur_value = None
         st._cur_latent_prior_mu = (eng.read("eps", rows) if self._latent_prior_type == "hypersphere_uniform"
                                    else None)                  # rmt:813-814: the unit prior sample of this forward
