@@ -411,6 +411,10 @@ gemm_splitk_reg_kernel(GemmArgs ga, Epi epi) {
 // Ring depth: 4 is the optimum on MI355X -- 3 starves, 5..8 get progressively slower (8: 8.5 us);
 // more requests in flight per CU do not help the L2 -> CU path, they hurt it.
 // Same LDS image / swizzles / split-K layout as splitk_reg_body, results are bit-identical.
+#ifndef PVAE_WS_LOADERS
+#define PVAE_WS_LOADERS 4        // loader waves of the wave-specialised kernel (8: 12-wave workgroups, A/B)
+#endif
+constexpr int kWsLoaders = PVAE_WS_LOADERS, kWsThreads = 256 + 64 * kWsLoaders, kWsPer = 8 / kWsLoaders;   // DMA pairs per loader wave and tile
 constexpr int kWsStages = 4;
 constexpr int kWsFloats = kWsStages * 2 * 32 * 64;       // 64 KB
 
@@ -427,8 +431,8 @@ __device__ inline void lds_dma16(const float* src, float* dst_wave_base) {
 __device__ inline void wait_dma_tile(int younger) {
     switch (younger) {
         case 0: wait_vmcnt<0>(); break;
-        case 1: wait_vmcnt<4>(); break;
-        default: wait_vmcnt<8>(); break;          // kWsStages - 2 = 2 is the most that can be younger
+        case 1: wait_vmcnt<2 * kWsPer>(); break;
+        default: wait_vmcnt<4 * kWsPer>(); break;          // kWsStages - 2 = 2 is the most that can be younger
     }
 }
 
@@ -466,7 +470,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
     // instructions each): it is in flight ~0.1 us after the workgroup starts instead of queueing
     // behind the loaders' three-tile prologue (each global_load_lds holds its wave ~150 cycles, so
     // the prologue alone took 0.67 us -- tools/timeline_probe.hip).
-    if (!PVAE_PROBE(6)) {
+    if (!PVAE_PROBE(6) && wave < 8) {
         const int j = wave * 64 + lane;                   // 16-byte slot inside the 8 KB tile image
         const float* s0q;
         const float* s0p;
@@ -488,11 +492,11 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
     if (wave >= 4) {
         // ---------------- loader waves ----------------  (s_setprio 1 here, or on the compute waves: +-0)
         const int u0 = wave - 4;
-        const float* sq[2];
-        const float* sp[2];
+        const float* sq[kWsPer];
+        const float* sp[kWsPer];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int j = (u0 + 4 * u) * 64 + lane;       // 16-byte slot inside the 8 KB tile image
+        for (int u = 0; u < kWsPer; ++u) {
+            const int j = (u0 + kWsLoaders * u) * 64 + lane;       // 16-byte slot inside the 8 KB tile image
             {
                 const int row = j >> 4, c = (j & 15) ^ (row & 15);
                 sq[u] = Q + (size_t)(q0 + row) * ldq + c * 4;
@@ -512,9 +516,9 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
             if (kt >= nk) kt -= nk;
             if (PVAE_PROBE(2)) kt = 0;                    // probe: every step re-reads tile 0 (cache-resident)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                lds_dma16(sq[u] + (size_t)kt * BK, slot + (u0 + 4 * u) * 256);
-                lds_dma16(sp[u] + (size_t)kt * kstep_p, slot + kTile + (u0 + 4 * u) * 256);
+            for (int u = 0; u < kWsPer; ++u) {
+                lds_dma16(sq[u] + (size_t)kt * BK, slot + (u0 + kWsLoaders * u) * 256);
+                lds_dma16(sp[u] + (size_t)kt * kstep_p, slot + kTile + (u0 + kWsLoaders * u) * 256);
             }
         };
 #ifdef PVAE_WS_SLOW0
@@ -528,7 +532,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
 #else
         if (1 < nk) issue(1);                                    // rides on tile 0's flight time
         PVAE_MARK(256, 4);
-        if (1 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>();       // this wave's share of tile 0 landed
+        if (1 < nk) wait_vmcnt<2 * kWsPer>(); else wait_vmcnt<0>();   // this wave's share of tile 0 landed
         PVAE_MARK(256, 5);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -639,7 +643,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
 }
 
 template <bool P_ROW, class Epi>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(kWsThreads)
 gemm_splitk_ws_kernel(GemmArgs ga, Epi epi) {
     __shared__ __attribute__((aligned(16))) float lds[kWsFloats];
     splitk_ws_body<P_ROW, Epi>(lds, blockIdx.x, ga, epi);
@@ -1600,7 +1604,7 @@ inline hipError_t gemm_forward_epi(const float* X, int ldx, const float* W, int 
         return hipGetLastError();
     }
     const GemmGrid g = make_grid(M, N, 32, 32);
-    PVAE_LAUNCH((gemm_splitk_ws_kernel<true, Epi>), dim3(g.grid), dim3(512), st,
+    PVAE_LAUNCH((gemm_splitk_ws_kernel<true, Epi>), dim3(g.grid), dim3(kWsThreads), st,
                        GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
     return hipGetLastError();
 }
@@ -1635,7 +1639,7 @@ inline hipError_t gemm_dgrad_epi(const float* dZ, int ldz, const float* W, int l
                                  const EpiD& e, hipStream_t st) {
     const DgradPlan d = plan_dgrad(dZ, ldz, W, ldw, M, Kin, N);
     if (d.ga.tile16) PVAE_LAUNCH((gemm_splitk_reg16_kernel<false, EpiD>), dim3(d.grid), dim3(256), st, d.ga, e);
-    else PVAE_LAUNCH((gemm_splitk_ws_kernel<false, EpiD>), dim3(d.grid), dim3(512), st, d.ga, e);
+    else PVAE_LAUNCH((gemm_splitk_ws_kernel<false, EpiD>), dim3(d.grid), dim3(kWsThreads), st, d.ga, e);
     return hipGetLastError();
 }
 inline hipError_t gemm_dgrad(const float* dZ, int ldz, const float* W, int ldw, const float* mask,
