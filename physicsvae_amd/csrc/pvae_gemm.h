@@ -32,6 +32,7 @@
 #include <hip/hip_ext.h>
 
 #include <cstdlib>
+#include <type_traits>
 // Timeline probe (tools/timeline_probe.hip defines PVAE_TIMELINE): thread `tid_` of each workgroup
 // stores the 100 MHz wall clock at numbered points of the wave-specialised kernel, and GemmArgs::krot
 // values >= 2 switch parts of it off (ablation).  Compiled out of the library.
@@ -640,6 +641,179 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
     }
     epi.finish(lds, tile_q * tiles_p + tile_p, tid);
     PVAE_MARK(0, 3);                                             // epilogue stores issued
+}
+
+// The same kernel on 64 x 32 output tiles (Q tile 64 rows, P tile 32 rows), for 512 rows and more: with 32x32 tiles a
+// 512-row layer is 512 workgroups, two per CU, each landing its own 16 KB per k-tile through an LDS-DMA path that
+// saturates at ~27 B/clk per CU -- the loop there IS loader-bound (not fetching X at all buys 1 us
+// of 13).  One 64x32 workgroup per CU lands 24 KB per k-tile for the MFMA work of two 32x32 tiles (32 KB): a quarter
+// less DMA traffic per flop.  Every output element is still the sum of the same four k-quarters in the same order, so
+// results equal the 32x32 kernel's bit for bit.  Ring: 4 slots x 24 KB = 96 KB.
+constexpr int kWs64Floats = kWsStages * (64 + 32) * 64;
+template <bool P_ROW, class Epi>
+__device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
+    constexpr int BK = 64, kTileQ = 64 * 64, kTileP = 32 * 64, kStage = kTileQ + kTileP, S = kWsStages;
+    static_assert(kWsLoaders == 4, "written for four loader waves");
+    const float* __restrict__ Q = ga.Q;
+    const float* __restrict__ P = ga.P;
+    const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int tile_p = xcd * ga.p_per_xcd + loc / tiles_q;
+    const int tile_q = loc % tiles_q;
+    if (tile_p >= tiles_p) return;
+    const int q0 = tile_q * 64, p0 = tile_p * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lh = lane >> 4;
+    const int nk = K / BK;
+    typename Epi::Pre epre[2] = {};
+    v4f acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+    const size_t kstep_p = P_ROW ? (size_t)BK : (size_t)BK * ldp;
+    // 16-byte slot j of an operand image -> its global source (same swizzles as splitk_ws_body)
+    auto src_q = [&](int j) {
+        const int row = j >> 4, c = (j & 15) ^ (row & 15);
+        return Q + (size_t)(q0 + row) * ldq + c * 4;
+    };
+    auto src_p = [&](int j) {
+        if (P_ROW) {
+            const int row = j >> 4, c = (j & 15) ^ (row & 15);
+            return P + (size_t)(p0 + row) * ldp + c * 4;
+        }
+        const int r = j >> 3, k = r ^ ((r >> 2) & 1);
+        return P + (size_t)k * ldp + p0 + (j & 7) * 4;
+    };
+    // k-tile 0 by all eight waves: Q image = 1024 slots (two per lane and wave), P image = 512 (one)
+    lds_dma16(src_q(wave * 64 + lane), lds + wave * 256);
+    lds_dma16(src_q((wave + 8) * 64 + lane), lds + (wave + 8) * 256);
+    lds_dma16(src_p(wave * 64 + lane), lds + kTileQ + wave * 256);
+    if (wave >= 4) {
+        // ---------------- loader waves: 4 Q + 2 P instructions per tile ----------------
+        const int u0 = wave - 4;
+        const float* sq[4];
+        const float* sp[2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sq[u] = src_q((u0 + 4 * u) * 64 + lane);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) sp[u] = src_p((u0 + 4 * u) * 64 + lane);
+        auto issue = [&](int t) {
+            float* slot = lds + (t % S) * kStage;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lds_dma16(sq[u] + (size_t)t * BK, slot + (u0 + 4 * u) * 256);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) lds_dma16(sp[u] + (size_t)t * kstep_p, slot + kTileQ + (u0 + 4 * u) * 256);
+        };
+        if (1 < nk) issue(1);
+        if (1 < nk) wait_vmcnt<6>(); else wait_vmcnt<0>();       // this wave's share of tile 0 landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int t = 2; t < S - 1; ++t)
+            if (t < nk) issue(t);
+        for (int t = 0; t < nk; ++t) {
+            int y = nk - 2 - t;                                  // tiles younger than t+1 still in flight
+            if (y > S - 3) y = S - 3;
+            if (y <= 0) wait_vmcnt<0>();
+            else if (y == 1) wait_vmcnt<6>();
+            else wait_vmcnt<12>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + S - 1 < nk) issue(t + S - 1);
+        }
+    } else {
+        // ---------------- compute waves: 64 x 32 over this wave's k-quarter ----------------
+        int oq[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int row = 16 * a + li;
+            oq[a] = row * 64 + (((4 * wave + lh) ^ (row & 15)) << 2);
+        }
+        const int kq = 16 * wave + 4 * lh;
+        wait_vmcnt<0>();                                         // this wave's share of tile 0 landed
+#pragma unroll
+        for (int h = 0; h < 2; ++h) epre[h] = epi.preload(q0 + 32 * h + (tid >> 3), p0 + ((tid & 7) << 2));
+        struct Frag { v4f q[4], p[2]; v2f c[4]; };
+        auto fread = [&](const float* st, Frag& f) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) f.q[a] = *reinterpret_cast<const v4f*>(st + oq[a]);
+            if (P_ROW) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) f.p[b] = *reinterpret_cast<const v4f*>(st + kTileQ + oq[b]);
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+                    f.c[s2] = *reinterpret_cast<const v2f*>(st + kTileQ + (((kq + s2) ^ (lh & 1)) * 32) + 2 * li);
+            }
+        };
+        auto mfmas = [&](const Frag& f) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const float pv = P_ROW ? f.p[b][s2] : f.c[s2][b];
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, f.q[a][s2], acc[a][b], 0, 0, 0);
+                    }
+        };
+        __builtin_amdgcn_s_barrier();                            // tile 0 landed
+        asm volatile("" ::: "memory");
+        Frag F0, F1;
+        fread(lds, F0);
+        for (int t0 = 0; t0 < nk; t0 += 2) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const int t = t0 + d;
+                if (t < nk) {
+                    Frag& F = d ? F1 : F0;
+                    Frag& Gf = d ? F0 : F1;
+                    __builtin_amdgcn_s_barrier();                // tile t+1 landed; tile t-1's slot is free
+                    asm volatile("" ::: "memory");
+                    fread(lds + ((t + 1) % S) * kStage, Gf);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(F);
+                }
+            }
+        }
+    }
+    // split-K reduction through LDS (fixed order: compute wave 0..3), epilogue on float4s by the 256 compute threads
+    __syncthreads();
+    constexpr int RS = 36;
+    if (wave < 4) {
+        float* red = lds + wave * (64 * RS);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = 16 * a + li;
+                    const int pl = P_ROW ? (16 * b + 4 * lh + r) : (8 * lh + 2 * r + b);
+                    red[ql * RS + pl] = acc[a][b][r];
+                }
+    }
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ql = 32 * h + (tid >> 3), pl = (tid & 7) << 2;
+            v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (64 * RS) + ql * RS + pl);
+            epi(q0 + ql, p0 + pl, v, epre[h]);
+        }
+    }
+    epi.finish(lds, tile_q * tiles_p + tile_p, tid);
+}
+
+template <bool P_ROW, class Epi>
+__global__ void __launch_bounds__(512)
+gemm_splitk_ws64_kernel(GemmArgs ga, Epi epi) {
+    __shared__ __attribute__((aligned(16))) float lds[kWs64Floats];
+    splitk_ws64_body<P_ROW, Epi>(lds, blockIdx.x, ga, epi);
 }
 
 template <bool P_ROW, class Epi>
@@ -1587,6 +1761,9 @@ inline GemmGrid make_grid(int rows_q, int cols_p, int bq, int bp) {
     return g;
 }
 
+// 512 rows and more: 64x32 tiles (splitk_ws64_body) whenever they still give every CU a workgroup; PVAE_WS64=0: off (A/B)
+static int g_ws64 = [] { const char* e = getenv("PVAE_WS64"); return (e && e[0] == '0') ? 0 : 1; }();
+inline bool uses_64x32(int M, int N) { return g_ws64 && M >= 512 && M % 64 == 0 && (M / 64) * (N / 32) >= 256; }
 // narrow outputs: under 128 workgroups of 32x32 -> use 16x16 tiles (4x the workgroups)
 inline bool forward_uses_16x16(int M, int N) { return (M / 32) * (N / 32) < 128; }
 inline int forward_tiles(int M, int N) {
@@ -1602,6 +1779,14 @@ inline hipError_t gemm_forward_epi(const float* X, int ldx, const float* W, int 
         PVAE_LAUNCH((gemm_splitk_reg16_kernel<true, Epi>), dim3(g.grid), dim3(256), st,
                            GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
         return hipGetLastError();
+    }
+    if constexpr (std::is_same<Epi, EpiBiasAct>::value) {
+        if (uses_64x32(M, N)) {
+            const GemmGrid g = make_grid(M, N, 64, 32);
+            PVAE_LAUNCH((gemm_splitk_ws64_kernel<true, Epi>), dim3(g.grid), dim3(512), st,
+                               GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+            return hipGetLastError();
+        }
     }
     const GemmGrid g = make_grid(M, N, 32, 32);
     PVAE_LAUNCH((gemm_splitk_ws_kernel<true, Epi>), dim3(g.grid), dim3(kWsThreads), st,
@@ -1637,6 +1822,14 @@ inline DgradPlan plan_dgrad(const float* dZ, int ldz, const float* W, int ldw, i
 template <class EpiD>
 inline hipError_t gemm_dgrad_epi(const float* dZ, int ldz, const float* W, int ldw, int M, int Kin, int N,
                                  const EpiD& e, hipStream_t st) {
+    if constexpr (std::is_same<EpiD, EpiMask>::value) {
+        if (uses_64x32(M, Kin)) {                               // stand-alone input gradient of a hidden layer at >= 512 rows
+            const GemmGrid g = make_grid(M, Kin, 64, 32);
+            PVAE_LAUNCH((gemm_splitk_ws64_kernel<false, EpiD>), dim3(g.grid), dim3(512), st,
+                               GemmArgs{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+            return hipGetLastError();
+        }
+    }
     const DgradPlan d = plan_dgrad(dZ, ldz, W, ldw, M, Kin, N);
     if (d.ga.tile16) PVAE_LAUNCH((gemm_splitk_reg16_kernel<false, EpiD>), dim3(d.grid), dim3(256), st, d.ga, e);
     else PVAE_LAUNCH((gemm_splitk_ws_kernel<false, EpiD>), dim3(d.grid), dim3(kWsThreads), st, d.ga, e);

@@ -4,6 +4,8 @@ minibatches from 1 row up, lookahead 1..3, MSE and L1.  Every case: loss terms r
 gradient 1e-4 (samples on a ReLU kink excluded, see oracle.refpath.relu_kink_margin), the pad
 entries of the arena stay zero, and three optimizer steps with Adam fused into the weight-gradient
 launches equal gradient-store + flat Adam bit for bit.  Seeds are fixed: the sweep is deterministic."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -12,6 +14,8 @@ from oracle import refpath as R
 from physicsvae_amd import _lib
 from physicsvae_amd.engine import make_step_params
 from util import make_trainer, max_err_scaled, rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -114,3 +118,37 @@ def test_schedule_and_geometry_switches_keep_parity():
                            env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (env, r.stdout[-2000:], r.stderr[-1000:])
         assert "40 passed" in r.stdout, (env, r.stdout[-500:])
+
+
+def test_64x32_tiles_equal_32x32_tiles_bit_for_bit(tmp_path):
+    """At 512 rows and more the forward / stand-alone input-gradient launches use 64x32 output tiles
+    (splitk_ws64_body: a quarter less LDS-DMA traffic per flop).  Every output element is still the sum of the same
+    four k-quarters in the same order, so the two tilings must agree to the bit: the same contractions in two
+    processes (PVAE_WS64 is read when the library loads), forward with bias + ReLU and input gradient with mask,
+    at 512 and 1024 rows, K = 1024 and 448."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from physicsvae_amd.engine import gemm_probe
+outs = []
+for m, n, k in ((512, 1024, 1024), (1024, 512, 448), (512, 1024, 256)):
+    g = torch.Generator().manual_seed(m + n + k)
+    x, w, b = torch.randn(m, k, generator=g).cuda(), torch.randn(n, k, generator=g).cuda(), torch.randn(n, generator=g).cuda()
+    dz, act = torch.randn(m, n, generator=g).cuda(), torch.randn(m, k, generator=g).cuda()
+    o = torch.full((m, n), float("nan"), device="cuda")
+    gemm_probe(0, x, w, o, bias_or_mask=b, relu=True, m=m, n=n, k=k)
+    d = torch.full((m, k), float("nan"), device="cuda")
+    gemm_probe(1, dz, w, d, bias_or_mask=act, m=m, n=n, k=k)
+    outs += [o.cpu(), d.cpu()]
+torch.save(outs, sys.argv[1])
+''' % ROOT
+    files = []
+    for mode in ("0", "1"):
+        f = str(tmp_path / ("out%s.pt" % mode))
+        env = dict(os.environ, PVAE_WS64=mode)
+        subprocess.run([sys.executable, "-c", script, f], check=True, env=env, timeout=300)
+        files.append(torch.load(f))
+    for a, b in zip(*files):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
