@@ -134,7 +134,10 @@ size_t pvae_workspace_bytes(const pvae_config* cfg);
 /* Float offset of a workspace panel (inspection / tests).  kind: 0 = input panel of `net`
  * [Bp][ld0], 1 = its gradient, 2 = output of layer `layer` [Bp][n_out_pad], 3 = gradient wrt the
  * pre-activation of that layer, 4 = target next-state panel, 5 = target action panel,
- * 6 = eps [Bp][Z].  Bp = max_batch rounded up to 32.  Returns <0 on bad arguments.
+ * 6 = eps [Bp][Z], 7 = dense copy [rows][2 Db] of the observation rows of the last pvae_infer /
+ * pvae_infer_logits call with <= 4 rows (what a deferred read of that forward -- mu / logvar, the
+ * world model's prediction, the value estimate -- re-uses, so the caller may recycle its buffer).
+ * Bp = max_batch rounded up to 32.  Returns <0 on bad arguments.
  * (Kinds 0, 4, 5 name the FIRST of the two sets of staging panels; pvae_train_step_prefetch /
  * pvae_dp_train_step alternate between the two, so inspect these panels only around the plain
  * pvae_gather / pvae_set_batch entry points.) */

@@ -574,6 +574,7 @@ struct RolloutIn {
     const float* eps; int noise;      // kind 2: supplied draws [rows][Z] or null (Philox) / noise off
     unsigned long long seed, offset;
     float* z_out; float* eps_used;    // kind 2, written by workgroup 0 (z_out may be null)
+    float* keep;                      // kind 1: workgroup 0 copies the observation rows here ([rows][Ka]; may be null)
 };
 template <int R>
 __global__ void __launch_bounds__(256)
@@ -607,6 +608,7 @@ gemv_rollout_kernel(RolloutIn in, int rows, const float* __restrict__ W, int ldw
         if (r < rows) {
             if (k < in.Ka) {
                 v = in.a[(size_t)r * in.lda + k];
+                if (in.kind == 1 && in.keep && blockIdx.x == 0) in.keep[(size_t)r * in.Ka + k] = v;
             } else if (k < in.Ka + in.Kb) {
                 const int j = k - in.Ka;
                 if (in.kind == 2) {
@@ -1149,6 +1151,7 @@ int64_t pvae_workspace_offset(const pvae_config* cfg, int kind, int net, int lay
         case 4: return W.s2;
         case 5: return W.act_t;
         case 6: return W.eps;
+        case 7: return W.obs_keep;
         default: return fail(-1, "bad kind %d", kind);
     }
 }
@@ -2269,7 +2272,8 @@ static int infer_impl(pvae_ctx* c, const float* obs, int32_t rows, const float* 
         // input panels of a staged training minibatch are not touched
         const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
         float* w = c->ws;
-        c->staged_rows_f = rows;
+        // (staged_rows / staged_rows_f stay as they are: a staged training minibatch remains valid, and
+        //  forward_net picks its kernels by staged_rows_f)
         auto run_net = [&](int n, RolloutIn first, float* out2, int ld2, int n2, const float* ls) -> int {
             const NetLayout& N = c->L.net[n];
             RolloutIn in = first;
@@ -2296,6 +2300,7 @@ static int infer_impl(pvae_ctx* c, const float* obs, int32_t rows, const float* 
         RolloutIn te;
         memset(&te, 0, sizeof(te));
         te.kind = 1; te.a = obs; te.lda = 2 * Db; te.Ka = 2 * Db;
+        te.keep = w + c->W.obs_keep;       // what a deferred read of this forward (mu / logvar / prediction / value) re-uses
         if ((rc = run_net(PVAE_NET_TE, te, nullptr, 0, 0, nullptr))) return rc;
         RolloutIn md;
         memset(&md, 0, sizeof(md));

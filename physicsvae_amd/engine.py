@@ -4,6 +4,7 @@ PyTorch is used for what it is good at here: device memory, streams, `torch.save
 arithmetic of the hot path happens in libpvae_gfx950.so (physicsvae_amd/csrc).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -103,6 +104,8 @@ class HipEngine:
         self.arch = arch
         self.max_batch = int(max_batch)
         self.lookahead = int(lookahead)          # steps unrolled per sample (tpv:277, 367-428)
+        # the library's <= 4-row rollout path (PVAE_ROLLOUT_FUSED=0 switches it off; read once, as the library does)
+        self.fused_rollout = os.environ.get("PVAE_ROLLOUT_FUSED", "1")[:1] != "0"
         self.device = torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:
             # an indexed device, so that comparisons with tensor.device (always indexed) are exact
@@ -457,6 +460,15 @@ class HipEngine:
                  "dz": lays[layer]["n_out_pad"], "s2": pad64(self.arch.Db), "act_t": pad64(self.arch.Da),
                  "eps": self.arch.Z}[kind]
         return self.workspace[off: off + bp * width].view(bp, width)
+
+    def kept_obs(self, rows):
+        """The library's own copy of the observation rows of the last rollout call with <= 4 rows (workspace kind 7):
+        a [rows, 2 Db] view that stays valid until the next such call, whatever the caller does with its buffer."""
+        off = getattr(self, "_obs_keep_off", None)
+        if off is None:
+            off = self._obs_keep_off = _lib.check(int(self.lib.pvae_workspace_offset(C.byref(self.cfg), 7, 0, 0)))
+        w = 2 * self.arch.Db
+        return self.workspace[off: off + rows * w].view(rows, w)
 
     def net_forward(self, net, x):
         self._need_gpu()

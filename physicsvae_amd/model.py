@@ -398,8 +398,11 @@ class PhysicsVAE(nn.Module):
         # mu / logvar / value (and the prediction, when lazy): computed when somebody asks
         # (supplied draws are copied: the deferred call must see what this one saw even if the caller reuses its buffer;
         #  the rollout loop supplies none -- Philox draws are a function of (seed, offset))
-        st._lazy = ((obs, rows, eps.clone() if (noise and eps is not None) else None, noise, st._rng_calls)
-                    if self.rollout_predicts_state == "lazy" else (obs, rows))
+        # The observation a deferred read re-uses is the library's own copy of it (<= 4 rows: written by the first
+        # encoder launch, `kept_obs`), or a clone: the caller may recycle its buffer right after this call.
+        keep = eng.kept_obs(rows) if rows <= 4 and eng.fused_rollout else obs.clone()
+        st._lazy = ((keep, rows, eps.clone() if (noise and eps is not None) else None, noise, st._rng_calls)
+                    if self.rollout_predicts_state == "lazy" else (keep, rows))
         st._mu = st._logvar = st._cur_value = None
         st._cur_latent_prior_mu = (eng.read("eps", rows) if self._latent_prior_type == "hypersphere_uniform"
                                    else None)                  # rmt:813-814: the unit prior sample of this forward
@@ -423,7 +426,9 @@ class PhysicsVAE(nn.Module):
         if self._lazy is not None and self._mu is None:
             rows = self._lazy[1]
             no_logvar = self._latent_prior_type in ("hypersphere_uniform", False)
-            self._mu = self.engine.read("z" if no_logvar else "mu", rows)
+            # (no-logvar encoders: mu IS the code this forward returned -- the decoder-input panel the engine's
+            #  "z" reads is not written by the <= 4-row rollout path)
+            self._mu = self._st._cur_task_encoder_variable if no_logvar else self.engine.read("mu", rows)
             self._logvar = None if no_logvar else self.engine.read("logvar", rows)
         return self._mu if name == "mu" else self._logvar
 

@@ -388,15 +388,33 @@ class TrainModel(torch_models.TrainModel):
         num = getattr(args, "num_data", None) if args is not None else None
         return load_dataset_for_PhysicsVAE(file, num_samples=num, lookahead=self.lookahead)
 
+    def _enter_joint_phase(self):                 # tpv:342-348
+        self.model.set_learnable_task_encoder(True)
+        self.model.set_learnable_motor_decoder(True)
+        self.model.set_learnable_world_model(False)
+        self.model.set_learnable_latent_prior(True)
+        self.read_loss_fn_coeff(world=False)
+
     def step(self):
         # the flip is tested BEFORE the increment: epochs 1..M are world, M+1.. joint (tpv:342)
         if self.iter == self.max_iter_world_model:
-            self.model.set_learnable_task_encoder(True)
-            self.model.set_learnable_motor_decoder(True)
-            self.model.set_learnable_world_model(False)
-            self.model.set_learnable_latent_prior(True)
-            self.read_loss_fn_coeff(world=False)
+            self._enter_joint_phase()
         return super().step()
+
+    def load_trainer_state(self, path):
+        """(ours) Besides what the base class restores, the PHASE: `setup` has put the trainer into the world
+        phase and `step` flips only when iter == max_iter_world_model, so a state saved after the switch
+        (iter > M) must re-enter the joint phase here -- otherwise the resumed run would train the world model
+        forever on joint-phase Adam counters."""
+        state = super().load_trainer_state(path)
+        m = self.max_iter_world_model
+        if m is not None and self.iter > m:
+            self._enter_joint_phase()
+        saved = state.get("learnable_nets")
+        if saved is not None and sorted(saved) != sorted(self.model.learnable_nets()):
+            raise RuntimeError("trainer_state.pt: learnable stacks %s do not match the phase its epoch counter "
+                               "implies (%s); was max_iter_world_model changed?" % (saved, self.model.learnable_nets()))
+        return state
 
     def create_model(self, config):
         return create_model(config)

@@ -153,11 +153,25 @@ def _latest_checkpoint(logdir):
     return best
 
 
+def _newest_run(exp_dir):
+    """Trial directories of the NEWEST run of an experiment: `trial_<stamp>` or `trial_<stamp>_<index>`, grouped by
+    stamp (an experiment directory accumulates one group per run, e.g. with the default --name)."""
+    groups = {}
+    for d in os.listdir(exp_dir):
+        parts = d.split("_")
+        if d.startswith("trial_") and len(parts) >= 3:
+            groups.setdefault("_".join(parts[1:3]), []).append(d)
+    return sorted(groups[max(groups)]) if groups else []
+
+
 def run(trainable_cls, config=None, stop=None, checkpoint_freq=0, checkpoint_at_end=False,
         local_dir="~/ray_results", name=None, verbose=1, resume=False, **_ignored):
     """`resume=True` (tpv:500, `--resume`): continue the experiment `name` under `local_dir` -- trial i picks
-    up the i-th existing trial directory at its newest checkpoint (weights through `restore`, the
-    iteration counter from the directory name, as Ray does) and runs on to the stop criterion."""
+    up the i-th trial directory of the experiment's NEWEST run at its newest checkpoint (weights through
+    `restore`, the iteration counter from the directory name, as Ray does) and runs on to the stop criterion.
+    As upstream (tm:215-216) that restores weights only: the trainer's epoch counter restarts at 0, so the
+    world-model phase is replayed and Adam / the lr schedule start afresh -- unless the config carries
+    "save_trainer_state" / "resume_trainer_state" (ours), which make the continuation bit-exact."""
     max_iter = int((stop or {}).get("training_iteration", 1))
     rank, world = _rank_world()
     stamp = time.strftime("%Y%m%d_%H%M%S")
@@ -169,7 +183,7 @@ def run(trainable_cls, config=None, stop=None, checkpoint_freq=0, checkpoint_at_
     variants = expand_grid(config or {})
     trials = []
     exp_dir = os.path.join(os.path.expanduser(local_dir), name or trainable_cls.__name__)
-    old = sorted(d for d in os.listdir(exp_dir) if d.startswith("trial_")) if (resume and os.path.isdir(exp_dir)) else []
+    old = _newest_run(exp_dir) if (resume and os.path.isdir(exp_dir)) else []
     for ti, cfg in enumerate(variants):
         tag = "trial_%s" % stamp if len(variants) == 1 else "trial_%s_%02d" % (stamp, ti)
         if ti < len(old):

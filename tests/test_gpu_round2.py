@@ -155,11 +155,12 @@ def test_gather_windows_across_the_2GiB_byte_boundary():
             assert float(eng.panel("in", _lib.NET_TE)[rows: (rows + 31) // 32 * 32].abs().max()) == 0.0
 
 
-def test_trainer_state_resume_is_bit_exact(golden, tmp_path):
+@pytest.mark.parametrize("stop_after", [3, 1, 2])
+def test_trainer_state_resume_is_bit_exact(golden, tmp_path, stop_after):
     """`save_trainer_state` / `resume_trainer_state` (ours; upstream resumes weights only, tm:215-216):
-    a run interrupted after 3 epochs (world -> joint switch at 2) and resumed from its checkpoint
-    directory continues bit for bit like the uninterrupted run: weights, Adam moments, step counts,
-    StepLR position, eps stream position."""
+    a run interrupted after `stop_after` epochs (world -> joint switch at 2: after it, before it, exactly at
+    it) and resumed from its checkpoint directory continues bit for bit like the uninterrupted run: weights,
+    Adam moments, step counts, StepLR position, eps stream position, and the PHASE."""
     g = golden("train_tiny")
     arch = arch_from_meta(g["meta"])
     n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
@@ -168,18 +169,19 @@ def test_trainer_state_resume_is_bit_exact(golden, tmp_path):
     kw = dict(m_world=2, device=DEV, lr_step=2, eps_fn=R.eps_stream(2, arch["Z"]))
     full = make_trainer(arch, data, batch, extra={"save_trainer_state": True}, **kw)
     full.model.load_state_dict(sd)
-    for _ in range(3):
+    for _ in range(stop_after):
         full.train()
     ck = full.save_checkpoint(str(tmp_path))
     assert os.path.exists(tmp_path / "trainer_state.pt")
-    want = [full.train()["mean_train_loss"] for _ in range(2)]
+    learnable_at_save = sorted(full.model.learnable_nets())
+    want = [full.train()["mean_train_loss"] for _ in range(3)]
     res = make_trainer(arch, data, batch, extra={"resume_trainer_state": True}, **kw)
     res.restore(ck)
-    assert res.iter == 3 and res.optimizer.net_steps == full.optimizer.net_steps or True
-    # flags follow the restored epoch counter on the next step (the phase test precedes the increment)
-    res.model.set_learnable_task_encoder(True); res.model.set_learnable_motor_decoder(True)
-    res.model.set_learnable_world_model(False); res.read_loss_fn_coeff(world=False)
-    got = [res.train()["mean_train_loss"] for _ in range(2)]
+    assert res.iter == stop_after
+    # the restore itself re-entered the phase the state was saved in (joint when saved after the switch)
+    assert sorted(res.model.learnable_nets()) == learnable_at_save
+    assert (res.a_rec_coeff > 0) == (stop_after > 2)
+    got = [res.train()["mean_train_loss"] for _ in range(3)]
     assert got == want
     assert torch.equal(res.engine.params, full.engine.params)
     assert torch.equal(res.engine.exp_avg, full.engine.exp_avg) and torch.equal(res.engine.exp_avg_sq, full.engine.exp_avg_sq)
@@ -253,6 +255,22 @@ def test_fused_rollout_path_equals_the_staged_forward(golden, rows):
     eng.infer(obs, noise=False)
     l1 = eng.forward_backward(_lib.PHASE_WORLD, 32, sp, backward=False).clone()
     assert torch.equal(l0, l1)
+    # the same in the JOINT phase with the backward pass (the encoder / decoder forwards pick their kernels by
+    # the staged row count: a rollout call must not shrink it to its own 1-4 rows)
+    cj = R.phase_coeffs(False)
+    spj = make_step_params(lr=5e-4, a_rec=cj["a_rec_coeff"], kl=cj["vae_kl_coeff"], s_rec=cj["s_rec_coeff"],
+                           cyc=cj["vae_cycle_coeff"], global_rows=32)
+    eps = torch.randn(32, arch["Z"], device=DEV)
+    eng.gather(0, 32)
+    j0 = eng.forward_backward(_lib.PHASE_JOINT, 32, spj, eps=eps, backward=True).clone()
+    g0 = eng.grads.clone()
+    eng.grads.zero_()
+    eng.gather(0, 32)
+    eng.infer(obs, noise=False)
+    j1 = eng.forward_backward(_lib.PHASE_JOINT, 32, spj, eps=eps, backward=True).clone()
+    assert torch.equal(j0, j1)
+    assert torch.equal(g0, eng.grads)
+    assert float(g0.abs().sum()) > 0
 
 
 def test_gather_of_cond_rel_windows_is_bit_exact(golden, tmp_path):
@@ -333,6 +351,15 @@ def test_module_forward_writes_logits_in_one_call_and_value_branch_runs_on_the_g
         want = m._value_branch(obs).squeeze(1)                       # torch path (autograd on)
         assert val.shape == (rows,) and not val.requires_grad and want.requires_grad
         assert float((val - want.detach()).abs().max()) < 1e-6 * max(1.0, float(want.abs().max()))
+    # deferred reads see the observation the ACTION was computed on, also when the caller recycles its buffer
+    # right after the call (the forward keeps the library's own copy of the rows, workspace kind 7)
+    buf = obs.clone()
+    with torch.no_grad():
+        m.forward({"obs_flat": buf}, [], None)
+        buf.normal_()                                                # the caller's next observation, in place
+        assert torch.equal(m._cur_future_state, s2)
+        assert torch.equal(m.value_function(), val)
+        assert torch.equal(m._cur_task_encoder_mu, eng.read("mu", rows))
     # any stack of dense layers, any row stride: a transposed-storage weight and a strided input
     w1 = torch.randn(19, 40, device=DEV)[:, :37]                     # rows 40 floats apart, 37 used
     b1 = torch.randn(19, device=DEV)

@@ -693,6 +693,20 @@ def test_tune_run_resume_continues_from_the_newest_checkpoint(tmp_path):
     assert os.listdir(tmp_path / "exp") == [os.path.basename(a1.logdir)]
 
 
+def test_tune_resume_picks_the_newest_run_of_an_experiment(tmp_path):
+    """An experiment directory accumulates one group of trial directories per run (default --name): resume continues
+    the NEWEST run, not the first ever made, and never mixes single- and multi-trial stamps."""
+    from physicsvae_amd import tune
+    exp = tmp_path / "exp"
+    for d in ("trial_20260101_000000", "trial_20260301_120000_00", "trial_20260301_120000_01",
+              "trial_20260201_000000_00", "other"):
+        os.makedirs(exp / d)
+    assert tune._newest_run(str(exp)) == ["trial_20260301_120000_00", "trial_20260301_120000_01"]
+    os.makedirs(exp / "trial_20260401_000000")
+    assert tune._newest_run(str(exp)) == ["trial_20260401_000000"]
+    assert tune._newest_run(str(tmp_path)) == []
+
+
 def test_no_prior_mode_layout_matches_the_reference_capture(golden):
     """latent_prior_type = False (rmt:622-623): the reference builds an encoder with Z outputs; same keys and
     shapes here, and its state dict round-trips through the arena views."""
