@@ -88,6 +88,10 @@ def parse_args(argv=None):
     ap.add_argument("--config", choices=["c2", "c5"], default="c2",
                     help="c2 = BASELINE configs[1..3] sizes (default); c5 = configs[4]: 1e6 transitions, "
                          "dim_state_body 400, dim_action 90, 512 rows per GPU")
+    ap.add_argument("--exchange", choices=["inline", "bucketed", "sharded", "p2p"], default=None,
+                    help="N > 1: how the gradient is exchanged (the trainer's dp_exchange): RCCL all-reduce in line / in 6 MiB "
+                         "overlapped buckets / RCCL reduce-scatter + sharded Adam + all-gather / the direct all-pairs exchange "
+                         "over peer-mapped arenas (no RCCL); default: the library's own schedule")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary-phase, roofline and rocprofv3 passes")
     ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 child runs (kernel trace + PMC)")
@@ -310,7 +314,8 @@ def main():
         workload = "BASELINE configs[4]: synthetic demo 1000x1001 (1e6 transitions), dim_state_body 400, dim_action 90"
     torch.manual_seed(1)                       # normc initialisation of the model's own constructor
     with contextlib.redirect_stdout(io.StringIO()):
-        tr = make_trainer(data, a.batch, dev, width=W, depth=D, latent=Z)
+        tr = make_trainer(data, a.batch, dev, width=W, depth=D, latent=Z,
+                          extra={"dp_exchange": a.exchange} if a.exchange else None)
     sd = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}     # for the CPU leg
     eng, dp = tr.engine, tr.dp
     ds = tr.train_loader.dataset
@@ -400,9 +405,16 @@ def main():
     shared_gpu = os.environ.get("PVAE_BENCH_SHARED_GPU") == "1"
     if not dp.collective:
         transport = "none (single rank: Adam inside the backward launches, deferred one launch behind each weight gradient)"
+    elif eng.has_p2p:
+        transport = ("in-library peer-mapped exchange (hipIpc-mapped arenas, no RCCL): one launch per stack -- rank-order "
+                     "reduce-scatter by the slice owners, Adam on the owned slice, parameters pushed to every peer")
     elif eng.has_comm:
-        transport = ("in-library RCCL all-reduce + flat Adam; default schedule: in line on the compute stream in the "
-                     "world phase, 6 MiB buckets overlapped on the exchange stream in the joint phase")
+        transport = {None: "in-library RCCL all-reduce + flat Adam; default schedule: in line on the compute stream in the "
+                           "world phase, 6 MiB buckets overlapped on the exchange stream in the joint phase",
+                     "inline": "in-library RCCL all-reduce per stack, in line on the compute stream, + flat Adam",
+                     "bucketed": "in-library RCCL all-reduce in 6 MiB buckets overlapped on the exchange stream + per-bucket Adam",
+                     "sharded": "in-library RCCL reduce-scatter -> Adam on the owned 1/N slice -> all-gather of the parameters",
+                     }[a.exchange]
     else:
         transport = "torch.distributed (%s) bucketed async all-reduce + per-bucket Adam" % dist.get_backend()
     out = {
@@ -416,6 +428,7 @@ def main():
         "timing": {"timed_steps_per_region": timed_steps, "regions": REPEATS, "statistic": "median",
                    "region_values": rates},
         "rccl_ranks": comm_ranks, "rccl_rank": comm_rank,
+        "p2p_ranks": eng.p2p_status(sync=False)[1], "exchange_mode": a.exchange or "default",
         "ranks_share_a_gpu": shared_gpu,
         "last_loss": last_loss,
     }
@@ -542,6 +555,15 @@ def main():
                                           "gather of the next minibatch rides in the trailing launch" % (gbytes / 1e6)}
         eng.invalidate_staging()
 
+    if dp.collective and eng.in_library_exchange and not a.no_extra:
+        # What the exchange ADDS to the step: the same data-parallel step with the exchange switched off (every rank
+        # applies Adam to its own gradient -- replicas diverge, so this is the LAST thing the benchmark times).
+        if eng.has_p2p:
+            out["p2p_timeouts"] = eng.p2p_status()[2]
+        eng.comm_mode("local")
+        _, ms_local, _, _ = timed(a.phase, MIN_TIMED_STEPS, max(a.warmup // 2, 5), 1)
+        out["step_without_exchange_us"] = ms_local * 1e3
+        out["exchange_exposed_us_per_step"] = (ms_per_step - ms_local) * 1e3
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, sd, Db, Da, Z, W, D, a.phase, synth_demo)
     if dist.is_initialized():

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PVAE_ABI_VERSION 4
+#define PVAE_ABI_VERSION 5
 
 typedef struct pvae_ctx pvae_ctx;
 
@@ -276,9 +276,47 @@ int pvae_comm_config(pvae_ctx* ctx, int64_t bucket_bytes, int32_t test_delay_us)
  *                                      slices.  Each rank then holds valid Adam moments for its own
  *                                      slice only (ZeRO-1 shaped).  Buckets whose length is not a
  *                                      multiple of 4*N floats fall back to the all-reduce form.
+ *   PVAE_EXCHANGE_P2P                  no RCCL: the direct all-pairs exchange of SURVEY.md section 8e over
+ *                                      peer-mapped arenas (pvae_p2p_export / pvae_p2p_open below).  ONE
+ *                                      launch per bucket: rank r signals "my gradient is final", waits for
+ *                                      every peer's signal, reads slice r of every rank's gradient arena
+ *                                      directly (7 links in parallel on an 8-GPU xGMI mesh), sums in RANK
+ *                                      ORDER (so every element is reduced once, by its owner, the same way:
+ *                                      replicas stay bit-identical by construction), applies Adam to its
+ *                                      slice and writes the updated parameters straight into every peer's
+ *                                      parameter arena; the last workgroup tells the peers it is done and
+ *                                      waits for theirs.  Moments as in the sharded form (ZeRO-1 shaped).
  * PVAE_DP_SHARDED=1 in the environment selects the sharded form at pvae_comm_init. */
-enum { PVAE_EXCHANGE_ALLREDUCE = 0, PVAE_EXCHANGE_SHARDED = 1 };
+enum { PVAE_EXCHANGE_ALLREDUCE = 0, PVAE_EXCHANGE_SHARDED = 1, PVAE_EXCHANGE_P2P = 2,
+       PVAE_EXCHANGE_LOCAL = 3 /* MEASUREMENT ONLY: no exchange at all, every rank applies Adam to its own
+                                  gradient (replicas diverge) -- the step time without the collective, against
+                                  which bench.py reports what an exchange adds */ };
 int pvae_comm_mode(pvae_ctx* ctx, int mode);
+/* Peer-mapped exchange (PVAE_EXCHANGE_P2P).  The reference has no counterpart (tm:131-161 is one process);
+ * this is what `north_star` asks for on top of it.  Set-up, after pvae_bind_arenas:
+ *   pvae_p2p_export   writes PVAE_P2P_BLOB_BYTES describing this rank's gradient arena, parameter arena and
+ *                     flag block (hipIpcGetMemHandle of the allocations they live in + offsets).  The arenas
+ *                     must come from hipMalloc (PyTorch's default allocator does; expandable segments do not).
+ *   (caller)          all-gathers the blobs of all ranks, by any transport (torch.distributed, a file, MPI)
+ *   pvae_p2p_open     collective in effect: maps every peer's three buffers (hipIpcOpenMemHandle) -- peers may
+ *                     be other GPUs of the node (xGMI) or other processes on the SAME device (functional tests
+ *                     on a 1-GPU box).  world <= PVAE_P2P_MAX_RANKS.
+ *   pvae_p2p_status   *timeouts = waits that gave up (a peer never signalled within the time-out, default 20 s,
+ *                     PVAE_P2P_TIMEOUT_MS): results are then garbage and the caller must stop.  Synchronises
+ *                     `stream`.  *rank / *world as passed to pvae_p2p_open (0 ranks: not open).
+ * pvae_dp_train_step then runs with or without an RCCL communicator. */
+#define PVAE_P2P_BLOB_BYTES 256
+#define PVAE_P2P_MAX_RANKS 8
+int pvae_p2p_export(pvae_ctx* ctx, void* blob);
+int pvae_p2p_open(pvae_ctx* ctx, int rank, int world, const void* blobs);
+int pvae_p2p_close(pvae_ctx* ctx);
+int pvae_p2p_status(pvae_ctx* ctx, int* rank, int* world, uint32_t* timeouts, void* stream);
+/* One bucket through the peer-mapped exchange, stream-ordered like any launch of this library: the slice
+ * [offset, offset + count) of the gradient arena (inside stack `net`, float4-aligned) is summed over the ranks
+ * by its owners, Adam-applied and the updated parameters written to every rank -- what pvae_dp_train_step does
+ * per bucket in PVAE_EXCHANGE_P2P mode.  Every rank must issue the same sequence of calls. */
+int pvae_p2p_exchange(pvae_ctx* ctx, int net, int64_t offset, int64_t count, const pvae_step_params* sp,
+                      void* stream);
 int pvae_allreduce_grads(pvae_ctx* ctx, int64_t offset, int64_t count, void* stream);
 int pvae_dp_train_step(pvae_ctx* ctx, int phase, int64_t first_window, int32_t rows,
                        const pvae_step_params* sp, const float* eps, float* loss_out,

@@ -30,9 +30,10 @@ ACT_KINDS = {"relu": 0, "tanh": 1, "sigmoid": 2, "elu": 3}      # pvae_config.ac
 PRIOR_KINDS = {"normal_zero_mean_one_std": 0, "normal_state_mean_one_std": 1, "hypersphere_uniform": 2, False: 3}
 PHASE_WORLD, PHASE_JOINT = 0, 1
 FLAG_FUSED_ADAM, FLAG_NO_BACKWARD = 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 LOSS_MSE, LOSS_L1 = 0, 1
-EXCHANGE_ALLREDUCE, EXCHANGE_SHARDED = 0, 1
+EXCHANGE_ALLREDUCE, EXCHANGE_SHARDED, EXCHANGE_P2P, EXCHANGE_LOCAL = 0, 1, 2, 3
+P2P_BLOB_BYTES, P2P_MAX_RANKS = 256, 8
 
 
 class Config(C.Structure):
@@ -89,6 +90,11 @@ _SIGS = {
     "pvae_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pvae_comm_config": (C.c_int, [_P, C.c_int64, C.c_int32]),
     "pvae_comm_mode": (C.c_int, [_P, C.c_int]),
+    "pvae_p2p_export": (C.c_int, [_P, _P]),
+    "pvae_p2p_open": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "pvae_p2p_close": (C.c_int, [_P]),
+    "pvae_p2p_exchange": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.POINTER(StepParams), _P]),
+    "pvae_p2p_status": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32), _P]),
     "pvae_allreduce_grads": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     "pvae_dp_train_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P,
                                      C.c_int64, C.c_int32, _P]),

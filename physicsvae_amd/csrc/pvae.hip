@@ -184,6 +184,19 @@ struct pvae_ctx {
     AdamSeg pending_adam;
     bool defer_adam = true;
     bool same_layer_pairs = true;  // PVAE_SAME_LAYER=0: wgrad_i rides with dgrad_{i-1} as before (A/B)
+    // peer-mapped exchange (PVAE_EXCHANGE_P2P): every rank's gradient arena, parameter arena and flag block,
+    // mapped into this process with hipIpcOpenMemHandle (index = rank; [rank] = the local pointers)
+    struct P2p {
+        bool open = false;
+        int rank = 0, world = 0;
+        unsigned* flags = nullptr;                       // own flag block (uncached device memory)
+        float* grads[PVAE_P2P_MAX_RANKS] = {};
+        float* params[PVAE_P2P_MAX_RANKS] = {};
+        unsigned* peer_flags[PVAE_P2P_MAX_RANKS] = {};
+        void* mapped[PVAE_P2P_MAX_RANKS][3] = {};        // what hipIpcOpenMemHandle returned (to close)
+        unsigned epoch = 0;                              // exchanges issued so far (identical on every rank)
+        long long timeout_ticks = 20ll * 100000000ll;    // 100 MHz wall clock
+    } p2p;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -486,6 +499,102 @@ adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __re
         reinterpret_cast<v4f*>(p)[i] = pp;
         reinterpret_cast<v4f*>(m)[i] = mm;
         reinterpret_cast<v4f*>(v)[i] = vv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Direct all-pairs gradient exchange over peer-mapped arenas (PVAE_EXCHANGE_P2P; SURVEY.md section 8e: "direct
+// reduce-scatter + all-gather across all 7 links").  ONE launch per bucket and rank:
+//   1. workgroup 0 tells every peer "my gradient of this bucket is final" (the launches that produced it precede
+//      this one in the stream): epoch -> peer's ready[me];
+//   2. every workgroup waits until all peers have told it the same (ready[q] >= epoch, local uncached memory);
+//   3. the rank owns slice `me` of the bucket: for each float4 of it, the N gradients are read straight from the
+//      N arenas (system-scope loads, all N in flight together), summed IN RANK ORDER, Adam is applied with the
+//      local moments, and the new parameters are written to the local arena AND pushed into every peer's;
+//   4. the last workgroup to finish (ticket) fences, tells every peer "done" and waits for every peer's "done":
+//      when the launch ends this rank's parameter arena is complete and its gradient arena may be overwritten.
+// Epochs only grow and every rank issues the same sequence of exchanges, so one word per (kind, source rank) is
+// enough and a peer that is one exchange ahead cannot be mistaken (>= comparisons).  Every wait is bounded: a
+// peer that never signals raises the error word instead of hanging the GPU.
+// Flag block (unsigned words): [0, 8) ready[src], [8, 16) done[src], 16 ticket, 17 waits that gave up.
+// ---------------------------------------------------------------------------------------
+constexpr int kP2pReady = 0, kP2pDone = 8, kP2pTicket = 16, kP2pErr = 17, kP2pFlagBytes = 4096;
+struct P2pArgs {
+    float* g[PVAE_P2P_MAX_RANKS];           // gradient arenas, bucket offset applied (g[me]: local)
+    float* p[PVAE_P2P_MAX_RANKS];           // parameter arenas, bucket offset applied
+    unsigned* f[PVAE_P2P_MAX_RANKS];        // flag blocks
+    float* m; float* v;                     // local moments, bucket offset applied
+    long long n4;                           // float4 elements in the bucket
+    int me;
+    unsigned epoch;
+    long long timeout_ticks;
+    AdamScalars s;
+};
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ inline unsigned p2p_ld(const unsigned* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ inline void p2p_st(unsigned* q, unsigned x) { __hip_atomic_store(q, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ inline void p2p_wait(const unsigned* flag, unsigned epoch, long long timeout, unsigned* err) {
+    const long long t0 = wall_clock64();
+    while ((int)(p2p_ld(flag) - epoch) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > timeout) { atomicAdd(err, 1u); return; }
+    }
+}
+template <int N>
+__global__ void __launch_bounds__(256) p2p_exchange_kernel(P2pArgs a) {
+    unsigned* mine = a.f[a.me];
+    const int tid = threadIdx.x, me = a.me;
+    if (blockIdx.x == 0 && tid < N && tid != me) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");             // (system scope; the producing launches ended before this one began)
+        p2p_st(a.f[tid] + kP2pReady + me, a.epoch);
+    }
+    if (tid < N && tid != me) {
+        p2p_wait(mine + kP2pReady + tid, a.epoch, a.timeout_ticks, mine + kP2pErr);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    __syncthreads();
+    const long long S = (a.n4 + N - 1) / N, lo = me * S, hi = lo + S < a.n4 ? lo + S : a.n4;
+    if (lo < hi) {
+        // buffer descriptors over this rank's slice of every arena: loads / stores with sc0 sc1 (system scope,
+        // past this device's caches) that the compiler schedules and counts like any other memory operation
+        __amdgpu_buffer_rsrc_t rg[N], rp[N];
+        const unsigned bytes = (unsigned)((hi - lo) * 16);
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            rg[q] = __builtin_amdgcn_make_buffer_rsrc(a.g[q] + 4 * lo, 0, bytes, 0x00020000);
+            rp[q] = __builtin_amdgcn_make_buffer_rsrc(a.p[q] + 4 * lo, 0, bytes, 0x00020000);
+        }
+        for (long long i = blockIdx.x * 256ll + tid; i < hi - lo; i += gridDim.x * 256ll) {
+            const unsigned off = (unsigned)(i * 16);
+            v4f g[N];
+#pragma unroll
+            for (int q = 0; q < N; ++q) g[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rg[q], off, 0, 17));
+            v4f pp = reinterpret_cast<const v4f*>(a.p[me])[lo + i];
+            v4f mm = reinterpret_cast<const v4f*>(a.m)[lo + i];
+            v4f vv = reinterpret_cast<const v4f*>(a.v)[lo + i];
+            v4f sum = g[0];
+#pragma unroll
+            for (int q = 1; q < N; ++q) sum += g[q];                // rank order, whoever owns the slice
+            adam_update4(sum, pp, mm, vv, a.s);
+            store_stream(a.m + 4 * (lo + i), mm);
+            store_stream(a.v + 4 * (lo + i), vv);
+#pragma unroll
+            for (int q = 0; q < N; ++q) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, pp), rp[q], off, 0, 17);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ unsigned last;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        last = atomicAdd(mine + kP2pTicket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    if (tid == 0) mine[kP2pTicket] = 0;
+    if (tid < N && tid != me) {
+        p2p_st(a.f[tid] + kP2pDone + me, a.epoch);
+        p2p_wait(mine + kP2pDone + tid, a.epoch, a.timeout_ticks, mine + kP2pErr);
     }
 }
 
@@ -1175,8 +1284,13 @@ int pvae_create(const pvae_config* cfg, pvae_ctx** out) {
     return 0;
 }
 
+int pvae_p2p_close(pvae_ctx* c);
 void pvae_destroy(pvae_ctx* ctx) {
     if (ctx && ctx->comm && g_rccl.ok()) g_rccl.CommDestroy(ctx->comm);
+    if (ctx) {
+        pvae_p2p_close(ctx);
+        if (ctx->p2p.flags) (void)hipFree(ctx->p2p.flags);
+    }
     delete ctx;
 }
 
@@ -1931,6 +2045,7 @@ int pvae_comm_unique_id(void* id128) {
     return 0;
 }
 
+static int ensure_comm_stream(pvae_ctx* c);
 int pvae_comm_init(pvae_ctx* c, int rank, int world, const void* id128) {
     if (!c || !id128) return fail(-1, "null argument");
     if (world < 1 || rank < 0 || rank >= world) return fail(-1, "rank %d outside [0, %d)", rank, world);
@@ -1942,20 +2057,199 @@ int pvae_comm_init(pvae_ctx* c, int rank, int world, const void* id128) {
     void* comm = nullptr;
     RCCL_TRY(g_rccl.CommInitRank(&comm, world, id, rank));
     c->comm = comm; c->comm_rank = rank; c->comm_world = world;
-    if (!c->comm_stream) {
-        int lo = 0, hi = 0;                                   // hi = numerically lowest = most urgent
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIP_TRY(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, hi));
-        for (hipEvent_t& e : c->bucket_ready) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->comm_done, hipEventDisableTiming));
-    }
+    if ((rc = ensure_comm_stream(c))) return rc;
     if (const char* e = getenv("PVAE_DP_BUCKET_MB")) c->bucket_bytes = (int64_t)(atof(e) * (1 << 20));
     if (const char* e = getenv("PVAE_DP_SHARDED")) c->exchange_mode = e[0] == '1' ? PVAE_EXCHANGE_SHARDED : PVAE_EXCHANGE_ALLREDUCE;
     return 0;
 }
 
+// the exchange stream and its events (bucketed + overlapped exchange), shared by the RCCL and the peer-mapped transport
+static int ensure_comm_stream(pvae_ctx* c) {
+    if (c->comm_stream) return 0;
+    int lo = 0, hi = 0;                                   // hi = numerically lowest = most urgent
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, hi));
+    for (hipEvent_t& e : c->bucket_ready) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->comm_done, hipEventDisableTiming));
+    return 0;
+}
+
+// ---- peer-mapped exchange: set-up ------------------------------------------------------------
+struct P2pBlob {                                          // PVAE_P2P_BLOB_BYTES on the wire
+    uint32_t magic, abi;
+    int64_t arena_floats;
+    hipIpcMemHandle_t h[3];                               // allocations holding grads, params, flags
+    int64_t off[3];                                       // byte offset of the buffer inside its allocation
+};
+static_assert(sizeof(P2pBlob) <= PVAE_P2P_BLOB_BYTES, "blob layout");
+constexpr uint32_t kP2pMagic = 0x50325056u;               // "PV2P"
+
+int pvae_p2p_export(pvae_ctx* c, void* blob) {
+    if (!c || !blob) return fail(-1, "null argument");
+    if (!c->params || !c->grads) return fail(-2, "parameter / gradient arenas not bound");
+    if (!c->p2p.flags) {
+        HIP_TRY(hipExtMallocWithFlags((void**)&c->p2p.flags, kP2pFlagBytes, hipDeviceMallocUncached));
+        HIP_TRY(hipMemset(c->p2p.flags, 0, kP2pFlagBytes));
+    }
+    P2pBlob b;
+    memset(&b, 0, sizeof(b));
+    b.magic = kP2pMagic; b.abi = PVAE_ABI_VERSION; b.arena_floats = c->L.arena_floats;
+    void* ptrs[3] = {c->grads, c->params, c->p2p.flags};
+    const char* what[3] = {"gradient arena", "parameter arena", "flag block"};
+    for (int k = 0; k < 3; ++k) {
+        void* base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, ptrs[k]) != hipSuccess || !base)
+            return fail(-10, "%s: not inside a hipMalloc allocation", what[k]);
+        hipError_t e = hipIpcGetMemHandle(&b.h[k], base);
+        if (e != hipSuccess)
+            return fail(-10, "hipIpcGetMemHandle(%s): %s (the arenas must come from hipMalloc -- PyTorch's default "
+                             "caching allocator, not expandable segments -- and HSA_ENABLE_IPC_MODE_LEGACY=0 must be set "
+                             "where the driver only supports dmabuf IPC)", what[k], hipGetErrorString(e));
+        b.off[k] = (char*)ptrs[k] - (char*)base;
+    }
+    memset(blob, 0, PVAE_P2P_BLOB_BYTES);
+    memcpy(blob, &b, sizeof(b));
+    return 0;
+}
+
+int pvae_p2p_close(pvae_ctx* c) {
+    if (!c) return fail(-1, "null ctx");
+    pvae_ctx::P2p& P = c->p2p;
+    for (int q = 0; q < PVAE_P2P_MAX_RANKS; ++q)
+        for (int k = 0; k < 3; ++k) {
+            if (!P.mapped[q][k]) continue;
+            bool dup = false;                             // one mapping may serve two buffers of a peer
+            for (int j = 0; j < k; ++j) dup = dup || P.mapped[q][j] == P.mapped[q][k];
+            if (!dup) (void)hipIpcCloseMemHandle(P.mapped[q][k]);
+        }
+    memset(P.mapped, 0, sizeof(P.mapped));
+    memset(P.grads, 0, sizeof(P.grads)); memset(P.params, 0, sizeof(P.params)); memset(P.peer_flags, 0, sizeof(P.peer_flags));
+    P.open = false; P.world = 0; P.rank = 0;
+    if (c->exchange_mode == PVAE_EXCHANGE_P2P) c->exchange_mode = PVAE_EXCHANGE_ALLREDUCE;
+    if (!c->comm) { c->comm_world = 1; c->comm_rank = 0; }
+    return 0;
+}
+
+int pvae_p2p_open(pvae_ctx* c, int rank, int world, const void* blobs) {
+    if (!c || !blobs) return fail(-1, "null argument");
+    if (world < 1 || world > PVAE_P2P_MAX_RANKS || rank < 0 || rank >= world)
+        return fail(-1, "rank %d / world %d outside [0, %d]", rank, world, PVAE_P2P_MAX_RANKS);
+    pvae_ctx::P2p& P = c->p2p;
+    if (P.open) return fail(-2, "peer-mapped exchange already open");
+    if (!P.flags || !c->params || !c->grads) return fail(-2, "pvae_p2p_export first");
+    if (c->comm && (c->comm_world != world || c->comm_rank != rank))
+        return fail(-1, "rank %d / world %d differ from the RCCL communicator's %d / %d", rank, world, c->comm_rank, c->comm_world);
+    const char* all = (const char*)blobs;
+    for (int q = 0; q < world; ++q) {
+        P2pBlob b;
+        memcpy(&b, all + (size_t)q * PVAE_P2P_BLOB_BYTES, sizeof(b));
+        if (b.magic != kP2pMagic || b.abi != PVAE_ABI_VERSION || b.arena_floats != c->L.arena_floats) {
+            pvae_p2p_close(c);
+            return fail(-1, "blob of rank %d does not describe a matching ctx", q);
+        }
+        if (q == rank) {
+            P.grads[q] = c->grads; P.params[q] = c->params; P.peer_flags[q] = P.flags;
+            continue;
+        }
+        void* base[3] = {nullptr, nullptr, nullptr};
+        for (int k = 0; k < 3; ++k) {
+            for (int j = 0; j < k; ++j)                   // two buffers inside one allocation: open it once
+                if (memcmp(&b.h[j], &b.h[k], sizeof(b.h[k])) == 0) base[k] = base[j];
+            if (!base[k]) {
+                hipError_t e = hipIpcOpenMemHandle(&base[k], b.h[k], hipIpcMemLazyEnablePeerAccess);
+                if (e != hipSuccess) {
+                    pvae_p2p_close(c);
+                    return fail(-10, "hipIpcOpenMemHandle(rank %d, buffer %d): %s", q, k, hipGetErrorString(e));
+                }
+            }
+            P.mapped[q][k] = base[k];
+        }
+        P.grads[q] = (float*)((char*)base[0] + b.off[0]);
+        P.params[q] = (float*)((char*)base[1] + b.off[1]);
+        P.peer_flags[q] = (unsigned*)((char*)base[2] + b.off[2]);
+    }
+    P.rank = rank; P.world = world; P.epoch = 0; P.open = true;
+    if (const char* e = getenv("PVAE_P2P_TIMEOUT_MS")) {
+        const long long ms = atoll(e);
+        if (ms > 0) P.timeout_ticks = ms * 100000ll;
+    }
+    c->comm_rank = rank; c->comm_world = world;
+    int rc = ensure_comm_stream(c);
+    if (rc) return rc;
+    if (const char* e = getenv("PVAE_DP_BUCKET_MB")) c->bucket_bytes = (int64_t)(atof(e) * (1 << 20));
+    return 0;
+}
+
+int pvae_p2p_status(pvae_ctx* c, int* rank, int* world, uint32_t* timeouts, void* stream) {
+    if (!c) return fail(-1, "null ctx");
+    if (rank) *rank = c->p2p.open ? c->p2p.rank : 0;
+    if (world) *world = c->p2p.open ? c->p2p.world : 0;
+    if (timeouts) {
+        *timeouts = 0;
+        if (c->p2p.flags) {
+            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
+            HIP_TRY(hipMemcpy(timeouts, c->p2p.flags + kP2pErr, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        }
+    }
+    return 0;
+}
+
+// one bucket through the peer-mapped exchange (see p2p_exchange_kernel)
+static int p2p_exchange(pvae_ctx* c, int net, int64_t off, int64_t cnt, const pvae_step_params* sp, hipStream_t cs) {
+    pvae_ctx::P2p& P = c->p2p;
+    if (!P.open) return fail(-2, "peer-mapped exchange not open (pvae_p2p_open)");
+    if (!c->m || !c->v) return fail(-2, "Adam moment arenas not bound");
+    if (P.grads[P.rank] != c->grads || P.params[P.rank] != c->params) return fail(-2, "arenas were re-bound after pvae_p2p_export");
+    if ((off & 3) || (cnt & 3) || cnt <= 0) return fail(-1, "bucket [%lld, +%lld) not float4-aligned", (long long)off, (long long)cnt);
+    P2pArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int q = 0; q < P.world; ++q) { a.g[q] = P.grads[q] + off; a.p[q] = P.params[q] + off; a.f[q] = P.peer_flags[q]; }
+    a.m = c->m + off; a.v = c->v + off;
+    a.n4 = cnt / 4; a.me = P.rank; a.epoch = ++P.epoch; a.timeout_ticks = P.timeout_ticks;
+    a.s = adam_scalars(sp, net);
+    const long long slice = (a.n4 + P.world - 1) / P.world;
+    int grid = (int)((slice + 255) / 256);
+    if (grid > 256) grid = 256;
+    if (grid < 1) grid = 1;
+    const int ps = g_prof.begin_range(4, (double)cnt * sizeof(float), cs);
+    switch (P.world) {
+#define PVAE_P2P_CASE(N) case N: hipLaunchKernelGGL((p2p_exchange_kernel<N>), dim3(grid), dim3(256), 0, cs, a); break;
+        PVAE_P2P_CASE(1) PVAE_P2P_CASE(2) PVAE_P2P_CASE(3) PVAE_P2P_CASE(4)
+        PVAE_P2P_CASE(5) PVAE_P2P_CASE(6) PVAE_P2P_CASE(7) PVAE_P2P_CASE(8)
+#undef PVAE_P2P_CASE
+        default: return fail(-1, "world %d", P.world);
+    }
+    HIP_TRY(hipGetLastError());
+    g_prof.end_range(ps, cs);
+    return 0;
+}
+
+int pvae_p2p_exchange(pvae_ctx* c, int net, int64_t offset, int64_t count, const pvae_step_params* sp, void* stream) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!sp) return fail(-1, "null step params");
+    if (net < 0 || net >= PVAE_NUM_NETS) return fail(-1, "bad net id %d", net);
+    const NetLayout& N = c->L.net[net];
+    if (offset < N.off || count < 0 || offset + count > N.off + N.count)
+        return fail(-1, "segment [%lld, +%lld) not inside net %d", (long long)offset, (long long)count, net);
+    if (count == 0) return 0;
+    return p2p_exchange(c, net, offset, count, sp, (hipStream_t)stream);
+}
+
 int pvae_comm_mode(pvae_ctx* c, int mode) {
     if (!c) return fail(-1, "null ctx");
+    if (mode == PVAE_EXCHANGE_P2P) {
+        if (!c->p2p.open) return fail(-2, "peer-mapped exchange not open (pvae_p2p_export / pvae_p2p_open)");
+        c->exchange_mode = mode;
+        return 0;
+    }
+    if (mode == PVAE_EXCHANGE_LOCAL) {
+        if (!c->comm && !c->p2p.open) return fail(-2, "no communicator and no peer-mapped exchange");
+        c->exchange_mode = mode;
+        return 0;
+    }
     if (mode != PVAE_EXCHANGE_ALLREDUCE && mode != PVAE_EXCHANGE_SHARDED) return fail(-1, "unknown exchange mode %d", mode);
     if (mode == PVAE_EXCHANGE_SHARDED) {
         int rc = rccl_load();
@@ -1990,7 +2284,8 @@ int pvae_comm_destroy(pvae_ctx* c) {
         RCCL_TRY(g_rccl.CommDestroy(c->comm));
         c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0;
     }
-    if (c->comm_stream) {
+    if (c->p2p.open) { c->comm_world = c->p2p.world; c->comm_rank = c->p2p.rank; }
+    if (c->comm_stream && !c->p2p.open) {
         HIP_TRY(hipStreamSynchronize(c->comm_stream));
         HIP_TRY(hipStreamDestroy(c->comm_stream));
         c->comm_stream = nullptr;
@@ -2055,6 +2350,8 @@ static int exchange_bucket(pvae_ctx* c, int net, const Bucket& b, const pvae_ste
     // bucket (reduce-scatter, in place), applies Adam to that slice (1/N of the p, g, m, v traffic) and the
     // updated parameter slices are all-gathered in place.  Same bytes on the links as a ring all-reduce;
     // the moments of the other ranks' slices are never touched here (they stay at whatever they were).
+    if (c->exchange_mode == PVAE_EXCHANGE_P2P) return p2p_exchange(c, net, b.off, b.cnt, sp, cs);
+    if (c->exchange_mode == PVAE_EXCHANGE_LOCAL) return pvae_adam_segment(c, net, b.off, b.cnt, sp, cs);
     const int64_t N = c->comm_world;
     if (c->exchange_mode == PVAE_EXCHANGE_SHARDED && g_rccl.ReduceScatter && g_rccl.AllGather &&
         b.cnt % (N * 4) == 0 && b.cnt > 0) {
@@ -2091,7 +2388,8 @@ int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t row
                        const float* eps, float* loss_out, int64_t next_first, int32_t next_rows, void* stream) {
     int rc = check_ready(c, true);
     if (rc) return rc;
-    if (!c->comm) return fail(-2, "no communicator (pvae_comm_init)");
+    if (!c->comm && !(c->p2p.open && (c->exchange_mode == PVAE_EXCHANGE_P2P || c->exchange_mode == PVAE_EXCHANGE_LOCAL)))
+        return fail(-2, "no communicator (pvae_comm_init) and no peer-mapped exchange (pvae_p2p_open + pvae_comm_mode)");
     if (!sp) return fail(-1, "null step params");
     if (!c->grads || !c->m || !c->v) return fail(-2, "grads / Adam moment arenas not bound");
     if (phase != PVAE_PHASE_WORLD && phase != PVAE_PHASE_JOINT) return fail(-1, "unknown phase %d", phase);

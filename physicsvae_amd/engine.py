@@ -131,6 +131,7 @@ class HipEngine:
         self.exp_avg_sq = torch.zeros(self.arena_floats, **f32)
         self.ctx = None
         self.has_comm = False                    # RCCL communicator owned by the ctx (comm_init)
+        self.has_p2p = False                     # peers' arenas mapped into this process (p2p_open)
         self.workspace = None
         self.dataset = None
         self._loss_scratch = None
@@ -312,6 +313,11 @@ class HipEngine:
             "pvae_train_step")
         return out
 
+    @property
+    def in_library_exchange(self):
+        """`dp_train_step` can run: the ctx has an RCCL communicator or its peers' arenas are mapped."""
+        return self.has_comm or self.has_p2p
+
     # -- data-parallel exchange inside the library (RCCL) ----------------------------------------
     def comm_unique_id(self):
         buf = C.create_string_buffer(128)
@@ -343,11 +349,49 @@ class HipEngine:
         include/pvae.h) and, for ordering tests, a delay in front of every reduction."""
         _lib.check(self.lib.pvae_comm_config(self.ctx, int(bucket_mb * (1 << 20)), int(test_delay_us)), "pvae_comm_config")
 
-    def comm_mode(self, sharded):
-        """Exchange form of dp_train_step: all-reduce + replicated Adam (default) or reduce-scatter ->
-        Adam on the owned 1/N slice -> all-gather of the parameters (include/pvae.h)."""
-        _lib.check(self.lib.pvae_comm_mode(self.ctx, _lib.EXCHANGE_SHARDED if sharded else _lib.EXCHANGE_ALLREDUCE),
-                   "pvae_comm_mode")
+    def comm_mode(self, mode):
+        """Exchange form of dp_train_step (include/pvae.h): "allreduce" (False) = all-reduce + replicated Adam,
+        "sharded" (True) = reduce-scatter -> Adam on the owned 1/N slice -> all-gather of the parameters, "p2p" =
+        the same shape as ONE launch over peer-mapped arenas, no RCCL (needs p2p_open)."""
+        code = {False: _lib.EXCHANGE_ALLREDUCE, True: _lib.EXCHANGE_SHARDED, "allreduce": _lib.EXCHANGE_ALLREDUCE,
+                "sharded": _lib.EXCHANGE_SHARDED, "p2p": _lib.EXCHANGE_P2P, "local": _lib.EXCHANGE_LOCAL}[mode]
+        _lib.check(self.lib.pvae_comm_mode(self.ctx, code), "pvae_comm_mode")
+
+    # -- peer-mapped exchange (PVAE_EXCHANGE_P2P) -------------------------------------------------
+    def p2p_export(self):
+        """This rank's 256-byte description of its gradient / parameter arenas and flag block (IPC handles)."""
+        self._need_gpu()
+        buf = C.create_string_buffer(_lib.P2P_BLOB_BYTES)
+        _lib.check(self.lib.pvae_p2p_export(self.ctx, buf), "pvae_p2p_export")
+        return buf.raw
+
+    def p2p_open(self, rank, world, blobs):
+        """Map every peer's buffers (`blobs`: the exports of ranks 0 .. world-1 in rank order)."""
+        self._need_gpu()
+        assert len(blobs) == world and all(len(b) == _lib.P2P_BLOB_BYTES for b in blobs)
+        _lib.check(self.lib.pvae_p2p_open(self.ctx, int(rank), int(world), C.c_char_p(b"".join(blobs))), "pvae_p2p_open")
+        self.has_p2p = True
+
+    def p2p_exchange(self, net, off, cnt, sp):
+        """One slice of the gradient arena through the peer-mapped exchange (sum over the ranks by the slice owners,
+        Adam, updated parameters to every rank); every rank issues the same calls."""
+        self._need_gpu()
+        _lib.check(self.lib.pvae_p2p_exchange(self.ctx, int(net), int(off), int(cnt), C.byref(sp), self._stream()),
+                   "pvae_p2p_exchange")
+
+    def p2p_close(self):
+        if self.ctx is not None and self.has_p2p:
+            _lib.check(self.lib.pvae_p2p_close(self.ctx), "pvae_p2p_close")
+            self.has_p2p = False
+
+    def p2p_status(self, sync=True):
+        """(rank, world, waits that gave up).  world = 0: not open.  `sync`: read the time-out word (synchronises)."""
+        r, n, t = C.c_int(), C.c_int(), C.c_uint32()
+        if self.ctx is None:
+            return 0, 0, 0
+        _lib.check(self.lib.pvae_p2p_status(self.ctx, C.byref(r), C.byref(n), C.byref(t) if sync else None,
+                                            self._stream()), "pvae_p2p_status")
+        return r.value, n.value, t.value
 
     def allreduce_grads(self, off, cnt):
         self._need_gpu()

@@ -89,6 +89,39 @@ class DataParallel:
             return False
         return True
 
+    def attach_p2p(self, engine):
+        """Peer-mapped exchange (`dp_exchange = "p2p"`, include/pvae.h PVAE_EXCHANGE_P2P): every rank exports IPC
+        handles of its gradient / parameter arenas and flag block, the blobs are all-gathered over whatever
+        backend torch.distributed runs (nccl, or gloo when the ranks share one GPU), every rank maps its peers'
+        buffers, and `pvae_dp_train_step` then exchanges each bucket with ONE launch, without RCCL.  Collective:
+        every rank takes part in every step and all agree (MIN over a success flag) on the outcome."""
+        if not self.collective or engine.ctx is None:
+            return False
+        if engine.has_p2p:
+            return True
+        blob, err = None, None
+        try:
+            blob = engine.p2p_export()
+        except Exception as exc:                                   # noqa: BLE001
+            err = str(exc)
+        blobs = [None] * self.world
+        dist.all_gather_object(blobs, blob, group=self.group)
+        ok = all(b is not None for b in blobs)
+        if ok:
+            try:
+                engine.p2p_open(self.rank, self.world, blobs)
+            except Exception as exc:                               # noqa: BLE001
+                ok, err = False, str(exc)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=engine.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) != 1:
+            engine.p2p_close()
+            if self.rank == 0 or err:
+                print("[physicsvae_amd] peer-mapped exchange unavailable (%s)" % (err or "another rank failed"), file=sys.stderr)
+            return False
+        engine.comm_mode("p2p")
+        return True
+
     def all_reduce(self, tensor):
         if self.collective:
             dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)

@@ -166,13 +166,30 @@ class TrainModel(tune.Trainable):
         self.device = self.engine.device
         self.dp = parallel.DataParallel.from_env()
         self.dp_bucket_mb = float(config.get("dp_bucket_mb", os.environ.get("PVAE_DP_BUCKET_MB", 0)))
-        self.dp.attach(self.engine)
-        if self.engine.has_comm and ("dp_bucket_mb" in config or "PVAE_DP_BUCKET_MB" in os.environ):
-            self.engine.comm_config(self.dp_bucket_mb)
+        # How the gradient is exchanged (every rank must choose the same): `dp_exchange` / PVAE_DP_EXCHANGE =
+        #   "inline"   RCCL all-reduce per stack on the compute stream + replicated Adam
+        #   "bucketed" the same in 6 MiB buckets (or dp_bucket_mb) on the library's exchange stream, overlapped
+        #   "sharded"  RCCL reduce-scatter -> Adam on the owned 1/N slice -> all-gather of the parameters
+        #   "p2p"      the sharded shape as ONE launch per stack over peer-mapped arenas, no RCCL (include/pvae.h)
+        #   unset      the library's default schedule
+        self.dp_exchange = config.get("dp_exchange", os.environ.get("PVAE_DP_EXCHANGE")) or None
+        if self.dp_exchange not in (None, "inline", "bucketed", "sharded", "p2p"):
+            raise ValueError("dp_exchange %r: expected inline / bucketed / sharded / p2p" % (self.dp_exchange,))
+        if self.dp_exchange == "p2p":
+            if self.dp.collective and not self.dp.attach_p2p(self.engine):
+                raise RuntimeError("dp_exchange = p2p: the peer-mapped exchange could not be set up (see stderr)")
+        else:
+            self.dp.attach(self.engine)
+        if self.dp_exchange == "bucketed" and self.dp_bucket_mb <= 0:
+            self.dp_bucket_mb = 6.0
+        if self.engine.in_library_exchange and (self.dp_exchange in ("inline", "bucketed", "sharded") or
+                                                "dp_bucket_mb" in config or "PVAE_DP_BUCKET_MB" in os.environ):
+            self.engine.comm_config(self.dp_bucket_mb if self.dp_exchange != "inline" else 0.0)
         # sharded exchange (default off): reduce-scatter -> Adam on the owned 1/N slice -> all-gather of the
         # parameters (include/pvae.h PVAE_EXCHANGE_SHARDED); every rank must choose the same
-        self.dp_sharded = bool(config.get("dp_sharded", os.environ.get("PVAE_DP_SHARDED", "0") == "1"))
-        if self.engine.has_comm:
+        self.dp_sharded = bool(config.get("dp_sharded", os.environ.get("PVAE_DP_SHARDED", "0") == "1")) or \
+            self.dp_exchange in ("sharded", "p2p")
+        if self.engine.has_comm and not self.engine.has_p2p:
             self.engine.comm_mode(self.dp_sharded)
         self.prefetch_gather = bool(config.get("prefetch_gather", os.environ.get("PVAE_PREFETCH", "1") != "0"))
         self.prepare_data(config)
@@ -264,7 +281,11 @@ class TrainModel(tune.Trainable):
             self.global_batch += 1
         if dp.collective:
             dp.all_reduce(out)
-        return out[:n_glob].cpu()                 # the single host sync of the epoch
+        host = out[:n_glob].cpu()                 # the single host sync of the epoch
+        if eng.has_p2p and eng.p2p_status()[2]:
+            raise RuntimeError("peer-mapped exchange: a rank waited for a peer that never signalled (time-out); "
+                               "parameters are no longer consistent")
+        return host
 
     def dp_step(self, phase, nets, first, rows, sp, eps, loss_out, next_span=None):
         """One data-parallel optimizer step.  The backward pass is issued launch by launch; the
@@ -280,7 +301,7 @@ class TrainModel(tune.Trainable):
         which at ~120 us per step outweighs what finer-grained overlap could hide (measured with
         one rank through RCCL: 5 collectives per step 206 us, 1 per step see DESIGN.md)."""
         eng, dp = self.engine, self.dp
-        if eng.has_comm:       # whole step inside the library (RCCL; in line, or bucketed + overlapped)
+        if eng.in_library_exchange:   # whole step inside the library (RCCL or peer-mapped; in line, or bucketed + overlapped)
             eng.dp_train_step(phase, first, rows, sp, eps=eps, loss_out=loss_out,
                               next_span=next_span if self.prefetch_gather else None)
             return

@@ -1,0 +1,209 @@
+"""The peer-mapped gradient exchange (PVAE_EXCHANGE_P2P; SURVEY.md section 8e's direct all-pairs reduce-scatter +
+all-gather) on ONE GPU: 2 and 4 processes share cuda:0, map one another's gradient / parameter arenas and flag
+blocks with hipIpcOpenMemHandle, and exchange inside kernels -- every "peer" is another process on the same
+device, which exercises the mapping, the cross-process flags, the ordering and the arithmetic (not the links).
+The reference has no counterpart (tm:131-161 is one process)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, io, contextlib, torch
+root = sys.argv[1]; out = sys.argv[2]; mode = sys.argv[4]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from physicsvae_amd import parallel, _lib
+rank, world, _ = parallel.init_from_env(backend="gloo")
+import torch.distributed as dist
+from oracle import refpath as R
+from util import make_trainer
+from physicsvae_amd.engine import make_step_params
+arch = R.make_arch(23, 7, latent=8, te=(64, 2), md=(96, 2), wm=(128, 3))
+data = R.synth_demo(0, 3, 40, 23, 7, kind="dynamics")          # 117 windows
+per_gpu = int(sys.argv[3])
+with contextlib.redirect_stdout(io.StringIO()):
+    tr = make_trainer(arch, data, per_gpu, m_world=1, device="cuda:0", eps_fn=R.eps_stream(2, 8))
+tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, 1), 3))
+eng = tr.engine
+res = {}
+if mode == "train":
+    if os.environ.get("PVAE_DP_EXCHANGE") == "p2p":
+        assert eng.has_p2p and not eng.has_comm and eng.p2p_status()[:2] == (rank, world)
+    losses = [tr.train()["mean_train_loss"] for _ in range(2)]
+    res = {"sd": {k: v.cpu() for k, v in tr.model.state_dict().items()}, "losses": losses,
+           "steps": dict(tr.optimizer.net_steps), "timeouts": eng.p2p_status()[2] if eng.has_p2p else 0}
+elif mode == "kernel":
+    # the exchange launch itself: known gradients per rank, slice owners sum in RANK ORDER, Adam, push
+    assert eng.has_p2p
+    te_off, te_cnt = eng.segments[_lib.NET_TE]
+    ok = True
+    for step in (1, 2, 3):
+        g = torch.Generator(device="cuda").manual_seed(100 * step + rank)
+        eng.grads.copy_(torch.randn(eng.grads.numel(), generator=g, device="cuda") * 1e-2)
+        torch.cuda.synchronize(); dist.barrier()
+        p0, m0, v0 = eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone()
+        mine = eng.grads.clone()
+        sp = make_step_params(lr=5e-4, adam_t=(step, step, step), global_rows=32)
+        eng.p2p_exchange(_lib.NET_TE, te_off, te_cnt, sp)
+        torch.cuda.synchronize()
+        got_p, got_m, got_v = eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone()
+        # expected: every rank's gradient (gathered over gloo), summed in rank order, flat Adam on the whole slice
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        total = parts[0].clone()
+        for q in range(1, world):
+            total += parts[q]
+        eng.params.copy_(p0); eng.exp_avg.copy_(m0); eng.exp_avg_sq.copy_(v0)
+        eng.grads.copy_(total)
+        eng.adam_segment(_lib.NET_TE, te_off, te_cnt, sp)
+        torch.cuda.synchronize()
+        sl = slice(te_off, te_off + te_cnt)
+        n4 = te_cnt // 4
+        S = (n4 + world - 1) // world
+        own = slice(te_off + 4 * rank * S, te_off + 4 * min((rank + 1) * S, n4))
+        ok = ok and torch.equal(got_p[sl], eng.params[sl])                      # all slices, whoever owned them
+        ok = ok and torch.equal(got_m[own], eng.exp_avg[own]) and torch.equal(got_v[own], eng.exp_avg_sq[own])
+        ok = ok and torch.equal(got_p[: te_off], p0[: te_off]) and torch.equal(got_p[te_off + te_cnt:], p0[te_off + te_cnt:])
+        # carry the exchanged state into the next round.  Each rank holds valid moments for ITS slice only (as the
+        # mode defines), so the expectation above needs them assembled from their owners first.
+        eng.params.copy_(got_p)
+        for dst, src in ((eng.exp_avg, got_m), (eng.exp_avg_sq, got_v)):
+            parts = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(parts, src)
+            for q in range(world):
+                oq = slice(te_off + 4 * q * S, te_off + 4 * min((q + 1) * S, n4))
+                dst[oq] = parts[q][oq]
+        torch.cuda.synchronize(); dist.barrier()
+    res = {"ok": bool(ok), "timeouts": eng.p2p_status()[2]}
+elif mode == "timeout":
+    # rank 0 enters an exchange its peer never joins: the wait gives up (PVAE_P2P_TIMEOUT_MS), no hang
+    assert eng.has_p2p
+    dist.barrier()
+    if rank == 0:
+        sp = make_step_params(lr=5e-4, global_rows=32)
+        eng.p2p_exchange(_lib.NET_TE, eng.segments[_lib.NET_TE][0], eng.segments[_lib.NET_TE][1], sp)
+    res = {"timeouts": eng.p2p_status()[2]}
+torch.save(res, out + ".%d" % rank)
+if world > 1:
+    dist.barrier()
+print("DONE", rank)
+'''
+
+
+def _run(tmp_path, world, per_gpu, tag, mode="train", port="29561", **extra_env):
+    script = tmp_path / "p2p_worker.py"
+    script.write_text(WORKER)
+    out = str(tmp_path / tag)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE=str(world),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, out, str(per_gpu), mode],
+                              env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [torch.load(out + ".%d" % r) for r in range(world)]
+
+
+def test_p2p_two_ranks_equal_the_allreduce_exchange_bit_for_bit(tmp_path):
+    """Two processes on one GPU, two epochs across the phase switch, ragged tail with an empty shard: replicas end
+    bit-identical, and equal what the all-reduce + replicated-Adam exchange produces on the same schedule (with two
+    ranks every sum is g0 + g1 whoever forms it)."""
+    p2p = _run(tmp_path, 2, 16, "p2p", PVAE_DP_EXCHANGE="p2p")
+    plain = _run(tmp_path, 2, 16, "plain", port="29562")
+    a, b = p2p
+    assert a["timeouts"] == 0 and b["timeouts"] == 0
+    for k in a["sd"]:
+        assert torch.equal(a["sd"][k], b["sd"][k]), k
+        assert torch.equal(a["sd"][k], plain[0]["sd"][k]), k
+    assert a["losses"] == plain[0]["losses"] and a["steps"] == plain[0]["steps"]
+
+
+def test_p2p_bucketed_overlapped_equals_in_line(tmp_path):
+    """The same exchange cut into per-layer buckets on the library's exchange stream (event hand-offs, several
+    exchange launches in flight per step) gives the in-line result bit for bit."""
+    inline = _run(tmp_path, 2, 16, "inline", PVAE_DP_EXCHANGE="p2p")
+    bucketed = _run(tmp_path, 2, 16, "bucketed", port="29563", PVAE_DP_EXCHANGE="p2p", PVAE_DP_BUCKET_MB="0.01")
+    assert all(r["timeouts"] == 0 for r in inline + bucketed)
+    for k in inline[0]["sd"]:
+        assert torch.equal(inline[0]["sd"][k], bucketed[0]["sd"][k]), k
+        assert torch.equal(bucketed[0]["sd"][k], bucketed[1]["sd"][k]), k
+
+
+def test_p2p_four_ranks_replicas_identical_and_match_one_process(tmp_path):
+    """Four processes on one GPU (global batch 32 = 4 x 8): replicas bit-identical; against one process with the
+    global batch the parameters agree to fp32 summation order."""
+    dp = _run(tmp_path, 4, 8, "p2p4", PVAE_DP_EXCHANGE="p2p")
+    single = _run(tmp_path, 1, 32, "single", port="29564")[0]
+    assert all(r["timeouts"] == 0 for r in dp)
+    for r in dp[1:]:
+        for k in dp[0]["sd"]:
+            assert torch.equal(dp[0]["sd"][k], r["sd"][k]), k
+    assert dp[0]["steps"] == single["steps"]
+    assert dp[0]["losses"] == pytest.approx(single["losses"], rel=1e-5)
+    for k, v in single["sd"].items():
+        if k.startswith("_value_branch"):
+            continue
+        err = float((dp[0]["sd"][k] - v).norm() / (v.norm() + 1e-30))
+        assert err < 2e-3, (k, err)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_p2p_exchange_launch_sums_in_rank_order_and_updates_every_replica(tmp_path, world):
+    """The exchange launch on known gradients: the parameters every rank ends with equal flat Adam on the rank-order
+    sum ((g0 + g1) + g2) + g3 bit for bit, over all slices (own slice computed here, the others pushed by their
+    owners), moments are updated on the own slice, nothing outside the exchanged segment moves; three rounds over
+    the same buffers (flag epochs, ticket reset, stale-cache hazards)."""
+    res = _run(tmp_path, world, 8, "k%d" % world, mode="kernel", port=str(29570 + world), PVAE_DP_EXCHANGE="p2p")
+    assert all(r["ok"] and r["timeouts"] == 0 for r in res), res
+
+
+def test_p2p_wait_for_a_missing_peer_gives_up_instead_of_hanging(tmp_path):
+    res = _run(tmp_path, 2, 8, "to", mode="timeout", port="29580", PVAE_DP_EXCHANGE="p2p", PVAE_P2P_TIMEOUT_MS="300")
+    assert res[0]["timeouts"] >= 1 and res[1]["timeouts"] == 0
+
+
+def test_p2p_calls_fail_loudly_without_setup():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import refpath as R
+    from physicsvae_amd import _lib
+    from physicsvae_amd.engine import make_step_params
+    from util import make_trainer
+    arch = R.make_arch(23, 7, latent=8, te=(64, 2), md=(96, 2), wm=(128, 3))
+    data = R.synth_demo(0, 3, 40, 23, 7, kind="dynamics")
+    tr = make_trainer(arch, data, 32, device="cuda")
+    eng = tr.engine
+    sp = make_step_params(lr=5e-4, global_rows=32)
+    with pytest.raises(RuntimeError, match="not open"):
+        eng.comm_mode("p2p")
+    with pytest.raises(RuntimeError, match="not open"):
+        eng.p2p_exchange(_lib.NET_TE, *eng.segments[_lib.NET_TE], sp)
+    assert eng.p2p_status() == (0, 0, 0)
+    blob = eng.p2p_export()                         # a single rank can open itself: the exchange is then local Adam
+    eng.p2p_open(0, 1, [blob])
+    eng.comm_mode("p2p")
+    eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
+    sd = R.perturb_biases(R.init_state_dict(arch, 1), 3)
+    eps = R.eps_stream(2, 8)(0, (32, 8))
+    for phase, world in ((_lib.PHASE_WORLD, True), (_lib.PHASE_JOINT, False)):
+        c = R.phase_coeffs(world)
+        res = []
+        for dp in (False, True):
+            tr.model.load_state_dict(sd)
+            eng.exp_avg.zero_(); eng.exp_avg_sq.zero_()
+            out = torch.zeros(5, device="cuda")
+            for t in (1, 2, 3):
+                spt = make_step_params(lr=5e-4, adam_t=(t, t, t), a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"],
+                                       s_rec=c["s_rec_coeff"], cyc=c["vae_cycle_coeff"], global_rows=32)
+                (eng.dp_train_step if dp else eng.train_step)(phase, 32 * (t - 1), 32, spt, eps=eps, loss_out=out)
+            res.append((eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(), out.clone()))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)                # one rank through the exchange launch == the fused single-GPU step
+    assert eng.p2p_status() == (0, 1, 0)
+    eng.p2p_close()
+    assert eng.p2p_status()[:2] == (0, 0)

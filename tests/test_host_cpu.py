@@ -25,11 +25,11 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     header = open(os.path.join(ROOT, "include", "pvae.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)        # drop comments
-    declared = set(re.findall(r"\b(pvae_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(pvae_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pvae_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.pvae_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_layout_queries_without_gpu():
