@@ -184,6 +184,10 @@ struct pvae_ctx {
     AdamSeg pending_adam;
     bool defer_adam = true;
     bool same_layer_pairs = true;  // PVAE_SAME_LAYER=0: wgrad_i rides with dgrad_{i-1} as before (A/B)
+    bool fold_sampler = false;     // PVAE_FOLD_SAMPLER=1: the sampler runs as the prologue of the decoder's first-layer launch
+                                   // (ProSampler).  Off by default: one launch less, but the step is not shorter -- the kernel
+                                   // trace shows 6.4-7.0 us for the merged launch against 4.4 + 4.6, and the un-profiled
+                                   // step 254.8 vs 254.5 us (profiles/r03_ab_fold_sampler.txt, docs/experiments.md)
     // peer-mapped exchange (PVAE_EXCHANGE_P2P): every rank's gradient arena, parameter arena and flag block,
     // mapped into this process with hipIpcOpenMemHandle (index = rank; [rank] = the local pointers)
     struct P2p {
@@ -290,8 +294,13 @@ __device__ inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) 
     const uint32_t n3 = (uint32_t)p0;
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
-__device__ inline float philox_normal(uint64_t seed, uint64_t offset, uint32_t row, uint32_t col) {
-    uint32_t c[4] = {(uint32_t)offset, (uint32_t)(offset >> 32), row, col};
+// One Philox call = four standard normals: the draws of columns 4g .. 4g + 3 of row `row` (counter = {offset, row,
+// g}; two Box-Muller pairs from the four 32-bit outputs).  Hardware transcendentals (v_log_f32, v_sqrt_f32,
+// v_sin_f32 / v_cos_f32, which take their argument in revolutions: cos(2 pi u) is ONE instruction): ~1 ulp, which a
+// random draw does not notice, at a tenth of the instructions of logf / cosf -- the draws are formed inside a
+// contraction launch by every workgroup that needs them (ProSampler below), so their cost is multiplied.
+__device__ inline v4f philox_normal4(uint64_t seed, uint64_t offset, uint32_t row, uint32_t group) {
+    uint32_t c[4] = {(uint32_t)offset, (uint32_t)(offset >> 32), row, group};
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
@@ -299,9 +308,19 @@ __device__ inline float philox_normal(uint64_t seed, uint64_t offset, uint32_t r
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
-    const float u1 = ((float)c[0] + 0.5f) * 2.3283064365386963e-10f;   // (0,1)
-    const float u2 = ((float)c[1] + 0.5f) * 2.3283064365386963e-10f;
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    v4f n;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)c[2 * h] + 0.5f) * 2.3283064365386963e-10f;       // (0, 1)
+        const float u2 = ((float)c[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
+        const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), log2 form
+        n[2 * h] = r * __builtin_amdgcn_cosf(u2);
+        n[2 * h + 1] = r * __builtin_amdgcn_sinf(u2);
+    }
+    return n;
+}
+__device__ inline float philox_normal(uint64_t seed, uint64_t offset, uint32_t row, uint32_t col) {
+    return philox_normal4(seed, offset, row, col >> 2)[col & 3];
 }
 
 // Reparameterisation sampler + KL-to-N(0,I) partial sums (rmt:734-740, 795-800; tpv:384-389):
@@ -322,7 +341,7 @@ reparam_kernel(const float* __restrict__ te_out, int ldte, const float* __restri
             const float mu = te_out[(size_t)r * ldte + c];
             const float lv = te_out[(size_t)r * ldte + Z + c];
             if (noise) e = eps_in ? eps_in[(size_t)r * Z + c] : philox_normal(seed, offset, r, c);
-            z = mu + e * expf(0.5f * lv);
+            z = __fmaf_rn(e, expf(0.5f * lv), mu);
             if (mu_p) {               // KL(N(mu, s^2) || N(mu_p, 1)), oracle/refpath.py PRIORS
                 const float d = mu - mu_p[(size_t)r * ldmp + c];
                 acc += 0.5f * (expf(lv) + d * d - 1.0f - lv);
@@ -337,6 +356,98 @@ reparam_kernel(const float* __restrict__ te_out, int ldte, const float* __restri
     const float s = block_sum_256(acc);
     if (threadIdx.x == 0 && partial) partial[blockIdx.x] = s;
 }
+
+// The same sampler as the PROLOGUE of the decoder's first-layer launch (pvae_gemm.h, splitk_ws_body / NoPro): every
+// workgroup of that launch forms z for its own 32 batch rows while its first k-tile is in flight and patches it over
+// the z columns of its input tile in LDS; the workgroups of column tile 0 also store z (the decoder's first-layer
+// weight gradient reads it from the input panel), the draws actually used, and the KL partial of their row block.
+// One launch less per joint step (the sampler launch was ~4.5 us of fixed cost for 8 K elements).
+struct ProSampler {
+    static constexpr bool kActive = true;
+    static constexpr int kMaxZ = 64, kScratchFloats = 8;
+    static constexpr int kPer = 32 * kMaxZ / 4 / 256;     // work items per thread at Z = kMaxZ
+    const float* te_out; int ldte;       // encoder output [mu | logvar]
+    const float* eps_in;                 // supplied draws [rows][Z], or null: Philox
+    float* eps_used;                     // [rows_pad][Z]
+    float* md_in; int ld_md;             // the decoder's input panel: z columns written by column tile 0
+    int c0, Z, rows, noise;              // z columns = [c0, c0 + Z), Z % 4 == 0
+    unsigned long long seed, offset;
+    float* partial;                      // KL partial per row block (tiles_q of them), or null
+    // work item = 4 consecutive z columns of one row (one Philox call, 16-byte accesses): item e of the workgroup is
+    // row e / (Z/4), columns 4 (e % (Z/4)) ..; thread tid owns items tid, tid + 256, ...
+    struct State { v4f mu[kPer], lv[kPer], ep[kPer], z[kPer]; bool formed; };
+    __device__ inline bool needs(int t) const { return t == (c0 >> 6) || t == ((c0 + Z - 1) >> 6); }
+    // request the inputs (the encoder's output was written through by the previous launch: cold fetches, which now
+    // travel while the k-tiles in front of the z columns are contracted)
+    __device__ inline State prepare(int q0, int tid) const {
+        State st;
+        const int G = Z >> 2;
+        const float* __restrict__ te = te_out;
+        const float* __restrict__ ei = eps_in;
+        const v4f zero = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int e = tid + 256 * u;
+            const int r = e / G, j = (e - r * G) * 4, q = q0 + r;
+            const bool live = e < 32 * G && q < rows;
+            st.mu[u] = live ? *reinterpret_cast<const v4f*>(te + (size_t)q * ldte + j) : zero;
+            st.lv[u] = live ? *reinterpret_cast<const v4f*>(te + (size_t)q * ldte + Z + j) : zero;
+            st.ep[u] = (live && noise && ei) ? *reinterpret_cast<const v4f*>(ei + (size_t)q * Z + j) : zero;
+            st.z[u] = zero;
+        }
+        st.formed = false;
+        return st;
+    }
+    // tile = the swizzled [32][64] image of k-tile t (chunk ^= row & 15, as the loaders write it)
+    __device__ inline void patch(float* tile, float* scratch, State& st, int t, int q0, int tile_p, int, int tid) const {
+        const int G = Z >> 2;
+        if (!st.formed) {                 // first patched tile: form z, KL partial, and (column tile 0) store z and the draws
+            float acc = 0.f;
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int e = tid + 256 * u;
+                if (e >= 32 * G) break;
+                const int r = e / G, j = (e - r * G) * 4, q = q0 + r;
+                v4f ee = v4f{0.f, 0.f, 0.f, 0.f};
+                if (q < rows) {
+                    if (noise) ee = eps_in ? st.ep[u] : philox_normal4(seed, offset, q, j >> 2);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        st.z[u][x] = __fmaf_rn(ee[x], expf(0.5f * st.lv[u][x]), st.mu[u][x]);
+                        acc += -0.5f * (1.0f + st.lv[u][x] - st.mu[u][x] * st.mu[u][x] - expf(st.lv[u][x]));
+                    }
+                }
+                if (tile_p == 0) {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) md_in[(size_t)q * ld_md + c0 + j + x] = st.z[u][x];      // (c0 = dim_body: unaligned)
+                    *reinterpret_cast<v4f*>(eps_used + (size_t)q * Z + j) = ee;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+            if ((tid & 63) == 0) scratch[tid >> 6] = acc;
+            st.formed = true;
+        }
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int e = tid + 256 * u;
+            if (e >= 32 * G) break;
+            const int r = e / G, j = (e - r * G) * 4;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int c = c0 + j + x;
+                if ((c >> 6) != t) continue;
+                const int kc = c & 63;
+                tile[r * 64 + ((((kc >> 2) ^ (r & 15))) << 2) + (kc & 3)] = st.z[u][x];
+            }
+        }
+    }
+    // behind the barrier that follows the first patch: the four compute waves' KL sums are in the scratch
+    __device__ inline void publish(const float* scratch, int t, int tile_p, int tile_q, int tid) const {
+        if (t == (c0 >> 6) && tile_p == 0 && tid == 0 && partial)
+            partial[tile_q] = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    }
+};
 
 // Backward of the sampler + KL (autograd of rmt:734-740 and tpv:388):
 //   dmu = dz + (beta/B) mu ;  dlogvar = dz * eps * 0.5 exp(0.5 lv) + (beta/B) 0.5 (exp(lv) - 1)
@@ -840,6 +951,7 @@ struct FwdTail {              // what the output layer's epilogue does besides b
     const EpiMse* mse = nullptr;      // fused MSE loss + gradient
     float* out2 = nullptr;            // or: copy the first n2 output columns to out2[:, off2:]
     int ld2 = 0, off2 = 0, n2 = 0;
+    const ProSampler* pro0 = nullptr; // layer 0 forms the sampler's z columns of its input itself (decoder, joint step)
 };
 
 // `row0`: first row of the time-step block to run on (0 unless lookahead > 1)
@@ -871,7 +983,10 @@ static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st, const F
             EpiBiasAct e{out, l.n_out_pad, c->params + l.b_off, l.last ? 0 : c->L.cfg.act_kind + 1};
             e.n_valid = l.n_out;
             if (l.last && tail.out2) { e.out2 = tail.out2; e.ld2 = tail.ld2; e.off2 = tail.off2; e.n2 = tail.n2; }
-            HIP_TRY(gemm_forward_epi(x, ldx, c->params + l.w_off, l.ld, rows_pad, l.n_out_pad, l.ld, e, st));
+            if (l.index == 0 && tail.pro0)
+                HIP_TRY(gemm_forward_pro(x, ldx, c->params + l.w_off, l.ld, rows_pad, l.n_out_pad, l.ld, e, *tail.pro0, st));
+            else
+                HIP_TRY(gemm_forward_epi(x, ldx, c->params + l.w_off, l.ld, rows_pad, l.n_out_pad, l.ld, e, st));
         }
         g_prof.end(ps, st);
         x = out;
@@ -1280,6 +1395,8 @@ int pvae_create(const pvae_config* cfg, pvae_ctx** out) {
     c->defer_adam = !(da && da[0] == '0');
     const char* sl = getenv("PVAE_SAME_LAYER");
     c->same_layer_pairs = !(sl && sl[0] == '0');
+    const char* fs = getenv("PVAE_FOLD_SAMPLER");
+    c->fold_sampler = fs && fs[0] == '1';
     *out = c;
     return 0;
 }
@@ -1427,7 +1544,18 @@ static int launch_sampler(pvae_ctx* c, const float* te_out, int ldte, const floa
 }
 
 // Everything a step needs that is a pure function of (phase, rows, step params).
+// The sampler runs as the prologue of the decoder's first-layer launch (ProSampler) when that launch is the 32x32-tile
+// kernel and the prior is the reference's default: joint training steps at lookahead 1, more than 4 rows.
+static bool sampler_folds(const pvae_ctx* c, int rows) {
+    const NetLayout& MD = c->L.net[PVAE_NET_MD];
+    return c->fold_sampler && c->pair_launch && c->W.L == 1 && c->L.cfg.prior_kind == PVAE_PRIOR_ZERO_MEAN &&
+           c->L.net[PVAE_NET_PR].layers.empty() && c->L.cfg.latent <= ProSampler::kMaxZ && c->L.cfg.latent % 4 == 0 &&
+           rows > 4 &&
+           MD.layers.size() > 1 && forward_pro_ok(pad32(rows), MD.layers[0].n_out_pad);
+}
+
 struct StepShape {
+    bool fold_sampler;
     int rows_pad, wm_tiles, gridz, nparts_a;
     bool seed_action, seed_sampler;   // stack hand-overs fused into input-gradient epilogues (plan_backward)
     int l1;                    // loss_kind of the three reconstruction terms
@@ -1450,6 +1578,8 @@ static int step_shape(pvae_ctx* c, int phase, int rows, const pvae_step_params* 
         return fail(-1, "batch x dim_body x lookahead too large for the loss partial buffer");
     S.Bg *= (float)T;                          // every term is the mean over the L steps (tpv:423-428)
     S.gridz = sampler_grid(c, S.rows_pad);
+    S.fold_sampler = phase == PVAE_PHASE_JOINT && sampler_folds(c, rows);
+    if (S.fold_sampler) S.gridz = S.rows_pad / 32;          // one KL partial per row block
     (void)Z;
     S.nparts_a = S.rows_pad < 64 ? S.rows_pad : 64;
     S.cyc_grad = backward && phase == PVAE_PHASE_JOINT && sp->cycle_coeff > 0.0f;
@@ -1542,15 +1672,25 @@ static int run_forward(pvae_ctx* c, int phase, int rows, const pvae_step_params*
     // joint forward: [prior mean ->] TE -> sampler -> MD -> WM (rmt:742-771, 801-809)
     if (learned_prior && (rc = forward_net(c, PVAE_NET_PR, S.rows_pad, st))) return rc;
     if ((rc = forward_net(c, PVAE_NET_TE, S.rows_pad, st))) return rc;
-    if ((rc = launch_sampler(c, w + wte.act.back(), TE.layers.back().n_out_pad, eps, w + c->W.eps, w + wmd.in,
-                             MD.layers[0].ld, rows, S.rows_pad, 1, (unsigned long long)sp->rng_seed,
-                             (unsigned long long)sp->rng_offset, part + 2 * kLossParts, (float*)nullptr,
-                             learned_prior ? w + wpr.act.back() : (const float*)nullptr,
-                             learned_prior ? PR.layers.back().n_out_pad : 0, st)))
+    ProSampler pro;
+    memset(&pro, 0, sizeof(pro));
+    if (S.fold_sampler) {                      // the sampler rides in the decoder's first-layer launch
+        pro.te_out = w + wte.act.back(); pro.ldte = TE.layers.back().n_out_pad;
+        pro.eps_in = eps; pro.eps_used = w + c->W.eps;
+        pro.md_in = w + wmd.in; pro.ld_md = MD.layers[0].ld;
+        pro.c0 = Db; pro.Z = Z; pro.rows = rows; pro.noise = 1;
+        pro.seed = (unsigned long long)sp->rng_seed; pro.offset = (unsigned long long)sp->rng_offset;
+        pro.partial = part + 2 * kLossParts;
+    } else if ((rc = launch_sampler(c, w + wte.act.back(), TE.layers.back().n_out_pad, eps, w + c->W.eps, w + wmd.in,
+                                    MD.layers[0].ld, rows, S.rows_pad, 1, (unsigned long long)sp->rng_seed,
+                                    (unsigned long long)sp->rng_offset, part + 2 * kLossParts, (float*)nullptr,
+                                    learned_prior ? w + wpr.act.back() : (const float*)nullptr,
+                                    learned_prior ? PR.layers.back().n_out_pad : 0, st))) {
         return rc;
-    (void)Z;
+    }
     FwdTail md_tail;                           // a_hat also lands in the action columns of the WM input
     md_tail.out2 = w + wwm.in; md_tail.ld2 = WM.layers[0].ld; md_tail.off2 = Db; md_tail.n2 = Da;
+    if (S.fold_sampler) md_tail.pro0 = &pro;
     if ((rc = forward_net(c, PVAE_NET_MD, S.rows_pad, st, md_tail))) return rc;
     // cycle loss (tpv:417-419) fused into the world model's output layer
     mse.grad_scale = sp->cycle_coeff * S.gs / (S.Bg * Db);

@@ -236,6 +236,27 @@ __device__ inline int k_rotation(const GemmArgs& ga, int loc, int tile_q, int nk
 }
 constexpr int kRegRingFloats = 2 * 2 * 32 * 64;      // 2 LDS slots x (Q tile + P tile) = 32 KB
 
+// Split-K partial tile of a wave -> its LDS reduction buffer red[32][RS], with 16-byte writes: the MFMA layout gives
+// each lane runs of consecutive p (P_ROW: acc[a][b] = 4 consecutive p of row 16a + li; output-contiguous operands:
+// for one a the eight values acc[a][0..1][0..3] are columns 8 lh .. 8 lh + 7).  RS = 36: the eight lanes of a
+// ds_write_b128 group (li = 0..7) land on rows 36 dwords apart = all 32 banks once; the scalar writes this replaces
+// hit 4-8 lanes per bank (PMC: 12-15 % of LDS cycles in the narrow launches of round 2).
+template <bool P_ROW>
+__device__ inline void store_partial_32x32(float* red, const v4f (&acc)[2][2], int li, int lh) {
+    constexpr int RS = 36;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        float* row = red + (16 * a + li) * RS;
+        if (P_ROW) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) *reinterpret_cast<v4f*>(row + 16 * b + 4 * lh) = acc[a][b];
+        } else {
+            *reinterpret_cast<v4f*>(row + 8 * lh) = v4f{acc[a][0][0], acc[a][1][0], acc[a][0][1], acc[a][1][1]};
+            *reinterpret_cast<v4f*>(row + 8 * lh + 4) = v4f{acc[a][0][2], acc[a][1][2], acc[a][0][3], acc[a][1][3]};
+        }
+    }
+}
+
 template <bool P_ROW, class Epi, int ABL = 0>
 __device__ inline void splitk_reg_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
     constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, D = PVAE_REG_DEPTH_D, S = 2;
@@ -373,17 +394,7 @@ __device__ inline void splitk_reg_body(float* lds, int bid, const GemmArgs& ga, 
         if (t0 + d < nk) tile_step(t0 + d, d, true);
 
     constexpr int RS = 36;
-    float* red = lds + wave * (32 * RS);
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ql = 16 * a + li;
-                const int pl = P_ROW ? (16 * b + 4 * lh + r) : (8 * lh + 2 * r + b);
-                red[ql * RS + pl] = acc[a][b][r];
-            }
+    store_partial_32x32<P_ROW>(lds + wave * (32 * RS), acc, li, lh);
     __syncthreads();
     {
         const int ql = tid >> 3, pl = (tid & 7) << 2;
@@ -437,8 +448,26 @@ __device__ inline void wait_dma_tile(int younger) {
     }
 }
 
-template <bool P_ROW, class Epi>
-__device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
+// Prologue hook of the wave-specialised kernel: a launch can OWN some columns of its Q operand -- form them itself
+// instead of reading what a separate launch stored.  The compute waves `prepare` (request the inputs of those
+// values for the workgroup's 32 rows: the loads travel while the first k-tiles are contracted) and `patch` the
+// values over the tile image of every k-tile that holds such columns, right after that tile has landed and before
+// its fragments are read (one extra workgroup barrier per patched tile; whatever the DMA brought for those columns
+// is overwritten); `publish` runs behind that barrier.  NoPro: nothing of this exists in the instantiation.  The one user is the decoder's first layer, whose input [s1 | z] carries the
+// sampler's z = mu + eps exp(logvar / 2) (ProSampler in pvae.hip: the sampler launch disappears).
+struct NoPro {
+    static constexpr bool kActive = false;
+    static constexpr int kScratchFloats = 4;
+    struct State {};
+    __device__ inline bool needs(int) const { return false; }
+    __device__ inline State prepare(int, int) const { return State(); }
+    __device__ inline void patch(float*, float*, State&, int, int, int, int, int) const {}
+    __device__ inline void publish(const float*, int, int, int, int) const {}
+};
+
+template <bool P_ROW, class Epi, class Pro = NoPro>
+__device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, Epi& epi, const Pro& pro = Pro(),
+                                      float* scratch = nullptr) {
     constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, S = kWsStages;
     static_assert(S == 4, "wait_dma_tile is written for a 4-slot ring");
     const float* __restrict__ Q = ga.Q;
@@ -537,6 +566,9 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
         PVAE_MARK(256, 5);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if constexpr (Pro::kActive) {
+            if (pro.needs(0)) __builtin_amdgcn_s_barrier();        // (the compute waves patch tile 0 in between)
+        }
 #pragma unroll
         for (int t = 2; t < S - 1; ++t)
             if (t < nk) issue(t);
@@ -549,6 +581,9 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
             wait_dma_tile(y);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if constexpr (Pro::kActive) {
+                if (t + 1 < nk && pro.needs(t + 1)) __builtin_amdgcn_s_barrier();
+            }
             if (t + S - 1 < nk) issue(t + S - 1);                  // refill the slot tile t-1 vacated
         }
     } else {
@@ -564,6 +599,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
         wait_vmcnt<0>();                                           // this wave's share of tile 0 landed
 #endif
         epre = epi.preload(q0 + (tid >> 3), p0 + ((tid & 7) << 2));   // epilogue operands: arrive under the loop
+        typename Pro::State pst = pro.prepare(q0, tid);
         struct Frag { v4f q[2], p[2]; v2f c[4]; };
         auto fread = [&](const float* st, Frag& f) {
 #pragma unroll
@@ -595,6 +631,14 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
         __builtin_amdgcn_s_barrier();                              // tile 0 landed
         asm volatile("" ::: "memory");
         PVAE_MARK(0, 1);
+        if constexpr (Pro::kActive) {
+            if (pro.needs(0)) {
+                pro.patch(lds, scratch, pst, 0, q0, tile_p, tile_q, tid);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                pro.publish(scratch, 0, tile_p, tile_q, tid);
+            }
+        }
         Frag F0, F1;
         fread(lds, F0);
         for (int t0 = 0; t0 < nk; t0 += 2) {
@@ -606,6 +650,14 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
                     Frag& Gf = d ? F0 : F1;
                     __builtin_amdgcn_s_barrier();                  // tile t+1 landed; tile t-1's slot is free
                     asm volatile("" ::: "memory");
+                    if constexpr (Pro::kActive) {
+                        if (t + 1 < nk && pro.needs(t + 1)) {
+                            pro.patch(lds + ((t + 1) % S) * kStage, scratch, pst, t + 1, q0, tile_p, tile_q, tid);
+                            __builtin_amdgcn_s_barrier();
+                            asm volatile("" ::: "memory");
+                            pro.publish(scratch, t + 1, tile_p, tile_q, tid);
+                        }
+                    }
                     fread(lds + ((t + 1) % S) * kStage, Gf);       // (past the end: stale slot, never used)
                     __builtin_amdgcn_sched_barrier(0);
                     mfmas(F);
@@ -618,19 +670,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
     PVAE_MARK(0, 2);                                             // main loop done (compute wave 0)
     __syncthreads();
     constexpr int RS = 36;
-    if (wave < 4) {
-        float* red = lds + wave * (32 * RS);
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ql = 16 * a + li;
-                    const int pl = P_ROW ? (16 * b + 4 * lh + r) : (8 * lh + 2 * r + b);
-                    red[ql * RS + pl] = acc[a][b][r];
-                }
-    }
+    if (wave < 4) store_partial_32x32<P_ROW>(lds + wave * (32 * RS), acc, li, lh);
     __syncthreads();
     if (wave < 4) {
         const int ql = tid >> 3, pl = (tid & 7) << 2;
@@ -785,15 +825,16 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
     if (wave < 4) {
         float* red = lds + wave * (64 * RS);
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a) {
+            float* row = red + (16 * a + li) * RS;           // (16-byte writes: see store_partial_32x32)
+            if (P_ROW) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ql = 16 * a + li;
-                    const int pl = P_ROW ? (16 * b + 4 * lh + r) : (8 * lh + 2 * r + b);
-                    red[ql * RS + pl] = acc[a][b][r];
-                }
+                for (int b = 0; b < 2; ++b) *reinterpret_cast<v4f*>(row + 16 * b + 4 * lh) = acc[a][b];
+            } else {
+                *reinterpret_cast<v4f*>(row + 8 * lh) = v4f{acc[a][0][0], acc[a][1][0], acc[a][0][1], acc[a][1][1]};
+                *reinterpret_cast<v4f*>(row + 8 * lh + 4) = v4f{acc[a][0][2], acc[a][1][2], acc[a][0][3], acc[a][1][3]};
+            }
+        }
     }
     __syncthreads();
     if (wave < 4) {
@@ -821,6 +862,13 @@ __global__ void __launch_bounds__(kWsThreads)
 gemm_splitk_ws_kernel(GemmArgs ga, Epi epi) {
     __shared__ __attribute__((aligned(16))) float lds[kWsFloats];
     splitk_ws_body<P_ROW, Epi>(lds, blockIdx.x, ga, epi);
+}
+template <class Epi, class Pro>
+__global__ void __launch_bounds__(kWsThreads)
+gemm_splitk_ws_pro_kernel(GemmArgs ga, Epi epi, Pro pro) {
+    __shared__ __attribute__((aligned(16))) float lds[kWsFloats];
+    __shared__ __attribute__((aligned(16))) float scratch[Pro::kScratchFloats];
+    splitk_ws_body<true, Epi, Pro>(lds, blockIdx.x, ga, epi, pro, scratch);
 }
 
 // ---- forward, 16x16 tile per workgroup (narrow output layers) ----------------------------------
@@ -857,6 +905,11 @@ __device__ inline void splitk_reg16_body(float* lds, int bid, const GemmArgs& ga
                             : P + (size_t)(tid >> 2) * ldp + p0 + (tid & 3) * 4;      // k = tid/4, 4 chunks per row
     const size_t kstep_p = P_ROW ? (size_t)BK : (size_t)BK * ldp;
     const int slot_off = tid * 4;
+    // input-gradient form: P image rows k are kept at row k ^ ((k >> 2) & 1).  A fragment read touches rows
+    // 4 lh + s2 (16 dwords each): rows 4 apart would otherwise fall on the same 16 banks for both halves of a
+    // 32-lane read group (2-way conflict on every k-step: 15 % of the LDS cycles of the sampler-seed launch)
+    const int pk = tid >> 2;
+    const int slot_off_p = P_ROW ? slot_off : ((pk ^ ((pk >> 2) & 1)) * 16 + (tid & 3) * 4);
 
     v4f rg[D][2];
     auto gload = [&](int t, v4f(&r)[2]) {
@@ -865,7 +918,7 @@ __device__ inline void splitk_reg16_body(float* lds, int bid, const GemmArgs& ga
     };
     auto lwrite = [&](float* slot, const v4f(&r)[2]) {
         *reinterpret_cast<v4f*>(slot + slot_off) = r[0];
-        *reinterpret_cast<v4f*>(slot + kTile + slot_off) = r[1];
+        *reinterpret_cast<v4f*>(slot + kTile + slot_off_p) = r[1];
     };
     v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
     const int of = li * 64 + (((4 * wave + lh) ^ li) << 2);
@@ -887,7 +940,7 @@ __device__ inline void splitk_reg16_body(float* lds, int bid, const GemmArgs& ga
             fp = *reinterpret_cast<const v4f*>(st + kTile + of);
         } else {
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) fp[s2] = st[kTile + (16 * wave + 4 * lh + s2) * 16 + li];
+            for (int s2 = 0; s2 < 4; ++s2) fp[s2] = st[kTile + ((16 * wave + 4 * lh + s2) ^ (lh & 1)) * 16 + li];
         }
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
@@ -918,8 +971,7 @@ __device__ inline void splitk_reg16_body(float* lds, int bid, const GemmArgs& ga
     constexpr int RS = 20;
     float* red = lds + wave * (16 * RS);
     const v4f mine = acc[0] + acc[1];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[li * RS + 4 * lh + r] = mine[r];
+    *reinterpret_cast<v4f*>(red + li * RS + 4 * lh) = mine;
     __syncthreads();
     if (tid < 64) {
         const int ql = tid >> 2, pl = (tid & 3) << 2;
@@ -1223,20 +1275,23 @@ __device__ inline void wgrad32_body(float* lds, int bid, const GemmArgs& ga, Epi
         if (t0 + d < nk) tile_step(t0 + d, d, true);
 
     // split-K reduction over the four waves (fixed order), epilogue on float4s by all 256 threads
+    // (lane (li, lh) holds, for a = 0, 1, the eight columns 8 lh .. 8 lh + 7 of output row 2 li + a.  Row 2 li + a is
+    //  kept at LDS row 16 a + li, so that the eight lanes of a 16-byte write group are 36 dwords apart: every bank once)
     constexpr int RS = 36;
     float* red = lds + wave * (32 * RS);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[(2 * li + a) * RS + 8 * lh + 2 * r + b] = acc[a][b][r];
+    for (int a = 0; a < 2; ++a) {
+        float* row = red + (16 * a + li) * RS;
+        *reinterpret_cast<v4f*>(row + 8 * lh) = v4f{acc[a][0][0], acc[a][1][0], acc[a][0][1], acc[a][1][1]};
+        *reinterpret_cast<v4f*>(row + 8 * lh + 4) = v4f{acc[a][0][2], acc[a][1][2], acc[a][0][3], acc[a][1][3]};
+    }
     __syncthreads();
     {
         const int ql = tid >> 3, pl = (tid & 7) << 2;
-        v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
+        const int qr = 16 * (ql & 1) + (ql >> 1);                   // LDS row of output row ql
+        v4f v = *reinterpret_cast<const v4f*>(lds + qr * RS + pl);
 #pragma unroll
-        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (32 * RS) + ql * RS + pl);
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (32 * RS) + qr * RS + pl);
         epi.apply(q0 + ql, p0 + pl, v, pre);
     }
     if (epi.loss.out && bid == 0 && wave == 3) finalize_loss_wave(epi.loss, lane);
@@ -1791,6 +1846,16 @@ inline hipError_t gemm_forward_epi(const float* X, int ldx, const float* W, int 
     const GemmGrid g = make_grid(M, N, 32, 32);
     PVAE_LAUNCH((gemm_splitk_ws_kernel<true, Epi>), dim3(g.grid), dim3(kWsThreads), st,
                        GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+    return hipGetLastError();
+}
+// forward layer on 32x32 tiles whose launch forms some of its own input columns (Pro, see splitk_ws_body)
+inline bool forward_pro_ok(int M, int N) { return !forward_uses_16x16(M, N) && !uses_64x32(M, N) && !g_krot && !g_rowxcd; }
+template <class Epi, class Pro>
+inline hipError_t gemm_forward_pro(const float* X, int ldx, const float* W, int ldw, int M, int N, int K, const Epi& e,
+                                   const Pro& pro, hipStream_t st) {
+    const GemmGrid g = make_grid(M, N, 32, 32);
+    PVAE_LAUNCH((gemm_splitk_ws_pro_kernel<Epi, Pro>), dim3(g.grid), dim3(kWsThreads), st,
+                GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e, pro);
     return hipGetLastError();
 }
 inline hipError_t gemm_forward(const float* X, int ldx, const float* W, int ldw, const float* bias,
