@@ -92,6 +92,7 @@ def parse_args(argv=None):
                     help="N > 1: how the gradient is exchanged (the trainer's dp_exchange): RCCL all-reduce in line / in 6 MiB "
                          "overlapped buckets / RCCL reduce-scatter + sharded Adam + all-gather / the direct all-pairs exchange "
                          "over peer-mapped arenas (no RCCL); default: the library's own schedule")
+    ap.add_argument("--no-sweep", action="store_true", help="N > 1: skip the back-to-back comparison of all exchange forms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary-phase, roofline and rocprofv3 passes")
     ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 child runs (kernel trace + PMC)")
@@ -555,15 +556,60 @@ def main():
                                           "gather of the next minibatch rides in the trailing launch" % (gbytes / 1e6)}
         eng.invalidate_staging()
 
-    if dp.collective and eng.in_library_exchange and not a.no_extra:
-        # What the exchange ADDS to the step: the same data-parallel step with the exchange switched off (every rank
-        # applies Adam to its own gradient -- replicas diverge, so this is the LAST thing the benchmark times).
+    if dp.collective and not a.no_extra and not a.no_sweep:
+        # Every exchange form this build has, timed back to back in THIS run (one region each), so that one multi-GPU
+        # lease yields the whole comparison: RCCL all-reduce in line / bucketed + overlapped / RCCL reduce-scatter +
+        # sharded Adam + all-gather / the peer-mapped all-pairs exchange, and the step with the exchange switched off
+        # ("local": every rank applies Adam to its own gradient -- what an exchange ADDS is the difference to it).
+        # The modes are switched at run time; "local" lets the replicas diverge, so it is timed last.  `value` above
+        # is untouched by this block.
+        sweep = {}
         if eng.has_p2p:
             out["p2p_timeouts"] = eng.p2p_status()[2]
-        eng.comm_mode("local")
-        _, ms_local, _, _ = timed(a.phase, MIN_TIMED_STEPS, max(a.warmup // 2, 5), 1)
-        out["step_without_exchange_us"] = ms_local * 1e3
-        out["exchange_exposed_us_per_step"] = (ms_per_step - ms_local) * 1e3
+
+        def one(mode):
+            entry = {}
+            try:
+                if mode == "p2p":
+                    if not dp.attach_p2p(eng):                     # collective: every rank agrees on the outcome
+                        return {"skipped": "peer-mapped exchange could not be set up (see stderr)"}
+                elif mode == "local":
+                    if not eng.in_library_exchange:
+                        return {"skipped": "no in-library exchange"}
+                    eng.comm_mode("local")
+                else:
+                    if not eng.has_comm:
+                        return {"skipped": "no RCCL communicator (ranks share a GPU over gloo)"}
+                    eng.comm_mode("sharded" if mode == "sharded" else "allreduce")
+                    eng.comm_config(6.0 if mode == "bucketed" else 0.0)
+                phase, nets = set_phase(a.phase)
+                run_steps(phase, nets, 10, 0)
+                lib.pvae_profile_enable(1)                         # HIP events around every collective / exchange launch
+                run_steps(phase, nets, 40, 10)
+                torch.cuda.synchronize()
+                lib.pvae_profile_enable(0)
+                coll = read_cats().get(4)
+                v, ms, _, _ = timed(a.phase, MIN_TIMED_STEPS, 5, 1)
+                entry = {"value": v, "ms_per_step": ms}
+                if coll:
+                    entry["exchange_launches_per_step"] = coll["launches"] / 40
+                    entry["us_per_step_inside_exchange_launches"] = coll["total_ms"] / 40 * 1e3
+                if mode == "p2p":
+                    entry["p2p_ranks"], entry["timeouts"] = eng.p2p_status()[1:]
+            except Exception as exc:                               # noqa: BLE001  (a rank-local failure: say so, go on)
+                entry = {"error": str(exc)[:300]}
+            return entry
+
+        for mode in ("inline", "bucketed", "sharded", "p2p", "local"):
+            sweep[mode] = one(mode)
+        base = sweep["local"].get("ms_per_step")
+        for mode, e in sweep.items():
+            if base and mode != "local" and "ms_per_step" in e:
+                e["exchange_exposed_us_per_step"] = (e["ms_per_step"] - base) * 1e3
+        out["exchange_sweep"] = sweep
+        if base:
+            out["step_without_exchange_us"] = base * 1e3
+            out["exchange_exposed_us_per_step"] = (ms_per_step - base) * 1e3
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, sd, Db, Da, Z, W, D, a.phase, synth_demo)
     if dist.is_initialized():

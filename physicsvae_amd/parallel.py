@@ -98,6 +98,7 @@ class DataParallel:
         if not self.collective or engine.ctx is None:
             return False
         if engine.has_p2p:
+            engine.comm_mode("p2p")
             return True
         blob, err = None, None
         try:
