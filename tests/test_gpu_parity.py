@@ -115,8 +115,8 @@ def test_single_batch_matches_oracle_and_golden(golden, name, world):
                                    rtol=5e-3, atol=1e-7)
     # (2) tight comparison against the oracle on the samples that are not on a ReLU kink
     margin = R.relu_kink_margin(arch, sd, x, y, eps, world)
-    keep = margin > 4e-6          # fp32 rounding of a K<=1024 dot product of O(1) terms is ~1e-6
-    assert int(keep.sum()) >= rows - max(4, rows // 4), "too many samples on a ReLU kink: %d" % int((~keep).sum())
+    keep = margin > 1e-6          # fp32 rounding of a K<=1024 dot product of O(1) terms is ~1e-7 (worst few e-7)
+    assert int(keep.sum()) >= rows - max(1, rows // 50), "too many samples on a ReLU kink: %d" % int((~keep).sum())   # <= 2 %
     x, y, eps = x[keep], y[keep], eps[keep]
     rows = x.shape[0]
     want = R.loss_and_grads(arch, sd, x, y, eps, world)
@@ -152,6 +152,42 @@ def test_single_batch_matches_oracle_and_golden(golden, name, world):
     assert torch.isfinite(seg).all()
     real = sum(gv[k].abs().double().sum().item() for k in want["grads"])
     assert seg.abs().double().sum().item() == pytest.approx(real, rel=1e-9)
+
+
+@pytest.mark.parametrize("name", ["single_tiny_clear", "single_c1_clear", "single_default_clear", "single_c2_clear"])
+@pytest.mark.parametrize("world", [True, False])
+def test_single_batch_matches_the_reference_capture_tightly(golden, name, world):
+    """The HIP path DIRECTLY against captures of the reference's compute_loss + backward (tpv:361-435), no oracle
+    in between, at the tolerances of the oracle comparison: loss 1e-5, internals 2e-5, every gradient tensor's
+    digest (sum, abs-sum, L2, 16 fixed entries) 1e-4.  The captured minibatches hold only rows off every ReLU
+    kink (oracle/gen_golden.py case_single_clear, margin 1e-5), so nothing is filtered here -- all `batch` rows
+    of the capture are compared; at 4x1024 that is a full 256-row minibatch."""
+    from test_oracle_golden import clear_batch, digest_close
+    g = golden(name)
+    arch, data, x, y, eps, sd = clear_batch(g)
+    rows = x.shape[0]
+    tr = make_trainer(arch, data, rows, device=DEV)
+    tr.model.load_state_dict(sd)
+    eng = tr.engine
+    tag = "world" if world else "joint"
+    c = R.phase_coeffs(world)
+    sp = make_step_params(lr=5e-4, a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"], s_rec=c["s_rec_coeff"],
+                          cyc=c["vae_cycle_coeff"], global_rows=rows)
+    eng.set_batch(x, y)
+    eng.grads.fill_(float("nan"))
+    loss = eng.forward_backward(_lib.PHASE_WORLD if world else _lib.PHASE_JOINT, rows, sp, eps=None if world else eps,
+                                fused_adam=False).cpu()
+    assert float(loss[0]) == pytest.approx(float(g[tag + "_total"]), rel=1e-5)
+    if not world:
+        for ours, theirs in (("mu", "mu"), ("logvar", "logvar"), ("z", "z"), ("s2_hat", "future_state")):
+            digest_close(R.tensor_digest(eng.read(ours, rows).cpu()), g["%s_%s_digest" % (tag, theirs)],
+                         float(g["%s_%s_max" % (tag, theirs)]), 2e-5)
+    gv = eng.named_views(eng.grads)
+    for k in g[tag + "_grad_keys"]:
+        k = str(k)
+        ours = gv[k].cpu()
+        assert torch.isfinite(ours).all(), k
+        digest_close(R.tensor_digest(ours), g["%s_graddigest::%s" % (tag, k)], float(g["%s_gradmax::%s" % (tag, k)]), 1e-4)
 
 
 @pytest.mark.parametrize("world", [True, False])

@@ -120,6 +120,53 @@ def test_single_batch_losses_and_grads_match_reference(golden, name):
     np.testing.assert_array_equal(g["joint_total_vb_perturbed"], g["joint_total"])
 
 
+CLEAR = ["single_tiny_clear", "single_c1_clear", "single_default_clear", "single_c2_clear"]
+
+
+def clear_batch(g):
+    """Inputs of a `*_clear` fixture: the demo's windows `rows_idx` (all off the ReLU kinks, oracle/gen_golden.py
+    case_single_clear) with the draws of those rows."""
+    arch = arch_from_meta(g)
+    n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
+    data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="iid")
+    X, Y = R.build_windows(data)
+    idx = torch.from_numpy(g["rows_idx"])
+    assert len(X) == int(g["n_windows"]) and idx.numel() == batch
+    x = torch.from_numpy(np.asarray(X)).float()[idx]
+    y = torch.from_numpy(np.asarray(Y)).float()[idx]
+    eps = R.eps_stream(2, arch["Z"])(0, (len(X), arch["Z"]))[idx]
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    return arch, data, x, y, eps, sd
+
+
+def digest_close(got, ref, vmax, tol):
+    """A tensor's fingerprint [sum, abs-sum, L2, 16 samples] against the captured one: abs-sum and L2 relative, the
+    (cancelling) sum against abs-sum, the samples against the tensor's largest magnitude."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert abs(got[1] - ref[1]) <= tol * ref[1] + 1e-30 and abs(got[2] - ref[2]) <= tol * ref[2] + 1e-30, (got[:3], ref[:3])
+    assert abs(got[0] - ref[0]) <= tol * ref[1] + 1e-30, (got[0], ref[0], ref[1])
+    assert np.abs(got[3:] - ref[3:]).max() <= tol * vmax + 1e-30, (np.abs(got[3:] - ref[3:]).max(), vmax)
+
+
+@pytest.mark.parametrize("name", CLEAR)
+def test_kink_free_batches_match_reference(golden, name):
+    """The minibatches the HIP gradients are held to tightly (tests/test_gpu_parity.py): rows off every ReLU kink, so
+    any two fp32 implementations agree to summation noise.  The restatement reproduces the reference's losses,
+    internals and every gradient tensor's digest; the recorded rows really clear the margin."""
+    g = golden(name)
+    arch, data, x, y, eps, sd = clear_batch(g)
+    for world in (True, False):
+        tag = "world" if world else "joint"
+        assert float(R.relu_kink_margin(arch, sd, x, y, eps, world).min()) > float(g["margin"])
+        out = R.loss_and_grads(arch, sd, x, y, eps, world)
+        np.testing.assert_allclose(out["total"].numpy(), g[tag + "_total"], rtol=1e-6)
+        for k in ("mu", "logvar", "z", "future_state"):
+            digest_close(R.tensor_digest(out[k]), g["%s_%s_digest" % (tag, k)], float(g["%s_%s_max" % (tag, k)]), 2e-6)
+        assert list(out["grads"].keys()) == list(g[tag + "_grad_keys"])
+        for k, gr in out["grads"].items():
+            digest_close(R.tensor_digest(gr), g["%s_graddigest::%s" % (tag, k)], float(g["%s_gradmax::%s" % (tag, k)]), 2e-5)
+
+
 @pytest.mark.parametrize("name", ["look3_tiny", "look2_c1", "l1_tiny", "l1_look2_c1"])
 def test_lookahead_unroll_matches_reference(golden, name):
     """tpv:367-428 with lookahead 3 / 2: windows, ragged last batch, loss terms averaged over the
