@@ -442,6 +442,51 @@ class HipEngine:
             s2.data_ptr() if s2 is not None else None, z.data_ptr(), self._stream()), "pvae_infer")
         return a_hat, s2, z
 
+    def infer_host(self, obs, noise=True, seed=0, offset=0, log_std=None, timeout_s=0.05):
+        """The control loop's call (rmt:742-771 at 1-4 rows; callers envs/rllib_env_imitation.py:215-266) with the
+        observation taken from, and the action delivered to, HOST memory by the kernels themselves: `obs` is a CPU
+        tensor / array [rows, 2 Db] (it is placed in a pinned staging buffer that the first encoder launch reads over
+        PCIe), and the decoder's last launch stores the action straight into a pinned result buffer.  No copy
+        launches either way and no stream synchronisation: the result buffer is pre-filled with NaN and the host
+        waits until every entry has been overwritten (each 4-byte store arrives whole; Philox draws only -- supplied
+        draws would need a copy of their own).  Returns a CPU tensor [rows, Da] ([rows, 2 Da] = [a_hat | log_std]
+        with `log_std`, a device tensor [Da]) that stays valid until the next call.  If an entry is still missing
+        after `timeout_s` (e.g. the model itself produced a NaN) the call falls back to a stream synchronisation."""
+        import time as _time
+        import numpy as _np
+        self._need_gpu()
+        Da, Db = self.arch.Da, self.arch.Db
+        if isinstance(obs, torch.Tensor):
+            obs = obs.detach().cpu().numpy()
+        obs = _np.asarray(obs, dtype=_np.float32).reshape(-1, 2 * Db)
+        rows = obs.shape[0]
+        if not (1 <= rows <= 4 and self.fused_rollout):
+            raise ValueError("infer_host serves the control loop's 1-4 rows (the library's rollout path)")
+        h = getattr(self, "_host_io", None)
+        if h is None:
+            h_obs = torch.empty(4, 2 * Db, dtype=torch.float32).pin_memory()
+            h_out = torch.empty(4, 2 * Da, dtype=torch.float32).pin_memory()
+            h = self._host_io = (h_obs, h_out, h_obs.numpy(), h_out.numpy())
+        h_obs, h_out, n_obs, n_out = h
+        n_obs[:rows] = obs
+        width = 2 * Da if log_std is not None else Da
+        res = n_out[:rows, :width]
+        res.fill(_np.nan)
+        if log_std is not None:
+            _lib.check(self.lib.pvae_infer_logits(self.ctx, h_obs.data_ptr(), rows, None, 1 if noise else 0, int(seed),
+                                                  int(offset), h_out.data_ptr(), 2 * Da, log_std.data_ptr(), None, None,
+                                                  self._stream()), "pvae_infer_logits")
+        else:
+            _lib.check(self.lib.pvae_infer_logits(self.ctx, h_obs.data_ptr(), rows, None, 1 if noise else 0, int(seed),
+                                                  int(offset), h_out.data_ptr(), 2 * Da, None, None, None,
+                                                  self._stream()), "pvae_infer_logits")
+        t0 = _time.perf_counter()
+        while _np.isnan(res).any():
+            if _time.perf_counter() - t0 > timeout_s:
+                torch.cuda.current_stream(self.device).synchronize()
+                break
+        return h_out[:rows, :width]
+
     def infer_logits(self, obs, log_std, eps=None, noise=True, seed=0, offset=0, want_s2=True):
         """`infer` with the module's output layout: returns (logits [rows, 2 Da] = [a_hat | log_std], s2_hat|None, z)
         -- the decoder's log-std vector (device tensor [Da]) is appended by the launch that writes the action

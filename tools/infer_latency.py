@@ -8,15 +8,16 @@ from physicsvae_amd import train_physics_vae as T
 import tempfile
 td = tempfile.mkdtemp(prefix="pvae_infer_")
 write_demo(os.path.join(td, "demo.pkl"), synth_demo(0, 2, 50, 197, 45))
-for name, sizes in (("default 256x2/512x3/1024x2", []),          # the trainer's own defaults (tpv:264-280)
-                    ("4x1024", [a for p in ("TE", "MD", "world_model") for a in ("--%s_width" % p, "1024", "--%s_depth" % p, "4")])):
+QUICK = "--quick" in sys.argv                      # default sizes, one row: the control loop's case only
+for name, sizes in ((("default 256x2/512x3/1024x2", []),) if QUICK else (("default 256x2/512x3/1024x2", []),          # the trainer's own defaults (tpv:264-280)
+                    ("4x1024", [a for p in ("TE", "MD", "world_model") for a in ("--%s_width" % p, "1024", "--%s_depth" % p, "4")]))):
     T.args = T.arg_parser().parse_args(["--data_train", os.path.join(td, "demo.pkl"), "--batch_size", "32"] + sizes)
     cfg = T.get_trainer_config(T.args)
     cfg["model"]["custom_model_config"]["device"] = "cuda"
     with contextlib.redirect_stdout(io.StringIO()):
         tr = T.TrainModel(cfg)
     eng = tr.engine
-    for rows in (1, 4, 32):
+    for rows in ((1,) if QUICK else (1, 4, 32)):
         obs = torch.randn(rows, 394, device="cuda")
         for want_s2 in (False, True):
             out = None
@@ -62,6 +63,26 @@ for name, sizes in (("default 256x2/512x3/1024x2", []),          # the trainer's
                   "as a HIP graph: %6.1f us back to back, %6.1f us single call"
                   % (name, rows, "TE+MD+WM" if want_s2 else "TE+MD   ", wall, (t1 - t0) / n * 1e6, lat[len(lat) // 2],
                      gwall, glat[len(glat) // 2]))
+    # host observation -> host action, what the control loop actually waits for (the env runs on the CPU): the plain way
+    # (copy the observation up, forward, copy the action down) against infer_host (the kernels read the observation from
+    # and write the action to pinned host memory themselves; no copy launches, no stream synchronisation)
+    obs_h = torch.randn(1, 394)
+    for label, fn in (("obs.cuda() -> infer -> a_hat.cpu()", lambda: eng.infer(obs_h.to("cuda", non_blocking=False), want_s2=False)[0].cpu()),
+                      ("infer_host (pinned in / out)      ", lambda: eng.infer_host(obs_h))):
+        for _ in range(30):
+            fn()
+        lat = []
+        for _ in range(200):
+            torch.cuda.synchronize()
+            t6 = time.perf_counter()
+            r = fn()
+            lat.append((time.perf_counter() - t6) * 1e6)
+        lat.sort()
+        print("%-28s rows  1  host obs -> host action, %s : %6.1f us median, %6.1f us p90"
+              % (name, label, lat[len(lat) // 2], lat[int(len(lat) * 0.9)]))
+    a_dev = eng.infer(obs_h.cuda(), noise=False, want_s2=False)[0].cpu()
+    a_host = eng.infer_host(obs_h, noise=False)
+    assert torch.equal(a_dev, a_host), "infer_host disagrees with infer"
     # the module surface RLlib drives (rmt:742-771 + value_function): forward alone, and forward + the lazily
     # evaluated value branch (plain torch Linear layers: it takes no part in the supervised path)
     m = tr.model
