@@ -101,3 +101,42 @@ def test_philox_draws_four_per_call_are_standard_normal_and_independent_across_c
     assert torch.equal(again, draws[3]) and not torch.equal(draws[3], draws[4])
     other = eng.reparam(ml, noise=True, seed=10, offset=3).double().cpu()
     assert not torch.equal(other, draws[3])
+
+
+@pytest.mark.parametrize("rows", [1, 2, 4])
+def test_rollout_from_host_observation_to_host_action(golden, rows):
+    """`HipEngine.infer_host` (rmt:742-771 for a control loop whose environment lives on the CPU,
+    envs/rllib_env_imitation.py:215-266): the observation is read from pinned host memory by the first encoder launch,
+    the action is written into a pinned buffer by the decoder's last launch, and the host polls that buffer (NaN
+    pre-fill) instead of synchronising.  Same kernels as `infer`: equal bit for bit, with and without sampler noise
+    (Philox draws keyed by seed / offset), with the log-std half appended; the staged minibatch is left alone."""
+    g = golden("single_default")
+    arch = arch_from_meta(g)
+    data = R.synth_demo(0, 2, 40, arch["Db"], arch["Da"], kind="dynamics")
+    tr = make_trainer(arch, data, 32, device=DEV)
+    tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3))
+    eng, Da = tr.engine, arch["Da"]
+    obs = torch.randn(rows, 2 * arch["Db"], generator=torch.Generator().manual_seed(rows))
+    for noise in (False, True):
+        for call in range(3):                                   # the pinned buffers are re-used call after call
+            want = eng.infer(obs.to(DEV), noise=noise, seed=5, offset=call, want_s2=False)[0].cpu()
+            got = eng.infer_host(obs, noise=noise, seed=5, offset=call)
+            assert got.device.type == "cpu" and got.shape == (rows, Da) and torch.equal(got, want)
+            got_np = eng.infer_host(obs.numpy(), noise=noise, seed=5, offset=call)       # numpy observations too
+            assert torch.equal(got_np, want)
+    ls = torch.full((Da,), -1.5, device=DEV)
+    logits = eng.infer_host(obs, noise=False, log_std=ls)
+    assert logits.shape == (rows, 2 * Da) and torch.equal(logits[:, :Da], eng.infer(obs.to(DEV), noise=False, want_s2=False)[0].cpu())
+    assert torch.equal(logits[:, Da:], ls.cpu().expand(rows, -1))
+    with pytest.raises(ValueError):
+        eng.infer_host(torch.randn(5, 2 * arch["Db"]))
+    # a staged training minibatch survives the call
+    eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
+    c = R.phase_coeffs(True)
+    sp = make_step_params(lr=5e-4, a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"], s_rec=c["s_rec_coeff"],
+                          cyc=c["vae_cycle_coeff"], global_rows=32)
+    eng.gather(0, 32)
+    l0 = eng.forward_backward(_lib.PHASE_WORLD, 32, sp, backward=False).clone()
+    eng.gather(0, 32)
+    eng.infer_host(obs, noise=False)
+    assert torch.equal(eng.forward_backward(_lib.PHASE_WORLD, 32, sp, backward=False), l0)
