@@ -406,6 +406,135 @@ __device__ inline void splitk_reg_body(float* lds, int bid, const GemmArgs& ga, 
     epi.finish(lds, tile_q * tiles_p + tile_p, tid);
 }
 
+
+// ---- input gradient on 64 x 32 output tiles, register-staged (the dgrad half of the fused pairs at >= 512 rows) ----
+// Same contraction and the same LDS images / swizzles as splitk_reg_body<false>, but the workgroup owns 64 batch rows:
+// per k-tile it stages a [64][64] dZ tile + a [64 k][32] W tile (24 KB) for the MFMA work of two 32x32 tiles (which
+// stage 2 x 16 KB), and every P fragment read feeds four MFMA tiles instead of two -- at 512 rows the 32x32 form put
+// 512 input-gradient workgroups beside the weight-gradient ones and the launch was bound by what they stage
+// (config-5 sizes).  Each wave still owns one k-quarter of every k-tile and walks it in the same order, and
+// the four partial tiles are summed in the same order, so results equal the 32x32 body's bit for bit.
+constexpr int kReg64RingFloats = 2 * (64 * 64 + 64 * 32);          // 2 slots x 24 KB = 48 KB
+template <class Epi>
+__device__ inline void splitk_reg64_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
+    constexpr int BK = 64, kTileQ = 64 * 64, kTileP = 64 * 32, kStage = kTileQ + kTileP, D = PVAE_REG_DEPTH_D;
+    constexpr int RS = 36;
+    static_assert(2 * kStage >= 4 * 64 * RS, "ring must hold the split-K reduction buffer");
+    const float* __restrict__ Q = ga.Q;
+    const float* __restrict__ P = ga.P;
+    const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int tile_p = xcd * ga.p_per_xcd + loc / tiles_q;
+    const int tile_q = loc % tiles_q;
+    if (tile_p >= tiles_p) return;
+    const int q0 = tile_q * 64, p0 = tile_p * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lh = lane >> 4;
+
+    const float* sq[4];
+    const float* sp[2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = tid + 256 * u, row = j >> 4, c = (j & 15) ^ (row & 15);
+        sq[u] = Q + (size_t)(q0 + row) * ldq + c * 4;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = tid + 256 * u, r = j >> 3, k = r ^ ((r >> 2) & 1);
+        sp[u] = P + (size_t)k * ldp + p0 + (j & 7) * 4;
+    }
+    const size_t kstep_p = (size_t)BK * ldp;
+    v4f rg[D][6];
+    auto gload = [&](int t, v4f(&r)[6]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const v4f*>(sq[u] + (size_t)t * BK);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) r[4 + u] = *reinterpret_cast<const v4f*>(sp[u] + (size_t)t * kstep_p);
+    };
+    auto lwrite = [&](float* slot, const v4f(&r)[6]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<v4f*>(slot + (tid + 256 * u) * 4) = r[u];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<v4f*>(slot + kTileQ + (tid + 256 * u) * 4) = r[4 + u];
+    };
+    v4f acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+    int oq[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int row = 16 * a + li;
+        oq[a] = row * 64 + (((4 * wave + lh) ^ (row & 15)) << 2);
+    }
+    const int kq = 16 * wave + 4 * lh;
+    const int nk = K / BK;
+#pragma unroll
+    for (int d = 0; d < D; ++d) gload(d < nk ? d : nk - 1, rg[d]);     // (clamped, not guarded: exact vmcnt)
+    lwrite(lds, rg[0]);
+    gload(D < nk ? D : nk - 1, rg[0]);
+    typename Epi::Pre epre[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) epre[h] = epi.preload(q0 + 32 * h + (tid >> 3), p0 + ((tid & 7) << 2));
+    __syncthreads();
+    auto tile_step = [&](int t, int d, bool guarded) {
+        const float* st = lds + (t & 1) * kStage;
+        v4f fq[4];
+        v2f fc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) fq[a] = *reinterpret_cast<const v4f*>(st + oq[a]);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+            fc[s2] = *reinterpret_cast<const v2f*>(st + kTileQ + (((kq + s2) ^ (lh & 1)) * 32) + 2 * li);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fc[s2][b], fq[a][s2], acc[a][b], 0, 0, 0);
+            if (s2 == 1) {
+                if (!guarded) {
+                    lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
+                    const int tn = t + 1 + D < nk ? t + 1 + D : nk - 1;
+                    gload(tn, rg[(d + 1) % D]);
+                } else if (t + 1 < nk) {
+                    lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
+                    if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D]);
+                }
+            }
+        }
+        __syncthreads();
+    };
+    int t0 = 0;
+    for (; t0 + D <= nk; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) tile_step(t0 + d, d, false);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (t0 + d < nk) tile_step(t0 + d, d, true);
+
+    float* red = lds + wave * (64 * RS);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float* row = red + (16 * a + li) * RS;                       // (16-byte writes: see store_partial_32x32)
+        *reinterpret_cast<v4f*>(row + 8 * lh) = v4f{acc[a][0][0], acc[a][1][0], acc[a][0][1], acc[a][1][1]};
+        *reinterpret_cast<v4f*>(row + 8 * lh + 4) = v4f{acc[a][0][2], acc[a][1][2], acc[a][0][3], acc[a][1][3]};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int ql = 32 * h + (tid >> 3), pl = (tid & 7) << 2;
+        v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (64 * RS) + ql * RS + pl);
+        epi(q0 + ql, p0 + pl, v, epre[h]);
+    }
+    epi.finish(lds, tile_q * tiles_p + tile_p, tid);
+}
+
 template <bool P_ROW, class Epi, int ABL = 0>
 __global__ void __launch_bounds__(256)
 gemm_splitk_reg_kernel(GemmArgs ga, Epi epi) {
@@ -1490,6 +1619,19 @@ bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, Adam
     PVAE_MARK(0, 3);
 }
 
+// The same fused launch with the input gradient on 64x32 tiles (splitk_reg64_body; 48 KB of LDS per workgroup): 512 rows
+// and more.
+template <class EpiD, class EpiW>
+__global__ void __launch_bounds__(256)
+bwd_pair64_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, AdamSeg ad) {
+    __shared__ __attribute__((aligned(16))) float lds[kReg64RingFloats];
+    const int b = blockIdx.x;
+    if (b < nd) splitk_reg64_body<EpiD>(lds, b, gd, ed);
+    else if (b < nd + nw) wgrad_body<EpiW>(lds, b - nd, gw, ew);
+    else if (b < nd + nw + bias_tiles(gw)) bias_grad_body(lds, b - nd - nw, gw, ew);
+    else adam_seg_body(ad, b - nd - nw - bias_tiles(gw));
+}
+
 // ---------------------------------------------------------------------------------------
 // epilogues: (q, p, 4 consecutive p values)
 // ---------------------------------------------------------------------------------------
@@ -1819,6 +1961,9 @@ inline GemmGrid make_grid(int rows_q, int cols_p, int bq, int bp) {
 // 512 rows and more: 64x32 tiles (splitk_ws64_body) whenever they still give every CU a workgroup; PVAE_WS64=0: off (A/B)
 static int g_ws64 = [] { const char* e = getenv("PVAE_WS64"); return (e && e[0] == '0') ? 0 : 1; }();
 inline bool uses_64x32(int M, int N) { return g_ws64 && M >= 512 && M % 64 == 0 && (M / 64) * (N / 32) >= 256; }
+// ... and the input-gradient half of the fused backward pairs (PVAE_PAIR64=0: off, A/B)
+static int g_pair64 = [] { const char* e = getenv("PVAE_PAIR64"); return (e && e[0] == '0') ? 0 : 1; }();
+inline bool pair_uses_64x32(int M, int N) { return g_pair64 && uses_64x32(M, N); }
 // narrow outputs: under 128 workgroups of 32x32 -> use 16x16 tiles (4x the workgroups)
 inline bool forward_uses_16x16(int M, int N) { return (M / 32) * (N / 32) < 128; }
 inline int forward_tiles(int M, int N) {
@@ -1953,6 +2098,15 @@ inline hipError_t gemm_bwd_pair_epi(const float* dZd, int ldzd, const float* Wd,
                                     int Kinw, int Mw, const EpiW& ew, hipStream_t st, const AdamSeg* ad = nullptr) {
     const DgradPlan d = plan_dgrad(dZd, ldzd, Wd, ldwd, Md, Kind, Nd);
     const WgradPlan w = plan_wgrad(dZw, ldzw, Xw, ldxw, Nw, Kinw, Mw);
+    if constexpr (std::is_same<EpiD, EpiMask>::value) {
+        if (pair_uses_64x32(Md, Kind)) {                        // hidden-layer input gradient at >= 512 rows
+            const GemmGrid g = make_grid(Md, Kind, 64, 32);
+            PVAE_LAUNCH((bwd_pair64_kernel<EpiD, EpiW>), dim3(g.grid + w.grid + w.nbias + adam_blocks(ad)), dim3(256), st,
+                        GemmArgs{dZd, ldzd, Wd, ldwd, Nd, g.tiles_q, g.tiles_p, g.p_per_xcd}, ed, g.grid, w.ga, ew, w.grid,
+                        ad ? *ad : AdamSeg());
+            return hipGetLastError();
+        }
+    }
     PVAE_LAUNCH((bwd_pair_kernel<EpiD, EpiW>), dim3(d.grid + w.grid + w.nbias + adam_blocks(ad)), dim3(256), st,
                        d.ga, ed, d.grid, w.ga, ew, w.grid, ad ? *ad : AdamSeg());
     return hipGetLastError();

@@ -152,3 +152,54 @@ torch.save(outs, sys.argv[1])
         files.append(torch.load(f))
     for a, b in zip(*files):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_pair_launch_with_64x32_input_gradient_tiles_is_bit_identical(tmp_path):
+    """The fused backward pairs at 512 rows and more run their input-gradient half on 64x32 tiles (splitk_reg64_body,
+    bwd_pair64_kernel; PVAE_PAIR64=0 keeps 32x32).  Same k-quarters per wave, same order of the four partial sums: a
+    whole backward pass (world and joint phase, 512 and 576 rows, 1024-wide stacks) leaves bit-identical gradients,
+    losses and -- through the fused step -- parameters and moments."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from oracle import refpath as R
+from physicsvae_amd import _lib
+from physicsvae_amd.engine import make_step_params
+from util import make_trainer
+arch = R.make_arch(23, 7, latent=8, te=(1024, 2), md=(1024, 3), wm=(1024, 2))
+data = R.synth_demo(0, 2, 400, 23, 7, kind="dynamics")
+outs = []
+for rows in (512, 576):
+    tr = make_trainer(arch, data, rows, device="cuda")
+    tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, 1), 3))
+    eng = tr.engine
+    eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
+    eps = R.eps_stream(2, 8)(0, (rows, 8))
+    for phase, world in ((_lib.PHASE_WORLD, True), (_lib.PHASE_JOINT, False)):
+        c = R.phase_coeffs(world)
+        sp = make_step_params(lr=5e-4, a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"], s_rec=c["s_rec_coeff"],
+                              cyc=c["vae_cycle_coeff"], global_rows=rows)
+        eng.gather(0, rows)
+        eng.grads.zero_()
+        loss = eng.forward_backward(phase, rows, sp, eps=eps, fused_adam=False).clone()
+        outs += [loss.cpu(), eng.grads.clone().cpu()]
+        out = torch.zeros(5, device="cuda")
+        for t in (1, 2):
+            spt = make_step_params(lr=5e-4, adam_t=(t, t, t), a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"],
+                                   s_rec=c["s_rec_coeff"], cyc=c["vae_cycle_coeff"], global_rows=rows)
+            eng.train_step(phase, 0, rows, spt, eps=eps, loss_out=out)
+        outs += [eng.params.clone().cpu(), eng.exp_avg.clone().cpu()]
+torch.save(outs, sys.argv[1])
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    files = []
+    for mode in ("0", "1"):
+        f = str(tmp_path / ("pair%s.pt" % mode))
+        env = dict(os.environ, PVAE_PAIR64=mode)
+        subprocess.run([sys.executable, "-c", script, f], check=True, env=env, timeout=600, stdout=subprocess.DEVNULL)
+        files.append(torch.load(f))
+    assert len(files[0]) == 16
+    for a, b in zip(*files):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert float(files[0][1].abs().sum()) > 0
