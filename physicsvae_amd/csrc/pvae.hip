@@ -1942,10 +1942,117 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
     const NetWork* wte = &NW[PVAE_NET_TE];
     const NetWork* wmd = &NW[PVAE_NET_MD];
     const NetWork* wwm = &NW[PVAE_NET_WM];
+
+    // Weight gradients contract over ALL steps at once (row blocks stacked): rows [0, krows) of a trainable stack.
+    // Row blocks that receive no gradient are cut off the end or zero-filled; the fills go first (nothing writes
+    // those blocks afterwards).
+    std::vector<int> train_nets;
+    if (joint) { train_nets.push_back(PVAE_NET_MD); train_nets.push_back(PVAE_NET_TE); }
+    else train_nets.push_back(PVAE_NET_WM);
+    int krows_of[PVAE_NUM_NETS] = {0, 0, 0, 0};
+    if (backward) {
+        for (int n : train_nets) {
+            const NetLayout* N = &NL[n];
+            const NetWork* nw = &NW[n];
+            std::vector<char> act;
+            if (n == PVAE_NET_WM) {
+                for (int t = 0; t < T; ++t) act.push_back(u.use_g);
+                for (int t = 0; t < T; ++t) act.push_back(p_act[t]);
+            } else {
+                for (int t = 0; t < T; ++t) act.push_back(md_act[t]);
+            }
+            int blocks = (int)act.size();
+            while (blocks > 0 && !act[blocks - 1]) --blocks;
+            for (int b = 0; b < blocks; ++b) {
+                if (act[b]) continue;
+                const int64_t r0 = u.blk(b);
+                const size_t nrows = (size_t)u.rows_pad;
+                push([=]() -> int {
+                    for (const Layer& l : N->layers)
+                        HIP_TRY(hipMemsetAsync(w + nw->dz[l.index] + r0 * l.n_out_pad, 0, nrows * l.n_out_pad * sizeof(float), st));
+                    return 0;
+                });
+            }
+            krows_of[n] = blocks * u.rows_pad;
+        }
+    }
+    const LossFinal* fold = S.lf.out ? &S.lf : nullptr;
+    // Step 0's input-gradient launches of a trainable stack run LAST in the backward pass, so by the time layer i's
+    // input gradient of step 0 is launched, dz[i] is final for every step: its weight gradient (over all steps) can
+    // share that launch -- the same-layer pairing of the lookahead-1 schedule (gradient stored, Adam deferred to
+    // workgroups of the next launch), instead of 3 weight-gradient launches per stack at the end (PVAE_LOOK_PAIR=0).
+    static const bool look_pair_env = [] { const char* e = getenv("PVAE_LOOK_PAIR"); return !(e && e[0] == '0'); }();
+    const bool can_defer = fused && c->defer_adam && c->grads != nullptr;
+    const bool look_pair = backward && look_pair_env && c->pair_launch && c->same_layer_pairs && (!fused || can_defer);
+    bool paired_done[PVAE_NUM_NETS] = {false, false, false, false};
+    // layers last .. lo of stack n: dgrad_i over row block `slot` || wgrad_i over rows [0, krows); then, when lo == 1,
+    // layer 0's weight gradient on its own.  `with_fold`: the stack's last launch also finalises the losses.
+    auto paired_chain = [&](int n, int slot, int lo, bool with_fold) {
+        const NetLayout* N = &NL[n];
+        const NetWork* nw = &NW[n];
+        const int64_t b = u.blk(slot);
+        const int rows_pad = u.rows_pad, krows = krows_of[n];
+        const AdamScalars as = adam_scalars(sp, n);
+        const int act = c->L.cfg.act_kind + 1;
+        LossFinal foldv;
+        memset(&foldv, 0, sizeof(foldv));
+        if (with_fold && fold) foldv = *fold;
+        for (int i = (int)N->layers.size() - 1; i >= 0; --i) {
+            const bool has_d = i >= lo;
+            const bool f = with_fold && fold && i == 0;
+            Stage& sref = push([=]() -> int {
+                const Layer& l = N->layers[i];
+                const float* mask = i > 0 ? w + nw->act[i - 1] + b * l.ld : nullptr;
+                float* out = i > 0 ? w + nw->dz[i - 1] + b * l.ld : w + nw->d_in + b * l.ld;
+                const float* dz = w + nw->dz[i];
+                const float* xin = i == 0 ? w + nw->in : w + nw->act[i - 1];
+                EpiGradAdam ea{c->params + l.w_off, c->m + l.w_off, c->v + l.w_off, l.ld, as};
+                ea.b = c->params + l.b_off; ea.bm = c->m + l.b_off; ea.bv = c->v + l.b_off;
+                EpiGradStore es{c->grads + l.w_off, l.ld};
+                es.gb = c->grads + l.b_off;
+                if (f) { ea.loss = foldv; es.loss = foldv; }
+                const AdamSeg ad = take_pending_adam(c);
+                hipError_t he;
+                if (has_d) {
+                    const int pp = g_prof.begin(3, 2.0 * rowsf * l.n_in * l.n_out * (1.0 + (double)krows / rows_pad), st);
+                    he = gemm_bwd_pair(dz + b * l.n_out_pad, l.n_out_pad, c->params + l.w_off, l.ld, mask, l.ld, out, l.ld,
+                                       rows_pad, l.ld, l.n_out_pad, dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, krows, es,
+                                       st, &ad, act);
+                    g_prof.end(pp, st);
+                    if (he == hipSuccess && fused) {                 // (this launch read W_i: its update waits for the next one)
+                        AdamSeg a;
+                        a.p = c->params + l.w_off; a.g = c->grads + l.w_off; a.m = c->m + l.w_off; a.v = c->v + l.w_off;
+                        a.n4 = (l.b_off + l.n_out_pad - l.w_off) / 4;
+                        a.s = as;
+                        c->pending_adam = a;
+                    }
+                } else {
+                    const int pw = g_prof.begin(2, 2.0 * rowsf * l.n_in * l.n_out * ((double)krows / rows_pad), st);
+                    he = fused ? gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, krows, ea, st, &ad)
+                               : gemm_wgrad(dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, krows, es, st, &ad);
+                    g_prof.end(pw, st);
+                }
+                if (he != hipSuccess) return fail(-10, "paired backward launch: %s", hipGetErrorString(he));
+                return 0;
+            });
+            sref.ready_off = N->layers[i].w_off;
+            sref.ready_cnt = N->layers[i].b_off + N->layers[i].n_out_pad - N->layers[i].w_off;
+            sref.net = n;
+        }
+        paired_done[n] = true;
+    };
+    const int last_train = train_nets.back();
     for (int t = T - 1; t >= 0; --t) {
         const int64_t bt = u.blk(t), bp = u.blk(T + t);
         const int rows_pad = u.rows_pad;
-        if (backward && u.use_g) dgrad_chain(PVAE_NET_WM, t, t > 0);
+        // step 0 in the WORLD phase: what flows back through the (frozen) decoder and encoder of step 0 reaches no
+        // trainable parameter -- only the world model's own layers above layer 0 need their input gradients
+        const bool upstream = joint || t > 0;
+        const bool pair_wm = look_pair && t == 0 && !joint && krows_of[PVAE_NET_WM] > 0;
+        if (backward && u.use_g) {
+            if (pair_wm && !p_act[t]) paired_chain(PVAE_NET_WM, t, 1, true);    // (no predicted-action chain follows)
+            else dgrad_chain(PVAE_NET_WM, t, t > 0);
+        }
         if (backward && p_act[t]) {
             if (t + 1 < T && any[t + 1]) {        // + gradient wrt s1_{t+1}, from every consumer of it
                 const int64_t nt = u.blk(t + 1), np = u.blk(T + t + 1);
@@ -1961,8 +2068,10 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
                     return 0;
                 });
             }
-            dgrad_chain(PVAE_NET_WM, T + t, true);
+            if (pair_wm) paired_chain(PVAE_NET_WM, T + t, 1, true);
+            else dgrad_chain(PVAE_NET_WM, T + t, upstream);
         }
+        if (!upstream) continue;
         // action reconstruction (tpv:381-382) + gradient arriving through the world model
         if (md_act[t] || (joint && sp->a_rec_coeff > 0.0f)) {
             const float ga = joint ? sp->a_rec_coeff * S.gs / (S.Bg * Da) : 0.0f;
@@ -1979,7 +2088,9 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
             });
         }
         if (!backward || !md_act[t]) continue;
-        dgrad_chain(PVAE_NET_MD, t, true);
+        const bool pair_here = look_pair && t == 0 && joint;
+        if (pair_here && krows_of[PVAE_NET_MD] > 0) paired_chain(PVAE_NET_MD, t, 0, false);
+        else dgrad_chain(PVAE_NET_MD, t, true);
         {
             const float kls = S.kl_active ? sp->kl_coeff / S.Bg : 0.0f;
             const int tot = rows_pad * ldo_te;
@@ -1992,40 +2103,21 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
                 return 0;
             });
         }
-        dgrad_chain(PVAE_NET_TE, t, t > 0);
+        if (pair_here && krows_of[PVAE_NET_TE] > 0) paired_chain(PVAE_NET_TE, t, 1, true);
+        else dgrad_chain(PVAE_NET_TE, t, t > 0);
     }
     if (!backward) return;
+    (void)last_train;
 
-    // weight gradients: one contraction per layer over the stacked blocks
-    const LossFinal* fold = S.lf.out ? &S.lf : nullptr;
-    std::vector<int> train_nets;
-    if (joint) { train_nets.push_back(PVAE_NET_MD); train_nets.push_back(PVAE_NET_TE); }
-    else train_nets.push_back(PVAE_NET_WM);
+    // weight gradients of the stacks whose launches were not paired above: one contraction per layer over the
+    // stacked blocks
     for (size_t k = 0; k < train_nets.size(); ++k) {
         const int n = train_nets[k];
+        if (paired_done[n]) continue;
         const NetLayout* N = &NL[n];
         const NetWork* nw = &NW[n];
-        // active row blocks of this net; trailing inactive ones are cut off, others are zeroed
-        std::vector<char> act;
-        if (n == PVAE_NET_WM) {
-            for (int t = 0; t < T; ++t) act.push_back(u.use_g);
-            for (int t = 0; t < T; ++t) act.push_back(p_act[t]);
-        } else {
-            for (int t = 0; t < T; ++t) act.push_back(md_act[t]);
-        }
-        int blocks = (int)act.size();
-        while (blocks > 0 && !act[blocks - 1]) --blocks;
-        for (int b = 0; b < blocks; ++b) {
-            if (act[b]) continue;
-            const int64_t r0 = u.blk(b);
-            const size_t nrows = (size_t)u.rows_pad;
-            push([=]() -> int {
-                for (const Layer& l : N->layers)
-                    HIP_TRY(hipMemsetAsync(w + nw->dz[l.index] + r0 * l.n_out_pad, 0, nrows * l.n_out_pad * sizeof(float), st));
-                return 0;
-            });
-        }
-        const int krows = blocks * u.rows_pad;
+        const int blocks = krows_of[n] / u.rows_pad;
+        const int krows = krows_of[n];
         const AdamScalars as = adam_scalars(sp, n);
         const bool last_net = k + 1 == train_nets.size();
         // two layers per launch (wgrad_pair_kernel), last layer first; an odd layer count leaves layer 0
