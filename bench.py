@@ -571,6 +571,9 @@ def main():
             entry = {}
             try:
                 if mode == "p2p":
+                    # (a peer that never answers must cost this run a fraction of a second per wait, not the
+                    #  library's default 20 s: the time-out is read when the peers are mapped)
+                    os.environ.setdefault("PVAE_P2P_TIMEOUT_MS", "250")
                     if not dp.attach_p2p(eng):                     # collective: every rank agrees on the outcome
                         return {"skipped": "peer-mapped exchange could not be set up (see stderr)"}
                 elif mode == "local":
@@ -584,6 +587,12 @@ def main():
                     eng.comm_config(6.0 if mode == "bucketed" else 0.0)
                 phase, nets = set_phase(a.phase)
                 run_steps(phase, nets, 10, 0)
+                if mode == "p2p":                                  # all ranks agree on whether any wait gave up
+                    bad = torch.tensor([eng.p2p_status()[2]], dtype=torch.int64, device=dev)
+                    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                    if int(bad.item()):
+                        eng.comm_mode("allreduce" if eng.has_comm else "local")
+                        return {"error": "%d waits for a peer gave up within the first 10 steps" % int(bad.item())}
                 lib.pvae_profile_enable(1)                         # HIP events around every collective / exchange launch
                 run_steps(phase, nets, 40, 10)
                 torch.cuda.synchronize()

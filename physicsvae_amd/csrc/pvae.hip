@@ -181,7 +181,8 @@ struct pvae_ctx {
     bool seed_pads_clean = false;  // pad columns of the seed panels zeroed (see plan_backward)
     // deferred Adam (AdamSeg, pvae_gemm.h): the layer whose gradient the last launch stored; the next
     // weight-gradient launch of the step updates it with extra workgroups (PVAE_DEFER_ADAM=0: off)
-    AdamSeg pending_adam;
+    AdamSeg pending_adam;          // the most recent one
+    AdamSeg held_adam;             // a big one that a narrow launch passed on to the next wide launch (take_pending)
     bool defer_adam = true;
     bool same_layer_pairs = true;  // PVAE_SAME_LAYER=0: wgrad_i rides with dgrad_{i-1} as before (A/B)
     bool fold_sampler = false;     // PVAE_FOLD_SAMPLER=1: the sampler runs as the prologue of the decoder's first-layer launch
@@ -1006,19 +1007,41 @@ struct Stage {
 typedef std::vector<Stage> Plan;
 
 // the pending deferred-Adam segment, handed to the launch that is about to go out
-static AdamSeg take_pending_adam(pvae_ctx* c) {
-    const AdamSeg a = c->pending_adam;
+// What the launch that is about to go out carries.  A hidden-layer pair absorbs the 28 B/param of a 1024x1024 update
+// at ~1 us; a launch with little work of its own (a stack's first / last layer) is as long as the update it
+// carries (the sampler-seed pair: 9.6 us, 40 MB).  So such a NARROW launch passes a big pending segment on (it stays
+// `held` for the next WIDE launch) and takes only what is small; wide launches and the step's last launch take all.
+enum { kTakeAll = 0, kTakeSmall = 1 };
+constexpr long long kBigAdamSeg = 150000;                       // float4 elements (a 1024x256 layer: 65.8 K, 1024x1024: 262 K)
+static AdamPair take_pending(pvae_ctx* c, int how = kTakeAll) {
+    AdamPair p;
+    if (how == kTakeSmall && c->pending_adam.n4 >= kBigAdamSeg && c->held_adam.n4 <= 0) {
+        c->held_adam = c->pending_adam;                         // pass it on
+        c->pending_adam = AdamSeg();
+        return p;
+    }
+    if (how == kTakeSmall && c->held_adam.n4 > 0) {             // still holding one: take the recent one if it is small
+        if (c->pending_adam.n4 < kBigAdamSeg) { p.s[0] = c->pending_adam; c->pending_adam = AdamSeg(); }
+        else { p.s[0] = c->held_adam; c->held_adam = c->pending_adam; c->pending_adam = AdamSeg(); }   // (two big ones: oldest goes)
+        return p;
+    }
+    p.s[0] = c->held_adam;
+    p.s[1] = c->pending_adam;
+    if (p.s[0].n4 <= 0) { p.s[0] = p.s[1]; p.s[1] = AdamSeg(); }
+    c->held_adam = AdamSeg();
     c->pending_adam = AdamSeg();
-    return a;
+    return p;
 }
-// nothing left to carry it: its own launch
+// nothing left to carry them: their own launches
 static int flush_pending_adam(pvae_ctx* c, hipStream_t st) {
-    const AdamSeg a = take_pending_adam(c);
-    if (a.n4 <= 0) return 0;
-    int grid = (int)((a.n4 + 255) / 256);
-    if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, st, a.p, a.g, a.m, a.v, a.n4, a.s);
-    HIP_TRY(hipGetLastError());
+    const AdamPair p = take_pending(c);
+    for (const AdamSeg& a : p.s) {
+        if (a.n4 <= 0) continue;
+        int grid = (int)((a.n4 + 255) / 256);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, st, a.p, a.g, a.m, a.v, a.n4, a.s);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
@@ -1065,7 +1088,7 @@ struct CarriedWgrad {
 static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool input_grad,
                               const pvae_step_params* sp, bool fused, hipStream_t st, const LossFinal* fold,
                               Plan& plan, const InputSeed* seed = nullptr, CarriedWgrad* carry_out = nullptr,
-                              const CarriedWgrad* carry_in = nullptr) {
+                              const CarriedWgrad* carry_in = nullptr, bool wide_follows_layer0 = false) {
     const NetLayout* N = &c->L.net[n];
     const NetWork* w = &c->W.net[n];
     const AdamScalars as = adam_scalars(sp, n);
@@ -1131,9 +1154,12 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
         const float* xin = i == 0 ? c->ws + w->in : c->ws + w->act[i - 1];
         // (j == i: the launch also reads W_i, so the update MUST wait for the next one)
         const bool defer = can_defer && j >= 0 && (!with_fold || j == i);
+        // (narrow launches -- a stack's last and first layer -- hand a big pending update on to the next hidden-layer
+        //  pair of the step, when there is one: take_pending)
+        const bool narrow = j == i && !with_fold && ((i == last && last >= 2) || (i == 0 && wide_follows_layer0));
         auto go = [&](auto e) -> int {
             if (with_fold) e.loss = foldv;
-            const AdamSeg ad = take_pending_adam(c);
+            const AdamPair ad = take_pending(c, narrow ? kTakeSmall : kTakeAll);
             if (j >= 0) {
                 const Layer& d = N->layers[j];
                 const float* dx_in = j == 0 ? c->ws + w->in : c->ws + w->act[j - 1];
@@ -1180,7 +1206,7 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
             if (with_fold) e1.loss = foldv;            // block 0 of the launch belongs to the first problem
             // the step's LAST launch also gathers the next minibatch into the alternate panels
             const bool carry = with_fold && c->next_stage.rows_pad > 0;
-            const AdamSeg ad = take_pending_adam(c);
+            const AdamPair ad = take_pending(c);
             HIP_TRY(gemm_wgrad_pair(c->ws + w->dz[1], l1.n_out_pad, c->ws + w->act[0], l1.ld, l1.n_out_pad, l1.ld, e1,
                                     c->ws + w->dz[0], l0.n_out_pad, c->ws + w->in, l0.ld, l0.n_out_pad, l0.ld, e0,
                                     rows_pad, st, carry ? &c->next_stage : nullptr, &ad));
@@ -1200,7 +1226,7 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
         auto go = [&](auto e0) -> int {
             if (with_fold) e0.loss = foldv;
             const bool carry = with_fold && c->next_stage.rows_pad > 0;
-            const AdamSeg ad = take_pending_adam(c);
+            const AdamPair ad = take_pending(c);
             HIP_TRY(gemm_wgrad_pair(c->ws + w->dz[0], l0.n_out_pad, c->ws + w->in, l0.ld, l0.n_out_pad, l0.ld, e0,
                                     (const float*)nullptr, 0, (const float*)nullptr, 0, 0, l0.ld, e0,
                                     rows_pad, st, carry ? &c->next_stage : nullptr, &ad));
@@ -1281,7 +1307,7 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
             carry_out->run_with_dgrad = [=](const DgradArgs& d) -> int {
                 const int pp = g_prof.begin(3, d.flops + 2.0 * rowsf * l.n_in * l.n_out, st);
                 hipError_t he;
-                const AdamSeg ad = take_pending_adam(c);
+                const AdamPair ad = take_pending(c);
                 if (fused) {
                     he = gemm_bwd_pair(d.dZ, d.ldz, d.W, d.ldw, d.mask, d.ldm, d.dX, d.ldo, d.M, d.Kin, d.Nd, dz,
                                        l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, adam_epi(l), st, &ad, act);
@@ -1778,7 +1804,9 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
     }
     CarriedWgrad carry;
     plan_backward_net(c, PVAE_NET_MD, S.rows_pad, true, true, sp, fused, st, nullptr, plan, &ss,
-                      seed_sampler ? &carry : nullptr);
+                      seed_sampler ? &carry : nullptr, nullptr,
+                      /* hidden-layer pairs of the encoder follow the decoder's first-layer pair: */
+                      !learned_prior && TE->layers.size() >= 3);
     if (!seed_sampler) {
         const int rows_pad = S.rows_pad;
         const int tot = rows_pad * TE->layers.back().n_out_pad;
@@ -2011,7 +2039,7 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
                 EpiGradStore es{c->grads + l.w_off, l.ld};
                 es.gb = c->grads + l.b_off;
                 if (f) { ea.loss = foldv; es.loss = foldv; }
-                const AdamSeg ad = take_pending_adam(c);
+                const AdamPair ad = take_pending(c);
                 hipError_t he;
                 if (has_d) {
                     const int pp = g_prof.begin(3, 2.0 * rowsf * l.n_in * l.n_out * (1.0 + (double)krows / rows_pad), st);
@@ -2187,9 +2215,9 @@ int pvae_forward_backward(pvae_ctx* c, int phase, int32_t rows, const pvae_step_
     if ((rc = run_forward(c, phase, rows, sp, eps, backward, S, st))) return rc;
     Plan plan;
     plan_backward(c, phase, rows, sp, backward, fused, S, st, plan);
-    c->pending_adam = AdamSeg();
+    c->pending_adam = c->held_adam = AdamSeg();
     for (Stage& s : plan)
-        if ((rc = s.run())) { c->pending_adam = AdamSeg(); return rc; }
+        if ((rc = s.run())) { c->pending_adam = c->held_adam = AdamSeg(); return rc; }
     if ((rc = flush_pending_adam(c, st))) return rc;
     if (loss_out && !backward) {
         hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(64), 0, st, S.lf);

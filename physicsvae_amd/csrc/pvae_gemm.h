@@ -1524,6 +1524,21 @@ __device__ inline void adam_seg_body(const AdamSeg& a, int blk) {
     }
 }
 inline int adam_blocks(const AdamSeg* a) { return a && a->n4 > 0 ? kAdamBlocks : 0; }
+// What one launch carries: up to two pending updates (a launch with little work of its own passes a big segment on to
+// the next wide one and takes a small one instead: see take_pending in pvae.hip), kAdamBlocks workgroups each.
+struct AdamPair {
+    AdamSeg s[2];
+    AdamPair() {}
+    AdamPair(const AdamSeg& a) { s[0] = a; }                  // (probes under tools/ pass a single segment)
+};
+inline int adam_blocks(const AdamPair* p) { return p ? adam_blocks(&p->s[0]) + adam_blocks(&p->s[1]) : 0; }
+__device__ inline void adam_pair_body(const AdamPair& p, int blk) {
+    if (p.s[0].n4 > 0) {
+        if (blk < kAdamBlocks) { adam_seg_body(p.s[0], blk); return; }
+        blk -= kAdamBlocks;
+    }
+    adam_seg_body(p.s[1], blk);
+}
 
 // Bias gradient of a weight-gradient problem, db[q] = sum over the K rows of Q[k][q], for 32
 // columns per workgroup (fixed summation order), handed to the epilogue's bias() (store, or Adam on
@@ -1567,12 +1582,12 @@ __device__ inline void bias_grad_body(float* lds, int tile, const GemmArgs& ga, 
 
 template <class Epi, int ABL = 0>
 __global__ void __launch_bounds__(256)
-gemm_wgrad_reg_kernel(GemmArgs ga, Epi epi, int nw, AdamSeg ad) {
+gemm_wgrad_reg_kernel(GemmArgs ga, Epi epi, int nw, AdamPair ad) {
     __shared__ __attribute__((aligned(16))) float lds[kPairLdsFloats];
     const int b = blockIdx.x, nb = bias_tiles(ga);
     if (b < nw) wgrad_body<Epi, ABL>(lds, b, ga, epi);
     else if (b < nw + nb) bias_grad_body(lds, b - nw, ga, epi);
-    else adam_seg_body(ad, b - nw - nb);
+    else adam_pair_body(ad, b - nw - nb);
 }
 
 // Horizontal fusion of two independent backward contractions in ONE launch: blocks [0, nd) run
@@ -1586,7 +1601,7 @@ gemm_wgrad_reg_kernel(GemmArgs ga, Epi epi, int nw, AdamSeg ad) {
 // step that precedes it instead of being a launch of its own.
 template <class EpiW>
 __global__ void __launch_bounds__(256)
-wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2, int n12, StageArgs sa, AdamSeg ad, int na) {
+wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2, int n12, StageArgs sa, AdamPair ad, int na) {
     __shared__ __attribute__((aligned(16))) float lds[kPairLdsFloats];
     const int b = blockIdx.x;
     const int nb1 = bias_tiles(g1), nb2 = bias_tiles(g2);
@@ -1594,7 +1609,7 @@ wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2, int n12, S
     else if (b < n12) wgrad_body<EpiW>(lds, b - n1, g2, e2);
     else if (b < n12 + nb1) bias_grad_body(lds, b - n12, g1, e1);
     else if (b < n12 + nb1 + nb2) bias_grad_body(lds, b - n12 - nb1, g2, e2);
-    else if (b < n12 + nb1 + nb2 + na) adam_seg_body(ad, b - n12 - nb1 - nb2);
+    else if (b < n12 + nb1 + nb2 + na) adam_pair_body(ad, b - n12 - nb1 - nb2);
     else stage_row(sa, b - n12 - nb1 - nb2 - na, 0, sa.rows_pad);
 }
 
@@ -1602,7 +1617,7 @@ wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2, int n12, S
 // pair needs 512-thread blocks and 64 KB of LDS per workgroup and measured 15 % slower.)
 template <class EpiD, class EpiW, int ABL = 0>          // ABL: ablation bits of the two bodies (probes only)
 __global__ void __launch_bounds__(256)
-bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, AdamSeg ad) {
+bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, AdamPair ad) {
     __shared__ __attribute__((aligned(16))) float lds[kPairLdsFloats];
     PVAE_MARK(0, 0);
     PVAE_MARK_HW();
@@ -1615,7 +1630,7 @@ bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, Adam
         else splitk_reg_body<false, EpiD, ABL>(lds, b, gd, ed);
     } else if (b < nd + nw) wgrad_body<EpiW, ABL>(lds, b - nd, gw, ew);
     else if (b < nd + nw + bias_tiles(gw)) bias_grad_body(lds, b - nd - nw, gw, ew);
-    else adam_seg_body(ad, b - nd - nw - bias_tiles(gw));
+    else adam_pair_body(ad, b - nd - nw - bias_tiles(gw));
     PVAE_MARK(0, 3);
 }
 
@@ -1623,13 +1638,13 @@ bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, Adam
 // and more.
 template <class EpiD, class EpiW>
 __global__ void __launch_bounds__(256)
-bwd_pair64_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, AdamSeg ad) {
+bwd_pair64_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, AdamPair ad) {
     __shared__ __attribute__((aligned(16))) float lds[kReg64RingFloats];
     const int b = blockIdx.x;
     if (b < nd) splitk_reg64_body<EpiD>(lds, b, gd, ed);
     else if (b < nd + nw) wgrad_body<EpiW>(lds, b - nd, gw, ew);
     else if (b < nd + nw + bias_tiles(gw)) bias_grad_body(lds, b - nd - nw, gw, ew);
-    else adam_seg_body(ad, b - nd - nw - bias_tiles(gw));
+    else adam_pair_body(ad, b - nd - nw - bias_tiles(gw));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2070,10 +2085,10 @@ inline WgradPlan plan_wgrad(const float* dZ, int ldz, const float* X, int ldx, i
 }
 template <class Epi>
 inline hipError_t gemm_wgrad(const float* dZ, int ldz, const float* X, int ldx, int N, int Kin, int M,
-                             const Epi& e, hipStream_t st, const AdamSeg* ad = nullptr) {
+                             const Epi& e, hipStream_t st, const AdamPair* ad = nullptr) {
     const WgradPlan w = plan_wgrad(dZ, ldz, X, ldx, N, Kin, M);
     PVAE_LAUNCH((gemm_wgrad_reg_kernel<Epi>), dim3(w.grid + w.nbias + adam_blocks(ad)), dim3(256), st, w.ga, e, w.grid,
-                ad ? *ad : AdamSeg());
+                ad ? *ad : AdamPair());
     return hipGetLastError();
 }
 // one launch, two independent weight gradients (the two last layers of a backward pass)
@@ -2081,21 +2096,21 @@ template <class EpiW>
 inline hipError_t gemm_wgrad_pair(const float* dZ1, int ldz1, const float* X1, int ldx1, int N1, int Kin1,
                                   const EpiW& e1, const float* dZ2, int ldz2, const float* X2, int ldx2, int N2,
                                   int Kin2, const EpiW& e2, int M, hipStream_t st, const StageArgs* next = nullptr,
-                                  const AdamSeg* ad = nullptr) {
+                                  const AdamPair* ad = nullptr) {
     const WgradPlan w1 = plan_wgrad(dZ1, ldz1, X1, ldx1, N1, Kin1, M);
     const WgradPlan w2 = plan_wgrad(dZ2, ldz2, X2, ldx2, N2, Kin2, M);
     StageArgs sa;
     memset(&sa, 0, sizeof(sa));
     if (next) sa = *next;                     // rows_pad extra blocks gather the next minibatch
     PVAE_LAUNCH((wgrad_pair_kernel<EpiW>), dim3(w1.grid + w2.grid + w1.nbias + w2.nbias + adam_blocks(ad) + sa.rows_pad),
-                dim3(256), st, w1.ga, e1, w1.grid, w2.ga, e2, w1.grid + w2.grid, sa, ad ? *ad : AdamSeg(), adam_blocks(ad));
+                dim3(256), st, w1.ga, e1, w1.grid, w2.ga, e2, w1.grid + w2.grid, sa, ad ? *ad : AdamPair(), adam_blocks(ad));
     return hipGetLastError();
 }
 // one launch: dX'[M][Kin'] = (dZ'[M][N'] W'[N'][Kin']) .* mask   ||   G[N][Kin] = dZ[M][N]^T X[M][Kin]
 template <class EpiD, class EpiW>
 inline hipError_t gemm_bwd_pair_epi(const float* dZd, int ldzd, const float* Wd, int ldwd, int Md, int Kind, int Nd,
                                     const EpiD& ed, const float* dZw, int ldzw, const float* Xw, int ldxw, int Nw,
-                                    int Kinw, int Mw, const EpiW& ew, hipStream_t st, const AdamSeg* ad = nullptr) {
+                                    int Kinw, int Mw, const EpiW& ew, hipStream_t st, const AdamPair* ad = nullptr) {
     const DgradPlan d = plan_dgrad(dZd, ldzd, Wd, ldwd, Md, Kind, Nd);
     const WgradPlan w = plan_wgrad(dZw, ldzw, Xw, ldxw, Nw, Kinw, Mw);
     if constexpr (std::is_same<EpiD, EpiMask>::value) {
@@ -2103,19 +2118,19 @@ inline hipError_t gemm_bwd_pair_epi(const float* dZd, int ldzd, const float* Wd,
             const GemmGrid g = make_grid(Md, Kind, 64, 32);
             PVAE_LAUNCH((bwd_pair64_kernel<EpiD, EpiW>), dim3(g.grid + w.grid + w.nbias + adam_blocks(ad)), dim3(256), st,
                         GemmArgs{dZd, ldzd, Wd, ldwd, Nd, g.tiles_q, g.tiles_p, g.p_per_xcd}, ed, g.grid, w.ga, ew, w.grid,
-                        ad ? *ad : AdamSeg());
+                        ad ? *ad : AdamPair());
             return hipGetLastError();
         }
     }
     PVAE_LAUNCH((bwd_pair_kernel<EpiD, EpiW>), dim3(d.grid + w.grid + w.nbias + adam_blocks(ad)), dim3(256), st,
-                       d.ga, ed, d.grid, w.ga, ew, w.grid, ad ? *ad : AdamSeg());
+                       d.ga, ed, d.grid, w.ga, ew, w.grid, ad ? *ad : AdamPair());
     return hipGetLastError();
 }
 template <class EpiW>
 inline hipError_t gemm_bwd_pair(const float* dZd, int ldzd, const float* Wd, int ldwd, const float* mask, int ldm,
                                 float* dXd, int ldod, int Md, int Kind, int Nd,
                                 const float* dZw, int ldzw, const float* Xw, int ldxw, int Nw, int Kinw, int Mw,
-                                const EpiW& ew, hipStream_t st, const AdamSeg* ad = nullptr, int act = 1) {
+                                const EpiW& ew, hipStream_t st, const AdamPair* ad = nullptr, int act = 1) {
     const EpiMask ed{dXd, ldod, mask, ldm, act};
     return gemm_bwd_pair_epi(dZd, ldzd, Wd, ldwd, Md, Kind, Nd, ed, dZw, ldzw, Xw, ldxw, Nw, Kinw, Mw, ew, st, ad);
 }

@@ -32,9 +32,9 @@ int main() {
     ea.b = W0 + (size_t)N * K0; ea.bm = m0 + (size_t)N * K0; ea.bv = v0 + (size_t)N * K0;
     EpiGradStore es{G0, K0};
     es.gb = G0 + (size_t)N * K0;
-    AdamSeg ad;
-    ad.p = p1; ad.g = g1; ad.m = m1; ad.v = v1; ad.n4 = (long long)(n1 / 4); ad.s = as;
-    const AdamSeg none;
+    AdamSeg seg;
+    seg.p = p1; seg.g = g1; seg.m = m1; seg.v = v1; seg.n4 = (long long)(n1 / 4); seg.s = as;
+    const AdamPair ad(seg), none;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     auto timeit = [&](const char* name, auto go) {
         for (int i = 0; i < 20; ++i) go();
