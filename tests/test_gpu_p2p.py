@@ -26,10 +26,15 @@ from physicsvae_amd.engine import make_step_params
 arch = R.make_arch(23, 7, latent=8, te=(64, 2), md=(96, 2), wm=(128, 3))
 data = R.synth_demo(0, 3, 40, 23, 7, kind="dynamics")          # 117 windows
 per_gpu = int(sys.argv[3])
+look = int(os.environ.get("P2P_TEST_LOOKAHEAD", "1"))
 with contextlib.redirect_stdout(io.StringIO()):
-    tr = make_trainer(arch, data, per_gpu, m_world=1, device="cuda:0", eps_fn=R.eps_stream(2, 8))
+    tr = make_trainer(arch, data, per_gpu, m_world=1, device="cuda:0", eps_fn=R.eps_stream(2, 8),
+                      extra={"lookahead": look} if look > 1 else None)
 tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, 1), 3))
 eng = tr.engine
+if "P2P_TEST_DELAY_US" in os.environ:          # a spin kernel in front of every exchange launch, a different one per rank
+    delay = int(os.environ["P2P_TEST_DELAY_US"].split(",")[rank])
+    eng.comm_config(float(os.environ.get("PVAE_DP_BUCKET_MB", "0")), delay)
 res = {}
 if mode == "train":
     if os.environ.get("PVAE_DP_EXCHANGE") == "p2p":
@@ -133,6 +138,30 @@ def test_p2p_bucketed_overlapped_equals_in_line(tmp_path):
     for k in inline[0]["sd"]:
         assert torch.equal(inline[0]["sd"][k], bucketed[0]["sd"][k]), k
         assert torch.equal(bucketed[0]["sd"][k], bucketed[1]["sd"][k]), k
+
+
+def test_p2p_ranks_that_arrive_at_different_times(tmp_path):
+    """Skew between the ranks (a 0 / 700 us spin kernel in front of every exchange launch of rank 0 / rank 1, in line and
+    with per-layer buckets on the exchange stream): the early rank waits inside its exchange launch for the late one's
+    "gradient final" flag and for its "done" flag; parameters end bit-identical to the run without skew."""
+    base = _run(tmp_path, 2, 16, "noskew", PVAE_DP_EXCHANGE="p2p")
+    for tag, port, extra in (("skew", "29565", {}), ("skewb", "29566", {"PVAE_DP_BUCKET_MB": "0.01"})):
+        got = _run(tmp_path, 2, 16, tag, port=port, PVAE_DP_EXCHANGE="p2p", P2P_TEST_DELAY_US="0,700", **extra)
+        assert all(r["timeouts"] == 0 for r in got)
+        for k in base[0]["sd"]:
+            assert torch.equal(base[0]["sd"][k], got[0]["sd"][k]) and torch.equal(got[0]["sd"][k], got[1]["sd"][k]), (tag, k)
+
+
+def test_p2p_with_a_lookahead_unroll(tmp_path):
+    """lookahead 2 (stacked time steps, weight gradients paired with step 0's input-gradient launches) under the
+    peer-mapped exchange: replicas bit-identical and equal to the all-reduce exchange of the same schedule."""
+    p2p = _run(tmp_path, 2, 16, "p2pL2", PVAE_DP_EXCHANGE="p2p", P2P_TEST_LOOKAHEAD="2")
+    plain = _run(tmp_path, 2, 16, "plainL2", port="29567", P2P_TEST_LOOKAHEAD="2")
+    assert all(r["timeouts"] == 0 for r in p2p)
+    for k in p2p[0]["sd"]:
+        assert torch.equal(p2p[0]["sd"][k], p2p[1]["sd"][k]), k
+        assert torch.equal(p2p[0]["sd"][k], plain[0]["sd"][k]), k
+    assert p2p[0]["losses"] == plain[0]["losses"]
 
 
 def test_p2p_four_ranks_replicas_identical_and_match_one_process(tmp_path):
