@@ -88,7 +88,7 @@ def parse_args(argv=None):
     ap.add_argument("--config", choices=["c2", "c5"], default="c2",
                     help="c2 = BASELINE configs[1..3] sizes (default); c5 = configs[4]: 1e6 transitions, "
                          "dim_state_body 400, dim_action 90, 512 rows per GPU")
-    ap.add_argument("--exchange", choices=["inline", "bucketed", "sharded", "p2p"], default=None,
+    ap.add_argument("--exchange", choices=["inline", "bucketed", "sharded", "p2p", "p2p_push"], default=None,
                     help="N > 1: how the gradient is exchanged (the trainer's dp_exchange): RCCL all-reduce in line / in 6 MiB "
                          "overlapped buckets / RCCL reduce-scatter + sharded Adam + all-gather / the direct all-pairs exchange "
                          "over peer-mapped arenas (no RCCL); default: the library's own schedule")
@@ -407,8 +407,9 @@ def main():
     if not dp.collective:
         transport = "none (single rank: Adam inside the backward launches, deferred one launch behind each weight gradient)"
     elif eng.has_p2p:
-        transport = ("in-library peer-mapped exchange (hipIpc-mapped arenas, no RCCL): one launch per stack -- rank-order "
-                     "reduce-scatter by the slice owners, Adam on the owned slice, parameters pushed to every peer")
+        transport = ("in-library peer-mapped exchange (hipIpc-mapped arenas, no RCCL; %s form): one launch per stack -- rank-order "
+                     "reduce-scatter by the slice owners, Adam on the owned slice, parameters pushed to every peer"
+                     % ("push" if a.exchange == "p2p_push" else "pull"))
     elif eng.has_comm:
         transport = {None: "in-library RCCL all-reduce + flat Adam; default schedule: in line on the compute stream in the "
                            "world phase, 6 MiB buckets overlapped on the exchange stream in the joint phase",
@@ -570,11 +571,11 @@ def main():
         def one(mode):
             entry = {}
             try:
-                if mode == "p2p":
+                if mode in ("p2p", "p2p_push"):
                     # (a peer that never answers must cost this run a fraction of a second per wait, not the
                     #  library's default 20 s: the time-out is read when the peers are mapped)
                     os.environ.setdefault("PVAE_P2P_TIMEOUT_MS", "250")
-                    if not dp.attach_p2p(eng):                     # collective: every rank agrees on the outcome
+                    if not dp.attach_p2p(eng, mode):               # collective: every rank agrees on the outcome
                         return {"skipped": "peer-mapped exchange could not be set up (see stderr)"}
                 elif mode == "local":
                     if not eng.in_library_exchange:
@@ -587,7 +588,7 @@ def main():
                     eng.comm_config(6.0 if mode == "bucketed" else 0.0)
                 phase, nets = set_phase(a.phase)
                 run_steps(phase, nets, 10, 0)
-                if mode == "p2p":                                  # all ranks agree on whether any wait gave up
+                if mode in ("p2p", "p2p_push"):                    # all ranks agree on whether any wait gave up
                     bad = torch.tensor([eng.p2p_status()[2]], dtype=torch.int64, device=dev)
                     dist.all_reduce(bad, op=dist.ReduceOp.MAX)
                     if int(bad.item()):
@@ -603,13 +604,13 @@ def main():
                 if coll:
                     entry["exchange_launches_per_step"] = coll["launches"] / 40
                     entry["us_per_step_inside_exchange_launches"] = coll["total_ms"] / 40 * 1e3
-                if mode == "p2p":
+                if mode in ("p2p", "p2p_push"):
                     entry["p2p_ranks"], entry["timeouts"] = eng.p2p_status()[1:]
             except Exception as exc:                               # noqa: BLE001  (a rank-local failure: say so, go on)
                 entry = {"error": str(exc)[:300]}
             return entry
 
-        for mode in ("inline", "bucketed", "sharded", "p2p", "local"):
+        for mode in ("inline", "bucketed", "sharded", "p2p", "p2p_push", "local"):
             sweep[mode] = one(mode)
         base = sweep["local"].get("ms_per_step")
         for mode, e in sweep.items():

@@ -290,12 +290,16 @@ int pvae_comm_config(pvae_ctx* ctx, int64_t bucket_bytes, int32_t test_delay_us)
 enum { PVAE_EXCHANGE_ALLREDUCE = 0, PVAE_EXCHANGE_SHARDED = 1, PVAE_EXCHANGE_P2P = 2,
        PVAE_EXCHANGE_LOCAL = 3 /* MEASUREMENT ONLY: no exchange at all, every rank applies Adam to its own
                                   gradient (replicas diverge) -- the step time without the collective, against
-                                  which bench.py reports what an exchange adds */ };
+                                  which bench.py reports what an exchange adds */,
+       PVAE_EXCHANGE_P2P_PUSH = 4 /* PVAE_EXCHANGE_P2P with remote WRITES only: every rank pushes its contribution to
+                                  slice q into owner q's staging buffer, the owner sums its slice from LOCAL memory in
+                                  rank order, applies Adam and pushes the parameters (same result bit for bit; links
+                                  that favour posted writes over read round trips want this form) */ };
 int pvae_comm_mode(pvae_ctx* ctx, int mode);
 /* Peer-mapped exchange (PVAE_EXCHANGE_P2P).  The reference has no counterpart (tm:131-161 is one process);
  * this is what `north_star` asks for on top of it.  Set-up, after pvae_bind_arenas:
- *   pvae_p2p_export   writes PVAE_P2P_BLOB_BYTES describing this rank's gradient arena, parameter arena and
- *                     flag block (hipIpcGetMemHandle of the allocations they live in + offsets).  The arenas
+ *   pvae_p2p_export   writes PVAE_P2P_BLOB_BYTES describing this rank's gradient arena, parameter arena, flag
+ *                     block and staging buffer (hipIpcGetMemHandle of the allocations they live in + offsets).  The arenas
  *                     must come from hipMalloc (PyTorch's default allocator does; expandable segments do not).
  *   (caller)          all-gathers the blobs of all ranks, by any transport (torch.distributed, a file, MPI)
  *   pvae_p2p_open     collective in effect: maps every peer's three buffers (hipIpcOpenMemHandle) -- peers may
@@ -305,12 +309,17 @@ int pvae_comm_mode(pvae_ctx* ctx, int mode);
  *                     PVAE_P2P_TIMEOUT_MS): results are then garbage and the caller must stop.  Synchronises
  *                     `stream`.  *rank / *world as passed to pvae_p2p_open (0 ranks: not open).
  * pvae_dp_train_step then runs with or without an RCCL communicator. */
-#define PVAE_P2P_BLOB_BYTES 256
+#define PVAE_P2P_BLOB_BYTES 512
 #define PVAE_P2P_MAX_RANKS 8
 int pvae_p2p_export(pvae_ctx* ctx, void* blob);
 int pvae_p2p_open(pvae_ctx* ctx, int rank, int world, const void* blobs);
 int pvae_p2p_close(pvae_ctx* ctx);
 int pvae_p2p_status(pvae_ctx* ctx, int* rank, int* world, uint32_t* timeouts, void* stream);
+/* Collective in effect (every rank calls it after pvae_p2p_open): each rank writes a record into every peer's flag
+ * block, signals, checks the records that arrived in its own block and reads its records back from the peers' --
+ * remote write, remote read and flag delivery are proven (or fail within 1 s) before the first training step.
+ * Synchronises `stream`. */
+int pvae_p2p_selftest(pvae_ctx* ctx, void* stream);
 /* One bucket through the peer-mapped exchange, stream-ordered like any launch of this library: the slice
  * [offset, offset + count) of the gradient arena (inside stack `net`, float4-aligned) is summed over the ranks
  * by its owners, Adam-applied and the updated parameters written to every rank -- what pvae_dp_train_step does

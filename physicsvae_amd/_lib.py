@@ -32,8 +32,8 @@ PHASE_WORLD, PHASE_JOINT = 0, 1
 FLAG_FUSED_ADAM, FLAG_NO_BACKWARD = 1, 2
 ABI_VERSION = 5
 LOSS_MSE, LOSS_L1 = 0, 1
-EXCHANGE_ALLREDUCE, EXCHANGE_SHARDED, EXCHANGE_P2P, EXCHANGE_LOCAL = 0, 1, 2, 3
-P2P_BLOB_BYTES, P2P_MAX_RANKS = 256, 8
+EXCHANGE_ALLREDUCE, EXCHANGE_SHARDED, EXCHANGE_P2P, EXCHANGE_LOCAL, EXCHANGE_P2P_PUSH = 0, 1, 2, 3, 4
+P2P_BLOB_BYTES, P2P_MAX_RANKS = 512, 8
 
 
 class Config(C.Structure):
@@ -93,6 +93,7 @@ _SIGS = {
     "pvae_p2p_export": (C.c_int, [_P, _P]),
     "pvae_p2p_open": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "pvae_p2p_close": (C.c_int, [_P]),
+    "pvae_p2p_selftest": (C.c_int, [_P, _P]),
     "pvae_p2p_exchange": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.POINTER(StepParams), _P]),
     "pvae_p2p_status": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32), _P]),
     "pvae_allreduce_grads": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),

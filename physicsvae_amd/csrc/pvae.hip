@@ -198,7 +198,9 @@ struct pvae_ctx {
         float* grads[PVAE_P2P_MAX_RANKS] = {};
         float* params[PVAE_P2P_MAX_RANKS] = {};
         unsigned* peer_flags[PVAE_P2P_MAX_RANKS] = {};
-        void* mapped[PVAE_P2P_MAX_RANKS][3] = {};        // what hipIpcOpenMemHandle returned (to close)
+        float* staging = nullptr;                        // own staging buffer of the push form (hipMalloc, arena-sized)
+        float* peer_staging[PVAE_P2P_MAX_RANKS] = {};
+        void* mapped[PVAE_P2P_MAX_RANKS][4] = {};        // what hipIpcOpenMemHandle returned (to close)
         unsigned epoch = 0;                              // exchanges issued so far (identical on every rank)
         long long timeout_ticks = 20ll * 100000000ll;    // 100 MHz wall clock
     } p2p;
@@ -630,11 +632,15 @@ adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __re
 // peer that never signals raises the error word instead of hanging the GPU.
 // Flag block (unsigned words): [0, 8) ready[src], [8, 16) done[src], 16 ticket, 17 waits that gave up.
 // ---------------------------------------------------------------------------------------
-constexpr int kP2pReady = 0, kP2pDone = 8, kP2pTicket = 16, kP2pErr = 17, kP2pFlagBytes = 4096;
+//                              18 second ticket, [24, 32) pushed[src] (push form), [32, 40) self-test tokens,
+//                              [64, 96) self-test payload (4 words per source rank).
+constexpr int kP2pReady = 0, kP2pDone = 8, kP2pTicket = 16, kP2pErr = 17, kP2pTicket2 = 18, kP2pPushed = 24, kP2pSelf = 32,
+              kP2pPayload = 64, kP2pFlagBytes = 4096;
 struct P2pArgs {
     float* g[PVAE_P2P_MAX_RANKS];           // gradient arenas, bucket offset applied (g[me]: local)
     float* p[PVAE_P2P_MAX_RANKS];           // parameter arenas, bucket offset applied
     unsigned* f[PVAE_P2P_MAX_RANKS];        // flag blocks
+    float* stage[PVAE_P2P_MAX_RANKS];       // staging buffers (push form): [N][slice] floats at each owner
     float* m; float* v;                     // local moments, bucket offset applied
     long long n4;                           // float4 elements in the bucket
     int me;
@@ -708,6 +714,112 @@ __global__ void __launch_bounds__(256) p2p_exchange_kernel(P2pArgs a) {
         p2p_st(a.f[tid] + kP2pDone + me, a.epoch);
         p2p_wait(mine + kP2pDone + tid, a.epoch, a.timeout_ticks, mine + kP2pErr);
     }
+}
+
+// The PUSH form of the same exchange (PVAE_EXCHANGE_P2P_PUSH): remote WRITES only.  Posted writes pipeline over a link
+// where reads are round trips, so this is the form a fabric with write-favouring links wants; which of the two wins
+// on xGMI is for the first multi-GPU run to say (bench.py's exchange_sweep times both).
+//   1. every rank writes, for each peer q, ITS contribution to slice q into slot `me` of q's staging buffer;
+//      the last workgroup to finish (ticket) fences and tells every peer "pushed";
+//   2. every workgroup waits for all peers' "pushed", then the owner sums its slice in rank order -- its own gradient
+//      from the arena, the others from its LOCAL staging (system-scope loads: remote agents wrote it) --, applies Adam
+//      and pushes the new parameters into every peer's parameter arena;
+//   3. last workgroup: "done" to every peer, wait for every peer's "done" (the staging may then be overwritten).
+template <int N>
+__global__ void __launch_bounds__(256) p2p_push_exchange_kernel(P2pArgs a) {
+    unsigned* mine = a.f[a.me];
+    const int tid = threadIdx.x, me = a.me;
+    const long long S = (a.n4 + N - 1) / N, stride = gridDim.x * 256ll;
+    __shared__ unsigned last;
+    {   // 1. scatter-push
+        __amdgpu_buffer_rsrc_t rs[N];
+#pragma unroll
+        for (int q = 0; q < N; ++q)
+            rs[q] = __builtin_amdgcn_make_buffer_rsrc(a.stage[q] + (size_t)me * S * 4, 0, (unsigned)(S * 16), 0x00020000);
+        for (long long i = blockIdx.x * 256ll + tid; i < S; i += stride) {
+#pragma unroll
+            for (int q = 0; q < N; ++q) {
+                if (q == me || q * S + i >= a.n4) continue;
+                const v4f g = reinterpret_cast<const v4f*>(a.g[me])[q * S + i];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, g), rs[q], (unsigned)(i * 16), 0, 17);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            last = atomicAdd(mine + kP2pTicket2, 1u) == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (last) {
+            if (tid == 0) mine[kP2pTicket2] = 0;
+            if (tid < N && tid != me) p2p_st(a.f[tid] + kP2pPushed + me, a.epoch);
+        }
+    }
+    if (tid < N && tid != me) {       // 2. everything for my slice has arrived
+        p2p_wait(mine + kP2pPushed + tid, a.epoch, a.timeout_ticks, mine + kP2pErr);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    __syncthreads();
+    const long long lo = me * S, hi = lo + S < a.n4 ? lo + S : a.n4;
+    if (lo < hi) {
+        const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(a.stage[me], 0, (unsigned)(N * S * 16), 0x00020000);
+        __amdgpu_buffer_rsrc_t rp[N];
+#pragma unroll
+        for (int q = 0; q < N; ++q) rp[q] = __builtin_amdgcn_make_buffer_rsrc(a.p[q] + 4 * lo, 0, (unsigned)((hi - lo) * 16), 0x00020000);
+        for (long long i = blockIdx.x * 256ll + tid; i < hi - lo; i += stride) {
+            v4f g[N];
+#pragma unroll
+            for (int q = 0; q < N; ++q)
+                g[q] = q == me ? reinterpret_cast<const v4f*>(a.g[me])[lo + i]
+                               : __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rst, (unsigned)((q * S + i) * 16), 0, 17));
+            v4f pp = reinterpret_cast<const v4f*>(a.p[me])[lo + i];
+            v4f mm = reinterpret_cast<const v4f*>(a.m)[lo + i];
+            v4f vv = reinterpret_cast<const v4f*>(a.v)[lo + i];
+            v4f sum = g[0];
+#pragma unroll
+            for (int q = 1; q < N; ++q) sum += g[q];                // rank order
+            adam_update4(sum, pp, mm, vv, a.s);
+            store_stream(a.m + 4 * (lo + i), mm);
+            store_stream(a.v + 4 * (lo + i), vv);
+#pragma unroll
+            for (int q = 0; q < N; ++q) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, pp), rp[q], (unsigned)(i * 16), 0, 17);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        last = atomicAdd(mine + kP2pTicket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    if (tid == 0) mine[kP2pTicket] = 0;
+    if (tid < N && tid != me) {
+        p2p_st(a.f[tid] + kP2pDone + me, a.epoch);
+        p2p_wait(mine + kP2pDone + tid, a.epoch, a.timeout_ticks, mine + kP2pErr);
+    }
+}
+
+// Self-test of the mappings, run once when the peers are opened: every rank writes a 4-word record into its slot of
+// every peer's flag block (remote write), signals, waits for the peers' signals, checks the records that arrived in
+// its own block (written by remote agents) and reads back, from every peer's block, the record it wrote there
+// (remote read).  Anything wrong -- a mapping that does not reach the peer, a flag that never arrives -- raises the
+// error word within `timeout_ticks` instead of surfacing as a hang in the first training step.
+__global__ void p2p_selftest_kernel(P2pArgs a, int n, unsigned token) {
+    unsigned* mine = a.f[a.me];
+    const int q = threadIdx.x, me = a.me;
+    if (q >= n || q == me) return;
+    unsigned* theirs = a.f[q];
+    for (int wd = 0; wd < 4; ++wd) p2p_st(theirs + kP2pPayload + me * 4 + wd, wd == 0 ? token : wd == 1 ? (unsigned)me : wd == 2 ? (unsigned)q : 0xC0FFEEu);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    p2p_st(theirs + kP2pSelf + me, token);
+    p2p_wait(mine + kP2pSelf + q, token, a.timeout_ticks, mine + kP2pErr);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    const bool got = p2p_ld(mine + kP2pPayload + q * 4) == token && p2p_ld(mine + kP2pPayload + q * 4 + 1) == (unsigned)q &&
+                     p2p_ld(mine + kP2pPayload + q * 4 + 2) == (unsigned)me && p2p_ld(mine + kP2pPayload + q * 4 + 3) == 0xC0FFEEu;
+    const bool back = p2p_ld(theirs + kP2pPayload + me * 4) == token && p2p_ld(theirs + kP2pPayload + me * 4 + 3) == 0xC0FFEEu;
+    if (!got || !back) atomicAdd(mine + kP2pErr, 1u);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1433,6 +1545,7 @@ void pvae_destroy(pvae_ctx* ctx) {
     if (ctx) {
         pvae_p2p_close(ctx);
         if (ctx->p2p.flags) (void)hipFree(ctx->p2p.flags);
+        if (ctx->p2p.staging) (void)hipFree(ctx->p2p.staging);
     }
     delete ctx;
 }
@@ -2338,8 +2451,8 @@ static int ensure_comm_stream(pvae_ctx* c) {
 struct P2pBlob {                                          // PVAE_P2P_BLOB_BYTES on the wire
     uint32_t magic, abi;
     int64_t arena_floats;
-    hipIpcMemHandle_t h[3];                               // allocations holding grads, params, flags
-    int64_t off[3];                                       // byte offset of the buffer inside its allocation
+    hipIpcMemHandle_t h[4];                               // allocations holding grads, params, flags, staging
+    int64_t off[4];                                       // byte offset of the buffer inside its allocation
 };
 static_assert(sizeof(P2pBlob) <= PVAE_P2P_BLOB_BYTES, "blob layout");
 constexpr uint32_t kP2pMagic = 0x50325056u;               // "PV2P"
@@ -2354,9 +2467,10 @@ int pvae_p2p_export(pvae_ctx* c, void* blob) {
     P2pBlob b;
     memset(&b, 0, sizeof(b));
     b.magic = kP2pMagic; b.abi = PVAE_ABI_VERSION; b.arena_floats = c->L.arena_floats;
-    void* ptrs[3] = {c->grads, c->params, c->p2p.flags};
-    const char* what[3] = {"gradient arena", "parameter arena", "flag block"};
-    for (int k = 0; k < 3; ++k) {
+    if (!c->p2p.staging) HIP_TRY(hipMalloc((void**)&c->p2p.staging, ((size_t)c->L.arena_floats + 256) * sizeof(float)));
+    void* ptrs[4] = {c->grads, c->params, c->p2p.flags, c->p2p.staging};
+    const char* what[4] = {"gradient arena", "parameter arena", "flag block", "staging buffer"};
+    for (int k = 0; k < 4; ++k) {
         void* base = nullptr;
         size_t size = 0;
         if (hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, ptrs[k]) != hipSuccess || !base)
@@ -2377,7 +2491,7 @@ int pvae_p2p_close(pvae_ctx* c) {
     if (!c) return fail(-1, "null ctx");
     pvae_ctx::P2p& P = c->p2p;
     for (int q = 0; q < PVAE_P2P_MAX_RANKS; ++q)
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 4; ++k) {
             if (!P.mapped[q][k]) continue;
             bool dup = false;                             // one mapping may serve two buffers of a peer
             for (int j = 0; j < k; ++j) dup = dup || P.mapped[q][j] == P.mapped[q][k];
@@ -2385,8 +2499,9 @@ int pvae_p2p_close(pvae_ctx* c) {
         }
     memset(P.mapped, 0, sizeof(P.mapped));
     memset(P.grads, 0, sizeof(P.grads)); memset(P.params, 0, sizeof(P.params)); memset(P.peer_flags, 0, sizeof(P.peer_flags));
+    memset(P.peer_staging, 0, sizeof(P.peer_staging));
     P.open = false; P.world = 0; P.rank = 0;
-    if (c->exchange_mode == PVAE_EXCHANGE_P2P) c->exchange_mode = PVAE_EXCHANGE_ALLREDUCE;
+    if (c->exchange_mode == PVAE_EXCHANGE_P2P || c->exchange_mode == PVAE_EXCHANGE_P2P_PUSH) c->exchange_mode = PVAE_EXCHANGE_ALLREDUCE;
     if (!c->comm) { c->comm_world = 1; c->comm_rank = 0; }
     return 0;
 }
@@ -2409,11 +2524,11 @@ int pvae_p2p_open(pvae_ctx* c, int rank, int world, const void* blobs) {
             return fail(-1, "blob of rank %d does not describe a matching ctx", q);
         }
         if (q == rank) {
-            P.grads[q] = c->grads; P.params[q] = c->params; P.peer_flags[q] = P.flags;
+            P.grads[q] = c->grads; P.params[q] = c->params; P.peer_flags[q] = P.flags; P.peer_staging[q] = P.staging;
             continue;
         }
-        void* base[3] = {nullptr, nullptr, nullptr};
-        for (int k = 0; k < 3; ++k) {
+        void* base[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int k = 0; k < 4; ++k) {
             for (int j = 0; j < k; ++j)                   // two buffers inside one allocation: open it once
                 if (memcmp(&b.h[j], &b.h[k], sizeof(b.h[k])) == 0) base[k] = base[j];
             if (!base[k]) {
@@ -2428,6 +2543,7 @@ int pvae_p2p_open(pvae_ctx* c, int rank, int world, const void* blobs) {
         P.grads[q] = (float*)((char*)base[0] + b.off[0]);
         P.params[q] = (float*)((char*)base[1] + b.off[1]);
         P.peer_flags[q] = (unsigned*)((char*)base[2] + b.off[2]);
+        P.peer_staging[q] = (float*)((char*)base[3] + b.off[3]);
     }
     P.rank = rank; P.world = world; P.epoch = 0; P.open = true;
     if (const char* e = getenv("PVAE_P2P_TIMEOUT_MS")) {
@@ -2456,6 +2572,31 @@ int pvae_p2p_status(pvae_ctx* c, int* rank, int* world, uint32_t* timeouts, void
     return 0;
 }
 
+int pvae_p2p_selftest(pvae_ctx* c, void* stream) {
+    if (!c) return fail(-1, "null ctx");
+    pvae_ctx::P2p& P = c->p2p;
+    if (!P.open) return fail(-2, "peer-mapped exchange not open (pvae_p2p_open)");
+    hipStream_t st = (hipStream_t)stream;
+    P2pArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int q = 0; q < P.world; ++q) a.f[q] = P.peer_flags[q];
+    a.me = P.rank;
+    a.timeout_ticks = P.timeout_ticks < 100000000ll ? P.timeout_ticks : 100000000ll;      // at most 1 s
+    uint32_t before = 0, after = 0;
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(&before, P.flags + kP2pErr, sizeof(before), hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(p2p_selftest_kernel, dim3(1), dim3(64), 0, st, a, P.world, 0x5E1F0000u + (unsigned)P.world);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(&after, P.flags + kP2pErr, sizeof(after), hipMemcpyDeviceToHost));
+    if (after != before) {
+        HIP_TRY(hipMemcpy(P.flags + kP2pErr, &before, sizeof(before), hipMemcpyHostToDevice));
+        return fail(-22, "peer-mapped exchange self-test failed on rank %d: %u record(s) / flag(s) from peers wrong or missing",
+                    P.rank, after - before);
+    }
+    return 0;
+}
+
 // one bucket through the peer-mapped exchange (see p2p_exchange_kernel)
 static int p2p_exchange(pvae_ctx* c, int net, int64_t off, int64_t cnt, const pvae_step_params* sp, hipStream_t cs) {
     pvae_ctx::P2p& P = c->p2p;
@@ -2465,7 +2606,10 @@ static int p2p_exchange(pvae_ctx* c, int net, int64_t off, int64_t cnt, const pv
     if ((off & 3) || (cnt & 3) || cnt <= 0) return fail(-1, "bucket [%lld, +%lld) not float4-aligned", (long long)off, (long long)cnt);
     P2pArgs a;
     memset(&a, 0, sizeof(a));
-    for (int q = 0; q < P.world; ++q) { a.g[q] = P.grads[q] + off; a.p[q] = P.params[q] + off; a.f[q] = P.peer_flags[q]; }
+    for (int q = 0; q < P.world; ++q) {
+        a.g[q] = P.grads[q] + off; a.p[q] = P.params[q] + off; a.f[q] = P.peer_flags[q]; a.stage[q] = P.peer_staging[q];
+    }
+    const bool push = c->exchange_mode == PVAE_EXCHANGE_P2P_PUSH;
     a.m = c->m + off; a.v = c->v + off;
     a.n4 = cnt / 4; a.me = P.rank; a.epoch = ++P.epoch; a.timeout_ticks = P.timeout_ticks;
     a.s = adam_scalars(sp, net);
@@ -2475,7 +2619,10 @@ static int p2p_exchange(pvae_ctx* c, int net, int64_t off, int64_t cnt, const pv
     if (grid < 1) grid = 1;
     const int ps = g_prof.begin_range(4, (double)cnt * sizeof(float), cs);
     switch (P.world) {
-#define PVAE_P2P_CASE(N) case N: hipLaunchKernelGGL((p2p_exchange_kernel<N>), dim3(grid), dim3(256), 0, cs, a); break;
+#define PVAE_P2P_CASE(N) case N:                                                                         \
+        if (push) hipLaunchKernelGGL((p2p_push_exchange_kernel<N>), dim3(grid), dim3(256), 0, cs, a); \
+        else hipLaunchKernelGGL((p2p_exchange_kernel<N>), dim3(grid), dim3(256), 0, cs, a);           \
+        break;
         PVAE_P2P_CASE(1) PVAE_P2P_CASE(2) PVAE_P2P_CASE(3) PVAE_P2P_CASE(4)
         PVAE_P2P_CASE(5) PVAE_P2P_CASE(6) PVAE_P2P_CASE(7) PVAE_P2P_CASE(8)
 #undef PVAE_P2P_CASE
@@ -2500,7 +2647,7 @@ int pvae_p2p_exchange(pvae_ctx* c, int net, int64_t offset, int64_t count, const
 
 int pvae_comm_mode(pvae_ctx* c, int mode) {
     if (!c) return fail(-1, "null ctx");
-    if (mode == PVAE_EXCHANGE_P2P) {
+    if (mode == PVAE_EXCHANGE_P2P || mode == PVAE_EXCHANGE_P2P_PUSH) {
         if (!c->p2p.open) return fail(-2, "peer-mapped exchange not open (pvae_p2p_export / pvae_p2p_open)");
         c->exchange_mode = mode;
         return 0;
@@ -2610,7 +2757,8 @@ static int exchange_bucket(pvae_ctx* c, int net, const Bucket& b, const pvae_ste
     // bucket (reduce-scatter, in place), applies Adam to that slice (1/N of the p, g, m, v traffic) and the
     // updated parameter slices are all-gathered in place.  Same bytes on the links as a ring all-reduce;
     // the moments of the other ranks' slices are never touched here (they stay at whatever they were).
-    if (c->exchange_mode == PVAE_EXCHANGE_P2P) return p2p_exchange(c, net, b.off, b.cnt, sp, cs);
+    if (c->exchange_mode == PVAE_EXCHANGE_P2P || c->exchange_mode == PVAE_EXCHANGE_P2P_PUSH)
+        return p2p_exchange(c, net, b.off, b.cnt, sp, cs);
     if (c->exchange_mode == PVAE_EXCHANGE_LOCAL) return pvae_adam_segment(c, net, b.off, b.cnt, sp, cs);
     const int64_t N = c->comm_world;
     if (c->exchange_mode == PVAE_EXCHANGE_SHARDED && g_rccl.ReduceScatter && g_rccl.AllGather &&
@@ -2648,7 +2796,8 @@ int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t row
                        const float* eps, float* loss_out, int64_t next_first, int32_t next_rows, void* stream) {
     int rc = check_ready(c, true);
     if (rc) return rc;
-    if (!c->comm && !(c->p2p.open && (c->exchange_mode == PVAE_EXCHANGE_P2P || c->exchange_mode == PVAE_EXCHANGE_LOCAL)))
+    if (!c->comm && !(c->p2p.open && (c->exchange_mode == PVAE_EXCHANGE_P2P || c->exchange_mode == PVAE_EXCHANGE_P2P_PUSH ||
+                                      c->exchange_mode == PVAE_EXCHANGE_LOCAL)))
         return fail(-2, "no communicator (pvae_comm_init) and no peer-mapped exchange (pvae_p2p_open + pvae_comm_mode)");
     if (!sp) return fail(-1, "null step params");
     if (!c->grads || !c->m || !c->v) return fail(-2, "grads / Adam moment arenas not bound");

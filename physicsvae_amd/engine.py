@@ -351,10 +351,12 @@ class HipEngine:
 
     def comm_mode(self, mode):
         """Exchange form of dp_train_step (include/pvae.h): "allreduce" (False) = all-reduce + replicated Adam,
-        "sharded" (True) = reduce-scatter -> Adam on the owned 1/N slice -> all-gather of the parameters, "p2p" =
-        the same shape as ONE launch over peer-mapped arenas, no RCCL (needs p2p_open)."""
+        "sharded" (True) = reduce-scatter -> Adam on the owned 1/N slice -> all-gather of the parameters, "p2p" /
+        "p2p_push" = the same shape as ONE launch over peer-mapped arenas, no RCCL (needs p2p_open; pull: owners read
+        their slice from the peers' arenas, push: every rank writes its contributions into the owners' staging)."""
         code = {False: _lib.EXCHANGE_ALLREDUCE, True: _lib.EXCHANGE_SHARDED, "allreduce": _lib.EXCHANGE_ALLREDUCE,
-                "sharded": _lib.EXCHANGE_SHARDED, "p2p": _lib.EXCHANGE_P2P, "local": _lib.EXCHANGE_LOCAL}[mode]
+                "sharded": _lib.EXCHANGE_SHARDED, "p2p": _lib.EXCHANGE_P2P, "p2p_push": _lib.EXCHANGE_P2P_PUSH,
+                "local": _lib.EXCHANGE_LOCAL}[mode]
         _lib.check(self.lib.pvae_comm_mode(self.ctx, code), "pvae_comm_mode")
 
     # -- peer-mapped exchange (PVAE_EXCHANGE_P2P) -------------------------------------------------
@@ -378,6 +380,11 @@ class HipEngine:
         self._need_gpu()
         _lib.check(self.lib.pvae_p2p_exchange(self.ctx, int(net), int(off), int(cnt), C.byref(sp), self._stream()),
                    "pvae_p2p_exchange")
+
+    def p2p_selftest(self):
+        """Prove remote write, remote read and flag delivery between all mapped peers (every rank calls it)."""
+        self._need_gpu()
+        _lib.check(self.lib.pvae_p2p_selftest(self.ctx, self._stream()), "pvae_p2p_selftest")
 
     def p2p_close(self):
         if self.ctx is not None and self.has_p2p:

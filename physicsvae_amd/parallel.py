@@ -89,7 +89,7 @@ class DataParallel:
             return False
         return True
 
-    def attach_p2p(self, engine):
+    def attach_p2p(self, engine, form="p2p"):
         """Peer-mapped exchange (`dp_exchange = "p2p"`, include/pvae.h PVAE_EXCHANGE_P2P): every rank exports IPC
         handles of its gradient / parameter arenas and flag block, the blobs are all-gathered over whatever
         backend torch.distributed runs (nccl, or gloo when the ranks share one GPU), every rank maps its peers'
@@ -97,8 +97,9 @@ class DataParallel:
         every rank takes part in every step and all agree (MIN over a success flag) on the outcome."""
         if not self.collective or engine.ctx is None:
             return False
+        assert form in ("p2p", "p2p_push")
         if engine.has_p2p:
-            engine.comm_mode("p2p")
+            engine.comm_mode(form)
             return True
         blob, err = None, None
         try:
@@ -115,12 +116,21 @@ class DataParallel:
                 ok, err = False, str(exc)
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=engine.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 1:
+            # every rank has its peers mapped: prove remote write / remote read / flag delivery before the first step
+            # (bounded: a mapping that does not reach its peer fails within a second instead of hanging a training step)
+            try:
+                engine.p2p_selftest()
+            except Exception as exc:                               # noqa: BLE001
+                ok, err = False, str(exc)
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=engine.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         if int(flag.item()) != 1:
             engine.p2p_close()
             if self.rank == 0 or err:
                 print("[physicsvae_amd] peer-mapped exchange unavailable (%s)" % (err or "another rank failed"), file=sys.stderr)
             return False
-        engine.comm_mode("p2p")
+        engine.comm_mode(form)
         return True
 
     def all_reduce(self, tensor):

@@ -170,14 +170,15 @@ class TrainModel(tune.Trainable):
         #   "inline"   RCCL all-reduce per stack on the compute stream + replicated Adam
         #   "bucketed" the same in 6 MiB buckets (or dp_bucket_mb) on the library's exchange stream, overlapped
         #   "sharded"  RCCL reduce-scatter -> Adam on the owned 1/N slice -> all-gather of the parameters
-        #   "p2p"      the sharded shape as ONE launch per stack over peer-mapped arenas, no RCCL (include/pvae.h)
+        #   "p2p"      the sharded shape as ONE launch per stack over peer-mapped arenas, no RCCL (include/pvae.h);
+        #   "p2p_push" the same with remote writes only (contributions pushed into the slice owners' staging buffers)
         #   unset      the library's default schedule
         self.dp_exchange = config.get("dp_exchange", os.environ.get("PVAE_DP_EXCHANGE")) or None
-        if self.dp_exchange not in (None, "inline", "bucketed", "sharded", "p2p"):
-            raise ValueError("dp_exchange %r: expected inline / bucketed / sharded / p2p" % (self.dp_exchange,))
-        if self.dp_exchange == "p2p":
-            if self.dp.collective and not self.dp.attach_p2p(self.engine):
-                raise RuntimeError("dp_exchange = p2p: the peer-mapped exchange could not be set up (see stderr)")
+        if self.dp_exchange not in (None, "inline", "bucketed", "sharded", "p2p", "p2p_push"):
+            raise ValueError("dp_exchange %r: expected inline / bucketed / sharded / p2p / p2p_push" % (self.dp_exchange,))
+        if self.dp_exchange in ("p2p", "p2p_push"):
+            if self.dp.collective and not self.dp.attach_p2p(self.engine, self.dp_exchange):
+                raise RuntimeError("dp_exchange = %s: the peer-mapped exchange could not be set up (see stderr)" % self.dp_exchange)
         else:
             self.dp.attach(self.engine)
         if self.dp_exchange == "bucketed" and self.dp_bucket_mb <= 0:
@@ -188,7 +189,7 @@ class TrainModel(tune.Trainable):
         # sharded exchange (default off): reduce-scatter -> Adam on the owned 1/N slice -> all-gather of the
         # parameters (include/pvae.h PVAE_EXCHANGE_SHARDED); every rank must choose the same
         self.dp_sharded = bool(config.get("dp_sharded", os.environ.get("PVAE_DP_SHARDED", "0") == "1")) or \
-            self.dp_exchange in ("sharded", "p2p")
+            self.dp_exchange in ("sharded", "p2p", "p2p_push")
         if self.engine.has_comm and not self.engine.has_p2p:
             self.engine.comm_mode(self.dp_sharded)
         self.prefetch_gather = bool(config.get("prefetch_gather", os.environ.get("PVAE_PREFETCH", "1") != "0"))

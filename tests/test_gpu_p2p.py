@@ -37,7 +37,7 @@ if "P2P_TEST_DELAY_US" in os.environ:          # a spin kernel in front of every
     eng.comm_config(float(os.environ.get("PVAE_DP_BUCKET_MB", "0")), delay)
 res = {}
 if mode == "train":
-    if os.environ.get("PVAE_DP_EXCHANGE") == "p2p":
+    if os.environ.get("PVAE_DP_EXCHANGE") in ("p2p", "p2p_push"):
         assert eng.has_p2p and not eng.has_comm and eng.p2p_status()[:2] == (rank, world)
     losses = [tr.train()["mean_train_loss"] for _ in range(2)]
     res = {"sd": {k: v.cpu() for k, v in tr.model.state_dict().items()}, "losses": losses,
@@ -115,11 +115,13 @@ def _run(tmp_path, world, per_gpu, tag, mode="train", port="29561", **extra_env)
     return [torch.load(out + ".%d" % r) for r in range(world)]
 
 
-def test_p2p_two_ranks_equal_the_allreduce_exchange_bit_for_bit(tmp_path):
+@pytest.mark.parametrize("form", ["p2p", "p2p_push"])
+def test_p2p_two_ranks_equal_the_allreduce_exchange_bit_for_bit(tmp_path, form):
     """Two processes on one GPU, two epochs across the phase switch, ragged tail with an empty shard: replicas end
     bit-identical, and equal what the all-reduce + replicated-Adam exchange produces on the same schedule (with two
-    ranks every sum is g0 + g1 whoever forms it)."""
-    p2p = _run(tmp_path, 2, 16, "p2p", PVAE_DP_EXCHANGE="p2p")
+    ranks every sum is g0 + g1 whoever forms it).  Both forms: owners PULL their slice from the peers' gradient arenas,
+    or every rank PUSHES its contributions into the owners' staging buffers (remote writes only)."""
+    p2p = _run(tmp_path, 2, 16, "p2p", PVAE_DP_EXCHANGE=form)
     plain = _run(tmp_path, 2, 16, "plain", port="29562")
     a, b = p2p
     assert a["timeouts"] == 0 and b["timeouts"] == 0
@@ -145,8 +147,9 @@ def test_p2p_ranks_that_arrive_at_different_times(tmp_path):
     with per-layer buckets on the exchange stream): the early rank waits inside its exchange launch for the late one's
     "gradient final" flag and for its "done" flag; parameters end bit-identical to the run without skew."""
     base = _run(tmp_path, 2, 16, "noskew", PVAE_DP_EXCHANGE="p2p")
-    for tag, port, extra in (("skew", "29565", {}), ("skewb", "29566", {"PVAE_DP_BUCKET_MB": "0.01"})):
-        got = _run(tmp_path, 2, 16, tag, port=port, PVAE_DP_EXCHANGE="p2p", P2P_TEST_DELAY_US="0,700", **extra)
+    for tag, port, form, extra in (("skew", "29565", "p2p", {}), ("skewb", "29566", "p2p", {"PVAE_DP_BUCKET_MB": "0.01"}),
+                                   ("skewp", "29568", "p2p_push", {}), ("skewpb", "29569", "p2p_push", {"PVAE_DP_BUCKET_MB": "0.01"})):
+        got = _run(tmp_path, 2, 16, tag, port=port, PVAE_DP_EXCHANGE=form, P2P_TEST_DELAY_US="700,0" if "p" in tag[4:] else "0,700", **extra)
         assert all(r["timeouts"] == 0 for r in got)
         for k in base[0]["sd"]:
             assert torch.equal(base[0]["sd"][k], got[0]["sd"][k]) and torch.equal(got[0]["sd"][k], got[1]["sd"][k]), (tag, k)
@@ -164,10 +167,11 @@ def test_p2p_with_a_lookahead_unroll(tmp_path):
     assert p2p[0]["losses"] == plain[0]["losses"]
 
 
-def test_p2p_four_ranks_replicas_identical_and_match_one_process(tmp_path):
+@pytest.mark.parametrize("form", ["p2p", "p2p_push"])
+def test_p2p_four_ranks_replicas_identical_and_match_one_process(tmp_path, form):
     """Four processes on one GPU (global batch 32 = 4 x 8): replicas bit-identical; against one process with the
     global batch the parameters agree to fp32 summation order."""
-    dp = _run(tmp_path, 4, 8, "p2p4", PVAE_DP_EXCHANGE="p2p")
+    dp = _run(tmp_path, 4, 8, "p2p4", PVAE_DP_EXCHANGE=form)
     single = _run(tmp_path, 1, 32, "single", port="29564")[0]
     assert all(r["timeouts"] == 0 for r in dp)
     for r in dp[1:]:
@@ -182,13 +186,14 @@ def test_p2p_four_ranks_replicas_identical_and_match_one_process(tmp_path):
         assert err < 2e-3, (k, err)
 
 
+@pytest.mark.parametrize("form", ["p2p", "p2p_push"])
 @pytest.mark.parametrize("world", [2, 3, 4])
-def test_p2p_exchange_launch_sums_in_rank_order_and_updates_every_replica(tmp_path, world):
+def test_p2p_exchange_launch_sums_in_rank_order_and_updates_every_replica(tmp_path, world, form):
     """The exchange launch on known gradients: the parameters every rank ends with equal flat Adam on the rank-order
     sum ((g0 + g1) + g2) + g3 bit for bit, over all slices (own slice computed here, the others pushed by their
     owners), moments are updated on the own slice, nothing outside the exchanged segment moves; three rounds over
     the same buffers (flag epochs, ticket reset, stale-cache hazards)."""
-    res = _run(tmp_path, world, 8, "k%d" % world, mode="kernel", port=str(29570 + world), PVAE_DP_EXCHANGE="p2p")
+    res = _run(tmp_path, world, 8, "k%d" % world, mode="kernel", port=str(29570 + world), PVAE_DP_EXCHANGE=form)
     assert all(r["ok"] and r["timeouts"] == 0 for r in res), res
 
 
@@ -215,6 +220,8 @@ def test_p2p_calls_fail_loudly_without_setup():
     assert eng.p2p_status() == (0, 0, 0)
     blob = eng.p2p_export()                         # a single rank can open itself: the exchange is then local Adam
     eng.p2p_open(0, 1, [blob])
+    eng.p2p_selftest()                              # (no peers: trivially passes)
+    eng.comm_mode("p2p_push")
     eng.comm_mode("p2p")
     eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
     sd = R.perturb_biases(R.init_state_dict(arch, 1), 3)

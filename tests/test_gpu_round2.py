@@ -44,8 +44,9 @@ def test_bench_plain_two_ranks_self_launch():
     assert "roofline" in d and 0 < d["roofline"]["frac"] < 1
     # every exchange form, back to back in the same run (what a multi-GPU lease must yield in one go)
     sweep = d["exchange_sweep"]
-    assert set(sweep) == {"inline", "bucketed", "sharded", "p2p", "local"}
-    assert sweep["p2p"]["p2p_ranks"] == 2 and sweep["p2p"]["timeouts"] == 0 and sweep["p2p"]["value"] > 0
+    assert set(sweep) == {"inline", "bucketed", "sharded", "p2p", "p2p_push", "local"}
+    for form in ("p2p", "p2p_push"):
+        assert sweep[form]["p2p_ranks"] == 2 and sweep[form]["timeouts"] == 0 and sweep[form]["value"] > 0
     assert sweep["p2p"]["exchange_launches_per_step"] >= 2          # one launch per bucket, two stacks in the joint phase
     assert sweep["local"]["ms_per_step"] > 0 and "exchange_exposed_us_per_step" in sweep["p2p"]
     if torch.cuda.device_count() < 2:

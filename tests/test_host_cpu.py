@@ -700,16 +700,17 @@ def test_python_constants_mirror_the_header():
     defs = dict(re.findall(r"#define\s+(PVAE_[A-Z0-9_]+)\s+(\d+)", header))
     assert int(defs["PVAE_ABI_VERSION"]) == _lib.ABI_VERSION
     assert int(defs["PVAE_P2P_BLOB_BYTES"]) == _lib.P2P_BLOB_BYTES and int(defs["PVAE_P2P_MAX_RANKS"]) == _lib.P2P_MAX_RANKS
-    enums = dict((k, int(v)) for k, v in re.findall(r"(PVAE_EXCHANGE_[A-Z0-9]+)\s*=\s*(\d+)", header))
+    enums = dict((k, int(v)) for k, v in re.findall(r"(PVAE_EXCHANGE_[A-Z0-9_]+)\s*=\s*(\d+)", header))
     assert enums == {"PVAE_EXCHANGE_ALLREDUCE": _lib.EXCHANGE_ALLREDUCE, "PVAE_EXCHANGE_SHARDED": _lib.EXCHANGE_SHARDED,
-                     "PVAE_EXCHANGE_P2P": _lib.EXCHANGE_P2P, "PVAE_EXCHANGE_LOCAL": _lib.EXCHANGE_LOCAL}
+                     "PVAE_EXCHANGE_P2P": _lib.EXCHANGE_P2P, "PVAE_EXCHANGE_LOCAL": _lib.EXCHANGE_LOCAL,
+                     "PVAE_EXCHANGE_P2P_PUSH": _lib.EXCHANGE_P2P_PUSH}
 
 
 def test_exchange_choice_is_validated_before_any_gpu_work():
     """`dp_exchange` / PVAE_DP_EXCHANGE: an unknown form is refused by name (every rank must choose the same, so a typo
     must not fall through to the default)."""
     src = open(os.path.join(ROOT, "physicsvae_amd", "torch_models.py")).read()
-    assert 'not in (None, "inline", "bucketed", "sharded", "p2p")' in src
+    assert 'not in (None, "inline", "bucketed", "sharded", "p2p", "p2p_push")' in src
     from physicsvae_amd import parallel
     dp = parallel.DataParallel(0, 1)
     assert not dp.collective and dp.attach_p2p(type("E", (), {"ctx": None, "has_p2p": False})()) is False
