@@ -93,6 +93,9 @@ def parse_args(argv=None):
                          "overlapped buckets / RCCL reduce-scatter + sharded Adam + all-gather / the direct all-pairs exchange "
                          "over peer-mapped arenas (no RCCL); default: the library's own schedule")
     ap.add_argument("--no-sweep", action="store_true", help="N > 1: skip the back-to-back comparison of all exchange forms")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="N > 1 without --exchange: keep the library's default schedule instead of choosing the exchange form by "
+                         "a short calibration before the warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary-phase, roofline and rocprofv3 passes")
     ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 child runs (kernel trace + PMC)")
@@ -400,23 +403,34 @@ def main():
         print(json.dumps({"inner": True, "phase": a.phase, "value": v, "ms_per_step": ms, "last_loss": loss}), flush=True)
         return
 
+    autotune = None
+    if dp.collective and dp.world > 1 and a.exchange is None and not a.no_autotune:
+        # The exchange form is chosen by measurement, before the warm-up: every form this build and this machine offer
+        # runs the same 6 + 24 steps from the same state (snapshotted, restored), the slowest rank's time counts, and a
+        # form whose replicas do not stay bit-identical is out (parallel.DataParallel.autotune_exchange).
+        os.environ.setdefault("PVAE_P2P_TIMEOUT_MS", "250")
+        ph, nets_ = set_phase(a.phase)
+        chosen, report = dp.autotune_exchange(eng, lambda n: run_steps(ph, nets_, n, 0))
+        autotune = {"chosen": chosen or "library default (no candidate qualified)", "candidates": report}
     timed_steps = max(a.steps, MIN_TIMED_STEPS)
     value, ms_per_step, last_loss, rates = timed(a.phase, timed_steps, a.warmup, REPEATS)
+    replicas_ok = dp.replicas_identical(eng) if dp.collective and dp.world > 1 else None
     comm_rank, comm_ranks = eng.comm_info()
     shared_gpu = os.environ.get("PVAE_BENCH_SHARED_GPU") == "1"
+    mode_now = a.exchange or (autotune["chosen"] if autotune and autotune["chosen"] in parallel.EXCHANGE_FORMS else None)
     if not dp.collective:
         transport = "none (single rank: Adam inside the backward launches, deferred one launch behind each weight gradient)"
-    elif eng.has_p2p:
+    elif mode_now in ("p2p", "p2p_push"):
         transport = ("in-library peer-mapped exchange (hipIpc-mapped arenas, no RCCL; %s form): one launch per stack -- rank-order "
                      "reduce-scatter by the slice owners, Adam on the owned slice, parameters pushed to every peer"
-                     % ("push" if a.exchange == "p2p_push" else "pull"))
+                     % ("push" if mode_now == "p2p_push" else "pull"))
     elif eng.has_comm:
         transport = {None: "in-library RCCL all-reduce + flat Adam; default schedule: in line on the compute stream in the "
                            "world phase, 6 MiB buckets overlapped on the exchange stream in the joint phase",
                      "inline": "in-library RCCL all-reduce per stack, in line on the compute stream, + flat Adam",
                      "bucketed": "in-library RCCL all-reduce in 6 MiB buckets overlapped on the exchange stream + per-bucket Adam",
                      "sharded": "in-library RCCL reduce-scatter -> Adam on the owned 1/N slice -> all-gather of the parameters",
-                     }[a.exchange]
+                     }[mode_now]
     else:
         transport = "torch.distributed (%s) bucketed async all-reduce + per-bucket Adam" % dist.get_backend()
     out = {
@@ -430,7 +444,9 @@ def main():
         "timing": {"timed_steps_per_region": timed_steps, "regions": REPEATS, "statistic": "median",
                    "region_values": rates},
         "rccl_ranks": comm_ranks, "rccl_rank": comm_rank,
-        "p2p_ranks": eng.p2p_status(sync=False)[1], "exchange_mode": a.exchange or "default",
+        "p2p_ranks": eng.p2p_status(sync=False)[1],
+        "exchange_mode": a.exchange or (autotune["chosen"] if autotune else "default"),
+        "exchange_autotune": autotune, "replicas_identical": replicas_ok,
         "ranks_share_a_gpu": shared_gpu,
         "last_loss": last_loss,
     }

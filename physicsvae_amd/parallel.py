@@ -139,6 +139,84 @@ class DataParallel:
         return tensor
 
 
+EXCHANGE_FORMS = ("inline", "bucketed", "sharded", "p2p", "p2p_push")
+
+
+def _set_exchange_form(self, engine, form):
+    """Switch the in-library exchange of `engine` to `form` (collective for the peer-mapped forms: every rank calls it with
+    the same value).  -> None, or the reason the form is not available here."""
+    if form in ("p2p", "p2p_push"):
+        if not self.attach_p2p(engine, form):
+            return "peer-mapped exchange could not be set up"
+        engine.comm_config(0.0)
+        return None
+    if not engine.has_comm:
+        return "no RCCL communicator"
+    engine.comm_mode("sharded" if form == "sharded" else "allreduce")
+    engine.comm_config(6.0 if form == "bucketed" else 0.0)
+    return None
+
+
+def _replicas_identical(self, engine):
+    """Every rank holds bit-identical parameters (checksum over the bit patterns, MAX == MIN over the ranks)."""
+    h = engine.params.view(torch.int32).to(torch.int64).sum().reshape(1)
+    hi, lo = h.clone(), h.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+    return int(hi.item()) == int(lo.item())
+
+
+def _autotune_exchange(self, engine, run_steps, steps=24, warm=6, forms=EXCHANGE_FORMS):
+    """Choose the exchange form by measurement: under every form available here, `run_steps(n)` (n data-parallel
+    optimizer steps, supplied by the caller) is timed from the SAME starting state -- parameters and Adam moments are
+    snapshotted first and restored after every candidate and at the end, so the calibration leaves no trace --, the
+    time is the maximum over the ranks (so every rank takes the same decision), and a candidate only counts if the
+    replicas are bit-identical after its steps and no peer wait gave up.  -> (chosen form | None, report)."""
+    import time
+    snap = [t.clone() for t in (engine.params, engine.exp_avg, engine.exp_avg_sq)]
+
+    def restore():
+        for dst, src in zip((engine.params, engine.exp_avg, engine.exp_avg_sq), snap):
+            dst.copy_(src)
+        engine.invalidate_staging()
+
+    report, best = {}, None
+    for form in forms:
+        why = self.set_exchange_form(engine, form)
+        if why:
+            report[form] = {"skipped": why}
+            continue
+        restore()
+        try:
+            run_steps(warm)
+            torch.cuda.synchronize(engine.device)
+            dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            run_steps(steps)
+            torch.cuda.synchronize(engine.device)
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=engine.device)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX, group=self.group)
+            ok = self.replicas_identical(engine)
+            bad = torch.tensor([engine.p2p_status()[2] if engine.has_p2p and form.startswith("p2p") else 0],
+                               dtype=torch.int64, device=engine.device)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+            report[form] = {"us_per_step": float(dt.item()) / steps * 1e6, "replicas_identical": ok,
+                            "peer_wait_timeouts": int(bad.item())}
+            if ok and int(bad.item()) == 0 and (best is None or report[form]["us_per_step"] < report[best]["us_per_step"]):
+                best = form
+        except Exception as exc:                                   # noqa: BLE001
+            report[form] = {"error": str(exc)[:300]}
+    restore()
+    if best is not None:
+        self.set_exchange_form(engine, best)
+    return best, report
+
+
+DataParallel.set_exchange_form = _set_exchange_form
+DataParallel.replicas_identical = _replicas_identical
+DataParallel.autotune_exchange = _autotune_exchange
+
+
 def _all_reduce_async(self, tensor):
     """SUM all-reduce that returns a Work handle (None for a single process).  With the nccl
     backend the collective is stream-ordered behind the kernels already queued on the current

@@ -173,10 +173,15 @@ class TrainModel(tune.Trainable):
         #   "p2p"      the sharded shape as ONE launch per stack over peer-mapped arenas, no RCCL (include/pvae.h);
         #   "p2p_push" the same with remote writes only (contributions pushed into the slice owners' staging buffers)
         #   unset      the library's default schedule
+        #   "auto"     measured: the first training epoch times every available form on its first minibatch (state
+        #              snapshotted and restored, parallel.DataParallel.autotune_exchange) and keeps the fastest
         self.dp_exchange = config.get("dp_exchange", os.environ.get("PVAE_DP_EXCHANGE")) or None
-        if self.dp_exchange not in (None, "inline", "bucketed", "sharded", "p2p", "p2p_push"):
-            raise ValueError("dp_exchange %r: expected inline / bucketed / sharded / p2p / p2p_push" % (self.dp_exchange,))
-        if self.dp_exchange in ("p2p", "p2p_push"):
+        if self.dp_exchange not in (None, "inline", "bucketed", "sharded", "p2p", "p2p_push", "auto"):
+            raise ValueError("dp_exchange %r: expected inline / bucketed / sharded / p2p / p2p_push / auto" % (self.dp_exchange,))
+        self.dp_exchange_report = None
+        if self.dp_exchange == "auto":
+            self.dp.attach(self.engine)               # RCCL when the backend offers it; the peer-mapped forms join at calibration
+        elif self.dp_exchange in ("p2p", "p2p_push"):
             if self.dp.collective and not self.dp.attach_p2p(self.engine, self.dp_exchange):
                 raise RuntimeError("dp_exchange = %s: the peer-mapped exchange could not be set up (see stderr)" % self.dp_exchange)
         else:
@@ -247,6 +252,8 @@ class TrainModel(tune.Trainable):
         phase, nets = self.phase()
         eng.bind_dataset(*loader.dataset.device_arrays(eng.device))
         n_glob = dp.global_steps(len(loader.dataset), loader.batch_size)
+        if train and dp.collective and self.dp_exchange == "auto" and self.dp_exchange_report is None:
+            self._autotune_exchange(loader, phase, nets)
         out = torch.zeros(max(n_glob, 1), 5, dtype=torch.float32, device=eng.device)
         for g in range(n_glob):
             first, rows, global_rows = dp.shard(g, len(loader.dataset), loader.batch_size)
@@ -287,6 +294,33 @@ class TrainModel(tune.Trainable):
             raise RuntimeError("peer-mapped exchange: a rank waited for a peer that never signalled (time-out); "
                                "parameters are no longer consistent")
         return host
+
+    def _autotune_exchange(self, loader, phase, nets):
+        """`dp_exchange = "auto"`: time every exchange form this build and this machine offer on the first global
+        minibatch (parameters and moments restored afterwards) and keep the fastest whose replicas stay bit-identical."""
+        eng, dp = self.engine, self.dp
+        if not eng.in_library_exchange:
+            dp.attach(eng)
+        first, rows, global_rows = dp.shard(0, len(loader.dataset), loader.batch_size)
+        scratch = torch.zeros(5, dtype=torch.float32, device=eng.device)
+
+        def run(n):
+            for _ in range(n):
+                sp = self.step_params(nets, global_rows, True)
+                sp.rng_seed, sp.rng_offset = self.rng_seed, dp.rank * 64
+                eng.dp_train_step(phase, first, rows, sp, eps=None, loss_out=scratch, next_span=None)
+
+        counts = dict(self.optimizer.net_steps)            # (step_params advances Adam's per-stack step counters)
+        chosen, self.dp_exchange_report = dp.autotune_exchange(eng, run)
+        self.optimizer.net_steps.clear()
+        self.optimizer.net_steps.update(counts)
+        if chosen is None:
+            raise RuntimeError("dp_exchange = auto: no in-library exchange form is available (%s)" % self.dp_exchange_report)
+        self.dp_sharded = chosen in ("sharded", "p2p", "p2p_push")
+        self.dp_exchange_chosen = chosen
+        if dp.rank == 0:
+            print("[physicsvae_amd] dp_exchange auto -> %s  %s" % (chosen, {k: round(v["us_per_step"], 1) for k, v in
+                                                                      self.dp_exchange_report.items() if "us_per_step" in v}))
 
     def dp_step(self, phase, nets, first, rows, sp, eps, loss_out, next_span=None):
         """One data-parallel optimizer step.  The backward pass is issued launch by launch; the

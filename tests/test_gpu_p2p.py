@@ -41,7 +41,8 @@ if mode == "train":
         assert eng.has_p2p and not eng.has_comm and eng.p2p_status()[:2] == (rank, world)
     losses = [tr.train()["mean_train_loss"] for _ in range(2)]
     res = {"sd": {k: v.cpu() for k, v in tr.model.state_dict().items()}, "losses": losses,
-           "steps": dict(tr.optimizer.net_steps), "timeouts": eng.p2p_status()[2] if eng.has_p2p else 0}
+           "steps": dict(tr.optimizer.net_steps), "timeouts": eng.p2p_status()[2] if eng.has_p2p else 0,
+           "report": {"chosen": getattr(tr, "dp_exchange_chosen", None), "candidates": tr.dp_exchange_report}}
 elif mode == "kernel":
     # the exchange launch itself: known gradients per rank, slice owners sum in RANK ORDER, Adam, push
     assert eng.has_p2p
@@ -153,6 +154,23 @@ def test_p2p_ranks_that_arrive_at_different_times(tmp_path):
         assert all(r["timeouts"] == 0 for r in got)
         for k in base[0]["sd"]:
             assert torch.equal(base[0]["sd"][k], got[0]["sd"][k]) and torch.equal(got[0]["sd"][k], got[1]["sd"][k]), (tag, k)
+
+
+def test_exchange_chosen_by_measurement_leaves_no_trace(tmp_path):
+    """`dp_exchange = "auto"`: the first training epoch times every exchange form available (here: the two peer-mapped
+    forms; RCCL needs one GPU per rank) from a snapshot of parameters and moments and restores it, so the run that
+    follows equals a run with that form chosen by hand bit for bit -- calibration steps leave no trace."""
+    auto = _run(tmp_path, 2, 16, "auto", PVAE_DP_EXCHANGE="auto")
+    hand = _run(tmp_path, 2, 16, "hand", port="29583", PVAE_DP_EXCHANGE="p2p")
+    assert all(r["timeouts"] == 0 for r in auto)
+    for k in auto[0]["sd"]:
+        assert torch.equal(auto[0]["sd"][k], auto[1]["sd"][k]), k
+        assert torch.equal(auto[0]["sd"][k], hand[0]["sd"][k]), k
+    assert auto[0]["losses"] == hand[0]["losses"] and auto[0]["steps"] == hand[0]["steps"]
+    rep = auto[0]["report"]
+    assert rep["chosen"] in ("p2p", "p2p_push")
+    assert all("skipped" in rep["candidates"][f] for f in ("inline", "bucketed", "sharded"))
+    assert all(rep["candidates"][f]["replicas_identical"] and rep["candidates"][f]["us_per_step"] > 0 for f in ("p2p", "p2p_push"))
 
 
 def test_p2p_with_a_lookahead_unroll(tmp_path):

@@ -710,7 +710,7 @@ def test_exchange_choice_is_validated_before_any_gpu_work():
     """`dp_exchange` / PVAE_DP_EXCHANGE: an unknown form is refused by name (every rank must choose the same, so a typo
     must not fall through to the default)."""
     src = open(os.path.join(ROOT, "physicsvae_amd", "torch_models.py")).read()
-    assert 'not in (None, "inline", "bucketed", "sharded", "p2p", "p2p_push")' in src
+    assert 'not in (None, "inline", "bucketed", "sharded", "p2p", "p2p_push", "auto")' in src
     from physicsvae_amd import parallel
     dp = parallel.DataParallel(0, 1)
     assert not dp.collective and dp.attach_p2p(type("E", (), {"ctx": None, "has_p2p": False})()) is False
