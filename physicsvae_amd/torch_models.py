@@ -16,6 +16,7 @@ Differences by design:
 """
 import math
 import os
+import sys
 
 import numpy as np
 import torch
@@ -314,10 +315,13 @@ class TrainModel(tune.Trainable):
         chosen, self.dp_exchange_report = dp.autotune_exchange(eng, run)
         self.optimizer.net_steps.clear()
         self.optimizer.net_steps.update(counts)
-        if chosen is None:
-            raise RuntimeError("dp_exchange = auto: no in-library exchange form is available (%s)" % self.dp_exchange_report)
-        self.dp_sharded = chosen in ("sharded", "p2p", "p2p_push")
         self.dp_exchange_chosen = chosen
+        if chosen is None:                         # nothing in-library qualified: the torch.distributed transport carries on
+            if dp.rank == 0:
+                print("[physicsvae_amd] dp_exchange auto: no in-library exchange form available (%s); using torch.distributed"
+                      % self.dp_exchange_report, file=sys.stderr)
+            return
+        self.dp_sharded = chosen in ("sharded", "p2p", "p2p_push")
         if dp.rank == 0:
             print("[physicsvae_amd] dp_exchange auto -> %s  %s" % (chosen, {k: round(v["us_per_step"], 1) for k, v in
                                                                       self.dp_exchange_report.items() if "us_per_step" in v}))
