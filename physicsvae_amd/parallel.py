@@ -180,6 +180,10 @@ def _autotune_exchange(self, engine, run_steps, steps=24, warm=6, forms=EXCHANGE
             dst.copy_(src)
         engine.invalidate_staging()
 
+    def sync():
+        if torch.device(engine.device).type == "cuda":
+            torch.cuda.synchronize(engine.device)
+
     report, best = {}, None
     for form in forms:
         why = self.set_exchange_form(engine, form)
@@ -189,11 +193,11 @@ def _autotune_exchange(self, engine, run_steps, steps=24, warm=6, forms=EXCHANGE
         restore()
         try:
             run_steps(warm)
-            torch.cuda.synchronize(engine.device)
+            sync()
             dist.barrier(group=self.group)
             t0 = time.perf_counter()
             run_steps(steps)
-            torch.cuda.synchronize(engine.device)
+            sync()
             dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=engine.device)
             dist.all_reduce(dt, op=dist.ReduceOp.MAX, group=self.group)
             ok = self.replicas_identical(engine)

@@ -339,6 +339,61 @@ def test_data_parallel_allreduce_gloo_world2(tmp_path):
         assert "OK %d" % r in o
 
 
+AUTOTUNE_WORKER = r'''
+import os, sys, time, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from physicsvae_amd import parallel
+rank, world, _ = parallel.init_from_env(backend="gloo")
+
+class Engine:                                   # what autotune_exchange touches of an engine, on the CPU
+    device = torch.device("cpu")
+    has_p2p = False
+    def __init__(self):
+        self.params, self.exp_avg, self.exp_avg_sq = torch.arange(8.), torch.zeros(8), torch.ones(8)
+        self.form = None
+    def invalidate_staging(self): pass
+    def p2p_status(self): return (0, 0, 0)
+
+class DP(parallel.DataParallel):                # three "forms": fast everywhere / slow on rank 1 / breaks the replicas
+    def set_exchange_form(self, engine, form):
+        if form == "bucketed":
+            return "not here"
+        engine.form = form
+        return None
+
+eng, dp = Engine(), DP(rank, world)
+cost = {"inline": (0.004, 0.004), "sharded": (0.001, 0.012), "p2p": (0.0005, 0.0005), "p2p_push": (0.002, 0.003)}
+def run_steps(n):
+    for _ in range(n):
+        time.sleep(cost[eng.form][rank])
+        eng.params += 1.0 if eng.form != "p2p" else float(rank + 1)          # "p2p" lets the replicas drift apart
+        eng.exp_avg += 0.5
+chosen, report = dp.autotune_exchange(eng, run_steps, steps=5, warm=1)
+assert chosen == "p2p_push", (chosen, report)                                # fastest by the SLOWEST rank among the valid ones
+assert report["bucketed"] == {"skipped": "not here"} and report["p2p"]["replicas_identical"] is False
+assert report["sharded"]["us_per_step"] > report["inline"]["us_per_step"] > report["p2p_push"]["us_per_step"]
+assert torch.equal(eng.params, torch.arange(8.)) and torch.equal(eng.exp_avg, torch.zeros(8))   # state restored
+assert eng.form == "p2p_push"
+dist.barrier()
+print("OK", rank)
+'''
+
+
+def test_exchange_autotune_decides_alike_on_every_rank_gloo_world2(tmp_path):
+    """`DataParallel.autotune_exchange` with two gloo ranks and a stand-in engine: forms that are unavailable are
+    skipped, a form whose replicas diverge is disqualified, the slowest rank's time decides (so both ranks choose
+    the same form), and the snapshot of parameters and moments is restored."""
+    script = tmp_path / "autotune_worker.py"
+    script.write_text(AUTOTUNE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "OK %d" % r in o
+
+
 def test_graft_entry_build_runs_without_gpu():
     """The driver's "does it build" check: compiles (or finds fresh) the gfx950 library, loads it,
     checks the ABI version and imports the package -- all without a GPU."""
