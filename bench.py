@@ -572,6 +572,29 @@ def main():
                                   "note": "launch-latency bound at this size (%.2f MB per launch); inside the step the "
                                           "gather of the next minibatch rides in the trailing launch" % (gbytes / 1e6)}
         eng.invalidate_staging()
+        # The same kernel where its launch is NOT the cost: 8192 windows per launch (an engine with token-sized stacks, the
+        # same resident demonstration set) -- what the gather reaches of the HBM roofline when it is bandwidth-bound.
+        try:
+            from physicsvae_amd.engine import Arch, HipEngine
+            big_rows = min(8192, n_win)
+            ge = HipEngine(Arch(Db, Da, Z, (64, 1), (64, 1), (64, 1)), big_rows, device=dev)
+            ge.bind_dataset(*ds.device_arrays(ge.device))
+            for _ in range(5):
+                ge.gather(0, big_rows)
+            torch.cuda.synchronize()
+            e0.record()
+            for i in range(50):
+                ge.gather((i * 97) % max(n_win - big_rows, 1), big_rows)
+            e1.record()
+            torch.cuda.synchronize()
+            us_b = e0.elapsed_time(e1) * 1e3 / 50
+            gb = 2.0 * big_rows * (2 * Db + Da) * 4
+            out["gather_roofline"]["bandwidth_bound_case"] = {
+                "rows": big_rows, "algorithmic_bytes_per_launch": gb, "avg_launch_us": us_b,
+                "achieved": gb / (us_b * 1e-6) / 1e9, "unit": "GB/s", "frac": gb / (us_b * 1e-6) / 1e9 / 8000.0}
+            del ge
+        except Exception as exc:                                   # noqa: BLE001
+            out["gather_roofline"]["bandwidth_bound_case"] = {"error": str(exc)[:200]}
 
     if dp.collective and not a.no_extra and not a.no_sweep:
         # Every exchange form this build has, timed back to back in THIS run (one region each), so that one multi-GPU
