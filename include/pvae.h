@@ -326,6 +326,13 @@ int pvae_p2p_selftest(pvae_ctx* ctx, void* stream);
  * per bucket in PVAE_EXCHANGE_P2P mode.  Every rank must issue the same sequence of calls. */
 int pvae_p2p_exchange(pvae_ctx* ctx, int net, int64_t offset, int64_t count, const pvae_step_params* sp,
                       void* stream);
+/* Which ranges of the arenas THIS rank keeps valid Adam moments for, for stack `net` trained in `phase`, under the
+ * current exchange mode and bucket settings: one entry per exchange bucket -- the rank's slice of it (sharded / peer-
+ * mapped forms; replicated[i] = 0) or the whole bucket (all-reduce form and buckets that fall back to it;
+ * replicated[i] = 1: every rank holds the same values).  What a checkpoint writer needs to assemble full moments
+ * (physicsvae_amd TrainModel.gather_moments).  *n entries are written (at most `max`). */
+int pvae_owned_slices(pvae_ctx* ctx, int phase, int net, int64_t* offsets, int64_t* counts, int32_t* replicated,
+                      int32_t max, int32_t* n);
 int pvae_allreduce_grads(pvae_ctx* ctx, int64_t offset, int64_t count, void* stream);
 int pvae_dp_train_step(pvae_ctx* ctx, int phase, int64_t first_window, int32_t rows,
                        const pvae_step_params* sp, const float* eps, float* loss_out,

@@ -96,6 +96,8 @@ _SIGS = {
     "pvae_p2p_selftest": (C.c_int, [_P, _P]),
     "pvae_p2p_exchange": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.POINTER(StepParams), _P]),
     "pvae_p2p_status": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32), _P]),
+    "pvae_owned_slices": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                    C.c_int32, C.POINTER(C.c_int32)]),
     "pvae_allreduce_grads": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     "pvae_dp_train_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int32, C.POINTER(StepParams), _P, _P,
                                      C.c_int64, C.c_int32, _P]),

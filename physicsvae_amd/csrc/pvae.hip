@@ -2733,6 +2733,36 @@ static std::vector<Bucket> exchange_buckets(const pvae_ctx* c, int net) {
     return out;
 }
 
+int pvae_owned_slices(pvae_ctx* c, int phase, int net, int64_t* offsets, int64_t* counts, int32_t* replicated,
+                      int32_t max, int32_t* n) {
+    if (!c || !offsets || !counts || !replicated || !n) return fail(-1, "null argument");
+    if (net < 0 || net >= PVAE_NUM_NETS) return fail(-1, "bad net id %d", net);
+    if (phase != PVAE_PHASE_WORLD && phase != PVAE_PHASE_JOINT) return fail(-1, "unknown phase %d", phase);
+    *n = 0;
+    if (c->L.net[net].layers.empty()) return 0;
+    const int64_t N = c->comm_world > 0 ? c->comm_world : 1, r = c->comm_rank;
+    const int64_t keep = c->bucket_bytes_now;
+    c->bucket_bytes_now = auto_bucket_bytes(c, phase);
+    const std::vector<Bucket> bk = exchange_buckets(c, net);
+    c->bucket_bytes_now = keep;
+    const bool p2p = c->exchange_mode == PVAE_EXCHANGE_P2P || c->exchange_mode == PVAE_EXCHANGE_P2P_PUSH;
+    for (const Bucket& b : bk) {
+        int64_t off = b.off, cnt = b.cnt;
+        int rep = 1;
+        if (N > 1 && p2p) {
+            const int64_t n4 = b.cnt / 4, S = (n4 + N - 1) / N, lo = r * S, hi = lo + S < n4 ? lo + S : n4;
+            off = b.off + 4 * lo; cnt = lo < hi ? 4 * (hi - lo) : 0; rep = 0;
+        } else if (N > 1 && c->exchange_mode == PVAE_EXCHANGE_SHARDED && g_rccl.ReduceScatter && g_rccl.AllGather &&
+                   b.cnt % (N * 4) == 0 && b.cnt > 0) {
+            cnt = b.cnt / N; off = b.off + r * cnt; rep = 0;
+        }
+        if (*n >= max) return fail(-1, "more than %d buckets", (int)max);
+        offsets[*n] = off; counts[*n] = cnt; replicated[*n] = rep;
+        ++*n;
+    }
+    return 0;
+}
+
 __global__ void spin_kernel(long long ticks) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);

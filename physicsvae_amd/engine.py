@@ -400,6 +400,14 @@ class HipEngine:
                                             self._stream()), "pvae_p2p_status")
         return r.value, n.value, t.value
 
+    def owned_slices(self, phase, net):
+        """[(offset, count, replicated)]: the arena ranges of stack `net` (trained in `phase`) for which this rank holds
+        valid Adam moments under the current exchange mode (include/pvae.h pvae_owned_slices)."""
+        n, cap = C.c_int32(), 64
+        off, cnt, rep = (C.c_int64 * cap)(), (C.c_int64 * cap)(), (C.c_int32 * cap)()
+        _lib.check(self.lib.pvae_owned_slices(self.ctx, int(phase), int(net), off, cnt, rep, cap, C.byref(n)), "pvae_owned_slices")
+        return [(off[i], cnt[i], bool(rep[i])) for i in range(n.value)]
+
     def allreduce_grads(self, off, cnt):
         self._need_gpu()
         _lib.check(self.lib.pvae_allreduce_grads(self.ctx, int(off), int(cnt), self._stream()), "pvae_allreduce_grads")

@@ -446,11 +446,34 @@ class TrainModel(tune.Trainable):
         return bool(getattr(self, "config", {}).get(name, False))
 
     # -- ours: everything a bit-exact resume needs beyond the weights -----------------
+    def gather_moments(self):
+        """COLLECTIVE (every rank calls it).  Under the sharded and peer-mapped exchanges a rank keeps valid Adam
+        moments only for the slices it owns; this assembles the full moments on every rank, in place: each rank
+        zeroes a copy outside what it owns (replicated ranges count for rank 0), the copies are SUM-all-reduced
+        (x + 0 + ... + 0 is exact) and written back.  After it `save_trainer_state` may run on any one rank."""
+        eng, dp = self.engine, self.dp
+        if not (dp.collective and dp.world > 1 and getattr(self, "dp_sharded", False) and eng.in_library_exchange):
+            return False
+        import torch.distributed as dist
+        mask = torch.zeros_like(eng.exp_avg, dtype=torch.bool)
+        for net, phase in ((NET_WM, PHASE_WORLD), (NET_TE, PHASE_JOINT), (NET_MD, PHASE_JOINT), (NET_PR, PHASE_JOINT)):
+            for off, cnt, rep in eng.owned_slices(phase, net):
+                if cnt > 0 and (not rep or dp.rank == 0):
+                    mask[off: off + cnt] = True
+        for t in (eng.exp_avg, eng.exp_avg_sq):
+            full = torch.where(mask, t, torch.zeros_like(t))
+            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=dp.group)
+            t.copy_(full)
+        self._moments_gathered_at = (self.iter, self.global_batch)
+        return True
+
     def save_trainer_state(self, path):
         """Adam moments (checkpoint key naming, CPU), per-stack Adam step counts, epoch counter, minibatch
-        counter (keys the eps / Philox stream) and the lr scheduler.  Not written under the sharded
-        exchange: there every rank holds valid moments for its own slices only."""
-        if getattr(self, "dp_sharded", False) and self.dp.world > 1:
+        counter (keys the eps / Philox stream) and the lr scheduler.  Under the sharded / peer-mapped exchanges
+        every rank holds valid moments for its own slices only: the file is written only if `gather_moments`
+        (collective) has assembled them at this very point of the run."""
+        if getattr(self, "dp_sharded", False) and self.dp.world > 1 and \
+                getattr(self, "_moments_gathered_at", None) != (self.iter, self.global_batch):
             return None
         mom = self.optimizer.moments()
         state = {

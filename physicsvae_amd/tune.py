@@ -216,6 +216,8 @@ def run(trainable_cls, config=None, stop=None, checkpoint_freq=0, checkpoint_at_
                 it = trial.training_iteration
                 if (checkpoint_freq and it % checkpoint_freq == 0) or (checkpoint_at_end and it == max_iter):
                     base = os.path.join(logdir, "checkpoint_%06d" % it)
+                    if world > 1 and getattr(trial, "config_flag", lambda k: False)("save_trainer_state"):
+                        trial.gather_moments()     # collective: sharded exchanges keep moments per owner (torch_models.py)
                     if rank == 0:                  # replicas are bit-identical: one writer is enough
                         rec.checkpoints.append(trial.save(base))
                     else:

@@ -86,6 +86,32 @@ elif mode == "kernel":
                 dst[oq] = parts[q][oq]
         torch.cuda.synchronize(); dist.barrier()
     res = {"ok": bool(ok), "timeouts": eng.p2p_status()[2]}
+elif mode == "resume":
+    # interrupted after `stop` epochs under the peer-mapped exchange, resumed from trainer_state.pt written after the
+    # collective gather of the moments; `full` = the uninterrupted run
+    stop = int(os.environ["P2P_TEST_STOP"])
+    ck_dir = sys.argv[2] + "_ck"
+    if os.environ.get("P2P_TEST_ROLE") == "first":
+        for _ in range(stop):
+            tr.train()
+        assert tr.save_trainer_state(os.path.join(ck_dir, "never.pt")) is None      # not gathered: refused
+        assert tr.gather_moments() is True
+        if rank == 0:
+            os.makedirs(ck_dir, exist_ok=True)
+            torch.save(tr.model.portable_state_dict(), os.path.join(ck_dir, "model.pth"))
+            assert tr.save_trainer_state(os.path.join(ck_dir, "trainer_state.pt")) is not None
+        dist.barrier()
+        losses = [tr.train()["mean_train_loss"] for _ in range(2)]
+    else:
+        tr.model.load_state_dict(torch.load(os.path.join(ck_dir, "model.pth"), map_location="cpu"))
+        tr.load_trainer_state(os.path.join(ck_dir, "trainer_state.pt"))
+        losses = [tr.train()["mean_train_loss"] for _ in range(2)]
+    own = []
+    for net, phase in ((_lib.NET_WM, _lib.PHASE_WORLD), (_lib.NET_TE, _lib.PHASE_JOINT), (_lib.NET_MD, _lib.PHASE_JOINT)):
+        own += [(o, c) for o, c, rep in eng.owned_slices(phase, net)]
+    res = {"sd": {k: v.cpu() for k, v in tr.model.state_dict().items()}, "losses": losses,
+           "m_own": torch.cat([eng.exp_avg[o: o + c] for o, c in own]).cpu(), "steps": dict(tr.optimizer.net_steps),
+           "timeouts": eng.p2p_status()[2]}
 elif mode == "timeout":
     # rank 0 enters an exchange its peer never joins: the wait gives up (PVAE_P2P_TIMEOUT_MS), no hang
     assert eng.has_p2p
@@ -171,6 +197,24 @@ def test_exchange_chosen_by_measurement_leaves_no_trace(tmp_path):
     assert rep["chosen"] in ("p2p", "p2p_push")
     assert all("skipped" in rep["candidates"][f] for f in ("inline", "bucketed", "sharded"))
     assert all(rep["candidates"][f]["replicas_identical"] and rep["candidates"][f]["us_per_step"] > 0 for f in ("p2p", "p2p_push"))
+
+
+@pytest.mark.parametrize("stop", [1, 2])
+def test_trainer_state_resume_under_the_peer_mapped_exchange(tmp_path, stop):
+    """Under the sharded / peer-mapped exchanges a rank keeps Adam moments for its own slices only, so
+    `trainer_state.pt` needs the collective `gather_moments` first (SUM all-reduce of the moments masked to what each
+    rank owns: exact).  A two-rank run interrupted before / after the phase switch and resumed from that file
+    continues bit for bit: epoch losses, weights, Adam counters, and the moments each rank owns."""
+    first = _run(tmp_path, 2, 16, "res", mode="resume", port="29584", PVAE_DP_EXCHANGE="p2p", P2P_TEST_STOP=str(stop),
+                 P2P_TEST_ROLE="first")
+    again = _run(tmp_path, 2, 16, "res", mode="resume", port="29585", PVAE_DP_EXCHANGE="p2p", P2P_TEST_STOP=str(stop),
+                 P2P_TEST_ROLE="second")
+    for a, b in zip(first, again):
+        assert a["timeouts"] == 0 and b["timeouts"] == 0
+        assert a["losses"] == b["losses"] and a["steps"] == b["steps"]
+        assert torch.equal(a["m_own"], b["m_own"])
+        for k in a["sd"]:
+            assert torch.equal(a["sd"][k], b["sd"][k]), k
 
 
 def test_p2p_with_a_lookahead_unroll(tmp_path):
