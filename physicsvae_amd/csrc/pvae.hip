@@ -212,8 +212,10 @@ struct pvae_ctx {
 
 // Minibatch staging as a launch of its own: one block per (padded) batch row and time step
 // (blockIdx.y = t < L); the work is stage_row (pvae_gemm.h).
+// (four rows per workgroup, one wave each, 16-byte panel stores: stage_row_vec)
 __global__ void __launch_bounds__(256) stage_batch_kernel(StageArgs a) {
-    stage_row(a, blockIdx.x, blockIdx.y, gridDim.x);
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r < a.rows_pad) stage_row_vec(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63, 64);
 }
 
 // s1 of step t+1 = world-model prediction of step t (tpv:421): copy the first Db columns of the
@@ -1627,7 +1629,7 @@ static int stage(pvae_ctx* c, long long first_window, const float* x, const floa
     if (rc) return rc;
     if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
     const StageArgs a = stage_args(c, first_window, x, y, rows, from_set, steps, false);
-    hipLaunchKernelGGL(stage_batch_kernel, dim3(a.rows_pad, steps), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(stage_batch_kernel, dim3((a.rows_pad + 3) / 4, steps), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     c->staged_rows = rows;
     c->staged_rows_f = rows;

@@ -190,6 +190,63 @@ __device__ inline void stage_row(const StageArgs& a, int r, int t, int rows_pad)
     }
 }
 
+// The same row with 16-byte panel stores: `nl` lanes (lane = 0 .. nl-1) cover the row four columns at a time.  The
+// panels are 64-float aligned with 64-float-multiple widths, so every store is a whole aligned float4; the sources
+// (rows of `states` / `actions`: dim_body / dim_action floats, not 16-byte multiples) are read one float per
+// element.  Used by the stand-alone gather launch, where several rows share a workgroup (stage_batch_kernel):
+// per window it moves ~7 KB in ~30 stores per lane-group instead of ~110.
+__device__ inline void stage_row_vec(const StageArgs& a, int r, int t, int rows_pad, int lane, int nl) {
+    const int Db = a.Db, Da = a.Da;
+    const size_t prow = (size_t)t * rows_pad + r;
+    const bool valid = r < a.rows;
+    const bool first = t == 0;
+    const float* p1 = nullptr;
+    const float* p2 = nullptr;
+    const float* pa = nullptr;
+    if (valid) {
+        if (a.window_row) {
+            const long long s = (long long)a.window_row[a.first_window + r] + t;
+            p1 = a.states + s * Db;
+            p2 = a.next_states ? a.next_states + s * Db : p1 + Db;
+            pa = a.actions + s * Da;
+        } else {
+            p1 = a.x + ((size_t)r * a.L + t) * 2 * Db;
+            p2 = p1 + Db;
+            pa = a.y ? a.y + ((size_t)r * a.L + t) * Da : nullptr;
+        }
+    }
+    int ld_max = a.ld_te;
+    if (a.ld_md > ld_max) ld_max = a.ld_md;
+    if (a.ld_wm > ld_max) ld_max = a.ld_wm;
+    if (a.ld_s2 > ld_max) ld_max = a.ld_s2;
+    for (int c0 = lane * 4; c0 < ld_max; c0 += nl * 4) {
+        v4f v1, v2, va, ute, uwm;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c0 + e;
+            v1[e] = (valid && first && c < Db) ? p1[c] : 0.f;
+            v2[e] = (valid && c < Db) ? p2[c] : 0.f;
+            va[e] = (valid && pa && c < Da) ? pa[c] : 0.f;
+            ute[e] = c < Db ? v1[e] : ((valid && c < 2 * Db) ? p2[c - Db] : 0.f);
+            uwm[e] = c < Db ? v1[e] : ((valid && pa && c < Db + Da) ? pa[c - Db] : 0.f);
+        }
+        if (a.pr_in && c0 < a.ld_pr) *reinterpret_cast<v4f*>(a.pr_in + prow * a.ld_pr + c0) = v1;
+        if (c0 < a.ld_te) *reinterpret_cast<v4f*>(a.te_in + prow * a.ld_te + c0) = ute;
+        if (c0 < a.ld_md) *reinterpret_cast<v4f*>(a.md_in + prow * a.ld_md + c0) = v1;       // z columns filled by the sampler
+        if (c0 < a.ld_wm) {
+            *reinterpret_cast<v4f*>(a.wm_in + prow * a.ld_wm + c0) = uwm;
+            if (a.wm_pred) {
+                v4f w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = c0 + e < Db ? v1[e] : 0.f;
+                *reinterpret_cast<v4f*>(a.wm_pred + prow * a.ld_wm + c0) = w;
+            }
+        }
+        if (c0 < a.ld_s2) *reinterpret_cast<v4f*>(a.s2 + prow * a.ld_s2 + c0) = v2;
+        if (c0 < a.ld_a) *reinterpret_cast<v4f*>(a.act_t + prow * a.ld_a + c0) = va;
+    }
+}
+
 // host-side default for GemmArgs::krot: off (measured: no gain); PVAE_KROT=1 enables
 // register sets in flight per lane in the register-staged kernels (A/B on the whole step: 2 / 2 /
 // 4 beats 4 / 4 / 4 by 1.8 %, 3 and 8 lose; compile-time switches for re-measuring)
