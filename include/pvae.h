@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PVAE_ABI_VERSION 5
+#define PVAE_ABI_VERSION 6
 
 typedef struct pvae_ctx pvae_ctx;
 
@@ -57,9 +57,12 @@ enum { PVAE_PHASE_WORLD = 0, PVAE_PHASE_JOINT = 1 };
 /* loss_fn of the three reconstruction terms (get_loss_fn tm:97-107; trainer key "loss", tpv:257) */
 enum { PVAE_LOSS_MSE = 0, PVAE_LOSS_L1 = 1 };
 
-/* hidden-layer activations (pvae_config.act_kind); "swish" needs the pre-activation in the backward
- * pass and is not offered */
-enum { PVAE_ACT_RELU = 0, PVAE_ACT_TANH = 1, PVAE_ACT_SIGMOID = 2, PVAE_ACT_ELU = 3 };
+/* hidden-layer activations (pvae_config.act_kind / layer_act; get_activation_fn rmt:30-46).  "swish" is not
+ * offered: upstream it is ray's Swish module with a learnable beta (a parameter outside the five checkpoint
+ * files' Linear tensors), and it needs the pre-activation in the backward pass.  PVAE_ACT_LINEAR: no
+ * activation after a hidden layer (rmt:32-33 "linear" / None), per-layer use only. */
+enum { PVAE_ACT_RELU = 0, PVAE_ACT_TANH = 1, PVAE_ACT_SIGMOID = 2, PVAE_ACT_ELU = 3, PVAE_ACT_LINEAR = 4 };
+#define PVAE_MAX_HIDDEN 15 /* hidden layers per stack */
 
 /* flags for pvae_forward_backward */
 enum {
@@ -88,6 +91,11 @@ typedef struct pvae_config {
     int32_t pr_width, pr_depth; /* learned prior stack (PVAE_PRIOR_STATE_MEAN only; else ignored) */
     int32_t act_kind;   /* PVAE_ACT_*: hidden activation of every stack = the trainer's "act_fn" (tpv:262;
                            get_activation_fn rmt:30-46).  0 = relu, so a zeroed field keeps the default */
+    /* Stacks gen_layers cannot emit but FC accepts (rmt:234-270: any list of fc layers, each with its own
+     * hidden_size and activation; reached through custom_model_config's *_layers, rmt:462-510).  Indexed
+     * [PVAE_NET_*][hidden layer]; zeroed = the uniform stack described by <net>_width / act_kind. */
+    int32_t layer_width[PVAE_NUM_NETS][16]; /* > 0: width of that hidden layer instead of <net>_width    */
+    int32_t layer_act[PVAE_NUM_NETS][16];   /* > 0: 1 + PVAE_ACT_* of that hidden layer instead of act_kind */
 } pvae_config;
 
 typedef struct pvae_layer_info {
@@ -99,6 +107,8 @@ typedef struct pvae_layer_info {
     int32_t n_out_pad; /* rows allocated (n_out padded to 64)           */
     int64_t w_offset;  /* float offset of W[0][0] in the arena          */
     int64_t b_offset;  /* float offset of bias[0] in the arena          */
+    int32_t act;       /* PVAE_ACT_* applied to this layer's output (PVAE_ACT_LINEAR for the output layer) */
+    int32_t reserved;
 } pvae_layer_info;
 
 /* Loss weights and Adam hyper-parameters of one optimizer step.
@@ -375,14 +385,15 @@ int pvae_infer_logits(pvae_ctx* ctx, const float* obs, int32_t rows, const float
                       uint64_t rng_seed, uint64_t rng_offset, float* logits, int32_t ld_logits,
                       const float* log_std, float* s2_hat, float* z_out, void* stream);
 /* A stack of Linear layers on CALLER-owned dense row-major weights (W[i]: [n_out[i]][n_in[i]], row stride
- * ldw[i], no alignment needed; bias may be NULL), hidden activation PVAE_ACT_*, linear output layer.
+ * ldw[i], no alignment needed; bias may be NULL), hidden activation PVAE_ACT_* (act_kind for every hidden
+ * layer, or layer_acts[i] per hidden layer when not NULL), linear output layer.
  * scratch: 2 * rows * (widest hidden layer) floats (device).  No context: this is the value branch of
  * the rollout model (rmt:846-853, value_fn_layers 2*Db -> 256 -> 256 -> 1), whose parameters stay plain
  * torch tensors because the supervised loss never touches them. */
 int pvae_mlp_forward(const float* x, int32_t rows, int32_t ldx, int32_t n_layers, const float* const* W,
                      const float* const* bias, const int32_t* n_in, const int32_t* n_out,
-                     const int32_t* ldw, int32_t act_kind, float* scratch, float* out, int32_t ld_out,
-                     void* stream);
+                     const int32_t* ldw, int32_t act_kind, const int32_t* layer_acts, float* scratch, float* out,
+                     int32_t ld_out, void* stream);
 
 /* One stack on its own: in[rows][n_in] (dense) -> out[rows][n_out] (dense).  The building
  * block behind forward_encoder / forward_decoder / forward_world (rmt:773-844) when a caller

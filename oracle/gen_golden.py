@@ -10,6 +10,7 @@ Inputs are regenerated from seeds by oracle/refpath.py on both sides, so fixture
 outputs (plus the seeds/dims that define the inputs).
 """
 import argparse
+import json
 import os
 import sys
 import tempfile
@@ -47,9 +48,12 @@ def make_reference_trainer(pkl, arch, batch, m_world, num_data=None, lookahead=1
     T.args = T.arg_parser().parse_args(argv)
     T.args.num_data = num_data
     cfg = resolve_grid(T.get_trainer_config(T.args))
-    cfg["TE_width"], cfg["TE_depth"] = arch["te"]
-    cfg["MD_width"], cfg["MD_depth"] = arch["md"]
-    cfg["world_model_width"], cfg["world_model_depth"] = arch["wm"]
+    # Stacks with per-layer widths / activations: FC accepts any list of fc layers (rmt:234-270) but the trainer
+    # always overwrites custom_model_config's *_layers with gen_layers(width, depth) (tpv:290-311), so for those the
+    # helper is wrapped for the duration of the construction: a "width" that is a layer-by-layer spec yields that
+    # layer list (same dict keys as gen_layers' rows).  Model, loss, optimizer and loop stay the reference's.
+    for key, spec in (("TE", arch["te"]), ("MD", arch["md"]), ("world_model", arch["wm"])):
+        cfg[key + "_width"], cfg[key + "_depth"] = (list(map(tuple, spec)), None) if general(spec) else spec
     cfg["lookahead"] = lookahead              # tpv:277 hard-wires 1; users edit the dict
     cfg["loss"] = loss                        # tpv:257 -> get_loss_fn (tm:97-107)
     if prior is not None:
@@ -57,7 +61,15 @@ def make_reference_trainer(pkl, arch, batch, m_world, num_data=None, lookahead=1
     cfg["act_fn"] = arch.get("act", "relu")   # tpv:262 -> gen_layers(act_hidden=...) for every stack
     if weight_decay is not None:
         cfg["weight_decay"] = weight_decay    # tpv:253 -> torch.optim.Adam(weight_decay=...) (tm:119-122)
-    return T.TrainModel(cfg)
+    orig = T.gen_layers
+
+    def gen_layers(width, depth, **kw):
+        return R.fc_layer_list(width) if isinstance(width, list) else orig(width=width, depth=depth, **kw)
+    T.gen_layers = gen_layers
+    try:
+        return T.TrainModel(cfg)
+    finally:
+        T.gen_layers = orig
 
 
 class EpsPatch:
@@ -80,10 +92,24 @@ class EpsPatch:
         torch.randn_like = self.orig
 
 
+def general(spec):
+    """A stack given layer by layer -- [(width, activation), ...] -- instead of gen_layers' (width, depth)."""
+    return len(spec) > 0 and isinstance(spec[0], (tuple, list))
+
+
+def wd(spec):
+    """(first width, depth) of a stack for the `meta` vector (general stacks travel in full as "stacks")."""
+    return (spec[0][0], len(spec)) if general(spec) else tuple(spec)
+
+
 def act_meta(arch):
-    """Extra entry of fixtures captured with an edited "act_fn" (files of the relu default stay as they were)."""
+    """Extra entries of fixtures captured with an edited "act_fn" or with stacks gen_layers cannot emit (files of the
+    relu / uniform default stay as they were)."""
     act = arch.get("act", "relu")
-    return {"act_fn": np.array(act)} if act != "relu" else {}
+    out = {"act_fn": np.array(act)} if act != "relu" else {}
+    if any(general(arch[k]) for k in ("te", "md", "wm")):
+        out["stacks"] = np.array(json.dumps({k: [list(l) for l in R.hidden_layers(arch[k], act)] for k in ("te", "md", "wm")}))
+    return out
 
 
 def grads_of(model):
@@ -180,7 +206,7 @@ def case_single(name, arch, n_ep, n_steps, batch, full):
                 fix["ckpt_te_outer_keys"] = np.array(list(obj.keys()))
                 obj = obj["task_encoder"]
             fix["ckpt_keys::" + f] = np.array(list(obj.keys()))
-    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"],
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *wd(arch["te"]), *wd(arch["md"]), *wd(arch["wm"]),
                             n_ep, n_steps, batch])
     fix.update(act_meta(arch))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
@@ -230,7 +256,7 @@ def case_single_clear(name, arch, n_ep, n_steps, batch, margin=1e-5):
             for k, g in grads.items():
                 fix["%s_graddigest::%s" % (tag, k)] = R.tensor_digest(g)
                 fix["%s_gradmax::%s" % (tag, k)] = np.array(float(g.abs().max()))
-    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"], n_ep, n_steps, batch])
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *wd(arch["te"]), *wd(arch["md"]), *wd(arch["wm"]), n_ep, n_steps, batch])
     fix.update(act_meta(arch))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
     print("wrote", name, "keys:", len(fix), "| rows skipped:", int(fix["rows_dropped_before_last"]),
@@ -272,8 +298,9 @@ def case_lookahead(name, arch, n_ep, n_steps, batch, lookahead, full, loss="MSE"
                 if full:
                     fix["%s_grad::%s" % (tag, k)] = g.numpy()
                 fix["%s_graddigest::%s" % (tag, k)] = R.tensor_digest(g)
-    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"],
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *wd(arch["te"]), *wd(arch["md"]), *wd(arch["wm"]),
                             n_ep, n_steps, batch, lookahead])
+    fix.update(act_meta(arch))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
     print("wrote", name, "keys:", len(fix), "world", fix["world_total"], "joint", fix["joint_total"])
 
@@ -321,7 +348,7 @@ def case_training(name, arch, n_ep, n_steps, batch, m_world, n_epochs, full, lr_
         fix["adam_keys"] = np.array(list(named.keys()))
         fix["adam_has_state"] = np.array(have)
         fix["adam_steps"] = np.array(steps)
-    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"],
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *wd(arch["te"]), *wd(arch["md"]), *wd(arch["wm"]),
                             n_ep, n_steps, batch, m_world, n_epochs, lr_step, lookahead])
     fix.update(act_meta(arch))
     if weight_decay:
@@ -386,7 +413,7 @@ def case_ingest(name, arch):
             for b, nm in ((0, "first"), (len(batches) - 1, "last")):
                 fix["%s_%s_x_digest" % (tag, nm)] = R.tensor_digest(batches[b][0])
                 fix["%s_%s_y_digest" % (tag, nm)] = R.tensor_digest(batches[b][1])
-    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"]])
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *wd(arch["te"]), *wd(arch["md"]), *wd(arch["wm"])])
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
     print("wrote", name, {k: int(v) for k, v in fix.items() if k.endswith(("n_windows", "n_batches", "last_batch_size"))})
 
@@ -425,7 +452,7 @@ def case_noprior(name, arch, n_ep, n_steps, batch):
             fix[tag + "_grad_keys"] = np.array(list(grads.keys()))
             for k, g in grads.items():
                 fix["%s_grad::%s" % (tag, k)] = g.numpy()
-    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"], n_ep, n_steps, batch])
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *wd(arch["te"]), *wd(arch["md"]), *wd(arch["wm"]), n_ep, n_steps, batch])
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
     print("wrote", name, "world", fix["world_total"], "joint", fix["joint_total"])
 
@@ -449,7 +476,7 @@ def case_ingest_rel(name, arch):
                 x, y = ds[i]
                 fix["L%d_%s_x" % (L, nm)] = x.numpy()
                 fix["L%d_%s_y" % (L, nm)] = y.numpy()
-    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"]])
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *wd(arch["te"]), *wd(arch["md"]), *wd(arch["wm"])])
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
     print("wrote", name, {k: int(v) for k, v in fix.items() if k.endswith("n_windows")})
 
@@ -508,7 +535,7 @@ def case_checkpoint_interop(name, arch):
         fix["obs"] = obs.numpy()
         fix["reference_logits_after_loading_our_files"] = logits.detach().numpy()
         fix["reference_future_state"] = ref.model._cur_future_state.detach().numpy()
-    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *arch["te"], *arch["md"], *arch["wm"]])
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *wd(arch["te"]), *wd(arch["md"]), *wd(arch["wm"])])
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
     print("wrote", name, "reference accepts our files:", ok)
 
@@ -523,7 +550,20 @@ def main():
     c1 = R.make_arch(197, 45, latent=32, te=(256, 2), md=(256, 2), wm=(256, 2))
     c2 = R.make_arch(197, 45, latent=32, te=(1024, 4), md=(1024, 4), wm=(1024, 4))
     dflt = R.make_arch(197, 45)              # DEFAULT_CONFIG arch: 26-tensor layout
+    # stacks gen_layers cannot emit but FC accepts (rmt:234-270): per-layer widths and activations
+    mixed_tiny = dict(tiny, te=[(16, "relu"), (24, "tanh")], md=[(32, "elu"), (16, "relu"), (24, "sigmoid")],
+                      wm=[(40, "relu"), (24, "linear"), (32, "relu")])
+    mixed_c1 = dict(c1, te=[(256, "relu"), (128, "tanh")], md=[(512, "relu"), (256, "elu"), (128, "relu")],
+                    wm=[(1024, "relu"), (512, "sigmoid"), (192, "relu")])
+    pyramid_c1 = dict(c1, te=[(512, "relu"), (256, "relu"), (96, "relu")], md=[(160, "relu"), (320, "relu")],
+                      wm=[(1024, "relu"), (256, "relu")])
     jobs = {
+        "single_mixed_tiny": lambda: case_single("single_mixed_tiny", mixed_tiny, 2, 14, 8, full=True),
+        "single_mixed_c1": lambda: case_single("single_mixed_c1", mixed_c1, 2, 200, 64, full=False),
+        "single_pyramid_c1_clear": lambda: case_single_clear("single_pyramid_c1_clear", pyramid_c1, 2, 200, 64),
+        "train_mixed_tiny": lambda: case_training("train_mixed_tiny", mixed_tiny, 3, 21, 8, m_world=2, n_epochs=5,
+                                                  full=True),
+        "look2_mixed_tiny": lambda: case_lookahead("look2_mixed_tiny", mixed_tiny, 2, 15, 8, lookahead=2, full=True),
         "single_tiny": lambda: case_single("single_tiny", tiny, 2, 14, 8, full=True),
         "single_c1": lambda: case_single("single_c1", c1, 2, 200, 64, full=False),
         "single_c2": lambda: case_single("single_c2", c2, 2, 300, 256, full=False),

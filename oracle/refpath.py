@@ -91,14 +91,48 @@ def make_arch(dim_body, dim_action, latent=32, te=(256, 2), md=(512, 3), wm=(102
 ACTIVATIONS = {"relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "elu": nn.ELU}      # rmt:37-44
 
 
+def hidden_layers(spec, default_act="relu"):
+    """Hidden layers of one stack as [(width, activation)].  `spec` is (width, depth) -- what gen_layers expands
+    (tpv:180-192), every layer with `default_act` -- or a list of (width, activation) pairs: the general layer
+    list FC.__init__ accepts (rmt:234-270; "linear" / None = no activation module, rmt:32-33)."""
+    if len(spec) and isinstance(spec[0], (tuple, list)):
+        out = [(int(w), "linear" if a is None else a) for w, a in spec]
+        assert all(a in ACTIVATIONS or a == "linear" for _, a in out), out
+        return out
+    w, d = spec
+    return [(int(w), default_act)] * int(d)
+
+
+def with_stacks(arch, stacks_json):
+    """`arch` with the per-layer stacks a fixture recorded as its "stacks" entry (json of {"te" / "md" / "wm":
+    [[width, activation], ...]}, written by oracle/gen_golden.py's act_meta)."""
+    import json
+    out = dict(arch)
+    out.update({k: [(int(w), a) for w, a in v] for k, v in json.loads(str(stacks_json)).items()})
+    out["pr"] = out["te"]
+    return out
+
+
+def stack_acts(arch, key):
+    """Activation names of the hidden layers of arch[key] ("te" / "md" / "wm" / "pr" / "vb")."""
+    default = "relu" if key == "vb" else arch.get("act", "relu")    # value_fn_layers keep their own relu (rmt:500)
+    return [a for _, a in hidden_layers(arch.get(key, arch["te"]), default)]
+
+
+def fc_layer_list(spec, default_act="relu"):
+    """The `*_layers` list of dicts (rmt:462-510 keys) describing a stack: gen_layers' output for (width, depth)."""
+    hid = hidden_layers(spec, default_act)
+    return [{"type": "fc", "hidden_size": w, "activation": a, "init_weight": {"name": "normc", "std": 1.0}} for w, a in hid] + [
+        {"type": "fc", "hidden_size": "output", "activation": "linear", "init_weight": {"name": "normc", "std": 0.01}}]
+
+
 def net_layer_dims(arch):
     """(in, out) of every Linear, per net, in registration order (rmt:638-699)."""
     Db, Da, Z = arch["Db"], arch["Da"], arch["Z"]
 
-    def chain(n_in, wd, n_out):
-        w, d = wd
+    def chain(n_in, spec, n_out):
         dims, prev = [], n_in
-        for _ in range(d):
+        for w, _ in hidden_layers(spec):
             dims.append((prev, w))
             prev = w
         dims.append((prev, n_out))
@@ -282,7 +316,7 @@ class _Slim(nn.Module):
     def __init__(self, n_in, n_out, relu, act="relu"):
         super().__init__()
         mods = [nn.Linear(n_in, n_out)]
-        if relu:
+        if relu and act != "linear":
             mods.append(ACTIVATIONS[act]())
         self._model = nn.Sequential(*mods)
 
@@ -293,7 +327,8 @@ class _Slim(nn.Module):
 class _Stack(nn.Module):
     def __init__(self, dims, act="relu"):
         super().__init__()
-        self._model = nn.Sequential(*[_Slim(i, o, relu=(n < len(dims) - 1), act=act)
+        acts = [act] * (len(dims) - 1) if isinstance(act, str) else list(act)
+        self._model = nn.Sequential(*[_Slim(i, o, relu=(n < len(dims) - 1), act=acts[n] if n < len(dims) - 1 else "relu")
                                       for n, (i, o) in enumerate(dims)])
 
     def forward(self, x):
@@ -309,13 +344,12 @@ class RefModel(nn.Module):
         self.arch = arch
         dims = net_layer_dims(arch)
         self.prior = arch.get("prior", PRIORS[0])
-        act = arch.get("act", "relu")
         if "_latent_prior" in dims:                                   # rmt:627-635: registered first
-            self._latent_prior = _Stack(dims["_latent_prior"], act)
-        self._task_encoder = _Stack(dims["_task_encoder"], act)
-        self._motor_decoder = _Stack(dims["_motor_decoder"], act)
-        self._world_model = _Stack(dims["_world_model"], act)
-        self._value_branch = _Stack(dims["_value_branch"])                # value_fn_layers keep their own relu (rmt:500)
+            self._latent_prior = _Stack(dims["_latent_prior"], stack_acts(arch, "pr"))
+        self._task_encoder = _Stack(dims["_task_encoder"], stack_acts(arch, "te"))
+        self._motor_decoder = _Stack(dims["_motor_decoder"], stack_acts(arch, "md"))
+        self._world_model = _Stack(dims["_world_model"], stack_acts(arch, "wm"))
+        self._value_branch = _Stack(dims["_value_branch"], stack_acts(arch, "vb"))
         self.log_std = math.log(0.1)            # AppendLogStd constant (rmt:160-206, 466)
         self.latent_prior_noise = True          # rmt:705
         self.eps_source = None                  # callable(shape) -> eps, else torch.randn
@@ -483,8 +517,9 @@ def relu_kink_margin(arch, sd, x, y, eps, world):
     sample's gradient path in ANY two fp32 implementations (MKL vs MFMA, CPU vs GPU).  Parity
     tests drop such samples (margin below a few ulps of the activation scale) before comparing
     gradients tightly."""
-    if arch.get("act", "relu") != "relu":              # tanh / sigmoid / elu are differentiable everywhere
-        return torch.full((x.shape[0],), float("inf"))
+    keys = {"_task_encoder": "te", "_motor_decoder": "md", "_world_model": "wm"}
+    if not any(a == "relu" for k in keys.values() for a in stack_acts(arch, k)):
+        return torch.full((x.shape[0],), float("inf"))     # tanh / sigmoid / elu are differentiable everywhere
     model = RefModel(arch)
     model.load_state_dict(sd)
     margins = []
@@ -498,8 +533,9 @@ def relu_kink_margin(arch, sd, x, y, eps, world):
             ["_task_encoder", "_motor_decoder", "_world_model"])
     hs = []
     for net in nets:
-        for slim in list(getattr(model, net)._model)[:-1]:        # hidden layers only
-            hs.append(slim._model[0].register_forward_hook(hook))
+        for slim, a in zip(list(getattr(model, net)._model)[:-1], stack_acts(arch, keys[net])):   # hidden ReLU layers only
+            if a == "relu":
+                hs.append(slim._model[0].register_forward_hook(hook))
     with torch.no_grad():
         x0 = x[:, 0, :]
         if world and L == 1:
@@ -510,6 +546,8 @@ def relu_kink_margin(arch, sd, x, y, eps, world):
             compute_loss(model, x, y, phase_coeffs(world))
     for h in hs:
         h.remove()
+    if not margins:                                # no ReLU on the path of this phase
+        return torch.full((x.shape[0],), float("inf"))
     return torch.stack(margins).min(dim=0).values
 
 

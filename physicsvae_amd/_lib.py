@@ -27,10 +27,14 @@ NUM_NETS = 4
 NET_NAMES = {NET_TE: "_task_encoder", NET_MD: "_motor_decoder", NET_WM: "_world_model", NET_PR: "_latent_prior"}
 # latent_prior_type (rmt:614-635) -> pvae_config.prior_kind
 ACT_KINDS = {"relu": 0, "tanh": 1, "sigmoid": 2, "elu": 3}      # pvae_config.act_kind (get_activation_fn rmt:30-46)
+ACT_LINEAR = 4                                                   # per-layer only: no activation after a hidden layer
+LAYER_ACTS = dict(ACT_KINDS, linear=ACT_LINEAR)                  # pvae_config.layer_act holds 1 + these
+LAYER_ACT_NAMES = {v: k for k, v in LAYER_ACTS.items()}
+MAX_HIDDEN = 15
 PRIOR_KINDS = {"normal_zero_mean_one_std": 0, "normal_state_mean_one_std": 1, "hypersphere_uniform": 2, False: 3}
 PHASE_WORLD, PHASE_JOINT = 0, 1
 FLAG_FUSED_ADAM, FLAG_NO_BACKWARD = 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 LOSS_MSE, LOSS_L1 = 0, 1
 EXCHANGE_ALLREDUCE, EXCHANGE_SHARDED, EXCHANGE_P2P, EXCHANGE_LOCAL, EXCHANGE_P2P_PUSH = 0, 1, 2, 3, 4
 P2P_BLOB_BYTES, P2P_MAX_RANKS = 512, 8
@@ -39,13 +43,14 @@ P2P_BLOB_BYTES, P2P_MAX_RANKS = 512, 8
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dim_body", "dim_action", "latent", "te_width", "te_depth", "md_width", "md_depth",
-        "wm_width", "wm_depth", "max_batch", "lookahead", "prior_kind", "pr_width", "pr_depth", "act_kind")]
+        "wm_width", "wm_depth", "max_batch", "lookahead", "prior_kind", "pr_width", "pr_depth", "act_kind")] + [
+        ("layer_width", (C.c_int32 * 16) * NUM_NETS), ("layer_act", (C.c_int32 * 16) * NUM_NETS)]
 
 
 class LayerInfo(C.Structure):
     _fields_ = [("net", C.c_int32), ("index", C.c_int32), ("n_in", C.c_int32),
                 ("n_out", C.c_int32), ("ld", C.c_int32), ("n_out_pad", C.c_int32),
-                ("w_offset", C.c_int64), ("b_offset", C.c_int64)]
+                ("w_offset", C.c_int64), ("b_offset", C.c_int64), ("act", C.c_int32), ("reserved", C.c_int32)]
 
 
 class StepParams(C.Structure):
@@ -108,7 +113,7 @@ _SIGS = {
     "pvae_read_tensor": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P]),
     "pvae_infer": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
     "pvae_infer_logits": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int, C.c_uint64, C.c_uint64, _P, C.c_int32, _P, _P, _P, _P]),
-    "pvae_mlp_forward": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, _P]),
+    "pvae_mlp_forward": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P, C.c_int32, _P]),
     "pvae_net_forward": (C.c_int, [_P, C.c_int, _P, C.c_int32, _P, _P]),
     "pvae_reparam": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int, C.c_uint64, C.c_uint64, _P, _P]),
     "pvae_mfma_clock_probe": (C.c_int, [_P, C.c_int64, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),

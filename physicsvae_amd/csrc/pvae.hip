@@ -1084,7 +1084,7 @@ static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st, const F
             const dim3 grid(l.n_out_pad / 4), block(256);
 #define PVAE_GEMV(R)                                                                                        \
     PVAE_LAUNCH((gemv_rows_kernel<R>), grid, block, st, x, ldx, c->params + l.w_off, l.ld,           \
-                       c->params + l.b_off, out, l.n_out_pad, l.ld, l.last ? 0 : c->L.cfg.act_kind + 1, o2, tail.ld2, tail.off2, tail.n2, l.n_out)
+                       c->params + l.b_off, out, l.n_out_pad, l.ld, l.act, o2, tail.ld2, tail.off2, tail.n2, l.n_out)
             if (rows == 1) PVAE_GEMV(1);
             else if (rows == 2) PVAE_GEMV(2);
             else PVAE_GEMV(4);
@@ -1095,7 +1095,7 @@ static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st, const F
             e.out = out; e.ldo = l.n_out_pad; e.bias = c->params + l.b_off;
             HIP_TRY(gemm_forward_epi(x, ldx, c->params + l.w_off, l.ld, rows_pad, l.n_out_pad, l.ld, e, st));
         } else {
-            EpiBiasAct e{out, l.n_out_pad, c->params + l.b_off, l.last ? 0 : c->L.cfg.act_kind + 1};
+            EpiBiasAct e{out, l.n_out_pad, c->params + l.b_off, l.act};
             e.n_valid = l.n_out;
             if (l.last && tail.out2) { e.out2 = tail.out2; e.ld2 = tail.ld2; e.off2 = tail.off2; e.n2 = tail.n2; }
             if (l.index == 0 && tail.pro0)
@@ -1191,6 +1191,7 @@ struct DgradArgs {
     const float* dZ; int ldz; const float* W; int ldw; const float* mask; int ldm; float* dX; int ldo;
     int M, Kin, Nd;
     double flops;
+    int act = 1;          // act_grad code of the layer behind `mask`
 };
 struct CarriedWgrad {
     bool valid = false;
@@ -1209,7 +1210,8 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
     const int last = (int)N->layers.size() - 1;
     const bool pair = train && c->pair_launch;
     const double rowsf = c->staged_rows_f;
-    const int act = c->L.cfg.act_kind + 1;          // act_grad code of the hidden layers
+    // act_grad code of the layer whose output masks the input gradient of layer i (layer i - 1; none for i == 0)
+    auto mask_act = [=](int i) { return i > 0 ? N->layers[i - 1].act : 1; };
     const int need = n == PVAE_NET_WM ? c->L.cfg.dim_action : c->L.cfg.latent;
     LossFinal foldv;
     memset(&foldv, 0, sizeof(foldv));
@@ -1243,7 +1245,7 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
                                    l.n_out_pad, e, st));
         } else {
             HIP_TRY(gemm_dgrad(c->ws + w->dz[i], l.n_out_pad, c->params + l.w_off, l.ld, i > 0 ? xin : nullptr, l.ld,
-                               i > 0 ? c->ws + w->dz[i - 1] : c->ws + w->d_in, l.ld, rows_pad, l.ld, l.n_out_pad, st, act));
+                               i > 0 ? c->ws + w->dz[i - 1] : c->ws + w->d_in, l.ld, rows_pad, l.ld, l.n_out_pad, st, mask_act(i)));
         }
         g_prof.end(ps, st);
         return 0;
@@ -1290,7 +1292,7 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
                     HIP_TRY(gemm_bwd_pair(c->ws + w->dz[j], d.n_out_pad, c->params + d.w_off, d.ld,
                                           j > 0 ? dx_in : nullptr, d.ld, j > 0 ? c->ws + w->dz[j - 1] : c->ws + w->d_in,
                                           d.ld, rows_pad, d.ld, d.n_out_pad, dz, l.n_out_pad, xin, l.ld, l.n_out_pad,
-                                          l.ld, rows_pad, e, st, &ad, act));
+                                          l.ld, rows_pad, e, st, &ad, mask_act(j)));
                 }
                 g_prof.end(pp, st);
             } else {
@@ -1393,7 +1395,7 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
             DgradArgs da{c->ws + w->dz[last], l.n_out_pad, c->params + l.w_off, l.ld,
                          last > 0 ? c->ws + w->act[last - 1] : nullptr, l.ld,
                          last > 0 ? c->ws + w->dz[last - 1] : c->ws + w->d_in, l.ld, rows_pad, l.ld, l.n_out_pad,
-                         2.0 * rowsf * l.n_in * l.n_out};
+                         2.0 * rowsf * l.n_in * l.n_out, mask_act(last)};
             Stage& sref = push([=] { return cw.run_with_dgrad(da); });
             sref.ready_off = cw.ready_off; sref.ready_cnt = cw.ready_cnt; sref.net = cw.net;
         } else {
@@ -1424,10 +1426,10 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
                 const AdamPair ad = take_pending(c);
                 if (fused) {
                     he = gemm_bwd_pair(d.dZ, d.ldz, d.W, d.ldw, d.mask, d.ldm, d.dX, d.ldo, d.M, d.Kin, d.Nd, dz,
-                                       l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, adam_epi(l), st, &ad, act);
+                                       l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, adam_epi(l), st, &ad, d.act);
                 } else {
                     he = gemm_bwd_pair(d.dZ, d.ldz, d.W, d.ldw, d.mask, d.ldm, d.dX, d.ldo, d.M, d.Kin, d.Nd, dz,
-                                       l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, store_epi(l), st, &ad, act);
+                                       l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, rows_pad, store_epi(l), st, &ad, d.act);
                 }
                 g_prof.end(pp, st);
                 if (he != hipSuccess) return fail(-10, "gemm_bwd_pair: %s", hipGetErrorString(he));
@@ -1467,6 +1469,7 @@ int pvae_layer(const pvae_config* cfg, int i, pvae_layer_info* out) {
             const Layer& l = N.layers[i];
             out->net = l.net; out->index = l.index; out->n_in = l.n_in; out->n_out = l.n_out;
             out->ld = l.ld; out->n_out_pad = l.n_out_pad; out->w_offset = l.w_off; out->b_offset = l.b_off;
+            out->act = l.act == 0 ? PVAE_ACT_LINEAR : l.act - 1; out->reserved = 0;
             return 0;
         }
         i -= (int)N.layers.size();
@@ -2072,7 +2075,7 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
                 float* out = i > 0 ? w + nw->dz[i - 1] + b * l.ld : w + nw->d_in + b * l.ld;
                 const int ps = g_prof.begin(1, 2.0 * rowsf * l.n_in * l.n_out, st);
                 HIP_TRY(gemm_dgrad(w + nw->dz[i] + b * l.n_out_pad, l.n_out_pad, c->params + l.w_off, l.ld, mask, l.ld,
-                                   out, l.ld, rows_pad, l.ld, l.n_out_pad, st, c->L.cfg.act_kind + 1));
+                                   out, l.ld, rows_pad, l.ld, l.n_out_pad, st, i > 0 ? N->layers[i - 1].act : 1));
                 g_prof.end(ps, st);
                 return 0;
             });
@@ -2136,7 +2139,6 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
         const int64_t b = u.blk(slot);
         const int rows_pad = u.rows_pad, krows = krows_of[n];
         const AdamScalars as = adam_scalars(sp, n);
-        const int act = c->L.cfg.act_kind + 1;
         LossFinal foldv;
         memset(&foldv, 0, sizeof(foldv));
         if (with_fold && fold) foldv = *fold;
@@ -2160,7 +2162,7 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
                     const int pp = g_prof.begin(3, 2.0 * rowsf * l.n_in * l.n_out * (1.0 + (double)krows / rows_pad), st);
                     he = gemm_bwd_pair(dz + b * l.n_out_pad, l.n_out_pad, c->params + l.w_off, l.ld, mask, l.ld, out, l.ld,
                                        rows_pad, l.ld, l.n_out_pad, dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld, krows, es,
-                                       st, &ad, act);
+                                       st, &ad, i > 0 ? N->layers[i - 1].act : 1);
                     g_prof.end(pp, st);
                     if (he == hipSuccess && fused) {                 // (this launch read W_i: its update waits for the next one)
                         AdamSeg a;
@@ -3024,7 +3026,7 @@ static int infer_impl(pvae_ctx* c, const float* obs, int32_t rows, const float* 
                 const int ps = g_prof.begin(0, 2.0 * rows * l.n_in * l.n_out, st);
 #define PVAE_ROLL(R)                                                                                                  \
     hipLaunchKernelGGL((gemv_rollout_kernel<R>), grid, block, shm, st, in, (int)rows, c->params + l.w_off, l.ld,      \
-                       c->params + l.b_off, out, l.n_out_pad, l.ld, l.last ? 0 : c->L.cfg.act_kind + 1, o2, ld2, n2, l.n_out, l.last ? ls : nullptr)
+                       c->params + l.b_off, out, l.n_out_pad, l.ld, l.act, o2, ld2, n2, l.n_out, l.last ? ls : nullptr)
                 if (rows == 1) PVAE_ROLL(1);
                 else if (rows == 2) PVAE_ROLL(2);
                 else PVAE_ROLL(4);
@@ -3117,10 +3119,13 @@ int pvae_infer_logits(pvae_ctx* c, const float* obs, int32_t rows, const float* 
 
 int pvae_mlp_forward(const float* x, int32_t rows, int32_t ldx, int32_t n_layers, const float* const* W,
                      const float* const* bias, const int32_t* n_in, const int32_t* n_out, const int32_t* ldw,
-                     int32_t act_kind, float* scratch, float* out, int32_t ld_out, void* stream) {
+                     int32_t act_kind, const int32_t* layer_acts, float* scratch, float* out, int32_t ld_out,
+                     void* stream) {
     if (!x || !W || !n_in || !n_out || !ldw || !out) return fail(-1, "null argument");
     if (rows < 1 || n_layers < 1 || n_layers > 16) return fail(-1, "rows %d / layers %d out of range", rows, n_layers);
     if (act_kind < 0 || act_kind > PVAE_ACT_ELU) return fail(-1, "unknown act_kind %d", act_kind);
+    for (int i = 0; layer_acts && i + 1 < n_layers; ++i)
+        if (layer_acts[i] < 0 || layer_acts[i] > PVAE_ACT_LINEAR) return fail(-1, "unknown activation %d of layer %d", layer_acts[i], i);
     int wmax = 0;
     for (int i = 0; i + 1 < n_layers; ++i) wmax = n_out[i] > wmax ? n_out[i] : wmax;
     if (n_layers > 1 && !scratch) return fail(-1, "scratch (2 * rows * widest hidden layer floats) is null");
@@ -3135,7 +3140,8 @@ int pvae_mlp_forward(const float* x, int32_t rows, int32_t ldx, int32_t n_layers
         const int ldo = last ? ld_out : wmax;
         const dim3 grid((n_out[i] + 3) / 4, (rows + 3) / 4);
         hipLaunchKernelGGL((gemv_dense_kernel<4>), grid, dim3(256), 0, st, in, ldi, (int)rows, W[i], (int)ldw[i],
-                           bias ? bias[i] : (const float*)nullptr, (int)n_in[i], (int)n_out[i], last ? 0 : act_kind + 1, o, ldo);
+                           bias ? bias[i] : (const float*)nullptr, (int)n_in[i], (int)n_out[i],
+                           last ? 0 : (layer_acts ? (layer_acts[i] == PVAE_ACT_LINEAR ? 0 : layer_acts[i] + 1) : act_kind + 1), o, ldo);
         HIP_TRY(hipGetLastError());
         in = o;
         ldi = ldo;

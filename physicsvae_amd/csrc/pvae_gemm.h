@@ -1827,7 +1827,7 @@ struct EpiMask {              // input gradient: out = acc * act'(a)   (relu: ac
     int ldo;
     const float* mask;        // activation a of the producing layer (its output), or null
     int ldm;
-    int act = 1;              // act_grad code of that layer
+    int act = 1;              // act_grad code of that layer (0: linear, the gradient passes unchanged)
     struct Pre { v4f m; };
     __device__ inline Pre preload(int q, int p) const {
         Pre r;
@@ -1836,7 +1836,8 @@ struct EpiMask {              // input gradient: out = acc * act'(a)   (relu: ac
     }
     __device__ inline void operator()(int q, int p, v4f v, const Pre& pre) const {
         const v4f m = pre.m;
-        if (act <= 1 || !mask) {
+        if (act == 0) {                         // no activation behind that layer (rmt:32-33 "linear"): dz = acc
+        } else if (act == 1 || !mask) {
             v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
             v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         } else {

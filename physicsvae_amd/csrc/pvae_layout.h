@@ -17,6 +17,7 @@ struct Layer {
     int net, index, n_in, n_out, ld, n_out_pad;
     int64_t w_off, b_off;
     bool last;
+    int act = 0;                  // act_apply / act_grad code of this layer's output: 0 linear, 1 + PVAE_ACT_* otherwise
 };
 
 struct NetLayout {
@@ -47,6 +48,11 @@ inline Layout make_layout(const pvae_config& c) {
     if (c.lookahead < 1 || c.lookahead > 64) { L.why = "lookahead must be in [1, 64]"; return L; }
     if (c.prior_kind < 0 || c.prior_kind > PVAE_PRIOR_NONE) { L.why = "unknown prior_kind"; return L; }
     if (c.act_kind < 0 || c.act_kind > PVAE_ACT_ELU) { L.why = "unknown act_kind"; return L; }
+    for (int n = 0; n < PVAE_NUM_NETS; ++n)
+        for (int i = 0; i < 16; ++i) {
+            if (c.layer_width[n][i] < 0) { L.why = "negative layer_width"; return L; }
+            if (c.layer_act[n][i] < 0 || c.layer_act[n][i] > 1 + PVAE_ACT_LINEAR) { L.why = "unknown layer_act"; return L; }
+        }
     if (c.prior_kind != PVAE_PRIOR_ZERO_MEAN && c.lookahead != 1) {
         L.why = "latent priors other than normal_zero_mean_one_std need lookahead == 1";
         return L;
@@ -71,7 +77,9 @@ inline Layout make_layout(const pvae_config& c) {
             Layer l;
             l.net = n; l.index = i; l.n_in = prev;
             l.last = (i == depths[n]);
-            l.n_out = l.last ? outs[n] : widths[n];
+            l.n_out = l.last ? outs[n] : (c.layer_width[n][i] > 0 ? c.layer_width[n][i] : widths[n]);
+            const int act_pub = l.last ? PVAE_ACT_LINEAR : (c.layer_act[n][i] > 0 ? c.layer_act[n][i] - 1 : c.act_kind);
+            l.act = act_pub == PVAE_ACT_LINEAR ? 0 : act_pub + 1;
             l.ld = pad64(l.n_in);
             l.n_out_pad = pad64(l.n_out);
             l.w_off = off; off += (int64_t)l.n_out_pad * l.ld;

@@ -14,32 +14,80 @@ from ._lib import ACT_KINDS, FLAG_FUSED_ADAM, FLAG_NO_BACKWARD, NET_MD, NET_NAME
 TENSOR_IDS = {"mu": 0, "logvar": 1, "z": 2, "a_hat": 3, "s2_hat": 4, "eps": 5, "prior_mu": 6}
 
 
+class Stack:
+    """Hidden layers of one FC stack as `FC.__init__` accepts them (rmt:234-270): a width and an activation per
+    layer ("linear" / None: none).  `gen_layers(width, depth)` (tpv:180-192) is the special case one width, one
+    activation; `Stack.of((width, depth), act)` builds that."""
+
+    def __init__(self, widths, acts="relu"):
+        self.widths = tuple(int(w) for w in widths)
+        if isinstance(acts, str) or acts is None:
+            acts = [acts] * len(self.widths)
+        self.acts = tuple("linear" if a is None else a for a in acts)
+        if not self.widths or len(self.widths) > _lib.MAX_HIDDEN or min(self.widths) < 1:
+            raise NotImplementedError("a stack needs 1..%d hidden layers of positive width, got %s" % (_lib.MAX_HIDDEN, self.widths))
+        if len(self.acts) != len(self.widths):
+            raise ValueError("one activation per hidden layer: %s vs %s" % (self.acts, self.widths))
+        for a in self.acts:                      # "swish"/"silu": ray's Swish module (learnable beta), not offered
+            if a not in _lib.LAYER_ACTS:
+                raise NotImplementedError("hidden activation %r: the HIP path offers %s" % (a, sorted(_lib.LAYER_ACTS)))
+
+    @classmethod
+    def of(cls, spec, act="relu"):
+        if isinstance(spec, Stack):
+            return spec
+        width, depth = spec
+        return cls([width] * int(depth), act)
+
+    def uniform(self, act):
+        return len(set(self.widths)) == 1 and set(self.acts) == {act}
+
+    def key(self):
+        return (self.widths, self.acts)
+
+    # (width, depth) of the first layer: what the uniform fields of pvae_config carry
+    def __getitem__(self, i):
+        return (self.widths[0], len(self.widths))[i]
+
+    def __iter__(self):
+        return iter((self.widths[0], len(self.widths)))
+
+
 class Arch:
-    """Dims of the three trainable stacks (tpv:247-286 keys, gen_layers tpv:180-192)."""
+    """Dims of the trainable stacks (tpv:247-286 keys, gen_layers tpv:180-192).  `te` / `md` / `wm` / `pr`:
+    (width, depth) with the one hidden activation `act` (everything the trainer can generate), or a `Stack`
+    (per-layer widths and activations, what custom_model_config's *_layers can describe, rmt:462-510)."""
 
     def __init__(self, dim_body, dim_action, latent, te, md, wm, prior="normal_zero_mean_one_std", pr=None,
                  act="relu"):
         self.Db, self.Da, self.Z = int(dim_body), int(dim_action), int(latent)
-        self.te, self.md, self.wm = tuple(te), tuple(md), tuple(wm)
         if prior not in PRIOR_KINDS:
             raise NotImplementedError("Unknown latent_prior_type:%s" % (prior,))      # rmt:624-625
         self.prior = prior                       # latent_prior_type (rmt:614-635; oracle/refpath.py PRIORS)
-        self.pr = tuple(pr) if pr is not None else tuple(te)      # learned prior stack (width, depth)
-        if act not in ACT_KINDS:                 # "swish"/"silu" need the pre-activation in the backward pass
+        if act not in ACT_KINDS:                 # "swish"/"silu": ray's Swish module (learnable beta), not offered
             raise NotImplementedError("hidden activation %r: the HIP path offers %s" % (act, sorted(ACT_KINDS)))
-        self.act = act                           # the trainer's "act_fn" (tpv:262), one for all stacks
+        self.act = act                           # the trainer's "act_fn" (tpv:262): the default of every stack
+        self.te, self.md, self.wm = Stack.of(te, act), Stack.of(md, act), Stack.of(wm, act)
+        self.pr = Stack.of(pr, act) if pr is not None else self.te      # learned prior stack
 
     @property
     def te_out(self):
         return self.Z if (self.prior == "hypersphere_uniform" or self.prior is False) else 2 * self.Z   # rmt:618-623
 
     def config(self, max_batch, lookahead=1):
-        return _lib.Config(self.Db, self.Da, self.Z, self.te[0], self.te[1], self.md[0],
-                           self.md[1], self.wm[0], self.wm[1], int(max_batch), int(lookahead),
-                           PRIOR_KINDS[self.prior], self.pr[0], self.pr[1], ACT_KINDS[self.act])
+        cfg = _lib.Config(self.Db, self.Da, self.Z, self.te[0], self.te[1], self.md[0],
+                          self.md[1], self.wm[0], self.wm[1], int(max_batch), int(lookahead),
+                          PRIOR_KINDS[self.prior], self.pr[0], self.pr[1], ACT_KINDS[self.act])
+        for net, st in ((NET_TE, self.te), (NET_MD, self.md), (NET_WM, self.wm), (NET_PR, self.pr)):
+            if st.uniform(self.act):             # (a zeroed row: the uniform stack the scalar fields describe)
+                continue
+            for i, (w, a) in enumerate(zip(st.widths, st.acts)):
+                cfg.layer_width[net][i] = w
+                cfg.layer_act[net][i] = 1 + _lib.LAYER_ACTS[a]
+        return cfg
 
     def key(self):
-        return (self.Db, self.Da, self.Z, self.te, self.md, self.wm, self.prior, self.pr, self.act)
+        return (self.Db, self.Da, self.Z, self.te.key(), self.md.key(), self.wm.key(), self.prior, self.pr.key(), self.act)
 
 
 class GraphedInfer:
@@ -523,13 +571,16 @@ class HipEngine:
 
     def mlp_forward(self, x, layers, act="relu"):
         """A stack of Linear layers on caller-owned dense weights: `layers` = [(weight [n_out, n_in], bias)], hidden
-        activation `act`, linear output (`pvae_mlp_forward`; the rollout model's value branch, rmt:846-853)."""
+        activation `act` (one name, or one per hidden layer), linear output (`pvae_mlp_forward`; the rollout model's
+        value branch, rmt:846-853)."""
         self._need_gpu()
         x = x.reshape(x.shape[0], -1).to(self.device, torch.float32)
         if x.stride(-1) != 1:
             x = x.contiguous()
         n = len(layers)
-        key = tuple((w.data_ptr(), b.data_ptr(), w.stride(0)) for w, b in layers)
+        acts = [act] * (n - 1) if isinstance(act, str) else ["linear" if a is None else a for a in act]
+        assert len(acts) == n - 1, "one activation per hidden layer"
+        key = tuple((w.data_ptr(), b.data_ptr(), w.stride(0)) for w, b in layers) + (tuple(acts),)
         plan = getattr(self, "_mlp_plan", None)
         if plan is None or plan[0] != key:              # pointer tables are rebuilt only when a tensor moved
             Pf = C.c_void_p * n
@@ -538,13 +589,14 @@ class HipEngine:
                 assert w.dtype == torch.float32 and w.device == self.device and w.stride(1) == 1 and b.is_contiguous()
             plan = (key, Pf(*[w.data_ptr() for w, _ in layers]), Pf(*[b.data_ptr() for _, b in layers]),
                     Ii(*[w.shape[1] for w, _ in layers]), Ii(*[w.shape[0] for w, _ in layers]),
-                    Ii(*[w.stride(0) for w, _ in layers]), max([w.shape[0] for w, _ in layers[:-1]] or [1]))
+                    Ii(*[w.stride(0) for w, _ in layers]), max([w.shape[0] for w, _ in layers[:-1]] or [1]),
+                    (C.c_int32 * max(n - 1, 1))(*[_lib.LAYER_ACTS[a] for a in acts]))
             self._mlp_plan = plan
         rows = x.shape[0]
         scratch = torch.empty(2 * rows * plan[6], dtype=torch.float32, device=self.device)
         out = torch.empty(rows, layers[-1][0].shape[0], dtype=torch.float32, device=self.device)
         _lib.check(self.lib.pvae_mlp_forward(x.data_ptr(), rows, x.stride(0), n, plan[1], plan[2], plan[3], plan[4], plan[5],
-                                             ACT_KINDS[act], scratch.data_ptr(), out.data_ptr(), out.shape[1],
+                                             0, plan[7], scratch.data_ptr(), out.data_ptr(), out.shape[1],
                                              self._stream()), "pvae_mlp_forward")
         return out
 

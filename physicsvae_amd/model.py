@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from ._lib import NET_MD, NET_NAMES, NET_PR, NET_TE, NET_WM, PRIOR_KINDS
-from .engine import Arch, HipEngine
+from .engine import Arch, HipEngine, Stack
 
 
 def fc_spec(width, depth, out_size="output", act_hidden="relu", act_out="linear"):
@@ -56,41 +56,61 @@ def normc_(tensor, std=1.0):
 ACTIVATIONS = {"relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "elu": nn.ELU}     # rmt:30-46 minus swish
 
 
-def _uniform_stack(layers, what):
-    """The HIP path covers what train_physics_vae.py can generate (gen_layers, tpv:180-192): fc layers of
-    one width with one activation (the trainer's "act_fn": relu unless changed), then a linear fc output
-    layer.  Anything else is refused loudly.  Returns (width, depth, activation)."""
+def get_initializer(info):
+    """rmt:220-232: "normc" (std), "xavier_normal" / "xavier_uniform" (gain); in place on a (strided) view."""
+    if info["name"] == "normc":
+        return lambda t: normc_(t, info["std"])
+    if info["name"] in ("xavier_normal", "xavier_uniform"):
+        fn = getattr(nn.init, info["name"] + "_")
+
+        def init(t):
+            with torch.no_grad():
+                t.copy_(fn(torch.empty(t.shape, dtype=torch.float32), gain=info["gain"]))
+            return t
+        return init
+    raise NotImplementedError(info["name"])
+
+
+def _fc_stack(layers, what):
+    """A `*_layers` list of the model config (rmt:462-510) as the HIP path takes it: fc layers only -- each with
+    its own integer width, its own activation out of relu / tanh / sigmoid / elu / linear and its own init_weight
+    (FC.__init__, rmt:234-270) -- then a linear fc output layer.  `gen_layers` (tpv:180-192) emits the special case
+    of one width and one activation.  Anything else (bn / softmax / hardmax layers, swish, a non-linear output) is
+    refused loudly.  Returns (Stack of the hidden layers, [init_weight dict per Linear])."""
     if not layers or any(l.get("type") != "fc" for l in layers):
         raise NotImplementedError("%s: only 'fc' layers are supported on the HIP path" % what)
     *hidden, last = layers
     if not hidden:
         raise NotImplementedError("%s: at least one hidden layer is required" % what)
-    widths = {l["hidden_size"] for l in hidden}
-    if len(widths) != 1 or not isinstance(next(iter(widths)), int):
-        raise NotImplementedError("%s: hidden layers must share one integer width, got %s" % (what, widths))
-    acts = {l.get("activation") for l in hidden}
-    if len(acts) != 1 or next(iter(acts)) not in ACTIVATIONS or last.get("activation") not in ("linear", None):
-        raise NotImplementedError("%s: hidden layers must share one activation out of %s and the output be linear, got %s"
-                                  % (what, sorted(ACTIVATIONS), sorted(map(str, acts))))
+    if any(not isinstance(l["hidden_size"], int) or isinstance(l["hidden_size"], bool) for l in hidden):
+        raise NotImplementedError("%s: hidden layers need integer widths, got %s" % (what, [l["hidden_size"] for l in hidden]))
+    acts = ["linear" if l.get("activation") is None else l.get("activation") for l in hidden]
+    if any(a not in ACTIVATIONS and a != "linear" for a in acts) or last.get("activation") not in ("linear", None):
+        raise NotImplementedError("%s: hidden activations out of %s and a linear output layer, got %s -> %s"
+                                  % (what, sorted(ACTIVATIONS) + ["linear"], acts, last.get("activation")))
     if last["hidden_size"] != "output":
         raise NotImplementedError("%s: last layer must have hidden_size 'output'" % what)
-    return next(iter(widths)), len(hidden), next(iter(acts))
+    default_init = [{"name": "normc", "std": 1.0}] * len(hidden) + [{"name": "normc", "std": 0.01}]
+    inits = [l.get("init_weight") or d for l, d in zip(layers, default_init)]
+    for info in inits:
+        get_initializer(info)                      # (unknown names fail here, not half-way through construction)
+    return Stack([l["hidden_size"] for l in hidden], acts), inits
 
 
 class SlimFC(nn.Module):
-    """Linear (+ReLU) held as `self._model = nn.Sequential(...)` -- the ray SlimFC shape that
+    """Linear (+activation) held as `self._model = nn.Sequential(...)` -- the ray SlimFC shape that
     gives the `._model.0.weight` key suffix."""
 
-    def __init__(self, in_size, out_size, relu, init_std, weight=None, bias=None, act="relu"):
+    def __init__(self, in_size, out_size, init, weight=None, bias=None, act=None):
         super().__init__()
         lin = nn.Linear(in_size, out_size)
         if weight is not None:                 # alias the engine arena instead of own storage
             lin.weight = nn.Parameter(weight)
             lin.bias = nn.Parameter(bias)
-        normc_(lin.weight.data, init_std)
+        get_initializer(init)(lin.weight.data)
         with torch.no_grad():
             lin.bias.zero_()
-        self._model = nn.Sequential(*([lin, ACTIVATIONS[act]()] if relu else [lin]))
+        self._model = nn.Sequential(*([lin, ACTIVATIONS[act]()] if act not in (None, "linear") else [lin]))
 
     def forward(self, x):
         return self._model(x)
@@ -137,14 +157,17 @@ class FC(nn.Module):
     """rmt:234-283: `self._model = nn.Sequential(SlimFC..., [AppendLogStd])`."""
 
     def __init__(self, dims, views=None, append_log_std=False, sample_std=1.0, log_std_type="constant",
-                 device=None, act="relu"):
+                 device=None, act="relu", inits=None):
+        """`act`: one name for every hidden layer, or one per hidden layer; `inits`: init_weight dict per Linear
+        (default: gen_layers' normc 1.0 / 0.01 for the output layer, tpv:184-189)."""
         super().__init__()
         mods = []
+        acts = [act] * (len(dims) - 1) if isinstance(act, str) else list(act)
         for i, (n_in, n_out) in enumerate(dims):
             last = i == len(dims) - 1
             w, b = (views[i] if views is not None else (None, None))
-            mods.append(SlimFC(n_in, n_out, relu=not last, init_std=0.01 if last else 1.0,
-                               weight=w, bias=b, act=act))
+            init = inits[i] if inits is not None else {"name": "normc", "std": 0.01 if last else 1.0}
+            mods.append(SlimFC(n_in, n_out, init, weight=w, bias=b, act=None if last else acts[i]))
         if append_log_std:
             mods.append(AppendLogStd(math.log(sample_std), dims[-1][1], type=log_std_type, device=device))
         self._model = nn.Sequential(*mods)
@@ -246,18 +269,18 @@ class PhysicsVAE(nn.Module):
         self._latent_prior_type = cfg["latent_prior_type"]
         self._motor_decoder_helper = None
 
-        te = _uniform_stack(cfg["task_encoder_layers"], "task_encoder_layers")
-        md = _uniform_stack(cfg["motor_decoder_layers"], "motor_decoder_layers")
-        wm = _uniform_stack(cfg["world_model_layers"], "world_model_layers")
-        vb = _uniform_stack(cfg["value_fn_layers"], "value_fn_layers")
+        te, te_init = _fc_stack(cfg["task_encoder_layers"], "task_encoder_layers")
+        md, md_init = _fc_stack(cfg["motor_decoder_layers"], "motor_decoder_layers")
+        wm, wm_init = _fc_stack(cfg["world_model_layers"], "world_model_layers")
+        vb, vb_init = _fc_stack(cfg["value_fn_layers"], "value_fn_layers")
         learned_prior = self._latent_prior_type == "normal_state_mean_one_std"
-        pr = _uniform_stack(cfg.get("latent_prior_layers") or cfg["task_encoder_layers"], "latent_prior_layers")
-        acts = {s[2] for s in ((te, md, wm, pr) if learned_prior else (te, md, wm))}
-        if len(acts) != 1:                      # gen_layers gives every stack the trainer's one "act_fn" (tpv:290-311)
-            raise NotImplementedError("the stacks on the HIP path share one hidden activation, got %s" % sorted(acts))
-        act = next(iter(acts))
-        self.arch = Arch(self.dim_state_body, self.dim_action, Z, te[:2], md[:2], wm[:2], prior=self._latent_prior_type,
-                         pr=pr[:2], act=act)
+        pr, pr_init = _fc_stack(cfg.get("latent_prior_layers") or cfg["task_encoder_layers"], "latent_prior_layers")
+        # the default activation of the ctx: the trainer's one "act_fn" when every layer agrees (tpv:290-311);
+        # stacks that differ from it travel layer by layer (pvae_config.layer_width / layer_act)
+        used = {a for st in ((te, md, wm, pr) if learned_prior else (te, md, wm)) for a in st.acts}
+        act = next(iter(used)) if len(used) == 1 and next(iter(used)) != "linear" else "relu"
+        self.arch = Arch(self.dim_state_body, self.dim_action, Z, te, md, wm, prior=self._latent_prior_type,
+                         pr=pr, act=act)
         device = cfg["device"] or ("cuda" if torch.cuda.is_available() else "cpu")
         self.engine = HipEngine(self.arch, int(cfg["max_batch"]), device=device,
                                 lookahead=int(cfg.get("lookahead", 1) or 1))
@@ -269,10 +292,12 @@ class PhysicsVAE(nn.Module):
             per_net[info["net"]].append(((info["n_in"], info["n_out"]),
                                          (views[base + "weight"], views[base + "bias"])))
 
+        stacks = {NET_TE: (te, te_init), NET_MD: (md, md_init), NET_WM: (wm, wm_init), NET_PR: (pr, pr_init)}
+
         def build(net, **kw):
             dims = [d for d, _ in per_net[net]]
             vws = [v for _, v in per_net[net]]
-            return FC(dims, views=vws, act=act, **kw)
+            return FC(dims, views=vws, act=stacks[net][0].acts, inits=stacks[net][1], **kw)
 
         # registration order fixes the state_dict order: [prior,] TE, MD, WM, VB (rmt:627-699)
         self._latent_prior = build(NET_PR) if learned_prior else None
@@ -282,12 +307,12 @@ class PhysicsVAE(nn.Module):
         self._world_model = build(NET_WM)
         self.__dict__["_als"] = self._motor_decoder._model[-1]      # (a plain reference: module lookups cost microseconds per forward)
         vb_dims, prev = [], self.dim_state
-        for _ in range(vb[1]):
-            vb_dims.append((prev, vb[0]))
-            prev = vb[0]
+        for width in vb.widths:
+            vb_dims.append((prev, width))
+            prev = width
         vb_dims.append((prev, 1))
-        self._value_branch = FC(vb_dims, act=vb[2]).to(self.engine.device)
-        self._vb_act = vb[2]
+        self._value_branch = FC(vb_dims, act=vb.acts, inits=vb_init).to(self.engine.device)
+        self._vb_act = vb.acts
 
         self._st = _Cur()
         self._cur_value = None

@@ -348,15 +348,18 @@ def get_trainer_config(a):
 
 
 def update_model_config(trainer_config):
-    """tpv:290-311: expand width/depth into layer-spec lists inside custom_model_config."""
+    """tpv:290-311: expand width/depth into layer-spec lists inside custom_model_config.  Ours: a trainer-config
+    key `TE_layers` / `MD_layers` / `world_model_layers` holding a full layer list (the dicts FC.__init__ reads,
+    rmt:234-270: per-layer hidden_size / activation / init_weight) takes the place of gen_layers' uniform stack --
+    the model accepts such lists upstream too, only the trainer's helper cannot emit them."""
     cmc = trainer_config["model"]["custom_model_config"]
     act = trainer_config.get("act_fn")
     cmc["task_encoder_output_dim"] = trainer_config.get("latent_dim")
     cmc["latent_prior_type"] = trainer_config.get("latent_prior_type")
     for key, prefix in (("task_encoder_layers", "TE"), ("motor_decoder_layers", "MD"),
                         ("world_model_layers", "world_model")):
-        cmc[key] = gen_layers(width=trainer_config.get(prefix + "_width"),
-                              depth=trainer_config.get(prefix + "_depth"), act_hidden=act)
+        cmc[key] = trainer_config.get(prefix + "_layers") or gen_layers(
+            width=trainer_config.get(prefix + "_width"), depth=trainer_config.get(prefix + "_depth"), act_hidden=act)
     cmc["max_batch"] = trainer_config.get("batch_size", cmc.get("max_batch", 256))
     cmc["lookahead"] = trainer_config.get("lookahead", 1) or 1     # sizes the unroll workspace
 

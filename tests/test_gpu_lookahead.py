@@ -26,7 +26,7 @@ def _params(world, rows, **kw):
 
 def _setup(golden, name):
     g = golden(name)
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     n_ep, n_steps, batch, L = [int(v) for v in g["meta"][9:13]]
     data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
     X, Y = R.build_windows(data, lookahead=L)
@@ -40,7 +40,7 @@ def _setup(golden, name):
     return g, arch, data, x, y, sd, eps, tr, L
 
 
-@pytest.mark.parametrize("name", ["look3_tiny", "look2_c1", "l1_tiny", "l1_look2_c1"])
+@pytest.mark.parametrize("name", ["look3_tiny", "look2_c1", "l1_tiny", "l1_look2_c1", "look2_mixed_tiny"])
 @pytest.mark.parametrize("world", [True, False])
 def test_unrolled_batch_matches_oracle_and_golden(golden, name, world):
     """l1_*: trainer key "loss" = "L1" (tm:100-101), lookahead 1 and 2."""
@@ -179,7 +179,7 @@ def test_unrolled_fused_adam_and_shards(golden):
 
 def test_unrolled_training_run_matches_reference_capture(golden):
     g = golden("train_tiny_look2")
-    arch = arch_from_meta(g["meta"])
+    arch = arch_from_meta(g)
     n_ep, n_steps, batch, m_world, n_epochs, lr_step, L = [int(v) for v in g["meta"][9:16]]
     data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
     tr = make_trainer(arch, data, batch, m_world=m_world, device=DEV, lr_step=lr_step,

@@ -92,7 +92,8 @@ def _setup_single(golden, name):
 
 @pytest.mark.parametrize("name", ["single_tiny", "single_c1", "single_c2", "single_default",
                                   # the trainer's "act_fn" edited (hidden activation of every stack)
-                                  "single_tiny_tanh", "single_tiny_sigmoid", "single_tiny_elu", "single_c1_tanh"])
+                                  "single_tiny_tanh", "single_tiny_sigmoid", "single_tiny_elu", "single_c1_tanh",
+                                  "single_mixed_tiny", "single_mixed_c1"])       # (last two: per-layer widths / activations)
 @pytest.mark.parametrize("world", [True, False])
 def test_single_batch_matches_oracle_and_golden(golden, name, world):
     g, arch, data, x, y, sd, eps, tr = _setup_single(golden, name)
@@ -154,7 +155,8 @@ def test_single_batch_matches_oracle_and_golden(golden, name, world):
     assert seg.abs().double().sum().item() == pytest.approx(real, rel=1e-9)
 
 
-@pytest.mark.parametrize("name", ["single_tiny_clear", "single_c1_clear", "single_default_clear", "single_c2_clear"])
+@pytest.mark.parametrize("name", ["single_tiny_clear", "single_c1_clear", "single_default_clear", "single_c2_clear",
+                                  "single_pyramid_c1_clear"])
 @pytest.mark.parametrize("world", [True, False])
 def test_single_batch_matches_the_reference_capture_tightly(golden, name, world):
     """The HIP path DIRECTLY against captures of the reference's compute_loss + backward (tpv:361-435), no oracle
@@ -555,7 +557,8 @@ def test_step_is_deterministic(golden):
 # ------------------------------------------------------------------------------------------
 # the whole loop against the reference's captured training runs
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["train_tiny", "train_c1", "train_tiny_elu_wd"])     # last: act_fn elu, weight_decay 0.01
+@pytest.mark.parametrize("name", ["train_tiny", "train_c1", "train_tiny_elu_wd",     # act_fn elu, weight_decay 0.01
+                                  "train_mixed_tiny"])                               # per-layer widths / activations
 def test_training_run_matches_reference_capture(golden, name):
     g = golden(name)
     arch = arch_from_meta(g)

@@ -140,3 +140,36 @@ def test_rollout_from_host_observation_to_host_action(golden, rows):
     eng.gather(0, 32)
     eng.infer_host(obs, noise=False)
     assert torch.equal(eng.forward_backward(_lib.PHASE_WORLD, 32, sp, backward=False), l0)
+
+
+@pytest.mark.parametrize("rows", [1, 4, 33])
+def test_rollout_and_value_branch_with_per_layer_stacks(golden, rows):
+    """PhysicsVAE.forward (rmt:742-771) on stacks given layer by layer -- own width and activation per hidden layer,
+    FC's general layer list (rmt:234-270) --, the value branch included (rmt:846-853: `pvae_mlp_forward` with one
+    activation per hidden layer when sampling, the torch module under autograd)."""
+    from physicsvae_amd.model import PhysicsVAE
+    g = golden("single_mixed_c1")
+    arch = dict(arch_from_meta(g), vb=[(48, "tanh"), (32, "linear"), (40, "elu")])
+    data = R.synth_demo(0, 2, 40, arch["Db"], arch["Da"], kind="dynamics")
+    tr = make_trainer(arch, data, 64, device=DEV)
+    cmc = dict(tr.config["model"]["custom_model_config"], value_fn_layers=R.fc_layer_list(arch["vb"]))
+    m = PhysicsVAE(cmc["observation_space"], cmc["action_space"], 2 * arch["Da"], {"custom_model_config": cmc}, "m")
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    m.load_state_dict(sd)
+    ref = R.RefModel(arch)
+    ref.load_state_dict(sd)
+    obs = torch.randn(rows, 2 * arch["Db"], generator=torch.Generator().manual_seed(rows))
+    e = R.eps_stream(2, arch["Z"])(0, (rows, arch["Z"]))
+    ref.eps_source = lambda shape: e
+    want = ref(obs).detach()
+    with torch.no_grad():
+        logits, _ = m.forward({"obs_flat": obs.to(DEV)}, [], None, eps=e)
+        value = m.value_function().cpu()
+    assert max_err_scaled(logits.cpu(), want) < 2e-5
+    assert max_err_scaled(m._cur_future_state.cpu(), ref.cur_future_state.detach()) < 2e-5
+    assert max_err_scaled(m.task_encoder_variable().cpu(), ref.cur_z.detach()) < 2e-5
+    assert max_err_scaled(value, ref.cur_value.detach()) < 1e-4
+    v_torch, _ = m.forward_value_branch(obs.to(DEV))                 # autograd on: the plain module
+    assert v_torch.requires_grad and max_err_scaled(v_torch.detach().cpu().reshape(-1), ref.cur_value.detach().reshape(-1)) < 1e-4
+    a_hat, s2, z = m.engine.infer(obs.to(DEV), eps=e.to(DEV))
+    assert max_err_scaled(a_hat.cpu(), want[:, : arch["Da"]]) < 2e-5 and max_err_scaled(s2.cpu(), ref.cur_future_state.detach()) < 2e-5

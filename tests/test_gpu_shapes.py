@@ -1,5 +1,5 @@
 """Randomised-shape sweep of the HIP path against the oracle: stack widths that are not multiples
-of any tile, depths 1..4 that differ per stack, tiny and odd observation / action / latent sizes,
+of any tile, depths 1..4 that differ per stack (a second sweep: widths and activations that differ per LAYER), tiny and odd observation / action / latent sizes,
 minibatches from 1 row up, lookahead 1..3, MSE and L1.  Every case: loss terms rel 1e-5, every
 gradient 1e-4 (samples on a ReLU kink excluded, see oracle.refpath.relu_kink_margin), the pad
 entries of the arena stay zero, and three optimizer steps with Adam fused into the weight-gradient
@@ -32,9 +32,29 @@ def _case(seed):
     return dict(Db=Db, Da=Da, Z=Z, te=nets[0], md=nets[1], wm=nets[2], L=L, rows=rows, loss=loss)
 
 
+def _case_stacks(seed):
+    """As _case, with every stack given layer by layer: its own width and activation per hidden layer -- the lists
+    FC accepts (rmt:234-270) but gen_layers cannot emit."""
+    r = np.random.default_rng(7000 + seed)
+    c = _case(seed)
+    widths = [5, 17, 31, 64, 100, 129, 200, 257, 320]
+    acts = ["relu", "relu", "tanh", "sigmoid", "elu", "linear"]
+    for key in ("te", "md", "wm"):
+        c[key] = [(int(r.choice(widths)), str(r.choice(acts))) for _ in range(int(r.integers(1, 5)))]
+    return c
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_per_layer_stacks_match_oracle(seed):
+    _check(_case_stacks(seed), seed)
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_random_shapes_match_oracle(seed):
-    c = _case(seed)
+    _check(_case(seed), seed)
+
+
+def _check(c, seed):
     L, rows, lk = c["L"], c["rows"], c["loss"]
     arch = R.make_arch(c["Db"], c["Da"], latent=c["Z"], te=c["te"], md=c["md"], wm=c["wm"])
     n_steps = rows + L + 3

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pvae_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.pvae_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_layout_queries_without_gpu():
@@ -828,9 +828,88 @@ def test_act_fn_and_weight_decay_reach_the_model_and_the_step_params():
     from physicsvae_amd import train_physics_vae as T
     tr = make_trainer(R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2)), data, 8, device="cpu")
     cfg = dict(tr.config["model"]["custom_model_config"])
-    cfg["world_model_layers"] = T.gen_layers(32, 2, act_hidden="tanh")          # stacks must agree on the HIP path
-    with pytest.raises(NotImplementedError):
-        PhysicsVAE(cfg["observation_space"], cfg["action_space"], 6, {"custom_model_config": cfg}, "m")
+    cfg["world_model_layers"] = T.gen_layers(32, 2, act_hidden="tanh")          # a stack with its own activation:
+    m = PhysicsVAE(cfg["observation_space"], cfg["action_space"], 6, {"custom_model_config": cfg}, "m")    # layer by layer
+    assert isinstance(m._world_model._model[0]._model[1], torch.nn.Tanh) and isinstance(m._task_encoder._model[0]._model[1], torch.nn.ReLU)
+    assert [l["act"] for l in m.engine.layers if l["net"] == _lib.NET_WM] == [_lib.ACT_KINDS["tanh"]] * 2 + [_lib.ACT_LINEAR]
+
+
+def test_stacks_with_per_layer_widths_and_activations(golden):
+    """FC accepts any list of fc layers, each with its own hidden_size / activation / init_weight (rmt:234-270,
+    get_activation_fn rmt:30-46, get_initializer rmt:220-232); gen_layers (tpv:180-192) emits only the uniform case.
+    The layout (pvae_config.layer_width / layer_act), the module tree and the state-dict keys / shapes against the
+    reference's own model built from the same lists (capture single_mixed_tiny); what stays refused."""
+    lib = _lib.load()
+    g = golden("single_mixed_tiny")
+    arch = arch_from_meta(g)
+    assert arch["md"] == [(32, "elu"), (16, "relu"), (24, "sigmoid")] and arch["wm"][1] == (24, "linear")
+    # --- the C layout: zeroed rows = the uniform stack; a row overrides width and activation per hidden layer
+    cfg = _lib.Config(7, 3, 4, 16, 2, 32, 3, 40, 3, 8, 1, 0, 0, 0, 0)
+    info = _lib.LayerInfo()
+
+    def layers_of(c):
+        out = []
+        for i in range(lib.pvae_num_layers(C.byref(c))):
+            _lib.check(lib.pvae_layer(C.byref(c), i, C.byref(info)))
+            out.append((info.net, info.index, info.n_in, info.n_out, info.act))
+        return out
+    uniform = layers_of(cfg)
+    assert [l[3] for l in uniform if l[0] == _lib.NET_MD] == [32, 32, 32, 3] and {l[4] for l in uniform} == {0, _lib.ACT_LINEAR}
+    for net, key in ((_lib.NET_TE, "te"), (_lib.NET_MD, "md"), (_lib.NET_WM, "wm")):
+        for i, (w, a) in enumerate(arch[key]):
+            cfg.layer_width[net][i] = w
+            cfg.layer_act[net][i] = 1 + _lib.LAYER_ACTS[a]
+    got = layers_of(cfg)
+    dims = R.net_layer_dims(arch)
+    for net, name, key in ((_lib.NET_TE, "_task_encoder", "te"), (_lib.NET_MD, "_motor_decoder", "md"), (_lib.NET_WM, "_world_model", "wm")):
+        mine = [l for l in got if l[0] == net]
+        assert [(l[2], l[3]) for l in mine] == dims[name]
+        assert [l[4] for l in mine] == [_lib.LAYER_ACTS[a] for _, a in arch[key]] + [_lib.ACT_LINEAR]
+    n_floats = lib.pvae_arena_floats(C.byref(cfg))
+    assert n_floats > 0
+    bad = _lib.Config(7, 3, 4, 16, 2, 32, 3, 40, 3, 8, 1, 0, 0, 0, 0)
+    bad.layer_act[_lib.NET_MD][1] = 7
+    assert lib.pvae_num_layers(C.byref(bad)) < 0 and b"layer_act" in lib.pvae_last_error()
+    bad.layer_act[_lib.NET_MD][1] = 0
+    bad.layer_width[_lib.NET_WM][0] = -4
+    assert lib.pvae_num_layers(C.byref(bad)) < 0 and b"layer_width" in lib.pvae_last_error()
+    # --- the module tree through the trainer (our `*_layers` trainer keys carry the lists)
+    data = R.synth_demo(0, 2, 14, 7, 3)
+    tr = make_trainer(arch, data, 8, device="cpu")
+    sd = tr.model.state_dict()
+    assert list(sd.keys()) == list(g["sd_keys"])
+    assert [list(v.shape) + [0] * (2 - v.dim()) for v in sd.values()] == g["sd_shapes"].tolist()
+    assert sum(v.numel() for v in sd.values()) == int(g["n_params"])
+    mods = {"relu": torch.nn.ReLU, "tanh": torch.nn.Tanh, "sigmoid": torch.nn.Sigmoid, "elu": torch.nn.ELU}
+    for name, key in (("_task_encoder", "te"), ("_motor_decoder", "md"), ("_world_model", "wm")):
+        slims = list(getattr(tr.model, name)._model)
+        for slim, (w, a) in zip(slims, arch[key]):
+            assert slim._model[0].out_features == w
+            assert (len(slim._model) == 1) if a == "linear" else isinstance(slim._model[1], mods[a])
+    assert tr.engine.cfg.act_kind == 0 and tr.engine.cfg.layer_width[_lib.NET_MD][2] == 24
+    for name, key in (("_task_encoder", "te"), ("_motor_decoder", "md"), ("_world_model", "wm")):
+        n = len(arch[key])                        # normc rows: 1.0 hidden, 0.01 output (the lists' init_weight)
+        for i in range(n + 1):
+            norms = sd["%s._model.%d._model.0.weight" % (name, i)].norm(dim=1)
+            assert torch.allclose(norms, torch.full_like(norms, 0.01 if i == n else 1.0), rtol=1e-4)
+    # --- init_weight per layer: a normc std of one's own, xavier with a gain; unknown names fail at construction
+    from physicsvae_amd.model import PhysicsVAE
+    cmc = dict(tr.config["model"]["custom_model_config"])
+    lay = [dict(l) for l in cmc["task_encoder_layers"]]
+    lay[0]["init_weight"] = {"name": "normc", "std": 0.5}
+    lay[1]["init_weight"] = {"name": "xavier_uniform", "gain": 2.0}
+    cmc["task_encoder_layers"] = lay
+    m = PhysicsVAE(cmc["observation_space"], cmc["action_space"], 6, {"custom_model_config": cmc}, "m")
+    w0, w1 = m._task_encoder._model[0]._model[0].weight, m._task_encoder._model[1]._model[0].weight
+    assert torch.allclose(w0.norm(dim=1), torch.full((16,), 0.5), atol=1e-5)
+    bound = 2.0 * (6.0 / (16 + 24)) ** 0.5
+    assert 0.5 * bound < float(w1.detach().abs().max()) <= bound
+    for edit in ({"init_weight": {"name": "orthogonal"}}, {"activation": "swish"}, {"type": "bn"}, {"hidden_size": "output"}):
+        lay2 = [dict(l) for l in lay]
+        lay2[0].update(edit)
+        cmc2 = dict(cmc, task_encoder_layers=lay2)
+        with pytest.raises(NotImplementedError):
+            PhysicsVAE(cmc2["observation_space"], cmc2["action_space"], 6, {"custom_model_config": cmc2}, "m")
 
 
 def test_cli_flags_for_act_fn_and_weight_decay(tmp_path):

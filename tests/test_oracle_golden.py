@@ -10,16 +10,19 @@ from oracle import refpath as R
 
 def arch_from_meta(meta):
     """`meta` of a fixture, or the fixture itself (then an edited "act_fn" recorded in it is honoured)."""
-    act = "relu"
+    act, stacks = "relu", None
     if hasattr(meta, "files"):
         act = str(meta["act_fn"]) if "act_fn" in meta.files else "relu"
+        stacks = meta["stacks"] if "stacks" in meta.files else None          # stacks recorded layer by layer
         meta = meta["meta"]
     Db, Da, Z, tw, td, mw, md_, ww, wd = [int(v) for v in meta[:9]]
-    return R.make_arch(Db, Da, latent=Z, te=(tw, td), md=(mw, md_), wm=(ww, wd), act=act)
+    arch = R.make_arch(Db, Da, latent=Z, te=(tw, td), md=(mw, md_), wm=(ww, wd), act=act)
+    return R.with_stacks(arch, stacks) if stacks is not None else arch
 
 
 SINGLE = ["single_tiny", "single_c1", "single_c2", "single_default",
-          "single_tiny_tanh", "single_tiny_sigmoid", "single_tiny_elu", "single_c1_tanh"]      # last four: "act_fn" edited
+          "single_tiny_tanh", "single_tiny_sigmoid", "single_tiny_elu", "single_c1_tanh",      # these four: "act_fn" edited
+          "single_mixed_tiny", "single_mixed_c1"]      # per-layer widths / activations (FC's general layer list, rmt:234-270)
 
 
 @pytest.mark.parametrize("name", SINGLE)
@@ -120,7 +123,7 @@ def test_single_batch_losses_and_grads_match_reference(golden, name):
     np.testing.assert_array_equal(g["joint_total_vb_perturbed"], g["joint_total"])
 
 
-CLEAR = ["single_tiny_clear", "single_c1_clear", "single_default_clear", "single_c2_clear"]
+CLEAR = ["single_tiny_clear", "single_c1_clear", "single_default_clear", "single_c2_clear", "single_pyramid_c1_clear"]
 
 
 def clear_batch(g):
@@ -167,7 +170,7 @@ def test_kink_free_batches_match_reference(golden, name):
             digest_close(R.tensor_digest(gr), g["%s_graddigest::%s" % (tag, k)], float(g["%s_gradmax::%s" % (tag, k)]), 2e-5)
 
 
-@pytest.mark.parametrize("name", ["look3_tiny", "look2_c1", "l1_tiny", "l1_look2_c1"])
+@pytest.mark.parametrize("name", ["look3_tiny", "look2_c1", "l1_tiny", "l1_look2_c1", "look2_mixed_tiny"])
 def test_lookahead_unroll_matches_reference(golden, name):
     """tpv:367-428 with lookahead 3 / 2: windows, ragged last batch, loss terms averaged over the
     steps, and the gradients of the back-propagation through every earlier step.  The l1_* cases
@@ -231,7 +234,7 @@ def test_checkpoint_layout_matches_reference(golden):
         assert list(obj.keys()) == list(g["ckpt_keys::" + f]), f
 
 
-@pytest.mark.parametrize("name", ["train_tiny", "train_c1", "train_tiny_look2", "train_tiny_elu_wd"])
+@pytest.mark.parametrize("name", ["train_tiny", "train_c1", "train_tiny_look2", "train_tiny_elu_wd", "train_mixed_tiny"])
 def test_training_run_matches_reference(golden, name):
     g = golden(name)
     arch = arch_from_meta(g)
