@@ -244,6 +244,15 @@ def init_from_env(backend=None):
     if os.environ.get("PVAE_LOCAL_DEVICE") is not None:
         local = int(os.environ["PVAE_LOCAL_DEVICE"])
     backend = backend or os.environ.get("PVAE_DIST_BACKEND")
+    # a launcher that starts more ranks on this node than it has GPUs (torchrun --nproc-per-node 8 on a 1-GPU box):
+    # the ranks share the devices round-robin over gloo, as with the test hooks above -- functional, not a measurement
+    # (every rank of the node sees the same LOCAL_WORLD_SIZE and device count, so all take the same branch)
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev and int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > ndev and os.environ.get("PVAE_LOCAL_DEVICE") is None:
+        local = local % ndev
+        backend = backend or "gloo"
+        os.environ["PVAE_LOCAL_DEVICE"] = str(local)
+        os.environ["PVAE_BENCH_SHARED_GPU"] = "1"
     force = os.environ.get("PVAE_DP_ALWAYS_REDUCE", "0") == "1"
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -249,7 +249,27 @@ def test_p2p_four_ranks_replicas_identical_and_match_one_process(tmp_path, form)
 
 
 @pytest.mark.parametrize("form", ["p2p", "p2p_push"])
-@pytest.mark.parametrize("world", [2, 3, 4])
+def test_p2p_eight_ranks_replicas_identical_and_match_one_process(tmp_path, form):
+    """BASELINE configs[3]'s rank count on the hardware there is: eight processes on one GPU (global batch 64 = 8 x 8),
+    every flag word, slice boundary and template instance of the 8-rank exchange in use.  Replicas bit-identical;
+    against one process with the global batch the parameters agree to fp32 summation order."""
+    dp = _run(tmp_path, 8, 8, "p2p8", port="29584", PVAE_DP_EXCHANGE=form)
+    single = _run(tmp_path, 1, 64, "single8", port="29585")[0]
+    assert all(r["timeouts"] == 0 for r in dp)
+    for r in dp[1:]:
+        for k in dp[0]["sd"]:
+            assert torch.equal(dp[0]["sd"][k], r["sd"][k]), k
+    assert dp[0]["steps"] == single["steps"]
+    assert dp[0]["losses"] == pytest.approx(single["losses"], rel=1e-5)
+    for k, v in single["sd"].items():
+        if k.startswith("_value_branch"):
+            continue
+        err = float((dp[0]["sd"][k] - v).norm() / (v.norm() + 1e-30))
+        assert err < 2e-3, (k, err)
+
+
+@pytest.mark.parametrize("form", ["p2p", "p2p_push"])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_p2p_exchange_launch_sums_in_rank_order_and_updates_every_replica(tmp_path, world, form):
     """The exchange launch on known gradients: the parameters every rank ends with equal flat Adam on the rank-order
     sum ((g0 + g1) + g2) + g3 bit for bit, over all slices (own slice computed here, the others pushed by their

@@ -55,6 +55,27 @@ def test_bench_plain_two_ranks_self_launch():
         assert all(sweep[m]["value"] > 0 for m in ("inline", "bucketed", "sharded"))
 
 
+def test_bench_under_the_launcher_command_of_the_scaling_run():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ...`: the command the multi-GPU scaling run uses, here with N = 2.  On a box with fewer GPUs than ranks
+    the ranks share the devices over gloo (`parallel.init_from_env`): same code path up to the transport, flagged in
+    the line; the last stdout line that parses is rank 0's ONE JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29633", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "10", "--warmup", "3"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 512 and d["value"] > 0 and np.isfinite(d["last_loss"])
+    assert d["replicas_identical"] is True
+    assert d["ranks_share_a_gpu"] is (torch.cuda.device_count() < 2)
+    assert d["exchange_autotune"]["chosen"] in ("inline", "bucketed", "sharded", "p2p", "p2p_push")
+
+
 def test_bench_plain_single_gpu_line():
     d = _bench("--steps", "20", "--warmup", "5", "--no-rocprof")
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 0 and d["config"]["phase"] == "joint"
