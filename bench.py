@@ -59,10 +59,12 @@ CAT_NAMES = {
     3: "bwd_pair_kernel (input gradient || weight gradient of one layer, + deferred Adam of the layer before)",
 }
 CAT_MATCH = {
-    0: ("gemm_splitk_ws_kernel<true", "gemm_splitk_reg16_kernel<true", "gemm_splitk_reg_kernel<true"),
-    1: ("gemm_splitk_ws_kernel<false", "gemm_splitk_reg16_kernel<false", "gemm_splitk_reg_kernel<false"),
+    0: ("gemm_splitk_ws_kernel<true", "gemm_splitk_ws64_kernel<true", "gemm_splitk_ws_pro_kernel",
+        "gemm_splitk_reg16_kernel<true", "gemm_splitk_reg_kernel<true"),
+    1: ("gemm_splitk_ws_kernel<false", "gemm_splitk_ws64_kernel<false", "gemm_splitk_reg16_kernel<false",
+        "gemm_splitk_reg_kernel<false"),
     2: ("wgrad_pair_kernel", "gemm_wgrad_reg_kernel"),
-    3: ("bwd_pair_kernel",),
+    3: ("bwd_pair_kernel", "bwd_pair64_kernel"),        # (64x32 input-gradient tiles at >= 512 rows)
 }
 
 
