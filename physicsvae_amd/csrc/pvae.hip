@@ -2464,10 +2464,14 @@ constexpr uint32_t kP2pMagic = 0x50325056u;               // "PV2P"
 int pvae_p2p_export(pvae_ctx* c, void* blob) {
     if (!c || !blob) return fail(-1, "null argument");
     if (!c->params || !c->grads) return fail(-2, "parameter / gradient arenas not bound");
-    if (!c->p2p.flags) {
-        HIP_TRY(hipExtMallocWithFlags((void**)&c->p2p.flags, kP2pFlagBytes, hipDeviceMallocUncached));
-        HIP_TRY(hipMemset(c->p2p.flags, 0, kP2pFlagBytes));
-    }
+    if (c->p2p.open) return fail(-2, "peer-mapped exchange is open: pvae_p2p_close before exporting again");
+    if (!c->p2p.flags) HIP_TRY(hipExtMallocWithFlags((void**)&c->p2p.flags, kP2pFlagBytes, hipDeviceMallocUncached));
+    // every set-up starts from a zeroed flag block (epochs restart at 0 in pvae_p2p_open): a block that an earlier,
+    // closed set-up left its epochs in would satisfy the first waits of the new one.  The exchange of the blobs that
+    // follows is the barrier between this and any peer's first write.
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(c->p2p.flags, 0, kP2pFlagBytes));
+    HIP_TRY(hipDeviceSynchronize());
     P2pBlob b;
     memset(&b, 0, sizeof(b));
     b.magic = kP2pMagic; b.abi = PVAE_ABI_VERSION; b.arena_floats = c->L.arena_floats;

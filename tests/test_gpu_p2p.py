@@ -48,7 +48,17 @@ elif mode == "kernel":
     assert eng.has_p2p
     te_off, te_cnt = eng.segments[_lib.NET_TE]
     ok = True
-    for step in (1, 2, 3):
+    for step in (1, 2, 3, 4, 5):
+        if step == 4:
+            if os.environ.get("P2P_TEST_REOPEN") != "1":
+                break
+            # the set-up torn down and made again (what a calibration does when it moves from one form to the next
+            # after a failed attach): flag epochs of the closed set-up must not satisfy the new one's waits
+            torch.cuda.synchronize(); dist.barrier()
+            eng.p2p_close()
+            assert not eng.has_p2p and eng.p2p_status()[1] == 0
+            dist.barrier()
+            assert tr.dp.attach_p2p(eng, os.environ["PVAE_DP_EXCHANGE"]) and eng.has_p2p
         g = torch.Generator(device="cuda").manual_seed(100 * step + rank)
         eng.grads.copy_(torch.randn(eng.grads.numel(), generator=g, device="cuda") * 1e-2)
         torch.cuda.synchronize(); dist.barrier()
@@ -276,6 +286,14 @@ def test_p2p_exchange_launch_sums_in_rank_order_and_updates_every_replica(tmp_pa
     owners), moments are updated on the own slice, nothing outside the exchanged segment moves; three rounds over
     the same buffers (flag epochs, ticket reset, stale-cache hazards)."""
     res = _run(tmp_path, world, 8, "k%d" % world, mode="kernel", port=str(29570 + world), PVAE_DP_EXCHANGE=form)
+    assert all(r["ok"] and r["timeouts"] == 0 for r in res), res
+
+
+@pytest.mark.parametrize("form", ["p2p", "p2p_push"])
+def test_p2p_closed_and_attached_again_starts_from_clean_flags(tmp_path, form):
+    """pvae_p2p_close, then export / open / self-test again in the same processes (three ranks): the exchange launches
+    of the second set-up are as exact as the first one's, no wait gives up."""
+    res = _run(tmp_path, 3, 8, "reopen", mode="kernel", port="29591", PVAE_DP_EXCHANGE=form, P2P_TEST_REOPEN="1")
     assert all(r["ok"] and r["timeouts"] == 0 for r in res), res
 
 
