@@ -253,6 +253,9 @@ __device__ inline void stage_row_vec(const StageArgs& a, int r, int t, int rows_
 #ifndef PVAE_REG_DEPTH_D
 #define PVAE_REG_DEPTH_D 2
 #endif
+#ifndef PVAE_REG_DEPTH_D64
+#define PVAE_REG_DEPTH_D64 1       // the 64x32 input-gradient body of the >= 512-row pairs: one set (A/B at config-5 sizes:
+#endif                             // 1 / 2 / 3 sets = 397.8 / 402.4 / 424 us per joint step, profiles/r03_ab_regdepth_c5.txt)
 #ifndef PVAE_REG_DEPTH_16
 #define PVAE_REG_DEPTH_16 4
 #endif
@@ -474,7 +477,7 @@ __device__ inline void splitk_reg_body(float* lds, int bid, const GemmArgs& ga, 
 constexpr int kReg64RingFloats = 2 * (64 * 64 + 64 * 32);          // 2 slots x 24 KB = 48 KB
 template <class Epi>
 __device__ inline void splitk_reg64_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
-    constexpr int BK = 64, kTileQ = 64 * 64, kTileP = 64 * 32, kStage = kTileQ + kTileP, D = PVAE_REG_DEPTH_D;
+    constexpr int BK = 64, kTileQ = 64 * 64, kTileP = 64 * 32, kStage = kTileQ + kTileP, D = PVAE_REG_DEPTH_D64;
     constexpr int RS = 36;
     static_assert(2 * kStage >= 4 * 64 * RS, "ring must hold the split-K reduction buffer");
     const float* __restrict__ Q = ga.Q;
