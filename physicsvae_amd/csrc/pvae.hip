@@ -2612,6 +2612,9 @@ static int p2p_exchange(pvae_ctx* c, int net, int64_t off, int64_t cnt, const pv
     if (!c->m || !c->v) return fail(-2, "Adam moment arenas not bound");
     if (P.grads[P.rank] != c->grads || P.params[P.rank] != c->params) return fail(-2, "arenas were re-bound after pvae_p2p_export");
     if ((off & 3) || (cnt & 3) || cnt <= 0) return fail(-1, "bucket [%lld, +%lld) not float4-aligned", (long long)off, (long long)cnt);
+    // (the kernels address a bucket through 32-bit buffer descriptors: one bucket stays below 4 GiB -- a billion
+    //  parameters; larger stacks go through in several buckets, PVAE_DP_BUCKET_MB)
+    if (cnt + 4 * (int64_t)P.world >= ((int64_t)1 << 30)) return fail(-1, "bucket of %lld floats: the peer-mapped exchange takes < 2^30 per bucket", (long long)cnt);
     P2pArgs a;
     memset(&a, 0, sizeof(a));
     for (int q = 0; q < P.world; ++q) {

@@ -922,3 +922,25 @@ def test_cli_flags_for_act_fn_and_weight_decay(tmp_path):
     a = T.arg_parser().parse_args(["--data_train", pkl])
     cfg = T.get_trainer_config(a)
     assert cfg["act_fn"] == "relu" and cfg["weight_decay"] == 0.0              # tpv:262, 253
+
+
+def test_launcher_with_more_ranks_than_gpus_shares_the_devices(monkeypatch):
+    """`parallel.init_from_env` under `torchrun --nproc-per-node 8` on a box with fewer GPUs: the ranks take the
+    devices round-robin and rendezvous over gloo (RCCL refuses two ranks on one device); with enough GPUs nothing
+    changes.  (Device count faked; no process group is created at WORLD_SIZE = 1.)"""
+    from physicsvae_amd import parallel
+    for k in ("PVAE_LOCAL_DEVICE", "PVAE_BENCH_SHARED_GPU", "PVAE_DIST_BACKEND", "PVAE_DP_ALWAYS_REDUCE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert parallel.init_from_env() == (0, 1, 1)                     # 5 % 2
+    assert os.environ["PVAE_LOCAL_DEVICE"] == "1" and os.environ["PVAE_BENCH_SHARED_GPU"] == "1"
+    monkeypatch.delenv("PVAE_LOCAL_DEVICE")
+    monkeypatch.delenv("PVAE_BENCH_SHARED_GPU")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert parallel.init_from_env() == (0, 1, 5)
+    assert "PVAE_LOCAL_DEVICE" not in os.environ and "PVAE_BENCH_SHARED_GPU" not in os.environ
