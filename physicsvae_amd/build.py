@@ -28,7 +28,9 @@ def is_stale():
 def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -amdgpu-kernarg-preload-count: leading scalar / pointer kernel arguments arrive in SGPRs at wave launch (gfx950)
+    # instead of by an s_load inside the kernel (pvae_gemm.h PVAE_GA_PARAMS; tools/kernarg_preload_probe.hip)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-kernarg-preload-count=16",
            "-Wall", "-Wno-unused-function", os.path.join(CSRC, "pvae.hip"), "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))

@@ -278,6 +278,17 @@ struct GemmArgs {
     int tile16 = 0;           // input gradient on 16x16 output tiles (splitk_reg16_body<false>) instead of 32x32
     int rowxcd = g_rowxcd;    // see g_rowxcd
 };
+// Kernel-argument preload (gfx950: the first user SGPRs are filled by the hardware at wave launch; hipcc -mllvm
+// -amdgpu-kernarg-preload-count=16 in physicsvae_amd/build.py, at most 14 dwords, scalars and pointers only -- a
+// struct passed by value is fetched by s_load inside the kernel, ~0.26 us on the critical path of every dependent
+// launch: tools/kernarg_preload_probe.hip).  The contraction kernels therefore take the operands every workgroup
+// needs before it can issue its first load as LEADING scalar parameters (11 dwords) and rebuild the GemmArgs from
+// them; epilogue structs follow and arrive by s_load while the first tiles are in flight.
+#define PVAE_GA_PARAMS(n) const float* n##Q, const float* n##P, int n##ldq, int n##ldp, int n##K, int n##tq, int n##tp, \
+                          int n##ppx, int n##fl
+#define PVAE_GA_PASS(g) (g).Q, (g).P, (g).ldq, (g).ldp, (g).K, (g).tiles_q, (g).tiles_p, (g).p_per_xcd, ga_flags(g)
+#define PVAE_GA_OF(n) GemmArgs{n##Q, n##ldq, n##P, n##ldp, n##K, n##tq, n##tp, n##ppx, n##fl & 1, (n##fl >> 1) & 1, (n##fl >> 2) & 1, (n##fl >> 3) & 1}
+inline int ga_flags(const GemmArgs& g) { return (g.krot & 1) | ((g.tile32 & 1) << 1) | ((g.tile16 & 1) << 2) | ((g.rowxcd & 1) << 3); }
 
 // Experiment (off by default): start each workgroup at a different k-tile and wrap around, so that
 // the workgroups of an XCD that share operand rows (same q-tile: X rows, same p-tile: W rows) do
@@ -597,7 +608,8 @@ __device__ inline void splitk_reg64_body(float* lds, int bid, const GemmArgs& ga
 
 template <bool P_ROW, class Epi, int ABL = 0>
 __global__ void __launch_bounds__(256)
-gemm_splitk_reg_kernel(GemmArgs ga, Epi epi) {
+gemm_splitk_reg_kernel(PVAE_GA_PARAMS(a_), Epi epi) {
+    const GemmArgs ga = PVAE_GA_OF(a_);
     __shared__ __attribute__((aligned(16))) float lds[kRegRingFloats];
     splitk_reg_body<P_ROW, Epi, ABL>(lds, blockIdx.x, ga, epi);
 }
@@ -1041,20 +1053,23 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
 
 template <bool P_ROW, class Epi>
 __global__ void __launch_bounds__(512)
-gemm_splitk_ws64_kernel(GemmArgs ga, Epi epi) {
+gemm_splitk_ws64_kernel(PVAE_GA_PARAMS(a_), Epi epi) {
+    const GemmArgs ga = PVAE_GA_OF(a_);
     __shared__ __attribute__((aligned(16))) float lds[kWs64Floats];
     splitk_ws64_body<P_ROW, Epi>(lds, blockIdx.x, ga, epi);
 }
 
 template <bool P_ROW, class Epi>
 __global__ void __launch_bounds__(kWsThreads)
-gemm_splitk_ws_kernel(GemmArgs ga, Epi epi) {
+gemm_splitk_ws_kernel(PVAE_GA_PARAMS(a_), Epi epi) {
+    const GemmArgs ga = PVAE_GA_OF(a_);
     __shared__ __attribute__((aligned(16))) float lds[kWsFloats];
     splitk_ws_body<P_ROW, Epi>(lds, blockIdx.x, ga, epi);
 }
 template <class Epi, class Pro>
 __global__ void __launch_bounds__(kWsThreads)
-gemm_splitk_ws_pro_kernel(GemmArgs ga, Epi epi, Pro pro) {
+gemm_splitk_ws_pro_kernel(PVAE_GA_PARAMS(a_), Epi epi, Pro pro) {
+    const GemmArgs ga = PVAE_GA_OF(a_);
     __shared__ __attribute__((aligned(16))) float lds[kWsFloats];
     __shared__ __attribute__((aligned(16))) float scratch[Pro::kScratchFloats];
     splitk_ws_body<true, Epi, Pro>(lds, blockIdx.x, ga, epi, pro, scratch);
@@ -1174,7 +1189,8 @@ __device__ inline void splitk_reg16_body(float* lds, int bid, const GemmArgs& ga
 
 template <bool P_ROW, class Epi>
 __global__ void __launch_bounds__(256)
-gemm_splitk_reg16_kernel(GemmArgs ga, Epi epi) {
+gemm_splitk_reg16_kernel(PVAE_GA_PARAMS(a_), Epi epi) {
+    const GemmArgs ga = PVAE_GA_OF(a_);
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * 16 * 64];
     splitk_reg16_body<P_ROW, Epi>(lds, blockIdx.x, ga, epi);
 }
@@ -1642,7 +1658,8 @@ __device__ inline void bias_grad_body(float* lds, int tile, const GemmArgs& ga, 
 
 template <class Epi, int ABL = 0>
 __global__ void __launch_bounds__(256)
-gemm_wgrad_reg_kernel(GemmArgs ga, Epi epi, int nw, AdamPair ad) {
+gemm_wgrad_reg_kernel(PVAE_GA_PARAMS(a_), int nw, Epi epi, AdamPair ad) {
+    const GemmArgs ga = PVAE_GA_OF(a_);
     __shared__ __attribute__((aligned(16))) float lds[kPairLdsFloats];
     const int b = blockIdx.x, nb = bias_tiles(ga);
     if (b < nw) wgrad_body<Epi, ABL>(lds, b, ga, epi);
@@ -1661,8 +1678,9 @@ gemm_wgrad_reg_kernel(GemmArgs ga, Epi epi, int nw, AdamPair ad) {
 // step that precedes it instead of being a launch of its own.
 template <class EpiW>
 __global__ void __launch_bounds__(256)
-wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2, int n12, StageArgs sa, AdamPair ad, int na) {
+wgrad_pair_kernel(int n1, int n12, int na, PVAE_GA_PARAMS(a_), GemmArgs g2, EpiW e1, EpiW e2, StageArgs sa, AdamPair ad) {
     __shared__ __attribute__((aligned(16))) float lds[kPairLdsFloats];
+    const GemmArgs g1 = PVAE_GA_OF(a_);
     const int b = blockIdx.x;
     const int nb1 = bias_tiles(g1), nb2 = bias_tiles(g2);
     if (b < n1) wgrad_body<EpiW>(lds, b, g1, e1);
@@ -1677,8 +1695,9 @@ wgrad_pair_kernel(GemmArgs g1, EpiW e1, int n1, GemmArgs g2, EpiW e2, int n12, S
 // pair needs 512-thread blocks and 64 KB of LDS per workgroup and measured 15 % slower.)
 template <class EpiD, class EpiW, int ABL = 0>          // ABL: ablation bits of the two bodies (probes only)
 __global__ void __launch_bounds__(256)
-bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, AdamPair ad) {
+bwd_pair_kernel(int nd, int nw, PVAE_GA_PARAMS(w_), GemmArgs gd, EpiD ed, EpiW ew, AdamPair ad) {
     __shared__ __attribute__((aligned(16))) float lds[kPairLdsFloats];
+    const GemmArgs gw = PVAE_GA_OF(w_);           // (preloaded: the weight-gradient workgroups are the launch's long pole)
     PVAE_MARK(0, 0);
     PVAE_MARK_HW();
     // (dispatch order matters: input-gradient workgroups first.  Weight-gradient workgroups first: world step
@@ -1698,8 +1717,9 @@ bwd_pair_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, Adam
 // and more.
 template <class EpiD, class EpiW>
 __global__ void __launch_bounds__(256)
-bwd_pair64_kernel(GemmArgs gd, EpiD ed, int nd, GemmArgs gw, EpiW ew, int nw, AdamPair ad) {
+bwd_pair64_kernel(int nd, int nw, PVAE_GA_PARAMS(w_), GemmArgs gd, EpiD ed, EpiW ew, AdamPair ad) {
     __shared__ __attribute__((aligned(16))) float lds[kReg64RingFloats];
+    const GemmArgs gw = PVAE_GA_OF(w_);
     const int b = blockIdx.x;
     if (b < nd) splitk_reg64_body<EpiD>(lds, b, gd, ed);
     else if (b < nd + nw) wgrad_body<EpiW>(lds, b - nd, gw, ew);
@@ -2052,21 +2072,21 @@ inline hipError_t gemm_forward_epi(const float* X, int ldx, const float* W, int 
                                    const Epi& e, hipStream_t st) {
     if (forward_uses_16x16(M, N)) {
         const GemmGrid g = make_grid(M, N, 16, 16);
-        PVAE_LAUNCH((gemm_splitk_reg16_kernel<true, Epi>), dim3(g.grid), dim3(256), st,
-                           GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+        const GemmArgs ga{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd};
+        PVAE_LAUNCH((gemm_splitk_reg16_kernel<true, Epi>), dim3(g.grid), dim3(256), st, PVAE_GA_PASS(ga), e);
         return hipGetLastError();
     }
     if constexpr (std::is_same<Epi, EpiBiasAct>::value) {
         if (uses_64x32(M, N)) {
             const GemmGrid g = make_grid(M, N, 64, 32);
-            PVAE_LAUNCH((gemm_splitk_ws64_kernel<true, Epi>), dim3(g.grid), dim3(512), st,
-                               GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+            const GemmArgs ga{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd};
+            PVAE_LAUNCH((gemm_splitk_ws64_kernel<true, Epi>), dim3(g.grid), dim3(512), st, PVAE_GA_PASS(ga), e);
             return hipGetLastError();
         }
     }
     const GemmGrid g = make_grid(M, N, 32, 32);
-    PVAE_LAUNCH((gemm_splitk_ws_kernel<true, Epi>), dim3(g.grid), dim3(kWsThreads), st,
-                       GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+    const GemmArgs ga{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd};
+    PVAE_LAUNCH((gemm_splitk_ws_kernel<true, Epi>), dim3(g.grid), dim3(kWsThreads), st, PVAE_GA_PASS(ga), e);
     return hipGetLastError();
 }
 // forward layer on 32x32 tiles whose launch forms some of its own input columns (Pro, see splitk_ws_body)
@@ -2075,8 +2095,8 @@ template <class Epi, class Pro>
 inline hipError_t gemm_forward_pro(const float* X, int ldx, const float* W, int ldw, int M, int N, int K, const Epi& e,
                                    const Pro& pro, hipStream_t st) {
     const GemmGrid g = make_grid(M, N, 32, 32);
-    PVAE_LAUNCH((gemm_splitk_ws_pro_kernel<Epi, Pro>), dim3(g.grid), dim3(kWsThreads), st,
-                GemmArgs{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd}, e, pro);
+    const GemmArgs ga{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd};
+    PVAE_LAUNCH((gemm_splitk_ws_pro_kernel<Epi, Pro>), dim3(g.grid), dim3(kWsThreads), st, PVAE_GA_PASS(ga), e, pro);
     return hipGetLastError();
 }
 inline hipError_t gemm_forward(const float* X, int ldx, const float* W, int ldw, const float* bias,
@@ -2111,14 +2131,14 @@ inline hipError_t gemm_dgrad_epi(const float* dZ, int ldz, const float* W, int l
     if constexpr (std::is_same<EpiD, EpiMask>::value) {
         if (uses_64x32(M, Kin)) {                               // stand-alone input gradient of a hidden layer at >= 512 rows
             const GemmGrid g = make_grid(M, Kin, 64, 32);
-            PVAE_LAUNCH((gemm_splitk_ws64_kernel<false, EpiD>), dim3(g.grid), dim3(512), st,
-                               GemmArgs{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd}, e);
+            const GemmArgs ga{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd};
+            PVAE_LAUNCH((gemm_splitk_ws64_kernel<false, EpiD>), dim3(g.grid), dim3(512), st, PVAE_GA_PASS(ga), e);
             return hipGetLastError();
         }
     }
     const DgradPlan d = plan_dgrad(dZ, ldz, W, ldw, M, Kin, N);
-    if (d.ga.tile16) PVAE_LAUNCH((gemm_splitk_reg16_kernel<false, EpiD>), dim3(d.grid), dim3(256), st, d.ga, e);
-    else PVAE_LAUNCH((gemm_splitk_ws_kernel<false, EpiD>), dim3(d.grid), dim3(kWsThreads), st, d.ga, e);
+    if (d.ga.tile16) PVAE_LAUNCH((gemm_splitk_reg16_kernel<false, EpiD>), dim3(d.grid), dim3(256), st, PVAE_GA_PASS(d.ga), e);
+    else PVAE_LAUNCH((gemm_splitk_ws_kernel<false, EpiD>), dim3(d.grid), dim3(kWsThreads), st, PVAE_GA_PASS(d.ga), e);
     return hipGetLastError();
 }
 inline hipError_t gemm_dgrad(const float* dZ, int ldz, const float* W, int ldw, const float* mask,
@@ -2148,8 +2168,8 @@ template <class Epi>
 inline hipError_t gemm_wgrad(const float* dZ, int ldz, const float* X, int ldx, int N, int Kin, int M,
                              const Epi& e, hipStream_t st, const AdamPair* ad = nullptr) {
     const WgradPlan w = plan_wgrad(dZ, ldz, X, ldx, N, Kin, M);
-    PVAE_LAUNCH((gemm_wgrad_reg_kernel<Epi>), dim3(w.grid + w.nbias + adam_blocks(ad)), dim3(256), st, w.ga, e, w.grid,
-                ad ? *ad : AdamPair());
+    PVAE_LAUNCH((gemm_wgrad_reg_kernel<Epi>), dim3(w.grid + w.nbias + adam_blocks(ad)), dim3(256), st, PVAE_GA_PASS(w.ga),
+                w.grid, e, ad ? *ad : AdamPair());
     return hipGetLastError();
 }
 // one launch, two independent weight gradients (the two last layers of a backward pass)
@@ -2164,7 +2184,7 @@ inline hipError_t gemm_wgrad_pair(const float* dZ1, int ldz1, const float* X1, i
     memset(&sa, 0, sizeof(sa));
     if (next) sa = *next;                     // rows_pad extra blocks gather the next minibatch
     PVAE_LAUNCH((wgrad_pair_kernel<EpiW>), dim3(w1.grid + w2.grid + w1.nbias + w2.nbias + adam_blocks(ad) + sa.rows_pad),
-                dim3(256), st, w1.ga, e1, w1.grid, w2.ga, e2, w1.grid + w2.grid, sa, ad ? *ad : AdamPair(), adam_blocks(ad));
+                dim3(256), st, w1.grid, w1.grid + w2.grid, adam_blocks(ad), PVAE_GA_PASS(w1.ga), w2.ga, e1, e2, sa, ad ? *ad : AdamPair());
     return hipGetLastError();
 }
 // one launch: dX'[M][Kin'] = (dZ'[M][N'] W'[N'][Kin']) .* mask   ||   G[N][Kin] = dZ[M][N]^T X[M][Kin]
@@ -2178,13 +2198,13 @@ inline hipError_t gemm_bwd_pair_epi(const float* dZd, int ldzd, const float* Wd,
         if (pair_uses_64x32(Md, Kind)) {                        // hidden-layer input gradient at >= 512 rows
             const GemmGrid g = make_grid(Md, Kind, 64, 32);
             PVAE_LAUNCH((bwd_pair64_kernel<EpiD, EpiW>), dim3(g.grid + w.grid + w.nbias + adam_blocks(ad)), dim3(256), st,
-                        GemmArgs{dZd, ldzd, Wd, ldwd, Nd, g.tiles_q, g.tiles_p, g.p_per_xcd}, ed, g.grid, w.ga, ew, w.grid,
+                        g.grid, w.grid, PVAE_GA_PASS(w.ga), GemmArgs{dZd, ldzd, Wd, ldwd, Nd, g.tiles_q, g.tiles_p, g.p_per_xcd}, ed, ew,
                         ad ? *ad : AdamPair());
             return hipGetLastError();
         }
     }
     PVAE_LAUNCH((bwd_pair_kernel<EpiD, EpiW>), dim3(d.grid + w.grid + w.nbias + adam_blocks(ad)), dim3(256), st,
-                       d.ga, ed, d.grid, w.ga, ew, w.grid, ad ? *ad : AdamPair());
+                       d.grid, w.grid, PVAE_GA_PASS(w.ga), d.ga, ed, ew, ad ? *ad : AdamPair());
     return hipGetLastError();
 }
 template <class EpiW>

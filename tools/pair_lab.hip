@@ -32,7 +32,7 @@ static float time_pair(hipStream_t st, const float* dZ, const float* W, const fl
     const AdamSeg adv = (parts & 8) ? ad : AdamSeg();
     auto launch = [&]() {
         hipLaunchKernelGGL((bwd_pair_kernel<EpiMask, EpiGradStore, ABL>), dim3(nd + nw + nb + adam_blocks(&adv)), dim3(256), 0, st,
-                           GemmArgs{dZ, N, W, K, N, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, nd, gw, es, nw, adv);
+                           nd, nw, PVAE_GA_PASS(gw), GemmArgs{dZ, N, W, K, N, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, es, adv);
     };
     for (int i = 0; i < 20; ++i) launch();
     hipStreamSynchronize(st);

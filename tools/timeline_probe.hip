@@ -38,7 +38,7 @@ int main() {
         GemmArgs ga{X, K, W, K, K, g.tiles_q, g.tiles_p, g.p_per_xcd};
         ga.krot = c.mode;
         auto go = [&]() {
-            hipLaunchKernelGGL((gemm_splitk_ws_kernel<true, EpiBiasAct>), dim3(g.grid), dim3(512), 0, st, ga, e);
+            hipLaunchKernelGGL((gemm_splitk_ws_kernel<true, EpiBiasAct>), dim3(g.grid), dim3(512), 0, st, PVAE_GA_PASS(ga), e);
         };
         for (int i = 0; i < 20; ++i) go();
         CK(hipStreamSynchronize(st));

@@ -17,7 +17,7 @@ static float run(const float* dZ, const float* X, float* G, int rows, hipStream_
     e.gb = G + (size_t)N * Kin;
     auto go = [&]() {
         hipLaunchKernelGGL((gemm_wgrad_reg_kernel<EpiGradStore, ABL>), dim3(g.grid), dim3(256), 0, st,
-                           GemmArgs{dZ, N, X, Kin, rows, g.tiles_q, g.tiles_p, g.p_per_xcd}, e, g.grid, AdamSeg());
+                           PVAE_GA_PASS((GemmArgs{dZ, N, X, Kin, rows, g.tiles_q, g.tiles_p, g.p_per_xcd})), g.grid, e, AdamSeg());
     };
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 10; ++i) go();
