@@ -288,7 +288,33 @@ struct GemmArgs {
                           int n##ppx, int n##fl
 #define PVAE_GA_PASS(g) (g).Q, (g).P, (g).ldq, (g).ldp, (g).K, (g).tiles_q, (g).tiles_p, (g).p_per_xcd, ga_flags(g)
 #define PVAE_GA_OF(n) GemmArgs{n##Q, n##ldq, n##P, n##ldp, n##K, n##tq, n##tp, n##ppx, n##fl & 1, (n##fl >> 1) & 1, (n##fl >> 2) & 1, (n##fl >> 3) & 1}
+// Launches that hold TWO contractions (input gradient || weight gradient, or the two trailing weight gradients) carry
+// both sets of operands in the 14 preloadable dwords: four pointers, and per contraction the two row strides, the two
+// tile counts (16 bits each) and the contraction length with the four switch bits (26 + 4 bits).  The workgroup
+// counts of the two bodies follow from the tile counts (make_grid).  A/B of what is preloaded, joint step / config-5
+// sizes: nothing 248.2 / 391.1 us, weight-gradient operands 246.4 / 388.7, input-gradient operands 244.4 / 385.5,
+// both (this) -- profiles/r03_ab_kernarg_preload.txt.
+#define PVAE_GA2_PARAMS const float* aQ, const float* aP, const float* bQ, const float* bP, unsigned a_ld, unsigned b_ld, \
+                        unsigned a_t, unsigned b_t, unsigned a_k, unsigned b_k
+#define PVAE_GA2_PASS(ga, gb) (ga).Q, (ga).P, (gb).Q, (gb).P, ga_pack_ld(ga), ga_pack_ld(gb), ga_pack_t(ga), ga_pack_t(gb), \
+                              ga_pack_k(ga), ga_pack_k(gb)
+#define PVAE_GA2_A ga_unpack(aQ, aP, a_ld, a_t, a_k)
+#define PVAE_GA2_B ga_unpack(bQ, bP, b_ld, b_t, b_k)
 inline int ga_flags(const GemmArgs& g) { return (g.krot & 1) | ((g.tile32 & 1) << 1) | ((g.tile16 & 1) << 2) | ((g.rowxcd & 1) << 3); }
+inline unsigned ga_pack_ld(const GemmArgs& g) { return (unsigned)g.ldq | ((unsigned)g.ldp << 16); }
+inline unsigned ga_pack_t(const GemmArgs& g) { return (unsigned)g.tiles_q | ((unsigned)g.tiles_p << 16); }
+inline unsigned ga_pack_k(const GemmArgs& g) { return (unsigned)g.K | ((unsigned)ga_flags(g) << 26); }
+// what the packed form can carry (checked by the launchers; pvae_layout.h refuses stacks beyond it)
+inline bool ga_packable(const GemmArgs& g) {
+    return g.ldq >= 0 && g.ldq < 65536 && g.ldp >= 0 && g.ldp < 65536 && g.tiles_q >= 0 && g.tiles_q < 65536 &&
+           g.tiles_p >= 0 && g.tiles_p < 65536 && g.K >= 0 && g.K < (1 << 26) && g.p_per_xcd == (g.tiles_p + 7) / 8;
+}
+__host__ __device__ inline int ga_grid(const GemmArgs& g) { return 8 * g.p_per_xcd * g.tiles_q; }
+__device__ inline GemmArgs ga_unpack(const float* Q, const float* P, unsigned ld, unsigned t, unsigned k) {
+    const int tp = (int)(t >> 16), fl = (int)(k >> 26);
+    return GemmArgs{Q, (int)(ld & 0xffffu), P, (int)(ld >> 16), (int)(k & 0x3ffffffu), (int)(t & 0xffffu), tp, (tp + 7) / 8,
+                    fl & 1, (fl >> 1) & 1, (fl >> 2) & 1, (fl >> 3) & 1};
+}
 
 // Experiment (off by default): start each workgroup at a different k-tile and wrap around, so that
 // the workgroups of an XCD that share operand rows (same q-tile: X rows, same p-tile: W rows) do
@@ -1678,9 +1704,10 @@ gemm_wgrad_reg_kernel(PVAE_GA_PARAMS(a_), int nw, Epi epi, AdamPair ad) {
 // step that precedes it instead of being a launch of its own.
 template <class EpiW>
 __global__ void __launch_bounds__(256)
-wgrad_pair_kernel(int n1, int n12, int na, PVAE_GA_PARAMS(a_), GemmArgs g2, EpiW e1, EpiW e2, StageArgs sa, AdamPair ad) {
+wgrad_pair_kernel(PVAE_GA2_PARAMS, int na, EpiW e1, EpiW e2, StageArgs sa, AdamPair ad) {
     __shared__ __attribute__((aligned(16))) float lds[kPairLdsFloats];
-    const GemmArgs g1 = PVAE_GA_OF(a_);
+    const GemmArgs g1 = PVAE_GA2_A, g2 = PVAE_GA2_B;
+    const int n1 = ga_grid(g1), n12 = n1 + ga_grid(g2);
     const int b = blockIdx.x;
     const int nb1 = bias_tiles(g1), nb2 = bias_tiles(g2);
     if (b < n1) wgrad_body<EpiW>(lds, b, g1, e1);
@@ -1695,9 +1722,10 @@ wgrad_pair_kernel(int n1, int n12, int na, PVAE_GA_PARAMS(a_), GemmArgs g2, EpiW
 // pair needs 512-thread blocks and 64 KB of LDS per workgroup and measured 15 % slower.)
 template <class EpiD, class EpiW, int ABL = 0>          // ABL: ablation bits of the two bodies (probes only)
 __global__ void __launch_bounds__(256)
-bwd_pair_kernel(int nd, int nw, PVAE_GA_PARAMS(w_), GemmArgs gd, EpiD ed, EpiW ew, AdamPair ad) {
+bwd_pair_kernel(PVAE_GA2_PARAMS, EpiD ed, EpiW ew, AdamPair ad) {
     __shared__ __attribute__((aligned(16))) float lds[kPairLdsFloats];
-    const GemmArgs gw = PVAE_GA_OF(w_);           // (preloaded: the weight-gradient workgroups are the launch's long pole)
+    const GemmArgs gd = PVAE_GA2_A, gw = PVAE_GA2_B;
+    const int nd = ga_grid(gd), nw = ga_grid(gw);          // (a body with tiles_q = 0 is absent: ablation probes)
     PVAE_MARK(0, 0);
     PVAE_MARK_HW();
     // (dispatch order matters: input-gradient workgroups first.  Weight-gradient workgroups first: world step
@@ -1717,9 +1745,10 @@ bwd_pair_kernel(int nd, int nw, PVAE_GA_PARAMS(w_), GemmArgs gd, EpiD ed, EpiW e
 // and more.
 template <class EpiD, class EpiW>
 __global__ void __launch_bounds__(256)
-bwd_pair64_kernel(int nd, int nw, PVAE_GA_PARAMS(w_), GemmArgs gd, EpiD ed, EpiW ew, AdamPair ad) {
+bwd_pair64_kernel(PVAE_GA2_PARAMS, EpiD ed, EpiW ew, AdamPair ad) {
     __shared__ __attribute__((aligned(16))) float lds[kReg64RingFloats];
-    const GemmArgs gw = PVAE_GA_OF(w_);
+    const GemmArgs gd = PVAE_GA2_A, gw = PVAE_GA2_B;
+    const int nd = ga_grid(gd), nw = ga_grid(gw);
     const int b = blockIdx.x;
     if (b < nd) splitk_reg64_body<EpiD>(lds, b, gd, ed);
     else if (b < nd + nw) wgrad_body<EpiW>(lds, b - nd, gw, ew);
@@ -2183,8 +2212,9 @@ inline hipError_t gemm_wgrad_pair(const float* dZ1, int ldz1, const float* X1, i
     StageArgs sa;
     memset(&sa, 0, sizeof(sa));
     if (next) sa = *next;                     // rows_pad extra blocks gather the next minibatch
+    if (!ga_packable(w1.ga) || !ga_packable(w2.ga) || ga_grid(w1.ga) != w1.grid || ga_grid(w2.ga) != w2.grid) return hipErrorInvalidValue;
     PVAE_LAUNCH((wgrad_pair_kernel<EpiW>), dim3(w1.grid + w2.grid + w1.nbias + w2.nbias + adam_blocks(ad) + sa.rows_pad),
-                dim3(256), st, w1.grid, w1.grid + w2.grid, adam_blocks(ad), PVAE_GA_PASS(w1.ga), w2.ga, e1, e2, sa, ad ? *ad : AdamPair());
+                dim3(256), st, PVAE_GA2_PASS(w1.ga, w2.ga), adam_blocks(ad), e1, e2, sa, ad ? *ad : AdamPair());
     return hipGetLastError();
 }
 // one launch: dX'[M][Kin'] = (dZ'[M][N'] W'[N'][Kin']) .* mask   ||   G[N][Kin] = dZ[M][N]^T X[M][Kin]
@@ -2197,14 +2227,16 @@ inline hipError_t gemm_bwd_pair_epi(const float* dZd, int ldzd, const float* Wd,
     if constexpr (std::is_same<EpiD, EpiMask>::value) {
         if (pair_uses_64x32(Md, Kind)) {                        // hidden-layer input gradient at >= 512 rows
             const GemmGrid g = make_grid(Md, Kind, 64, 32);
+            const GemmArgs gd64{dZd, ldzd, Wd, ldwd, Nd, g.tiles_q, g.tiles_p, g.p_per_xcd};
+            if (!ga_packable(gd64) || !ga_packable(w.ga) || ga_grid(w.ga) != w.grid) return hipErrorInvalidValue;
             PVAE_LAUNCH((bwd_pair64_kernel<EpiD, EpiW>), dim3(g.grid + w.grid + w.nbias + adam_blocks(ad)), dim3(256), st,
-                        g.grid, w.grid, PVAE_GA_PASS(w.ga), GemmArgs{dZd, ldzd, Wd, ldwd, Nd, g.tiles_q, g.tiles_p, g.p_per_xcd}, ed, ew,
-                        ad ? *ad : AdamPair());
+                        PVAE_GA2_PASS(gd64, w.ga), ed, ew, ad ? *ad : AdamPair());
             return hipGetLastError();
         }
     }
+    if (!ga_packable(d.ga) || !ga_packable(w.ga) || ga_grid(d.ga) != d.grid || ga_grid(w.ga) != w.grid) return hipErrorInvalidValue;
     PVAE_LAUNCH((bwd_pair_kernel<EpiD, EpiW>), dim3(d.grid + w.grid + w.nbias + adam_blocks(ad)), dim3(256), st,
-                       d.grid, w.grid, PVAE_GA_PASS(w.ga), d.ga, ed, ew, ad ? *ad : AdamPair());
+                       PVAE_GA2_PASS(d.ga, w.ga), ed, ew, ad ? *ad : AdamPair());
     return hipGetLastError();
 }
 template <class EpiW>

@@ -82,6 +82,8 @@ inline Layout make_layout(const pvae_config& c) {
             l.act = act_pub == PVAE_ACT_LINEAR ? 0 : act_pub + 1;
             l.ld = pad64(l.n_in);
             l.n_out_pad = pad64(l.n_out);
+            // (the fused backward launches carry row strides in 16 bits: pvae_gemm.h ga_packable)
+            if (l.ld >= 65536 || l.n_out_pad >= 65536) { L.why = "layer wider than 65535 (padded) unsupported"; return L; }
             l.w_off = off; off += (int64_t)l.n_out_pad * l.ld;
             l.b_off = off; off += l.n_out_pad;
             N.layers.push_back(l);

@@ -30,9 +30,11 @@ static float time_pair(hipStream_t st, const float* dZ, const float* W, const fl
     const int nb = (parts & 4) ? bias_tiles(gw) : 0;
     if (!(parts & 4)) es.gb = nullptr;
     const AdamSeg adv = (parts & 8) ? ad : AdamSeg();
+    GemmArgs gw_ = gw;
+    if (!nw) gw_.tiles_q = 0;                     // (an absent body: no tiles; bias_tiles() reads tiles_q ... see nb above)
     auto launch = [&]() {
         hipLaunchKernelGGL((bwd_pair_kernel<EpiMask, EpiGradStore, ABL>), dim3(nd + nw + nb + adam_blocks(&adv)), dim3(256), 0, st,
-                           nd, nw, PVAE_GA_PASS(gw), GemmArgs{dZ, N, W, K, N, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, es, adv);
+                           PVAE_GA2_PASS((GemmArgs{dZ, N, W, K, N, nd ? g1.tiles_q : 0, g1.tiles_p, g1.p_per_xcd}), gw_), ed, es, adv);
     };
     for (int i = 0; i < 20; ++i) launch();
     hipStreamSynchronize(st);

@@ -106,8 +106,8 @@ int main() {
         auto launch = [&]() {
             const int nd = (part & 1) ? g1.grid : 0, nw2 = (part & 2) ? g2.grid : 0;
             hipLaunchKernelGGL((bwd_pair_kernel<EpiMask, EpiGradAdam, A>), dim3(nd + nw2), dim3(256), 0, st,
-                               nd, nw2, PVAE_GA_PASS((GemmArgs{dZ, N, X, K, M, g2.tiles_q, g2.tiles_p, g2.p_per_xcd})),
-                               GemmArgs{dZ, N, W, K, N, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, e, AdamSeg());
+                               PVAE_GA2_PASS((GemmArgs{dZ, N, W, K, N, nd ? g1.tiles_q : 0, g1.tiles_p, g1.p_per_xcd}),
+                                             (GemmArgs{dZ, N, X, K, M, nw2 ? g2.tiles_q : 0, g2.tiles_p, g2.p_per_xcd})), ed, e, AdamSeg());
         };
         for (int i = 0; i < 10; ++i) launch();
         hipStreamSynchronize(st);
@@ -146,8 +146,8 @@ int main() {
             const GemmGrid g1 = make_grid(dM, K, 32, 32), g2 = make_grid(wN, K, 64, 64);
             auto launch = [&]() {
                 hipLaunchKernelGGL((bwd_pair_kernel<EpiMask, EpiGradStore, 0>), dim3(g1.grid + g2.grid), dim3(256), 0, st,
-                                   g1.grid, g2.grid, PVAE_GA_PASS((GemmArgs{big, wN, X, K, wM, g2.tiles_q, g2.tiles_p, g2.p_per_xcd})),
-                                   GemmArgs{big, dN, W, K, dN, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, es, AdamSeg());
+                                   PVAE_GA2_PASS((GemmArgs{big, dN, W, K, dN, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}),
+                                                 (GemmArgs{big, wN, X, K, wM, g2.tiles_q, g2.tiles_p, g2.p_per_xcd})), ed, es, AdamSeg());
             };
             for (int i = 0; i < 10; ++i) launch();
             hipStreamSynchronize(st);

@@ -47,7 +47,7 @@ int main() {
     const int nd = g1.grid, nwg = gg2.grid, nb = bias_tiles(gw), na = adam_blocks(&ad), grid = nd + nwg + nb + na;
     auto launch = [&]() {
         hipLaunchKernelGGL((bwd_pair_kernel<EpiMask, EpiGradStore, 0>), dim3(grid), dim3(256), 0, st,
-                           nd, nwg, PVAE_GA_PASS(gw), GemmArgs{dZ, N, W, K, N, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}, ed, es, ad);
+                           PVAE_GA2_PASS((GemmArgs{dZ, N, W, K, N, g1.tiles_q, g1.tiles_p, g1.p_per_xcd}), gw), ed, es, ad);
     };
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int i = 0; i < 20; ++i) launch();
