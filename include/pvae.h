@@ -410,7 +410,8 @@ int pvae_reparam(pvae_ctx* ctx, const float* mu_logvar, int32_t rows, const floa
  * kernel's own start and end (hipExtLaunchKernelGGL), i.e. the duration rocprofv3 --kernel-trace
  * reports, without the launch seam (this serialises the host a little, so it is used in a
  * separate instrumented pass, never in a timed region).
- * category: 0 = forward kernel, 1 = input-gradient kernel (alone), 2 = weight-gradient(+Adam)
+ * category: 0 = forward kernel (32x32 / 64x32 tiles), 5 = forward kernel of the narrow layers (16x16 tiles: output
+ * layers, the fused-loss layer), 1 = input-gradient kernel (alone), 2 = weight-gradient(+Adam)
  * launches (single or the two trailing layers in one launch), 3 = fused input-gradient +
  * weight-gradient(+Adam) launch, 4 = the RCCL all-reduce of pvae_allreduce_grads /
  * pvae_dp_train_step (events recorded on the stream around the collective; total_flops then

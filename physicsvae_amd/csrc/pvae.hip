@@ -1077,8 +1077,10 @@ static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st, const F
     int ldx = N.layers[0].ld;
     for (const Layer& l : N.layers) {
         float* out = c->ws + c->W.net[n].act[l.index] + row0 * l.n_out_pad;
-        const int ps = g_prof.begin(0, 2.0 * c->staged_rows_f * l.n_in * l.n_out, st);
         const int rows = (int)c->staged_rows_f;
+        // (category 5: the narrow layers that run on 16x16 tiles -- another kernel, gemm_splitk_reg16_kernel)
+        const int ps = g_prof.begin(forward_uses_16x16(pad32(rows), l.n_out_pad) && rows > 4 ? 5 : 0,
+                                    2.0 * c->staged_rows_f * l.n_in * l.n_out, st);
         if (rows <= 4 && !tail.mse) {            // rollout batch: stream W once over all CUs
             float* o2 = (l.last && tail.out2) ? tail.out2 : nullptr;
             const dim3 grid(l.n_out_pad / 4), block(256);
