@@ -73,10 +73,16 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define PVAE_STORE_SC1 1
 #endif
 __device__ inline void store_stream(float* p, const v4f& v) {
-#if PVAE_STORE_SC1
+#if PVAE_STORE_SC1 == 1
     // (s_nop 1: the store reads its four data registers over the following states and hipcc pads nothing
     //  inside an asm statement -- cdna_hip_programming.md 5.7)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#elif PVAE_STORE_SC1 == 2          // A/B variants of the cache-policy bits (profiles/r03_ab_store_policy.txt)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#elif PVAE_STORE_SC1 == 3
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#elif PVAE_STORE_SC1 == 4
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #else
     *reinterpret_cast<v4f*>(p) = v;
 #endif
