@@ -293,10 +293,10 @@ struct GemmArgs {
 #define PVAE_GA_PARAMS(n) const float* n##Q, const float* n##P, int n##ldq, int n##ldp, int n##K, int n##tq, int n##tp, \
                           int n##ppx, int n##fl
 #define PVAE_GA_PASS(g) (g).Q, (g).P, (g).ldq, (g).ldp, (g).K, (g).tiles_q, (g).tiles_p, (g).p_per_xcd, ga_flags(g)
-#define PVAE_GA_OF(n) GemmArgs{n##Q, n##ldq, n##P, n##ldp, n##K, n##tq, n##tp, n##ppx, n##fl & 1, (n##fl >> 1) & 1, (n##fl >> 2) & 1, (n##fl >> 3) & 1}
+#define PVAE_GA_OF(n) GemmArgs{n##Q, n##ldq, n##P, n##ldp, n##K, n##tq, n##tp, n##ppx, n##fl & 7, (n##fl >> 3) & 1, (n##fl >> 4) & 1, (n##fl >> 5) & 1}
 // Launches that hold TWO contractions (input gradient || weight gradient, or the two trailing weight gradients) carry
 // both sets of operands in the 14 preloadable dwords: four pointers, and per contraction the two row strides, the two
-// tile counts (16 bits each) and the contraction length with the four switch bits (26 + 4 bits).  The workgroup
+// tile counts (16 bits each) and the contraction length with the six switch bits (26 + 6 bits).  The workgroup
 // counts of the two bodies follow from the tile counts (make_grid).  A/B of what is preloaded, joint step / config-5
 // sizes: nothing 248.2 / 391.1 us, weight-gradient operands 246.4 / 388.7, input-gradient operands 244.4 / 385.5,
 // both (this) -- profiles/r03_ab_kernarg_preload.txt.
@@ -306,7 +306,8 @@ struct GemmArgs {
                               ga_pack_k(ga), ga_pack_k(gb)
 #define PVAE_GA2_A ga_unpack(aQ, aP, a_ld, a_t, a_k)
 #define PVAE_GA2_B ga_unpack(bQ, bP, b_ld, b_t, b_k)
-inline int ga_flags(const GemmArgs& g) { return (g.krot & 1) | ((g.tile32 & 1) << 1) | ((g.tile16 & 1) << 2) | ((g.rowxcd & 1) << 3); }
+// (krot: three bits -- the probes under tools/ use it as their ablation mode)
+inline int ga_flags(const GemmArgs& g) { return (g.krot & 7) | ((g.tile32 & 1) << 3) | ((g.tile16 & 1) << 4) | ((g.rowxcd & 1) << 5); }
 inline unsigned ga_pack_ld(const GemmArgs& g) { return (unsigned)g.ldq | ((unsigned)g.ldp << 16); }
 inline unsigned ga_pack_t(const GemmArgs& g) { return (unsigned)g.tiles_q | ((unsigned)g.tiles_p << 16); }
 inline unsigned ga_pack_k(const GemmArgs& g) { return (unsigned)g.K | ((unsigned)ga_flags(g) << 26); }
@@ -319,7 +320,7 @@ __host__ __device__ inline int ga_grid(const GemmArgs& g) { return 8 * g.p_per_x
 __device__ inline GemmArgs ga_unpack(const float* Q, const float* P, unsigned ld, unsigned t, unsigned k) {
     const int tp = (int)(t >> 16), fl = (int)(k >> 26);
     return GemmArgs{Q, (int)(ld & 0xffffu), P, (int)(ld >> 16), (int)(k & 0x3ffffffu), (int)(t & 0xffffu), tp, (tp + 7) / 8,
-                    fl & 1, (fl >> 1) & 1, (fl >> 2) & 1, (fl >> 3) & 1};
+                    fl & 7, (fl >> 3) & 1, (fl >> 4) & 1, (fl >> 5) & 1};
 }
 
 // Experiment (off by default): start each workgroup at a different k-tile and wrap around, so that
