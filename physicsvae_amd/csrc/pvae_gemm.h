@@ -657,6 +657,9 @@ gemm_splitk_reg_kernel(PVAE_GA_PARAMS(a_), Epi epi) {
 // Ring depth: 4 is the optimum on MI355X -- 3 starves, 5..8 get progressively slower (8: 8.5 us);
 // more requests in flight per CU do not help the L2 -> CU path, they hurt it.
 // Same LDS image / swizzles / split-K layout as splitk_reg_body, results are bit-identical.
+#ifndef PVAE_WS_SUPER
+#define PVAE_WS_SUPER 0            // 1: two k-tiles per workgroup barrier in the wave-specialised 32x32 kernel (A/B)
+#endif
 #ifndef PVAE_WS_LOADERS
 #define PVAE_WS_LOADERS 4        // loader waves of the wave-specialised kernel (8: 12-wave workgroups, A/B)
 #endif
@@ -803,6 +806,22 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
         if constexpr (Pro::kActive) {
             if (pro.needs(0)) __builtin_amdgcn_s_barrier();        // (the compute waves patch tile 0 in between)
         }
+#if PVAE_WS_SUPER
+        if constexpr (!Pro::kActive) {
+            // super-steps of TWO k-tiles per workgroup barrier (half the barriers of the loop below).  At the barrier
+            // in front of tiles (t0, t0+1): t0+1 and t0+2 have landed, the fragments of t0 and everything older have
+            // been read, so the slots of t0-1 and t0 take t0+3 and t0+4 -- which have one super-step to land.
+            if (2 < nk) issue(2);
+            for (int t0 = 0; t0 < nk; t0 += 2) {
+                wait_vmcnt<0>();                                       // tiles t0+1, t0+2 (all that is in flight) landed
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (t0 + 3 < nk) issue(t0 + 3);
+                if (t0 + 4 < nk) issue(t0 + 4);
+            }
+        } else
+#endif
+        {
 #pragma unroll
         for (int t = 2; t < S - 1; ++t)
             if (t < nk) issue(t);
@@ -820,6 +839,9 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
             }
             if (t + S - 1 < nk) issue(t + S - 1);                  // refill the slot tile t-1 vacated
         }
+#ifndef PVAE_WS_SLOW0
+        }
+#endif
     } else {
         // ---------------- compute waves ----------------
         int oq[2];
@@ -875,6 +897,22 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
         }
         Frag F0, F1;
         fread(lds, F0);
+#if PVAE_WS_SUPER && !defined(PVAE_WS_SLOW0)
+        if constexpr (!Pro::kActive) {
+            for (int t0 = 0; t0 < nk; t0 += 2) {
+                __builtin_amdgcn_s_barrier();                      // tiles t0+1 and t0+2 landed; slots of t0-1, t0 are free
+                asm volatile("" ::: "memory");
+                fread(lds + ((t0 + 1) % S) * kStage, F1);          // (past the end: stale slot, never used)
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(F0);
+                if (t0 + 1 < nk) {
+                    fread(lds + ((t0 + 2) % S) * kStage, F0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(F1);
+                }
+            }
+        } else
+#endif
         for (int t0 = 0; t0 < nk; t0 += 2) {
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
