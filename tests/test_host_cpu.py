@@ -875,6 +875,10 @@ def test_stacks_with_per_layer_widths_and_activations(golden):
     bad.layer_act[_lib.NET_MD][1] = 0
     bad.layer_width[_lib.NET_WM][0] = -4
     assert lib.pvae_num_layers(C.byref(bad)) < 0 and b"layer_width" in lib.pvae_last_error()
+    bad.layer_width[_lib.NET_WM][0] = 65536          # (row strides travel in 16 bits in the fused backward launches)
+    assert lib.pvae_num_layers(C.byref(bad)) < 0 and b"wider than 65535" in lib.pvae_last_error()
+    bad.layer_width[_lib.NET_WM][0] = 65472
+    assert lib.pvae_num_layers(C.byref(bad)) > 0
     # --- the module tree through the trainer (our `*_layers` trainer keys carry the lists)
     data = R.synth_demo(0, 2, 14, 7, 3)
     tr = make_trainer(arch, data, 8, device="cpu")
