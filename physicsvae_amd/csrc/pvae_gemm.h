@@ -657,8 +657,13 @@ gemm_splitk_reg_kernel(PVAE_GA_PARAMS(a_), Epi epi) {
 // Ring depth: 4 is the optimum on MI355X -- 3 starves, 5..8 get progressively slower (8: 8.5 us);
 // more requests in flight per CU do not help the L2 -> CU path, they hurt it.
 // Same LDS image / swizzles / split-K layout as splitk_reg_body, results are bit-identical.
+// Workgroup barriers per k-tile in the wave-specialised 32x32 kernel.  0: one barrier per tile, 4-slot ring (rounds 1-2).
+// 2 (what runs): super-steps of TWO tiles per barrier on a 6-slot ring -- at the barrier in front of tiles (t0, t0+1)
+// the tiles t0+1, t0+2 have landed, t0+3, t0+4 are in flight and t0+5, t0+6 are requested: half the barriers, the load
+// stream stays continuous; joint step 243.7 -> 241.5 us.  1: the same on the 4-slot ring (nothing in flight across a
+// barrier): 264.9 us -- the L2 -> LDS path needs the continuous stream (profiles/r03_ab_ws_superstep.txt).
 #ifndef PVAE_WS_SUPER
-#define PVAE_WS_SUPER 0            // 1: two k-tiles per workgroup barrier in the wave-specialised 32x32 kernel (A/B)
+#define PVAE_WS_SUPER 2
 #endif
 #ifndef PVAE_WS_LOADERS
 #define PVAE_WS_LOADERS 4        // loader waves of the wave-specialised kernel (8: 12-wave workgroups, A/B)
@@ -705,8 +710,9 @@ struct NoPro {
 template <bool P_ROW, class Epi, class Pro = NoPro>
 __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, Epi& epi, const Pro& pro = Pro(),
                                       float* scratch = nullptr) {
-    constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, S = kWsStages;
-    static_assert(S == 4, "wait_dma_tile is written for a 4-slot ring");
+    // (PVAE_WS_SUPER=2: six slots, two k-tiles per barrier with the two after next already in flight -- plain kernel only)
+    constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, S = (PVAE_WS_SUPER == 2 && !Pro::kActive) ? 6 : kWsStages;
+    static_assert(S == 4 || PVAE_WS_SUPER == 2, "wait_dma_tile is written for a 4-slot ring");
     const float* __restrict__ Q = ga.Q;
     const float* __restrict__ P = ga.P;
     const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
@@ -812,6 +818,21 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
             // in front of tiles (t0, t0+1): t0+1 and t0+2 have landed, the fragments of t0 and everything older have
             // been read, so the slots of t0-1 and t0 take t0+3 and t0+4 -- which have one super-step to land.
             if (2 < nk) issue(2);
+            if constexpr (S == 6) {
+                // six slots: t0+3 and t0+4 are already in flight when t0+1 and t0+2 are awaited (a continuous stream)
+                if (3 < nk) issue(3);
+                if (4 < nk) issue(4);
+                for (int t0 = 0; t0 < nk; t0 += 2) {
+                    const int younger = nk - 3 - t0;                   // tiles t0+3, t0+4 that exist
+                    if (younger >= 2) wait_vmcnt<4 * kWsPer>();
+                    else if (younger == 1) wait_vmcnt<2 * kWsPer>();
+                    else wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (t0 + 5 < nk) issue(t0 + 5);
+                    if (t0 + 6 < nk) issue(t0 + 6);
+                }
+            } else
             for (int t0 = 0; t0 < nk; t0 += 2) {
                 wait_vmcnt<0>();                                       // tiles t0+1, t0+2 (all that is in flight) landed
                 __builtin_amdgcn_s_barrier();
@@ -1134,7 +1155,7 @@ template <bool P_ROW, class Epi>
 __global__ void __launch_bounds__(kWsThreads)
 gemm_splitk_ws_kernel(PVAE_GA_PARAMS(a_), Epi epi) {
     const GemmArgs ga = PVAE_GA_OF(a_);
-    __shared__ __attribute__((aligned(16))) float lds[kWsFloats];
+    __shared__ __attribute__((aligned(16))) float lds[PVAE_WS_SUPER == 2 ? 6 * 2 * 32 * 64 : kWsFloats];
     splitk_ws_body<P_ROW, Epi>(lds, blockIdx.x, ga, epi);
 }
 template <class Epi, class Pro>
