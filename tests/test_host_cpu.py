@@ -950,3 +950,17 @@ def test_launcher_with_more_ranks_than_gpus_shares_the_devices(monkeypatch):
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
     assert parallel.init_from_env() == (0, 1, 5)
     assert "PVAE_LOCAL_DEVICE" not in os.environ and "PVAE_BENCH_SHARED_GPU" not in os.environ
+
+
+def test_build_command_keeps_the_kernarg_preload_switch():
+    """The contraction kernels take what a workgroup needs for its first tile load as leading scalar parameters
+    (pvae_gemm.h PVAE_GA_PARAMS / PVAE_GA2_PARAMS) so that gfx950 preloads them into SGPRs at wave launch; that only
+    happens when hipcc is given -amdgpu-kernarg-preload-count (0.26 us per dependent launch otherwise)."""
+    import inspect
+    from physicsvae_amd import build as B
+    src = inspect.getsource(B.build)
+    assert '"-mllvm", "-amdgpu-kernarg-preload-count=16"' in src
+    hdr = open(os.path.join(ROOT, "physicsvae_amd", "csrc", "pvae_gemm.h")).read()
+    for kernel in ("gemm_splitk_ws_kernel(PVAE_GA_PARAMS(a_)", "gemm_splitk_reg16_kernel(PVAE_GA_PARAMS(a_)",
+                   "bwd_pair_kernel(PVAE_GA2_PARAMS", "wgrad_pair_kernel(PVAE_GA2_PARAMS"):
+        assert kernel in hdr, kernel
