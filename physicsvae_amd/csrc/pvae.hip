@@ -185,7 +185,7 @@ struct pvae_ctx {
     AdamSeg held_adam;             // a big one that a narrow launch passed on to the next wide launch (take_pending)
     bool defer_adam = true;
     bool same_layer_pairs = true;  // PVAE_SAME_LAYER=0: wgrad_i rides with dgrad_{i-1} as before (A/B)
-    bool fold_sampler = false;     // PVAE_FOLD_SAMPLER=1: the sampler runs as the prologue of the decoder's first-layer launch
+    bool fold_sampler = true;      // the sampler runs as the prologue of the decoder's first-layer launch (PVAE_FOLD_SAMPLER=0: its own launch)
                                    // (ProSampler).  Off by default: one launch less, but the step is not shorter -- the kernel
                                    // trace shows 6.4-7.0 us for the merged launch against 4.4 + 4.6, and the un-profiled
                                    // step 254.8 vs 254.5 us (profiles/r03_ab_fold_sampler.txt, docs/experiments.md)
@@ -1541,7 +1541,7 @@ int pvae_create(const pvae_config* cfg, pvae_ctx** out) {
     const char* sl = getenv("PVAE_SAME_LAYER");
     c->same_layer_pairs = !(sl && sl[0] == '0');
     const char* fs = getenv("PVAE_FOLD_SAMPLER");
-    c->fold_sampler = fs && fs[0] == '1';
+    c->fold_sampler = !(fs && fs[0] == '0');
     *out = c;
     return 0;
 }
