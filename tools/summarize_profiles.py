@@ -16,6 +16,7 @@ def short(n):
     if "wgrad_reg" in n: return "gemm_wgrad_reg_kernel<%s>" % epi
     if "reg16" in n and "EpiMse" in n: return "gemm_splitk_reg16_kernel<EpiMse>"
     if "reg16" in n: return "gemm_splitk_reg16_kernel<EpiBiasAct>"
+    if "splitk_ws_pro" in n: return "gemm_splitk_ws_pro_kernel<EpiBiasAct,ProSampler>"
     if "splitk_ws" in n and "EpiMse" in n: return "gemm_splitk_ws_kernel<P_ROW,EpiMse>"
     if "splitk_ws" in n and "EpiBiasAct" in n: return "gemm_splitk_ws_kernel<P_ROW,EpiBiasAct>"
     if "splitk_ws" in n and "EpiMask" in n: return "gemm_splitk_ws_kernel<P_COL,EpiMask>"
