@@ -1647,7 +1647,10 @@ struct AdamSeg {
     long long n4 = 0;          // float4 count (0: nothing pending)
     AdamScalars s{};
 };
-constexpr int kAdamBlocks = 256;
+#ifndef PVAE_ADAM_BLOCKS
+#define PVAE_ADAM_BLOCKS 256        // workgroups per deferred-Adam segment (A/B: 128 / 256 / 512, profiles/r03_ab_adam_blocks.txt)
+#endif
+constexpr int kAdamBlocks = PVAE_ADAM_BLOCKS;
 #ifndef PVAE_ADAM_UNROLL
 #define PVAE_ADAM_UNROLL 1     // float4 elements per thread in flight (A/B: >1 issues all trips' loads up front)
 #endif
