@@ -263,6 +263,82 @@ def case_single_clear(name, arch, n_ep, n_steps, batch, margin=1e-5):
           "| min margin %.3g" % float(fix["min_margin_of_batch"]))
 
 
+def case_trained(name, arch, n_ep, n_steps, batch, m_world, n_epochs, lr_step, margin=1e-5):
+    """The reference's compute_loss + backward (tpv:361-435) at TRAINED weights: the reference trainer itself runs
+    `m_world` world-model epochs and `n_epochs - m_world` joint epochs on learnable data (StepLR shortened to `lr_step`
+    epochs so that the rate has decayed several times, eps keyed by forward call), then one kink-free minibatch is
+    captured in both phases exactly as case_single_clear does at initialisation -- but where the trajectory lives:
+    a fitted world model, a collapsed posterior (KL ~ 1e-4 and below), output layers grown from |row| = 0.01.
+    Stores the trained TE / MD / WM tensors in full (fp32; the value branch never receives a gradient, tm:119-122 +
+    torch's `grad is None` skip, and stays at its seeded initial value), the minibatch's window indices, losses,
+    digests of the internals and per gradient tensor digest + max, plus the trainer's read-outs of the run."""
+    data = R.synth_demo(seed=0, n_episodes=n_ep, n_steps=n_steps, dim_body=arch["Db"], dim_action=arch["Da"], kind="dynamics")
+    fix = {}
+    with tempfile.TemporaryDirectory() as td:
+        pkl = os.path.join(td, "demo.pkl")
+        R.write_demo(pkl, data)
+        tr = make_reference_trainer(pkl, arch, batch, m_world=m_world)
+        tr.lr_scheduler = torch.optim.lr_scheduler.StepLR(tr.optimizer, step_size=lr_step, gamma=0.7)
+        sd0 = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+        tr.model.load_state_dict(sd0)
+        eps_fn = R.eps_stream(2, arch["Z"])
+        losses = []
+        with EpsPatch(lambda c, shape: eps_fn(c, shape)):
+            for e in range(n_epochs):
+                losses.append(tr.train()["mean_train_loss"])
+        fix["epoch_losses"] = np.array(losses, dtype=np.float64)
+        fix["final_lr"] = np.array(tr.optimizer.param_groups[0]["lr"], dtype=np.float64)
+        sd = {k: v.detach().clone() for k, v in tr.model.state_dict().items()}
+        for k, v in sd.items():
+            if k.startswith("_value_branch"):
+                assert torch.equal(v, sd0[k]), k                 # never trained: regenerated from the seed by the tests
+            else:
+                fix["trained::" + k] = v.numpy().copy()
+        # Adam's per-parameter step counters at that point (WM stopped at the switch; TE / MD started at 1 there)
+        named = dict(tr.model.named_parameters())
+        fix["adam_keys"] = np.array(list(named.keys()))
+        fix["adam_steps"] = np.array([float(tr.optimizer.state.get(p, {}).get("step", -1.0)) for p in named.values()])
+        X, Y = R.build_windows(data)
+        xa = torch.from_numpy(np.asarray(X)).float()
+        ya = torch.from_numpy(np.asarray(Y)).float()
+        n = xa.shape[0]
+        eps_all = R.eps_stream(5, arch["Z"])(0, (n, arch["Z"]))
+        m = torch.minimum(R.relu_kink_margin(arch, sd, xa, ya, eps_all, True),
+                          R.relu_kink_margin(arch, sd, xa, ya, eps_all, False))
+        idx = torch.nonzero(m > margin).reshape(-1)[:batch]
+        assert idx.numel() == batch, "only %d of %d windows clear the margin" % (idx.numel(), n)
+        x, y, eps = xa[idx], ya[idx], eps_all[idx]
+        fix["rows_idx"] = idx.numpy().astype(np.int64)
+        fix["n_windows"] = np.array(n)
+        fix["margin"] = np.array(margin)
+        fix["min_margin_of_batch"] = np.array(float(m[idx].min()))
+        fix["rows_dropped_before_last"] = np.array(int(idx[-1]) + 1 - batch)
+        for world in (True, False):
+            tag = "world" if world else "joint"
+            out, grads = single_batch_capture(tr, x, y, eps, world)
+            for k, v in out.items():
+                if v.ndim == 0:
+                    fix["%s_%s" % (tag, k)] = v
+                else:
+                    fix["%s_%s_digest" % (tag, k)] = R.tensor_digest(torch.from_numpy(v))
+                    fix["%s_%s_max" % (tag, k)] = np.array(float(np.abs(v).max()))
+            # the KL term on its own, from the tensors the reference's model holds after compute_loss (tpv:385-389)
+            m_ = tr.model
+            if not world:
+                mu, lv = m_._cur_task_encoder_mu.detach(), m_._cur_task_encoder_logvar.detach()
+                fix["joint_loss_kl"] = torch.mean(-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp(), dim=1), dim=0).numpy()
+            fix["%s_grad_keys" % tag] = np.array(list(grads.keys()))
+            for k, g in grads.items():
+                fix["%s_graddigest::%s" % (tag, k)] = R.tensor_digest(g)
+                fix["%s_gradmax::%s" % (tag, k)] = np.array(float(g.abs().max()))
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *wd(arch["te"]), *wd(arch["md"]), *wd(arch["wm"]), n_ep, n_steps, batch,
+                            m_world, n_epochs, lr_step])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
+    print("wrote", name, "| epoch losses: first %.4g, at switch %.4g, after switch %.4g, last %.4g | lr %.3g | KL %.3g"
+          % (losses[0], losses[m_world - 1], losses[m_world], losses[-1], float(fix["final_lr"]), float(fix["joint_loss_kl"])),
+          "| rows skipped:", int(fix["rows_dropped_before_last"]), "| min margin %.3g" % float(fix["min_margin_of_batch"]))
+
+
 def case_lookahead(name, arch, n_ep, n_steps, batch, lookahead, full, loss="MSE"):
     """One minibatch through the reference's multi-step unroll (tpv:367-428), both phases."""
     data = R.synth_demo(seed=0, n_episodes=n_ep, n_steps=n_steps, dim_body=arch["Db"],
@@ -573,6 +649,8 @@ def main():
         "single_c2_clear": lambda: case_single_clear("single_c2_clear", c2, 2, 300, 256),
         "single_default_clear": lambda: case_single_clear("single_default_clear", dflt, 2, 100, 32),
         "single_tiny_clear": lambda: case_single_clear("single_tiny_clear", tiny, 2, 14, 8),
+        # the reference's compute_loss + backward at TRAINED weights (30 world + 40 joint epochs, six LR decays)
+        "trained_c1": lambda: case_trained("trained_c1", c1, 4, 200, 64, m_world=30, n_epochs=70, lr_step=10),
         "train_tiny": lambda: case_training("train_tiny", tiny, 3, 21, 8, m_world=2, n_epochs=5,
                                             full=True),
         "train_c1": lambda: case_training("train_c1", c1, 4, 200, 64, m_world=2, n_epochs=4,

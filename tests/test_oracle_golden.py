@@ -170,6 +170,72 @@ def test_kink_free_batches_match_reference(golden, name):
             digest_close(R.tensor_digest(gr), g["%s_graddigest::%s" % (tag, k)], float(g["%s_gradmax::%s" % (tag, k)]), 2e-5)
 
 
+def trained_batch(g):
+    """Inputs of the `trained_*` fixture (oracle/gen_golden.py case_trained): the weights the REFERENCE's trainer ended
+    with (TE / MD / WM as stored; the value branch never receives a gradient and is regenerated from its seed), the
+    kink-free windows `rows_idx` of the learnable demo and their draws."""
+    arch = arch_from_meta(g)
+    n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
+    data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
+    X, Y = R.build_windows(data)
+    idx = torch.from_numpy(g["rows_idx"])
+    assert len(X) == int(g["n_windows"]) and idx.numel() == batch
+    x = torch.from_numpy(np.asarray(X)).float()[idx]
+    y = torch.from_numpy(np.asarray(Y)).float()[idx]
+    eps = R.eps_stream(5, arch["Z"])(0, (len(X), arch["Z"]))[idx]
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    for k in sd:
+        if not k.startswith("_value_branch"):
+            sd[k] = torch.from_numpy(g["trained::" + k]).clone()
+    return arch, data, x, y, eps, sd
+
+
+def test_trained_weights_capture_is_where_the_trajectory_lives(golden):
+    """What `trained_c1` holds is not initialisation statistics: the world model fitted (epoch loss down 5x), the
+    posterior collapsed (KL ~ 5e-5, |mu|, |logvar| < 0.05), the learning rate decayed seven times, output layers moved
+    by more than their initial size (decoder 17x, world model 30x), and the per-net Adam counters show the phase machine (WM stopped at the switch, TE / MD started there)."""
+    g = golden("trained_c1")
+    arch, data, x, y, eps, sd = trained_batch(g)
+    m_world, n_epochs, lr_step = [int(v) for v in g["meta"][12:15]]
+    losses = g["epoch_losses"]
+    assert len(losses) == n_epochs and losses[m_world - 1] < 0.25 * losses[0] and losses[-1] < losses[m_world]
+    assert float(g["final_lr"]) == pytest.approx(5e-4 * 0.7 ** (n_epochs // lr_step), rel=1e-12)
+    assert 0.0 < float(g["joint_loss_kl"]) < 1e-3
+    sd0 = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    for net in ("_task_encoder", "_motor_decoder", "_world_model"):
+        k = [k for k in sd if k.startswith(net) and k.endswith("weight")][-1]          # the output layer
+        assert float((sd[k] - sd0[k]).norm() / sd0[k].norm()) > 1.0, k          # moved by more than its own initial size
+    out = R.loss_and_grads(arch, sd, x, y, eps, False)
+    assert float(out["mu"].abs().max()) < 0.05 and float(out["logvar"].abs().max()) < 0.05     # the collapsed posterior
+    steps_per_epoch = -(-int(g["n_windows"]) // int(g["meta"][11]))
+    steps = dict(zip([str(k) for k in g["adam_keys"]], g["adam_steps"]))
+    for k, v in steps.items():
+        want = (m_world * steps_per_epoch if k.startswith("_world_model") else
+                -1 if k.startswith("_value_branch") else (n_epochs - m_world) * steps_per_epoch)
+        assert v == want, (k, v, want)
+
+
+def test_oracle_matches_reference_at_trained_weights(golden):
+    """The restatement against the reference's own compute_loss + backward at the weights the reference's trainer
+    ended with: total loss, the KL term on its own, internals, every gradient tensor's digest, both phases."""
+    g = golden("trained_c1")
+    arch, data, x, y, eps, sd = trained_batch(g)
+    for world in (True, False):
+        tag = "world" if world else "joint"
+        assert float(R.relu_kink_margin(arch, sd, x, y, eps, world).min()) > float(g["margin"])
+        out = R.loss_and_grads(arch, sd, x, y, eps, world)
+        np.testing.assert_allclose(out["total"].numpy(), g[tag + "_total"], rtol=1e-6)
+        if not world:
+            # (1 + lv - mu^2 - exp(lv) at lv, mu ~ 1e-3 is a cancellation: the term is held to the ulp of the 1 it
+            #  cancels against, summed over Z entries)
+            assert float(out["loss_kl"]) == pytest.approx(float(g["joint_loss_kl"]), rel=1e-5, abs=arch["Z"] * 2.0 ** -24)
+        for k in ("mu", "logvar", "z", "future_state"):
+            digest_close(R.tensor_digest(out[k]), g["%s_%s_digest" % (tag, k)], float(g["%s_%s_max" % (tag, k)]), 2e-6)
+        assert list(out["grads"].keys()) == list(g[tag + "_grad_keys"])
+        for k, gr in out["grads"].items():
+            digest_close(R.tensor_digest(gr), g["%s_graddigest::%s" % (tag, k)], float(g["%s_gradmax::%s" % (tag, k)]), 2e-5)
+
+
 @pytest.mark.parametrize("name", ["look3_tiny", "look2_c1", "l1_tiny", "l1_look2_c1", "look2_mixed_tiny"])
 def test_lookahead_unroll_matches_reference(golden, name):
     """tpv:367-428 with lookahead 3 / 2: windows, ragged last batch, loss terms averaged over the

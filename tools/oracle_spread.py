@@ -9,7 +9,12 @@ be read: an implementation cannot be held closer to the oracle than the oracle i
 
     python tools/oracle_spread.py --run base --out /tmp/base.json [--epochs 800 --world 300 --threads 4]
     python tools/oracle_spread.py --run ulp  --out /tmp/ulp.json
+    python tools/oracle_spread.py --run ulp  --seed 12346 --threads 16 --out /tmp/ulp2.json     (another sibling)
     python tools/oracle_spread.py --compare /tmp/base.json /tmp/ulp.json > profiles/rNN_oracle_spread.json
+    python tools/oracle_spread.py --summary /tmp/base.json /tmp/ulp*.json > profiles/rNN_oracle_spread.json
+--summary lists every run (threads, perturbation seed, final terms, mean of the last 20 epochs), the spread inside each
+thread count and the offset BETWEEN thread counts (torch's CPU GEMM splits its reductions by thread count, so two
+thread counts are two different fp32 implementations of the same loop).
 CPU only (no GPU, no library): a measurement tool around the checker, not the product path."""
 import argparse
 import json
@@ -33,7 +38,7 @@ def run(a):
     data = R.synth_demo(0, 10, 1000, 197, 45, kind="dynamics")
     sd = R.init_state_dict(arch, seed=1)
     if a.run == "ulp":
-        rng = np.random.default_rng(12345)
+        rng = np.random.default_rng(a.seed)
         for k, v in sd.items():
             if k.endswith("weight"):
                 sign = torch.from_numpy(rng.integers(0, 2, size=tuple(v.shape)).astype(np.float32) * 2 - 1)
@@ -46,9 +51,11 @@ def run(a):
         out.append([r["mean_train_loss"]] + [ref.last_terms[k] for k in TERMS[1:]])
         if (e + 1) % 25 == 0:
             print("%s epoch %d / %d  (%.0f s)" % (a.run, e + 1, a.epochs, time.perf_counter() - t0), file=sys.stderr, flush=True)
-            json.dump({"run": a.run, "epochs": a.epochs, "world": a.world, "threads": a.threads, "terms": out}, open(a.out, "w"))
-    json.dump({"run": a.run, "epochs": a.epochs, "world": a.world, "threads": a.threads, "terms": out,
-               "seconds": time.perf_counter() - t0}, open(a.out, "w"))
+            json.dump({"run": a.run, "seed": a.seed if a.run == "ulp" else None, "epochs": a.epochs, "world": a.world,
+                       "threads": a.threads, "terms": out}, open(a.out, "w"))
+    json.dump({"run": a.run, "seed": a.seed if a.run == "ulp" else None, "epochs": a.epochs, "world": a.world,
+               "threads": a.threads, "terms": out, "seconds": time.perf_counter() - t0, "host_cpus": os.cpu_count()},
+              open(a.out, "w"))
 
 
 def compare(pa, pb):
@@ -78,16 +85,60 @@ def compare(pa, pb):
     print(json.dumps(rep, indent=1))
 
 
+def summary(paths):
+    """Every complete run side by side: what the oracle's own trajectory spreads to at the end of configs[2]."""
+    runs = []
+    for p in paths:
+        d = json.load(open(p))
+        if len(d["terms"]) < d["epochs"]:
+            continue
+        t = d["terms"]
+        last = t[-20:]
+        runs.append({"file": os.path.basename(p), "run": d["run"], "perturbation_seed": d.get("seed"), "threads": d["threads"],
+                     "host_cpus": d.get("host_cpus"), "seconds": d.get("seconds"),
+                     "world_loss_at_switch": t[d["world"] - 1][3],
+                     "final": dict(zip(TERMS, t[-1])),
+                     "mean_last_20": {n: sum(r[i] for r in last) / len(last) for i, n in enumerate(TERMS)}})
+    by_threads = {}
+    for r in runs:
+        by_threads.setdefault(r["threads"], []).append(r)
+
+    def stats(vals):
+        m = sum(vals) / len(vals)
+        sd = (sum((v - m) ** 2 for v in vals) / max(len(vals) - 1, 1)) ** 0.5
+        return {"n": len(vals), "mean": m, "std": sd, "min": min(vals), "max": max(vals), "rel_range": (max(vals) - min(vals)) / m}
+    rep = {"what": "oracle (oracle/refpath.RefTrainer) against itself over BASELINE configs[2] at full length: same data / eps / "
+                   "schedule; siblings differ by a one-ulp perturbation of the initial weights and by torch's thread count",
+           "runs": runs, "final_total_by_threads": {}, "mean_last_20_total_by_threads": {}}
+    for th, rs in sorted(by_threads.items()):
+        rep["final_total_by_threads"][str(th)] = stats([r["final"]["total"] for r in rs])
+        rep["mean_last_20_total_by_threads"][str(th)] = stats([r["mean_last_20"]["total"] for r in rs])
+    rep["final_total_all_runs"] = stats([r["final"]["total"] for r in runs])
+    rep["mean_last_20_total_all_runs"] = stats([r["mean_last_20"]["total"] for r in runs])
+    ths = sorted(by_threads)
+    if len(ths) >= 2:
+        m = rep["mean_last_20_total_by_threads"]
+        lo, hi = str(ths[0]), str(ths[-1])
+        rep["thread_count_effect_on_mean_last_20_total"] = {
+            "threads": [ths[0], ths[-1]], "rel_offset": (m[hi]["mean"] - m[lo]["mean"]) / m[lo]["mean"],
+            "pooled_std_rel": ((m[hi]["std"] ** 2 + m[lo]["std"] ** 2) / 2) ** 0.5 / m[lo]["mean"]}
+    print(json.dumps(rep, indent=1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--run", choices=["base", "ulp"])
     ap.add_argument("--out")
     ap.add_argument("--compare", nargs=2)
+    ap.add_argument("--summary", nargs="+")
+    ap.add_argument("--seed", type=int, default=12345, help="seed of the one-ulp perturbation (--run ulp)")
     ap.add_argument("--epochs", type=int, default=800)
     ap.add_argument("--world", type=int, default=300)
     ap.add_argument("--threads", type=int, default=4)
     a = ap.parse_args()
-    if a.compare:
+    if a.summary:
+        summary(a.summary)
+    elif a.compare:
         compare(*a.compare)
     else:
         run(a)
