@@ -418,6 +418,75 @@ def main():
     timed_steps = max(a.steps, MIN_TIMED_STEPS)
     value, ms_per_step, last_loss, rates = timed(a.phase, timed_steps, a.warmup, REPEATS)
     replicas_ok = dp.replicas_identical(eng) if dp.collective and dp.world > 1 else None
+
+    def reference_steps(K=3):
+        """N ranks against ONE process: K optimizer steps of the timed phase from a common state (this run's current
+        parameters, moments zeroed, Adam counters 1..K, draws supplied) through the data-parallel step as timed above,
+        and the same K global minibatches through a second engine on rank 0 that holds the whole global batch.  The
+        loss of step k+1 is a function of the parameters step k produced, so a rank that reads STALE parameters of
+        slices its peers own (replicas would still be bit-identical) shows up here and nowhere else.  Agreement is to
+        fp32 summation order: the ranks sum N shard gradients where the single process contracts over all rows."""
+        from physicsvae_amd.engine import HipEngine
+        phase, nets = set_phase(a.phase)
+        snap = [t.clone() for t in (eng.params, eng.exp_avg, eng.exp_avg_sq)]
+        counts = dict(tr.optimizer.net_steps)
+        eng.invalidate_staging()
+        eng.exp_avg.zero_()
+        eng.exp_avg_sq.zero_()
+        B = a.batch * dp.world
+        gen = torch.Generator(device="cpu").manual_seed(1234)
+        eps_all = torch.randn(K, B, Z, generator=gen).to(dev)                 # identical on every rank
+        losses = torch.zeros(K, 5, dtype=torch.float32, device=dev)
+        sps = []
+        for i in range(K):
+            first, rows, grows = dp.shard(i, n_win, a.batch)
+            sp = tr.step_params(nets, grows, True)
+            for n_ in range(len(sp.adam_t)):
+                sp.adam_t[n_] = i + 1
+            sps.append(sp)
+            lo = first - dp.global_first(i, a.batch)
+            tr.dp_step(phase, nets, first, rows, sp, eps_all[i, lo:lo + rows].unsqueeze(0).contiguous(), losses[i], next_span=None)
+        torch.cuda.synchronize()
+        dp.all_reduce(losses)
+        res = None
+        if rank == 0:
+            try:                                   # (rank-local work: whatever happens here, rank 0 reaches the barrier below)
+                e1 = HipEngine(eng.arch, B, device=dev)
+                e1.params.copy_(snap[0])
+                e1.exp_avg.zero_()
+                e1.exp_avg_sq.zero_()
+                e1.bind_dataset(*ds.device_arrays(e1.device))
+                l1 = torch.zeros(K, 5, dtype=torch.float32, device=dev)
+                for i in range(K):
+                    e1.train_step(phase, dp.global_first(i, a.batch), B, sps[i], eps=eps_all[i].unsqueeze(0).contiguous(),
+                                  loss_out=l1[i], next_span=None)
+                torch.cuda.synchronize()
+                ld = ((losses[:, 0] - l1[:, 0]).abs() / l1[:, 0].abs().clamp_min(1e-30)).max().item()
+                d_dp = (eng.segment(eng.params, nets) - eng.segment(snap[0], nets)).double()
+                d_1 = (e1.segment(e1.params, nets) - eng.segment(snap[0], nets)).double()
+                ud = float((d_dp - d_1).norm() / d_1.norm().clamp_min(1e-30))
+                res = {"steps": K, "global_batch": B, "losses_n_ranks": losses[:, 0].tolist(),
+                       "losses_one_process": l1[:, 0].tolist(), "max_rel_loss_diff": ld, "update_rel_l2_diff": ud,
+                       "tolerance": {"loss": 2e-4, "update": 2e-2},
+                       "matches": bool(ld < 2e-4 and ud < 2e-2 and float(d_1.norm()) > 0.0)}
+                del e1
+            except Exception as exc:                               # noqa: BLE001
+                res = {"error": str(exc)[:300], "matches": None}
+        for dst, src in zip((eng.params, eng.exp_avg, eng.exp_avg_sq), snap):
+            dst.copy_(src)
+        tr.optimizer.net_steps.clear()
+        tr.optimizer.net_steps.update(counts)
+        eng.invalidate_staging()
+        torch.cuda.synchronize()
+        dist.barrier()
+        return res
+
+    single_ref = None
+    if dp.collective and dp.world > 1:
+        try:
+            single_ref = reference_steps()
+        except Exception as exc:                                   # noqa: BLE001
+            single_ref = {"error": str(exc)[:300], "matches": None}
     comm_rank, comm_ranks = eng.comm_info()
     shared_gpu = os.environ.get("PVAE_BENCH_SHARED_GPU") == "1"
     mode_now = a.exchange or (autotune["chosen"] if autotune and autotune["chosen"] in parallel.EXCHANGE_FORMS else None)
@@ -450,6 +519,7 @@ def main():
         "p2p_ranks": eng.p2p_status(sync=False)[1],
         "exchange_mode": a.exchange or (autotune["chosen"] if autotune else "default"),
         "exchange_autotune": autotune, "replicas_identical": replicas_ok,
+        "matches_single_process": (single_ref or {}).get("matches"), "single_process_reference": single_ref,
         "ranks_share_a_gpu": shared_gpu,
         "last_loss": last_loss,
     }

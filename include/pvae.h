@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PVAE_ABI_VERSION 6
+#define PVAE_ABI_VERSION 7
 
 typedef struct pvae_ctx pvae_ctx;
 
@@ -325,11 +325,21 @@ int pvae_p2p_export(pvae_ctx* ctx, void* blob);
 int pvae_p2p_open(pvae_ctx* ctx, int rank, int world, const void* blobs);
 int pvae_p2p_close(pvae_ctx* ctx);
 int pvae_p2p_status(pvae_ctx* ctx, int* rank, int* world, uint32_t* timeouts, void* stream);
-/* Collective in effect (every rank calls it after pvae_p2p_open): each rank writes a record into every peer's flag
+/* Collective in effect (every rank calls it after pvae_p2p_open): (1) each rank writes a record into every peer's flag
  * block, signals, checks the records that arrived in its own block and reads its records back from the peers' --
- * remote write, remote read and flag delivery are proven (or fail within 1 s) before the first training step.
- * Synchronises `stream`. */
+ * remote write, remote read and flag delivery are proven (or fail within 1 s) before the first training step;
+ * (2) the CACHED arenas, through the exchange's own access paths: a test region of the parameter arena and of the
+ * staging buffer is first read into this device's L2s from every XCD (LDS-DMA and plain loads, what the forward
+ * kernels use), the peers overwrite it with the exchange's `buffer_store ... sc0 sc1`, and a fresh dependent launch
+ * re-reads it from every XCD -- a stale line is an error; a gradient line is read remotely, overwritten by its owner
+ * and read again (reader-side staleness).  The regions are restored.  A failure (-22) means this machine must not
+ * run the peer-mapped forms: replicas would stay bit-identical while training on stale weights.
+ * PVAE_P2P_SELFTEST_FLAGS_ONLY=1 skips (2).  Synchronises `stream`. */
 int pvae_p2p_selftest(pvae_ctx* ctx, void* stream);
+/* Zero the count pvae_p2p_status reports (after the caller has handled the time-outs, e.g. dropped a calibration
+ * candidate and restored its snapshot).  Since ABI 7 a wait that gives up also ABORTS that rank's part of the
+ * exchange launch: no gradient is summed, no moment moves, nothing is pushed to the peers.  Synchronises `stream`. */
+int pvae_p2p_clear_errors(pvae_ctx* ctx, void* stream);
 /* One bucket through the peer-mapped exchange, stream-ordered like any launch of this library: the slice
  * [offset, offset + count) of the gradient arena (inside stack `net`, float4-aligned) is summed over the ranks
  * by its owners, Adam-applied and the updated parameters written to every rank -- what pvae_dp_train_step does
@@ -378,12 +388,42 @@ int pvae_read_tensor(pvae_ctx* ctx, int what, float* dst, int32_t rows, void* st
 int pvae_infer(pvae_ctx* ctx, const float* obs, int32_t rows, const float* eps, int noise,
                uint64_t rng_seed, uint64_t rng_offset, float* a_hat, float* s2_hat, float* z_out,
                void* stream);
+/* 1 when calls of <= 4 rows take the rollout path that keeps the observation rows for deferred reads (rmt:742-771's
+ * _cur_* state) and leaves a staged training minibatch alone; 0 under PVAE_ROLLOUT_FUSED=0 (read once per process by
+ * the LIBRARY: callers ask here instead of reading the environment themselves). */
+int pvae_rollout_is_fused(void);
 /* pvae_infer with the module's output layout (rmt:742-771 + AppendLogStd rmt:160-206): the action lands in
  * logits[r * ld_logits + 0 .. Da) and, when log_std (device, [Da]) is given, log_std behind it --
  * logits = [a_hat | log_std], what PhysicsVAE.forward returns to RLlib's action distribution. */
 int pvae_infer_logits(pvae_ctx* ctx, const float* obs, int32_t rows, const float* eps, int noise,
                       uint64_t rng_seed, uint64_t rng_offset, float* logits, int32_t ld_logits,
                       const float* log_std, float* s2_hat, float* z_out, void* stream);
+/* ---- call-persistent rollout server (the single-launch rollout path) ------------------------
+ * Replaces, for the 30 Hz control loop's forward at B = 1, PhysicsVAE.forward (rmt:742-771: task encoder ->
+ * sampler rmt:734-740 -> motor decoder; callers envs/rllib_env_imitation.py:215-266) by ZERO launches per call: one
+ * kernel stays resident on the 32 CUs of one XCD with the encoder's and the decoder's weights in LDS (1/32 of every
+ * layer's output features per workgroup), polls a mailbox in pinned host memory, walks the layers with a barrier in
+ * that XCD's L2 between them and writes the action back to the mailbox.  All pointers below are HOST pointers; the
+ * calls are plain host functions (no stream, no launch) once the server runs.
+ *   pvae_rollout_server_start   plans the LDS layout (-24 with a message when the stacks do not fit 156 KB per
+ *                               workgroup, e.g. 4x1024: callers keep using pvae_infer), allocates the mailbox and
+ *                               launches the kernel on a stream of its own; returns once it serves.  The kernel
+ *                               leaves by itself after idle_timeout_ms without a request (default 100 ms; the next
+ *                               pvae_rollout_server_infer brings it back) and never lives longer than lifetime_s
+ *                               (default 600 s).  Arguments <= 0 keep the current / default values.  While it is
+ *                               resident a DEVICE-wide synchronisation waits for it (at most the idle time-out).
+ *   pvae_rollout_server_infer   obs[2*Db] -> a_hat[Da] (+ mu_logvar[2*Z], z[Z] when not NULL): the same values as
+ *                               pvae_infer(rows = 1, eps = NULL, noise, rng_seed, rng_offset), bit for bit.  reload != 0:
+ *                               the weights are copied from the parameter arena into LDS again first (after an
+ *                               optimizer step or load_weights*, rmt:870-928).  Blocks at most timeout_ms (<= 0: 1 s).
+ *   pvae_rollout_server_stop    ends the kernel (also done by pvae_destroy).
+ *   pvae_rollout_server_status  *serving = 1 while the kernel is resident and answering. */
+int pvae_rollout_server_start(pvae_ctx* ctx, double idle_timeout_ms, double lifetime_s);
+int pvae_rollout_server_infer(pvae_ctx* ctx, const float* obs, int noise, uint64_t rng_seed, uint64_t rng_offset, int reload,
+                              float* a_hat, float* mu_logvar, float* z, double timeout_ms);
+int pvae_rollout_server_stop(pvae_ctx* ctx);
+int pvae_rollout_server_status(pvae_ctx* ctx, int32_t* serving, uint32_t* served, int32_t* lds_bytes);
+
 /* A stack of Linear layers on CALLER-owned dense row-major weights (W[i]: [n_out[i]][n_in[i]], row stride
  * ldw[i], no alignment needed; bias may be NULL), hidden activation PVAE_ACT_* (act_kind for every hidden
  * layer, or layer_acts[i] per hidden layer when not NULL), linear output layer.

@@ -34,7 +34,7 @@ MAX_HIDDEN = 15
 PRIOR_KINDS = {"normal_zero_mean_one_std": 0, "normal_state_mean_one_std": 1, "hypersphere_uniform": 2, False: 3}
 PHASE_WORLD, PHASE_JOINT = 0, 1
 FLAG_FUSED_ADAM, FLAG_NO_BACKWARD = 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 LOSS_MSE, LOSS_L1 = 0, 1
 EXCHANGE_ALLREDUCE, EXCHANGE_SHARDED, EXCHANGE_P2P, EXCHANGE_LOCAL, EXCHANGE_P2P_PUSH = 0, 1, 2, 3, 4
 P2P_BLOB_BYTES, P2P_MAX_RANKS = 512, 8
@@ -99,6 +99,12 @@ _SIGS = {
     "pvae_p2p_open": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "pvae_p2p_close": (C.c_int, [_P]),
     "pvae_p2p_selftest": (C.c_int, [_P, _P]),
+    "pvae_p2p_clear_errors": (C.c_int, [_P, _P]),
+    "pvae_rollout_is_fused": (C.c_int, []),
+    "pvae_rollout_server_start": (C.c_int, [_P, C.c_double, C.c_double]),
+    "pvae_rollout_server_infer": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _P, _P, _P, C.c_double]),
+    "pvae_rollout_server_stop": (C.c_int, [_P]),
+    "pvae_rollout_server_status": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
     "pvae_p2p_exchange": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.POINTER(StepParams), _P]),
     "pvae_p2p_status": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32), _P]),
     "pvae_owned_slices": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32),

@@ -7,12 +7,14 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <functional>
 #include <new>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -202,9 +204,13 @@ struct pvae_ctx {
         float* peer_staging[PVAE_P2P_MAX_RANKS] = {};
         void* mapped[PVAE_P2P_MAX_RANKS][4] = {};        // what hipIpcOpenMemHandle returned (to close)
         unsigned epoch = 0;                              // exchanges issued so far (identical on every rank)
+        float* self_buf = nullptr;                       // self-test scratch: saved regions + checksums (hipMalloc)
+        unsigned selftests = 0;                          // self-tests run since the flags were zeroed (identical on every rank)
         long long timeout_ticks = 20ll * 100000000ll;    // 100 MHz wall clock
     } p2p;
+    struct RolloutServer* server = nullptr;              // call-persistent rollout kernel (pvae_rollout_server_*)
 };
+static void server_free(pvae_ctx* c);
 
 // ---------------------------------------------------------------------------------------
 // glue kernels
@@ -212,10 +218,19 @@ struct pvae_ctx {
 
 // Minibatch staging as a launch of its own: one block per (padded) batch row and time step
 // (blockIdx.y = t < L); the work is stage_row (pvae_gemm.h).
-// (four rows per workgroup, one wave each, 16-byte panel stores: stage_row_vec)
+// (four rows per workgroup, one wave each, every source load of a 512-column chunk in flight before the first store:
+//  stage_row_wave; PVAE_GATHER_VEC=1 at build time keeps round 3's stage_row_vec for an A/B)
+#ifndef PVAE_GATHER_VEC
+#define PVAE_GATHER_VEC 0
+#endif
 __global__ void __launch_bounds__(256) stage_batch_kernel(StageArgs a) {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r < a.rows_pad) stage_row_vec(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63, 64);
+    const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // (provably wave-uniform: the row's
+    if (r >= a.rows_pad) return;                                                          //  buffer descriptors live in SGPRs)
+#if PVAE_GATHER_VEC
+    stage_row_vec(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63, 64);
+#else
+    stage_row_wave(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63);
+#endif
 }
 
 // s1 of step t+1 = world-model prediction of step t (tpv:421): copy the first Db columns of the
@@ -653,12 +668,13 @@ struct P2pArgs {
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 __device__ inline unsigned p2p_ld(const unsigned* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ inline void p2p_st(unsigned* q, unsigned x) { __hip_atomic_store(q, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ inline void p2p_wait(const unsigned* flag, unsigned epoch, long long timeout, unsigned* err) {
+__device__ inline bool p2p_wait(const unsigned* flag, unsigned epoch, long long timeout, unsigned* err) {
     const long long t0 = wall_clock64();
     while ((int)(p2p_ld(flag) - epoch) < 0) {
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > timeout) { atomicAdd(err, 1u); return; }
+        if (wall_clock64() - t0 > timeout) { atomicAdd(err, 1u); return false; }
     }
+    return true;
 }
 template <int N>
 __global__ void __launch_bounds__(256) p2p_exchange_kernel(P2pArgs a) {
@@ -668,13 +684,19 @@ __global__ void __launch_bounds__(256) p2p_exchange_kernel(P2pArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");             // (system scope; the producing launches ended before this one began)
         p2p_st(a.f[tid] + kP2pReady + me, a.epoch);
     }
+    // A wait that gives up ABORTS the exchange on this rank: no peer gradient that may be unfinished is summed, no
+    // moment moves, nothing is pushed -- parameters and moments stay what they were before the launch, the error word
+    // says so (pvae_p2p_status), and the "done" hand-shake below still runs so that the peers are not left waiting.
+    __shared__ int abort_;
+    if (tid == 0) abort_ = 0;
+    __syncthreads();
     if (tid < N && tid != me) {
-        p2p_wait(mine + kP2pReady + tid, a.epoch, a.timeout_ticks, mine + kP2pErr);
+        if (!p2p_wait(mine + kP2pReady + tid, a.epoch, a.timeout_ticks, mine + kP2pErr)) abort_ = 1;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
     __syncthreads();
     const long long S = (a.n4 + N - 1) / N, lo = me * S, hi = lo + S < a.n4 ? lo + S : a.n4;
-    if (lo < hi) {
+    if (lo < hi && !abort_) {
         // buffer descriptors over this rank's slice of every arena: loads / stores with sc0 sc1 (system scope,
         // past this device's caches) that the compiler schedules and counts like any other memory operation
         __amdgpu_buffer_rsrc_t rg[N], rp[N];
@@ -758,13 +780,16 @@ __global__ void __launch_bounds__(256) p2p_push_exchange_kernel(P2pArgs a) {
             if (tid < N && tid != me) p2p_st(a.f[tid] + kP2pPushed + me, a.epoch);
         }
     }
+    __shared__ int abort_;              // (see p2p_exchange_kernel: a wait that gives up aborts this rank's update)
+    if (tid == 0) abort_ = 0;
+    __syncthreads();
     if (tid < N && tid != me) {       // 2. everything for my slice has arrived
-        p2p_wait(mine + kP2pPushed + tid, a.epoch, a.timeout_ticks, mine + kP2pErr);
+        if (!p2p_wait(mine + kP2pPushed + tid, a.epoch, a.timeout_ticks, mine + kP2pErr)) abort_ = 1;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
     __syncthreads();
     const long long lo = me * S, hi = lo + S < a.n4 ? lo + S : a.n4;
-    if (lo < hi) {
+    if (lo < hi && !abort_) {
         const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(a.stage[me], 0, (unsigned)(N * S * 16), 0x00020000);
         __amdgpu_buffer_rsrc_t rp[N];
 #pragma unroll
@@ -822,6 +847,172 @@ __global__ void p2p_selftest_kernel(P2pArgs a, int n, unsigned token) {
                      p2p_ld(mine + kP2pPayload + q * 4 + 2) == (unsigned)me && p2p_ld(mine + kP2pPayload + q * 4 + 3) == 0xC0FFEEu;
     const bool back = p2p_ld(theirs + kP2pPayload + me * 4) == token && p2p_ld(theirs + kP2pPayload + me * 4 + 3) == 0xC0FFEEu;
     if (!got || !back) atomicAdd(mine + kP2pErr, 1u);
+}
+
+
+// ---- self-test of the CACHED arenas ---------------------------------------------------------
+// The flag block above is uncached memory; the arenas the exchange really moves are plain hipMalloc (coarse-grained)
+// memory that this device's L2s cache.  Peers overwrite this rank's parameters over the links while the lines may
+// still sit in the local L2s from the last forward pass, and the next forward launch starts behind an agent-scope
+// acquire only.  If a remote write left a stale line behind, every rank would train on old weights of the slices it
+// does not own -- and the replicas would still be bit-identical.  So, once per set-up, the very access paths of the
+// exchange are exercised on a TEST REGION of each buffer and every read-back is compared with what was written:
+//   parameters  first kSelfFloats floats of the arena (saved first, restored at the end), one 128-byte line per source
+//               rank: primed into the local L2s of all XCDs (LDS-DMA loads, the forward kernels' path, and plain
+//               loads), overwritten by the peers with the exchange's own `buffer_store ... sc0 sc1`, re-read by a FRESH
+//               dependent launch on every XCD through the same two load paths;
+//   staging     the 256-float tail of the staging buffer: primed, overwritten by the peers, read in the SAME launch
+//               behind the flag wait with the push form's system-scope loads, and again by the fresh launch;
+//   gradients   first kSelfFloats floats of the arena (saved / restored): the owner writes pattern A with plain stores, the
+//               peers read their line with the pull form's `buffer_load ... sc0 sc1`; the owner overwrites it with
+//               pattern B and the peers read again -- a reader-side stale line would return A.
+// Any mismatch or missing flag raises the error word; pvae_p2p_selftest then fails and the caller drops the form.
+constexpr int kP2pPrimed = 96, kP2pWritten = 104, kP2pGradB = 112, kP2pFin = 120;       // flag words, [src rank]
+constexpr int kSelfLine = 32, kSelfFloats = PVAE_P2P_MAX_RANKS * kSelfLine;             // 8 lines of 128 bytes
+constexpr int kSelfGrid = 64;                                                           // 8 workgroups on every XCD
+struct SelfArgs {
+    P2pArgs a;              // g / p / f / stage: the test regions' base pointers (stage: the tail), me, timeout
+    float* save;            // [2 * kSelfFloats]: what the parameter and gradient regions held
+    unsigned* sink;         // [kSelfGrid] checksums (keeps the priming loads alive)
+    int n;
+    unsigned token;
+};
+__device__ inline float self_pat(unsigned token, int src, int dst, int j, int round) {
+    return (float)(((token & 0xFFFFu) * 131u + (unsigned)src * 1021u + (unsigned)dst * 67u + (unsigned)round * 4099u) % 65521u) +
+           (float)j * 0.0078125f;                                     // exactly representable, distinct per (src, dst, j, round)
+}
+// the two paths a forward launch reads parameters through: LDS-DMA (default cache policy) and a plain 16-byte load
+__device__ inline v4f self_read_dma(const float* region, float* lds, int lane) {
+    lds_dma16(region + 4 * lane, lds);                                // 64 lanes x 16 bytes = the 1 KB region
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    return *reinterpret_cast<const v4f*>(lds + 4 * lane);
+}
+__global__ void __launch_bounds__(64) p2p_self_prime_kernel(SelfArgs s) {
+    __shared__ __attribute__((aligned(16))) float lds[kSelfFloats];
+    const int lane = threadIdx.x, me = s.a.me;
+    const v4f pd = self_read_dma(s.a.p[me], lds, lane);
+    const v4f pl = *reinterpret_cast<const v4f*>(s.a.p[me] + 4 * lane);
+    const v4f sl = *reinterpret_cast<const v4f*>(s.a.stage[me] + 4 * lane);
+    const v4f gl = *reinterpret_cast<const v4f*>(s.a.g[me] + 4 * lane);
+    if (blockIdx.x == 0) {
+        *reinterpret_cast<v4f*>(s.save + 4 * lane) = pl;
+        *reinterpret_cast<v4f*>(s.save + kSelfFloats + 4 * lane) = gl;
+        v4f a;                                                        // gradient pattern A: line q is what peer q will read
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = self_pat(s.token, me, (4 * lane + e) / kSelfLine, (4 * lane + e) % kSelfLine, 0);
+        *reinterpret_cast<v4f*>(s.a.g[me] + 4 * lane) = a;            // plain store, as an ordinary producer would
+    }
+    const float c = pd[0] + pd[3] + pl[1] + sl[2] + gl[0];
+    if (lane == 0) s.sink[blockIdx.x] = __float_as_uint(c);
+}
+// one wave: signal "primed", wait for the peers', write my lines into every peer's parameter and staging regions with the
+// exchange's stores, read my line of every peer's gradient region (pattern A) with the exchange's loads, signal
+// "written", wait for the peers', and check my staging region in this same launch (the push form's situation)
+__global__ void __launch_bounds__(64) p2p_self_write_kernel(SelfArgs s) {
+    unsigned* mine = s.a.f[s.a.me];
+    const int lane = threadIdx.x, me = s.a.me, n = s.n;
+    unsigned bad = 0;
+    if (lane < n && lane != me) {
+        p2p_st(s.a.f[lane] + kP2pPrimed + me, s.token);
+        p2p_wait(mine + kP2pPrimed + lane, s.token, s.a.timeout_ticks, mine + kP2pErr);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    __builtin_amdgcn_s_barrier();
+    for (int q = 0; q < n; ++q) {
+        if (q == me) continue;
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(s.a.p[q], 0, kSelfFloats * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(s.a.stage[q], 0, kSelfFloats * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(s.a.g[q], 0, kSelfFloats * 4, 0x00020000);
+        if (lane < kSelfLine / 4) {
+            v4f w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = self_pat(s.token, me, q, 4 * lane + e, 0);
+            const unsigned off = (unsigned)((me * kSelfLine + 4 * lane) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, w), rp, off, 0, 17);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, w), rs, off, 0, 17);
+            const v4f g = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 17));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bad += g[e] != self_pat(s.token, q, me, 4 * lane + e, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __builtin_amdgcn_s_barrier();
+    if (lane < n && lane != me) {
+        p2p_st(s.a.f[lane] + kP2pWritten + me, s.token);
+        p2p_wait(mine + kP2pWritten + lane, s.token, s.a.timeout_ticks, mine + kP2pErr);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    __builtin_amdgcn_s_barrier();
+    const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(s.a.stage[me], 0, kSelfFloats * 4, 0x00020000);
+    const int q = (4 * lane) / kSelfLine;
+    if (q < n && q != me) {
+        const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rst, (unsigned)(lane * 16), 0, 17));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bad += v[e] != self_pat(s.token, q, me, (4 * lane + e) % kSelfLine, 0);
+    }
+    if (bad) atomicAdd(mine + kP2pErr, bad);
+}
+// the fresh dependent launch: every XCD re-reads the parameter region through both forward-pass load paths and the
+// staging region through plain and system-scope loads; the lines of the peers must hold what the peers wrote
+__global__ void __launch_bounds__(64) p2p_self_verify_kernel(SelfArgs s) {
+    __shared__ __attribute__((aligned(16))) float lds[kSelfFloats];
+    const int lane = threadIdx.x, me = s.a.me;
+    const v4f pd = self_read_dma(s.a.p[me], lds, lane);
+    const v4f pl = *reinterpret_cast<const v4f*>(s.a.p[me] + 4 * lane);
+    const v4f sl = *reinterpret_cast<const v4f*>(s.a.stage[me] + 4 * lane);
+    const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(s.a.stage[me], 0, kSelfFloats * 4, 0x00020000);
+    const v4f ss = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rst, (unsigned)(lane * 16), 0, 17));
+    const int q = (4 * lane) / kSelfLine;
+    unsigned bad = 0;
+    if (q < s.n && q != me) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float want = self_pat(s.token, q, me, (4 * lane + e) % kSelfLine, 0);
+            bad += (pd[e] != want) + (pl[e] != want) + (sl[e] != want) + (ss[e] != want);
+        }
+    }
+    if (bad) atomicAdd(s.a.f[me] + kP2pErr, bad);
+}
+// pattern B over the gradient region (plain stores); the next launch tells the peers and reads theirs
+__global__ void __launch_bounds__(64) p2p_self_gradb_kernel(SelfArgs s) {
+    const int lane = threadIdx.x, me = s.a.me;
+    v4f b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[e] = self_pat(s.token, me, (4 * lane + e) / kSelfLine, (4 * lane + e) % kSelfLine, 1);
+    *reinterpret_cast<v4f*>(s.a.g[me] + 4 * lane) = b;
+}
+__global__ void __launch_bounds__(64) p2p_self_reread_kernel(SelfArgs s) {
+    unsigned* mine = s.a.f[s.a.me];
+    const int lane = threadIdx.x, me = s.a.me, n = s.n;
+    unsigned bad = 0;
+    if (lane < n && lane != me) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        p2p_st(s.a.f[lane] + kP2pGradB + me, s.token);
+        p2p_wait(mine + kP2pGradB + lane, s.token, s.a.timeout_ticks, mine + kP2pErr);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    __builtin_amdgcn_s_barrier();
+    for (int q = 0; q < n; ++q) {
+        if (q == me || lane >= kSelfLine / 4) continue;
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(s.a.g[q], 0, kSelfFloats * 4, 0x00020000);
+        const v4f g = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rg, (unsigned)((me * kSelfLine + 4 * lane) * 4), 0, 17));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bad += g[e] != self_pat(s.token, q, me, 4 * lane + e, 1);
+    }
+    if (bad) atomicAdd(mine + kP2pErr, bad);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (lane < n && lane != me) {                 // nobody restores its regions while a peer may still be reading them
+        p2p_st(s.a.f[lane] + kP2pFin + me, s.token);
+        p2p_wait(mine + kP2pFin + lane, s.token, s.a.timeout_ticks, mine + kP2pErr);
+    }
+}
+__global__ void __launch_bounds__(64) p2p_self_restore_kernel(SelfArgs s) {
+    const int lane = threadIdx.x, me = s.a.me;
+    *reinterpret_cast<v4f*>(s.a.p[me] + 4 * lane) = *reinterpret_cast<const v4f*>(s.save + 4 * lane);
+    *reinterpret_cast<v4f*>(s.a.g[me] + 4 * lane) = *reinterpret_cast<const v4f*>(s.save + kSelfFloats + 4 * lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1553,6 +1744,8 @@ void pvae_destroy(pvae_ctx* ctx) {
         pvae_p2p_close(ctx);
         if (ctx->p2p.flags) (void)hipFree(ctx->p2p.flags);
         if (ctx->p2p.staging) (void)hipFree(ctx->p2p.staging);
+        if (ctx->p2p.self_buf) (void)hipFree(ctx->p2p.self_buf);
+        server_free(ctx);
     }
     delete ctx;
 }
@@ -2474,6 +2667,7 @@ int pvae_p2p_export(pvae_ctx* c, void* blob) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(c->p2p.flags, 0, kP2pFlagBytes));
     HIP_TRY(hipDeviceSynchronize());
+    c->p2p.selftests = 0;
     P2pBlob b;
     memset(&b, 0, sizeof(b));
     b.magic = kP2pMagic; b.abi = PVAE_ABI_VERSION; b.arena_floats = c->L.arena_floats;
@@ -2592,18 +2786,54 @@ int pvae_p2p_selftest(pvae_ctx* c, void* stream) {
     for (int q = 0; q < P.world; ++q) a.f[q] = P.peer_flags[q];
     a.me = P.rank;
     a.timeout_ticks = P.timeout_ticks < 100000000ll ? P.timeout_ticks : 100000000ll;      // at most 1 s
+    // (one token per call, the same on every rank: the waits compare with >=, so a second self-test on the same flag
+    //  block must not be satisfied by the first one's tokens)
+    const unsigned token = 0x5E1F0000u + (++P.selftests) * 16u + (unsigned)P.world;
     uint32_t before = 0, after = 0;
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpy(&before, P.flags + kP2pErr, sizeof(before), hipMemcpyDeviceToHost));
-    hipLaunchKernelGGL(p2p_selftest_kernel, dim3(1), dim3(64), 0, st, a, P.world, 0x5E1F0000u + (unsigned)P.world);
+    // (1) the uncached flag block: remote write, remote read, flag delivery
+    hipLaunchKernelGGL(p2p_selftest_kernel, dim3(1), dim3(64), 0, st, a, P.world, token);
     HIP_TRY(hipGetLastError());
+    // (2) the cached arenas, through the exchange's own access paths (see p2p_self_prime_kernel)
+    const bool arenas = P.world > 1 && c->L.arena_floats >= kSelfFloats && getenv("PVAE_P2P_SELFTEST_FLAGS_ONLY") == nullptr;
+    if (arenas) {
+        if (!P.self_buf) HIP_TRY(hipMalloc((void**)&P.self_buf, (2 * kSelfFloats + kSelfGrid) * sizeof(float)));
+        SelfArgs s;
+        memset(&s, 0, sizeof(s));
+        s.a = a;
+        for (int q = 0; q < P.world; ++q) {
+            s.a.g[q] = P.grads[q]; s.a.p[q] = P.params[q];
+            s.a.stage[q] = P.peer_staging[q] + c->L.arena_floats;        // the 256-float tail behind the arena-sized part
+        }
+        s.save = P.self_buf; s.sink = (unsigned*)(P.self_buf + 2 * kSelfFloats); s.n = P.world; s.token = token;
+        hipLaunchKernelGGL(p2p_self_prime_kernel, dim3(kSelfGrid), dim3(64), 0, st, s);
+        hipLaunchKernelGGL(p2p_self_write_kernel, dim3(1), dim3(64), 0, st, s);
+        hipLaunchKernelGGL(p2p_self_verify_kernel, dim3(kSelfGrid), dim3(64), 0, st, s);
+        hipLaunchKernelGGL(p2p_self_gradb_kernel, dim3(1), dim3(64), 0, st, s);
+        hipLaunchKernelGGL(p2p_self_reread_kernel, dim3(1), dim3(64), 0, st, s);
+        hipLaunchKernelGGL(p2p_self_restore_kernel, dim3(1), dim3(64), 0, st, s);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpy(&after, P.flags + kP2pErr, sizeof(after), hipMemcpyDeviceToHost));
     if (after != before) {
         HIP_TRY(hipMemcpy(P.flags + kP2pErr, &before, sizeof(before), hipMemcpyHostToDevice));
-        return fail(-22, "peer-mapped exchange self-test failed on rank %d: %u record(s) / flag(s) from peers wrong or missing",
-                    P.rank, after - before);
+        return fail(-22, "peer-mapped exchange self-test failed on rank %d: %u record(s) / flag(s) / arena word(s) from peers wrong, "
+                         "stale or missing", P.rank, after - before);
     }
+    return 0;
+}
+
+/* Zero the "waits that gave up" word (after the caller has dealt with them: a rejected calibration candidate,
+ * a restored snapshot).  Synchronises `stream`. */
+int pvae_p2p_clear_errors(pvae_ctx* c, void* stream) {
+    if (!c) return fail(-1, "null ctx");
+    if (!c->p2p.flags) return 0;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    const uint32_t zero = 0;
+    HIP_TRY(hipMemcpy(c->p2p.flags + kP2pErr, &zero, sizeof(zero), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -3007,6 +3237,11 @@ int pvae_read_tensor(pvae_ctx* c, int what, float* dst, int32_t rows, void* stre
 
 // pvae_infer / pvae_infer_logits: the action lands in a_hat[r * ld_a + 0 .. Da) and, when `log_std` is given, the
 // decoder's log-std vector behind it (AppendLogStd rmt:160-206: logits = [a_hat | log_std]).
+// PVAE_ROLLOUT_FUSED=0 (read once per process): rollout calls of <= 4 rows go through the staged path (A/B)
+static bool rollout_fused() {
+    static const bool on = [] { const char* e = getenv("PVAE_ROLLOUT_FUSED"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static int infer_impl(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, int noise, uint64_t rng_seed,
                       uint64_t rng_offset, float* a_hat, int ld_a, const float* log_std, float* s2_hat, float* z_out,
                       void* stream) {
@@ -3016,7 +3251,7 @@ static int infer_impl(pvae_ctx* c, const float* obs, int32_t rows, const float* 
     if (ld_a < c->L.cfg.dim_action * (log_std ? 2 : 1)) return fail(-1, "row stride %d of the action buffer is too small", ld_a);
     hipStream_t st = (hipStream_t)stream;
     if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
-    static const bool fused_rollout = [] { const char* e = getenv("PVAE_ROLLOUT_FUSED"); return !(e && e[0] == '0'); }();
+    const bool fused_rollout = rollout_fused();
     if (rows <= 4 && fused_rollout) {
         // latency path of the control loop (rmt:742-771 at B = 1): no staging / sampler / copy launches, the
         // input panels of a staged training minibatch are not touched
@@ -3113,6 +3348,428 @@ static int infer_impl(pvae_ctx* c, const float* obs, int32_t rows, const float* 
     }
     return 0;
 }
+
+}   // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// Call-persistent rollout server (rmt:742-771 at B = 1; callers envs/rllib_env_imitation.py:215-266).
+//
+// The per-layer launches above cost the control loop 7 dependent launches whose weights are a cold fetch each
+// (35 us device -> device).  Here ONE kernel stays resident across calls on the 32 CUs of ONE XCD.  It copies the
+// encoder's and the decoder's weights into LDS once (every workgroup holds the rows of 1/32 of every layer's output
+// features: 3.4 MB over 32 x 160 KB for the default stacks), then serves requests from a mailbox in pinned host
+// memory: workgroup 0 polls the request word over PCIe, fetches the observation, and releases the other 31
+// through a word in the XCD's L2; every layer is a GEMV from LDS-resident weights followed by the single-XCD L2
+// barrier of tools/xcd_barrier.hip (arrive = atomic add that executes in the L2, poll = sc1 load, payload = plain
+// stores drained before arriving and read back with sc1 loads: 1.2 us per round); the sampler of rmt:734-740 is
+// formed in place by every workgroup; after the last barrier workgroup 0 writes [a_hat | mu | logvar | z] to the
+// mailbox and then the completion word.  No launch, no stream operation and no cold weight fetch per call.
+// The arithmetic of a feature is gemv_rollout_kernel's, operation for operation (same lane -> k mapping, same fma
+// chain, same butterfly), so the action equals pvae_infer's bit for bit.
+// Bounded by construction: workgroup 0 gives up after `idle_ticks` without a request (the host relaunches on the
+// next call), every spin re-checks an absolute lifetime, and a stop command ends it at once.  While it is resident,
+// a DEVICE-wide synchronisation (hipDeviceSynchronize, hipFree) waits for it -- at most the idle time-out.
+// ---------------------------------------------------------------------------------------
+constexpr int kSrvMaxLayers = 8, kSrvGroups = 32, kSrvMaxObs = 2048, kSrvMaxOut = 1024;
+struct SrvMailbox {                       // pinned host memory, device-mapped
+    // host -> device (one cache line of control words, then the observation)
+    volatile uint32_t req_seq;            // written LAST by the host: request number (0: none yet)
+    uint32_t cmd;                         // 0 infer, 1 stop, 2 reload the weights from the arena, then infer
+    uint32_t noise, pad0;
+    uint64_t rng_seed, rng_offset;
+    uint32_t pad1[8];
+    float obs[kSrvMaxObs];
+    // device -> host
+    volatile uint32_t done_seq;           // written LAST by the device: the request this result belongs to
+    volatile uint32_t state;              // 0 not started, 1 serving, 2 exited (idle / stop / lifetime), 3 refused (placement)
+    uint32_t served, pad2[13];
+    float out[kSrvMaxOut];                // [a_hat (Da) | mu (Z) | logvar (Z) | z (Z)]
+};
+struct SrvLayer { long long w_off, b_off; int ld, n_out_pad, n_out, act, F, lds_off; };
+struct SrvArgs {
+    SrvLayer layer[kSrvMaxLayers];
+    int n_layers, n_te;                   // layers [0, n_te) are the encoder's, the rest the decoder's
+    int Db, Da, Z, prior_kind;
+    const float* params;
+    float* acts;                          // [n_layers + 1][kSrvActStride]: slot 0 = the observation, slot l + 1 = layer l's output
+    unsigned* sync;                       // device words: 0 barrier counter, 1 go_seq, 2 cmd, 3 noise, 4..7 seed / offset, 8 xcc of group 0, 9 error
+    SrvMailbox* mb;
+    long long idle_ticks, life_ticks;     // 100 MHz wall clock
+    int xs_off;                           // float offset of the input vector inside the dynamic LDS
+};
+constexpr int kSrvActStride = 2048;
+__device__ inline float srv_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // sc1: past the L1
+__device__ inline unsigned srv_ldu(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float srv_lds[];
+    __shared__ unsigned s_word[8];
+    if ((blockIdx.x & 7) != 0) return;                    // workgroup b runs on XCD b % 8: the 32 of XCD 0 stay
+    const int g = blockIdx.x >> 3, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long t_start = wall_clock64();
+    float* xs = srv_lds + a.xs_off;
+    unsigned* ctr = a.sync;
+    // placement check: all 32 groups must sit on the XCD of group 0 (the barrier and the hand-overs live in ITS L2)
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;
+    if (tid == 0) {
+        if (g == 0) __hip_atomic_store(a.sync + 8, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned x0;
+        while ((x0 = srv_ldu(a.sync + 8)) == 0u) {
+            if (wall_clock64() - t_start > a.life_ticks) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (x0 != xcc + 1u) atomicAdd(a.sync + 9, 1u);
+    }
+    auto load_weights = [&]() {
+        for (int l = 0; l < a.n_layers; ++l) {
+            const SrvLayer L = a.layer[l];
+            const int n4 = L.F * L.ld / 4;                 // this group's rows are contiguous in the arena
+            const v4f* src = reinterpret_cast<const v4f*>(a.params + L.w_off + (long long)g * L.F * L.ld);
+            v4f* dst = reinterpret_cast<v4f*>(srv_lds + L.lds_off);
+            for (int i = tid; i < n4; i += 256) dst[i] = src[i];
+            if (tid < L.F) srv_lds[L.lds_off + L.F * L.ld + tid] = a.params[L.b_off + g * L.F + tid];
+        }
+        __syncthreads();
+    };
+    load_weights();
+    unsigned round = 0;
+    bool alive = true;
+    auto barrier = [&]() {                                // single-XCD L2 barrier; false: gave up (lifetime)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ++round;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);       // executes in the L2
+            const unsigned want = kSrvGroups * round;
+            unsigned ok = 1;
+            while ((int)(srv_ldu(ctr) - want) < 0) {
+                if (wall_clock64() - t_start > a.life_ticks) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_word[7] = ok;
+        }
+        __syncthreads();
+        return s_word[7] != 0;
+    };
+    if (!barrier()) alive = false;                         // everybody placed, checked and loaded
+    if (alive && srv_ldu(a.sync + 9) != 0u) {              // not on one XCD: refuse (the host falls back to the launches)
+        if (g == 0 && tid == 0) { a.mb->state = 3; __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
+        return;
+    }
+    if (g == 0 && tid == 0 && alive) { a.mb->state = 1; __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
+    unsigned last = 0;
+    while (alive) {
+        // ---- wait for a request: group 0 polls the mailbox, the others the go word in the L2 ----
+        if (tid == 0) {
+            unsigned seq = last, cmd = 1;
+            const long long t_idle = wall_clock64();
+            if (g == 0) {
+                for (;;) {
+                    seq = __hip_atomic_load(&a.mb->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (seq != last) { cmd = a.mb->cmd; break; }
+                    const long long now = wall_clock64();
+                    if (now - t_idle > a.idle_ticks || now - t_start > a.life_ticks) { seq = last + 1u; cmd = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                s_word[0] = seq; s_word[1] = cmd;
+                s_word[2] = a.mb->noise;
+                const unsigned long long sd = a.mb->rng_seed, of = a.mb->rng_offset;
+                s_word[3] = (unsigned)sd; s_word[4] = (unsigned)(sd >> 32); s_word[5] = (unsigned)of; s_word[6] = (unsigned)(of >> 32);
+            }
+        }
+        if (g == 0) {
+            __syncthreads();
+            if (s_word[1] != 1u) {                         // the observation: pinned host memory -> slot 0 (device)
+                const int n = 2 * a.Db;
+                for (int i = tid; i < n; i += 256)
+                    a.acts[i] = __hip_atomic_load(a.mb->obs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                for (int i = 1; i < 7; ++i) __hip_atomic_store(a.sync + 1 + i, s_word[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(a.sync + 1, s_word[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            if (tid == 0) {
+                unsigned seq;
+                while ((seq = srv_ldu(a.sync + 1)) == last) {
+                    if (wall_clock64() - t_start > a.life_ticks + 100000000ll) { seq = last + 1u; s_word[1] = 1; break; }   // (group 0 is gone)
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                s_word[0] = seq;
+                if (seq == srv_ldu(a.sync + 1))
+                    for (int i = 1; i < 7; ++i) s_word[i] = srv_ldu(a.sync + 1 + i);
+            }
+        }
+        __syncthreads();
+        last = s_word[0];
+        const unsigned cmd = s_word[1];
+        if (cmd == 1u) break;
+        if (cmd == 2u) load_weights();
+        const int noise = (int)s_word[2];
+        const unsigned long long seed = s_word[3] | ((unsigned long long)s_word[4] << 32);
+        const unsigned long long offset = s_word[5] | ((unsigned long long)s_word[6] << 32);
+        // ---- the seven layers ----
+        for (int l = 0; l < a.n_layers && alive; ++l) {
+            const SrvLayer L = a.layer[l];
+            const float* prev = a.acts + (size_t)l * kSrvActStride;          // slot l: the previous layer's output (0: obs)
+            if (l == 0) {                                                    // [s1 | s2 | 0]
+                for (int k = tid; k < L.ld; k += 256) xs[k] = k < 2 * a.Db ? srv_ld(a.acts + k) : 0.f;
+            } else if (l == a.n_te) {                                        // [s1 | z | 0], the sampler formed in place
+                for (int k = tid; k < L.ld; k += 256) {
+                    float v = 0.f;
+                    if (k < a.Db) v = srv_ld(a.acts + k);
+                    else if (k < a.Db + a.Z) {
+                        const int j = k - a.Db;
+                        if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_ld(prev + j);
+                        else {
+                            const float mu = srv_ld(prev + j), lv = srv_ld(prev + a.Z + j);
+                            const float e = noise ? philox_normal(seed, offset, 0, j) : 0.f;
+                            v = mu + e * expf(0.5f * lv);
+                        }
+                    }
+                    xs[k] = v;
+                }
+            } else {
+                for (int k = tid; k < L.ld; k += 256) xs[k] = srv_ld(prev + k);
+            }
+            __syncthreads();
+            const float* Wl = srv_lds + L.lds_off;
+            for (int f = wave; f < L.F; f += 4) {                            // one wave per feature: gemv_rollout_kernel's sum
+                const float* wrow = Wl + f * L.ld;
+                float acc = 0.f;
+                for (int k = lane * 4; k < L.ld; k += 256) {
+                    const v4f wv = *reinterpret_cast<const v4f*>(wrow + k);
+                    const v4f xv = *reinterpret_cast<const v4f*>(xs + k);
+                    acc = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc))));
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                if (lane == 0) {
+                    const int n = g * L.F + f;
+                    float v = acc + Wl[L.F * L.ld + f];
+                    v = (L.act > 1 && n >= L.n_out) ? 0.f : act_apply(v, L.act);
+                    a.acts[(size_t)(l + 1) * kSrvActStride + n] = v;
+                }
+            }
+            if (!barrier()) alive = false;
+        }
+        if (!alive) break;
+        // ---- result: group 0 -> mailbox, payload first, completion word last ----
+        if (g == 0) {
+            const float* md_out = a.acts + (size_t)a.n_layers * kSrvActStride;
+            const float* te_out = a.acts + (size_t)a.n_te * kSrvActStride;
+            const int n_out = a.Da + 3 * a.Z;
+            for (int i = tid; i < n_out; i += 256) {
+                float v;
+                if (i < a.Da) v = srv_ld(md_out + i);
+                else if (i < a.Da + 2 * a.Z) v = srv_ld(te_out + (i - a.Da));
+                else {                                                       // z as the decoder saw it (same expression as above)
+                    const int j = i - a.Da - 2 * a.Z;
+                    if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_ld(te_out + j);
+                    else {
+                        const float e = noise ? philox_normal(seed, offset, 0, j) : 0.f;
+                        v = srv_ld(te_out + j) + e * expf(0.5f * srv_ld(te_out + a.Z + j));
+                    }
+                }
+                __hip_atomic_store(a.mb->out + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                a.mb->served = a.mb->served + 1u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                __hip_atomic_store(&a.mb->done_seq, last, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    if (g == 0 && tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __hip_atomic_store(&a.mb->state, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+struct RolloutServer {
+    SrvMailbox* mb = nullptr;             // hipHostMalloc (mapped)
+    SrvMailbox* mb_dev = nullptr;
+    unsigned* sync = nullptr;             // device
+    float* acts = nullptr;                // device
+    hipStream_t stream = nullptr;
+    SrvArgs args{};
+    size_t lds_bytes = 0;
+    uint32_t seq = 0;
+    bool launched = false;
+    double idle_ms = 100.0, life_s = 600.0;
+};
+
+static int server_plan(pvae_ctx* c, RolloutServer& S) {
+    const NetLayout& TE = c->L.net[PVAE_NET_TE];
+    const NetLayout& MD = c->L.net[PVAE_NET_MD];
+    const int n = (int)(TE.layers.size() + MD.layers.size());
+    if (n > kSrvMaxLayers) return fail(-24, "rollout server: %d layers (at most %d)", n, kSrvMaxLayers);
+    if (c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE)
+        return fail(-24, "rollout server: this latent prior is served by the per-layer launches only");
+    SrvArgs& a = S.args;
+    memset(&a, 0, sizeof(a));
+    int off = 0, max_ld = 0, i = 0;
+    for (const NetLayout* N : {&TE, &MD})
+        for (const Layer& l : N->layers) {
+            SrvLayer& L = a.layer[i++];
+            L.w_off = l.w_off; L.b_off = l.b_off; L.ld = l.ld; L.n_out_pad = l.n_out_pad; L.n_out = l.n_out; L.act = l.act;
+            L.F = l.n_out_pad / kSrvGroups;
+            if (L.F < 1 || L.F * kSrvGroups != l.n_out_pad) return fail(-24, "rollout server: layer width %d", l.n_out_pad);
+            if (l.n_out_pad > kSrvActStride || l.ld > kSrvActStride) return fail(-24, "rollout server: layer wider than %d", kSrvActStride);
+            L.lds_off = off;
+            off += L.F * l.ld + ((L.F + 3) & ~3);                         // rows + biases (16-byte granules)
+            if (l.ld > max_ld) max_ld = l.ld;
+        }
+    a.n_layers = n; a.n_te = (int)TE.layers.size();
+    a.Db = c->L.cfg.dim_body; a.Da = c->L.cfg.dim_action; a.Z = c->L.cfg.latent; a.prior_kind = c->L.cfg.prior_kind;
+    if (2 * a.Db > kSrvMaxObs || a.Da + 3 * a.Z > kSrvMaxOut) return fail(-24, "rollout server: observation / action too wide");
+    a.xs_off = off;
+    S.lds_bytes = (size_t)(off + max_ld) * sizeof(float);
+    if (S.lds_bytes > 156 * 1024)
+        return fail(-24, "rollout server: the encoder's and decoder's weights need %zu KB of LDS per workgroup (1/32 of every "
+                         "layer), more than a CU has: these stacks are served by the per-layer launches", S.lds_bytes / 1024);
+    return 0;
+}
+
+static int server_launch(pvae_ctx* c, RolloutServer& S) {
+    HIP_TRY(hipMemsetAsync(S.sync, 0, 64 * sizeof(unsigned), S.stream));
+    S.mb->state = 0; S.mb->req_seq = 0; S.mb->done_seq = 0; S.mb->cmd = 0;
+    S.seq = 0;
+    S.args.params = c->params;
+    S.args.idle_ticks = (long long)(S.idle_ms * 1e5);
+    S.args.life_ticks = (long long)(S.life_s * 1e8);
+    HIP_TRY(hipFuncSetAttribute((const void*)rollout_server_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes));
+    hipLaunchKernelGGL(rollout_server_kernel, dim3(8 * kSrvGroups), dim3(256), S.lds_bytes, S.stream, S.args);
+    HIP_TRY(hipGetLastError());
+    S.launched = true;
+    // until the kernel reports "serving" (or refuses): bounded
+    const auto t0 = std::chrono::steady_clock::now();
+    while (S.mb->state == 0) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0)
+            return fail(-25, "rollout server: the kernel did not come up within 5 s");
+        std::this_thread::yield();
+    }
+    if (S.mb->state == 3) {
+        HIP_TRY(hipStreamSynchronize(S.stream));
+        S.launched = false;
+        return fail(-24, "rollout server: its 32 workgroups were not placed on one XCD; use the per-layer launches");
+    }
+    return 0;
+}
+
+extern "C" {
+/* see include/pvae.h */
+int pvae_rollout_server_start(pvae_ctx* c, double idle_timeout_ms, double lifetime_s) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!c->server) c->server = new RolloutServer();
+    RolloutServer& S = *c->server;
+    if (S.launched && S.mb && S.mb->state == 1) return 0;                 // already serving
+    if ((rc = server_plan(c, S))) return rc;
+    if (!S.mb) {
+        HIP_TRY(hipHostMalloc((void**)&S.mb, sizeof(SrvMailbox), hipHostMallocMapped));
+        memset((void*)S.mb, 0, sizeof(SrvMailbox));
+        HIP_TRY(hipHostGetDevicePointer((void**)&S.mb_dev, (void*)S.mb, 0));
+        HIP_TRY(hipMalloc((void**)&S.sync, 64 * sizeof(unsigned)));
+        HIP_TRY(hipMalloc((void**)&S.acts, (size_t)(kSrvMaxLayers + 1) * kSrvActStride * sizeof(float)));
+        HIP_TRY(hipMemset(S.acts, 0, (size_t)(kSrvMaxLayers + 1) * kSrvActStride * sizeof(float)));
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));               // lo: least urgent.  A priority of its own = a hardware
+        HIP_TRY(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, lo));   // queue no compute stream is mapped onto
+    }
+    if (S.launched) { HIP_TRY(hipStreamSynchronize(S.stream)); S.launched = false; }   // an instance that gave up (idle): reap it
+    if (idle_timeout_ms > 0) S.idle_ms = idle_timeout_ms;
+    if (lifetime_s > 0) S.life_s = lifetime_s;
+    S.args.mb = S.mb_dev; S.args.sync = S.sync; S.args.acts = S.acts;
+    return server_launch(c, S);
+}
+
+static int server_request(pvae_ctx* c, uint32_t cmd, const float* obs, int noise, uint64_t seed, uint64_t offset, double timeout_ms) {
+    RolloutServer& S = *c->server;
+    SrvMailbox* mb = S.mb;
+    if (obs) memcpy((void*)mb->obs, obs, (size_t)2 * S.args.Db * sizeof(float));
+    mb->cmd = cmd; mb->noise = noise ? 1u : 0u; mb->rng_seed = seed; mb->rng_offset = offset;
+    const uint32_t seq = ++S.seq;
+    __atomic_store_n(&mb->req_seq, seq, __ATOMIC_RELEASE);
+    if (cmd == 1) return 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 1023u) == 0) {
+            if (__atomic_load_n(&mb->state, __ATOMIC_ACQUIRE) != 1u) return 1;           // the kernel left (idle time-out raced the request)
+            if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeout_ms)
+                return fail(-25, "rollout server: no answer within %.1f ms", timeout_ms);
+        }
+    }
+    return 0;
+}
+
+int pvae_rollout_server_infer(pvae_ctx* c, const float* obs, int noise, uint64_t rng_seed, uint64_t rng_offset, int reload,
+                              float* a_hat, float* mu_logvar, float* z, double timeout_ms) {
+    if (!c || !c->server || !c->server->mb) return fail(-2, "rollout server not started (pvae_rollout_server_start)");
+    if (!obs || !a_hat) return fail(-1, "obs / a_hat is null");
+    RolloutServer& S = *c->server;
+    if (timeout_ms <= 0) timeout_ms = 1000.0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!S.launched || S.mb->state != 1u) {                  // it left after its idle time: bring it back (weights re-read)
+            int rc = pvae_rollout_server_start(c, 0, 0);
+            if (rc) return rc;
+            reload = 0;
+        }
+        const int r = server_request(c, reload ? 2u : 0u, obs, noise, rng_seed, rng_offset, timeout_ms);
+        if (r < 0) return r;
+        if (r == 0) {
+            const int Da = S.args.Da, Z = S.args.Z;
+            memcpy(a_hat, (const void*)S.mb->out, (size_t)Da * sizeof(float));
+            if (mu_logvar) memcpy(mu_logvar, (const void*)(S.mb->out + Da), (size_t)2 * Z * sizeof(float));
+            if (z) memcpy(z, (const void*)(S.mb->out + Da + 2 * Z), (size_t)Z * sizeof(float));
+            return 0;
+        }
+    }
+    return fail(-25, "rollout server: the kernel left twice while a request was pending");
+}
+
+int pvae_rollout_server_stop(pvae_ctx* c) {
+    if (!c) return fail(-1, "null ctx");
+    if (!c->server || !c->server->mb) return 0;
+    RolloutServer& S = *c->server;
+    if (S.launched) {
+        if (S.mb->state == 1u) server_request(c, 1u, nullptr, 0, 0, 0, 0);
+        HIP_TRY(hipStreamSynchronize(S.stream));                 // bounded: stop command, else idle time-out, else lifetime
+        S.launched = false;
+    }
+    return 0;
+}
+
+int pvae_rollout_server_status(pvae_ctx* c, int32_t* serving, uint32_t* served, int32_t* lds_bytes) {
+    if (!c) return fail(-1, "null ctx");
+    const RolloutServer* S = c->server;
+    if (serving) *serving = (S && S->mb && S->launched && S->mb->state == 1u) ? 1 : 0;
+    if (served) *served = (S && S->mb) ? S->mb->served : 0u;
+    if (lds_bytes) *lds_bytes = S ? (int32_t)S->lds_bytes : 0;
+    return 0;
+}
+}   // extern "C"
+
+static void server_free(pvae_ctx* c) {
+    if (!c->server) return;
+    (void)pvae_rollout_server_stop(c);
+    RolloutServer& S = *c->server;
+    if (S.stream) (void)hipStreamDestroy(S.stream);
+    if (S.sync) (void)hipFree(S.sync);
+    if (S.acts) (void)hipFree(S.acts);
+    if (S.mb) (void)hipHostFree((void*)S.mb);
+    delete c->server;
+    c->server = nullptr;
+}
+
+extern "C" {
+int pvae_rollout_is_fused(void) { return rollout_fused() ? 1 : 0; }
 
 int pvae_infer(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, int noise, uint64_t rng_seed,
                uint64_t rng_offset, float* a_hat, float* s2_hat, float* z_out, void* stream) {

@@ -253,6 +253,82 @@ __device__ inline void stage_row_vec(const StageArgs& a, int r, int t, int rows_
     }
 }
 
+// The same row by ONE wave with every source load in flight before the first store (the stand-alone gather launch:
+// stage_batch_kernel, four rows per workgroup).  Lane l owns columns l + 64 k of every panel, so each load and each
+// store instruction of the wave covers 256 contiguous bytes -- whole 128-byte lines on the panel side (rows are
+// 64-float aligned), and on the source side as well as rows of dim_body / dim_action floats allow (they are 4-byte
+// aligned only, which is why the copy is dword-granular: 16-byte accesses would straddle).  Every access is a BUFFER
+// access through a descriptor that spans exactly one source row / one panel row: a load past the row's end returns 0
+// and a store past it is dropped by the address unit, which is precisely "pad columns are zero" / "this panel is
+// narrower" -- so the body has no branch at all and hipcc's wait counts stay exact: per chunk of 512 columns up to
+// 5 x 8 independent loads ([s_t | s_{t+1}] is ONE contiguous run of 2 Db floats of `states`; the target panel and the
+// action columns of the world-model panel re-read it at their own lane mapping: L1 hits) and only then the stores,
+// which retire in the background while the wave's next chunk / the SIMD's other seven waves load.  The dataset rows
+// are read once per epoch: nontemporal loads.  Same values as stage_row / stage_row_vec, bit for bit (a copy).
+// `w` = the wave's index inside the workgroup, wave-uniform by construction (readfirstlane'd by the caller).
+__device__ inline void stage_row_wave(const StageArgs& a, int r, int t, int rows_pad, int lane) {
+    const int Db = a.Db, Da = a.Da;
+    const size_t prow = (size_t)t * rows_pad + r;
+    const bool valid = r < a.rows;
+    const bool first = t == 0;
+    const float* p1 = a.te_in;                          // (any mapped address: descriptors of absent rows have length 0)
+    const float* p2 = a.te_in;
+    const float* pa = a.te_in;
+    bool have_a = false;
+    if (valid) {
+        if (a.window_row) {
+            const long long s = (long long)__builtin_amdgcn_readfirstlane(a.window_row[a.first_window + r]) + t;
+            p1 = a.states + s * Db;
+            p2 = a.next_states ? a.next_states + s * Db : p1 + Db;
+            pa = a.actions + s * Da;
+            have_a = true;
+        } else {
+            p1 = a.x + ((size_t)r * a.L + t) * 2 * Db;
+            p2 = p1 + Db;
+            if (a.y) { pa = a.y + ((size_t)r * a.L + t) * Da; have_a = true; }
+        }
+    }
+    int ld_max = a.ld_te;
+    if (a.ld_md > ld_max) ld_max = a.ld_md;
+    if (a.ld_wm > ld_max) ld_max = a.ld_wm;
+    if (a.ld_s2 > ld_max) ld_max = a.ld_s2;
+    if (a.ld_a > ld_max) ld_max = a.ld_a;
+    if (a.pr_in && a.ld_pr > ld_max) ld_max = a.ld_pr;
+    constexpr int kFlags = 0x00020000, kNt = 2;         // raw buffer, 32-bit data; aux bit 1 = nontemporal
+    const auto src = [](const float* p, int n) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, n * 4, kFlags); };
+    const auto dst = [&](float* p, int ld) { return __builtin_amdgcn_make_buffer_rsrc(p ? p + prow * ld : a.te_in, 0, p ? ld * 4 : 0, kFlags); };
+    const __amdgpu_buffer_rsrc_t rs1 = src(p1, valid && first ? Db : 0), rs2 = src(p2, valid ? Db : 0), ra = src(pa, have_a ? Da : 0);
+    const __amdgpu_buffer_rsrc_t dte = dst(a.te_in, a.ld_te), dmd = dst(a.md_in, a.ld_md), dwm = dst(a.wm_in, a.ld_wm),
+                                 dwp = dst(a.wm_pred, a.ld_wm), dpr = dst(a.pr_in, a.ld_pr), ds2 = dst(a.s2, a.ld_s2),
+                                 dac = dst(a.act_t, a.ld_a);
+    constexpr int KC = 8;                               // columns per lane and chunk
+    for (int c0 = 0; c0 < ld_max; c0 += 64 * KC) {
+        float v1[KC], v2[KC], vt[KC], vw[KC], va[KC];   // s1, s2 at the encoder's mapping; s2 at the target's; action at the world model's; action
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int c = c0 + 64 * k + lane;           // (offsets below zero wrap to far beyond any row: read as 0)
+            v1[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, (unsigned)c * 4u, 0, kNt));
+            v2[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, (unsigned)(c - Db) * 4u, 0, kNt));
+            vt[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, (unsigned)c * 4u, 0, kNt));
+            vw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, (unsigned)(c - Db) * 4u, 0, kNt));
+            va[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, (unsigned)c * 4u, 0, kNt));
+        }
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int c = c0 + 64 * k + lane;
+            const unsigned off = (unsigned)c * 4u;
+            const unsigned u1 = __builtin_bit_cast(unsigned, v1[k]);
+            __builtin_amdgcn_raw_buffer_store_b32(u1, dpr, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c < Db ? v1[k] : v2[k]), dte, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(u1, dmd, off, 0, 0);            // z columns filled by the sampler
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c < Db ? v1[k] : vw[k]), dwm, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(u1, dwp, off, 0, 0);            // a_hat columns filled by the decoder
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vt[k]), ds2, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, va[k]), dac, off, 0, 0);
+        }
+    }
+}
+
 // host-side default for GemmArgs::krot: off (measured: no gain); PVAE_KROT=1 enables
 // register sets in flight per lane in the register-staged kernels (A/B on the whole step: 2 / 2 /
 // 4 beats 4 / 4 / 4 by 1.8 %, 3 and 8 lose; compile-time switches for re-measuring)

@@ -152,8 +152,9 @@ class HipEngine:
         self.arch = arch
         self.max_batch = int(max_batch)
         self.lookahead = int(lookahead)          # steps unrolled per sample (tpv:277, 367-428)
-        # the library's <= 4-row rollout path (PVAE_ROLLOUT_FUSED=0 switches it off; read once, as the library does)
-        self.fused_rollout = os.environ.get("PVAE_ROLLOUT_FUSED", "1")[:1] != "0"
+        # the library's <= 4-row rollout path: the LIBRARY's effective setting (it reads PVAE_ROLLOUT_FUSED once per
+        # process), asked -- not re-read from the environment here, where the two could disagree
+        self.fused_rollout = bool(self.lib.pvae_rollout_is_fused())
         self.device = torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:
             # an indexed device, so that comparisons with tensor.device (always indexed) are exact
@@ -180,6 +181,7 @@ class HipEngine:
         self.ctx = None
         self.has_comm = False                    # RCCL communicator owned by the ctx (comm_init)
         self.has_p2p = False                     # peers' arenas mapped into this process (p2p_open)
+        self.exchange_code = _lib.EXCHANGE_ALLREDUCE   # what comm_mode last selected (p2p_close falls back to all-reduce)
         self.workspace = None
         self.dataset = None
         self._loss_scratch = None
@@ -406,6 +408,12 @@ class HipEngine:
                 "sharded": _lib.EXCHANGE_SHARDED, "p2p": _lib.EXCHANGE_P2P, "p2p_push": _lib.EXCHANGE_P2P_PUSH,
                 "local": _lib.EXCHANGE_LOCAL}[mode]
         _lib.check(self.lib.pvae_comm_mode(self.ctx, code), "pvae_comm_mode")
+        self.exchange_code = code
+
+    @property
+    def p2p_active(self):
+        """The peer-mapped exchange is what dp_train_step runs (its peers are mapped AND one of its forms is selected)."""
+        return self.has_p2p and self.exchange_code in (_lib.EXCHANGE_P2P, _lib.EXCHANGE_P2P_PUSH)
 
     # -- peer-mapped exchange (PVAE_EXCHANGE_P2P) -------------------------------------------------
     def p2p_export(self):
@@ -434,10 +442,17 @@ class HipEngine:
         self._need_gpu()
         _lib.check(self.lib.pvae_p2p_selftest(self.ctx, self._stream()), "pvae_p2p_selftest")
 
+    def p2p_clear_errors(self):
+        """Zero the time-out count `p2p_status` reports (the caller has dealt with them: candidate dropped, snapshot restored)."""
+        if self.ctx is not None:
+            _lib.check(self.lib.pvae_p2p_clear_errors(self.ctx, self._stream()), "pvae_p2p_clear_errors")
+
     def p2p_close(self):
         if self.ctx is not None and self.has_p2p:
             _lib.check(self.lib.pvae_p2p_close(self.ctx), "pvae_p2p_close")
             self.has_p2p = False
+            if self.exchange_code in (_lib.EXCHANGE_P2P, _lib.EXCHANGE_P2P_PUSH):
+                self.exchange_code = _lib.EXCHANGE_ALLREDUCE          # (what the library falls back to)
 
     def p2p_status(self, sync=True):
         """(rank, world, waits that gave up).  world = 0: not open.  `sync`: read the time-out word (synchronises)."""
@@ -534,7 +549,10 @@ class HipEngine:
         n_obs[:rows] = obs
         width = 2 * Da if log_std is not None else Da
         res = n_out[:rows, :width]
-        res.fill(_np.nan)
+        # "not written yet" = one particular quiet-NaN bit pattern no arithmetic produces (a NaN the MODEL computes is the
+        # canonical 0x7fc00000 / 0xffc00000 and counts as delivered): compared as integers, never with isnan
+        bits = res.view(_np.uint32)
+        bits.fill(0x7FC0DEAD)
         if log_std is not None:
             _lib.check(self.lib.pvae_infer_logits(self.ctx, h_obs.data_ptr(), rows, None, 1 if noise else 0, int(seed),
                                                   int(offset), h_out.data_ptr(), 2 * Da, log_std.data_ptr(), None, None,
@@ -544,11 +562,49 @@ class HipEngine:
                                                   int(offset), h_out.data_ptr(), 2 * Da, None, None, None,
                                                   self._stream()), "pvae_infer_logits")
         t0 = _time.perf_counter()
-        while _np.isnan(res).any():
+        while (bits == 0x7FC0DEAD).any():
             if _time.perf_counter() - t0 > timeout_s:
                 torch.cuda.current_stream(self.device).synchronize()
                 break
         return h_out[:rows, :width]
+
+    # -- call-persistent rollout server (include/pvae.h pvae_rollout_server_*) ---------------------------------
+    def rollout_server_start(self, idle_ms=100.0, lifetime_s=600.0):
+        """Launch the resident rollout kernel (one XCD, encoder + decoder weights in LDS, mailbox in pinned host memory).
+        Raises RuntimeError when the stacks do not fit a CU's LDS (e.g. 4x1024): keep using `infer` / `infer_host` then.
+        While it is resident, device-wide synchronisations wait for it (at most `idle_ms` after the last request)."""
+        self._need_gpu()
+        _lib.check(self.lib.pvae_rollout_server_start(self.ctx, float(idle_ms), float(lifetime_s)), "pvae_rollout_server_start")
+        if getattr(self, "_srv_io", None) is None:
+            import numpy as _np
+            Da, Db, Z = self.arch.Da, self.arch.Db, self.arch.Z
+            bufs = (_np.zeros(2 * Db, _np.float32), _np.zeros(Da, _np.float32), _np.zeros(2 * Z, _np.float32), _np.zeros(Z, _np.float32))
+            self._srv_io = bufs + tuple(b.ctypes.data for b in bufs)
+
+    def rollout_server_infer(self, obs, noise=True, seed=0, offset=0, reload=False, timeout_ms=1000.0):
+        """obs [2 Db] (CPU array / tensor) -> (a_hat [Da], mu_logvar [2 Z], z [Z]) as numpy views that stay valid until
+        the next call; the same values as `infer(obs[None], noise=noise, seed=seed, offset=offset)`, bit for bit.
+        A plain host call: no launch, no stream operation.  `reload`: copy the weights from the arena into LDS first."""
+        io = getattr(self, "_srv_io", None)
+        if io is None:
+            raise RuntimeError("rollout server not started (rollout_server_start)")
+        n_obs, n_a, n_ml, n_z, p_obs, p_a, p_ml, p_z = io
+        n_obs[:] = obs.reshape(-1) if not isinstance(obs, torch.Tensor) else obs.detach().cpu().numpy().reshape(-1)
+        _lib.check(self.lib.pvae_rollout_server_infer(self.ctx, p_obs, 1 if noise else 0, int(seed), int(offset), 1 if reload else 0,
+                                                      p_a, p_ml, p_z, float(timeout_ms)), "pvae_rollout_server_infer")
+        return n_a, n_ml, n_z
+
+    def rollout_server_stop(self):
+        if self.ctx is not None:
+            _lib.check(self.lib.pvae_rollout_server_stop(self.ctx), "pvae_rollout_server_stop")
+
+    def rollout_server_status(self):
+        """(serving, requests served so far, LDS bytes per workgroup)."""
+        a, b, c = C.c_int32(), C.c_uint32(), C.c_int32()
+        if self.ctx is None:
+            return False, 0, 0
+        _lib.check(self.lib.pvae_rollout_server_status(self.ctx, C.byref(a), C.byref(b), C.byref(c)), "pvae_rollout_server_status")
+        return bool(a.value), b.value, c.value
 
     def infer_logits(self, obs, log_std, eps=None, noise=True, seed=0, offset=0, want_s2=True):
         """`infer` with the module's output layout: returns (logits [rows, 2 Da] = [a_hat | log_std], s2_hat|None, z)

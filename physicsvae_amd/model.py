@@ -406,9 +406,12 @@ class PhysicsVAE(nn.Module):
         if obs.dim() != 2 or obs.shape[0] > eng.max_batch or self._latent_prior is not None or eng.lookahead != 1:
             return self._forward_staged(obs, state, seq_lens, eps)
         rows = obs.shape[0]
-        obs = obs.to(eng.device)
         noise = bool(self.latent_prior_noise)
         st = self._st
+        if (self.__dict__.get("_srv_on") and rows == 1 and obs.device.type == "cpu" and (eps is None or not noise)
+                and self._latent_prior_type != "hypersphere_uniform"):
+            return self._forward_served(obs, state, noise)
+        obs = obs.to(eng.device)
         st._rng_calls += 1
         # (eager on purpose: with the input assembly, the sampler and the output copies inside the layer
         #  launches the call is 10 launches, and issue -> result at B = 1 measures 37 us eager against 44 us
@@ -431,6 +434,56 @@ class PhysicsVAE(nn.Module):
         st._mu = st._logvar = st._cur_value = None
         st._cur_latent_prior_mu = (eng.read("eps", rows) if self._latent_prior_type == "hypersphere_uniform"
                                    else None)                  # rmt:813-814: the unit prior sample of this forward
+        return logits, state
+
+    # -- the call-persistent rollout server (opt-in; include/pvae.h pvae_rollout_server_*) -------------------
+    def start_rollout_server(self, idle_ms=100.0, lifetime_s=600.0):
+        """Serve `forward` at B = 1 from the resident rollout kernel (one XCD, encoder + decoder weights in LDS, mailbox
+        in pinned host memory): a forward whose observation arrives as a CPU tensor of ONE row then costs no launch and
+        no device copy, and returns CPU tensors (the 30 Hz control loop of envs/rllib_env_imitation.py:215-266 hands the
+        action to a CPU simulator anyway).  Same action as the launch path, bit for bit; mu / logvar / z come with it;
+        the world model's prediction and the value estimate stay lazy (launches, on first read).  The resident copy of
+        the weights follows `load_state_dict` / `load_weights*`; after optimizer steps call `reload_rollout_server()`.
+        Raises RuntimeError when the stacks do not fit a CU's LDS (4x1024): the launch path stays in use."""
+        self.engine.rollout_server_start(idle_ms=idle_ms, lifetime_s=lifetime_s)
+        self.__dict__["_srv_on"] = True
+        self.__dict__["_srv_reload"] = False
+
+    def stop_rollout_server(self):
+        self.__dict__["_srv_on"] = False
+        self.engine.rollout_server_stop()
+
+    def reload_rollout_server(self):
+        """The parameters changed (optimizer step, direct write): the next served forward re-reads them into LDS."""
+        self.__dict__["_srv_reload"] = True
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.__dict__["_srv_reload"] = True          # (submodule loads -- load_weights_task_encoder etc. -- set it as well)
+        return out
+
+    def _forward_served(self, obs, state, noise):
+        eng, st = self.engine, self._st
+        st._rng_calls += 1
+        d = self.__dict__
+        a, ml, z = eng.rollout_server_infer(obs, noise=noise, seed=self._rng_seed, offset=st._rng_calls,
+                                            reload=d.get("_srv_reload", False))
+        d["_srv_reload"] = False
+        Da, Z = self.dim_action, self._task_encoder_output_dim
+        logits = torch.empty(1, 2 * Da)
+        logits[0, :Da] = torch.from_numpy(a)
+        logits[0, Da:] = d["_als"].log_std.detach().cpu().reshape(-1)       # (a host tensor already when "constant")
+        st._cur_future_state = None
+        st._cur_body_encoder_variable = obs[..., : self.dim_state_body]
+        st._cur_task_encoder_variable = torch.from_numpy(z.copy())[None]
+        keep = obs.clone()
+        st._lazy = (keep, 1, None, noise, st._rng_calls) if self.rollout_predicts_state == "lazy" else (keep, 1)
+        st._cur_value = None
+        if self._latent_prior_type is False:
+            st._mu, st._logvar = st._cur_task_encoder_variable, None
+        else:
+            st._mu, st._logvar = torch.from_numpy(ml[:Z].copy())[None], torch.from_numpy(ml[Z:].copy())[None]
+        st._cur_latent_prior_mu = None
         return logits, state
 
     def _forward_staged(self, obs, state, seq_lens, eps=None):
@@ -553,6 +606,7 @@ class PhysicsVAE(nn.Module):
     def load_weights_task_encoder(self, file):
         self._task_encoder.load_state_dict(torch.load(file, map_location="cpu")["task_encoder"])
         self._task_encoder.eval()
+        self.__dict__["_srv_reload"] = True
 
     def save_weights_motor_decoder(self, file):
         torch.save(_portable(self._motor_decoder.state_dict()), file)
@@ -565,6 +619,7 @@ class PhysicsVAE(nn.Module):
                 loaded[key] = current[key]
         self._motor_decoder.load_state_dict(loaded)
         self._motor_decoder.eval()
+        self.__dict__["_srv_reload"] = True
 
     def save_weights_world_model(self, file):
         torch.save(_portable(self._world_model.state_dict()), file)

@@ -166,12 +166,32 @@ def _replicas_identical(self, engine):
     return int(hi.item()) == int(lo.item())
 
 
+def _all_agree(self, engine, ok):
+    """True iff `ok` holds on EVERY rank (MIN over the ranks): the outcome all of them act on."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=engine.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+    return int(flag.item()) == 1
+
+
+def _p2p_timeouts(self, engine):
+    """Waits of the peer-mapped exchange that gave up, MAX over the ranks (a time-out on one rank concerns all)."""
+    bad = torch.tensor([engine.p2p_status()[2] if engine.has_p2p else 0], dtype=torch.int64, device=engine.device)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+    return int(bad.item())
+
+
 def _autotune_exchange(self, engine, run_steps, steps=24, warm=6, forms=EXCHANGE_FORMS):
     """Choose the exchange form by measurement: under every form available here, `run_steps(n)` (n data-parallel
     optimizer steps, supplied by the caller) is timed from the SAME starting state -- parameters and Adam moments are
     snapshotted first and restored after every candidate and at the end, so the calibration leaves no trace --, the
     time is the maximum over the ranks (so every rank takes the same decision), and a candidate only counts if the
-    replicas are bit-identical after its steps and no peer wait gave up.  -> (chosen form | None, report)."""
+    replicas are bit-identical after its steps and no peer wait gave up.  -> (chosen form | None, report).
+
+    Every decision is collective: whether a candidate ran through is agreed with a MIN over the ranks OUTSIDE the
+    try blocks (a rank that raised locally still takes part, so nobody is left inside a barrier), and a candidate of
+    the peer-mapped forms that failed or timed out is torn down on every rank -- error word cleared, peers unmapped --
+    so that the next attach starts from zeroed flags and epochs (a half-finished sequence leaves the ranks' exchange
+    epochs apart, and the waits compare with >=)."""
     import time
     snap = [t.clone() for t in (engine.params, engine.exp_avg, engine.exp_avg_sq)]
 
@@ -184,6 +204,25 @@ def _autotune_exchange(self, engine, run_steps, steps=24, warm=6, forms=EXCHANGE
         if torch.device(engine.device).type == "cuda":
             torch.cuda.synchronize(engine.device)
 
+    def attempt(n):
+        """`run_steps(n)` + device sync on this rank; -> error text or None.  Never raises."""
+        try:
+            run_steps(n)
+            sync()
+            return None
+        except Exception as exc:                                   # noqa: BLE001
+            return str(exc)[:300]
+
+    def drop(form):
+        """A failed candidate leaves nothing behind (collective: every rank calls it)."""
+        if form in ("p2p", "p2p_push") and engine.has_p2p:
+            try:
+                sync()
+            except Exception:                                      # noqa: BLE001
+                pass
+            engine.p2p_clear_errors()
+            engine.p2p_close()
+
     report, best = {}, None
     for form in forms:
         why = self.set_exchange_form(engine, form)
@@ -191,31 +230,40 @@ def _autotune_exchange(self, engine, run_steps, steps=24, warm=6, forms=EXCHANGE
             report[form] = {"skipped": why}
             continue
         restore()
-        try:
-            run_steps(warm)
-            sync()
-            dist.barrier(group=self.group)
-            t0 = time.perf_counter()
-            run_steps(steps)
-            sync()
-            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=engine.device)
-            dist.all_reduce(dt, op=dist.ReduceOp.MAX, group=self.group)
-            ok = self.replicas_identical(engine)
-            bad = torch.tensor([engine.p2p_status()[2] if engine.has_p2p and form.startswith("p2p") else 0],
-                               dtype=torch.int64, device=engine.device)
-            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
-            report[form] = {"us_per_step": float(dt.item()) / steps * 1e6, "replicas_identical": ok,
-                            "peer_wait_timeouts": int(bad.item())}
-            if ok and int(bad.item()) == 0 and (best is None or report[form]["us_per_step"] < report[best]["us_per_step"]):
-                best = form
-        except Exception as exc:                                   # noqa: BLE001
-            report[form] = {"error": str(exc)[:300]}
+        err = attempt(warm)
+        if not self.all_agree(engine, err is None):
+            report[form] = {"error": err or "another rank failed during the warm-up steps"}
+            drop(form)
+            continue
+        dist.barrier(group=self.group)
+        t0 = time.perf_counter()
+        err = attempt(steps)
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=engine.device)
+        if not self.all_agree(engine, err is None):
+            report[form] = {"error": err or "another rank failed during the timed steps"}
+            drop(form)
+            continue
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX, group=self.group)
+        ok = self.replicas_identical(engine)
+        bad = self.p2p_timeouts(engine) if form.startswith("p2p") else 0
+        report[form] = {"us_per_step": float(dt.item()) / steps * 1e6, "replicas_identical": ok, "peer_wait_timeouts": bad}
+        if bad or not ok:
+            drop(form)
+        elif best is None or report[form]["us_per_step"] < report[best]["us_per_step"]:
+            best = form
     restore()
     if best is not None:
-        self.set_exchange_form(engine, best)
+        why = self.set_exchange_form(engine, best)           # (re-attaches the peers if a later candidate's failure unmapped them)
+        if why:
+            report[best]["error"] = "could not be selected again: " + why
+            best = None
+    if engine.has_p2p:
+        engine.p2p_clear_errors()                            # nothing a rejected candidate left behind may fail the first epoch
     return best, report
 
 
+DataParallel.all_agree = _all_agree
+DataParallel.p2p_timeouts = _p2p_timeouts
 DataParallel.set_exchange_form = _set_exchange_form
 DataParallel.replicas_identical = _replicas_identical
 DataParallel.autotune_exchange = _autotune_exchange

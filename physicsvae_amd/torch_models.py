@@ -173,13 +173,21 @@ class TrainModel(tune.Trainable):
         #   "sharded"  RCCL reduce-scatter -> Adam on the owned 1/N slice -> all-gather of the parameters
         #   "p2p"      the sharded shape as ONE launch per stack over peer-mapped arenas, no RCCL (include/pvae.h);
         #   "p2p_push" the same with remote writes only (contributions pushed into the slice owners' staging buffers)
-        #   unset      the library's default schedule
-        #   "auto"     measured: the first training epoch times every available form on its first minibatch (state
-        #              snapshotted and restored, parallel.DataParallel.autotune_exchange) and keeps the fastest
+        #   "default"  the library's own schedule, chosen by arithmetic
+        #   "auto"     measured: the first training epoch of EACH phase times every available form on its first minibatch
+        #              (state snapshotted and restored, parallel.DataParallel.autotune_exchange) and keeps the fastest
+        #              whose replicas stay bit-identical.  What an unset key means with more than one rank (round 4;
+        #              before: "default").
         self.dp_exchange = config.get("dp_exchange", os.environ.get("PVAE_DP_EXCHANGE")) or None
+        if self.dp_exchange is None and self.dp.world > 1:
+            self.dp_exchange = "auto"
+        if self.dp_exchange == "default":
+            self.dp_exchange = None
         if self.dp_exchange not in (None, "inline", "bucketed", "sharded", "p2p", "p2p_push", "auto"):
-            raise ValueError("dp_exchange %r: expected inline / bucketed / sharded / p2p / p2p_push / auto" % (self.dp_exchange,))
-        self.dp_exchange_report = None
+            raise ValueError("dp_exchange %r: expected default / inline / bucketed / sharded / p2p / p2p_push / auto" % (self.dp_exchange,))
+        self.dp_exchange_report = None            # the calibration of the phase being trained (None: not run yet)
+        self.dp_exchange_reports = {}             # {phase: report}
+        self._replicas_checked = set()            # phases whose first epoch has been followed by the replica check
         if self.dp_exchange == "auto":
             self.dp.attach(self.engine)               # RCCL when the backend offers it; the peer-mapped forms join at calibration
         elif self.dp_exchange in ("p2p", "p2p_push"):
@@ -253,7 +261,9 @@ class TrainModel(tune.Trainable):
         phase, nets = self.phase()
         eng.bind_dataset(*loader.dataset.device_arrays(eng.device))
         n_glob = dp.global_steps(len(loader.dataset), loader.batch_size)
-        if train and dp.collective and self.dp_exchange == "auto" and self.dp_exchange_report is None:
+        if train and dp.collective and self.dp_exchange == "auto" and phase not in self.dp_exchange_reports:
+            # (per phase: the world phase trains one stack and has nothing to overlap an exchange with, the joint phase
+            #  two or three -- the form and bucketing that win need not be the same)
             self._autotune_exchange(loader, phase, nets)
         out = torch.zeros(max(n_glob, 1), 5, dtype=torch.float32, device=eng.device)
         for g in range(n_glob):
@@ -291,9 +301,21 @@ class TrainModel(tune.Trainable):
         if dp.collective:
             dp.all_reduce(out)
         host = out[:n_glob].cpu()                 # the single host sync of the epoch
-        if eng.has_p2p and eng.p2p_status()[2]:
-            raise RuntimeError("peer-mapped exchange: a rank waited for a peer that never signalled (time-out); "
-                               "parameters are no longer consistent")
+        if dp.collective and eng.p2p_active:
+            # only while a peer-mapped form is what runs (a rejected calibration candidate leaves nothing behind:
+            # autotune_exchange clears the word), and collectively: a wait that gave up on ONE rank aborted that rank's
+            # part of the exchange, so every rank's parameters are suspect and every rank must stop
+            bad = dp.p2p_timeouts(eng)
+            if bad:
+                raise RuntimeError("peer-mapped exchange: %d wait(s) for a peer gave up (time-out) on some rank; that "
+                                   "rank's update was skipped and the replicas are no longer consistent" % bad)
+        if train and dp.collective and dp.world > 1 and eng.in_library_exchange and phase not in self._replicas_checked:
+            # once per phase, after its first epoch, whatever chose the exchange form (an explicit dp_exchange = p2p
+            # never went through the calibration's check): two checksum all-reduces
+            self._replicas_checked.add(phase)
+            if not dp.replicas_identical(eng):
+                raise RuntimeError("data-parallel replicas hold different parameters after the first epoch of phase %d "
+                                   "(exchange %s)" % (phase, self.dp_exchange or "default"))
         return host
 
     def _autotune_exchange(self, loader, phase, nets):
@@ -313,6 +335,7 @@ class TrainModel(tune.Trainable):
 
         counts = dict(self.optimizer.net_steps)            # (step_params advances Adam's per-stack step counters)
         chosen, self.dp_exchange_report = dp.autotune_exchange(eng, run)
+        self.dp_exchange_reports[phase] = self.dp_exchange_report
         self.optimizer.net_steps.clear()
         self.optimizer.net_steps.update(counts)
         self.dp_exchange_chosen = chosen

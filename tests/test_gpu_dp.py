@@ -41,6 +41,9 @@ def _run(tmp_path, world, per_gpu, tag, **extra_env):
     script = tmp_path / "dp_worker.py"
     script.write_text(WORKER)
     out = str(tmp_path / tag)
+    # (with more than one rank an unset dp_exchange means "auto" since round 4 -- on this box that would pick a
+    #  peer-mapped form; these tests are about the torch.distributed transport and the library's own schedule)
+    extra_env.setdefault("PVAE_DP_EXCHANGE", "default")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", WORLD_SIZE=str(world), **extra_env)
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, out, str(per_gpu)],
                               env=dict(env, RANK=str(r), LOCAL_RANK="0"),

@@ -42,7 +42,8 @@ if mode == "train":
     losses = [tr.train()["mean_train_loss"] for _ in range(2)]
     res = {"sd": {k: v.cpu() for k, v in tr.model.state_dict().items()}, "losses": losses,
            "steps": dict(tr.optimizer.net_steps), "timeouts": eng.p2p_status()[2] if eng.has_p2p else 0,
-           "report": {"chosen": getattr(tr, "dp_exchange_chosen", None), "candidates": tr.dp_exchange_report}}
+           "report": {"chosen": getattr(tr, "dp_exchange_chosen", None), "candidates": tr.dp_exchange_report},
+           "phases_calibrated": list(tr.dp_exchange_reports), "replica_checks": sorted(tr._replicas_checked)}
 elif mode == "kernel":
     # the exchange launch itself: known gradients per rank, slice owners sum in RANK ORDER, Adam, push
     assert eng.has_p2p
@@ -159,7 +160,7 @@ def test_p2p_two_ranks_equal_the_allreduce_exchange_bit_for_bit(tmp_path, form):
     ranks every sum is g0 + g1 whoever forms it).  Both forms: owners PULL their slice from the peers' gradient arenas,
     or every rank PUSHES its contributions into the owners' staging buffers (remote writes only)."""
     p2p = _run(tmp_path, 2, 16, "p2p", PVAE_DP_EXCHANGE=form)
-    plain = _run(tmp_path, 2, 16, "plain", port="29562")
+    plain = _run(tmp_path, 2, 16, "plain", port="29562", PVAE_DP_EXCHANGE="default")
     a, b = p2p
     assert a["timeouts"] == 0 and b["timeouts"] == 0
     for k in a["sd"]:
@@ -209,6 +210,24 @@ def test_exchange_chosen_by_measurement_leaves_no_trace(tmp_path):
     assert all(rep["candidates"][f]["replicas_identical"] and rep["candidates"][f]["us_per_step"] > 0 for f in ("p2p", "p2p_push"))
 
 
+def test_unset_dp_exchange_means_auto_and_calibrates_each_phase(tmp_path):
+    """With more than one rank an unset `dp_exchange` IS "auto" (round 4): the first epoch of the world phase and the
+    first epoch of the joint phase each calibrate (the phases have different amounts of work to hide an exchange
+    behind), the run equals the hand-chosen form bit for bit, and the replicas are checked after each phase's first
+    epoch whatever chose the form."""
+    if "PVAE_DP_EXCHANGE" in os.environ:
+        pytest.skip("PVAE_DP_EXCHANGE is set in the environment")
+    auto = _run(tmp_path, 2, 16, "unset", port="29586")
+    hand = _run(tmp_path, 2, 16, "hand2", port="29587", PVAE_DP_EXCHANGE="p2p")
+    assert all(r["timeouts"] == 0 for r in auto)
+    assert auto[0]["report"]["chosen"] in ("p2p", "p2p_push") and sorted(auto[0]["phases_calibrated"]) == [0, 1]
+    assert auto[0]["replica_checks"] == [0, 1] and hand[0]["replica_checks"] == [0, 1]
+    for k in auto[0]["sd"]:
+        assert torch.equal(auto[0]["sd"][k], auto[1]["sd"][k]), k
+        assert torch.equal(auto[0]["sd"][k], hand[0]["sd"][k]), k
+    assert auto[0]["losses"] == hand[0]["losses"]
+
+
 @pytest.mark.parametrize("stop", [1, 2])
 def test_trainer_state_resume_under_the_peer_mapped_exchange(tmp_path, stop):
     """Under the sharded / peer-mapped exchanges a rank keeps Adam moments for its own slices only, so
@@ -231,7 +250,7 @@ def test_p2p_with_a_lookahead_unroll(tmp_path):
     """lookahead 2 (stacked time steps, weight gradients paired with step 0's input-gradient launches) under the
     peer-mapped exchange: replicas bit-identical and equal to the all-reduce exchange of the same schedule."""
     p2p = _run(tmp_path, 2, 16, "p2pL2", PVAE_DP_EXCHANGE="p2p", P2P_TEST_LOOKAHEAD="2")
-    plain = _run(tmp_path, 2, 16, "plainL2", port="29567", P2P_TEST_LOOKAHEAD="2")
+    plain = _run(tmp_path, 2, 16, "plainL2", port="29567", P2P_TEST_LOOKAHEAD="2", PVAE_DP_EXCHANGE="default")
     assert all(r["timeouts"] == 0 for r in p2p)
     for k in p2p[0]["sd"]:
         assert torch.equal(p2p[0]["sd"][k], p2p[1]["sd"][k]), k

@@ -1,0 +1,204 @@
+"""The call-persistent rollout server (include/pvae.h pvae_rollout_server_*): one kernel resident on
+one XCD with the encoder's and decoder's weights in LDS, a mailbox in pinned host memory, zero launches per call.
+What it replaces is PhysicsVAE.forward at B = 1 (rmt:742-771; callers envs/rllib_env_imitation.py:215-266), so every
+check is against the per-layer launch path `pvae_infer`, bit for bit.
+
+Every test stops the server before it returns (a resident kernel makes device-wide synchronisations wait for it) and
+uses a short idle time-out, so that even a failing assertion cannot leave the GPU occupied for long."""
+import contextlib
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import refpath as R
+from physicsvae_amd import _lib
+from physicsvae_amd.engine import make_step_params
+from util import make_trainer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@contextlib.contextmanager
+def served(eng, idle_ms=200.0, lifetime_s=30.0):
+    eng.rollout_server_start(idle_ms=idle_ms, lifetime_s=lifetime_s)
+    try:
+        yield eng
+    finally:
+        eng.rollout_server_stop()
+
+
+def _default_trainer(batch=8, seed=1):
+    arch = R.make_arch(197, 45)                    # DEFAULT_CONFIG stacks: TE 2x256, MD 3x512 (3.4 MB of weights)
+    data = R.synth_demo(0, 2, 40, 197, 45, kind="dynamics")
+    tr = make_trainer(arch, data, batch, device=DEV)
+    tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, seed=seed), seed=3))
+    X, _ = R.build_windows(data)
+    obs = torch.from_numpy(np.asarray(X)).float()[:, 0, :]        # [N, 2 Db]
+    return arch, tr, obs
+
+
+@pytest.mark.parametrize("noise", [False, True])
+def test_server_equals_the_launch_path_bit_for_bit(noise):
+    arch, tr, obs = _default_trainer()
+    eng = tr.engine
+    with served(eng):
+        serving, _, lds = eng.rollout_server_status()
+        assert serving and 64 * 1024 < lds <= 156 * 1024
+        for i in range(12):
+            o = obs[i]
+            a, ml, z = (x.copy() for x in eng.rollout_server_infer(o.numpy(), noise=noise, seed=11, offset=1000 + i))
+            want_a, _, want_z = eng.infer(o[None].to(DEV), noise=noise, seed=11, offset=1000 + i, want_s2=False)
+            assert np.array_equal(a, want_a.cpu().numpy()[0]), i
+            assert np.array_equal(z, want_z.cpu().numpy()[0]), i
+            assert np.array_equal(ml[: arch["Z"]], eng.read("mu", 1).cpu().numpy()[0]), i
+            assert np.array_equal(ml[arch["Z"]:], eng.read("logvar", 1).cpu().numpy()[0]), i
+            if not noise:
+                assert np.array_equal(z, ml[: arch["Z"]])             # z = mu (latent_prior_noise False)
+        assert eng.rollout_server_status()[1] == 12
+    assert eng.rollout_server_status()[0] is False
+    # and the action is the model's: against the oracle's forward at 2e-5 (as every rollout test)
+    sd = {k: v.detach().cpu() for k, v in tr.model.state_dict().items()}
+    m = R.RefModel(arch)
+    m.load_state_dict(sd)
+    m.eps_source = lambda shape: torch.zeros(shape)
+    with torch.no_grad():
+        logits = m(obs[:1])
+    with served(eng):
+        a, _, _ = eng.rollout_server_infer(obs[0].numpy(), noise=False)
+        assert np.abs(a - logits[0, : arch["Da"]].numpy()).max() <= 2e-5 * max(1.0, float(logits.abs().max()))
+
+
+def test_server_follows_the_weights_on_reload_and_after_a_restart():
+    arch, tr, obs = _default_trainer()
+    eng = tr.engine
+    o = obs[3].numpy()
+    with served(eng, idle_ms=3000.0):
+        before = eng.rollout_server_infer(o, noise=False)[0].copy()
+        # an optimizer step moves the decoder: the resident copy in LDS is stale until told
+        sp = make_step_params(lr=5e-3, global_rows=8)
+        eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
+        tr.model.set_learnable_task_encoder(True)
+        tr.model.set_learnable_motor_decoder(True)
+        tr.model.set_learnable_world_model(False)
+        eng.train_step(_lib.PHASE_JOINT, 0, 8, sp)
+        torch.cuda.current_stream().synchronize()
+        want = eng.infer(torch.from_numpy(o)[None].to(DEV), noise=False, want_s2=False)[0].cpu().numpy()[0]
+        assert not np.array_equal(want, before)
+        assert np.array_equal(eng.rollout_server_infer(o, noise=False)[0], before)          # still the old weights
+        assert np.array_equal(eng.rollout_server_infer(o, noise=False, reload=True)[0], want)
+        assert np.array_equal(eng.rollout_server_infer(o, noise=False)[0], want)            # and they stay
+    # idle time-out: the kernel leaves by itself, the next call brings it back (weights read from the arena again)
+    with served(eng, idle_ms=30.0):
+        assert np.array_equal(eng.rollout_server_infer(o, noise=False)[0], want)
+        time.sleep(0.3)
+        assert eng.rollout_server_status()[0] is False
+        assert np.array_equal(eng.rollout_server_infer(o, noise=False)[0], want)
+        assert eng.rollout_server_status()[0] is True
+        served_before = eng.rollout_server_status()[1]
+        for i in range(5):
+            eng.rollout_server_infer(obs[i].numpy(), noise=True, seed=3, offset=i)
+        assert eng.rollout_server_status()[1] == served_before + 5
+
+
+def test_module_forward_served_equals_module_forward_launched():
+    """PhysicsVAE.forward (rmt:742-771) with a one-row CPU observation, served by the resident kernel, against the same
+    module's launch path: logits [a_hat | log_std], z, mu / logvar bit-identical; the lazily evaluated prediction and
+    value estimate agree; `load_state_dict` reaches the resident copy of the weights."""
+    arch, tr, obs = _default_trainer()
+    m = tr.model
+    m.eval()
+    m.set_exploration_std(0.2)
+
+    def call(o):
+        with torch.no_grad():
+            logits, _ = m.forward({"obs_flat": o}, [], None)
+            return (logits.cpu().clone(), m.task_encoder_variable().cpu().clone(), m._cur_task_encoder_mu.cpu().clone(),
+                    m._cur_task_encoder_logvar.cpu().clone(), m._cur_future_state.cpu().clone(), m.value_function().cpu().clone())
+    for noise in (False, True):
+        m.latent_prior_noise = noise
+        m._st._rng_calls = 100
+        want = [call(obs[i:i + 1].to(DEV)) for i in range(4)]
+        m.start_rollout_server(idle_ms=2000.0, lifetime_s=30.0)
+        try:
+            m._st._rng_calls = 100
+            got = [call(obs[i:i + 1]) for i in range(4)]
+        finally:
+            m.stop_rollout_server()
+        for w, g in zip(want, got):
+            for a, b in zip(w, g):
+                assert torch.equal(a, b)
+    # new weights through the module API reach the kernel's LDS copy
+    sd2 = R.perturb_biases(R.init_state_dict(arch, seed=9), seed=4)
+    m.latent_prior_noise = False
+    m.start_rollout_server(idle_ms=2000.0, lifetime_s=30.0)
+    try:
+        first = call(obs[:1])[0]
+        m.load_state_dict(sd2)
+        second = call(obs[:1])[0]
+    finally:
+        m.stop_rollout_server()
+    assert not torch.equal(first, second)
+    assert torch.equal(second, call(obs[:1].to(DEV))[0])
+
+
+def test_server_coexists_with_launches_on_the_compute_stream():
+    """Training steps and per-layer rollout launches run while the server is resident (its stream has a hardware queue
+    of its own; the other XCDs' CUs are free), and requests are answered in between."""
+    arch, tr, obs = _default_trainer()
+    eng = tr.engine
+    eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
+    sp = make_step_params(lr=5e-4, global_rows=8, s_rec=1.0, a_rec=0.0, kl=0.0, cyc=0.0)
+    with served(eng, idle_ms=500.0):
+        t0 = time.perf_counter()
+        for i in range(20):
+            eng.train_step(_lib.PHASE_WORLD, 0, 8, sp)                  # world phase: encoder / decoder untouched
+            a = eng.rollout_server_infer(obs[i].numpy(), noise=False)[0].copy()
+            want = eng.infer(obs[i][None].to(DEV), noise=False, want_s2=False)[0]
+            torch.cuda.current_stream().synchronize()
+            assert np.array_equal(a, want.cpu().numpy()[0]), i
+        assert time.perf_counter() - t0 < 5.0                           # nothing waited for an idle time-out
+
+
+def test_server_refuses_stacks_that_do_not_fit_and_the_launch_path_stays():
+    arch = R.make_arch(197, 45, latent=32, te=(1024, 4), md=(1024, 4), wm=(1024, 4))
+    data = R.synth_demo(0, 2, 20, 197, 45, kind="iid")
+    tr = make_trainer(arch, data, 8, device=DEV)
+    eng = tr.engine
+    with pytest.raises(RuntimeError, match="LDS"):
+        eng.rollout_server_start()
+    assert eng.rollout_server_status()[0] is False
+    with pytest.raises(RuntimeError, match="not started"):
+        eng.rollout_server_infer(np.zeros(394, np.float32))
+    X, _ = R.build_windows(data)
+    o = torch.from_numpy(np.asarray(X)).float()[:1, 0, :].to(DEV)
+    assert torch.isfinite(eng.infer(o, noise=False)[0]).all()
+
+
+def test_server_latency_is_below_the_launch_path():
+    """Host observation -> host action at B = 1: the server against `infer_host` (7 launches, kernels reading / writing
+    pinned host memory).  Medians over 300 calls each; the server must be clearly faster (the figure itself is
+    measured by tools/infer_latency.py and committed under profiles/)."""
+    arch, tr, obs = _default_trainer()
+    eng = tr.engine
+    o = obs[0].numpy()
+    for _ in range(20):
+        eng.infer_host(o[None], noise=True, seed=1, offset=5)
+    t_launch = []
+    for i in range(300):
+        t0 = time.perf_counter()
+        eng.infer_host(o[None], noise=True, seed=1, offset=i)
+        t_launch.append(time.perf_counter() - t0)
+    with served(eng):
+        for _ in range(20):
+            eng.rollout_server_infer(o, noise=True, seed=1, offset=5)
+        t_srv = []
+        for i in range(300):
+            t0 = time.perf_counter()
+            eng.rollout_server_infer(o, noise=True, seed=1, offset=i)
+            t_srv.append(time.perf_counter() - t0)
+    med_l, med_s = np.median(t_launch) * 1e6, np.median(t_srv) * 1e6
+    print("host -> host: launches %.1f us, server %.1f us" % (med_l, med_s))
+    assert med_s < 0.8 * med_l, (med_l, med_s)

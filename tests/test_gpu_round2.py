@@ -42,6 +42,12 @@ def test_bench_plain_two_ranks_self_launch():
         assert d["ranks_share_a_gpu"] is False and d["rccl_ranks"] == 2
         assert d["allreduce_us_per_step"] > 0
     assert "roofline" in d and 0 < d["roofline"]["frac"] < 1
+    # the N-rank step against ONE process with the global batch (three optimizer steps from a common state): what a
+    # stale read of peer-written parameters could not pass while the replicas stay bit-identical
+    ref = d["single_process_reference"]
+    assert d["matches_single_process"] is True and d["replicas_identical"] is True, ref
+    assert ref["steps"] == 3 and ref["global_batch"] == 512 and ref["max_rel_loss_diff"] < 2e-4 and ref["update_rel_l2_diff"] < 2e-2
+    assert ref["losses_n_ranks"][0] != ref["losses_n_ranks"][1]                 # the steps really trained
     # every exchange form, back to back in the same run (what a multi-GPU lease must yield in one go)
     sweep = d["exchange_sweep"]
     assert set(sweep) == {"inline", "bucketed", "sharded", "p2p", "p2p_push", "local"}
@@ -71,7 +77,7 @@ def test_bench_under_the_launcher_command_of_the_scaling_run():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 3 and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 512 and d["value"] > 0 and np.isfinite(d["last_loss"])
-    assert d["replicas_identical"] is True
+    assert d["replicas_identical"] is True and d["matches_single_process"] is True, d.get("single_process_reference")
     assert d["ranks_share_a_gpu"] is (torch.cuda.device_count() < 2)
     assert d["exchange_autotune"]["chosen"] in ("inline", "bucketed", "sharded", "p2p", "p2p_push")
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pvae_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.pvae_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_layout_queries_without_gpu():
@@ -347,31 +347,41 @@ rank, world, _ = parallel.init_from_env(backend="gloo")
 
 class Engine:                                   # what autotune_exchange touches of an engine, on the CPU
     device = torch.device("cpu")
-    has_p2p = False
     def __init__(self):
         self.params, self.exp_avg, self.exp_avg_sq = torch.arange(8.), torch.zeros(8), torch.ones(8)
-        self.form = None
+        self.form, self.has_p2p, self.closed, self.cleared = None, False, 0, 0
     def invalidate_staging(self): pass
     def p2p_status(self): return (0, 0, 0)
+    def p2p_close(self): self.has_p2p = False; self.closed += 1
+    def p2p_clear_errors(self): self.cleared += 1
 
 class DP(parallel.DataParallel):                # three "forms": fast everywhere / slow on rank 1 / breaks the replicas
     def set_exchange_form(self, engine, form):
         if form == "bucketed":
             return "not here"
         engine.form = form
+        if form.startswith("p2p"):
+            engine.has_p2p = True                # (attach_p2p maps the peers again after a close)
         return None
 
 eng, dp = Engine(), DP(rank, world)
-cost = {"inline": (0.004, 0.004), "sharded": (0.001, 0.012), "p2p": (0.0005, 0.0005), "p2p_push": (0.002, 0.003)}
+cost = {"inline": (0.012, 0.012), "sharded": (0.001, 0.012), "p2p": (0.0005, 0.0005), "p2p_push": (0.002, 0.003)}
 def run_steps(n):
-    for _ in range(n):
+    for i in range(n):
+        if eng.form == "sharded" and rank == 1 and n > 1 and i == 2:
+            raise RuntimeError("boom on rank 1 only")                        # a rank-local failure in the timed steps
         time.sleep(cost[eng.form][rank])
         eng.params += 1.0 if eng.form != "p2p" else float(rank + 1)          # "p2p" lets the replicas drift apart
         eng.exp_avg += 0.5
 chosen, report = dp.autotune_exchange(eng, run_steps, steps=5, warm=1)
 assert chosen == "p2p_push", (chosen, report)                                # fastest by the SLOWEST rank among the valid ones
 assert report["bucketed"] == {"skipped": "not here"} and report["p2p"]["replicas_identical"] is False
-assert report["sharded"]["us_per_step"] > report["inline"]["us_per_step"] > report["p2p_push"]["us_per_step"]
+assert report["inline"]["us_per_step"] > report["p2p_push"]["us_per_step"]
+# the rank-local failure is agreed on by BOTH ranks (nobody is left waiting in a barrier), the candidate is dropped
+assert "error" in report["sharded"] and ("boom" in report["sharded"]["error"]) == (rank == 1), report["sharded"]
+# the peer-mapped candidate whose replicas diverged was torn down (error word cleared, peers unmapped) and the winner
+# attached again from clean flags
+assert eng.closed == 1 and eng.cleared >= 2 and eng.has_p2p
 assert torch.equal(eng.params, torch.arange(8.)) and torch.equal(eng.exp_avg, torch.zeros(8))   # state restored
 assert eng.form == "p2p_push"
 dist.barrier()
@@ -381,8 +391,9 @@ print("OK", rank)
 
 def test_exchange_autotune_decides_alike_on_every_rank_gloo_world2(tmp_path):
     """`DataParallel.autotune_exchange` with two gloo ranks and a stand-in engine: forms that are unavailable are
-    skipped, a form whose replicas diverge is disqualified, the slowest rank's time decides (so both ranks choose
-    the same form), and the snapshot of parameters and moments is restored."""
+    skipped, a form whose replicas diverge is disqualified and torn down, a failure on ONE rank drops the candidate on
+    both without a hang, the slowest rank's time decides (so both ranks choose the same form), and the snapshot of
+    parameters and moments is restored."""
     script = tmp_path / "autotune_worker.py"
     script.write_text(AUTOTUNE_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", WORLD_SIZE="2")

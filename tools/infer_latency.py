@@ -83,6 +83,39 @@ for name, sizes in ((("default 256x2/512x3/1024x2", []),) if QUICK else (("defau
     a_dev = eng.infer(obs_h.cuda(), noise=False, want_s2=False)[0].cpu()
     a_host = eng.infer_host(obs_h, noise=False)
     assert torch.equal(a_dev, a_host), "infer_host disagrees with infer"
+    # the call-persistent rollout server (include/pvae.h pvae_rollout_server_*): a kernel resident on one XCD with the
+    # encoder's and decoder's weights in LDS answers from a mailbox in pinned host memory -- no launch per call
+    try:
+        eng.rollout_server_start(idle_ms=200.0, lifetime_s=60.0)
+    except RuntimeError as exc:
+        print("%-28s rows  1  rollout server: %s" % (name, str(exc).split(":")[-1].strip()[:160]))
+    else:
+        try:
+            o = obs_h.numpy()[0]
+            for i in range(50):
+                eng.rollout_server_infer(o, noise=True, seed=0, offset=i)
+            lat = []
+            for i in range(500):
+                t7 = time.perf_counter()
+                eng.rollout_server_infer(o, noise=True, seed=0, offset=i)
+                lat.append((time.perf_counter() - t7) * 1e6)
+            lat.sort()
+            a_srv = eng.rollout_server_infer(o, noise=False)[0].copy()
+            print("%-28s rows  1  host obs -> host action, rollout server (resident kernel)   : %6.1f us median, %6.1f us p90, "
+                  "%6.1f us min  (LDS %d KB per workgroup)" % (name, lat[len(lat) // 2], lat[int(len(lat) * 0.9)], lat[0],
+                                                              eng.rollout_server_status()[2] // 1024))
+            # a 30 Hz control loop: 33 ms of host work between two calls (the kernel stays resident: idle time-out 200 ms)
+            lat = []
+            for i in range(20):
+                time.sleep(0.033)
+                t7 = time.perf_counter()
+                eng.rollout_server_infer(o, noise=True, seed=0, offset=i)
+                lat.append((time.perf_counter() - t7) * 1e6)
+            lat.sort()
+            print("%-28s rows  1  the same at 30 Hz (33 ms between calls)                      : %6.1f us median" % (name, lat[len(lat) // 2]))
+        finally:
+            eng.rollout_server_stop()
+        assert (a_srv == a_dev.numpy()[0]).all(), "rollout server disagrees with infer"
     # the module surface RLlib drives (rmt:742-771 + value_function): forward alone, and forward + the lazily
     # evaluated value branch (plain torch Linear layers: it takes no part in the supervised path)
     m = tr.model
