@@ -402,8 +402,9 @@ int pvae_infer_logits(pvae_ctx* ctx, const float* obs, int32_t rows, const float
  * Replaces, for the 30 Hz control loop's forward at B = 1, PhysicsVAE.forward (rmt:742-771: task encoder ->
  * sampler rmt:734-740 -> motor decoder; callers envs/rllib_env_imitation.py:215-266) by ZERO launches per call: one
  * kernel stays resident on the 32 CUs of one XCD with the encoder's and the decoder's weights in LDS (1/32 of every
- * layer's output features per workgroup), polls a mailbox in pinned host memory, walks the layers with a barrier in
- * that XCD's L2 between them and writes the action back to the mailbox.  All pointers below are HOST pointers; the
+ * layer's output features per workgroup), polls a mailbox in pinned host memory, walks the layers -- every value handed
+ * from a layer to the next as one tagged 8-byte word that the consumer polls in that XCD's L2, no barrier -- and writes
+ * the action back to the mailbox.  All pointers below are HOST pointers; the
  * calls are plain host functions (no stream, no launch) once the server runs.
  *   pvae_rollout_server_start   plans the LDS layout (-24 with a message when the stacks do not fit 156 KB per
  *                               workgroup, e.g. 4x1024: callers keep using pvae_infer), allocates the mailbox and
@@ -422,6 +423,9 @@ int pvae_rollout_server_start(pvae_ctx* ctx, double idle_timeout_ms, double life
 int pvae_rollout_server_infer(pvae_ctx* ctx, const float* obs, int noise, uint64_t rng_seed, uint64_t rng_offset, int reload,
                               float* a_hat, float* mu_logvar, float* z, double timeout_ms);
 int pvae_rollout_server_stop(pvae_ctx* ctx);
+/* Measurement: n requests back to back with one observation, us[i] = host observation -> host action of request i on the
+ * host's steady clock, taken inside the call (a compiled host's view; tools/infer_latency.py reports it next to Python's). */
+int pvae_rollout_server_selfbench(pvae_ctx* ctx, const float* obs, int noise, int32_t n, double* us);
 int pvae_rollout_server_status(pvae_ctx* ctx, int32_t* serving, uint32_t* served, int32_t* lds_bytes);
 
 /* A stack of Linear layers on CALLER-owned dense row-major weights (W[i]: [n_out[i]][n_in[i]], row stride

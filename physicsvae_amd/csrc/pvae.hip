@@ -218,18 +218,24 @@ static void server_free(pvae_ctx* c);
 
 // Minibatch staging as a launch of its own: one block per (padded) batch row and time step
 // (blockIdx.y = t < L); the work is stage_row (pvae_gemm.h).
-// (four rows per workgroup, one wave each, every source load of a 512-column chunk in flight before the first store:
-//  stage_row_wave; PVAE_GATHER_VEC=1 at build time keeps round 3's stage_row_vec for an A/B)
-#ifndef PVAE_GATHER_VEC
-#define PVAE_GATHER_VEC 0
+// (four rows per workgroup, one wave each.  PVAE_GATHER=2, what runs: the row's sources land in LDS by LDS-DMA and the
+//  panels are written with whole 16-byte stores, stage_row_lds; rows too wide for the wave's LDS, and PVAE_GATHER=1:
+//  stage_row_wave, branch-free dword-granular buffer accesses; PVAE_GATHER=0: round 3's stage_row_vec -- A/B builds)
+#ifndef PVAE_GATHER
+#define PVAE_GATHER 2
 #endif
 __global__ void __launch_bounds__(256) stage_batch_kernel(StageArgs a) {
-    const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // (provably wave-uniform: the row's
-    if (r >= a.rows_pad) return;                                                          //  buffer descriptors live in SGPRs)
-#if PVAE_GATHER_VEC
+    __shared__ float stage_lds[PVAE_GATHER == 2 ? 4 * kStageLdsFloats : 4];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                      // (provably wave-uniform: the row's
+    const int r = blockIdx.x * 4 + w;                                                    //  descriptors / LDS base live in SGPRs)
+    if (r >= a.rows_pad) return;
+#if PVAE_GATHER == 0
     stage_row_vec(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63, 64);
-#else
+#elif PVAE_GATHER == 1
     stage_row_wave(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63);
+#else
+    if (2 * a.Db + a.Da + 64 <= kStageLdsFloats) stage_row_lds(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63, stage_lds + w * kStageLdsFloats);
+    else stage_row_wave(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63);
 #endif
 }
 
@@ -3370,13 +3376,13 @@ static int infer_impl(pvae_ctx* c, const float* obs, int32_t rows, const float* 
 // next call), every spin re-checks an absolute lifetime, and a stop command ends it at once.  While it is resident,
 // a DEVICE-wide synchronisation (hipDeviceSynchronize, hipFree) waits for it -- at most the idle time-out.
 // ---------------------------------------------------------------------------------------
-constexpr int kSrvMaxLayers = 8, kSrvGroups = 32, kSrvMaxObs = 2048, kSrvMaxOut = 1024;
+constexpr int kSrvMaxLayers = 12, kSrvGroups = 32, kSrvMaxObs = 2048, kSrvMaxOut = 1024;
 struct SrvMailbox {                       // pinned host memory, device-mapped
-    // host -> device (one cache line of control words, then the observation)
+    // host -> device: ONE 64-byte line of control words (a single PCIe read delivers all of them), then the observation
     volatile uint32_t req_seq;            // written LAST by the host: request number (0: none yet)
     uint32_t cmd;                         // 0 infer, 1 stop, 2 reload the weights from the arena, then infer
     uint32_t noise, pad0;
-    uint64_t rng_seed, rng_offset;
+    uint32_t seed_lo, seed_hi, off_lo, off_hi;
     uint32_t pad1[8];
     float obs[kSrvMaxObs];
     // device -> host
@@ -3386,39 +3392,59 @@ struct SrvMailbox {                       // pinned host memory, device-mapped
     float out[kSrvMaxOut];                // [a_hat (Da) | mu (Z) | logvar (Z) | z (Z)]
 };
 struct SrvLayer { long long w_off, b_off; int ld, n_out_pad, n_out, act, F, lds_off; };
+constexpr int kSrvActStride = 2048;
 struct SrvArgs {
     SrvLayer layer[kSrvMaxLayers];
     int n_layers, n_te;                   // layers [0, n_te) are the encoder's, the rest the decoder's
     int Db, Da, Z, prior_kind;
     const float* params;
-    float* acts;                          // [n_layers + 1][kSrvActStride]: slot 0 = the observation, slot l + 1 = layer l's output
-    unsigned* sync;                       // device words: 0 barrier counter, 1 go_seq, 2 cmd, 3 noise, 4..7 seed / offset, 8 xcc of group 0, 9 error
+    unsigned long long* acts;             // [n_layers + 1][kSrvActStride] TAGGED values: slot 0 = the observation, slot l + 1 = layer l's output
+    unsigned* sync;                       // device words: 0 start-up barrier, 1 go_seq, 2..8 the request's control words, 16 xcc of group 0, 17 error
     SrvMailbox* mb;
     long long idle_ticks, life_ticks;     // 100 MHz wall clock
     int xs_off;                           // float offset of the input vector inside the dynamic LDS
+    unsigned seq0;                        // requests served by earlier instances (this one answers seq0 + 1, ...)
 };
-constexpr int kSrvActStride = 2048;
-__device__ inline float srv_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // sc1: past the L1
-__device__ inline unsigned srv_ldu(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline unsigned srv_ldu(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // sc1: past the L1
+// A value travels between workgroups as ONE 8-byte word {tag, float bits}: the consumer polls the word itself (sc1 loads,
+// served by the XCD's L2) until it carries the tag of this request and layer -- no barrier between a layer and the next,
+// one L2 round trip after the producer's store has landed.  Tags only grow (request * 16 + layer), so a word left over from
+// an earlier request can never be mistaken.
+__device__ inline void srv_put(unsigned long long* slot, float v, unsigned tag) {
+    __hip_atomic_store(slot, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline float srv_get(const unsigned long long* slot, unsigned tag, long long t_start, long long life, int& failed) {
+    unsigned long long u;
+    unsigned spins = 0;
+    while ((unsigned)((u = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag) {
+        if ((++spins & 255u) == 0 && wall_clock64() - t_start > life) { failed = 1; break; }
+    }
+    return __uint_as_float((unsigned)u);
+}
 
 __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float srv_lds[];
     __shared__ unsigned s_word[8];
+    __shared__ int s_failed;
     if ((blockIdx.x & 7) != 0) return;                    // workgroup b runs on XCD b % 8: the 32 of XCD 0 stay
     const int g = blockIdx.x >> 3, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long t_start = wall_clock64();
     float* xs = srv_lds + a.xs_off;
     unsigned* ctr = a.sync;
-    // placement check: all 32 groups must sit on the XCD of group 0 (the barrier and the hand-overs live in ITS L2)
+    if (tid == 0) s_failed = 0;
+    // placement check: all 32 groups must sit on the XCD of group 0 (the hand-overs live in ITS L2)
     const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;
     if (tid == 0) {
-        if (g == 0) __hip_atomic_store(a.sync + 8, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g == 0) {
+            __hip_atomic_store(a.sync + 1, a.seq0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (go word: nothing new yet)
+            __hip_atomic_store(a.sync + 16, xcc + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
         unsigned x0;
-        while ((x0 = srv_ldu(a.sync + 8)) == 0u) {
+        while ((x0 = srv_ldu(a.sync + 16)) == 0u) {
             if (wall_clock64() - t_start > a.life_ticks) break;
             __builtin_amdgcn_s_sleep(2);
         }
-        if (x0 != xcc + 1u) atomicAdd(a.sync + 9, 1u);
+        if (x0 != xcc + 1u) atomicAdd(a.sync + 17, 1u);
     }
     auto load_weights = [&]() {
         for (int l = 0; l < a.n_layers; ++l) {
@@ -3432,75 +3458,70 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
         __syncthreads();
     };
     load_weights();
-    unsigned round = 0;
     bool alive = true;
-    auto barrier = [&]() {                                // single-XCD L2 barrier; false: gave up (lifetime)
+    {   // start-up barrier in the XCD's L2 (once): everybody placed, checked and loaded
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        ++round;
         if (tid == 0) {
             __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);       // executes in the L2
-            const unsigned want = kSrvGroups * round;
             unsigned ok = 1;
-            while ((int)(srv_ldu(ctr) - want) < 0) {
+            while (srv_ldu(ctr) < (unsigned)kSrvGroups) {
                 if (wall_clock64() - t_start > a.life_ticks) { ok = 0; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
             s_word[7] = ok;
         }
         __syncthreads();
-        return s_word[7] != 0;
-    };
-    if (!barrier()) alive = false;                         // everybody placed, checked and loaded
-    if (alive && srv_ldu(a.sync + 9) != 0u) {              // not on one XCD: refuse (the host falls back to the launches)
+        if (s_word[7] == 0) alive = false;
+    }
+    if (alive && srv_ldu(a.sync + 17) != 0u) {              // not on one XCD: refuse (the host falls back to the launches)
         if (g == 0 && tid == 0) { a.mb->state = 3; __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
         return;
     }
     if (g == 0 && tid == 0 && alive) { a.mb->state = 1; __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
-    unsigned last = 0;
-    while (alive) {
-        // ---- wait for a request: group 0 polls the mailbox, the others the go word in the L2 ----
-        if (tid == 0) {
-            unsigned seq = last, cmd = 1;
-            const long long t_idle = wall_clock64();
-            if (g == 0) {
+    unsigned last = a.seq0;                                // (request numbers keep growing across instances of the kernel:
+    while (alive) {                                        //  the tags of the hand-over words derive from them)
+        // ---- wait for a request: wave 0 of group 0 polls the mailbox's control line, the other groups the go word in the L2 ----
+        if (g == 0) {
+            if (wave == 0) {
+                const long long t_idle = wall_clock64();
+                const unsigned* line = (const unsigned*)&a.mb->req_seq;
+                unsigned w = 0, seq = last, cmd = 1;
                 for (;;) {
-                    seq = __hip_atomic_load(&a.mb->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (seq != last) { cmd = a.mb->cmd; break; }
+                    if (lane < 8) w = __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // one 32-byte read
+                    seq = __builtin_amdgcn_readlane(w, 0);
+                    if (seq != last) { cmd = __builtin_amdgcn_readlane(w, 1); break; }
                     const long long now = wall_clock64();
                     if (now - t_idle > a.idle_ticks || now - t_start > a.life_ticks) { seq = last + 1u; cmd = 1; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                s_word[0] = seq; s_word[1] = cmd;
-                s_word[2] = a.mb->noise;
-                const unsigned long long sd = a.mb->rng_seed, of = a.mb->rng_offset;
-                s_word[3] = (unsigned)sd; s_word[4] = (unsigned)(sd >> 32); s_word[5] = (unsigned)of; s_word[6] = (unsigned)(of >> 32);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                if (lane == 0) { s_word[0] = seq; s_word[1] = cmd; }
+                if (lane >= 2 && lane < 8) s_word[lane] = w;                   // noise, pad, seed lo / hi, offset lo / hi
+                // release the other groups at once (they start polling the observation's words)
+                if (lane >= 1 && lane < 8)
+                    __hip_atomic_store(a.sync + 1 + lane, lane == 1 ? cmd : w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(a.sync + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
-        }
-        if (g == 0) {
             __syncthreads();
-            if (s_word[1] != 1u) {                         // the observation: pinned host memory -> slot 0 (device)
+            if (s_word[1] != 1u) {                         // the observation: pinned host memory -> slot 0, tagged
+                const unsigned tag0 = s_word[0] * 16u;
                 const int n = 2 * a.Db;
                 for (int i = tid; i < n; i += 256)
-                    a.acts[i] = __hip_atomic_load(a.mb->obs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                for (int i = 1; i < 7; ++i) __hip_atomic_store(a.sync + 1 + i, s_word[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(a.sync + 1, s_word[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    srv_put(a.acts + i, __hip_atomic_load(a.mb->obs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), tag0);
             }
         } else {
             if (tid == 0) {
                 unsigned seq;
                 while ((seq = srv_ldu(a.sync + 1)) == last) {
-                    if (wall_clock64() - t_start > a.life_ticks + 100000000ll) { seq = last + 1u; s_word[1] = 1; break; }   // (group 0 is gone)
-                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - t_start > a.life_ticks + 100000000ll) { seq = last + 1u; break; }   // (group 0 is gone)
+                    __builtin_amdgcn_s_sleep(1);
                 }
                 s_word[0] = seq;
+                s_word[1] = 1;
                 if (seq == srv_ldu(a.sync + 1))
-                    for (int i = 1; i < 7; ++i) s_word[i] = srv_ldu(a.sync + 1 + i);
+                    for (int i = 1; i < 8; ++i) s_word[i] = srv_ldu(a.sync + 1 + i);
             }
         }
         __syncthreads();
@@ -3509,23 +3530,27 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
         if (cmd == 1u) break;
         if (cmd == 2u) load_weights();
         const int noise = (int)s_word[2];
-        const unsigned long long seed = s_word[3] | ((unsigned long long)s_word[4] << 32);
-        const unsigned long long offset = s_word[5] | ((unsigned long long)s_word[6] << 32);
-        // ---- the seven layers ----
-        for (int l = 0; l < a.n_layers && alive; ++l) {
+        const unsigned long long seed = s_word[4] | ((unsigned long long)s_word[5] << 32);
+        const unsigned long long offset = s_word[6] | ((unsigned long long)s_word[7] << 32);
+        const unsigned tag0 = last * 16u;
+        int failed = 0;
+        // ---- the layers: inputs polled word by word, outputs published word by word ----
+        for (int l = 0; l < a.n_layers; ++l) {
             const SrvLayer L = a.layer[l];
-            const float* prev = a.acts + (size_t)l * kSrvActStride;          // slot l: the previous layer's output (0: obs)
+            const unsigned long long* prev = a.acts + (size_t)l * kSrvActStride;   // slot l: the previous layer's output (0: obs)
+            const unsigned tagp = tag0 + (unsigned)l;
             if (l == 0) {                                                    // [s1 | s2 | 0]
-                for (int k = tid; k < L.ld; k += 256) xs[k] = k < 2 * a.Db ? srv_ld(a.acts + k) : 0.f;
+                for (int k = tid; k < L.ld; k += 256) xs[k] = k < 2 * a.Db ? srv_get(a.acts + k, tag0, t_start, a.life_ticks, failed) : 0.f;
             } else if (l == a.n_te) {                                        // [s1 | z | 0], the sampler formed in place
                 for (int k = tid; k < L.ld; k += 256) {
                     float v = 0.f;
-                    if (k < a.Db) v = srv_ld(a.acts + k);
+                    if (k < a.Db) v = srv_get(a.acts + k, tag0, t_start, a.life_ticks, failed);
                     else if (k < a.Db + a.Z) {
                         const int j = k - a.Db;
-                        if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_ld(prev + j);
+                        if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_get(prev + j, tagp, t_start, a.life_ticks, failed);
                         else {
-                            const float mu = srv_ld(prev + j), lv = srv_ld(prev + a.Z + j);
+                            const float mu = srv_get(prev + j, tagp, t_start, a.life_ticks, failed);
+                            const float lv = srv_get(prev + a.Z + j, tagp, t_start, a.life_ticks, failed);
                             const float e = noise ? philox_normal(seed, offset, 0, j) : 0.f;
                             v = mu + e * expf(0.5f * lv);
                         }
@@ -3533,10 +3558,12 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                     xs[k] = v;
                 }
             } else {
-                for (int k = tid; k < L.ld; k += 256) xs[k] = srv_ld(prev + k);
+                for (int k = tid; k < L.ld; k += 256) xs[k] = srv_get(prev + k, tagp, t_start, a.life_ticks, failed);
             }
+            if (failed) s_failed = 1;
             __syncthreads();
             const float* Wl = srv_lds + L.lds_off;
+            unsigned long long* outp = a.acts + (size_t)(l + 1) * kSrvActStride;
             for (int f = wave; f < L.F; f += 4) {                            // one wave per feature: gemv_rollout_kernel's sum
                 const float* wrow = Wl + f * L.ld;
                 float acc = 0.f;
@@ -3551,27 +3578,32 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                     const int n = g * L.F + f;
                     float v = acc + Wl[L.F * L.ld + f];
                     v = (L.act > 1 && n >= L.n_out) ? 0.f : act_apply(v, L.act);
-                    a.acts[(size_t)(l + 1) * kSrvActStride + n] = v;
+                    srv_put(outp + n, v, tagp + 1u);
                 }
             }
-            if (!barrier()) alive = false;
+            __syncthreads();                                                 // xs is rewritten by the next layer
+            if (s_failed) break;
         }
-        if (!alive) break;
+        if (s_failed) { alive = false; break; }
         // ---- result: group 0 -> mailbox, payload first, completion word last ----
         if (g == 0) {
-            const float* md_out = a.acts + (size_t)a.n_layers * kSrvActStride;
-            const float* te_out = a.acts + (size_t)a.n_te * kSrvActStride;
+            const unsigned long long* md_out = a.acts + (size_t)a.n_layers * kSrvActStride;
+            const unsigned long long* te_out = a.acts + (size_t)a.n_te * kSrvActStride;
+            const unsigned tag_md = tag0 + (unsigned)a.n_layers, tag_te = tag0 + (unsigned)a.n_te;
             const int n_out = a.Da + 3 * a.Z;
             for (int i = tid; i < n_out; i += 256) {
                 float v;
-                if (i < a.Da) v = srv_ld(md_out + i);
-                else if (i < a.Da + 2 * a.Z) v = srv_ld(te_out + (i - a.Da));
+                if (i < a.Da) v = srv_get(md_out + i, tag_md, t_start, a.life_ticks, failed);
+                else if (i < a.Da + 2 * a.Z) v = a.prior_kind == PVAE_PRIOR_NONE && i >= a.Da + a.Z ? 0.f
+                                                 : srv_get(te_out + (i - a.Da), tag_te, t_start, a.life_ticks, failed);
                 else {                                                       // z as the decoder saw it (same expression as above)
                     const int j = i - a.Da - 2 * a.Z;
-                    if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_ld(te_out + j);
+                    if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_get(te_out + j, tag_te, t_start, a.life_ticks, failed);
                     else {
+                        const float mu = srv_get(te_out + j, tag_te, t_start, a.life_ticks, failed);
+                        const float lv = srv_get(te_out + a.Z + j, tag_te, t_start, a.life_ticks, failed);
                         const float e = noise ? philox_normal(seed, offset, 0, j) : 0.f;
-                        v = srv_ld(te_out + j) + e * expf(0.5f * srv_ld(te_out + a.Z + j));
+                        v = mu + e * expf(0.5f * lv);
                     }
                 }
                 __hip_atomic_store(a.mb->out + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -3595,7 +3627,7 @@ struct RolloutServer {
     SrvMailbox* mb = nullptr;             // hipHostMalloc (mapped)
     SrvMailbox* mb_dev = nullptr;
     unsigned* sync = nullptr;             // device
-    float* acts = nullptr;                // device
+    unsigned long long* acts = nullptr;   // device: tagged hand-over words
     hipStream_t stream = nullptr;
     SrvArgs args{};
     size_t lds_bytes = 0;
@@ -3638,8 +3670,8 @@ static int server_plan(pvae_ctx* c, RolloutServer& S) {
 
 static int server_launch(pvae_ctx* c, RolloutServer& S) {
     HIP_TRY(hipMemsetAsync(S.sync, 0, 64 * sizeof(unsigned), S.stream));
-    S.mb->state = 0; S.mb->req_seq = 0; S.mb->done_seq = 0; S.mb->cmd = 0;
-    S.seq = 0;
+    S.mb->state = 0; S.mb->req_seq = S.seq; S.mb->done_seq = S.seq; S.mb->cmd = 0;
+    S.args.seq0 = S.seq;
     S.args.params = c->params;
     S.args.idle_ticks = (long long)(S.idle_ms * 1e5);
     S.args.life_ticks = (long long)(S.life_s * 1e8);
@@ -3676,8 +3708,8 @@ int pvae_rollout_server_start(pvae_ctx* c, double idle_timeout_ms, double lifeti
         memset((void*)S.mb, 0, sizeof(SrvMailbox));
         HIP_TRY(hipHostGetDevicePointer((void**)&S.mb_dev, (void*)S.mb, 0));
         HIP_TRY(hipMalloc((void**)&S.sync, 64 * sizeof(unsigned)));
-        HIP_TRY(hipMalloc((void**)&S.acts, (size_t)(kSrvMaxLayers + 1) * kSrvActStride * sizeof(float)));
-        HIP_TRY(hipMemset(S.acts, 0, (size_t)(kSrvMaxLayers + 1) * kSrvActStride * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&S.acts, (size_t)(kSrvMaxLayers + 1) * kSrvActStride * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(S.acts, 0, (size_t)(kSrvMaxLayers + 1) * kSrvActStride * sizeof(unsigned long long)));
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));               // lo: least urgent.  A priority of its own = a hardware
         HIP_TRY(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, lo));   // queue no compute stream is mapped onto
@@ -3693,7 +3725,8 @@ static int server_request(pvae_ctx* c, uint32_t cmd, const float* obs, int noise
     RolloutServer& S = *c->server;
     SrvMailbox* mb = S.mb;
     if (obs) memcpy((void*)mb->obs, obs, (size_t)2 * S.args.Db * sizeof(float));
-    mb->cmd = cmd; mb->noise = noise ? 1u : 0u; mb->rng_seed = seed; mb->rng_offset = offset;
+    mb->cmd = cmd; mb->noise = noise ? 1u : 0u;
+    mb->seed_lo = (uint32_t)seed; mb->seed_hi = (uint32_t)(seed >> 32); mb->off_lo = (uint32_t)offset; mb->off_hi = (uint32_t)(offset >> 32);
     const uint32_t seq = ++S.seq;
     __atomic_store_n(&mb->req_seq, seq, __ATOMIC_RELEASE);
     if (cmd == 1) return 0;
@@ -3732,6 +3765,21 @@ int pvae_rollout_server_infer(pvae_ctx* c, const float* obs, int noise, uint64_t
         }
     }
     return fail(-25, "rollout server: the kernel left twice while a request was pending");
+}
+
+/* n requests back to back with the SAME observation, each timed on the host clock inside this call (what a compiled host
+ * sees; a Python caller adds its own call overhead): us[i] = host observation -> host action of request i. */
+int pvae_rollout_server_selfbench(pvae_ctx* c, const float* obs, int noise, int32_t n, double* us) {
+    if (!c || !c->server || !c->server->mb) return fail(-2, "rollout server not started (pvae_rollout_server_start)");
+    if (!obs || !us || n < 1) return fail(-1, "bad arguments");
+    std::vector<float> a(c->server->args.Da);
+    for (int i = 0; i < n; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = pvae_rollout_server_infer(c, obs, noise, 1, (uint64_t)i, 0, a.data(), nullptr, nullptr, 1000.0);
+        us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int pvae_rollout_server_stop(pvae_ctx* c) {

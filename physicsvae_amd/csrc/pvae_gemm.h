@@ -329,6 +329,76 @@ __device__ inline void stage_row_wave(const StageArgs& a, int r, int t, int rows
     }
 }
 
+// The same row by one wave THROUGH LDS (what the stand-alone gather launch runs when a row's sources fit the wave's
+// 8 KB of LDS): the sources -- [s_t | s_{t+1}] and a_t, 4-byte aligned runs of dim_body / dim_action floats -- land in
+// LDS by LDS-DMA (global_load_lds_dword: 256 contiguous bytes per instruction, no register, nothing waited for until
+// all of the row is in flight: ceil((2 Db + Da) / 64) instructions), and every panel row is then written with whole
+// 16-byte stores assembled from LDS (the misalignment between a source run and the 64-float-aligned panel is absorbed
+// by the LDS reads, which cost nothing next to the memory system).  Per window at the configs[2] dims: 8 loads + 6
+// stores instead of stage_row_wave's 40 + 56 dword-granular buffer instructions (most of them out of range), which
+// made that form instruction-bound (16.2 us per 8192 windows against 13.3 for stage_row_vec).  Bit-identical (a copy).
+constexpr int kStageLdsFloats = 2048;                   // per wave
+__device__ inline void stage_row_lds(const StageArgs& a, int r, int t, int rows_pad, int lane, float* sl) {
+    const int Db = a.Db, Da = a.Da;
+    const size_t prow = (size_t)t * rows_pad + r;
+    const bool valid = r < a.rows;
+    const bool first = t == 0;
+    bool have_a = false;
+    if (valid) {
+        const float* p1; const float* p2; const float* pa = nullptr;
+        if (a.window_row) {
+            const long long s = (long long)__builtin_amdgcn_readfirstlane(a.window_row[a.first_window + r]) + t;
+            p1 = a.states + s * Db;
+            p2 = a.next_states ? a.next_states + s * Db : p1 + Db;
+            pa = a.actions + s * Da;
+        } else {
+            p1 = a.x + ((size_t)r * a.L + t) * 2 * Db;
+            p2 = p1 + Db;
+            if (a.y) pa = a.y + ((size_t)r * a.L + t) * Da;
+        }
+        have_a = pa != nullptr;
+        // LDS image: [0, Db) s1, [Db, 2 Db) s2, [2 Db, 2 Db + Da) action; the tail of each 64-float DMA group that
+        // reaches past a run lands in the next run's space (overwritten by that run's own DMA, issued later) or past
+        // the end (never read).  Order: s1, s2, action.
+        auto dma = [&](const float* src, int n, int dst0) {
+            for (int c = 0; c < n; c += 64) {
+                const int cc = c + lane < n ? c + lane : n - 1;          // (clamped: no read past the run)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + cc),
+                                                 (__attribute__((address_space(3))) void*)(sl + dst0 + c), 4, 0, 2);
+            }
+        };
+        if (p2 == p1 + Db) dma(p1, 2 * Db, 0);
+        else { dma(p1, Db, 0); dma(p2, Db, Db); }
+        if (have_a) dma(pa, Da, 2 * Db);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // value(c) = (LDS index, condition): the read is unconditional (any index inside the wave's region is safe), the
+    // zero-fill a select -- no divergent branch per element
+    auto put = [&](float* panel, int ld, auto&& where) {                 // 16 bytes per lane and trip
+        if (!panel) return;
+        float* row = panel + prow * ld;
+        for (int c = lane * 4; c < ld; c += 256) {
+            v4f v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int idx; bool on;
+                where(c + e, idx, on);
+                const float x = sl[idx & (kStageLdsFloats - 1)];
+                v[e] = on ? x : 0.f;
+            }
+            *reinterpret_cast<v4f*>(row + c) = v;
+        }
+    };
+    const bool s1_on = valid && first;
+    put(a.te_in, a.ld_te, [&](int c, int& i, bool& on) { i = c; on = c < Db ? s1_on : (valid && c < 2 * Db); });
+    put(a.md_in, a.ld_md, [&](int c, int& i, bool& on) { i = c; on = s1_on && c < Db; });          // z columns filled by the sampler
+    put(a.wm_in, a.ld_wm, [&](int c, int& i, bool& on) { i = c < Db ? c : c + Db; on = c < Db ? s1_on : (have_a && c < Db + Da); });
+    put(a.wm_pred, a.ld_wm, [&](int c, int& i, bool& on) { i = c; on = s1_on && c < Db; });        // a_hat columns filled by the decoder
+    put(a.pr_in, a.ld_pr, [&](int c, int& i, bool& on) { i = c; on = s1_on && c < Db; });
+    put(a.s2, a.ld_s2, [&](int c, int& i, bool& on) { i = Db + c; on = valid && c < Db; });
+    put(a.act_t, a.ld_a, [&](int c, int& i, bool& on) { i = 2 * Db + c; on = have_a && c < Da; });
+}
+
 // host-side default for GemmArgs::krot: off (measured: no gain); PVAE_KROT=1 enables
 // register sets in flight per lane in the register-staged kernels (A/B on the whole step: 2 / 2 /
 // 4 beats 4 / 4 / 4 by 1.8 %, 3 and 8 lose; compile-time switches for re-measuring)
@@ -783,6 +853,44 @@ struct NoPro {
     __device__ inline void publish(const float*, int, int, int, int) const {}
 };
 
+// Experiment (PVAE_L2_TOUCH=1 at build time; off in production): every XCD's L2 has to be filled with the operand panels
+// its 32 workgroups share (X is re-fetched by each XCD: the 2.2x over-fetch of the forward launches), and a k-tile whose
+// lines are still on their way from the Infinity Cache is what the LDS-DMA stream waits for.  Here the compute waves of a
+// workgroup -- which issue no vector-memory instruction inside the loop -- TOUCH, right after their share of k-tile 0, the
+// workgroup's share of everything its XCD will stream (one 4-byte load per 128-byte line, never waited for inside the
+// loop): the workgroups that share a Q row block split its K range among them, likewise the ones that share a P tile.
+// The loads land in one dead register that stays reserved until l2_touch_drain.
+#ifndef PVAE_L2_TOUCH
+#define PVAE_L2_TOUCH 0
+#endif
+__device__ inline void l2_touch(float& sink, const float* p) {
+    asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
+}
+__device__ inline void l2_touch_drain(float& sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory"); }
+template <bool P_ROW>
+__device__ inline void l2_touch_share(float& sink, const float* Q, int ldq, int q0, int rows_q, const float* P, int ldp, int p0,
+                                      int K, int xi, int nx, int wi, int nw, int wave, int lane) {
+    if (nx > 0 && K % (nx * 32) == 0) {                       // Q rows [q0, +rows_q), k-slice xi of nx
+        const int kx = K / nx, lines = kx / 32, total = rows_q * lines;
+        for (int i = wave * 64 + lane; i < total; i += 256) {
+            const int row = i / lines, ln = i - row * lines;
+            l2_touch(sink, Q + (size_t)(q0 + row) * ldq + xi * kx + ln * 32);
+        }
+    }
+    if (nw > 0 && K % (nw * 32) == 0) {                       // the P tile's k-slice wi of nw
+        const int kw = K / nw;
+        if (P_ROW) {
+            const int lines = kw / 32, total = 32 * lines;
+            for (int i = wave * 64 + lane; i < total; i += 256) {
+                const int row = i / lines, ln = i - row * lines;
+                l2_touch(sink, P + (size_t)(p0 + row) * ldp + wi * kw + ln * 32);
+            }
+        } else {
+            for (int i = wave * 64 + lane; i < kw; i += 256) l2_touch(sink, P + (size_t)(wi * kw + i) * ldp + p0);
+        }
+    }
+}
+
 template <bool P_ROW, class Epi, class Pro = NoPro>
 __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, Epi& epi, const Pro& pro = Pro(),
                                       float* scratch = nullptr) {
@@ -953,6 +1061,14 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
 #endif
         epre = epi.preload(q0 + (tid >> 3), p0 + ((tid & 7) << 2));   // epilogue operands: arrive under the loop
         typename Pro::State pst = pro.prepare(q0, tid);
+#if PVAE_L2_TOUCH
+        float l2sink = 0.f;
+        if (!ga.rowxcd) {
+            int np = tiles_p - xcd * ga.p_per_xcd;
+            if (np > ga.p_per_xcd) np = ga.p_per_xcd;
+            l2_touch_share<P_ROW>(l2sink, Q, ldq, q0, 32, P, ldp, p0, K, tile_p - xcd * ga.p_per_xcd, np, tile_q, tiles_q, wave, lane);
+        }
+#endif
         struct Frag { v4f q[2], p[2]; v2f c[4]; };
         auto fread = [&](const float* st, Frag& f) {
 #pragma unroll
@@ -1033,6 +1149,9 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
                 }
             }
         }
+#if PVAE_L2_TOUCH
+        l2_touch_drain(l2sink);
+#endif
     }
     // split-K reduction through LDS (fixed order: compute wave 0..3), epilogue on float4s by the
     // 256 compute threads; every wave takes part in the barriers
@@ -1058,11 +1177,16 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
 // of 13).  One 64x32 workgroup per CU lands 24 KB per k-tile for the MFMA work of two 32x32 tiles (32 KB): a quarter
 // less DMA traffic per flop.  Every output element is still the sum of the same four k-quarters in the same order, so
 // results equal the 32x32 kernel's bit for bit.  Ring: 4 slots x 24 KB = 96 KB.
-constexpr int kWs64Floats = kWsStages * (64 + 32) * 64;
+#ifndef PVAE_WS64_STAGES
+#define PVAE_WS64_STAGES 4          // ring slots of the 64x32 kernel (24 KB each; A/B: 5, 6)
+#endif
+constexpr int kWs64Stages = PVAE_WS64_STAGES;
+constexpr int kWs64Floats = kWs64Stages * (64 + 32) * 64;
 template <bool P_ROW, class Epi>
 __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
-    constexpr int BK = 64, kTileQ = 64 * 64, kTileP = 32 * 64, kStage = kTileQ + kTileP, S = kWsStages;
+    constexpr int BK = 64, kTileQ = 64 * 64, kTileP = 32 * 64, kStage = kTileQ + kTileP, S = kWs64Stages;
     static_assert(kWsLoaders == 4, "written for four loader waves");
+    static_assert(S >= 4 && S <= 6, "the loaders' wait ladder covers up to four tiles in flight");
     const float* __restrict__ Q = ga.Q;
     const float* __restrict__ P = ga.P;
     const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
@@ -1127,7 +1251,8 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
             if (y > S - 3) y = S - 3;
             if (y <= 0) wait_vmcnt<0>();
             else if (y == 1) wait_vmcnt<6>();
-            else wait_vmcnt<12>();
+            else if (y == 2) wait_vmcnt<12>();
+            else wait_vmcnt<18>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (t + S - 1 < nk) issue(t + S - 1);
@@ -1144,6 +1269,14 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
         wait_vmcnt<0>();                                         // this wave's share of tile 0 landed
 #pragma unroll
         for (int h = 0; h < 2; ++h) epre[h] = epi.preload(q0 + 32 * h + (tid >> 3), p0 + ((tid & 7) << 2));
+#if PVAE_L2_TOUCH
+        float l2sink = 0.f;
+        {
+            int np = tiles_p - xcd * ga.p_per_xcd;
+            if (np > ga.p_per_xcd) np = ga.p_per_xcd;
+            l2_touch_share<P_ROW>(l2sink, Q, ldq, q0, 64, P, ldp, p0, K, tile_p - xcd * ga.p_per_xcd, np, tile_q, tiles_q, wave, lane);
+        }
+#endif
         struct Frag { v4f q[4], p[2]; v2f c[4]; };
         auto fread = [&](const float* st, Frag& f) {
 #pragma unroll
@@ -1187,6 +1320,9 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
                 }
             }
         }
+#if PVAE_L2_TOUCH
+        l2_touch_drain(l2sink);
+#endif
     }
     // split-K reduction through LDS (fixed order: compute wave 0..3), epilogue on float4s by the 256 compute threads
     __syncthreads();

@@ -181,6 +181,7 @@ class HipEngine:
         self.ctx = None
         self.has_comm = False                    # RCCL communicator owned by the ctx (comm_init)
         self.has_p2p = False                     # peers' arenas mapped into this process (p2p_open)
+        self._srv_io = None                      # buffers of the rollout server's calls (rollout_server_start)
         self.exchange_code = _lib.EXCHANGE_ALLREDUCE   # what comm_mode last selected (p2p_close falls back to all-reduce)
         self.workspace = None
         self.dataset = None
@@ -575,24 +576,37 @@ class HipEngine:
         While it is resident, device-wide synchronisations wait for it (at most `idle_ms` after the last request)."""
         self._need_gpu()
         _lib.check(self.lib.pvae_rollout_server_start(self.ctx, float(idle_ms), float(lifetime_s)), "pvae_rollout_server_start")
-        if getattr(self, "_srv_io", None) is None:
+        if self._srv_io is None:
             import numpy as _np
             Da, Db, Z = self.arch.Da, self.arch.Db, self.arch.Z
             bufs = (_np.zeros(2 * Db, _np.float32), _np.zeros(Da, _np.float32), _np.zeros(2 * Z, _np.float32), _np.zeros(Z, _np.float32))
-            self._srv_io = bufs + tuple(b.ctypes.data for b in bufs)
+            self._srv_io = bufs + tuple(C.c_void_p(b.ctypes.data) for b in bufs)       # (argument objects built once)
+            self._srv_fn = self.lib.pvae_rollout_server_infer
 
     def rollout_server_infer(self, obs, noise=True, seed=0, offset=0, reload=False, timeout_ms=1000.0):
         """obs [2 Db] (CPU array / tensor) -> (a_hat [Da], mu_logvar [2 Z], z [Z]) as numpy views that stay valid until
         the next call; the same values as `infer(obs[None], noise=noise, seed=seed, offset=offset)`, bit for bit.
         A plain host call: no launch, no stream operation.  `reload`: copy the weights from the arena into LDS first."""
-        io = getattr(self, "_srv_io", None)
+        io = self._srv_io
         if io is None:
             raise RuntimeError("rollout server not started (rollout_server_start)")
         n_obs, n_a, n_ml, n_z, p_obs, p_a, p_ml, p_z = io
-        n_obs[:] = obs.reshape(-1) if not isinstance(obs, torch.Tensor) else obs.detach().cpu().numpy().reshape(-1)
-        _lib.check(self.lib.pvae_rollout_server_infer(self.ctx, p_obs, 1 if noise else 0, int(seed), int(offset), 1 if reload else 0,
-                                                      p_a, p_ml, p_z, float(timeout_ms)), "pvae_rollout_server_infer")
+        if isinstance(obs, torch.Tensor):
+            obs = obs.detach().cpu().numpy()
+        n_obs[:] = obs.reshape(-1)
+        rc = self._srv_fn(self.ctx, p_obs, 1 if noise else 0, seed, offset, 1 if reload else 0, p_a, p_ml, p_z, timeout_ms)
+        if rc:
+            _lib.check(rc, "pvae_rollout_server_infer")
         return n_a, n_ml, n_z
+
+    def rollout_server_selfbench(self, obs, n=1000, noise=True):
+        """us per request of n back-to-back requests, timed on the host clock INSIDE the library call (no Python per request)."""
+        import numpy as _np
+        o = _np.ascontiguousarray(_np.asarray(obs, dtype=_np.float32).reshape(-1))
+        us = _np.zeros(int(n), _np.float64)
+        _lib.check(self.lib.pvae_rollout_server_selfbench(self.ctx, o.ctypes.data, 1 if noise else 0, int(n), us.ctypes.data),
+                   "pvae_rollout_server_selfbench")
+        return us
 
     def rollout_server_stop(self):
         if self.ctx is not None:

@@ -1,6 +1,6 @@
-"""Round-2 GPU tests: bench.py launched plainly (N = 1 and N = 2 self-launch), HIP-graph rollout
-replays interleaved with prefetched training steps, identity device moves of the module, and the
-gather kernel on a demonstration set whose byte offsets cross 2^31."""
+"""The rollout side of the boundary (rmt:742-771 and the PhysicsVAE module surface RLlib drives): the <= 4-row
+rollout path against the staged forward, host observation -> host action, the module forward + value branch (also on
+stacks given layer by layer), HIP-graph replays between prefetched training steps, device moves of the module, log_std."""
 import json
 import os
 import subprocess
@@ -12,87 +12,12 @@ import torch
 
 from oracle import refpath as R
 from physicsvae_amd import _lib
-from util import arch_from_meta, make_trainer
+from physicsvae_amd.engine import make_step_params
+from util import arch_from_meta, make_trainer, max_err_scaled
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _bench(*flags, timeout=900):
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), cwd=ROOT, env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
-    return json.loads(r.stdout.strip().splitlines()[-1])
-
-
-def test_bench_plain_two_ranks_self_launch():
-    """`python bench.py --gpus 2`, launched plainly, starts its two ranks itself and prints ONE line.
-    On a 1-GPU box the ranks share the device and exchange over gloo (RCCL refuses two ranks on one
-    device): same sharding / reduction / Adam path, flagged in the line."""
-    d = _bench("--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-rocprof")
-    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5
-    assert d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp2"
-    assert d["timing"]["timed_steps_per_region"] >= 200 and d["timing"]["regions"] == 3
-    assert d["value"] > 0 and np.isfinite(d["last_loss"])
-    if torch.cuda.device_count() < 2:
-        assert d["ranks_share_a_gpu"] is True and d["rccl_ranks"] == 0
-    else:
-        assert d["ranks_share_a_gpu"] is False and d["rccl_ranks"] == 2
-        assert d["allreduce_us_per_step"] > 0
-    assert "roofline" in d and 0 < d["roofline"]["frac"] < 1
-    # the N-rank step against ONE process with the global batch (three optimizer steps from a common state): what a
-    # stale read of peer-written parameters could not pass while the replicas stay bit-identical
-    ref = d["single_process_reference"]
-    assert d["matches_single_process"] is True and d["replicas_identical"] is True, ref
-    assert ref["steps"] == 3 and ref["global_batch"] == 512 and ref["max_rel_loss_diff"] < 2e-4 and ref["update_rel_l2_diff"] < 2e-2
-    assert ref["losses_n_ranks"][0] != ref["losses_n_ranks"][1]                 # the steps really trained
-    # every exchange form, back to back in the same run (what a multi-GPU lease must yield in one go)
-    sweep = d["exchange_sweep"]
-    assert set(sweep) == {"inline", "bucketed", "sharded", "p2p", "p2p_push", "local"}
-    for form in ("p2p", "p2p_push"):
-        assert sweep[form]["p2p_ranks"] == 2 and sweep[form]["timeouts"] == 0 and sweep[form]["value"] > 0
-    assert sweep["p2p"]["exchange_launches_per_step"] >= 2          # one launch per bucket, two stacks in the joint phase
-    assert sweep["local"]["ms_per_step"] > 0 and "exchange_exposed_us_per_step" in sweep["p2p"]
-    if torch.cuda.device_count() < 2:
-        assert all("skipped" in sweep[m] for m in ("inline", "bucketed", "sharded"))     # RCCL needs one GPU per rank
-    else:
-        assert all(sweep[m]["value"] > 0 for m in ("inline", "bucketed", "sharded"))
-
-
-def test_bench_under_the_launcher_command_of_the_scaling_run():
-    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
-    --gpus N ...`: the command the multi-GPU scaling run uses, here with N = 2.  On a box with fewer GPUs than ranks
-    the ranks share the devices over gloo (`parallel.init_from_env`): same code path up to the transport, flagged in
-    the line; the last stdout line that parses is rank 0's ONE JSON line."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29633", os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "10", "--warmup", "3"], cwd=ROOT, env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, lines
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 3 and d["scaling"] == "weak"
-    assert d["config"]["global_batch"] == 512 and d["value"] > 0 and np.isfinite(d["last_loss"])
-    assert d["replicas_identical"] is True and d["matches_single_process"] is True, d.get("single_process_reference")
-    assert d["ranks_share_a_gpu"] is (torch.cuda.device_count() < 2)
-    assert d["exchange_autotune"]["chosen"] in ("inline", "bucketed", "sharded", "p2p", "p2p_push")
-
-
-def test_bench_plain_single_gpu_line():
-    d = _bench("--steps", "20", "--warmup", "5", "--no-rocprof")
-    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 0 and d["config"]["phase"] == "joint"
-    assert d["metric"].startswith("train samples/sec (world-model+VAE step)")
-    for key in ("roofline", "world_roofline", "cpu_baseline", "world_value"):
-        assert key in d, key
-    for roof in (d["roofline"], d["world_roofline"]):
-        assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["peak"] == 157.3
-    cb = d["cpu_baseline"]
-    assert cb["value"] >= cb["value_1thread"] > 0 and cb["threads_best"] in [int(k) for k in cb["sweep"]]
-    assert len(d["timing"]["region_values"]) == 3
 
 
 def test_graph_replays_between_prefetched_train_steps_do_not_touch_the_training_batch(golden):
@@ -154,76 +79,6 @@ def test_identity_device_moves_of_the_module(golden):
         m.to("cpu")
     with pytest.raises(RuntimeError):
         m.double()
-
-
-def test_gather_windows_across_the_2GiB_byte_boundary():
-    """A demonstration set of 1.5e6 state rows x 400 floats = 2.4 GB: byte offsets of the rows a
-    window reads cross 2^31 (row 1 342 177).  The panels the gather kernel fills for windows at the
-    start, straddling the boundary and at the very end equal the oracle's definition of a window
-    (x = [s_t | s_{t+1}], y = a_t; tpv:133-156) bit for bit."""
-    from physicsvae_amd.engine import Arch, HipEngine
-    Db, Da, B = 400, 90, 512
-    rows_total = 1_500_000
-    eng = HipEngine(Arch(Db, Da, 32, (64, 1), (64, 1), (64, 1)), B, device=DEV)
-    gen = torch.Generator(device=DEV).manual_seed(3)
-    states = torch.randn(rows_total, Db, generator=gen, device=DEV)
-    actions = torch.randn(rows_total, Da, generator=gen, device=DEV)
-    assert states.numel() * 4 > 2 ** 31
-    # windows: every row but the last of each 1000-row "episode" (episode boundaries are skipped)
-    idx = torch.arange(rows_total, device=DEV)
-    window_row = idx[(idx % 1000) != 999].to(torch.int32)
-    eng.bind_dataset(states, actions, window_row)
-    n = window_row.numel()
-    boundary_row = 2 ** 31 // (Db * 4)                   # first row whose bytes start beyond 2^31
-    first_over = int(torch.searchsorted(window_row, torch.tensor(boundary_row, device=DEV, dtype=torch.int32)))
-    for first, rows in ((0, B), (first_over - B // 2, B), (n - B, B), (n - 37, 37)):
-        eng.gather(first, rows)
-        torch.cuda.synchronize()
-        r = window_row[first: first + rows].long()
-        te_in = eng.panel("in", _lib.NET_TE)[:rows]
-        wm_in = eng.panel("in", _lib.NET_WM)[:rows]
-        md_in = eng.panel("in", _lib.NET_MD)[:rows]
-        assert torch.equal(te_in[:, :Db], states[r]) and torch.equal(te_in[:, Db: 2 * Db], states[r + 1])
-        assert torch.equal(wm_in[:, :Db], states[r]) and torch.equal(wm_in[:, Db: Db + Da], actions[r])
-        assert torch.equal(md_in[:, :Db], states[r])
-        assert torch.equal(eng.panel("s2")[:rows, :Db], states[r + 1])
-        assert torch.equal(eng.panel("act_t")[:rows, :Da], actions[r])
-        assert float(te_in[:, 2 * Db:].abs().max()) == 0.0            # pad columns are zeros
-        if rows < B:
-            assert float(eng.panel("in", _lib.NET_TE)[rows: (rows + 31) // 32 * 32].abs().max()) == 0.0
-
-
-@pytest.mark.parametrize("stop_after", [3, 1, 2])
-def test_trainer_state_resume_is_bit_exact(golden, tmp_path, stop_after):
-    """`save_trainer_state` / `resume_trainer_state` (ours; upstream resumes weights only, tm:215-216):
-    a run interrupted after `stop_after` epochs (world -> joint switch at 2: after it, before it, exactly at
-    it) and resumed from its checkpoint directory continues bit for bit like the uninterrupted run: weights,
-    Adam moments, step counts, StepLR position, eps stream position, and the PHASE."""
-    g = golden("train_tiny")
-    arch = arch_from_meta(g["meta"])
-    n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
-    data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
-    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
-    kw = dict(m_world=2, device=DEV, lr_step=2, eps_fn=R.eps_stream(2, arch["Z"]))
-    full = make_trainer(arch, data, batch, extra={"save_trainer_state": True}, **kw)
-    full.model.load_state_dict(sd)
-    for _ in range(stop_after):
-        full.train()
-    ck = full.save_checkpoint(str(tmp_path))
-    assert os.path.exists(tmp_path / "trainer_state.pt")
-    learnable_at_save = sorted(full.model.learnable_nets())
-    want = [full.train()["mean_train_loss"] for _ in range(3)]
-    res = make_trainer(arch, data, batch, extra={"resume_trainer_state": True}, **kw)
-    res.restore(ck)
-    assert res.iter == stop_after
-    # the restore itself re-entered the phase the state was saved in (joint when saved after the switch)
-    assert sorted(res.model.learnable_nets()) == learnable_at_save
-    assert (res.a_rec_coeff > 0) == (stop_after > 2)
-    got = [res.train()["mean_train_loss"] for _ in range(3)]
-    assert got == want
-    assert torch.equal(res.engine.params, full.engine.params)
-    assert torch.equal(res.engine.exp_avg, full.engine.exp_avg) and torch.equal(res.engine.exp_avg_sq, full.engine.exp_avg_sq)
-    assert res.optimizer.net_steps == full.optimizer.net_steps and res.optimizer.lr == full.optimizer.lr
 
 
 def test_state_independent_log_std_is_a_parameter_the_loss_never_touches(golden):
@@ -311,47 +166,6 @@ def test_fused_rollout_path_equals_the_staged_forward(golden, rows):
     assert float(g0.abs().sum()) > 0
 
 
-def test_gather_of_cond_rel_windows_is_bit_exact(golden, tmp_path):
-    """cond = "rel" datasets on the device: the gather kernel reads the second half of x and the target
-    s2 from the row-aligned `next_states` array; the panels equal the dataset's windows bit for bit and
-    a training epoch over them runs (the world model then learns state DIFFERENCES)."""
-    from physicsvae_amd import train_physics_vae as T
-    g = golden("ingest_rel_tiny")
-    arch = arch_from_meta(g["meta"])
-    Db, Da = arch["Db"], arch["Da"]
-    data = R.synth_demo(3, 3, 12, Db, Da, kind="iid", quantum=0.0)
-    pkl = str(tmp_path / "a.pkl")
-    R.write_demo(pkl, data)
-    tr = make_trainer(arch, data, 8, m_world=1, device=DEV)
-    ds = T.load_dataset_for_PhysicsVAE([pkl], cond="rel")
-    tr.train_loader.dataset = ds
-    eng = tr.engine
-    eng.bind_dataset(*ds.device_arrays(eng.device))
-    for first, rows in ((0, 8), (25, 8), (32, 1)):
-        eng.gather(first, rows)
-        torch.cuda.synchronize()
-        xs = torch.stack([ds[i][0][0] for i in range(first, first + rows)]).to(DEV)      # [rows, 2Db]
-        ys = torch.stack([ds[i][1][0] for i in range(first, first + rows)]).to(DEV)
-        assert torch.equal(eng.panel("in", _lib.NET_TE)[:rows, : 2 * Db], xs)
-        assert torch.equal(eng.panel("s2")[:rows, :Db], xs[:, Db:])
-        assert torch.equal(eng.panel("in", _lib.NET_WM)[:rows, :Db], xs[:, :Db])
-        assert torch.equal(eng.panel("in", _lib.NET_WM)[:rows, Db: Db + Da], ys)
-    r1, r2 = tr.train(), tr.train()
-    assert np.isfinite(r1["mean_train_loss"]) and np.isfinite(r2["mean_train_loss"])
-    # against the oracle on the same windows
-    X, Y = R.build_windows(data, cond="rel")
-    x, y = next(iter(R.make_loader(X, Y, 8)))
-    sd = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
-    want = R.loss_and_grads(arch, sd, x, y, None, world=True)
-    c = R.phase_coeffs(True)
-    from physicsvae_amd.engine import make_step_params
-    sp = make_step_params(lr=5e-4, a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"], s_rec=c["s_rec_coeff"],
-                          cyc=c["vae_cycle_coeff"], global_rows=8)
-    eng.gather(0, 8)
-    got = eng.forward_backward(_lib.PHASE_WORLD, 8, sp, backward=False).cpu()
-    assert float(got[0]) == pytest.approx(float(want["total"]), rel=1e-5)
-
-
 @pytest.mark.parametrize("rows", [1, 2, 3, 4, 6, 33])
 def test_module_forward_writes_logits_in_one_call_and_value_branch_runs_on_the_gemv_chain(golden, rows):
     """`PhysicsVAE.forward` = one `pvae_infer_logits` call: [a_hat | log_std] written by the launch that produces
@@ -421,3 +235,75 @@ def test_state_independent_log_std_reaches_the_logits(golden):
         m._motor_decoder._model[-1].log_std.copy_(torch.arange(arch["Da"], dtype=torch.float32) * 0.1 - 1.0)
         logits, _ = m.forward({"obs_flat": torch.zeros(1, 2 * arch["Db"], device=DEV)}, [], None)
     assert torch.allclose(logits[0, arch["Da"]:].cpu(), torch.arange(arch["Da"], dtype=torch.float32) * 0.1 - 1.0)
+
+
+@pytest.mark.parametrize("rows", [1, 2, 4])
+def test_rollout_from_host_observation_to_host_action(golden, rows):
+    """`HipEngine.infer_host` (rmt:742-771 for a control loop whose environment lives on the CPU,
+    envs/rllib_env_imitation.py:215-266): the observation is read from pinned host memory by the first encoder launch,
+    the action is written into a pinned buffer by the decoder's last launch, and the host polls that buffer (NaN
+    pre-fill) instead of synchronising.  Same kernels as `infer`: equal bit for bit, with and without sampler noise
+    (Philox draws keyed by seed / offset), with the log-std half appended; the staged minibatch is left alone."""
+    g = golden("single_default")
+    arch = arch_from_meta(g)
+    data = R.synth_demo(0, 2, 40, arch["Db"], arch["Da"], kind="dynamics")
+    tr = make_trainer(arch, data, 32, device=DEV)
+    tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3))
+    eng, Da = tr.engine, arch["Da"]
+    obs = torch.randn(rows, 2 * arch["Db"], generator=torch.Generator().manual_seed(rows))
+    for noise in (False, True):
+        for call in range(3):                                   # the pinned buffers are re-used call after call
+            want = eng.infer(obs.to(DEV), noise=noise, seed=5, offset=call, want_s2=False)[0].cpu()
+            got = eng.infer_host(obs, noise=noise, seed=5, offset=call)
+            assert got.device.type == "cpu" and got.shape == (rows, Da) and torch.equal(got, want)
+            got_np = eng.infer_host(obs.numpy(), noise=noise, seed=5, offset=call)       # numpy observations too
+            assert torch.equal(got_np, want)
+    ls = torch.full((Da,), -1.5, device=DEV)
+    logits = eng.infer_host(obs, noise=False, log_std=ls)
+    assert logits.shape == (rows, 2 * Da) and torch.equal(logits[:, :Da], eng.infer(obs.to(DEV), noise=False, want_s2=False)[0].cpu())
+    assert torch.equal(logits[:, Da:], ls.cpu().expand(rows, -1))
+    with pytest.raises(ValueError):
+        eng.infer_host(torch.randn(5, 2 * arch["Db"]))
+    # a staged training minibatch survives the call
+    eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
+    c = R.phase_coeffs(True)
+    sp = make_step_params(lr=5e-4, a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"], s_rec=c["s_rec_coeff"],
+                          cyc=c["vae_cycle_coeff"], global_rows=32)
+    eng.gather(0, 32)
+    l0 = eng.forward_backward(_lib.PHASE_WORLD, 32, sp, backward=False).clone()
+    eng.gather(0, 32)
+    eng.infer_host(obs, noise=False)
+    assert torch.equal(eng.forward_backward(_lib.PHASE_WORLD, 32, sp, backward=False), l0)
+
+
+@pytest.mark.parametrize("rows", [1, 4, 33])
+def test_rollout_and_value_branch_with_per_layer_stacks(golden, rows):
+    """PhysicsVAE.forward (rmt:742-771) on stacks given layer by layer -- own width and activation per hidden layer,
+    FC's general layer list (rmt:234-270) --, the value branch included (rmt:846-853: `pvae_mlp_forward` with one
+    activation per hidden layer when sampling, the torch module under autograd)."""
+    from physicsvae_amd.model import PhysicsVAE
+    g = golden("single_mixed_c1")
+    arch = dict(arch_from_meta(g), vb=[(48, "tanh"), (32, "linear"), (40, "elu")])
+    data = R.synth_demo(0, 2, 40, arch["Db"], arch["Da"], kind="dynamics")
+    tr = make_trainer(arch, data, 64, device=DEV)
+    cmc = dict(tr.config["model"]["custom_model_config"], value_fn_layers=R.fc_layer_list(arch["vb"]))
+    m = PhysicsVAE(cmc["observation_space"], cmc["action_space"], 2 * arch["Da"], {"custom_model_config": cmc}, "m")
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    m.load_state_dict(sd)
+    ref = R.RefModel(arch)
+    ref.load_state_dict(sd)
+    obs = torch.randn(rows, 2 * arch["Db"], generator=torch.Generator().manual_seed(rows))
+    e = R.eps_stream(2, arch["Z"])(0, (rows, arch["Z"]))
+    ref.eps_source = lambda shape: e
+    want = ref(obs).detach()
+    with torch.no_grad():
+        logits, _ = m.forward({"obs_flat": obs.to(DEV)}, [], None, eps=e)
+        value = m.value_function().cpu()
+    assert max_err_scaled(logits.cpu(), want) < 2e-5
+    assert max_err_scaled(m._cur_future_state.cpu(), ref.cur_future_state.detach()) < 2e-5
+    assert max_err_scaled(m.task_encoder_variable().cpu(), ref.cur_z.detach()) < 2e-5
+    assert max_err_scaled(value, ref.cur_value.detach()) < 1e-4
+    v_torch, _ = m.forward_value_branch(obs.to(DEV))                 # autograd on: the plain module
+    assert v_torch.requires_grad and max_err_scaled(v_torch.detach().cpu().reshape(-1), ref.cur_value.detach().reshape(-1)) < 1e-4
+    a_hat, s2, z = m.engine.infer(obs.to(DEV), eps=e.to(DEV))
+    assert max_err_scaled(a_hat.cpu(), want[:, : arch["Da"]]) < 2e-5 and max_err_scaled(s2.cpu(), ref.cur_future_state.detach()) < 2e-5

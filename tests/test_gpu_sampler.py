@@ -1,5 +1,10 @@
-"""Round-3 GPU tests: the sampler as the prologue of the decoder's first-layer launch (opt-in A/B switch),
-the re-worked Philox stream (four normals per call)."""
+"""The reparameterisation sampler (rmt:734-740): folded into the decoder's first-layer launch vs its own launch, and the
+statistics of the Philox stream that stands in for torch.randn_like."""
+import json
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -11,10 +16,9 @@ from util import arch_from_meta, make_trainer, max_err_scaled
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name,rows", [("single_c2", 256), ("single_c2", 200), ("single_default", 192), ("single_default", 129),
-                                       ("single_c1", 64), ("single_tiny", 8)])       # (the last two: 16x16-tile layers, no fold)
 def test_sampler_folded_into_the_decoder_launch_equals_the_sampler_launch(golden, monkeypatch, name, rows):
     """PVAE_FOLD_SAMPLER=1: every workgroup of the decoder's first-layer launch forms z = mu + eps exp(logvar / 2)
     for its own 32 rows and patches it over the z columns of its input tile in LDS; column tile 0 stores z, the draws
@@ -101,75 +105,3 @@ def test_philox_draws_four_per_call_are_standard_normal_and_independent_across_c
     assert torch.equal(again, draws[3]) and not torch.equal(draws[3], draws[4])
     other = eng.reparam(ml, noise=True, seed=10, offset=3).double().cpu()
     assert not torch.equal(other, draws[3])
-
-
-@pytest.mark.parametrize("rows", [1, 2, 4])
-def test_rollout_from_host_observation_to_host_action(golden, rows):
-    """`HipEngine.infer_host` (rmt:742-771 for a control loop whose environment lives on the CPU,
-    envs/rllib_env_imitation.py:215-266): the observation is read from pinned host memory by the first encoder launch,
-    the action is written into a pinned buffer by the decoder's last launch, and the host polls that buffer (NaN
-    pre-fill) instead of synchronising.  Same kernels as `infer`: equal bit for bit, with and without sampler noise
-    (Philox draws keyed by seed / offset), with the log-std half appended; the staged minibatch is left alone."""
-    g = golden("single_default")
-    arch = arch_from_meta(g)
-    data = R.synth_demo(0, 2, 40, arch["Db"], arch["Da"], kind="dynamics")
-    tr = make_trainer(arch, data, 32, device=DEV)
-    tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3))
-    eng, Da = tr.engine, arch["Da"]
-    obs = torch.randn(rows, 2 * arch["Db"], generator=torch.Generator().manual_seed(rows))
-    for noise in (False, True):
-        for call in range(3):                                   # the pinned buffers are re-used call after call
-            want = eng.infer(obs.to(DEV), noise=noise, seed=5, offset=call, want_s2=False)[0].cpu()
-            got = eng.infer_host(obs, noise=noise, seed=5, offset=call)
-            assert got.device.type == "cpu" and got.shape == (rows, Da) and torch.equal(got, want)
-            got_np = eng.infer_host(obs.numpy(), noise=noise, seed=5, offset=call)       # numpy observations too
-            assert torch.equal(got_np, want)
-    ls = torch.full((Da,), -1.5, device=DEV)
-    logits = eng.infer_host(obs, noise=False, log_std=ls)
-    assert logits.shape == (rows, 2 * Da) and torch.equal(logits[:, :Da], eng.infer(obs.to(DEV), noise=False, want_s2=False)[0].cpu())
-    assert torch.equal(logits[:, Da:], ls.cpu().expand(rows, -1))
-    with pytest.raises(ValueError):
-        eng.infer_host(torch.randn(5, 2 * arch["Db"]))
-    # a staged training minibatch survives the call
-    eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
-    c = R.phase_coeffs(True)
-    sp = make_step_params(lr=5e-4, a_rec=c["a_rec_coeff"], kl=c["vae_kl_coeff"], s_rec=c["s_rec_coeff"],
-                          cyc=c["vae_cycle_coeff"], global_rows=32)
-    eng.gather(0, 32)
-    l0 = eng.forward_backward(_lib.PHASE_WORLD, 32, sp, backward=False).clone()
-    eng.gather(0, 32)
-    eng.infer_host(obs, noise=False)
-    assert torch.equal(eng.forward_backward(_lib.PHASE_WORLD, 32, sp, backward=False), l0)
-
-
-@pytest.mark.parametrize("rows", [1, 4, 33])
-def test_rollout_and_value_branch_with_per_layer_stacks(golden, rows):
-    """PhysicsVAE.forward (rmt:742-771) on stacks given layer by layer -- own width and activation per hidden layer,
-    FC's general layer list (rmt:234-270) --, the value branch included (rmt:846-853: `pvae_mlp_forward` with one
-    activation per hidden layer when sampling, the torch module under autograd)."""
-    from physicsvae_amd.model import PhysicsVAE
-    g = golden("single_mixed_c1")
-    arch = dict(arch_from_meta(g), vb=[(48, "tanh"), (32, "linear"), (40, "elu")])
-    data = R.synth_demo(0, 2, 40, arch["Db"], arch["Da"], kind="dynamics")
-    tr = make_trainer(arch, data, 64, device=DEV)
-    cmc = dict(tr.config["model"]["custom_model_config"], value_fn_layers=R.fc_layer_list(arch["vb"]))
-    m = PhysicsVAE(cmc["observation_space"], cmc["action_space"], 2 * arch["Da"], {"custom_model_config": cmc}, "m")
-    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
-    m.load_state_dict(sd)
-    ref = R.RefModel(arch)
-    ref.load_state_dict(sd)
-    obs = torch.randn(rows, 2 * arch["Db"], generator=torch.Generator().manual_seed(rows))
-    e = R.eps_stream(2, arch["Z"])(0, (rows, arch["Z"]))
-    ref.eps_source = lambda shape: e
-    want = ref(obs).detach()
-    with torch.no_grad():
-        logits, _ = m.forward({"obs_flat": obs.to(DEV)}, [], None, eps=e)
-        value = m.value_function().cpu()
-    assert max_err_scaled(logits.cpu(), want) < 2e-5
-    assert max_err_scaled(m._cur_future_state.cpu(), ref.cur_future_state.detach()) < 2e-5
-    assert max_err_scaled(m.task_encoder_variable().cpu(), ref.cur_z.detach()) < 2e-5
-    assert max_err_scaled(value, ref.cur_value.detach()) < 1e-4
-    v_torch, _ = m.forward_value_branch(obs.to(DEV))                 # autograd on: the plain module
-    assert v_torch.requires_grad and max_err_scaled(v_torch.detach().cpu().reshape(-1), ref.cur_value.detach().reshape(-1)) < 1e-4
-    a_hat, s2, z = m.engine.infer(obs.to(DEV), eps=e.to(DEV))
-    assert max_err_scaled(a_hat.cpu(), want[:, : arch["Da"]]) < 2e-5 and max_err_scaled(s2.cpu(), ref.cur_future_state.detach()) < 2e-5

@@ -4,7 +4,7 @@ Every other tight comparison in this suite (loss 1e-5, gradients 1e-4) starts fr
 initialisation with perturbed biases.  The trajectory lives elsewhere: after the phase switch the posterior
 collapses (KL 1e-4 .. 1e-7, mu and logvar within 1e-2 of 0), the output layers have grown from |row| = 0.01 by one
 to two orders of magnitude, the world model is fitted (its residual, the thing the MSE gradient is made of, is a
-small difference of large numbers) and the learning rate has decayed 0.7^6 .. 0.7^15.  Here the HIP path is held
+small difference of large numbers) and the learning rate has decayed 0.7^6 .. 0.7^16.  Here the HIP path is held
 
   (1) DIRECTLY to a capture of the reference's own compute_loss + backward (tpv:361-435) at weights the
       REFERENCE's trainer produced (tests/golden/trained_c1.npz, oracle/gen_golden.py case_trained: 30 world + 40
@@ -13,7 +13,7 @@ small difference of large numbers) and the learning rate has decayed 0.7^6 .. 0.
       B = 256, 4x1024, 300 world + 500 joint epochs, StepLR(50, 0.7)) at three points of that run -- end of the
       world phase, 100 joint epochs in, end of the run -- one full minibatch each: loss terms 1e-5, forward
       internals 2e-5, every gradient 1e-4 on the kink-free rows (at most 2 % filtered), plus one Adam step with the
-      decayed rate and the large step counts against torch.optim.Adam on the identical gradient, fused == flat.
+      decayed rate (0.7^6 .. 0.7^16) and the large step counts against torch.optim.Adam on the identical gradient, fused == flat.
 
 The oracle (oracle/refpath.py) is the checker only; everything measured runs through the C ABI.
 """
@@ -102,9 +102,24 @@ def run():
                              steps=dict(tr.optimizer.net_steps), lr=tr.optimizer.lr,
                              sd={k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()})
     X, Y = R.build_windows(data)
-    loader = list(R.make_loader(X, Y, 256))
-    r.batches = {300: loader[0], 400: loader[17], 800: loader[38]}       # three different full minibatches
+    r.loader = list(R.make_loader(X, Y, 256))[:39]                        # the 39 full minibatches of an epoch
+    r.batches = {300: r.loader[0], 400: r.loader[17], 800: r.loader[38]}  # (the Adam test: any full minibatch will do)
     return r
+
+
+def _kink_free_batch(r, epoch, world, start):
+    """The first full minibatch from `start` on (cyclically) with at most 2 % of its rows within 1e-6 of a ReLU kink at
+    THIS point's weights, and those rows removed.  With 12 288 hidden units per row in the joint phase an average
+    minibatch has 5-7 such rows of 256, so a fixed choice would sit on the edge of the 2 % allowance; which minibatch
+    is used is a function of the trained weights only (deterministic: the run is)."""
+    arch, sd = r.arch, r.snap[epoch]["sd"]
+    for i in range(len(r.loader)):
+        x, y = r.loader[(start + i) % len(r.loader)]
+        eps = r.eps_fn(10 ** 6 + epoch, (x.shape[0], arch["Z"]))
+        keep = R.relu_kink_margin(arch, sd, x, y, eps, world) > 1e-6
+        if int(keep.sum()) >= x.shape[0] - x.shape[0] // 50:
+            return x[keep], y[keep], eps[keep], (start + i) % len(r.loader), int((~keep).sum())
+    raise AssertionError("no minibatch of the epoch has <= 2 % of its rows on a ReLU kink")
 
 
 def _restore(r, epoch):
@@ -118,11 +133,13 @@ def _restore(r, epoch):
 
 def test_the_run_reached_the_regime_the_tight_checks_never_saw(run):
     """Guard for the fixture: the three points really are trained states (so that the comparisons below mean
-    something): world-model MSE down > 5x, KL collapsed below 1e-3, rate decayed to 0.7^15, counters 12 000 / 20 000."""
+    something): world-model MSE down > 5x, KL collapsed below 1e-3, rate decayed to 0.7^16, counters 12 000 / 20 000."""
     c = np.asarray(run.curve)
     assert c[299, 3] < 0.2 * c[0, 3]                                     # world-model MSE (loss_s)
     assert c[-1, 0] < c[300, 0] and 0.0 <= c[-1, 2] < 1e-3               # joint total falls; KL collapsed
-    assert run.snap[800]["lr"] == pytest.approx(5e-4 * 0.7 ** 15, rel=1e-12)
+    # (snapshots are taken after the epoch's scheduler tick: the rate the NEXT step would use)
+    assert run.snap[800]["lr"] == pytest.approx(5e-4 * 0.7 ** 16, rel=1e-12)
+    assert run.snap[300]["lr"] == pytest.approx(5e-4 * 0.7 ** 6, rel=1e-12)
     assert run.snap[300]["steps"][_lib.NET_WM] == 12000 and run.snap[300]["steps"][_lib.NET_TE] == 0
     assert run.snap[800]["steps"][_lib.NET_WM] == 12000 and run.snap[800]["steps"][_lib.NET_TE] == 20000
     sd0 = R.init_state_dict(run.arch, seed=1)
@@ -137,13 +154,9 @@ def test_single_step_matches_the_oracle_at_trained_weights(run, point, world):
     epoch = POINTS[point]
     s = _restore(run, epoch)
     arch, eng = run.arch, run.tr.engine
-    x, y = run.batches[epoch]
-    eps = run.eps_fn(10 ** 6 + epoch, (x.shape[0], arch["Z"]))
-    margin = R.relu_kink_margin(arch, s["sd"], x, y, eps, world)
-    keep = margin > 1e-6
-    assert int(keep.sum()) >= x.shape[0] - max(1, x.shape[0] // 50), "rows on a ReLU kink: %d" % int((~keep).sum())    # <= 2 %
-    x, y, eps = x[keep], y[keep], eps[keep]
+    x, y, eps, which, dropped = _kink_free_batch(run, epoch, world, {300: 0, 400: 17, 800: 38}[epoch])
     rows = x.shape[0]
+    assert rows >= 251 and dropped <= 5                                   # <= 2 % filtered
     want = R.loss_and_grads(arch, s["sd"], x, y, eps, world)
     eng.set_batch(x, y)
     eng.grads.fill_(float("nan"))

@@ -101,6 +101,9 @@ for name, sizes in ((("default 256x2/512x3/1024x2", []),) if QUICK else (("defau
                 lat.append((time.perf_counter() - t7) * 1e6)
             lat.sort()
             a_srv = eng.rollout_server_infer(o, noise=False)[0].copy()
+            us = sorted(eng.rollout_server_selfbench(o, n=2000))
+            print("%-28s rows  1  the same timed inside the library call (a compiled host's view)    : %6.1f us median, %6.1f us p90, "
+                  "%6.1f us min" % (name, us[len(us) // 2], us[int(len(us) * 0.9)], us[0]))
             print("%-28s rows  1  host obs -> host action, rollout server (resident kernel)   : %6.1f us median, %6.1f us p90, "
                   "%6.1f us min  (LDS %d KB per workgroup)" % (name, lat[len(lat) // 2], lat[int(len(lat) * 0.9)], lat[0],
                                                               eng.rollout_server_status()[2] // 1024))
