@@ -418,7 +418,10 @@ int pvae_infer_logits(pvae_ctx* ctx, const float* obs, int32_t rows, const float
  *                               the weights are copied from the parameter arena into LDS again first (after an
  *                               optimizer step or load_weights*, rmt:870-928).  Blocks at most timeout_ms (<= 0: 1 s).
  *   pvae_rollout_server_stop    ends the kernel (also done by pvae_destroy).
- *   pvae_rollout_server_status  *serving = 1 while the kernel is resident and answering. */
+ *   pvae_rollout_server_status  *serving != 0 while the kernel is resident and answering: 2 when the request block lives in
+ *                               DEVICE memory that the host writes through the BAR (hipDeviceAttributeIsLargeBar; the host
+ *                               pushes the observation, the kernel polls local memory), 1 when it lives in pinned host
+ *                               memory that the kernel pulls from (PVAE_SERVER_MAILBOX=host forces this form). */
 int pvae_rollout_server_start(pvae_ctx* ctx, double idle_timeout_ms, double lifetime_s);
 int pvae_rollout_server_infer(pvae_ctx* ctx, const float* obs, int noise, uint64_t rng_seed, uint64_t rng_offset, int reload,
                               float* a_hat, float* mu_logvar, float* z, double timeout_ms);

@@ -224,8 +224,17 @@ static void server_free(pvae_ctx* c);
 #ifndef PVAE_GATHER
 #define PVAE_GATHER 2
 #endif
-__global__ void __launch_bounds__(256) stage_batch_kernel(StageArgs a) {
-    __shared__ float stage_lds[PVAE_GATHER == 2 ? 4 * kStageLdsFloats : 4];
+// per-wave LDS of the gather: the smallest power of two that holds a row's sources + one DMA group of slack (2 KB at the
+// configs[2] dims, 4 KB at configs[4]'s: all eight workgroups a CU can hold are resident at once); 0: rows too wide
+static inline int stage_lds_floats(int Db, int Da) {
+    const int need = 2 * Db + Da + 64;
+    if (need > kStageLdsFloats) return 0;
+    int n = 256;
+    while (n < need) n <<= 1;
+    return n;
+}
+__global__ void __launch_bounds__(256) stage_batch_kernel(StageArgs a, int lds_floats) {
+    extern __shared__ float stage_lds[];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                      // (provably wave-uniform: the row's
     const int r = blockIdx.x * 4 + w;                                                    //  descriptors / LDS base live in SGPRs)
     if (r >= a.rows_pad) return;
@@ -234,7 +243,7 @@ __global__ void __launch_bounds__(256) stage_batch_kernel(StageArgs a) {
 #elif PVAE_GATHER == 1
     stage_row_wave(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63);
 #else
-    if (2 * a.Db + a.Da + 64 <= kStageLdsFloats) stage_row_lds(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63, stage_lds + w * kStageLdsFloats);
+    if (lds_floats > 0) stage_row_lds(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63, stage_lds + w * lds_floats, lds_floats - 1);
     else stage_row_wave(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63);
 #endif
 }
@@ -1833,7 +1842,8 @@ static int stage(pvae_ctx* c, long long first_window, const float* x, const floa
     if (rc) return rc;
     if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
     const StageArgs a = stage_args(c, first_window, x, y, rows, from_set, steps, false);
-    hipLaunchKernelGGL(stage_batch_kernel, dim3((a.rows_pad + 3) / 4, steps), dim3(256), 0, st, a);
+    const int lf = PVAE_GATHER == 2 ? stage_lds_floats(a.Db, a.Da) : 0;
+    hipLaunchKernelGGL(stage_batch_kernel, dim3((a.rows_pad + 3) / 4, steps), dim3(256), (size_t)4 * lf * sizeof(float), st, a, lf);
     HIP_TRY(hipGetLastError());
     c->staged_rows = rows;
     c->staged_rows_f = rows;
@@ -3377,15 +3387,17 @@ static int infer_impl(pvae_ctx* c, const float* obs, int32_t rows, const float* 
 // a DEVICE-wide synchronisation (hipDeviceSynchronize, hipFree) waits for it -- at most the idle time-out.
 // ---------------------------------------------------------------------------------------
 constexpr int kSrvMaxLayers = 12, kSrvGroups = 32, kSrvMaxObs = 2048, kSrvMaxOut = 1024;
-struct SrvMailbox {                       // pinned host memory, device-mapped
-    // host -> device: ONE 64-byte line of control words (a single PCIe read delivers all of them), then the observation
-    volatile uint32_t req_seq;            // written LAST by the host: request number (0: none yet)
+struct SrvRequest {                       // host -> device.  Lives in DEVICE memory when the host can write it directly
+    // (large BAR: the host PUSHES the observation and the kernel polls local memory), else in pinned host memory (the
+    // kernel PULLS over PCIe).  ONE 32-byte line of control words, then the observation.
+    volatile uint32_t req_seq;            // written LAST by the host: request number
     uint32_t cmd;                         // 0 infer, 1 stop, 2 reload the weights from the arena, then infer
     uint32_t noise, pad0;
     uint32_t seed_lo, seed_hi, off_lo, off_hi;
     uint32_t pad1[8];
     float obs[kSrvMaxObs];
-    // device -> host
+};
+struct SrvReply {                         // device -> host, pinned host memory (the host spins on its own RAM)
     volatile uint32_t done_seq;           // written LAST by the device: the request this result belongs to
     volatile uint32_t state;              // 0 not started, 1 serving, 2 exited (idle / stop / lifetime), 3 refused (placement)
     uint32_t served, pad2[13];
@@ -3400,7 +3412,9 @@ struct SrvArgs {
     const float* params;
     unsigned long long* acts;             // [n_layers + 1][kSrvActStride] TAGGED values: slot 0 = the observation, slot l + 1 = layer l's output
     unsigned* sync;                       // device words: 0 start-up barrier, 1 go_seq, 2..8 the request's control words, 16 xcc of group 0, 17 error
-    SrvMailbox* mb;
+    SrvRequest* req;                      // device view of the request block
+    SrvReply* mb;                         // device view of the reply block
+    int obs_direct;                       // the request block is device memory: every group reads the observation from it
     long long idle_ticks, life_ticks;     // 100 MHz wall clock
     int xs_off;                           // float offset of the input vector inside the dynamic LDS
     unsigned seq0;                        // requests served by earlier instances (this one answers seq0 + 1, ...)
@@ -3485,7 +3499,7 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
         if (g == 0) {
             if (wave == 0) {
                 const long long t_idle = wall_clock64();
-                const unsigned* line = (const unsigned*)&a.mb->req_seq;
+                const unsigned* line = (const unsigned*)&a.req->req_seq;
                 unsigned w = 0, seq = last, cmd = 1;
                 for (;;) {
                     if (lane < 8) w = __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // one 32-byte read
@@ -3505,11 +3519,11 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                 if (lane == 0) __hip_atomic_store(a.sync + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
-            if (s_word[1] != 1u) {                         // the observation: pinned host memory -> slot 0, tagged
+            if (s_word[1] != 1u && !a.obs_direct) {        // the observation: pinned host memory -> slot 0, tagged
                 const unsigned tag0 = s_word[0] * 16u;
                 const int n = 2 * a.Db;
                 for (int i = tid; i < n; i += 256)
-                    srv_put(a.acts + i, __hip_atomic_load(a.mb->obs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), tag0);
+                    srv_put(a.acts + i, __hip_atomic_load(a.req->obs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), tag0);
             }
         } else {
             if (tid == 0) {
@@ -3540,11 +3554,15 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
             const unsigned long long* prev = a.acts + (size_t)l * kSrvActStride;   // slot l: the previous layer's output (0: obs)
             const unsigned tagp = tag0 + (unsigned)l;
             if (l == 0) {                                                    // [s1 | s2 | 0]
-                for (int k = tid; k < L.ld; k += 256) xs[k] = k < 2 * a.Db ? srv_get(a.acts + k, tag0, t_start, a.life_ticks, failed) : 0.f;
+                for (int k = tid; k < L.ld; k += 256)
+                    xs[k] = k >= 2 * a.Db ? 0.f
+                            : a.obs_direct ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)   // (complete before
+                            : srv_get(a.acts + k, tag0, t_start, a.life_ticks, failed);                                       //  the request word)
             } else if (l == a.n_te) {                                        // [s1 | z | 0], the sampler formed in place
                 for (int k = tid; k < L.ld; k += 256) {
                     float v = 0.f;
-                    if (k < a.Db) v = srv_get(a.acts + k, tag0, t_start, a.life_ticks, failed);
+                    if (k < a.Db) v = a.obs_direct ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                                   : srv_get(a.acts + k, tag0, t_start, a.life_ticks, failed);
                     else if (k < a.Db + a.Z) {
                         const int j = k - a.Db;
                         if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_get(prev + j, tagp, t_start, a.life_ticks, failed);
@@ -3624,8 +3642,11 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
 }
 
 struct RolloutServer {
-    SrvMailbox* mb = nullptr;             // hipHostMalloc (mapped)
-    SrvMailbox* mb_dev = nullptr;
+    SrvReply* mb = nullptr;               // hipHostMalloc (mapped)
+    SrvReply* mb_dev = nullptr;
+    SrvRequest* req = nullptr;            // host view of the request block (device mode: the device pointer itself, written through the BAR)
+    SrvRequest* req_dev = nullptr;
+    bool req_on_device = false;
     unsigned* sync = nullptr;             // device
     unsigned long long* acts = nullptr;   // device: tagged hand-over words
     hipStream_t stream = nullptr;
@@ -3670,7 +3691,9 @@ static int server_plan(pvae_ctx* c, RolloutServer& S) {
 
 static int server_launch(pvae_ctx* c, RolloutServer& S) {
     HIP_TRY(hipMemsetAsync(S.sync, 0, 64 * sizeof(unsigned), S.stream));
-    S.mb->state = 0; S.mb->req_seq = S.seq; S.mb->done_seq = S.seq; S.mb->cmd = 0;
+    S.mb->state = 0; S.mb->done_seq = S.seq;
+    S.req->cmd = 0; S.req->req_seq = S.seq;
+    __builtin_ia32_sfence();                                    // (device-resident request block: write-combined stores)
     S.args.seq0 = S.seq;
     S.args.params = c->params;
     S.args.idle_ticks = (long long)(S.idle_ms * 1e5);
@@ -3704,9 +3727,28 @@ int pvae_rollout_server_start(pvae_ctx* c, double idle_timeout_ms, double lifeti
     if (S.launched && S.mb && S.mb->state == 1) return 0;                 // already serving
     if ((rc = server_plan(c, S))) return rc;
     if (!S.mb) {
-        HIP_TRY(hipHostMalloc((void**)&S.mb, sizeof(SrvMailbox), hipHostMallocMapped));
-        memset((void*)S.mb, 0, sizeof(SrvMailbox));
+        HIP_TRY(hipHostMalloc((void**)&S.mb, sizeof(SrvReply), hipHostMallocMapped));
+        memset((void*)S.mb, 0, sizeof(SrvReply));
         HIP_TRY(hipHostGetDevicePointer((void**)&S.mb_dev, (void*)S.mb, 0));
+        // The request block: with a large BAR the host reaches device memory through the pointer itself (tools/bar_probe.py),
+        // so the block lives in UNCACHED device memory -- the host pushes observation + request word, the kernel polls and
+        // reads local memory.  Otherwise (or PVAE_SERVER_MAILBOX=host) pinned host memory that the kernel pulls from.
+        int dev = 0, large_bar = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev);
+        const char* mbx = getenv("PVAE_SERVER_MAILBOX");
+        S.req_on_device = large_bar != 0 && !(mbx && mbx[0] == 'h');
+        if (mbx && mbx[0] == 'd') S.req_on_device = true;
+        if (S.req_on_device) {
+            HIP_TRY(hipExtMallocWithFlags((void**)&S.req_dev, sizeof(SrvRequest), hipDeviceMallocUncached));
+            HIP_TRY(hipMemset(S.req_dev, 0, sizeof(SrvRequest)));
+            HIP_TRY(hipDeviceSynchronize());
+            S.req = S.req_dev;
+        } else {
+            HIP_TRY(hipHostMalloc((void**)&S.req, sizeof(SrvRequest), hipHostMallocMapped));
+            memset((void*)S.req, 0, sizeof(SrvRequest));
+            HIP_TRY(hipHostGetDevicePointer((void**)&S.req_dev, (void*)S.req, 0));
+        }
         HIP_TRY(hipMalloc((void**)&S.sync, 64 * sizeof(unsigned)));
         HIP_TRY(hipMalloc((void**)&S.acts, (size_t)(kSrvMaxLayers + 1) * kSrvActStride * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(S.acts, 0, (size_t)(kSrvMaxLayers + 1) * kSrvActStride * sizeof(unsigned long long)));
@@ -3717,18 +3759,24 @@ int pvae_rollout_server_start(pvae_ctx* c, double idle_timeout_ms, double lifeti
     if (S.launched) { HIP_TRY(hipStreamSynchronize(S.stream)); S.launched = false; }   // an instance that gave up (idle): reap it
     if (idle_timeout_ms > 0) S.idle_ms = idle_timeout_ms;
     if (lifetime_s > 0) S.life_s = lifetime_s;
-    S.args.mb = S.mb_dev; S.args.sync = S.sync; S.args.acts = S.acts;
+    S.args.mb = S.mb_dev; S.args.req = S.req_dev; S.args.obs_direct = S.req_on_device ? 1 : 0;
+    S.args.sync = S.sync; S.args.acts = S.acts;
     return server_launch(c, S);
 }
 
 static int server_request(pvae_ctx* c, uint32_t cmd, const float* obs, int noise, uint64_t seed, uint64_t offset, double timeout_ms) {
     RolloutServer& S = *c->server;
-    SrvMailbox* mb = S.mb;
-    if (obs) memcpy((void*)mb->obs, obs, (size_t)2 * S.args.Db * sizeof(float));
-    mb->cmd = cmd; mb->noise = noise ? 1u : 0u;
-    mb->seed_lo = (uint32_t)seed; mb->seed_hi = (uint32_t)(seed >> 32); mb->off_lo = (uint32_t)offset; mb->off_hi = (uint32_t)(offset >> 32);
+    SrvReply* mb = S.mb;
+    SrvRequest* rq = S.req;
+    if (obs) memcpy((void*)rq->obs, obs, (size_t)2 * S.args.Db * sizeof(float));
+    rq->cmd = cmd; rq->noise = noise ? 1u : 0u;
+    rq->seed_lo = (uint32_t)seed; rq->seed_hi = (uint32_t)(seed >> 32); rq->off_lo = (uint32_t)offset; rq->off_hi = (uint32_t)(offset >> 32);
     const uint32_t seq = ++S.seq;
-    __atomic_store_n(&mb->req_seq, seq, __ATOMIC_RELEASE);
+    // the request word goes LAST: behind a store fence when the block is device memory (write-combined stores through the
+    // BAR may leave the core out of order; posted PCIe writes then arrive in the order they left)
+    if (S.req_on_device) __builtin_ia32_sfence();
+    __atomic_store_n(&rq->req_seq, seq, __ATOMIC_RELEASE);
+    if (S.req_on_device) __builtin_ia32_sfence();
     if (cmd == 1) return 0;
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
@@ -3797,7 +3845,7 @@ int pvae_rollout_server_stop(pvae_ctx* c) {
 int pvae_rollout_server_status(pvae_ctx* c, int32_t* serving, uint32_t* served, int32_t* lds_bytes) {
     if (!c) return fail(-1, "null ctx");
     const RolloutServer* S = c->server;
-    if (serving) *serving = (S && S->mb && S->launched && S->mb->state == 1u) ? 1 : 0;
+    if (serving) *serving = (S && S->mb && S->launched && S->mb->state == 1u) ? (S->req_on_device ? 2 : 1) : 0;   // 2: request block in device memory
     if (served) *served = (S && S->mb) ? S->mb->served : 0u;
     if (lds_bytes) *lds_bytes = S ? (int32_t)S->lds_bytes : 0;
     return 0;
@@ -3812,6 +3860,7 @@ static void server_free(pvae_ctx* c) {
     if (S.sync) (void)hipFree(S.sync);
     if (S.acts) (void)hipFree(S.acts);
     if (S.mb) (void)hipHostFree((void*)S.mb);
+    if (S.req) { if (S.req_on_device) (void)hipFree((void*)S.req); else (void)hipHostFree((void*)S.req); }
     delete c->server;
     c->server = nullptr;
 }

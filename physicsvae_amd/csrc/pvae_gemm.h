@@ -337,8 +337,8 @@ __device__ inline void stage_row_wave(const StageArgs& a, int r, int t, int rows
 // by the LDS reads, which cost nothing next to the memory system).  Per window at the configs[2] dims: 8 loads + 6
 // stores instead of stage_row_wave's 40 + 56 dword-granular buffer instructions (most of them out of range), which
 // made that form instruction-bound (16.2 us per 8192 windows against 13.3 for stage_row_vec).  Bit-identical (a copy).
-constexpr int kStageLdsFloats = 2048;                   // per wave
-__device__ inline void stage_row_lds(const StageArgs& a, int r, int t, int rows_pad, int lane, float* sl) {
+constexpr int kStageLdsFloats = 2048;                   // per wave, at most (the launch sizes it to the row: stage_lds_floats)
+__device__ inline void stage_row_lds(const StageArgs& a, int r, int t, int rows_pad, int lane, float* sl, int mask) {
     const int Db = a.Db, Da = a.Da;
     const size_t prow = (size_t)t * rows_pad + r;
     const bool valid = r < a.rows;
@@ -383,7 +383,7 @@ __device__ inline void stage_row_lds(const StageArgs& a, int r, int t, int rows_
             for (int e = 0; e < 4; ++e) {
                 int idx; bool on;
                 where(c + e, idx, on);
-                const float x = sl[idx & (kStageLdsFloats - 1)];
+                const float x = sl[idx & mask];
                 v[e] = on ? x : 0.f;
             }
             *reinterpret_cast<v4f*>(row + c) = v;

@@ -612,6 +612,15 @@ class HipEngine:
         if self.ctx is not None:
             _lib.check(self.lib.pvae_rollout_server_stop(self.ctx), "pvae_rollout_server_stop")
 
+    def rollout_server_mailbox(self):
+        """Where the request block lives while the server runs: "device" (the host writes device memory through the BAR,
+        the kernel polls local memory), "host" (pinned host memory the kernel pulls from), None (not serving)."""
+        a = C.c_int32()
+        if self.ctx is None:
+            return None
+        _lib.check(self.lib.pvae_rollout_server_status(self.ctx, C.byref(a), None, None), "pvae_rollout_server_status")
+        return {0: None, 1: "host", 2: "device"}[a.value]
+
     def rollout_server_status(self):
         """(serving, requests served so far, LDS bytes per workgroup)."""
         a, b, c = C.c_int32(), C.c_uint32(), C.c_int32()

@@ -40,13 +40,20 @@ def _default_trainer(batch=8, seed=1):
     return arch, tr, obs
 
 
+@pytest.mark.parametrize("mailbox", ["auto", "host"])
 @pytest.mark.parametrize("noise", [False, True])
-def test_server_equals_the_launch_path_bit_for_bit(noise):
+def test_server_equals_the_launch_path_bit_for_bit(noise, mailbox, monkeypatch):
+    """Both homes of the request block: device memory the host writes through the BAR (what a large-BAR machine gets by
+    itself) and pinned host memory the kernel pulls from."""
+    if mailbox != "auto":
+        monkeypatch.setenv("PVAE_SERVER_MAILBOX", mailbox)
     arch, tr, obs = _default_trainer()
     eng = tr.engine
     with served(eng):
         serving, _, lds = eng.rollout_server_status()
         assert serving and 64 * 1024 < lds <= 156 * 1024
+        mode = eng.rollout_server_mailbox()
+        assert mode in ("host", "device") and (mailbox != "host" or mode == "host")
         for i in range(12):
             o = obs[i]
             a, ml, z = (x.copy() for x in eng.rollout_server_infer(o.numpy(), noise=noise, seed=11, offset=1000 + i))

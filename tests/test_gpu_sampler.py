@@ -19,6 +19,8 @@ DEV = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.mark.parametrize("name,rows", [("single_c2", 256), ("single_c2", 200), ("single_default", 192), ("single_default", 129),
+                                       ("single_c1", 64), ("single_tiny", 8)])       # (the last two: 16x16-tile layers, no fold)
 def test_sampler_folded_into_the_decoder_launch_equals_the_sampler_launch(golden, monkeypatch, name, rows):
     """PVAE_FOLD_SAMPLER=1: every workgroup of the decoder's first-layer launch forms z = mu + eps exp(logvar / 2)
     for its own 32 rows and patches it over the z columns of its input tile in LDS; column tile 0 stores z, the draws

@@ -105,8 +105,9 @@ for name, sizes in ((("default 256x2/512x3/1024x2", []),) if QUICK else (("defau
             print("%-28s rows  1  the same timed inside the library call (a compiled host's view)    : %6.1f us median, %6.1f us p90, "
                   "%6.1f us min" % (name, us[len(us) // 2], us[int(len(us) * 0.9)], us[0]))
             print("%-28s rows  1  host obs -> host action, rollout server (resident kernel)   : %6.1f us median, %6.1f us p90, "
-                  "%6.1f us min  (LDS %d KB per workgroup)" % (name, lat[len(lat) // 2], lat[int(len(lat) * 0.9)], lat[0],
-                                                              eng.rollout_server_status()[2] // 1024))
+                  "%6.1f us min  (LDS %d KB per workgroup, request block in %s memory)"
+                  % (name, lat[len(lat) // 2], lat[int(len(lat) * 0.9)], lat[0], eng.rollout_server_status()[2] // 1024,
+                     eng.rollout_server_mailbox()))
             # a 30 Hz control loop: 33 ms of host work between two calls (the kernel stays resident: idle time-out 200 ms)
             lat = []
             for i in range(20):
