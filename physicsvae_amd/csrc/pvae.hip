@@ -3411,7 +3411,7 @@ struct SrvArgs {
     int Db, Da, Z, prior_kind;
     const float* params;
     unsigned long long* acts;             // [n_layers + 1][kSrvActStride] TAGGED values: slot 0 = the observation, slot l + 1 = layer l's output
-    unsigned* sync;                       // device words: 0 start-up barrier, 1 go_seq, 2..8 the request's control words, 16 xcc of group 0, 17 error
+    unsigned* sync;                       // device words: 0 start-up barrier, 1 go_seq, 2..8 the request's control words, 16 xcc of group 0, 17 error, 18 group 0 has left
     SrvRequest* req;                      // device view of the request block
     SrvReply* mb;                         // device view of the reply block
     int obs_direct;                       // the request block is device memory: every group reads the observation from it
@@ -3427,13 +3427,31 @@ __device__ inline unsigned srv_ldu(const unsigned* p) { return __hip_atomic_load
 __device__ inline void srv_put(unsigned long long* slot, float v, unsigned tag) {
     __hip_atomic_store(slot, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ inline float srv_get(const unsigned long long* slot, unsigned tag, long long t_start, long long life, int& failed) {
+__device__ inline float srv_get(const unsigned long long* slot, unsigned tag, long long t_start, long long life, int& failed,
+                                const unsigned* gone) {
     unsigned long long u;
     unsigned spins = 0;
     while ((unsigned)((u = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag) {
-        if ((++spins & 255u) == 0 && wall_clock64() - t_start > life) { failed = 1; break; }
+        // (a producer that never comes: group 0 left on its idle time-out just as this request arrived, or the lifetime is over)
+        if ((++spins & 255u) == 0 && (srv_ldu(gone) != 0u || wall_clock64() - t_start > life)) { failed = 1; break; }
     }
     return __uint_as_float((unsigned)u);
+}
+
+// Lane 0's value of `for (o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64)`: the halving tree r[i] += r[i + h], h = 32 ... 1
+// (additions commute, so only the association matters), with the two cross-row steps as gfx950's permlane swaps and the
+// four in-row steps as DPP row shifts -- register moves, where __shfl_xor compiles to a ds_bpermute round trip per step.
+// Lanes other than 0 hold partial garbage.
+__device__ inline float srv_tree_sum(float v) {
+    unsigned u = __float_as_uint(v);
+    v += __uint_as_float(__builtin_amdgcn_permlane32_swap(u, u, false, false)[1]);       // lanes 0..31 += lanes 32..63
+    u = __float_as_uint(v);
+    v += __uint_as_float(__builtin_amdgcn_permlane16_swap(u, u, false, false)[1]);       // lanes 0..15 += lanes 16..31
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x108, 0xf, 0xf, true));   // row_shl:8
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x104, 0xf, 0xf, true));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x102, 0xf, 0xf, true));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x101, 0xf, 0xf, true));
+    return v;
 }
 
 __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
@@ -3512,11 +3530,13 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
                 if (lane == 0) { s_word[0] = seq; s_word[1] = cmd; }
                 if (lane >= 2 && lane < 8) s_word[lane] = w;                   // noise, pad, seed lo / hi, offset lo / hi
-                // release the other groups at once (they start polling the observation's words)
-                if (lane >= 1 && lane < 8)
-                    __hip_atomic_store(a.sync + 1 + lane, lane == 1 ? cmd : w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(a.sync + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (!a.obs_direct) {
+                    // release the other groups at once (they start polling the observation's words)
+                    if (lane >= 1 && lane < 8)
+                        __hip_atomic_store(a.sync + 1 + lane, lane == 1 ? cmd : w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(a.sync + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             __syncthreads();
             if (s_word[1] != 1u && !a.obs_direct) {        // the observation: pinned host memory -> slot 0, tagged
@@ -3524,6 +3544,25 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                 const int n = 2 * a.Db;
                 for (int i = tid; i < n; i += 256)
                     srv_put(a.acts + i, __hip_atomic_load(a.req->obs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), tag0);
+            }
+        } else if (a.obs_direct) {
+            // the request block is device memory: every group watches its control line itself (no hop through group 0);
+            // group 0's own exits (idle time-out, lifetime) still arrive through the go word
+            if (wave == 0) {
+                const unsigned* line = (const unsigned*)&a.req->req_seq;
+                unsigned w = 0, seq = last, cmd = 1, polls = 0;
+                for (;;) {
+                    if (lane < 8) w = __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    seq = __builtin_amdgcn_readlane(w, 0);
+                    if (seq != last) { cmd = __builtin_amdgcn_readlane(w, 1); break; }
+                    if ((++polls & 15u) == 0) {
+                        if (srv_ldu(a.sync + 18) != 0u || wall_clock64() - t_start > a.life_ticks + 100000000ll) { seq = last + 1u; cmd = 1; w = 0; break; }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                if (lane == 0) { s_word[0] = seq; s_word[1] = cmd; }
+                if (lane >= 2 && lane < 8) s_word[lane] = w;
             }
         } else {
             if (tid == 0) {
@@ -3557,18 +3596,18 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                 for (int k = tid; k < L.ld; k += 256)
                     xs[k] = k >= 2 * a.Db ? 0.f
                             : a.obs_direct ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)   // (complete before
-                            : srv_get(a.acts + k, tag0, t_start, a.life_ticks, failed);                                       //  the request word)
+                            : srv_get(a.acts + k, tag0, t_start, a.life_ticks, failed, a.sync + 18);                                       //  the request word)
             } else if (l == a.n_te) {                                        // [s1 | z | 0], the sampler formed in place
                 for (int k = tid; k < L.ld; k += 256) {
                     float v = 0.f;
                     if (k < a.Db) v = a.obs_direct ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                                   : srv_get(a.acts + k, tag0, t_start, a.life_ticks, failed);
+                                                   : srv_get(a.acts + k, tag0, t_start, a.life_ticks, failed, a.sync + 18);
                     else if (k < a.Db + a.Z) {
                         const int j = k - a.Db;
-                        if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_get(prev + j, tagp, t_start, a.life_ticks, failed);
+                        if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_get(prev + j, tagp, t_start, a.life_ticks, failed, a.sync + 18);
                         else {
-                            const float mu = srv_get(prev + j, tagp, t_start, a.life_ticks, failed);
-                            const float lv = srv_get(prev + a.Z + j, tagp, t_start, a.life_ticks, failed);
+                            const float mu = srv_get(prev + j, tagp, t_start, a.life_ticks, failed, a.sync + 18);
+                            const float lv = srv_get(prev + a.Z + j, tagp, t_start, a.life_ticks, failed, a.sync + 18);
                             const float e = noise ? philox_normal(seed, offset, 0, j) : 0.f;
                             v = mu + e * expf(0.5f * lv);
                         }
@@ -3576,27 +3615,39 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                     xs[k] = v;
                 }
             } else {
-                for (int k = tid; k < L.ld; k += 256) xs[k] = srv_get(prev + k, tagp, t_start, a.life_ticks, failed);
+                for (int k = tid; k < L.ld; k += 256) xs[k] = srv_get(prev + k, tagp, t_start, a.life_ticks, failed, a.sync + 18);
             }
             if (failed) s_failed = 1;
             __syncthreads();
             const float* Wl = srv_lds + L.lds_off;
             unsigned long long* outp = a.acts + (size_t)(l + 1) * kSrvActStride;
-            for (int f = wave; f < L.F; f += 4) {                            // one wave per feature: gemv_rollout_kernel's sum
-                const float* wrow = Wl + f * L.ld;
-                float acc = 0.f;
+            // one wave per feature, gemv_rollout_kernel's sum operation for operation -- four features of the wave at a time,
+            // so that their reductions overlap, and the butterfly as register moves (srv_tree_sum) instead of six
+            // ds_bpermute round trips per feature
+            for (int f0 = wave; f0 < L.F; f0 += 16) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
                 for (int k = lane * 4; k < L.ld; k += 256) {
-                    const v4f wv = *reinterpret_cast<const v4f*>(wrow + k);
                     const v4f xv = *reinterpret_cast<const v4f*>(xs + k);
-                    acc = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc))));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int f = f0 + 4 * i;
+                        if (f < L.F) {
+                            const v4f wv = *reinterpret_cast<const v4f*>(Wl + f * L.ld + k);
+                            acc[i] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[i]))));
+                        }
+                    }
                 }
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-                if (lane == 0) {
-                    const int n = g * L.F + f;
-                    float v = acc + Wl[L.F * L.ld + f];
-                    v = (L.act > 1 && n >= L.n_out) ? 0.f : act_apply(v, L.act);
-                    srv_put(outp + n, v, tagp + 1u);
+                for (int i = 0; i < 4; ++i) acc[i] = srv_tree_sum(acc[i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = f0 + 4 * i;
+                    if (lane == 0 && f < L.F) {
+                        const int n = g * L.F + f;
+                        float v = acc[i] + Wl[L.F * L.ld + f];
+                        v = (L.act > 1 && n >= L.n_out) ? 0.f : act_apply(v, L.act);
+                        srv_put(outp + n, v, tagp + 1u);
+                    }
                 }
             }
             __syncthreads();                                                 // xs is rewritten by the next layer
@@ -3611,15 +3662,15 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
             const int n_out = a.Da + 3 * a.Z;
             for (int i = tid; i < n_out; i += 256) {
                 float v;
-                if (i < a.Da) v = srv_get(md_out + i, tag_md, t_start, a.life_ticks, failed);
+                if (i < a.Da) v = srv_get(md_out + i, tag_md, t_start, a.life_ticks, failed, a.sync + 18);
                 else if (i < a.Da + 2 * a.Z) v = a.prior_kind == PVAE_PRIOR_NONE && i >= a.Da + a.Z ? 0.f
-                                                 : srv_get(te_out + (i - a.Da), tag_te, t_start, a.life_ticks, failed);
+                                                 : srv_get(te_out + (i - a.Da), tag_te, t_start, a.life_ticks, failed, a.sync + 18);
                 else {                                                       // z as the decoder saw it (same expression as above)
                     const int j = i - a.Da - 2 * a.Z;
-                    if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_get(te_out + j, tag_te, t_start, a.life_ticks, failed);
+                    if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_get(te_out + j, tag_te, t_start, a.life_ticks, failed, a.sync + 18);
                     else {
-                        const float mu = srv_get(te_out + j, tag_te, t_start, a.life_ticks, failed);
-                        const float lv = srv_get(te_out + a.Z + j, tag_te, t_start, a.life_ticks, failed);
+                        const float mu = srv_get(te_out + j, tag_te, t_start, a.life_ticks, failed, a.sync + 18);
+                        const float lv = srv_get(te_out + a.Z + j, tag_te, t_start, a.life_ticks, failed, a.sync + 18);
                         const float e = noise ? philox_normal(seed, offset, 0, j) : 0.f;
                         v = mu + e * expf(0.5f * lv);
                     }
@@ -3628,14 +3679,14 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) {
-                a.mb->served = a.mb->served + 1u;
+            if (tid == 0) {                               // (no read of host memory on this path: the served count is the host's)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
                 __hip_atomic_store(&a.mb->done_seq, last, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
     if (g == 0 && tid == 0) {
+        __hip_atomic_store(a.sync + 18, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);       // "group 0 has left" (see srv_get)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         __hip_atomic_store(&a.mb->state, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -3652,7 +3703,7 @@ struct RolloutServer {
     hipStream_t stream = nullptr;
     SrvArgs args{};
     size_t lds_bytes = 0;
-    uint32_t seq = 0;
+    uint32_t seq = 0, served = 0;
     bool launched = false;
     double idle_ms = 100.0, life_s = 600.0;
 };
@@ -3805,6 +3856,7 @@ int pvae_rollout_server_infer(pvae_ctx* c, const float* obs, int noise, uint64_t
         const int r = server_request(c, reload ? 2u : 0u, obs, noise, rng_seed, rng_offset, timeout_ms);
         if (r < 0) return r;
         if (r == 0) {
+            ++S.served;
             const int Da = S.args.Da, Z = S.args.Z;
             memcpy(a_hat, (const void*)S.mb->out, (size_t)Da * sizeof(float));
             if (mu_logvar) memcpy(mu_logvar, (const void*)(S.mb->out + Da), (size_t)2 * Z * sizeof(float));
@@ -3846,7 +3898,7 @@ int pvae_rollout_server_status(pvae_ctx* c, int32_t* serving, uint32_t* served, 
     if (!c) return fail(-1, "null ctx");
     const RolloutServer* S = c->server;
     if (serving) *serving = (S && S->mb && S->launched && S->mb->state == 1u) ? (S->req_on_device ? 2 : 1) : 0;   // 2: request block in device memory
-    if (served) *served = (S && S->mb) ? S->mb->served : 0u;
+    if (served) *served = S ? S->served : 0u;
     if (lds_bytes) *lds_bytes = S ? (int32_t)S->lds_bytes : 0;
     return 0;
 }
