@@ -425,7 +425,8 @@ def main():
         and the same K global minibatches through a second engine on rank 0 that holds the whole global batch.  The
         loss of step k+1 is a function of the parameters step k produced, so a rank that reads STALE parameters of
         slices its peers own (replicas would still be bit-identical) shows up here and nowhere else.  Agreement is to
-        fp32 summation order: the ranks sum N shard gradients where the single process contracts over all rows."""
+        fp32 summation order: the ranks sum N shard gradients where the single process contracts over all rows (two ranks
+        on one GPU measure 7e-8 on the losses and 3e-6 on the update; the bounds are 1e-5 / 1e-3)."""
         from physicsvae_amd.engine import HipEngine
         phase, nets = set_phase(a.phase)
         snap = [t.clone() for t in (eng.params, eng.exp_avg, eng.exp_avg_sq)]
@@ -467,8 +468,8 @@ def main():
                 ud = float((d_dp - d_1).norm() / d_1.norm().clamp_min(1e-30))
                 res = {"steps": K, "global_batch": B, "losses_n_ranks": losses[:, 0].tolist(),
                        "losses_one_process": l1[:, 0].tolist(), "max_rel_loss_diff": ld, "update_rel_l2_diff": ud,
-                       "tolerance": {"loss": 2e-4, "update": 2e-2},
-                       "matches": bool(ld < 2e-4 and ud < 2e-2 and float(d_1.norm()) > 0.0)}
+                       "tolerance": {"loss": 1e-5, "update": 1e-3},
+                       "matches": bool(ld < 1e-5 and ud < 1e-3 and float(d_1.norm()) > 0.0)}
                 del e1
             except Exception as exc:                               # noqa: BLE001
                 res = {"error": str(exc)[:300], "matches": None}

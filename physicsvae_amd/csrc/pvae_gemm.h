@@ -377,14 +377,22 @@ __device__ inline void stage_row_lds(const StageArgs& a, int r, int t, int rows_
     auto put = [&](float* panel, int ld, auto&& where) {                 // 16 bytes per lane and trip
         if (!panel) return;
         float* row = panel + prow * ld;
+        // (read j of lane l takes element (j + l / 8) & 3 of the lane's four: lanes l, l + 8, l + 16, l + 24 -- whose
+        //  elements would share a bank, 4 l + e mod 32 -- hit four different banks; PMC: 70 % conflict cycles without)
+        const int rot = (lane >> 3) & 3;
         for (int c = lane * 4; c < ld; c += 256) {
-            v4f v;
+            v4f v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int j = 0; j < 4; ++j) {
+                const int e = (j + rot) & 3;
                 int idx; bool on;
                 where(c + e, idx, on);
-                const float x = sl[idx & mask];
-                v[e] = on ? x : 0.f;
+                const float raw = sl[idx & mask];                 // (unconditional: any masked index is inside the wave's image)
+                const float x = on ? raw : 0.f;
+                v[0] = e == 0 ? x : v[0];
+                v[1] = e == 1 ? x : v[1];
+                v[2] = e == 2 ? x : v[2];
+                v[3] = e == 3 ? x : v[3];
             }
             *reinterpret_cast<v4f*>(row + c) = v;
         }
@@ -1177,6 +1185,9 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
 // of 13).  One 64x32 workgroup per CU lands 24 KB per k-tile for the MFMA work of two 32x32 tiles (32 KB): a quarter
 // less DMA traffic per flop.  Every output element is still the sum of the same four k-quarters in the same order, so
 // results equal the 32x32 kernel's bit for bit.  Ring: 4 slots x 24 KB = 96 KB.
+#ifndef PVAE_XCD_GRID
+#define PVAE_XCD_GRID 0
+#endif
 #ifndef PVAE_WS64_STAGES
 #define PVAE_WS64_STAGES 4          // ring slots of the 64x32 kernel (24 KB each; A/B: 5, 6)
 #endif
@@ -1191,8 +1202,17 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
     const float* __restrict__ P = ga.P;
     const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
     const int xcd = bid & 7, loc = bid >> 3;
-    const int tile_p = xcd * ga.p_per_xcd + loc / tiles_q;
-    const int tile_q = loc % tiles_q;
+    int tile_p = xcd * ga.p_per_xcd + loc / tiles_q;
+    int tile_q = loc % tiles_q;
+#if PVAE_XCD_GRID
+    // Experiment: a 2 x 4 grid of XCDs over (row blocks, column blocks) instead of 1 x 8.  What the 8 L2s fetch from the
+    // fabric for one layer is 8 (X / a + W / b) with a b = 8: at 512 rows (X 2 MB, W 4 MB) 20 MB for 1 x 8, 16 MB for 2 x 4
+    // (at 256 rows both give 12 MB: the "2.2x over-fetch" of the forward launches is the floor of any XCD partition).
+    if (tiles_q == 8 && tiles_p == 32 && ga.p_per_xcd == 4) {
+        tile_q = (xcd & 1) * 4 + (loc & 3);
+        tile_p = (xcd >> 1) * 8 + (loc >> 2);
+    }
+#endif
     if (tile_p >= tiles_p) return;
     const int q0 = tile_q * 64, p0 = tile_p * 32;
     const int tid = threadIdx.x, lane = tid & 63;

@@ -46,7 +46,7 @@ def test_bench_plain_two_ranks_self_launch():
     # stale read of peer-written parameters could not pass while the replicas stay bit-identical
     ref = d["single_process_reference"]
     assert d["matches_single_process"] is True and d["replicas_identical"] is True, ref
-    assert ref["steps"] == 3 and ref["global_batch"] == 512 and ref["max_rel_loss_diff"] < 2e-4 and ref["update_rel_l2_diff"] < 2e-2
+    assert ref["steps"] == 3 and ref["global_batch"] == 512 and ref["max_rel_loss_diff"] < 1e-5 and ref["update_rel_l2_diff"] < 1e-3
     assert ref["losses_n_ranks"][0] != ref["losses_n_ranks"][1]                 # the steps really trained
     # every exchange form, back to back in the same run (what a multi-GPU lease must yield in one go)
     sweep = d["exchange_sweep"]
