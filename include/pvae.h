@@ -406,9 +406,13 @@ int pvae_infer_logits(pvae_ctx* ctx, const float* obs, int32_t rows, const float
  * from a layer to the next as one tagged 8-byte word that the consumer polls in that XCD's L2, no barrier -- and writes
  * the action back to the mailbox.  All pointers below are HOST pointers; the
  * calls are plain host functions (no stream, no launch) once the server runs.
- *   pvae_rollout_server_start   plans the LDS layout (-24 with a message when the stacks do not fit 156 KB per
- *                               workgroup, e.g. 4x1024: callers keep using pvae_infer), allocates the mailbox and
- *                               launches the kernel on a stream of its own; returns once it serves.  The kernel
+ *   pvae_rollout_server_start   plans the LDS layout, allocates the mailbox and launches the kernel on a stream of its own;
+ *                               returns once it serves.  scope 0: one XCD (32 workgroups; the other seven XCDs stay free
+ *                               for training launches) when 1/32 of every layer fits a CU's LDS, else the whole chip (256
+ *                               workgroups, 1/256 of every layer each: 4x1024 stacks take 122 KB per CU -- kernels that
+ *                               need more than the remaining LDS then wait for the server to leave); 1 / 2 force either
+ *                               (PVAE_SERVER_SCOPE=xcd|chip as well).  A hand-over word costs 0.43-0.53 us inside an XCD,
+ *                               0.51-0.64 us across XCDs (tools/xcd_pingpong.hip).  -24 with a message when nothing fits.  The kernel
  *                               leaves by itself after idle_timeout_ms without a request (default 100 ms; the next
  *                               pvae_rollout_server_infer brings it back) and never lives longer than lifetime_s
  *                               (default 600 s).  Arguments <= 0 keep the current / default values.  While it is
@@ -418,11 +422,12 @@ int pvae_infer_logits(pvae_ctx* ctx, const float* obs, int32_t rows, const float
  *                               the weights are copied from the parameter arena into LDS again first (after an
  *                               optimizer step or load_weights*, rmt:870-928).  Blocks at most timeout_ms (<= 0: 1 s).
  *   pvae_rollout_server_stop    ends the kernel (also done by pvae_destroy).
- *   pvae_rollout_server_status  *serving != 0 while the kernel is resident and answering: 2 when the request block lives in
+ *   pvae_rollout_server_status  *lds_bytes < 0: dealt out over the whole chip (|value| bytes per workgroup).
+ *                               *serving != 0 while the kernel is resident and answering: 2 when the request block lives in
  *                               DEVICE memory that the host writes through the BAR (hipDeviceAttributeIsLargeBar; the host
  *                               pushes the observation, the kernel polls local memory), 1 when it lives in pinned host
  *                               memory that the kernel pulls from (PVAE_SERVER_MAILBOX=host forces this form). */
-int pvae_rollout_server_start(pvae_ctx* ctx, double idle_timeout_ms, double lifetime_s);
+int pvae_rollout_server_start(pvae_ctx* ctx, double idle_timeout_ms, double lifetime_s, int scope);
 int pvae_rollout_server_infer(pvae_ctx* ctx, const float* obs, int noise, uint64_t rng_seed, uint64_t rng_offset, int reload,
                               float* a_hat, float* mu_logvar, float* z, double timeout_ms);
 int pvae_rollout_server_stop(pvae_ctx* ctx);

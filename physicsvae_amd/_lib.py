@@ -101,7 +101,7 @@ _SIGS = {
     "pvae_p2p_selftest": (C.c_int, [_P, _P]),
     "pvae_p2p_clear_errors": (C.c_int, [_P, _P]),
     "pvae_rollout_is_fused": (C.c_int, []),
-    "pvae_rollout_server_start": (C.c_int, [_P, C.c_double, C.c_double]),
+    "pvae_rollout_server_start": (C.c_int, [_P, C.c_double, C.c_double, C.c_int]),
     "pvae_rollout_server_infer": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _P, _P, _P, C.c_double]),
     "pvae_rollout_server_stop": (C.c_int, [_P]),
     "pvae_rollout_server_selfbench": (C.c_int, [_P, _P, C.c_int, C.c_int32, _P]),

@@ -3386,7 +3386,7 @@ static int infer_impl(pvae_ctx* c, const float* obs, int32_t rows, const float* 
 // next call), every spin re-checks an absolute lifetime, and a stop command ends it at once.  While it is resident,
 // a DEVICE-wide synchronisation (hipDeviceSynchronize, hipFree) waits for it -- at most the idle time-out.
 // ---------------------------------------------------------------------------------------
-constexpr int kSrvMaxLayers = 12, kSrvGroups = 32, kSrvMaxObs = 2048, kSrvMaxOut = 1024;
+constexpr int kSrvMaxLayers = 12, kSrvMaxObs = 2048, kSrvMaxOut = 1024;
 struct SrvRequest {                       // host -> device.  Lives in DEVICE memory when the host can write it directly
     // (large BAR: the host PUSHES the observation and the kernel polls local memory), else in pinned host memory (the
     // kernel PULLS over PCIe).  ONE 32-byte line of control words, then the observation.
@@ -3403,11 +3403,13 @@ struct SrvReply {                         // device -> host, pinned host memory 
     uint32_t served, pad2[13];
     float out[kSrvMaxOut];                // [a_hat (Da) | mu (Z) | logvar (Z) | z (Z)]
 };
-struct SrvLayer { long long w_off, b_off; int ld, n_out_pad, n_out, act, F, lds_off; };
+struct SrvLayer { long long w_off, b_off; int ld, n_out_pad, n_out, act, F, lds_off; };   // F: features per group (the last
+                                                                                          // active group may own fewer)
 constexpr int kSrvActStride = 2048;
 struct SrvArgs {
     SrvLayer layer[kSrvMaxLayers];
     int n_layers, n_te;                   // layers [0, n_te) are the encoder's, the rest the decoder's
+    int groups, one_xcd;                  // 32 workgroups on ONE XCD, or 256 over the whole chip (stacks too big for one XCD's LDS)
     int Db, Da, Z, prior_kind;
     const float* params;
     unsigned long long* acts;             // [n_layers + 1][kSrvActStride] TAGGED values: slot 0 = the observation, slot l + 1 = layer l's output
@@ -3458,8 +3460,8 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float srv_lds[];
     __shared__ unsigned s_word[8];
     __shared__ int s_failed;
-    if ((blockIdx.x & 7) != 0) return;                    // workgroup b runs on XCD b % 8: the 32 of XCD 0 stay
-    const int g = blockIdx.x >> 3, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.one_xcd && (blockIdx.x & 7) != 0) return;       // workgroup b runs on XCD b % 8: the 32 of XCD 0 stay
+    const int g = a.one_xcd ? blockIdx.x >> 3 : blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long t_start = wall_clock64();
     float* xs = srv_lds + a.xs_off;
     unsigned* ctr = a.sync;
@@ -3476,16 +3478,18 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
             if (wall_clock64() - t_start > a.life_ticks) break;
             __builtin_amdgcn_s_sleep(2);
         }
-        if (x0 != xcc + 1u) atomicAdd(a.sync + 17, 1u);
+        if (a.one_xcd && x0 != xcc + 1u) atomicAdd(a.sync + 17, 1u);
     }
     auto load_weights = [&]() {
         for (int l = 0; l < a.n_layers; ++l) {
             const SrvLayer L = a.layer[l];
-            const int n4 = L.F * L.ld / 4;                 // this group's rows are contiguous in the arena
+            int nf = L.n_out_pad - g * L.F;                // this group's features of the layer (0: none -- narrow layers
+            nf = nf < 0 ? 0 : (nf > L.F ? L.F : nf);       //  leave the last groups idle)
+            const int n4 = nf * L.ld / 4;                  // its rows are contiguous in the arena
             const v4f* src = reinterpret_cast<const v4f*>(a.params + L.w_off + (long long)g * L.F * L.ld);
             v4f* dst = reinterpret_cast<v4f*>(srv_lds + L.lds_off);
             for (int i = tid; i < n4; i += 256) dst[i] = src[i];
-            if (tid < L.F) srv_lds[L.lds_off + L.F * L.ld + tid] = a.params[L.b_off + g * L.F + tid];
+            if (tid < nf) srv_lds[L.lds_off + L.F * L.ld + tid] = a.params[L.b_off + g * L.F + tid];
         }
         __syncthreads();
     };
@@ -3495,9 +3499,9 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);       // executes in the L2
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned ok = 1;
-            while (srv_ldu(ctr) < (unsigned)kSrvGroups) {
+            while (srv_ldu(ctr) < (unsigned)a.groups) {
                 if (wall_clock64() - t_start > a.life_ticks) { ok = 0; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -3624,14 +3628,16 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
             // one wave per feature, gemv_rollout_kernel's sum operation for operation -- four features of the wave at a time,
             // so that their reductions overlap, and the butterfly as register moves (srv_tree_sum) instead of six
             // ds_bpermute round trips per feature
-            for (int f0 = wave; f0 < L.F; f0 += 16) {
+            int nf = L.n_out_pad - g * L.F;
+            nf = nf < 0 ? 0 : (nf > L.F ? L.F : nf);
+            for (int f0 = wave; f0 < nf; f0 += 16) {
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
                 for (int k = lane * 4; k < L.ld; k += 256) {
                     const v4f xv = *reinterpret_cast<const v4f*>(xs + k);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int f = f0 + 4 * i;
-                        if (f < L.F) {
+                        if (f < nf) {
                             const v4f wv = *reinterpret_cast<const v4f*>(Wl + f * L.ld + k);
                             acc[i] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[i]))));
                         }
@@ -3642,7 +3648,7 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int f = f0 + 4 * i;
-                    if (lane == 0 && f < L.F) {
+                    if (lane == 0 && f < nf) {
                         const int n = g * L.F + f;
                         float v = acc[i] + Wl[L.F * L.ld + f];
                         v = (L.act > 1 && n >= L.n_out) ? 0.f : act_apply(v, L.act);
@@ -3704,17 +3710,16 @@ struct RolloutServer {
     SrvArgs args{};
     size_t lds_bytes = 0;
     uint32_t seq = 0, served = 0;
+    int scope = 0;
     bool launched = false;
     double idle_ms = 100.0, life_s = 600.0;
 };
 
-static int server_plan(pvae_ctx* c, RolloutServer& S) {
+// LDS bytes per workgroup when every layer's output features are dealt out over `groups` workgroups (0: a layer or the
+// observation is wider than the server takes); fills S.args.layer / counts
+static size_t server_layout(pvae_ctx* c, RolloutServer& S, int groups) {
     const NetLayout& TE = c->L.net[PVAE_NET_TE];
     const NetLayout& MD = c->L.net[PVAE_NET_MD];
-    const int n = (int)(TE.layers.size() + MD.layers.size());
-    if (n > kSrvMaxLayers) return fail(-24, "rollout server: %d layers (at most %d)", n, kSrvMaxLayers);
-    if (c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE)
-        return fail(-24, "rollout server: this latent prior is served by the per-layer launches only");
     SrvArgs& a = S.args;
     memset(&a, 0, sizeof(a));
     int off = 0, max_ld = 0, i = 0;
@@ -3722,22 +3727,38 @@ static int server_plan(pvae_ctx* c, RolloutServer& S) {
         for (const Layer& l : N->layers) {
             SrvLayer& L = a.layer[i++];
             L.w_off = l.w_off; L.b_off = l.b_off; L.ld = l.ld; L.n_out_pad = l.n_out_pad; L.n_out = l.n_out; L.act = l.act;
-            L.F = l.n_out_pad / kSrvGroups;
-            if (L.F < 1 || L.F * kSrvGroups != l.n_out_pad) return fail(-24, "rollout server: layer width %d", l.n_out_pad);
-            if (l.n_out_pad > kSrvActStride || l.ld > kSrvActStride) return fail(-24, "rollout server: layer wider than %d", kSrvActStride);
+            L.F = (l.n_out_pad + groups - 1) / groups;
+            if (l.n_out_pad > kSrvActStride || l.ld > kSrvActStride) return 0;
             L.lds_off = off;
             off += L.F * l.ld + ((L.F + 3) & ~3);                         // rows + biases (16-byte granules)
             if (l.ld > max_ld) max_ld = l.ld;
         }
-    a.n_layers = n; a.n_te = (int)TE.layers.size();
+    a.n_layers = i; a.n_te = (int)TE.layers.size();
+    a.groups = groups; a.one_xcd = groups == 32 ? 1 : 0;
     a.Db = c->L.cfg.dim_body; a.Da = c->L.cfg.dim_action; a.Z = c->L.cfg.latent; a.prior_kind = c->L.cfg.prior_kind;
-    if (2 * a.Db > kSrvMaxObs || a.Da + 3 * a.Z > kSrvMaxOut) return fail(-24, "rollout server: observation / action too wide");
     a.xs_off = off;
-    S.lds_bytes = (size_t)(off + max_ld) * sizeof(float);
-    if (S.lds_bytes > 156 * 1024)
-        return fail(-24, "rollout server: the encoder's and decoder's weights need %zu KB of LDS per workgroup (1/32 of every "
-                         "layer), more than a CU has: these stacks are served by the per-layer launches", S.lds_bytes / 1024);
-    return 0;
+    return (size_t)(off + max_ld) * sizeof(float);
+}
+
+// scope: 0 = one XCD if the stacks fit its CUs' LDS, else the whole chip; 1 = one XCD; 2 = the whole chip
+static int server_plan(pvae_ctx* c, RolloutServer& S, int scope) {
+    const int n = (int)(c->L.net[PVAE_NET_TE].layers.size() + c->L.net[PVAE_NET_MD].layers.size());
+    if (n > kSrvMaxLayers) return fail(-24, "rollout server: %d layers (at most %d)", n, kSrvMaxLayers);
+    if (c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE)
+        return fail(-24, "rollout server: this latent prior is served by the per-layer launches only");
+    if (2 * c->L.cfg.dim_body > kSrvMaxObs || c->L.cfg.dim_action + 3 * c->L.cfg.latent > kSrvMaxOut)
+        return fail(-24, "rollout server: observation / action too wide");
+    constexpr size_t kFit = 156 * 1024;
+    size_t need = 0;
+    for (int groups : {32, 256}) {
+        if ((groups == 32 && scope == 2) || (groups == 256 && scope == 1)) continue;
+        need = server_layout(c, S, groups);
+        if (need == 0) return fail(-24, "rollout server: a layer wider than %d", kSrvActStride);
+        if (need <= kFit) { S.lds_bytes = need; return 0; }
+    }
+    return fail(-24, "rollout server: the encoder's and decoder's weights need %zu KB of LDS per workgroup even when dealt out over "
+                     "%s, more than a CU has: these stacks are served by the per-layer launches", need / 1024,
+                scope == 1 ? "the 32 CUs of one XCD" : "all 256 CUs");
 }
 
 static int server_launch(pvae_ctx* c, RolloutServer& S) {
@@ -3750,7 +3771,7 @@ static int server_launch(pvae_ctx* c, RolloutServer& S) {
     S.args.idle_ticks = (long long)(S.idle_ms * 1e5);
     S.args.life_ticks = (long long)(S.life_s * 1e8);
     HIP_TRY(hipFuncSetAttribute((const void*)rollout_server_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes));
-    hipLaunchKernelGGL(rollout_server_kernel, dim3(8 * kSrvGroups), dim3(256), S.lds_bytes, S.stream, S.args);
+    hipLaunchKernelGGL(rollout_server_kernel, dim3(256), dim3(256), S.lds_bytes, S.stream, S.args);
     HIP_TRY(hipGetLastError());
     S.launched = true;
     // until the kernel reports "serving" (or refuses): bounded
@@ -3763,20 +3784,24 @@ static int server_launch(pvae_ctx* c, RolloutServer& S) {
     if (S.mb->state == 3) {
         HIP_TRY(hipStreamSynchronize(S.stream));
         S.launched = false;
-        return fail(-24, "rollout server: its 32 workgroups were not placed on one XCD; use the per-layer launches");
+        return fail(-24, "rollout server: its 32 workgroups were not placed on one XCD; use scope 2 (whole chip) or the per-layer launches");
     }
     return 0;
 }
 
 extern "C" {
 /* see include/pvae.h */
-int pvae_rollout_server_start(pvae_ctx* c, double idle_timeout_ms, double lifetime_s) {
+int pvae_rollout_server_start(pvae_ctx* c, double idle_timeout_ms, double lifetime_s, int scope) {
     int rc = check_ready(c, true);
     if (rc) return rc;
     if (!c->server) c->server = new RolloutServer();
     RolloutServer& S = *c->server;
     if (S.launched && S.mb && S.mb->state == 1) return 0;                 // already serving
-    if ((rc = server_plan(c, S))) return rc;
+    if (scope < 0) scope = S.scope;                                       // (a relaunch keeps what the caller chose)
+    if (const char* e = getenv("PVAE_SERVER_SCOPE")) scope = e[0] == 'x' ? 1 : e[0] == 'c' ? 2 : scope;
+    if (scope < 0 || scope > 2) return fail(-1, "scope %d: 0 auto, 1 one XCD, 2 the whole chip", scope);
+    S.scope = scope;
+    if ((rc = server_plan(c, S, scope))) return rc;
     if (!S.mb) {
         HIP_TRY(hipHostMalloc((void**)&S.mb, sizeof(SrvReply), hipHostMallocMapped));
         memset((void*)S.mb, 0, sizeof(SrvReply));
@@ -3849,7 +3874,7 @@ int pvae_rollout_server_infer(pvae_ctx* c, const float* obs, int noise, uint64_t
     if (timeout_ms <= 0) timeout_ms = 1000.0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (!S.launched || S.mb->state != 1u) {                  // it left after its idle time: bring it back (weights re-read)
-            int rc = pvae_rollout_server_start(c, 0, 0);
+            int rc = pvae_rollout_server_start(c, 0, 0, -1);
             if (rc) return rc;
             reload = 0;
         }
@@ -3899,7 +3924,7 @@ int pvae_rollout_server_status(pvae_ctx* c, int32_t* serving, uint32_t* served, 
     const RolloutServer* S = c->server;
     if (serving) *serving = (S && S->mb && S->launched && S->mb->state == 1u) ? (S->req_on_device ? 2 : 1) : 0;   // 2: request block in device memory
     if (served) *served = S ? S->served : 0u;
-    if (lds_bytes) *lds_bytes = S ? (int32_t)S->lds_bytes : 0;
+    if (lds_bytes) *lds_bytes = S ? (int32_t)S->lds_bytes * (S->args.one_xcd ? 1 : -1) : 0;   // (negative: dealt out over the whole chip)
     return 0;
 }
 }   // extern "C"

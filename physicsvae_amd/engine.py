@@ -570,12 +570,15 @@ class HipEngine:
         return h_out[:rows, :width]
 
     # -- call-persistent rollout server (include/pvae.h pvae_rollout_server_*) ---------------------------------
-    def rollout_server_start(self, idle_ms=100.0, lifetime_s=600.0):
-        """Launch the resident rollout kernel (one XCD, encoder + decoder weights in LDS, mailbox in pinned host memory).
-        Raises RuntimeError when the stacks do not fit a CU's LDS (e.g. 4x1024): keep using `infer` / `infer_host` then.
+    def rollout_server_start(self, idle_ms=100.0, lifetime_s=600.0, scope="auto"):
+        """Launch the resident rollout kernel (encoder + decoder weights in LDS, request block written by the host).
+        `scope`: "xcd" = 32 workgroups on one XCD (the rest of the chip stays free), "chip" = 256 workgroups over all CUs
+        (stacks too big for one XCD, e.g. 4x1024: kernels that need more LDS than is left wait for the server to leave),
+        "auto" = one XCD when the stacks fit.  Raises RuntimeError when nothing fits: keep using `infer` / `infer_host`.
         While it is resident, device-wide synchronisations wait for it (at most `idle_ms` after the last request)."""
         self._need_gpu()
-        _lib.check(self.lib.pvae_rollout_server_start(self.ctx, float(idle_ms), float(lifetime_s)), "pvae_rollout_server_start")
+        _lib.check(self.lib.pvae_rollout_server_start(self.ctx, float(idle_ms), float(lifetime_s),
+                                                      {"auto": 0, "xcd": 1, "chip": 2}[scope]), "pvae_rollout_server_start")
         if self._srv_io is None:
             import numpy as _np
             Da, Db, Z = self.arch.Da, self.arch.Db, self.arch.Z
@@ -627,7 +630,15 @@ class HipEngine:
         if self.ctx is None:
             return False, 0, 0
         _lib.check(self.lib.pvae_rollout_server_status(self.ctx, C.byref(a), C.byref(b), C.byref(c)), "pvae_rollout_server_status")
-        return bool(a.value), b.value, c.value
+        return bool(a.value), b.value, abs(c.value)
+
+    def rollout_server_scope(self):
+        """"xcd" / "chip": over how much of the GPU the resident kernel's workgroups are dealt (None: never planned)."""
+        c = C.c_int32()
+        if self.ctx is None:
+            return None
+        _lib.check(self.lib.pvae_rollout_server_status(self.ctx, None, None, C.byref(c)), "pvae_rollout_server_status")
+        return None if c.value == 0 else ("xcd" if c.value > 0 else "chip")
 
     def infer_logits(self, obs, log_std, eps=None, noise=True, seed=0, offset=0, want_s2=True):
         """`infer` with the module's output layout: returns (logits [rows, 2 Da] = [a_hat | log_std], s2_hat|None, z)

@@ -437,15 +437,16 @@ class PhysicsVAE(nn.Module):
         return logits, state
 
     # -- the call-persistent rollout server (opt-in; include/pvae.h pvae_rollout_server_*) -------------------
-    def start_rollout_server(self, idle_ms=100.0, lifetime_s=600.0):
+    def start_rollout_server(self, idle_ms=100.0, lifetime_s=600.0, scope="auto"):
         """Serve `forward` at B = 1 from the resident rollout kernel (one XCD, encoder + decoder weights in LDS, mailbox
         in pinned host memory): a forward whose observation arrives as a CPU tensor of ONE row then costs no launch and
         no device copy, and returns CPU tensors (the 30 Hz control loop of envs/rllib_env_imitation.py:215-266 hands the
         action to a CPU simulator anyway).  Same action as the launch path, bit for bit; mu / logvar / z come with it;
         the world model's prediction and the value estimate stay lazy (launches, on first read).  The resident copy of
         the weights follows `load_state_dict` / `load_weights*`; after optimizer steps call `reload_rollout_server()`.
-        Raises RuntimeError when the stacks do not fit a CU's LDS (4x1024): the launch path stays in use."""
-        self.engine.rollout_server_start(idle_ms=idle_ms, lifetime_s=lifetime_s)
+        `scope`: "xcd" (one XCD), "chip" (all CUs: stacks too big for one XCD, e.g. 4x1024), "auto".  Raises RuntimeError when
+        nothing fits: the launch path stays in use."""
+        self.engine.rollout_server_start(idle_ms=idle_ms, lifetime_s=lifetime_s, scope=scope)
         self.__dict__["_srv_on"] = True
         self.__dict__["_srv_reload"] = False
 

@@ -22,8 +22,8 @@ DEV = "cuda"
 
 
 @contextlib.contextmanager
-def served(eng, idle_ms=200.0, lifetime_s=30.0):
-    eng.rollout_server_start(idle_ms=idle_ms, lifetime_s=lifetime_s)
+def served(eng, idle_ms=200.0, lifetime_s=30.0, scope="auto"):
+    eng.rollout_server_start(idle_ms=idle_ms, lifetime_s=lifetime_s, scope=scope)
     try:
         yield eng
     finally:
@@ -51,7 +51,7 @@ def test_server_equals_the_launch_path_bit_for_bit(noise, mailbox, monkeypatch):
     eng = tr.engine
     with served(eng):
         serving, _, lds = eng.rollout_server_status()
-        assert serving and 64 * 1024 < lds <= 156 * 1024
+        assert serving and 64 * 1024 < lds <= 156 * 1024 and eng.rollout_server_scope() == "xcd"
         mode = eng.rollout_server_mailbox()
         assert mode in ("host", "device") and (mailbox != "host" or mode == "host")
         for i in range(12):
@@ -169,21 +169,56 @@ def test_server_coexists_with_launches_on_the_compute_stream():
         assert time.perf_counter() - t0 < 5.0                           # nothing waited for an idle time-out
 
 
-def test_server_refuses_stacks_that_do_not_fit_and_the_launch_path_stays():
+def _big_trainer():
     arch = R.make_arch(197, 45, latent=32, te=(1024, 4), md=(1024, 4), wm=(1024, 4))
     data = R.synth_demo(0, 2, 20, 197, 45, kind="iid")
     tr = make_trainer(arch, data, 8, device=DEV)
+    tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, seed=2), seed=5))
+    X, _ = R.build_windows(data)
+    return arch, tr, torch.from_numpy(np.asarray(X)).float()[:, 0, :]
+
+
+def test_server_refuses_what_does_not_fit_and_the_launch_path_stays():
+    """4x1024 stacks need 459 KB per workgroup on ONE XCD: refused by name when that scope is forced; stacks that fit
+    nowhere (4x2048: 390 KB per workgroup even over all 256 CUs) are refused in every scope.  The launch path is untouched."""
+    arch, tr, obs = _big_trainer()
     eng = tr.engine
     with pytest.raises(RuntimeError, match="LDS"):
-        eng.rollout_server_start()
+        eng.rollout_server_start(scope="xcd")
     assert eng.rollout_server_status()[0] is False
     with pytest.raises(RuntimeError, match="not started"):
         eng.rollout_server_infer(np.zeros(394, np.float32))
     with pytest.raises(RuntimeError, match="not started"):
         eng.rollout_server_selfbench(np.zeros(394, np.float32), n=3)
-    X, _ = R.build_windows(data)
-    o = torch.from_numpy(np.asarray(X)).float()[:1, 0, :].to(DEV)
-    assert torch.isfinite(eng.infer(o, noise=False)[0]).all()
+    assert torch.isfinite(eng.infer(obs[:1].to(DEV), noise=False)[0]).all()
+    huge = R.make_arch(197, 45, latent=32, te=(2048, 4), md=(2048, 4), wm=(256, 2))
+    tr2 = make_trainer(huge, R.synth_demo(0, 2, 20, 197, 45, kind="iid"), 8, device=DEV)
+    with pytest.raises(RuntimeError, match="all 256 CUs"):
+        tr2.engine.rollout_server_start()
+
+
+@pytest.mark.parametrize("which", ["4x1024", "default"])
+@pytest.mark.parametrize("noise", [False, True])
+def test_chip_wide_server_equals_the_launch_path_bit_for_bit(which, noise):
+    """Stacks too big for one XCD's LDS (4x1024: 28 MB of weights) are dealt out over all 256 CUs, 1/256 of every layer's
+    features each; the hand-over words then cross XCDs (agent-scope stores / loads: 0.5-0.64 us per hop against 0.43-0.53
+    inside an XCD, tools/xcd_pingpong.hip).  Same action, mu / logvar, z as the launch path, bit for bit -- also for the
+    default stacks when the chip-wide scope is asked for."""
+    arch, tr, obs = _big_trainer() if which == "4x1024" else _default_trainer()
+    eng = tr.engine
+    with served(eng, scope="auto" if which == "4x1024" else "chip"):
+        assert eng.rollout_server_scope() == "chip" and eng.rollout_server_status()[2] <= 156 * 1024
+        for i in range(10):
+            o = obs[i]
+            a, ml, z = (x.copy() for x in eng.rollout_server_infer(o.numpy(), noise=noise, seed=5, offset=77 + i))
+            want_a, _, want_z = eng.infer(o[None].to(DEV), noise=noise, seed=5, offset=77 + i, want_s2=False)
+            assert np.array_equal(a, want_a.cpu().numpy()[0]), i
+            assert np.array_equal(z, want_z.cpu().numpy()[0]), i
+            assert np.array_equal(ml[: arch["Z"]], eng.read("mu", 1).cpu().numpy()[0]), i
+            assert np.array_equal(ml[arch["Z"]:], eng.read("logvar", 1).cpu().numpy()[0]), i
+        us = np.sort(eng.rollout_server_selfbench(obs[0].numpy(), n=300))
+        print("%s, chip-wide server: %.1f us median inside the library call" % (which, us[len(us) // 2]))
+    assert eng.rollout_server_status()[0] is False
 
 
 def test_server_latency_is_below_the_launch_path():

@@ -85,13 +85,20 @@ for name, sizes in ((("default 256x2/512x3/1024x2", []),) if QUICK else (("defau
     assert torch.equal(a_dev, a_host), "infer_host disagrees with infer"
     # the call-persistent rollout server (include/pvae.h pvae_rollout_server_*): a kernel resident on one XCD with the
     # encoder's and decoder's weights in LDS answers from a mailbox in pinned host memory -- no launch per call
-    try:
-        eng.rollout_server_start(idle_ms=200.0, lifetime_s=60.0)
-    except RuntimeError as exc:
-        print("%-28s rows  1  rollout server: %s" % (name, str(exc).split(":")[-1].strip()[:160]))
-    else:
+    for scope in (("auto",) if QUICK else ("auto", "chip")):
+        try:
+            eng.rollout_server_start(idle_ms=200.0, lifetime_s=60.0, scope=scope)
+        except RuntimeError as exc:
+            print("%-28s rows  1  rollout server: %s" % (name, str(exc).split(":")[-1].strip()[:160]))
+            continue
+        if scope == "chip" and eng.rollout_server_scope() != "chip":
+            eng.rollout_server_stop()
+            continue
         try:
             o = obs_h.numpy()[0]
+            where = "%s, LDS %d KB per workgroup, request block in %s memory" % (
+                {"xcd": "32 workgroups on one XCD", "chip": "256 workgroups over the chip"}[eng.rollout_server_scope()],
+                eng.rollout_server_status()[2] // 1024, eng.rollout_server_mailbox())
             for i in range(50):
                 eng.rollout_server_infer(o, noise=True, seed=0, offset=i)
             lat = []
@@ -102,12 +109,11 @@ for name, sizes in ((("default 256x2/512x3/1024x2", []),) if QUICK else (("defau
             lat.sort()
             a_srv = eng.rollout_server_infer(o, noise=False)[0].copy()
             us = sorted(eng.rollout_server_selfbench(o, n=2000))
-            print("%-28s rows  1  the same timed inside the library call (a compiled host's view)    : %6.1f us median, %6.1f us p90, "
-                  "%6.1f us min" % (name, us[len(us) // 2], us[int(len(us) * 0.9)], us[0]))
-            print("%-28s rows  1  host obs -> host action, rollout server (resident kernel)   : %6.1f us median, %6.1f us p90, "
-                  "%6.1f us min  (LDS %d KB per workgroup, request block in %s memory)"
-                  % (name, lat[len(lat) // 2], lat[int(len(lat) * 0.9)], lat[0], eng.rollout_server_status()[2] // 1024,
-                     eng.rollout_server_mailbox()))
+            print("%-28s rows  1  host obs -> host action, rollout server (%s)" % (name, where))
+            print("%-28s          timed inside the library call (a compiled host's view) : %6.1f us median, %6.1f us p90, %6.1f us min"
+                  % (name, us[len(us) // 2], us[int(len(us) * 0.9)], us[0]))
+            print("%-28s          through Python (ctypes)                               : %6.1f us median, %6.1f us p90, %6.1f us min"
+                  % (name, lat[len(lat) // 2], lat[int(len(lat) * 0.9)], lat[0]))
             # a 30 Hz control loop: 33 ms of host work between two calls (the kernel stays resident: idle time-out 200 ms)
             lat = []
             for i in range(20):
@@ -116,7 +122,7 @@ for name, sizes in ((("default 256x2/512x3/1024x2", []),) if QUICK else (("defau
                 eng.rollout_server_infer(o, noise=True, seed=0, offset=i)
                 lat.append((time.perf_counter() - t7) * 1e6)
             lat.sort()
-            print("%-28s rows  1  the same at 30 Hz (33 ms between calls)                      : %6.1f us median" % (name, lat[len(lat) // 2]))
+            print("%-28s          at 30 Hz (33 ms between calls), through Python         : %6.1f us median" % (name, lat[len(lat) // 2]))
         finally:
             eng.rollout_server_stop()
         assert (a_srv == a_dev.numpy()[0]).all(), "rollout server disagrees with infer"
