@@ -434,6 +434,11 @@ int pvae_rollout_server_stop(pvae_ctx* ctx);
 /* Measurement: n requests back to back with one observation, us[i] = host observation -> host action of request i on the
  * host's steady clock, taken inside the call (a compiled host's view; tools/infer_latency.py reports it next to Python's). */
 int pvae_rollout_server_selfbench(pvae_ctx* ctx, const float* obs, int noise, int32_t n, double* us);
+/* Measurement: where the LAST request's time went on the device (wall-clock stamps of workgroup 0, microseconds after it saw
+ * the request): us[1 + 2 l] = layer l's inputs in LDS, us[2 + 2 l] = layer l's outputs published, us[1 + 2 n_layers] =
+ * completion word issued, then ONE more entry: the shader clock during the request in MHz (s_memtime ticks per microsecond
+ * of the 100 MHz wall clock: a mostly-idle resident kernel lets the part clock down).  *n = entries written (at most max). */
+int pvae_rollout_server_timeline(pvae_ctx* ctx, double* us, int32_t max, int32_t* n);
 int pvae_rollout_server_status(pvae_ctx* ctx, int32_t* serving, uint32_t* served, int32_t* lds_bytes);
 
 /* A stack of Linear layers on CALLER-owned dense row-major weights (W[i]: [n_out[i]][n_in[i]], row stride

@@ -3420,6 +3420,7 @@ struct SrvArgs {
     long long idle_ticks, life_ticks;     // 100 MHz wall clock
     int xs_off;                           // float offset of the input vector inside the dynamic LDS
     unsigned seq0;                        // requests served by earlier instances (this one answers seq0 + 1, ...)
+    unsigned long long* dbg;              // [64] wall-clock stamps of group 0 for the LAST request (pvae_rollout_server_timeline)
 };
 __device__ inline unsigned srv_ldu(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // sc1: past the L1
 // A value travels between workgroups as ONE 8-byte word {tag, float bits}: the consumer polls the word itself (sc1 loads,
@@ -3438,6 +3439,46 @@ __device__ inline float srv_get(const unsigned long long* slot, unsigned tag, lo
         if ((++spins & 255u) == 0 && (srv_ldu(gone) != 0u || wall_clock64() - t_start > life)) { failed = 1; break; }
     }
     return __uint_as_float((unsigned)u);
+}
+
+__device__ inline void srv_get2(const unsigned long long* p0, const unsigned long long* p1, unsigned tag, float& v0, float& v1,
+                                long long t_start, long long life, int& failed, const unsigned* gone) {
+    unsigned long long u0, u1;
+    unsigned spins = 0;
+    for (;;) {
+        u0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(u0 >> 32) == tag && (unsigned)(u1 >> 32) == tag) break;
+        if ((++spins & 255u) == 0 && (srv_ldu(gone) != 0u || wall_clock64() - t_start > life)) { failed = 1; break; }
+    }
+    v0 = __uint_as_float((unsigned)u0);
+    v1 = __uint_as_float((unsigned)u1);
+}
+// xs[k] = word k of `prev` for k = tid, tid + 256, ... < n (tag `tag`), ALL of a thread's words polled together: their loads are
+// in flight at once and a spin costs one round trip whatever the layer's width (one word after the other, a 1024-wide input
+// cost four round trips per layer: 34 us for the 4x1024 stacks against 19 now)
+__device__ inline void srv_get_row(float* xs, const unsigned long long* prev, int n, int ld, unsigned tag, int tid, long long t_start,
+                                   long long life, int& failed, const unsigned* gone) {
+    constexpr int kMax = kSrvActStride / 256;
+    unsigned long long u[kMax];
+    unsigned spins = 0;
+    for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < kMax; ++i) {
+            const int k = tid + 256 * i;
+            u[i] = k < n ? __hip_atomic_load(prev + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+        }
+#pragma unroll
+        for (int i = 0; i < kMax; ++i) all = all && (unsigned)(u[i] >> 32) == tag;
+        if (all) break;
+        if ((++spins & 255u) == 0 && (srv_ldu(gone) != 0u || wall_clock64() - t_start > life)) { failed = 1; break; }
+    }
+#pragma unroll
+    for (int i = 0; i < kMax; ++i) {
+        const int k = tid + 256 * i;
+        if (k < ld) xs[k] = k < n ? __uint_as_float((unsigned)u[i]) : 0.f;
+    }
 }
 
 // Lane 0's value of `for (o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64)`: the halving tree r[i] += r[i + h], h = 32 ... 1
@@ -3531,15 +3572,16 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                     if (now - t_idle > a.idle_ticks || now - t_start > a.life_ticks) { seq = last + 1u; cmd = 1; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                // (no acquire fence: it would invalidate the L2, ~1.7 us; everything read after this point is read with
+                //  system- / agent-scope loads that do not hit stale lines, issued behind the load that saw the request word)
                 if (lane == 0) { s_word[0] = seq; s_word[1] = cmd; }
                 if (lane >= 2 && lane < 8) s_word[lane] = w;                   // noise, pad, seed lo / hi, offset lo / hi
                 if (!a.obs_direct) {
                     // release the other groups at once (they start polling the observation's words)
                     if (lane >= 1 && lane < 8)
                         __hip_atomic_store(a.sync + 1 + lane, lane == 1 ? cmd : w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(a.sync + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the control words have landed; a release store would
+                    if (lane == 0) __hip_atomic_store(a.sync + 1, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   //  write the L2 back)
                 }
             }
             __syncthreads();
@@ -3564,7 +3606,8 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                // (no acquire fence: it would invalidate the L2, ~1.7 us; everything read after this point is read with
+                //  system- / agent-scope loads that do not hit stale lines, issued behind the load that saw the request word)
                 if (lane == 0) { s_word[0] = seq; s_word[1] = cmd; }
                 if (lane >= 2 && lane < 8) s_word[lane] = w;
             }
@@ -3591,16 +3634,20 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
         const unsigned long long offset = s_word[6] | ((unsigned long long)s_word[7] << 32);
         const unsigned tag0 = last * 16u;
         int failed = 0;
+        const bool stamp = g == 0 && tid == 0;
+        if (stamp) { a.dbg[0] = wall_clock64(); a.dbg[62] = (unsigned long long)clock64(); }   // request seen by group 0 (+ shader clock)
         // ---- the layers: inputs polled word by word, outputs published word by word ----
         for (int l = 0; l < a.n_layers; ++l) {
             const SrvLayer L = a.layer[l];
             const unsigned long long* prev = a.acts + (size_t)l * kSrvActStride;   // slot l: the previous layer's output (0: obs)
             const unsigned tagp = tag0 + (unsigned)l;
             if (l == 0) {                                                    // [s1 | s2 | 0]
-                for (int k = tid; k < L.ld; k += 256)
-                    xs[k] = k >= 2 * a.Db ? 0.f
-                            : a.obs_direct ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)   // (complete before
-                            : srv_get(a.acts + k, tag0, t_start, a.life_ticks, failed, a.sync + 18);                                       //  the request word)
+                if (a.obs_direct) {                                          // (complete before the request word)
+                    for (int k = tid; k < L.ld; k += 256)
+                        xs[k] = k < 2 * a.Db ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
+                } else {
+                    srv_get_row(xs, a.acts, 2 * a.Db, L.ld, tag0, tid, t_start, a.life_ticks, failed, a.sync + 18);
+                }
             } else if (l == a.n_te) {                                        // [s1 | z | 0], the sampler formed in place
                 for (int k = tid; k < L.ld; k += 256) {
                     float v = 0.f;
@@ -3610,19 +3657,20 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                         const int j = k - a.Db;
                         if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_get(prev + j, tagp, t_start, a.life_ticks, failed, a.sync + 18);
                         else {
-                            const float mu = srv_get(prev + j, tagp, t_start, a.life_ticks, failed, a.sync + 18);
-                            const float lv = srv_get(prev + a.Z + j, tagp, t_start, a.life_ticks, failed, a.sync + 18);
-                            const float e = noise ? philox_normal(seed, offset, 0, j) : 0.f;
+                            const float e = noise ? philox_normal(seed, offset, 0, j) : 0.f;       // (before the wait: off its path)
+                            float mu, lv;
+                            srv_get2(prev + j, prev + a.Z + j, tagp, mu, lv, t_start, a.life_ticks, failed, a.sync + 18);
                             v = mu + e * expf(0.5f * lv);
                         }
                     }
                     xs[k] = v;
                 }
             } else {
-                for (int k = tid; k < L.ld; k += 256) xs[k] = srv_get(prev + k, tagp, t_start, a.life_ticks, failed, a.sync + 18);
+                srv_get_row(xs, prev, L.ld, L.ld, tagp, tid, t_start, a.life_ticks, failed, a.sync + 18);
             }
             if (failed) s_failed = 1;
             __syncthreads();
+            if (stamp) a.dbg[1 + 2 * l] = wall_clock64();                    // layer l: inputs in LDS
             const float* Wl = srv_lds + L.lds_off;
             unsigned long long* outp = a.acts + (size_t)(l + 1) * kSrvActStride;
             // one wave per feature, gemv_rollout_kernel's sum operation for operation -- four features of the wave at a time,
@@ -3631,32 +3679,61 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
             int nf = L.n_out_pad - g * L.F;
             nf = nf < 0 ? 0 : (nf > L.F ? L.F : nf);
             for (int f0 = wave; f0 < nf; f0 += 16) {
-                float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int k = lane * 4; k < L.ld; k += 256) {
-                    const v4f xv = *reinterpret_cast<const v4f*>(xs + k);
+                const int cnt = (nf - f0 + 3) >> 2;                          // features f0, f0 + 4, ... of this wave in this pass
+                auto rows = [&](auto nrows) {                                // (one unguarded body per count: the LDS reads of a
+                    constexpr int N = decltype(nrows)::value;                //  k-step are in flight together)
+                    float acc[N];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int f = f0 + 4 * i;
-                        if (f < nf) {
-                            const v4f wv = *reinterpret_cast<const v4f*>(Wl + f * L.ld + k);
-                            acc[i] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[i]))));
-                        }
+                    for (int i = 0; i < N; ++i) acc[i] = 0.f;
+                    for (int k = lane * 4; k < L.ld; k += 256) {
+                        const v4f xv = *reinterpret_cast<const v4f*>(xs + k);
+                        v4f wv[N];
+#pragma unroll
+                        for (int i = 0; i < N; ++i) wv[i] = *reinterpret_cast<const v4f*>(Wl + (f0 + 4 * i) * L.ld + k);
+#pragma unroll
+                        for (int i = 0; i < N; ++i)
+                            acc[i] = fmaf(wv[i].x, xv.x, fmaf(wv[i].y, xv.y, fmaf(wv[i].z, xv.z, fmaf(wv[i].w, xv.w, acc[i]))));
                     }
-                }
+#ifdef PVAE_SRV_FINE
+                    if (stamp && l == 4) a.dbg[40] = wall_clock64();
+#endif
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = srv_tree_sum(acc[i]);
+                    for (int i = 0; i < N; ++i) acc[i] = srv_tree_sum(acc[i]);
+#ifdef PVAE_SRV_FINE
+                    if (stamp && l == 4) a.dbg[41] = wall_clock64();
+#endif
+                    // lane i finishes feature i (bias, activation, hand-over word): the N epilogues run side by side instead of
+                    // one after the other on lane 0 (0.6 us of a 1.3 us layer when they did)
+                    float mine = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int f = f0 + 4 * i;
-                    if (lane == 0 && f < nf) {
-                        const int n = g * L.F + f;
-                        float v = acc[i] + Wl[L.F * L.ld + f];
+                    for (int i = 0; i < N; ++i) {
+                        const float si = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc[i]), 0));
+                        mine = lane == i ? si : mine;
+                    }
+                    if (lane < N) {
+                        const int f = f0 + 4 * lane, n = g * L.F + f;
+                        float v = mine + Wl[L.F * L.ld + f];
                         v = (L.act > 1 && n >= L.n_out) ? 0.f : act_apply(v, L.act);
                         srv_put(outp + n, v, tagp + 1u);
                     }
-                }
+                };
+#ifdef PVAE_SRV_FINE
+                if (stamp && l == 4) a.dbg[39] = wall_clock64();
+#endif
+                if (cnt >= 4) rows(std::integral_constant<int, 4>());
+                else if (cnt == 3) rows(std::integral_constant<int, 3>());
+                else if (cnt == 2) rows(std::integral_constant<int, 2>());
+                else rows(std::integral_constant<int, 1>());
             }
-            __syncthreads();                                                 // xs is rewritten by the next layer
+            // (a bare barrier: only LDS is shared here.  __syncthreads() would also wait for the hand-over stores above to be
+            //  acknowledged by the memory system -- half a microsecond per layer that now overlaps the next layer's polling)
+#ifdef PVAE_SRV_FINE
+            if (stamp && l == 4) a.dbg[42] = wall_clock64();
+#endif
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (stamp) a.dbg[2 + 2 * l] = wall_clock64();                    // layer l: this group's outputs published
             if (s_failed) break;
         }
         if (s_failed) { alive = false; break; }
@@ -3675,9 +3752,9 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                     const int j = i - a.Da - 2 * a.Z;
                     if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_get(te_out + j, tag_te, t_start, a.life_ticks, failed, a.sync + 18);
                     else {
-                        const float mu = srv_get(te_out + j, tag_te, t_start, a.life_ticks, failed, a.sync + 18);
-                        const float lv = srv_get(te_out + a.Z + j, tag_te, t_start, a.life_ticks, failed, a.sync + 18);
                         const float e = noise ? philox_normal(seed, offset, 0, j) : 0.f;
+                        float mu, lv;
+                        srv_get2(te_out + j, te_out + a.Z + j, tag_te, mu, lv, t_start, a.life_ticks, failed, a.sync + 18);
                         v = mu + e * expf(0.5f * lv);
                     }
                 }
@@ -3685,9 +3762,14 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) {                               // (no read of host memory on this path: the served count is the host's)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-                __hip_atomic_store(&a.mb->done_seq, last, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // (no read of host memory on this path, and no release fence -- it would write the whole L2 back, twice: the payload
+            //  went out as system-scope stores that are not cached, the wait above saw them acknowledged, and posted writes of
+            //  one agent arrive in order)
+            if (tid == 0) {
+                __hip_atomic_store(&a.mb->done_seq, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                a.dbg[1 + 2 * a.n_layers] = wall_clock64();                  // completion word issued
+                a.dbg[2 + 2 * a.n_layers] = (unsigned long long)a.n_layers;
+                a.dbg[63] = (unsigned long long)clock64();
             }
         }
     }
@@ -3705,6 +3787,7 @@ struct RolloutServer {
     SrvRequest* req_dev = nullptr;
     bool req_on_device = false;
     unsigned* sync = nullptr;             // device
+    unsigned long long* dbg = nullptr;    // device: group 0's stamps of the last request
     unsigned long long* acts = nullptr;   // device: tagged hand-over words
     hipStream_t stream = nullptr;
     SrvArgs args{};
@@ -3826,6 +3909,8 @@ int pvae_rollout_server_start(pvae_ctx* c, double idle_timeout_ms, double lifeti
             HIP_TRY(hipHostGetDevicePointer((void**)&S.req_dev, (void*)S.req, 0));
         }
         HIP_TRY(hipMalloc((void**)&S.sync, 64 * sizeof(unsigned)));
+        HIP_TRY(hipMalloc((void**)&S.dbg, 64 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(S.dbg, 0, 64 * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc((void**)&S.acts, (size_t)(kSrvMaxLayers + 1) * kSrvActStride * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(S.acts, 0, (size_t)(kSrvMaxLayers + 1) * kSrvActStride * sizeof(unsigned long long)));
         int lo = 0, hi = 0;
@@ -3836,7 +3921,7 @@ int pvae_rollout_server_start(pvae_ctx* c, double idle_timeout_ms, double lifeti
     if (idle_timeout_ms > 0) S.idle_ms = idle_timeout_ms;
     if (lifetime_s > 0) S.life_s = lifetime_s;
     S.args.mb = S.mb_dev; S.args.req = S.req_dev; S.args.obs_direct = S.req_on_device ? 1 : 0;
-    S.args.sync = S.sync; S.args.acts = S.acts;
+    S.args.sync = S.sync; S.args.acts = S.acts; S.args.dbg = S.dbg;
     return server_launch(c, S);
 }
 
@@ -3907,6 +3992,24 @@ int pvae_rollout_server_selfbench(pvae_ctx* c, const float* obs, int noise, int3
     return 0;
 }
 
+/* Where the last request's time went on the device: us[0] = 0 (request seen by workgroup 0), us[1 + 2 l] = layer l's inputs
+ * in LDS, us[2 + 2 l] = layer l's outputs published, us[1 + 2 n_layers] = completion word issued; *n = entries written. */
+int pvae_rollout_server_timeline(pvae_ctx* c, double* us, int32_t max, int32_t* n) {
+    if (!c || !c->server || !c->server->dbg) return fail(-2, "rollout server not started (pvae_rollout_server_start)");
+    unsigned long long t[64];
+    HIP_TRY(hipMemcpy(t, c->server->dbg, sizeof(t), hipMemcpyDeviceToHost));
+    const int cnt = 2 + 2 * c->server->args.n_layers;
+    int m = 0;
+    for (; m < cnt && m < max; ++m) us[m] = (double)(long long)(t[m] - t[0]) / 100.0;
+    // last entry: the shader clock during the request, MHz (s_memtime ticks per microsecond of the 100 MHz wall clock)
+    if (m < max && cnt >= 2 && t[cnt - 1] > t[0]) us[m++] = (double)(long long)(t[63] - t[62]) / ((double)(long long)(t[cnt - 1] - t[0]) / 100.0);
+#ifdef PVAE_SRV_FINE
+    for (int k = 39; k <= 42 && m < max; ++k) us[m++] = (double)(long long)(t[k] - t[0]) / 100.0;
+#endif
+    if (n) *n = m;
+    return 0;
+}
+
 int pvae_rollout_server_stop(pvae_ctx* c) {
     if (!c) return fail(-1, "null ctx");
     if (!c->server || !c->server->mb) return 0;
@@ -3935,6 +4038,7 @@ static void server_free(pvae_ctx* c) {
     RolloutServer& S = *c->server;
     if (S.stream) (void)hipStreamDestroy(S.stream);
     if (S.sync) (void)hipFree(S.sync);
+    if (S.dbg) (void)hipFree(S.dbg);
     if (S.acts) (void)hipFree(S.acts);
     if (S.mb) (void)hipHostFree((void*)S.mb);
     if (S.req) { if (S.req_on_device) (void)hipFree((void*)S.req); else (void)hipHostFree((void*)S.req); }

@@ -611,6 +611,14 @@ class HipEngine:
                    "pvae_rollout_server_selfbench")
         return us
 
+    def rollout_server_timeline(self):
+        """Microseconds after workgroup 0 saw the LAST request: [0, layer 0 inputs in LDS, layer 0 outputs published, ...,
+        completion word issued], and the shader clock during that request in MHz -> (stamps, mhz)."""
+        import numpy as _np
+        us, n = _np.zeros(64, _np.float64), C.c_int32()
+        _lib.check(self.lib.pvae_rollout_server_timeline(self.ctx, us.ctypes.data, 64, C.byref(n)), "pvae_rollout_server_timeline")
+        return us[: n.value - 1], float(us[n.value - 1])
+
     def rollout_server_stop(self):
         if self.ctx is not None:
             _lib.check(self.lib.pvae_rollout_server_stop(self.ctx), "pvae_rollout_server_stop")

@@ -114,6 +114,9 @@ for name, sizes in ((("default 256x2/512x3/1024x2", []),) if QUICK else (("defau
                   % (name, us[len(us) // 2], us[int(len(us) * 0.9)], us[0]))
             print("%-28s          through Python (ctypes)                               : %6.1f us median, %6.1f us p90, %6.1f us min"
                   % (name, lat[len(lat) // 2], lat[int(len(lat) * 0.9)], lat[0]))
+            tl, mhz = eng.rollout_server_timeline()
+            print("%-28s          on the device, us after workgroup 0 saw the request: %s | reply issued %.1f | shader clock %.0f MHz"
+                  % (name, "  ".join("L%d in %.1f out %.1f" % (l, tl[1 + 2 * l], tl[2 + 2 * l]) for l in range((len(tl) - 2) // 2)), tl[-1], mhz))
             # a 30 Hz control loop: 33 ms of host work between two calls (the kernel stays resident: idle time-out 200 ms)
             lat = []
             for i in range(20):
