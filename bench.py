@@ -670,9 +670,18 @@ def main():
             torch.cuda.synchronize()
             us_b = e0.elapsed_time(e1) * 1e3 / 50
             gb = 2.0 * big_rows * (2 * Db + Da) * 4
+            # what the launch really moves: every window is written into FIVE padded panels (encoder [s1|s2], decoder [s1|z],
+            # world model [s1|a], the two targets: each stack's first layer contracts over a dense 64-float-aligned panel of
+            # its own) -- 2.9x the algorithmic write bytes at these dims, which caps `frac` at ~0.4 whatever the kernel does
+            pad = lambda n: (n + 63) // 64 * 64                                                     # noqa: E731
+            real = big_rows * 4.0 * ((2 * Db + Da) + pad(2 * Db) + pad(Db + Z) + pad(Db + Da) + pad(Db) + pad(Da))
             out["gather_roofline"]["bandwidth_bound_case"] = {
                 "rows": big_rows, "algorithmic_bytes_per_launch": gb, "avg_launch_us": us_b,
-                "achieved": gb / (us_b * 1e-6) / 1e9, "unit": "GB/s", "frac": gb / (us_b * 1e-6) / 1e9 / 8000.0}
+                "achieved": gb / (us_b * 1e-6) / 1e9, "unit": "GB/s", "frac": gb / (us_b * 1e-6) / 1e9 / 8000.0,
+                "panel_bytes_per_launch": real, "achieved_panel_traffic": real / (us_b * 1e-6) / 1e9,
+                "frac_panel_traffic": real / (us_b * 1e-6) / 1e9 / 8000.0,
+                "note": "achieved / frac: SURVEY.md 8d's algorithmic bytes ((2 Db + Da) * 4 read + the same written per window); "
+                        "panel traffic: the bytes the five padded input / target panels of a window really take (DESIGN.md section 4)"}
             del ge
         except Exception as exc:                                   # noqa: BLE001
             out["gather_roofline"]["bandwidth_bound_case"] = {"error": str(exc)[:200]}

@@ -3410,6 +3410,7 @@ struct SrvArgs {
     SrvLayer layer[kSrvMaxLayers];
     int n_layers, n_te;                   // layers [0, n_te) are the encoder's, the rest the decoder's
     int groups, one_xcd;                  // 32 workgroups on ONE XCD, or 256 over the whole chip (stacks too big for one XCD's LDS)
+    int xcd;                              // which XCD (one_xcd): servers of one process take different ones
     int Db, Da, Z, prior_kind;
     const float* params;
     unsigned long long* acts;             // [n_layers + 1][kSrvActStride] TAGGED values: slot 0 = the observation, slot l + 1 = layer l's output
@@ -3501,7 +3502,7 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float srv_lds[];
     __shared__ unsigned s_word[8];
     __shared__ int s_failed;
-    if (a.one_xcd && (blockIdx.x & 7) != 0) return;       // workgroup b runs on XCD b % 8: the 32 of XCD 0 stay
+    if (a.one_xcd && (int)(blockIdx.x & 7) != a.xcd) return;   // workgroup b runs on XCD b % 8: the 32 of one XCD stay
     const int g = a.one_xcd ? blockIdx.x >> 3 : blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long t_start = wall_clock64();
     float* xs = srv_lds + a.xs_off;
@@ -3793,7 +3794,7 @@ struct RolloutServer {
     SrvArgs args{};
     size_t lds_bytes = 0;
     uint32_t seq = 0, served = 0;
-    int scope = 0;
+    int scope = 0, xcd = -1;
     bool launched = false;
     double idle_ms = 100.0, life_s = 600.0;
 };
@@ -3922,6 +3923,10 @@ int pvae_rollout_server_start(pvae_ctx* c, double idle_timeout_ms, double lifeti
     if (lifetime_s > 0) S.life_s = lifetime_s;
     S.args.mb = S.mb_dev; S.args.req = S.req_dev; S.args.obs_direct = S.req_on_device ? 1 : 0;
     S.args.sync = S.sync; S.args.acts = S.acts; S.args.dbg = S.dbg;
+    // (every server of this process on an XCD of its own: two engines can serve side by side)
+    static int next_xcd = 0;
+    if (S.xcd < 0) S.xcd = next_xcd++ & 7;
+    S.args.xcd = S.xcd;
     return server_launch(c, S);
 }
 

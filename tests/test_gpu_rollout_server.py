@@ -151,6 +151,21 @@ def test_module_forward_served_equals_module_forward_launched():
     assert torch.equal(second, call(obs[:1].to(DEV))[0])
 
 
+def test_two_engines_serve_side_by_side():
+    """Two models in one process, each with a resident server: they take different XCDs and answer independently."""
+    arch, tr1, obs = _default_trainer(seed=1)
+    _, tr2, _ = _default_trainer(seed=7)
+    e1, e2 = tr1.engine, tr2.engine
+    with served(e1, idle_ms=2000.0), served(e2, idle_ms=2000.0):
+        for i in range(6):
+            o = obs[i]
+            a1 = e1.rollout_server_infer(o.numpy(), noise=True, seed=2, offset=i)[0].copy()
+            a2 = e2.rollout_server_infer(o.numpy(), noise=True, seed=2, offset=i)[0].copy()
+            assert np.array_equal(a1, e1.infer(o[None].to(DEV), noise=True, seed=2, offset=i, want_s2=False)[0].cpu().numpy()[0])
+            assert np.array_equal(a2, e2.infer(o[None].to(DEV), noise=True, seed=2, offset=i, want_s2=False)[0].cpu().numpy()[0])
+            assert not np.array_equal(a1, a2)
+
+
 def test_server_coexists_with_launches_on_the_compute_stream():
     """Training steps and per-layer rollout launches run while the server is resident (its stream has a hardware queue
     of its own; the other XCDs' CUs are free), and requests are answered in between."""
