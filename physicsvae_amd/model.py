@@ -138,6 +138,7 @@ class AppendLogStd(nn.Module):
         assert np.isscalar(val), "Only scalar is currently supported"
         self.log_std[:] = float(val)
         self._dev = None
+        self._ver = getattr(self, "_ver", 0) + 1
 
     def on_device(self, device):
         """The vector as a device tensor for the inference launches (a constant log_std lives on the host, as
@@ -464,28 +465,42 @@ class PhysicsVAE(nn.Module):
         return out
 
     def _forward_served(self, obs, state, noise):
-        eng, st = self.engine, self._st
+        """One served forward.  The library writes straight into persistent CPU tensors (no per-call allocation; the
+        `_cur_*` tensors of this path are valid until the next forward, the returned logits are a fresh copy)."""
+        st, d = self._st, self.__dict__
         st._rng_calls += 1
-        d = self.__dict__
-        a, ml, z = eng.rollout_server_infer(obs, noise=noise, seed=self._rng_seed, offset=st._rng_calls,
-                                            reload=d.get("_srv_reload", False))
-        d["_srv_reload"] = False
+        io = d.get("_srv_t")
         Da, Z = self.dim_action, self._task_encoder_output_dim
-        logits = torch.empty(1, 2 * Da)
-        logits[0, :Da] = torch.from_numpy(a)
-        logits[0, Da:] = d["_als"].log_std.detach().cpu().reshape(-1)       # (a host tensor already when "constant")
+        if io is None:
+            import ctypes as _C
+            t_obs, t_log, t_ml, t_z = torch.zeros(1, 2 * self.dim_state_body), torch.zeros(1, 2 * Da), torch.zeros(1, 2 * Z), torch.zeros(1, Z)
+            io = d["_srv_t"] = (t_obs, t_log, t_ml, t_z, t_ml[:, :Z], t_ml[:, Z:], t_obs[:, : self.dim_state_body],
+                                tuple(_C.c_void_p(t.data_ptr()) for t in (t_obs, t_log, t_ml, t_z)), self.engine.lib.pvae_rollout_server_infer)
+            d["_srv_ls"] = None
+        t_obs, t_log, t_ml, t_z, v_mu, v_lv, v_s1, ptrs, fn = io
+        als = d["_als"]
+        ls = als.log_std
+        if d["_srv_ls"] is not ls or als.type != "constant" or d.get("_srv_ls_ver") != getattr(als, "_ver", 0):
+            t_log[0, Da:] = ls.detach().cpu().reshape(-1)          # [a_hat | log_std] (AppendLogStd, rmt:160-206)
+            d["_srv_ls"], d["_srv_ls_ver"] = ls, getattr(als, "_ver", 0)
+        t_obs.copy_(obs)
+        rc = fn(self.engine.ctx, ptrs[0], 1 if noise else 0, self._rng_seed, st._rng_calls, 1 if d.get("_srv_reload") else 0,
+                ptrs[1], ptrs[2], ptrs[3], 1000.0)
+        if rc:
+            from . import _lib
+            _lib.check(rc, "pvae_rollout_server_infer")
+        d["_srv_reload"] = False
         st._cur_future_state = None
-        st._cur_body_encoder_variable = obs[..., : self.dim_state_body]
-        st._cur_task_encoder_variable = torch.from_numpy(z.copy())[None]
-        keep = obs.clone()
-        st._lazy = (keep, 1, None, noise, st._rng_calls) if self.rollout_predicts_state == "lazy" else (keep, 1)
+        st._cur_body_encoder_variable = v_s1
+        st._cur_task_encoder_variable = t_z
+        st._lazy = (t_obs, 1, None, noise, st._rng_calls) if self.rollout_predicts_state == "lazy" else (t_obs, 1)
         st._cur_value = None
         if self._latent_prior_type is False:
-            st._mu, st._logvar = st._cur_task_encoder_variable, None
+            st._mu, st._logvar = t_z, None
         else:
-            st._mu, st._logvar = torch.from_numpy(ml[:Z].copy())[None], torch.from_numpy(ml[Z:].copy())[None]
+            st._mu, st._logvar = v_mu, v_lv
         st._cur_latent_prior_mu = None
-        return logits, state
+        return t_log.clone(), state
 
     def _forward_staged(self, obs, state, seq_lens, eps=None):
         """The same forward stage by stage (forward_encoder / forward_decoder / forward_world): batches

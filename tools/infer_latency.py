@@ -152,3 +152,24 @@ for name, sizes in ((("default 256x2/512x3/1024x2", []),) if QUICK else (("defau
         lat.sort()
         print("%-28s rows  1  PhysicsVAE.forward%s : %6.1f us single-call latency"
               % (name, " + value_function()" if with_value else "                   ", lat[len(lat) // 2]))
+    # the same module call served by the resident kernel: a one-row CPU observation in, CPU logits out
+    try:
+        m.start_rollout_server(idle_ms=200.0, lifetime_s=60.0)
+    except RuntimeError:
+        pass
+    else:
+        try:
+            obs_c = obs1.cpu()
+            lat = []
+            with torch.no_grad():
+                for _ in range(50):
+                    m.forward({"obs_flat": obs_c}, [], None)
+                for _ in range(300):
+                    t5 = time.perf_counter()
+                    logits, _ = m.forward({"obs_flat": obs_c}, [], None)
+                    lat.append((time.perf_counter() - t5) * 1e6)
+            lat.sort()
+            print("%-28s rows  1  PhysicsVAE.forward, CPU observation, served by the resident kernel : %6.1f us median"
+                  % (name, lat[len(lat) // 2]))
+        finally:
+            m.stop_rollout_server()
