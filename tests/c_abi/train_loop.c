@@ -1,7 +1,8 @@
 /* A host written in plain C against include/pvae.h: no Python, no torch -- only the HIP runtime
  * for device memory.  It is what a compiled caller of the drop-in boundary looks like:
  * query the layout, allocate the arenas, bind a demonstration set, run world-model steps and then
- * joint steps with pvae_train_step, read the losses back.
+ * joint steps with pvae_train_step, read the losses back; then serve one observation through the launches and through the
+ * call-persistent rollout server and compare the actions.
  *
  *   gcc -std=c11 -D__HIP_PLATFORM_AMD__ tests/c_abi/train_loop.c -Iinclude -I/opt/rocm/include \
  *       -L/opt/rocm/lib -lamdhip64 -ldl -lm -o train_loop
@@ -35,6 +36,11 @@ typedef int (*pvae_bind_arenas_t)(pvae_ctx*, float*, float*, float*, float*);
 typedef int (*pvae_bind_workspace_t)(pvae_ctx*, void*, size_t);
 typedef int (*pvae_bind_dataset_t)(pvae_ctx*, const float*, const float*, const int32_t*, int64_t, int64_t);
 typedef int (*pvae_train_step_t)(pvae_ctx*, int, int64_t, int32_t, const pvae_step_params*, const float*, float*, void*);
+typedef int (*pvae_infer_t)(pvae_ctx*, const float*, int32_t, const float*, int, uint64_t, uint64_t, float*, float*, float*, void*);
+typedef int (*pvae_rollout_server_start_t)(pvae_ctx*, double, double, int);
+typedef int (*pvae_rollout_server_infer_t)(pvae_ctx*, const float*, int, uint64_t, uint64_t, int, float*, float*, float*, double);
+typedef int (*pvae_rollout_server_selfbench_t)(pvae_ctx*, const float*, int, int32_t, double*);
+typedef int (*pvae_rollout_server_stop_t)(pvae_ctx*);
 
 static uint32_t lcg_state = 12345u;
 static float uniform(void) {                     /* (-1, 1) */
@@ -48,7 +54,8 @@ int main(int argc, char** argv) {
     if (!h) { fprintf(stderr, "dlopen %s: %s\n", path, dlerror()); return 2; }
     LOAD(pvae_abi_version) LOAD(pvae_last_error) LOAD(pvae_num_layers) LOAD(pvae_layer) LOAD(pvae_arena_floats)
     LOAD(pvae_workspace_bytes) LOAD(pvae_create) LOAD(pvae_destroy) LOAD(pvae_bind_arenas) LOAD(pvae_bind_workspace)
-    LOAD(pvae_bind_dataset) LOAD(pvae_train_step)
+    LOAD(pvae_bind_dataset) LOAD(pvae_train_step) LOAD(pvae_infer)
+    LOAD(pvae_rollout_server_start) LOAD(pvae_rollout_server_infer) LOAD(pvae_rollout_server_selfbench) LOAD(pvae_rollout_server_stop)
     if (pvae_abi_version() != PVAE_ABI_VERSION) { fprintf(stderr, "ABI %d != header %d\n", pvae_abi_version(), PVAE_ABI_VERSION); return 2; }
 
     pvae_config cfg;
@@ -151,6 +158,27 @@ int main(int argc, char** argv) {
                    phase == PVAE_PHASE_WORLD ? "world-model MSE" : "action MSE", mean);
         }
     }
+    /* The consumer of the trained weights (rmt:742-771 at B = 1; envs/rllib_env_imitation.py:215-266): one observation through the
+     * per-layer launches (device buffers, stream), then through the call-persistent rollout server (host pointers in and out, no
+     * launch per call) -- the two actions must be the same bits. */
+    float obs[2 * 23], a_launch[7], a_served[7], *dobs, *dact, *dz;
+    for (int c = 0; c < 2 * Db; ++c) obs[c] = hs[c];                    /* rows 0 and 1 of the demonstrations: [s_0 | s_1] */
+    CHECK_HIP(hipMalloc((void**)&dobs, sizeof(obs)));
+    CHECK_HIP(hipMalloc((void**)&dact, sizeof(a_launch)));
+    CHECK_HIP(hipMalloc((void**)&dz, 8 * sizeof(float)));
+    CHECK_HIP(hipMemcpy(dobs, obs, sizeof(obs), hipMemcpyHostToDevice));
+    CHECK(pvae_infer(ctx, dobs, 1, NULL, 1, 7, 4242, dact, NULL, dz, NULL));
+    CHECK_HIP(hipMemcpy(a_launch, dact, sizeof(a_launch), hipMemcpyDeviceToHost));
+    CHECK(pvae_rollout_server_start(ctx, 50.0, 30.0, 0));
+    CHECK(pvae_rollout_server_infer(ctx, obs, 1, 7, 4242, 0, a_served, NULL, NULL, 1000.0));
+    double us[200], med;
+    CHECK(pvae_rollout_server_selfbench(ctx, obs, 1, 200, us));
+    CHECK(pvae_rollout_server_stop(ctx));
+    for (int i = 1; i < 200; ++i) { double v = us[i]; int j = i; while (j > 0 && us[j - 1] > v) { us[j] = us[j - 1]; --j; } us[j] = v; }
+    med = us[100];
+    if (memcmp(a_launch, a_served, sizeof(a_launch)) != 0) { fprintf(stderr, "served action differs from the launched one\n"); return 6; }
+    for (int c = 0; c < Da; ++c) if (!isfinite(a_served[c])) { fprintf(stderr, "non-finite action\n"); return 6; }
+    printf("rollout: served action == launched action (bit for bit), %.1f us host observation -> host action\n", med);
     pvae_destroy(ctx);
     if (!(last_[0] < 0.7f * first[0])) { fprintf(stderr, "world-model loss did not fall: %g -> %g\n", first[0], last_[0]); return 5; }
     if (!(last_[1] < 0.9f * first[1])) { fprintf(stderr, "action loss did not fall: %g -> %g\n", first[1], last_[1]); return 5; }

@@ -1,7 +1,8 @@
 """The drop-in boundary used from plain C: tests/c_abi/train_loop.c is a host program with no
 Python and no torch in it (dlopen of libpvae_gfx950.so + the HIP runtime for device memory).  The CPU
 test compiles it against include/pvae.h; the GPU test runs it: world-model steps, then joint steps,
-finite losses that fall."""
+finite losses that fall; then one observation through the per-layer launches and through the call-persistent
+rollout server (host pointers in and out), whose actions must be the same bits."""
 import os
 import shutil
 import subprocess
@@ -35,4 +36,5 @@ def test_c_host_trains_through_the_abi(tmp_path):
     r = subprocess.run([exe, build.LIB], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert r.stdout.strip().splitlines()[-1].startswith("ok "), r.stdout[-500:]
+    assert "served action == launched action (bit for bit)" in r.stdout
     print(r.stdout[-400:], file=sys.stderr)
