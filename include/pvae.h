@@ -430,6 +430,10 @@ int pvae_infer_logits(pvae_ctx* ctx, const float* obs, int32_t rows, const float
 int pvae_rollout_server_start(pvae_ctx* ctx, double idle_timeout_ms, double lifetime_s, int scope);
 int pvae_rollout_server_infer(pvae_ctx* ctx, const float* obs, int noise, uint64_t rng_seed, uint64_t rng_offset, int reload,
                               float* a_hat, float* mu_logvar, float* z, double timeout_ms);
+/* forward_decoder at B = 1 (rmt:822-837; the "pass_through" rollout of envs/rllib_env_imitation.py:233-258, where the caller draws
+ * z itself): s1_z = [s1 (Db) | z (Z)] (host) -> a_hat[Da] (host), the same bits as pvae_net_forward(PVAE_NET_MD) on that row.
+ * The encoder's layers are skipped. */
+int pvae_rollout_server_decode(pvae_ctx* ctx, const float* s1_z, float* a_hat, double timeout_ms);
 int pvae_rollout_server_stop(pvae_ctx* ctx);
 /* Measurement: n requests back to back with one observation, us[i] = host observation -> host action of request i on the
  * host's steady clock, taken inside the call (a compiled host's view; tools/infer_latency.py reports it next to Python's). */

@@ -103,6 +103,7 @@ _SIGS = {
     "pvae_rollout_is_fused": (C.c_int, []),
     "pvae_rollout_server_start": (C.c_int, [_P, C.c_double, C.c_double, C.c_int]),
     "pvae_rollout_server_infer": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _P, _P, _P, C.c_double]),
+    "pvae_rollout_server_decode": (C.c_int, [_P, _P, _P, C.c_double]),
     "pvae_rollout_server_stop": (C.c_int, [_P]),
     "pvae_rollout_server_selfbench": (C.c_int, [_P, _P, C.c_int, C.c_int32, _P]),
     "pvae_rollout_server_timeline": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),

@@ -3391,7 +3391,8 @@ struct SrvRequest {                       // host -> device.  Lives in DEVICE me
     // (large BAR: the host PUSHES the observation and the kernel polls local memory), else in pinned host memory (the
     // kernel PULLS over PCIe).  ONE 32-byte line of control words, then the observation.
     volatile uint32_t req_seq;            // written LAST by the host: request number
-    uint32_t cmd;                         // 0 infer, 1 stop, 2 reload the weights from the arena, then infer
+    uint32_t cmd;                         // 0 infer, 1 stop, 2 reload the weights from the arena, then infer,
+                                          // 3 decoder only ("pass_through", rllib_env_imitation.py:233-258): obs = [s1 (Db) | z (Z)]
     uint32_t noise, pad0;
     uint32_t seed_lo, seed_hi, off_lo, off_hi;
     uint32_t pad1[8];
@@ -3588,7 +3589,7 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
             __syncthreads();
             if (s_word[1] != 1u && !a.obs_direct) {        // the observation: pinned host memory -> slot 0, tagged
                 const unsigned tag0 = s_word[0] * 16u;
-                const int n = 2 * a.Db;
+                const int n = s_word[1] == 3u ? a.Db + a.Z : 2 * a.Db;
                 for (int i = tid; i < n; i += 256)
                     srv_put(a.acts + i, __hip_atomic_load(a.req->obs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), tag0);
             }
@@ -3638,7 +3639,8 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
         const bool stamp = g == 0 && tid == 0;
         if (stamp) { a.dbg[0] = wall_clock64(); a.dbg[62] = (unsigned long long)clock64(); }   // request seen by group 0 (+ shader clock)
         // ---- the layers: inputs polled word by word, outputs published word by word ----
-        for (int l = 0; l < a.n_layers; ++l) {
+        const bool decode_only = cmd == 3u;                                  // the caller supplies z: the encoder is skipped
+        for (int l = decode_only ? a.n_te : 0; l < a.n_layers; ++l) {
             const SrvLayer L = a.layer[l];
             const unsigned long long* prev = a.acts + (size_t)l * kSrvActStride;   // slot l: the previous layer's output (0: obs)
             const unsigned tagp = tag0 + (unsigned)l;
@@ -3648,6 +3650,13 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                         xs[k] = k < 2 * a.Db ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
                 } else {
                     srv_get_row(xs, a.acts, 2 * a.Db, L.ld, tag0, tid, t_start, a.life_ticks, failed, a.sync + 18);
+                }
+            } else if (l == a.n_te && decode_only) {                         // [s1 | z | 0] as the caller sent it
+                if (a.obs_direct) {
+                    for (int k = tid; k < L.ld; k += 256)
+                        xs[k] = k < a.Db + a.Z ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
+                } else {
+                    srv_get_row(xs, a.acts, a.Db + a.Z, L.ld, tag0, tid, t_start, a.life_ticks, failed, a.sync + 18);
                 }
             } else if (l == a.n_te) {                                        // [s1 | z | 0], the sampler formed in place
                 for (int k = tid; k < L.ld; k += 256) {
@@ -3743,7 +3752,7 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
             const unsigned long long* md_out = a.acts + (size_t)a.n_layers * kSrvActStride;
             const unsigned long long* te_out = a.acts + (size_t)a.n_te * kSrvActStride;
             const unsigned tag_md = tag0 + (unsigned)a.n_layers, tag_te = tag0 + (unsigned)a.n_te;
-            const int n_out = a.Da + 3 * a.Z;
+            const int n_out = decode_only ? a.Da : a.Da + 3 * a.Z;           // (decoder only: just the action)
             for (int i = tid; i < n_out; i += 256) {
                 float v;
                 if (i < a.Da) v = srv_get(md_out + i, tag_md, t_start, a.life_ticks, failed, a.sync + 18);
@@ -3934,7 +3943,7 @@ static int server_request(pvae_ctx* c, uint32_t cmd, const float* obs, int noise
     RolloutServer& S = *c->server;
     SrvReply* mb = S.mb;
     SrvRequest* rq = S.req;
-    if (obs) memcpy((void*)rq->obs, obs, (size_t)2 * S.args.Db * sizeof(float));
+    if (obs) memcpy((void*)rq->obs, obs, (size_t)(cmd == 3u ? S.args.Db + S.args.Z : 2 * S.args.Db) * sizeof(float));
     rq->cmd = cmd; rq->noise = noise ? 1u : 0u;
     rq->seed_lo = (uint32_t)seed; rq->seed_hi = (uint32_t)(seed >> 32); rq->off_lo = (uint32_t)offset; rq->off_hi = (uint32_t)(offset >> 32);
     const uint32_t seq = ++S.seq;
@@ -3976,6 +3985,29 @@ int pvae_rollout_server_infer(pvae_ctx* c, const float* obs, int noise, uint64_t
             memcpy(a_hat, (const void*)S.mb->out, (size_t)Da * sizeof(float));
             if (mu_logvar) memcpy(mu_logvar, (const void*)(S.mb->out + Da), (size_t)2 * Z * sizeof(float));
             if (z) memcpy(z, (const void*)(S.mb->out + Da + 2 * Z), (size_t)Z * sizeof(float));
+            return 0;
+        }
+    }
+    return fail(-25, "rollout server: the kernel left twice while a request was pending");
+}
+
+/* forward_decoder at B = 1 ("pass_through" rollouts, rllib_env_imitation.py:233-258: z drawn by the caller): s1_z = [s1 (Db) | z (Z)]
+ * -> a_hat[Da], the same bits as pvae_net_forward(PVAE_NET_MD) on that row.  The encoder's layers are skipped. */
+int pvae_rollout_server_decode(pvae_ctx* c, const float* s1_z, float* a_hat, double timeout_ms) {
+    if (!c || !c->server || !c->server->mb) return fail(-2, "rollout server not started (pvae_rollout_server_start)");
+    if (!s1_z || !a_hat) return fail(-1, "s1_z / a_hat is null");
+    RolloutServer& S = *c->server;
+    if (timeout_ms <= 0) timeout_ms = 1000.0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!S.launched || S.mb->state != 1u) {
+            int rc = pvae_rollout_server_start(c, 0, 0, -1);
+            if (rc) return rc;
+        }
+        const int r = server_request(c, 3u, s1_z, 0, 0, 0, timeout_ms);
+        if (r < 0) return r;
+        if (r == 0) {
+            ++S.served;
+            memcpy(a_hat, (const void*)S.mb->out, (size_t)S.args.Da * sizeof(float));
             return 0;
         }
     }

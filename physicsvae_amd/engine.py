@@ -602,6 +602,20 @@ class HipEngine:
             _lib.check(rc, "pvae_rollout_server_infer")
         return n_a, n_ml, n_z
 
+    def rollout_server_decode(self, s1_z, timeout_ms=1000.0):
+        """forward_decoder at B = 1 through the resident kernel: s1_z = [s1 (Db) | z (Z)] (CPU array) -> a_hat [Da] (numpy view,
+        valid until the next call); the same bits as `net_forward(NET_MD, s1_z[None])`."""
+        import numpy as _np
+        io = self._srv_io
+        if io is None:
+            raise RuntimeError("rollout server not started (rollout_server_start)")
+        x = _np.ascontiguousarray(_np.asarray(s1_z, dtype=_np.float32).reshape(-1))
+        assert x.size == self.arch.Db + self.arch.Z, "s1_z must hold [s1 (Db) | z (Z)]"
+        rc = self.lib.pvae_rollout_server_decode(self.ctx, x.ctypes.data, io[5], float(timeout_ms))
+        if rc:
+            _lib.check(rc, "pvae_rollout_server_decode")
+        return io[1]
+
     def rollout_server_selfbench(self, obs, n=1000, noise=True):
         """us per request of n back-to-back requests, timed on the host clock INSIDE the library call (no Python per request)."""
         import numpy as _np

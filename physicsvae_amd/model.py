@@ -567,6 +567,11 @@ class PhysicsVAE(nn.Module):
                                    seed=self._rng_seed, offset=self._rng_calls)
 
     def forward_decoder(self, z_body, z_task, state=None, seq_lens=None, state_cnt=0):
+        if (self.__dict__.get("_srv_on") and z_body.device.type == "cpu" and z_task.device.type == "cpu" and z_body.dim() == 2
+                and z_body.shape[0] == 1):
+            # the "pass_through" rollout (envs/rllib_env_imitation.py:233-258: z drawn by the caller) served by the resident kernel
+            a = self.engine.rollout_server_decode(torch.cat([z_body.float(), z_task.float()], dim=-1).numpy())
+            return self._motor_decoder._model[-1](torch.from_numpy(a.copy())[None]), state_cnt
         z = torch.cat([z_body.to(self.engine.device), z_task.to(self.engine.device)], dim=-1)
         a_hat = self.engine.net_forward(NET_MD, z)
         return self._motor_decoder._model[-1](a_hat), state_cnt

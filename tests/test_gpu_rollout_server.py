@@ -151,6 +151,38 @@ def test_module_forward_served_equals_module_forward_launched():
     assert torch.equal(second, call(obs[:1].to(DEV))[0])
 
 
+@pytest.mark.parametrize("mailbox", ["auto", "host"])
+def test_decoder_only_requests_equal_forward_decoder(mailbox, monkeypatch):
+    """The "pass_through" rollout (envs/rllib_env_imitation.py:233-258): the caller draws z itself and calls
+    `forward_decoder(z_body, z_task)` (rmt:822-837).  Served: the encoder's layers are skipped, the action equals the
+    launch path's `net_forward(NET_MD, [s1 | z])` bit for bit -- at the engine and at the module surface, interleaved with
+    full requests."""
+    if mailbox != "auto":
+        monkeypatch.setenv("PVAE_SERVER_MAILBOX", mailbox)
+    arch, tr, obs = _default_trainer()
+    eng, m = tr.engine, tr.model
+    Db, Z = arch["Db"], arch["Z"]
+    g = torch.Generator().manual_seed(3)
+    m.start_rollout_server(idle_ms=2000.0, lifetime_s=30.0)
+    try:
+        for i in range(8):
+            s1, z = obs[i, :Db], torch.randn(Z, generator=g)
+            x = torch.cat([s1, z])[None]
+            want = eng.net_forward(_lib.NET_MD, x.to(DEV))[:, : arch["Da"]].cpu()
+            got = eng.rollout_server_decode(x.numpy()).copy()
+            assert np.array_equal(got, want.numpy()[0]), i
+            with torch.no_grad():
+                logits, _ = m.forward_decoder(s1[None], z[None])
+            assert logits.device.type == "cpu" and torch.equal(logits[:, : arch["Da"]], want)
+            a = eng.rollout_server_infer(obs[i].numpy(), noise=False)[0].copy()        # a full request in between
+            assert np.array_equal(a, eng.infer(obs[i][None].to(DEV), noise=False, want_s2=False)[0].cpu().numpy()[0])
+    finally:
+        m.stop_rollout_server()
+    with torch.no_grad():
+        logits_launch, _ = m.forward_decoder(obs[7:8, :Db].to(DEV), z[None].to(DEV))     # the launch path, same module call
+    assert torch.equal(logits_launch.cpu(), logits)
+
+
 def test_two_engines_serve_side_by_side():
     """Two models in one process, each with a resident server: they take different XCDs and answer independently."""
     arch, tr1, obs = _default_trainer(seed=1)
