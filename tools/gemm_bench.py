@@ -23,7 +23,10 @@ SHAPES = {  # (M rows, N out, K in) of the 4x1024 stacks at batch 256
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--rows", type=int, nargs="*", default=[], help="also time the 1024 x 1024 hidden layer at these row counts")
     a = ap.parse_args()
+    for r in a.rows:
+        SHAPES["hidden b%d" % r] = (r, 1024, 1024)
     dev = "cuda"
     print("%-20s %-8s %10s %10s" % ("shape", "kind", "us", "TFLOP/s"))
     for name, (m, n, k) in SHAPES.items():
