@@ -421,6 +421,11 @@ int pvae_infer_logits(pvae_ctx* ctx, const float* obs, int32_t rows, const float
  *                               pvae_infer(rows = 1, eps = NULL, noise, rng_seed, rng_offset), bit for bit.  reload != 0:
  *                               the weights are copied from the parameter arena into LDS again first (after an
  *                               optimizer step or load_weights*, rmt:870-928).  Blocks at most timeout_ms (<= 0: 1 s).
+ *                               Optimizer steps issued through THIS library (pvae_train_step*, pvae_dp_train_step,
+ *                               pvae_adam*, pvae_p2p_exchange) are noticed: the next request waits for their stream and
+ *                               re-reads the weights by itself.  Parameters written behind the library's back (a
+ *                               framework's load_state_dict into the arena, rmt:870-928) are announced with
+ *                               pvae_params_changed.
  *   pvae_rollout_server_stop    ends the kernel (also done by pvae_destroy).
  *   pvae_rollout_server_status  *lds_bytes < 0: dealt out over the whole chip (|value| bytes per workgroup).
  *                               *serving != 0 while the kernel is resident and answering: 2 when the request block lives in
@@ -435,6 +440,10 @@ int pvae_rollout_server_infer(pvae_ctx* ctx, const float* obs, int noise, uint64
  * The encoder's layers are skipped. */
 int pvae_rollout_server_decode(pvae_ctx* ctx, const float* s1_z, float* a_hat, double timeout_ms);
 int pvae_rollout_server_stop(pvae_ctx* ctx);
+/* The caller wrote the parameter arena itself (load_state_dict / load_weights*, rmt:870-928; a torch optimizer) with work
+ * queued on `stream` (NULL: the default stream): whatever holds a copy of the parameters -- the rollout server's LDS -- refreshes it before its
+ * next answer, after that stream has drained. */
+int pvae_params_changed(pvae_ctx* ctx, void* stream);
 /* Measurement: n requests back to back with one observation, us[i] = host observation -> host action of request i on the
  * host's steady clock, taken inside the call (a compiled host's view; tools/infer_latency.py reports it next to Python's). */
 int pvae_rollout_server_selfbench(pvae_ctx* ctx, const float* obs, int noise, int32_t n, double* us);

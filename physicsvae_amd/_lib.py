@@ -105,6 +105,7 @@ _SIGS = {
     "pvae_rollout_server_infer": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _P, _P, _P, C.c_double]),
     "pvae_rollout_server_decode": (C.c_int, [_P, _P, _P, C.c_double]),
     "pvae_rollout_server_stop": (C.c_int, [_P]),
+    "pvae_params_changed": (C.c_int, [_P, _P]),
     "pvae_rollout_server_selfbench": (C.c_int, [_P, _P, C.c_int, C.c_int32, _P]),
     "pvae_rollout_server_timeline": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     "pvae_rollout_server_status": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),

@@ -209,7 +209,20 @@ struct pvae_ctx {
         long long timeout_ticks = 20ll * 100000000ll;    // 100 MHz wall clock
     } p2p;
     struct RolloutServer* server = nullptr;              // call-persistent rollout kernel (pvae_rollout_server_*)
+    // every call that changes parameters through this library counts here and leaves its stream: the rollout server re-reads
+    // its resident copy when the count moved (after that stream has drained)
+    unsigned long long param_version = 0;
+    hipStream_t param_stream = nullptr;                  // (NULL is a stream too: the default one)
+    bool param_pending = false;                          // work that writes the parameters may still be queued on it
 };
+static inline void params_touched(pvae_ctx* c, hipStream_t st, bool queued = true) {
+    ++c->param_version; c->param_stream = st; c->param_pending = queued;
+}
+static inline hipError_t params_settle(pvae_ctx* c) {
+    if (!c->param_pending) return hipSuccess;
+    c->param_pending = false;
+    return hipStreamSynchronize(c->param_stream);
+}
 static void server_free(pvae_ctx* c);
 
 // ---------------------------------------------------------------------------------------
@@ -1771,6 +1784,7 @@ int pvae_bind_arenas(pvae_ctx* c, float* params, float* grads, float* exp_avg, f
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
         return fail(-1, "arenas must be 16-byte aligned");
     c->params = params; c->grads = grads; c->m = exp_avg; c->v = exp_avg_sq;
+    params_touched(c, nullptr, false);
     return 0;
 }
 
@@ -2538,6 +2552,7 @@ int pvae_forward_backward(pvae_ctx* c, int phase, int32_t rows, const pvae_step_
     int rc = check_step(c, phase, rows, sp, backward, fused);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (backward && fused) params_touched(c, st);
     StepShape S;
     if ((rc = step_shape(c, phase, rows, sp, loss_out, backward, S))) return rc;
     if ((rc = run_forward(c, phase, rows, sp, eps, backward, S, st))) return rc;
@@ -2592,6 +2607,7 @@ int pvae_adam_segment(pvae_ctx* c, int net, int64_t offset, int64_t count, const
         return fail(-1, "segment [%lld, +%lld) not inside net %d or not float4-aligned", (long long)offset,
                     (long long)count, net);
     if (count == 0) return 0;
+    params_touched(c, (hipStream_t)stream);
     const long long n4 = count / 4;
     int grid = (int)((n4 + 255) / 256);
     if (grid > 2048) grid = 2048;
@@ -2606,6 +2622,7 @@ int pvae_adam(pvae_ctx* c, int net_mask, const pvae_step_params* sp, void* strea
     if (rc) return rc;
     if (!sp) return fail(-1, "null step params");
     if (!c->grads || !c->m || !c->v) return fail(-2, "grads / Adam moment arenas not bound");
+    params_touched(c, (hipStream_t)stream);
     for (int n = 0; n < PVAE_NUM_NETS; ++n) {
         if (!(net_mask & (1 << n))) continue;
         const NetLayout& N = c->L.net[n];
@@ -2901,6 +2918,7 @@ int pvae_p2p_exchange(pvae_ctx* c, int net, int64_t offset, int64_t count, const
     if (offset < N.off || count < 0 || offset + count > N.off + N.count)
         return fail(-1, "segment [%lld, +%lld) not inside net %d", (long long)offset, (long long)count, net);
     if (count == 0) return 0;
+    params_touched(c, (hipStream_t)stream);
     return p2p_exchange(c, net, offset, count, sp, (hipStream_t)stream);
 }
 
@@ -3092,6 +3110,7 @@ int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t row
     if (!c->grads || !c->m || !c->v) return fail(-2, "grads / Adam moment arenas not bound");
     if (phase != PVAE_PHASE_WORLD && phase != PVAE_PHASE_JOINT) return fail(-1, "unknown phase %d", phase);
     hipStream_t st = (hipStream_t)stream;
+    params_touched(c, st);
     const bool learned_prior = !c->L.net[PVAE_NET_PR].layers.empty();
     const int nets[3] = {phase == PVAE_PHASE_WORLD ? PVAE_NET_WM : PVAE_NET_MD,
                          phase == PVAE_PHASE_WORLD ? -1 : (learned_prior ? PVAE_NET_PR : PVAE_NET_TE),
@@ -3803,6 +3822,7 @@ struct RolloutServer {
     SrvArgs args{};
     size_t lds_bytes = 0;
     uint32_t seq = 0, served = 0;
+    unsigned long long loaded_version = 0;   // pvae_ctx::param_version of the resident weights
     int scope = 0, xcd = -1;
     bool launched = false;
     double idle_ms = 100.0, life_s = 600.0;
@@ -3859,6 +3879,8 @@ static int server_launch(pvae_ctx* c, RolloutServer& S) {
     S.mb->state = 0; S.mb->done_seq = S.seq;
     S.req->cmd = 0; S.req->req_seq = S.seq;
     __builtin_ia32_sfence();                                    // (device-resident request block: write-combined stores)
+    HIP_TRY(params_settle(c));                                   // (the launch reads the parameters as they are NOW)
+    S.loaded_version = c->param_version;
     S.args.seq0 = S.seq;
     S.args.params = c->params;
     S.args.idle_ticks = (long long)(S.idle_ms * 1e5);
@@ -3977,6 +3999,11 @@ int pvae_rollout_server_infer(pvae_ctx* c, const float* obs, int noise, uint64_t
             if (rc) return rc;
             reload = 0;
         }
+        if (S.loaded_version != c->param_version) {              // optimizer steps went through this library since: re-read
+            HIP_TRY(params_settle(c));
+            S.loaded_version = c->param_version;
+            reload = 1;
+        }
         const int r = server_request(c, reload ? 2u : 0u, obs, noise, rng_seed, rng_offset, timeout_ms);
         if (r < 0) return r;
         if (r == 0) {
@@ -3999,6 +4026,10 @@ int pvae_rollout_server_decode(pvae_ctx* c, const float* s1_z, float* a_hat, dou
     RolloutServer& S = *c->server;
     if (timeout_ms <= 0) timeout_ms = 1000.0;
     for (int attempt = 0; attempt < 2; ++attempt) {
+        if (S.launched && S.mb->state == 1u && S.loaded_version != c->param_version) {
+            int rc = pvae_rollout_server_stop(c);                // (no reload form of this request: a relaunch re-reads)
+            if (rc) return rc;
+        }
         if (!S.launched || S.mb->state != 1u) {
             int rc = pvae_rollout_server_start(c, 0, 0, -1);
             if (rc) return rc;
@@ -4056,6 +4087,12 @@ int pvae_rollout_server_stop(pvae_ctx* c) {
         HIP_TRY(hipStreamSynchronize(S.stream));                 // bounded: stop command, else idle time-out, else lifetime
         S.launched = false;
     }
+    return 0;
+}
+
+int pvae_params_changed(pvae_ctx* c, void* stream) {
+    if (!c) return fail(-1, "null ctx");
+    params_touched(c, (hipStream_t)stream);
     return 0;
 }
 

@@ -602,6 +602,12 @@ class HipEngine:
             _lib.check(rc, "pvae_rollout_server_infer")
         return n_a, n_ml, n_z
 
+    def params_changed(self, stream=None):
+        """The parameter arena was written outside the library (load_state_dict, a torch optimizer): holders of a copy -- the
+        rollout server's LDS -- refresh before their next answer.  Optimizer steps through the library count by themselves."""
+        if self.ctx is not None:
+            _lib.check(self.lib.pvae_params_changed(self.ctx, stream), "pvae_params_changed")
+
     def rollout_server_decode(self, s1_z, timeout_ms=1000.0):
         """forward_decoder at B = 1 through the resident kernel: s1_z = [s1 (Db) | z (Z)] (CPU array) -> a_hat [Da] (numpy view,
         valid until the next call); the same bits as `net_forward(NET_MD, s1_z[None])`."""

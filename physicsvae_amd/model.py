@@ -444,24 +444,28 @@ class PhysicsVAE(nn.Module):
         no device copy, and returns CPU tensors (the 30 Hz control loop of envs/rllib_env_imitation.py:215-266 hands the
         action to a CPU simulator anyway).  Same action as the launch path, bit for bit; mu / logvar / z come with it;
         the world model's prediction and the value estimate stay lazy (launches, on first read).  The resident copy of
-        the weights follows `load_state_dict` / `load_weights*`; after optimizer steps call `reload_rollout_server()`.
+        the weights follows `load_state_dict` / `load_weights*` and the HIP trainer's optimizer steps (`reload_rollout_server()`
+        after writes the library cannot see).
         `scope`: "xcd" (one XCD), "chip" (all CUs: stacks too big for one XCD, e.g. 4x1024), "auto".  Raises RuntimeError when
         nothing fits: the launch path stays in use."""
         self.engine.rollout_server_start(idle_ms=idle_ms, lifetime_s=lifetime_s, scope=scope)
         self.__dict__["_srv_on"] = True
-        self.__dict__["_srv_reload"] = False
 
     def stop_rollout_server(self):
         self.__dict__["_srv_on"] = False
         self.engine.rollout_server_stop()
 
     def reload_rollout_server(self):
-        """The parameters changed (optimizer step, direct write): the next served forward re-reads them into LDS."""
-        self.__dict__["_srv_reload"] = True
+        """The parameters were written outside the library (a torch optimizer, a direct write into a parameter): the next
+        served request re-reads them into LDS (`pvae_params_changed`).  Optimizer steps through the HIP trainer and
+        `load_state_dict` / `load_weights*` are noticed without this call."""
+        eng = self.__dict__.get("engine")
+        if eng is not None and eng.ctx is not None:
+            eng.params_changed(torch.cuda.current_stream(eng.device).cuda_stream)
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
-        self.__dict__["_srv_reload"] = True          # (submodule loads -- load_weights_task_encoder etc. -- set it as well)
+        self.reload_rollout_server()                 # (submodule loads -- load_weights_task_encoder etc. -- call it as well)
         return out
 
     def _forward_served(self, obs, state, noise):
@@ -484,12 +488,10 @@ class PhysicsVAE(nn.Module):
             t_log[0, Da:] = ls.detach().cpu().reshape(-1)          # [a_hat | log_std] (AppendLogStd, rmt:160-206)
             d["_srv_ls"], d["_srv_ls_ver"] = ls, getattr(als, "_ver", 0)
         t_obs.copy_(obs)
-        rc = fn(self.engine.ctx, ptrs[0], 1 if noise else 0, self._rng_seed, st._rng_calls, 1 if d.get("_srv_reload") else 0,
-                ptrs[1], ptrs[2], ptrs[3], 1000.0)
+        rc = fn(self.engine.ctx, ptrs[0], 1 if noise else 0, self._rng_seed, st._rng_calls, 0, ptrs[1], ptrs[2], ptrs[3], 1000.0)
         if rc:
             from . import _lib
             _lib.check(rc, "pvae_rollout_server_infer")
-        d["_srv_reload"] = False
         st._cur_future_state = None
         st._cur_body_encoder_variable = v_s1
         st._cur_task_encoder_variable = t_z
@@ -627,7 +629,7 @@ class PhysicsVAE(nn.Module):
     def load_weights_task_encoder(self, file):
         self._task_encoder.load_state_dict(torch.load(file, map_location="cpu")["task_encoder"])
         self._task_encoder.eval()
-        self.__dict__["_srv_reload"] = True
+        self.reload_rollout_server()
 
     def save_weights_motor_decoder(self, file):
         torch.save(_portable(self._motor_decoder.state_dict()), file)
@@ -640,7 +642,7 @@ class PhysicsVAE(nn.Module):
                 loaded[key] = current[key]
         self._motor_decoder.load_state_dict(loaded)
         self._motor_decoder.eval()
-        self.__dict__["_srv_reload"] = True
+        self.reload_rollout_server()
 
     def save_weights_world_model(self, file):
         torch.save(_portable(self._world_model.state_dict()), file)

@@ -84,19 +84,34 @@ def test_server_follows_the_weights_on_reload_and_after_a_restart():
     o = obs[3].numpy()
     with served(eng, idle_ms=3000.0):
         before = eng.rollout_server_infer(o, noise=False)[0].copy()
-        # an optimizer step moves the decoder: the resident copy in LDS is stale until told
+        # an optimizer step through the library moves the decoder: the next request waits for the step's stream and
+        # re-reads the weights by itself (no synchronisation, no reload by the caller)
         sp = make_step_params(lr=5e-3, global_rows=8)
         eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
         tr.model.set_learnable_task_encoder(True)
         tr.model.set_learnable_motor_decoder(True)
         tr.model.set_learnable_world_model(False)
         eng.train_step(_lib.PHASE_JOINT, 0, 8, sp)
-        torch.cuda.current_stream().synchronize()
+        after = eng.rollout_server_infer(o, noise=False)[0].copy()
         want = eng.infer(torch.from_numpy(o)[None].to(DEV), noise=False, want_s2=False)[0].cpu().numpy()[0]
         assert not np.array_equal(want, before)
-        assert np.array_equal(eng.rollout_server_infer(o, noise=False)[0], before)          # still the old weights
-        assert np.array_equal(eng.rollout_server_infer(o, noise=False, reload=True)[0], want)
+        assert np.array_equal(after, want)
         assert np.array_equal(eng.rollout_server_infer(o, noise=False)[0], want)            # and they stay
+        # a write the library cannot see (here: a direct write into the arena) is stale until announced
+        with torch.no_grad():
+            eng.params.mul_(0.5)
+        torch.cuda.current_stream().synchronize()
+        want2 = eng.infer(torch.from_numpy(o)[None].to(DEV), noise=False, want_s2=False)[0].cpu().numpy()[0]
+        assert not np.array_equal(want2, want)
+        assert np.array_equal(eng.rollout_server_infer(o, noise=False)[0], want)            # still the old weights
+        assert np.array_equal(eng.rollout_server_infer(o, noise=False, reload=True)[0], want2)
+        with torch.no_grad():
+            eng.params.mul_(2.0)                                                            # (exact: back to the trained weights)
+        eng.params_changed(torch.cuda.current_stream().cuda_stream)
+        assert np.array_equal(eng.rollout_server_infer(o, noise=False)[0], want)
+        assert np.array_equal(eng.rollout_server_decode(np.concatenate([o[: arch["Db"]], np.zeros(arch["Z"], np.float32)])),
+                              eng.net_forward(_lib.NET_MD, torch.cat([torch.from_numpy(o[: arch["Db"]]), torch.zeros(arch["Z"])])[None].to(DEV))
+                              [:, : arch["Da"]].cpu().numpy()[0])
     # idle time-out: the kernel leaves by itself, the next call brings it back (weights read from the arena again)
     with served(eng, idle_ms=30.0):
         assert np.array_equal(eng.rollout_server_infer(o, noise=False)[0], want)
@@ -149,6 +164,20 @@ def test_module_forward_served_equals_module_forward_launched():
         m.stop_rollout_server()
     assert not torch.equal(first, second)
     assert torch.equal(second, call(obs[:1].to(DEV))[0])
+    # ... also when the FIRST request after the load is a decoder-only one
+    Db, Z = arch["Db"], arch["Z"]
+    s1, z = obs[:1, :Db], torch.full((1, Z), 0.25)
+    m.start_rollout_server(idle_ms=2000.0, lifetime_s=30.0)
+    try:
+        with torch.no_grad():
+            d1 = m.forward_decoder(s1, z)[0].clone()
+            m.load_state_dict(R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3))
+            d2 = m.forward_decoder(s1, z)[0].clone()
+    finally:
+        m.stop_rollout_server()
+    with torch.no_grad():
+        want = m.forward_decoder(s1.to(DEV), z.to(DEV))[0].cpu()
+    assert not torch.equal(d1, d2) and torch.equal(d2, want)
 
 
 @pytest.mark.parametrize("mailbox", ["auto", "host"])
