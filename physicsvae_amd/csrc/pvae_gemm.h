@@ -1192,10 +1192,16 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
 #define PVAE_WS64_STAGES 4          // ring slots of the 64x32 kernel (24 KB each; A/B: 5, 6)
 #endif
 constexpr int kWs64Stages = PVAE_WS64_STAGES;
-constexpr int kWs64Floats = kWs64Stages * (64 + 32) * 64;
-template <bool P_ROW, class Epi>
+// PT = 32: the 64x32 tile above.  PT = 64 (round 4, 1024 rows and more): 64x64 outputs per workgroup, 32 KB per k-tile for
+// twice the MFMA work of the 24 KB of 64x32 -- 16 flop per DMA byte instead of 10.7; the k-loop is as long as its DMA stream
+// (docs/experiments.md), so that is what pays.  Ring 4 x 32 KB.  Same k-quarters per wave, same order: bit-identical again.
+template <int PT> constexpr int ws64_floats() { return (PT == 64 ? 4 : kWs64Stages) * (64 + PT) * 64; }
+template <bool P_ROW, class Epi, int PT = 32>
 __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
-    constexpr int BK = 64, kTileQ = 64 * 64, kTileP = 32 * 64, kStage = kTileQ + kTileP, S = kWs64Stages;
+    static_assert(PT == 32 || PT == 64, "P tile of 32 or 64 rows");
+    constexpr int BK = 64, kTileQ = 64 * 64, kTileP = PT * 64, kStage = kTileQ + kTileP, S = PT == 64 ? 4 : kWs64Stages;
+    constexpr int NB = PT / 16;                                  // 16-wide p blocks of the tile = P DMA instructions per loader wave
+    constexpr int PER = 4 + NB;                                  // DMA instructions per loader wave and tile
     static_assert(kWsLoaders == 4, "written for four loader waves");
     static_assert(S >= 4 && S <= 6, "the loaders' wait ladder covers up to four tiles in flight");
     const float* __restrict__ Q = ga.Q;
@@ -1208,23 +1214,23 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
     // Experiment: a 2 x 4 grid of XCDs over (row blocks, column blocks) instead of 1 x 8.  What the 8 L2s fetch from the
     // fabric for one layer is 8 (X / a + W / b) with a b = 8: at 512 rows (X 2 MB, W 4 MB) 20 MB for 1 x 8, 16 MB for 2 x 4
     // (at 256 rows both give 12 MB: the "2.2x over-fetch" of the forward launches is the floor of any XCD partition).
-    if (tiles_q == 8 && tiles_p == 32 && ga.p_per_xcd == 4) {
+    if (PT == 32 && tiles_q == 8 && tiles_p == 32 && ga.p_per_xcd == 4) {
         tile_q = (xcd & 1) * 4 + (loc & 3);
         tile_p = (xcd >> 1) * 8 + (loc >> 2);
     }
 #endif
     if (tile_p >= tiles_p) return;
-    const int q0 = tile_q * 64, p0 = tile_p * 32;
+    const int q0 = tile_q * 64, p0 = tile_p * PT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lh = lane >> 4;
     const int nk = K / BK;
-    typename Epi::Pre epre[2] = {};
-    v4f acc[4][2];
+    typename Epi::Pre epre[NB] = {};
+    v4f acc[4][NB];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NB; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
     const size_t kstep_p = P_ROW ? (size_t)BK : (size_t)BK * ldp;
     // 16-byte slot j of an operand image -> its global source (same swizzles as splitk_ws_body)
     auto src_q = [&](int j) {
@@ -1236,31 +1242,33 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
             const int row = j >> 4, c = (j & 15) ^ (row & 15);
             return P + (size_t)(p0 + row) * ldp + c * 4;
         }
+        if (PT == 64) return P + (size_t)(j >> 4) * ldp + p0 + (j & 15) * 4;   // [64 k][64 p]: a k-row is all 64 banks, no swizzle
         const int r = j >> 3, k = r ^ ((r >> 2) & 1);
         return P + (size_t)k * ldp + p0 + (j & 7) * 4;
     };
-    // k-tile 0 by all eight waves: Q image = 1024 slots (two per lane and wave), P image = 512 (one)
+    // k-tile 0 by all eight waves: Q image = 1024 slots (two per lane and wave), P image = 512 / 1024 (one / two)
     lds_dma16(src_q(wave * 64 + lane), lds + wave * 256);
     lds_dma16(src_q((wave + 8) * 64 + lane), lds + (wave + 8) * 256);
     lds_dma16(src_p(wave * 64 + lane), lds + kTileQ + wave * 256);
+    if (PT == 64) lds_dma16(src_p((wave + 8) * 64 + lane), lds + kTileQ + (wave + 8) * 256);
     if (wave >= 4) {
-        // ---------------- loader waves: 4 Q + 2 P instructions per tile ----------------
+        // ---------------- loader waves: 4 Q + NB P instructions per tile ----------------
         const int u0 = wave - 4;
         const float* sq[4];
-        const float* sp[2];
+        const float* sp[NB];
 #pragma unroll
         for (int u = 0; u < 4; ++u) sq[u] = src_q((u0 + 4 * u) * 64 + lane);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) sp[u] = src_p((u0 + 4 * u) * 64 + lane);
+        for (int u = 0; u < NB; ++u) sp[u] = src_p((u0 + 4 * u) * 64 + lane);
         auto issue = [&](int t) {
             float* slot = lds + (t % S) * kStage;
 #pragma unroll
             for (int u = 0; u < 4; ++u) lds_dma16(sq[u] + (size_t)t * BK, slot + (u0 + 4 * u) * 256);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) lds_dma16(sp[u] + (size_t)t * kstep_p, slot + kTileQ + (u0 + 4 * u) * 256);
+            for (int u = 0; u < NB; ++u) lds_dma16(sp[u] + (size_t)t * kstep_p, slot + kTileQ + (u0 + 4 * u) * 256);
         };
         if (1 < nk) issue(1);
-        if (1 < nk) wait_vmcnt<6>(); else wait_vmcnt<0>();       // this wave's share of tile 0 landed
+        if (1 < nk) wait_vmcnt<PER>(); else wait_vmcnt<0>();     // this wave's share of tile 0 landed
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -1270,15 +1278,15 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
             int y = nk - 2 - t;                                  // tiles younger than t+1 still in flight
             if (y > S - 3) y = S - 3;
             if (y <= 0) wait_vmcnt<0>();
-            else if (y == 1) wait_vmcnt<6>();
-            else if (y == 2) wait_vmcnt<12>();
-            else wait_vmcnt<18>();
+            else if (y == 1) wait_vmcnt<PER>();
+            else if (y == 2) wait_vmcnt<2 * PER>();
+            else wait_vmcnt<3 * PER>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (t + S - 1 < nk) issue(t + S - 1);
         }
     } else {
-        // ---------------- compute waves: 64 x 32 over this wave's k-quarter ----------------
+        // ---------------- compute waves: 64 x PT over this wave's k-quarter ----------------
         int oq[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -1288,22 +1296,27 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
         const int kq = 16 * wave + 4 * lh;
         wait_vmcnt<0>();                                         // this wave's share of tile 0 landed
 #pragma unroll
-        for (int h = 0; h < 2; ++h) epre[h] = epi.preload(q0 + 32 * h + (tid >> 3), p0 + ((tid & 7) << 2));
+        for (int h = 0; h < NB; ++h)
+            epre[h] = PT == 64 ? epi.preload(q0 + 16 * h + (tid >> 4), p0 + ((tid & 15) << 2))
+                               : epi.preload(q0 + 32 * h + (tid >> 3), p0 + ((tid & 7) << 2));
 #if PVAE_L2_TOUCH
         float l2sink = 0.f;
-        {
+        if (PT == 32) {
             int np = tiles_p - xcd * ga.p_per_xcd;
             if (np > ga.p_per_xcd) np = ga.p_per_xcd;
             l2_touch_share<P_ROW>(l2sink, Q, ldq, q0, 64, P, ldp, p0, K, tile_p - xcd * ga.p_per_xcd, np, tile_q, tiles_q, wave, lane);
         }
 #endif
-        struct Frag { v4f q[4], p[2]; v2f c[4]; };
+        struct Frag { v4f q[4], p[NB]; v2f c[4]; v4f c4[4]; };   // (P_ROW: p; P_COL: c at PT = 32, c4 at PT = 64)
         auto fread = [&](const float* st, Frag& f) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) f.q[a] = *reinterpret_cast<const v4f*>(st + oq[a]);
             if (P_ROW) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b) f.p[b] = *reinterpret_cast<const v4f*>(st + kTileQ + oq[b]);
+                for (int b = 0; b < NB; ++b) f.p[b] = *reinterpret_cast<const v4f*>(st + kTileQ + oq[b]);
+            } else if (PT == 64) {
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) f.c4[s2] = *reinterpret_cast<const v4f*>(st + kTileQ + (kq + s2) * 64 + 4 * li);
             } else {
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2)
@@ -1316,8 +1329,8 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const float pv = P_ROW ? f.p[b][s2] : f.c[s2][b];
+                    for (int b = 0; b < NB; ++b) {
+                        const float pv = P_ROW ? f.p[b][s2] : (PT == 64 ? f.c4[s2][b] : f.c[s2][b]);
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, f.q[a][s2], acc[a][b], 0, 0, 0);
                     }
         };
@@ -1346,7 +1359,7 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
     }
     // split-K reduction through LDS (fixed order: compute wave 0..3), epilogue on float4s by the 256 compute threads
     __syncthreads();
-    constexpr int RS = 36;
+    constexpr int RS = PT + 4;
     if (wave < 4) {
         float* red = lds + wave * (64 * RS);
 #pragma unroll
@@ -1354,7 +1367,11 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
             float* row = red + (16 * a + li) * RS;           // (16-byte writes: see store_partial_32x32)
             if (P_ROW) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b) *reinterpret_cast<v4f*>(row + 16 * b + 4 * lh) = acc[a][b];
+                for (int b = 0; b < NB; ++b) *reinterpret_cast<v4f*>(row + 16 * b + 4 * lh) = acc[a][b];
+            } else if constexpr (PT == 64) {                 // lane holds p = 16 lh + 4 j + b of row 16 a + li
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<v4f*>(row + 16 * lh + 4 * j) = v4f{acc[a][0][j], acc[a][1][j], acc[a][2][j], acc[a][3][j]};
             } else {
                 *reinterpret_cast<v4f*>(row + 8 * lh) = v4f{acc[a][0][0], acc[a][1][0], acc[a][0][1], acc[a][1][1]};
                 *reinterpret_cast<v4f*>(row + 8 * lh + 4) = v4f{acc[a][0][2], acc[a][1][2], acc[a][0][3], acc[a][1][3]};
@@ -1364,8 +1381,9 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
     __syncthreads();
     if (wave < 4) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ql = 32 * h + (tid >> 3), pl = (tid & 7) << 2;
+        for (int h = 0; h < NB; ++h) {
+            const int ql = PT == 64 ? 16 * h + (tid >> 4) : 32 * h + (tid >> 3);
+            const int pl = PT == 64 ? (tid & 15) << 2 : (tid & 7) << 2;
             v4f v = *reinterpret_cast<const v4f*>(lds + ql * RS + pl);
 #pragma unroll
             for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const v4f*>(lds + w * (64 * RS) + ql * RS + pl);
@@ -1375,12 +1393,12 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
     epi.finish(lds, tile_q * tiles_p + tile_p, tid);
 }
 
-template <bool P_ROW, class Epi>
+template <bool P_ROW, class Epi, int PT = 32>
 __global__ void __launch_bounds__(512)
 gemm_splitk_ws64_kernel(PVAE_GA_PARAMS(a_), Epi epi) {
     const GemmArgs ga = PVAE_GA_OF(a_);
-    __shared__ __attribute__((aligned(16))) float lds[kWs64Floats];
-    splitk_ws64_body<P_ROW, Epi>(lds, blockIdx.x, ga, epi);
+    __shared__ __attribute__((aligned(16))) float lds[ws64_floats<PT>()];
+    splitk_ws64_body<P_ROW, Epi, PT>(lds, blockIdx.x, ga, epi);
 }
 
 template <bool P_ROW, class Epi>
@@ -2387,6 +2405,9 @@ inline GemmGrid make_grid(int rows_q, int cols_p, int bq, int bp) {
 // 512 rows and more: 64x32 tiles (splitk_ws64_body) whenever they still give every CU a workgroup; PVAE_WS64=0: off (A/B)
 static int g_ws64 = [] { const char* e = getenv("PVAE_WS64"); return (e && e[0] == '0') ? 0 : 1; }();
 inline bool uses_64x32(int M, int N) { return g_ws64 && M >= 512 && M % 64 == 0 && (M / 64) * (N / 32) >= 256; }
+// 1024 rows and more: 64x64 tiles whenever THEY still give every CU a workgroup; PVAE_WS6464=0: off (A/B)
+static int g_ws6464 = [] { const char* e = getenv("PVAE_WS6464"); return (e && e[0] == '0') ? 0 : 1; }();
+inline bool uses_64x64(int M, int N) { return g_ws6464 && uses_64x32(M, N) && N % 64 == 0 && (M / 64) * (N / 64) >= 256; }
 // ... and the input-gradient half of the fused backward pairs (PVAE_PAIR64=0: off, A/B)
 static int g_pair64 = [] { const char* e = getenv("PVAE_PAIR64"); return (e && e[0] == '0') ? 0 : 1; }();
 inline bool pair_uses_64x32(int M, int N) { return g_pair64 && uses_64x32(M, N); }
@@ -2407,6 +2428,12 @@ inline hipError_t gemm_forward_epi(const float* X, int ldx, const float* W, int 
         return hipGetLastError();
     }
     if constexpr (std::is_same<Epi, EpiBiasAct>::value) {
+        if (uses_64x64(M, N)) {
+            const GemmGrid g = make_grid(M, N, 64, 64);
+            const GemmArgs ga{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd};
+            PVAE_LAUNCH((gemm_splitk_ws64_kernel<true, Epi, 64>), dim3(g.grid), dim3(512), st, PVAE_GA_PASS(ga), e);
+            return hipGetLastError();
+        }
         if (uses_64x32(M, N)) {
             const GemmGrid g = make_grid(M, N, 64, 32);
             const GemmArgs ga{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd};
@@ -2459,6 +2486,12 @@ template <class EpiD>
 inline hipError_t gemm_dgrad_epi(const float* dZ, int ldz, const float* W, int ldw, int M, int Kin, int N,
                                  const EpiD& e, hipStream_t st) {
     if constexpr (std::is_same<EpiD, EpiMask>::value) {
+        if (uses_64x64(M, Kin)) {                               // ... at >= 1024 rows
+            const GemmGrid g = make_grid(M, Kin, 64, 64);
+            const GemmArgs ga{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd};
+            PVAE_LAUNCH((gemm_splitk_ws64_kernel<false, EpiD, 64>), dim3(g.grid), dim3(512), st, PVAE_GA_PASS(ga), e);
+            return hipGetLastError();
+        }
         if (uses_64x32(M, Kin)) {                               // stand-alone input gradient of a hidden layer at >= 512 rows
             const GemmGrid g = make_grid(M, Kin, 64, 32);
             const GemmArgs ga{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd};

@@ -174,6 +174,39 @@ torch.save(outs, sys.argv[1])
         assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
+def test_64x64_tiles_equal_64x32_and_32x32_tiles_bit_for_bit(tmp_path):
+    """At 1024 rows and more the forward / stand-alone input-gradient launches use 64x64 output tiles whenever those still
+    give every CU a workgroup (splitk_ws64_body<PT = 64>: 16 flop per DMA byte where 64x32 has 10.7).  Same four k-quarters,
+    same order: all three tilings agree to the bit -- forward with bias + ReLU and input gradient with mask, 1024 ... 4096
+    rows, K = 1024 / 448 / 256, N = 1024 / 512 (the switches are read when the library loads: one process each)."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from physicsvae_amd.engine import gemm_probe
+outs = []
+for m, n, k in ((1024, 1024, 1024), (2048, 512, 448), (1024, 1024, 256), (4096, 1024, 1024), (1088, 1024, 192)):
+    g = torch.Generator().manual_seed(m + n + k)
+    x, w, b = torch.randn(m, k, generator=g).cuda(), torch.randn(n, k, generator=g).cuda(), torch.randn(n, generator=g).cuda()
+    dz, act = torch.randn(m, n, generator=g).cuda(), torch.randn(m, k, generator=g).cuda()
+    o = torch.full((m, n), float("nan"), device="cuda")
+    gemm_probe(0, x, w, o, bias_or_mask=b, relu=True, m=m, n=n, k=k)
+    outs.append(o.cpu())
+    d = torch.full((m, k), float("nan"), device="cuda")
+    gemm_probe(1, dz, w, d, bias_or_mask=act, m=m, n=n, k=k)
+    outs.append(d.cpu())
+torch.save(outs, sys.argv[1])
+''' % ROOT
+    files = []
+    for env_add in ({"PVAE_WS64": "0"}, {"PVAE_WS6464": "0"}, {}):
+        f = str(tmp_path / ("out%d.pt" % len(files)))
+        subprocess.run([sys.executable, "-c", script, f], check=True, env=dict(os.environ, **env_add), timeout=300)
+        files.append(torch.load(f))
+    for a, b, c in zip(*files):
+        assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c)
+
+
 def test_pair_launch_with_64x32_input_gradient_tiles_is_bit_identical(tmp_path):
     """The fused backward pairs at 512 rows and more run their input-gradient half on 64x32 tiles (splitk_reg64_body,
     bwd_pair64_kernel; PVAE_PAIR64=0 keeps 32x32).  Same k-quarters per wave, same order of the four partial sums: a
