@@ -207,6 +207,42 @@ torch.save(outs, sys.argv[1])
         assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c)
 
 
+def test_whole_step_at_1024_rows_on_64x64_tiles_matches_the_oracle():
+    """One minibatch of exactly 1024 kink-free rows through 1024-wide stacks -- every hidden forward layer and every
+    stand-alone input gradient of the frozen world model on 64x64 tiles, the pairs on 64x32 -- against the oracle: losses
+    1e-5, every gradient 1e-4 (both phases)."""
+    arch = R.make_arch(23, 7, latent=8, te=(1024, 2), md=(1024, 3), wm=(1024, 2))
+    data = R.synth_demo(5, 2, 700, 23, 7, kind="dynamics")
+    X, Y = R.build_windows(data)
+    x, y = next(iter(R.make_loader(X, Y, 1300)))
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=2), seed=4)
+    eps = R.eps_stream(3, 8)(0, (x.shape[0], 8))
+    tr = make_trainer(arch, data, 1024, device="cuda")
+    tr.model.load_state_dict(sd)
+    eng = tr.engine
+    for world in (True, False):
+        keep = torch.nonzero(R.relu_kink_margin(arch, sd, x, y, eps, world) > 4e-6)[:, 0]
+        assert keep.numel() >= 1024
+        keep = keep[:1024]
+        xk, yk, ek = x[keep], y[keep], eps[keep]
+        co = R.phase_coeffs(world)
+        want = R.loss_and_grads(arch, sd, xk, yk, ek, world)
+        sp = make_step_params(lr=5e-4, a_rec=co["a_rec_coeff"], kl=co["vae_kl_coeff"], s_rec=co["s_rec_coeff"],
+                              cyc=co["vae_cycle_coeff"], global_rows=1024)
+        eng.set_batch(xk, yk)
+        eng.grads.fill_(float("nan"))
+        loss = eng.forward_backward(_lib.PHASE_WORLD if world else _lib.PHASE_JOINT, 1024, sp, eps=None if world else ek,
+                                    fused_adam=False).cpu()
+        assert float(loss[0]) == pytest.approx(float(want["total"]), rel=1e-5, abs=1e-9), world
+        for i, k in enumerate(("loss_a", "loss_kl", "loss_s", "loss_cyc")):
+            assert float(loss[1 + i]) == pytest.approx(float(want[k]), rel=1e-5, abs=1e-9), (world, k)
+        gv = eng.named_views(eng.grads)
+        for k, gr in want["grads"].items():
+            ours = gv[k].cpu()
+            assert torch.isfinite(ours).all(), (world, k)
+            assert max_err_scaled(ours, gr) < 1e-4 and rel_err(ours, gr) < 1e-4, (world, k)
+
+
 def test_pair_launch_with_64x32_input_gradient_tiles_is_bit_identical(tmp_path):
     """The fused backward pairs at 512 rows and more run their input-gradient half on 64x32 tiles (splitk_reg64_body,
     bwd_pair64_kernel; PVAE_PAIR64=0 keeps 32x32).  Same k-quarters per wave, same order of the four partial sums: a
