@@ -254,7 +254,7 @@ class PhysicsVAE(nn.Module):
         if cfg["task_encoder_inputs"] != ["body", "task"] or cfg["motor_decoder_inputs"] != ["body", "task"]:
             raise NotImplementedError("task-encoder / motor-decoder inputs must be ['body','task']")
         if cfg.get("motor_decoder_helper_enable"):
-            raise NotImplementedError("motor_decoder_helper_enable: not implemented upstream either (rmt:665-668 raises)")
+            raise NotImplementedError("motor_decoder_helper is not part of the training path")
 
         self.dim_state_body = int(np.prod(cfg["observation_space_body"].shape))
         self.dim_state_task = int(np.prod(cfg["observation_space_task"].shape))
