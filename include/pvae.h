@@ -456,10 +456,12 @@ int pvae_rollout_server_status(pvae_ctx* ctx, int32_t* serving, uint32_t* served
 
 /* A stack of Linear layers on CALLER-owned dense row-major weights (W[i]: [n_out[i]][n_in[i]], row stride
  * ldw[i], no alignment needed; bias may be NULL), hidden activation PVAE_ACT_* (act_kind for every hidden
- * layer, or layer_acts[i] per hidden layer when not NULL), linear output layer.
+ * layer, or layer_acts[i] per hidden layer when not NULL), linear output layer -- or, with (1 + PVAE_ACT_*) << 8 added
+ * to act_kind, that activation on the output layer (the motor decoder's helper ends in tanh, rmt:491-495, 672).
  * scratch: 2 * rows * (widest hidden layer) floats (device).  No context: this is the value branch of
  * the rollout model (rmt:846-853, value_fn_layers 2*Db -> 256 -> 256 -> 1), whose parameters stay plain
- * torch tensors because the supervised loss never touches them. */
+ * torch tensors because the supervised loss never touches them; likewise the motor decoder's helper (rmt:670-680,
+ * 833-835), a residual policy for RL fine-tuning that train_physics_vae.py never builds. */
 int pvae_mlp_forward(const float* x, int32_t rows, int32_t ldx, int32_t n_layers, const float* const* W,
                      const float* const* bias, const int32_t* n_in, const int32_t* n_out,
                      const int32_t* ldw, int32_t act_kind, const int32_t* layer_acts, float* scratch, float* out,

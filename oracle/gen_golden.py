@@ -616,6 +616,65 @@ def case_checkpoint_interop(name, arch):
     print("wrote", name, "reference accepts our files:", ok)
 
 
+def case_helper(name, arch, batch=6):
+    """`motor_decoder_helper_enable` (rmt:490-498, 670-680, 833-835): the reference's model built by its trainer with the
+    helper switched on in custom_model_config (the trainer passes the dict through, tpv:290-311).  Recorded: the
+    state-dict layout (the helper registers between the motor decoder and the world model), and the reference's forward
+    on fixed observations at seeded weights -- logits, z, the world model's prediction (which sees the helped action,
+    rmt:758) and the value -- with the sampler's noise off and on (draws supplied), plus `forward_decoder` alone."""
+    harch = R.with_helper(arch)
+    data = R.synth_demo(seed=0, n_episodes=2, n_steps=14, dim_body=arch["Db"], dim_action=arch["Da"], kind="iid")
+    fix = {}
+    with tempfile.TemporaryDirectory() as td:
+        pkl = os.path.join(td, "demo.pkl")
+        R.write_demo(pkl, data)
+        orig = T.update_model_config
+
+        def update_model_config(trainer_config):
+            orig(trainer_config)
+            cmc = trainer_config["model"]["custom_model_config"]
+            cmc["motor_decoder_helper_enable"] = True                  # rmt:490 (layers / range: the defaults, rmt:491-498)
+        T.update_model_config = update_model_config
+        try:
+            tr = make_reference_trainer(pkl, arch, 8, m_world=2)
+        finally:
+            T.update_model_config = orig
+        m = tr.model
+        ref_sd = m.state_dict()
+        fix["sd_keys"] = np.array(list(ref_sd.keys()))
+        fix["sd_shapes"] = np.array([list(v.shape) + [0] * (2 - v.dim()) for v in ref_sd.values()])
+        fix["helper_range"] = np.array(m._motor_decoder_helper_range)
+        sd = R.perturb_biases(R.init_state_dict(harch, seed=1), seed=3)
+        # (an output layer of norm 0.01 would make the helper's term 1e-3 of the action: give it weight)
+        k_out = "_motor_decoder_helper._model.%d._model.0.weight" % len(harch["mh"])
+        sd[k_out] = sd[k_out] * 60.0
+        m.load_state_dict(sd)
+        m.eval()
+        obs = torch.from_numpy(np.random.default_rng(5).standard_normal((batch, 2 * arch["Db"])).astype(np.float32))
+        eps = R.eps_stream(2, arch["Z"])(0, (batch, arch["Z"]))
+        fix["obs"], fix["eps"] = obs.numpy(), eps.numpy()
+        for noise in (False, True):
+            tag = "noise" if noise else "mean"
+            m.latent_prior_noise = noise
+            with EpsPatch(lambda c, shape: eps):
+                with torch.no_grad():
+                    logits, _ = m(input_dict={"obs": obs, "obs_flat": obs}, state=None, seq_lens=None)
+            fix[tag + "_logits"] = logits.numpy()
+            fix[tag + "_z"] = m._cur_task_encoder_variable.numpy()
+            fix[tag + "_future_state"] = m._cur_future_state.numpy()
+            fix[tag + "_value"] = m.value_function().detach().numpy()
+        with torch.no_grad():
+            zb, zt = obs[:, : arch["Db"]], eps
+            fix["decoder_logits"] = m.forward_decoder(zb, zt, None, None, 0)[0].numpy()
+        # the five-plus-one files of the reference for a helper model: which loaders / savers exist
+        f = os.path.join(td, "helper.pt")
+        m.save_weights_motor_decoder_helper(f)
+        fix["helper_file_keys"] = np.array(list(torch.load(f).keys()))
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *wd(arch["te"]), *wd(arch["md"]), *wd(arch["wm"]), batch])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
+    print("wrote", name, "keys", len(fix["sd_keys"]), "max |logits| mean", float(np.abs(fix["mean_logits"]).max()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -659,6 +718,8 @@ def main():
         "ingest_tiny": lambda: case_ingest("ingest_tiny", tiny),
         "ingest_rel_tiny": lambda: case_ingest_rel("ingest_rel_tiny", tiny),
         "noprior_tiny": lambda: case_noprior("noprior_tiny", tiny, 2, 14, 8),
+        "helper_tiny": lambda: case_helper("helper_tiny", tiny),
+        "helper_default": lambda: case_helper("helper_default", dflt),
         # the trainer's "act_fn" (hidden activation of every stack) and Adam's weight_decay: config keys a user edits
         "single_tiny_tanh": lambda: case_single("single_tiny_tanh", dict(tiny, act="tanh"), 2, 14, 8, full=True),
         "single_tiny_sigmoid": lambda: case_single("single_tiny_sigmoid", dict(tiny, act="sigmoid"), 2, 14, 8, full=True),

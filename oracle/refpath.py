@@ -88,6 +88,17 @@ def make_arch(dim_body, dim_action, latent=32, te=(256, 2), md=(512, 3), wm=(102
                 pr=tuple(pr) if pr is not None else tuple(te), act=act)
 
 
+HELPER_DEFAULT = ((128, "relu"), (128, "relu"))        # motor_decoder_helper_layers' hidden part (rmt:491-495); output: tanh
+
+
+def with_helper(arch, hidden=HELPER_DEFAULT, rng=0.5):
+    """`arch` with the motor decoder's helper switched on (rmt:490-498, 670-680): a second stack on the decoder's input
+    [s1 | z] with a tanh output layer whose `range`-scaled output is added to the action half of the logits
+    (rmt:833-835).  Registered between the motor decoder and the world model."""
+    assert rng > 0                                         # rmt:673
+    return dict(arch, mh=[(int(w), a) for w, a in hidden], mh_range=float(rng))
+
+
 ACTIVATIONS = {"relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "elu": nn.ELU}      # rmt:37-44
 
 
@@ -144,6 +155,7 @@ def net_layer_dims(arch):
     return OrderedDict(learned + [                                             # rmt:627-635 comes first
         ("_task_encoder", chain(2 * Db, arch["te"], te_out)),      # rmt:638-644, 612-613
         ("_motor_decoder", chain(Db + Z, arch["md"], Da)),         # rmt:646-668
+    ] + ([("_motor_decoder_helper", chain(Db + Z, arch["mh"], Da))] if arch.get("mh") else []) + [   # rmt:670-680
         ("_world_model", chain(Db + Da, arch["wm"], Db)),          # rmt:682-689
         ("_value_branch", chain(2 * Db, arch["vb"], 1)),           # rmt:693-699
     ])
@@ -325,10 +337,11 @@ class _Slim(nn.Module):
 
 
 class _Stack(nn.Module):
-    def __init__(self, dims, act="relu"):
+    def __init__(self, dims, act="relu", out_act=None):
         super().__init__()
         acts = [act] * (len(dims) - 1) if isinstance(act, str) else list(act)
-        self._model = nn.Sequential(*[_Slim(i, o, relu=(n < len(dims) - 1), act=acts[n] if n < len(dims) - 1 else "relu")
+        last = len(dims) - 1
+        self._model = nn.Sequential(*[_Slim(i, o, relu=(n < last or out_act is not None), act=acts[n] if n < last else (out_act or "relu"))
                                       for n, (i, o) in enumerate(dims)])
 
     def forward(self, x):
@@ -348,6 +361,8 @@ class RefModel(nn.Module):
             self._latent_prior = _Stack(dims["_latent_prior"], stack_acts(arch, "pr"))
         self._task_encoder = _Stack(dims["_task_encoder"], stack_acts(arch, "te"))
         self._motor_decoder = _Stack(dims["_motor_decoder"], stack_acts(arch, "md"))
+        if arch.get("mh"):                                            # rmt:670-680 (its output layer ends in tanh, rmt:672)
+            self._motor_decoder_helper = _Stack(dims["_motor_decoder_helper"], stack_acts(arch, "mh"), out_act="tanh")
         self._world_model = _Stack(dims["_world_model"], stack_acts(arch, "wm"))
         self._value_branch = _Stack(dims["_value_branch"], stack_acts(arch, "vb"))
         self.log_std = math.log(0.1)            # AppendLogStd constant (rmt:160-206, 466)
@@ -387,7 +402,10 @@ class RefModel(nn.Module):
             if self.prior == "normal_state_mean_one_std":             # rmt:801-809
                 self.cur_prior_mu = self._latent_prior(obs[..., :Db])
         self.cur_z = z
-        a_hat = self._motor_decoder(torch.cat([obs[..., :Db], z], dim=-1))     # rmt:822-831
+        zin = torch.cat([obs[..., :Db], z], dim=-1)
+        a_hat = self._motor_decoder(zin)                              # rmt:822-831
+        if self.arch.get("mh"):                                       # rmt:833-835
+            a_hat = a_hat + self.arch["mh_range"] * self._motor_decoder_helper(zin)
         logits = torch.cat([a_hat, torch.full_like(a_hat, self.log_std)], dim=-1)
         self.cur_future_state = self.forward_world(obs, logits)       # rmt:758
         self.cur_value = self._value_branch(obs).squeeze(1)           # rmt:760-769

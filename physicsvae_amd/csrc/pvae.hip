@@ -4141,7 +4141,10 @@ int pvae_mlp_forward(const float* x, int32_t rows, int32_t ldx, int32_t n_layers
                      void* stream) {
     if (!x || !W || !n_in || !n_out || !ldw || !out) return fail(-1, "null argument");
     if (rows < 1 || n_layers < 1 || n_layers > 16) return fail(-1, "rows %d / layers %d out of range", rows, n_layers);
+    const int out_code = (act_kind >> 8) & 0xff;                 // 1 + PVAE_ACT_* of the OUTPUT layer (0: linear)
+    act_kind &= 0xff;
     if (act_kind < 0 || act_kind > PVAE_ACT_ELU) return fail(-1, "unknown act_kind %d", act_kind);
+    if (out_code > PVAE_ACT_ELU + 1) return fail(-1, "unknown output activation %d", out_code - 1);
     for (int i = 0; layer_acts && i + 1 < n_layers; ++i)
         if (layer_acts[i] < 0 || layer_acts[i] > PVAE_ACT_LINEAR) return fail(-1, "unknown activation %d of layer %d", layer_acts[i], i);
     int wmax = 0;
@@ -4159,7 +4162,7 @@ int pvae_mlp_forward(const float* x, int32_t rows, int32_t ldx, int32_t n_layers
         const dim3 grid((n_out[i] + 3) / 4, (rows + 3) / 4);
         hipLaunchKernelGGL((gemv_dense_kernel<4>), grid, dim3(256), 0, st, in, ldi, (int)rows, W[i], (int)ldw[i],
                            bias ? bias[i] : (const float*)nullptr, (int)n_in[i], (int)n_out[i],
-                           last ? 0 : (layer_acts ? (layer_acts[i] == PVAE_ACT_LINEAR ? 0 : layer_acts[i] + 1) : act_kind + 1), o, ldo);
+                           last ? out_code : (layer_acts ? (layer_acts[i] == PVAE_ACT_LINEAR ? 0 : layer_acts[i] + 1) : act_kind + 1), o, ldo);
         HIP_TRY(hipGetLastError());
         in = o;
         ldi = ldo;

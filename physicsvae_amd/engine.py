@@ -687,10 +687,10 @@ class HipEngine:
             s2.data_ptr() if s2 is not None else None, z.data_ptr(), self._stream()), "pvae_infer_logits")
         return logits, s2, z
 
-    def mlp_forward(self, x, layers, act="relu"):
+    def mlp_forward(self, x, layers, act="relu", out_act=None):
         """A stack of Linear layers on caller-owned dense weights: `layers` = [(weight [n_out, n_in], bias)], hidden
-        activation `act` (one name, or one per hidden layer), linear output (`pvae_mlp_forward`; the rollout model's
-        value branch, rmt:846-853)."""
+        activation `act` (one name, or one per hidden layer), output layer linear or `out_act` (`pvae_mlp_forward`; the
+        rollout model's value branch, rmt:846-853, and the motor decoder's helper, rmt:833-835)."""
         self._need_gpu()
         x = x.reshape(x.shape[0], -1).to(self.device, torch.float32)
         if x.stride(-1) != 1:
@@ -699,8 +699,9 @@ class HipEngine:
         acts = [act] * (n - 1) if isinstance(act, str) else ["linear" if a is None else a for a in act]
         assert len(acts) == n - 1, "one activation per hidden layer"
         key = tuple((w.data_ptr(), b.data_ptr(), w.stride(0)) for w, b in layers) + (tuple(acts),)
-        plan = getattr(self, "_mlp_plan", None)
-        if plan is None or plan[0] != key:              # pointer tables are rebuilt only when a tensor moved
+        plans = self.__dict__.setdefault("_mlp_plans", {})
+        plan = plans.get(key)
+        if plan is None:                                # pointer tables are rebuilt only when a tensor moved
             Pf = C.c_void_p * n
             Ii = C.c_int32 * n
             for w, b in layers:
@@ -709,12 +710,15 @@ class HipEngine:
                     Ii(*[w.shape[1] for w, _ in layers]), Ii(*[w.shape[0] for w, _ in layers]),
                     Ii(*[w.stride(0) for w, _ in layers]), max([w.shape[0] for w, _ in layers[:-1]] or [1]),
                     (C.c_int32 * max(n - 1, 1))(*[_lib.LAYER_ACTS[a] for a in acts]))
-            self._mlp_plan = plan
+            if len(plans) > 8:
+                plans.clear()
+            plans[key] = plan
         rows = x.shape[0]
         scratch = torch.empty(2 * rows * plan[6], dtype=torch.float32, device=self.device)
         out = torch.empty(rows, layers[-1][0].shape[0], dtype=torch.float32, device=self.device)
         _lib.check(self.lib.pvae_mlp_forward(x.data_ptr(), rows, x.stride(0), n, plan[1], plan[2], plan[3], plan[4], plan[5],
-                                             0, plan[7], scratch.data_ptr(), out.data_ptr(), out.shape[1],
+                                             0 if out_act in (None, "linear") else (1 + _lib.LAYER_ACTS[out_act]) << 8,
+                                             plan[7], scratch.data_ptr(), out.data_ptr(), out.shape[1],
                                              self._stream()), "pvae_mlp_forward")
         return out
 

@@ -97,6 +97,23 @@ def _fc_stack(layers, what):
     return Stack([l["hidden_size"] for l in hidden], acts), inits
 
 
+def _helper_stack(layers, rng):
+    """`motor_decoder_helper_layers` (rmt:491-495): fc layers, the output layer ending in tanh (asserted upstream,
+    rmt:672-673, as is a positive range).  Returns (widths, hidden activations, [init_weight dict per Linear])."""
+    assert layers[-1]["activation"] == "tanh"
+    assert rng > 0
+    if any(l.get("type") != "fc" for l in layers) or layers[-1]["hidden_size"] != "output" or len(layers) < 2:
+        raise NotImplementedError("motor_decoder_helper_layers: fc hidden layers and an fc output layer")
+    hidden = layers[:-1]
+    acts = ["linear" if l.get("activation") is None else l["activation"] for l in hidden]
+    if any(a not in ACTIVATIONS and a != "linear" for a in acts):
+        raise NotImplementedError("motor_decoder_helper_layers: hidden activations out of %s" % (sorted(ACTIVATIONS) + ["linear"]))
+    inits = [l.get("init_weight") or {"name": "normc", "std": 0.01 if l is layers[-1] else 1.0} for l in layers]
+    for info in inits:
+        get_initializer(info)
+    return [int(l["hidden_size"]) for l in hidden], acts, inits
+
+
 class SlimFC(nn.Module):
     """Linear (+activation) held as `self._model = nn.Sequential(...)` -- the ray SlimFC shape that
     gives the `._model.0.weight` key suffix."""
@@ -158,9 +175,10 @@ class FC(nn.Module):
     """rmt:234-283: `self._model = nn.Sequential(SlimFC..., [AppendLogStd])`."""
 
     def __init__(self, dims, views=None, append_log_std=False, sample_std=1.0, log_std_type="constant",
-                 device=None, act="relu", inits=None):
+                 device=None, act="relu", inits=None, out_act=None):
         """`act`: one name for every hidden layer, or one per hidden layer; `inits`: init_weight dict per Linear
-        (default: gen_layers' normc 1.0 / 0.01 for the output layer, tpv:184-189)."""
+        (default: gen_layers' normc 1.0 / 0.01 for the output layer, tpv:184-189); `out_act`: activation of the output
+        layer (the motor decoder's helper ends in tanh, rmt:491-495)."""
         super().__init__()
         mods = []
         acts = [act] * (len(dims) - 1) if isinstance(act, str) else list(act)
@@ -168,7 +186,7 @@ class FC(nn.Module):
             last = i == len(dims) - 1
             w, b = (views[i] if views is not None else (None, None))
             init = inits[i] if inits is not None else {"name": "normc", "std": 0.01 if last else 1.0}
-            mods.append(SlimFC(n_in, n_out, init, weight=w, bias=b, act=None if last else acts[i]))
+            mods.append(SlimFC(n_in, n_out, init, weight=w, bias=b, act=out_act if last else acts[i]))
         if append_log_std:
             mods.append(AppendLogStd(math.log(sample_std), dims[-1][1], type=log_std_type, device=device))
         self._model = nn.Sequential(*mods)
@@ -224,7 +242,11 @@ class PhysicsVAE(nn.Module):
         "motor_decoder_layers": DEFAULT_FC_512X3,
         "motor_decoder_load_weights": None,
         "motor_decoder_learnable": True,
-        "motor_decoder_helper_enable": False,
+        "motor_decoder_helper_enable": False,                              # rmt:490-498
+        "motor_decoder_helper_layers": fc_spec(128, 2, act_out="tanh"),
+        "motor_decoder_helper_load_weights": None,
+        "motor_decoder_helper_learnable": True,
+        "motor_decoder_helper_range": 0.5,
         "value_fn_layers": DEFAULT_FC_256X2,
         "world_model_layers": DEFAULT_FC_1024X2,
         "world_model_load_weights": None,
@@ -253,8 +275,6 @@ class PhysicsVAE(nn.Module):
             raise NotImplementedError("Unknown latent_prior_type:%s" % (cfg["latent_prior_type"],))    # rmt:624-625
         if cfg["task_encoder_inputs"] != ["body", "task"] or cfg["motor_decoder_inputs"] != ["body", "task"]:
             raise NotImplementedError("task-encoder / motor-decoder inputs must be ['body','task']")
-        if cfg.get("motor_decoder_helper_enable"):
-            raise NotImplementedError("motor_decoder_helper is not part of the training path")
 
         self.dim_state_body = int(np.prod(cfg["observation_space_body"].shape))
         self.dim_state_task = int(np.prod(cfg["observation_space_task"].shape))
@@ -268,7 +288,6 @@ class PhysicsVAE(nn.Module):
         # "normal_state_mean_one_std" / "hypersphere_uniform": the reference sketches them and crashes
         # (rmt:632, tpv:395-396, 406); built here to the specification in oracle/refpath.py (PRIORS)
         self._latent_prior_type = cfg["latent_prior_type"]
-        self._motor_decoder_helper = None
 
         te, te_init = _fc_stack(cfg["task_encoder_layers"], "task_encoder_layers")
         md, md_init = _fc_stack(cfg["motor_decoder_layers"], "motor_decoder_layers")
@@ -305,6 +324,21 @@ class PhysicsVAE(nn.Module):
         self._task_encoder = build(NET_TE)
         self._motor_decoder = build(NET_MD, append_log_std=True, sample_std=cfg["sample_std"],
                                     log_std_type=cfg["log_std_type"], device=self.engine.device)
+        # The helper (rmt:670-680, 833-835): a residual policy on the decoder's input whose tanh output, scaled by
+        # `motor_decoder_helper_range`, is added to the action.  train_physics_vae.py never builds it (RL fine-tuning
+        # does), so -- like the value branch -- it stays plain torch parameters: evaluated by `pvae_mlp_forward`, or by
+        # the torch module itself under autograd so that a policy-gradient learner can train it as upstream.
+        self._motor_decoder_helper = None
+        self._motor_decoder_helper_range = cfg.get("motor_decoder_helper_range")
+        if cfg.get("motor_decoder_helper_enable"):
+            widths, acts, inits = _helper_stack(cfg["motor_decoder_helper_layers"], self._motor_decoder_helper_range)
+            dims, prev = [], self.dim_state_body + Z
+            for width in widths:
+                dims.append((prev, width))
+                prev = width
+            dims.append((prev, self.dim_action))
+            self._motor_decoder_helper = FC(dims, act=acts, inits=inits, out_act="tanh").to(self.engine.device)
+            self.__dict__["_mh_acts"] = acts
         self._world_model = build(NET_WM)
         self.__dict__["_als"] = self._motor_decoder._model[-1]      # (a plain reference: module lookups cost microseconds per forward)
         vb_dims, prev = [], self.dim_state
@@ -340,6 +374,9 @@ class PhysicsVAE(nn.Module):
         if cfg.get("motor_decoder_load_weights"):
             self.load_weights_motor_decoder(rooted(cfg["motor_decoder_load_weights"]))
             self.set_learnable_motor_decoder(cfg["motor_decoder_learnable"])
+        if cfg.get("motor_decoder_helper_load_weights"):                                    # rmt:721-723
+            self.load_weights_motor_decoder_helper(rooted(cfg["motor_decoder_helper_load_weights"]))
+            self.set_learnable_motor_decoder_helper(cfg["motor_decoder_helper_learnable"])
         if cfg.get("world_model_load_weights"):
             self.load_weights_world_model(rooted(cfg["world_model_load_weights"]))
             self.set_learnable_world_model(cfg["world_model_learnable"])
@@ -404,7 +441,8 @@ class PhysicsVAE(nn.Module):
         (`_cur_task_encoder_mu`, `value_function()`): the rollout loop reads neither."""
         obs = input_dict["obs_flat"].float()
         eng = self.engine
-        if obs.dim() != 2 or obs.shape[0] > eng.max_batch or self._latent_prior is not None or eng.lookahead != 1:
+        if (obs.dim() != 2 or obs.shape[0] > eng.max_batch or self._latent_prior is not None or eng.lookahead != 1
+                or self._motor_decoder_helper is not None):       # (the helper's term joins between decoder and world model)
             return self._forward_staged(obs, state, seq_lens, eps)
         rows = obs.shape[0]
         noise = bool(self.latent_prior_noise)
@@ -448,6 +486,9 @@ class PhysicsVAE(nn.Module):
         after writes the library cannot see).
         `scope`: "xcd" (one XCD), "chip" (all CUs: stacks too big for one XCD, e.g. 4x1024), "auto".  Raises RuntimeError when
         nothing fits: the launch path stays in use."""
+        if self._motor_decoder_helper is not None:
+            raise NotImplementedError("the rollout server serves encoder + decoder; a model with motor_decoder_helper_enable "
+                                      "keeps the launch path")
         self.engine.rollout_server_start(idle_ms=idle_ms, lifetime_s=lifetime_s, scope=scope)
         self.__dict__["_srv_on"] = True
 
@@ -576,6 +617,16 @@ class PhysicsVAE(nn.Module):
             return self._motor_decoder._model[-1](torch.from_numpy(a.copy())[None]), state_cnt
         z = torch.cat([z_body.to(self.engine.device), z_task.to(self.engine.device)], dim=-1)
         a_hat = self.engine.net_forward(NET_MD, z)
+        mh = self._motor_decoder_helper
+        if mh is not None:                                            # rmt:833-835
+            if torch.is_grad_enabled():
+                add = mh(z.float())
+            else:
+                layers = self.__dict__.get("_mh_layers")
+                if layers is None:
+                    layers = self.__dict__["_mh_layers"] = [(m._model[0].weight, m._model[0].bias) for m in mh._model]
+                add = self.engine.mlp_forward(z, layers, act=self.__dict__["_mh_acts"], out_act="tanh")
+            a_hat = a_hat + self._motor_decoder_helper_range * add
         return self._motor_decoder._model[-1](a_hat), state_cnt
 
     def forward_world(self, obs, logits):
@@ -644,6 +695,15 @@ class PhysicsVAE(nn.Module):
         self._motor_decoder.eval()
         self.reload_rollout_server()
 
+    def save_weights_motor_decoder_helper(self, file):                # rmt:891-893
+        if self._motor_decoder_helper is not None:
+            torch.save(_portable(self._motor_decoder_helper.state_dict()), file)
+
+    def load_weights_motor_decoder_helper(self, file):                # rmt:907-910
+        if self._motor_decoder_helper is not None:
+            self._motor_decoder_helper.load_state_dict(torch.load(file, map_location="cpu"))
+            self._motor_decoder_helper.eval()
+
     def save_weights_world_model(self, file):
         torch.save(_portable(self._world_model.state_dict()), file)
 
@@ -668,6 +728,11 @@ class PhysicsVAE(nn.Module):
     def set_learnable_motor_decoder(self, learnable, free_log_std=True):       # rmt:936-941
         for name, p in self._motor_decoder.named_parameters():
             p.requires_grad = free_log_std if "log_std" in name else learnable
+
+    def set_learnable_motor_decoder_helper(self, learnable):           # rmt:942-946
+        if self._motor_decoder_helper is not None:
+            for p in self._motor_decoder_helper.parameters():
+                p.requires_grad = learnable
 
     def set_learnable_world_model(self, learnable):
         for p in self._world_model.parameters():

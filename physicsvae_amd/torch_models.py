@@ -163,6 +163,11 @@ class TrainModel(tune.Trainable):
     # -- Trainable hooks ------------------------------------------------------------------
     def setup(self, config):
         self.model = self.create_model(config)
+        if getattr(self.model, "_motor_decoder_helper", None) is not None:
+            # upstream's supervised loss would see the helper's term in a_hat (rmt:833-835) and train the helper with the
+            # decoder; the HIP step computes the decoder's action alone -- refuse instead of training a different model
+            raise NotImplementedError("supervised training with motor_decoder_helper_enable is not built: the helper is served "
+                                      "on the rollout path (PhysicsVAE.forward / forward_decoder) only")
         self.engine = self.model.engine
         self.device = self.engine.device
         self.dp = parallel.DataParallel.from_env()

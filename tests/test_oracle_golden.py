@@ -280,6 +280,33 @@ def test_lookahead_unroll_matches_reference(golden, name):
     assert all(str(k).startswith("_world_model") for k in g["world_grad_keys"])
 
 
+@pytest.mark.parametrize("name,arch", [("helper_tiny", R.make_arch(7, 3, latent=4, te=(16, 2), md=(24, 2), wm=(32, 2))),
+                                       ("helper_default", R.make_arch(197, 45))])
+def test_motor_decoder_helper_restatement_matches_reference(golden, name, arch):
+    """`motor_decoder_helper_enable` (rmt:490-498, 670-680, 833-835): layout and forward of the restated model against the
+    reference's own model at the same weights, observations and draws -- bit for bit on CPU."""
+    g = golden(name)
+    h = R.with_helper(arch, rng=float(g["helper_range"]))
+    assert [k for k, _ in R.state_dict_spec(h)] == list(g["sd_keys"])
+    assert [list(s) + [0] * (2 - len(s)) for _, s in R.state_dict_spec(h)] == g["sd_shapes"].tolist()
+    sd = R.perturb_biases(R.init_state_dict(h, seed=1), seed=3)
+    k_out = "_motor_decoder_helper._model.%d._model.0.weight" % len(h["mh"])
+    sd[k_out] = sd[k_out] * 60.0
+    m = R.RefModel(h)
+    m.load_state_dict(sd)
+    m.eval()
+    obs, eps = torch.from_numpy(g["obs"]), torch.from_numpy(g["eps"])
+    for noise, tag in ((False, "mean"), (True, "noise")):
+        m.latent_prior_noise = noise
+        m.eps_source = lambda shape: eps
+        with torch.no_grad():
+            logits = m(obs)
+        assert torch.equal(logits, torch.from_numpy(g[tag + "_logits"]))
+        assert torch.equal(m.cur_z, torch.from_numpy(g[tag + "_z"]))
+        assert torch.equal(m.cur_future_state, torch.from_numpy(g[tag + "_future_state"]))
+        assert torch.equal(m.cur_value, torch.from_numpy(g[tag + "_value"]))
+
+
 def test_frozen_nets_get_no_grad(golden):
     g = golden("single_tiny")
     assert all(str(k).startswith("_world_model") for k in g["world_grad_keys"])
