@@ -1219,6 +1219,16 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
         tile_p = (xcd >> 1) * 8 + (loc >> 2);
     }
 #endif
+    if (PT == 64 && ga.rowxcd) {
+        // Many row blocks (1024 rows and more): every XCD takes a RANGE OF ROW BLOCKS and walks all column blocks with it,
+        // row blocks fastest -- its share of X (rq x 256 KB) stays in its L2 while the W tiles stream through once per
+        // XCD.  The column-range mapping above re-reads all of X for every column block an XCD owns: at 4096 rows 256 MB
+        // of fabric traffic per layer against 48 MB here.
+        const int rq = (tiles_q + 7) >> 3;
+        tile_q = xcd * rq + loc % rq;
+        tile_p = loc / rq;
+        if (tile_q >= tiles_q) return;
+    }
     if (tile_p >= tiles_p) return;
     const int q0 = tile_q * 64, p0 = tile_p * PT;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2408,6 +2418,17 @@ inline bool uses_64x32(int M, int N) { return g_ws64 && M >= 512 && M % 64 == 0 
 // 1024 rows and more: 64x64 tiles whenever THEY still give every CU a workgroup; PVAE_WS6464=0: off (A/B)
 static int g_ws6464 = [] { const char* e = getenv("PVAE_WS6464"); return (e && e[0] == '0') ? 0 : 1; }();
 inline bool uses_64x64(int M, int N) { return g_ws6464 && uses_64x32(M, N) && N % 64 == 0 && (M / 64) * (N / 64) >= 256; }
+// ... with the XCDs partitioning the ROW blocks (see splitk_ws64_body); PVAE_WS6464_ROWS=0: column ranges as elsewhere (A/B)
+static int g_ws6464_rows = [] { const char* e = getenv("PVAE_WS6464_ROWS"); return (e && e[0] == '0') ? 0 : 1; }();
+inline GemmGrid make_grid_6464(int M, int N, GemmArgs& ga) {
+    GemmGrid g = make_grid(M, N, 64, 64);
+    ga.tiles_q = g.tiles_q; ga.tiles_p = g.tiles_p; ga.p_per_xcd = g.p_per_xcd;
+    if (g_ws6464_rows) {
+        ga.rowxcd = 1;
+        g.grid = 8 * ((g.tiles_q + 7) / 8) * g.tiles_p;
+    }
+    return g;
+}
 // ... and the input-gradient half of the fused backward pairs (PVAE_PAIR64=0: off, A/B)
 static int g_pair64 = [] { const char* e = getenv("PVAE_PAIR64"); return (e && e[0] == '0') ? 0 : 1; }();
 inline bool pair_uses_64x32(int M, int N) { return g_pair64 && uses_64x32(M, N); }
@@ -2429,8 +2450,8 @@ inline hipError_t gemm_forward_epi(const float* X, int ldx, const float* W, int 
     }
     if constexpr (std::is_same<Epi, EpiBiasAct>::value) {
         if (uses_64x64(M, N)) {
-            const GemmGrid g = make_grid(M, N, 64, 64);
-            const GemmArgs ga{X, ldx, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd};
+            GemmArgs ga{X, ldx, W, ldw, K, 0, 0, 0};
+            const GemmGrid g = make_grid_6464(M, N, ga);
             PVAE_LAUNCH((gemm_splitk_ws64_kernel<true, Epi, 64>), dim3(g.grid), dim3(512), st, PVAE_GA_PASS(ga), e);
             return hipGetLastError();
         }
@@ -2487,8 +2508,8 @@ inline hipError_t gemm_dgrad_epi(const float* dZ, int ldz, const float* W, int l
                                  const EpiD& e, hipStream_t st) {
     if constexpr (std::is_same<EpiD, EpiMask>::value) {
         if (uses_64x64(M, Kin)) {                               // ... at >= 1024 rows
-            const GemmGrid g = make_grid(M, Kin, 64, 64);
-            const GemmArgs ga{dZ, ldz, W, ldw, N, g.tiles_q, g.tiles_p, g.p_per_xcd};
+            GemmArgs ga{dZ, ldz, W, ldw, N, 0, 0, 0};
+            const GemmGrid g = make_grid_6464(M, Kin, ga);
             PVAE_LAUNCH((gemm_splitk_ws64_kernel<false, EpiD, 64>), dim3(g.grid), dim3(512), st, PVAE_GA_PASS(ga), e);
             return hipGetLastError();
         }
