@@ -12,7 +12,12 @@ import numpy as np
 def short(n):
     epi = "EpiGradStore" if "EpiGradStore" in n else "EpiGradAdam"
     if "wgrad_pair" in n: return "wgrad_pair_kernel<%s>" % epi
+    if "bwd_pair64" in n: return "bwd_pair64_kernel<EpiMask,%s>" % epi
     if "bwd_pair" in n: return "bwd_pair_kernel<%s,%s>" % ("EpiSamplerSeed" if "SamplerSeed" in n else "EpiMask", epi)
+    if "splitk_ws64" in n:                       # 64x32 tiles, or 64x64 (third template argument 64)
+        kind = "P_ROW,EpiBiasAct" if "EpiBiasAct" in n else "P_COL,EpiMask"
+        return "gemm_splitk_ws64_kernel<%s%s>" % (kind, ",64" if (", 64>" in n or "Li64E" in n) else "")
+    if "EpiActionSeed" in n: return "gemm_splitk_%s_kernel<P_COL,EpiActionSeed>" % ("reg16" if "reg16" in n else "ws")
     if "wgrad_reg" in n: return "gemm_wgrad_reg_kernel<%s>" % epi
     if "reg16" in n and "EpiMse" in n: return "gemm_splitk_reg16_kernel<EpiMse>"
     if "reg16" in n: return "gemm_splitk_reg16_kernel<EpiBiasAct>"
