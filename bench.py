@@ -30,7 +30,8 @@ the rocprofv3 duration when it is available (the larger of the two).  `traffic` 
 launch from separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md HBM
 section), collected live by the same child runs.  `cpu_baseline` is the oracle's restatement of
 the reference loop (oracle/refpath.py: the checker, timed here, never the product path) on this
-host's cores over a bounded sample, swept over thread counts.
+host's cores: a short thread-count sweep, then one warm-up epoch and three timed epochs at the
+best count.
 """
 import argparse
 import ctypes as C
@@ -252,40 +253,83 @@ def cpu_model():
     return "unknown"
 
 
+def physical_cores():
+    """(physical cores, sockets) of this host from /proc/cpuinfo's (physical id, core id) pairs; (None, None) if unreadable."""
+    try:
+        cores, phys, cur = set(), set(), {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = (t.strip() for t in line.split(":", 1))
+                cur[k] = v
+            elif not line.strip() and cur:
+                if "physical id" in cur and "core id" in cur:
+                    cores.add((cur["physical id"], cur["core id"]))
+                    phys.add(cur["physical id"])
+                cur = {}
+        return (len(cores) or None), (len(phys) or None)
+    except OSError:
+        return None, None
+
+
 def cpu_baseline(a, sd, Db, Da, Z, W, D, phase, synth_demo):
+    """the oracle's restatement of the reference loop (per-sample Dataset + DataLoader collate, full forward
+    incl. value branch, torch.optim.Adam, per-batch .item()) on this host's cores, same dataset shape / batch / stacks:
+    a short sweep picks the thread count, then ONE warm-up epoch and >= 3 timed epochs at that count (bounded: ~10 k
+    samples per epoch, ~1 s each at the best count on the boxes seen so far).  Also the 1-thread and default-thread rates
+    of the sweep.  `cores` = threads used for `value`; the host's physical core count is reported beside it."""
     import torch
     from oracle import refpath as R        # the checker, timed as the CPU baseline -- this leg only
     arch = R.make_arch(Db, Da, latent=Z, te=(W, D), md=(W, D), wm=(W, D))
-    data = synth_demo(0, 10, 1000, Db, Da)                       # bounded CPU sample of the workload's shape
+    data = synth_demo(0, 10, 1000, Db, Da)                       # the configs[1-2] demo set (9 990 windows)
     X, Y = R.build_windows(data)
     default_threads = torch.get_num_threads()
     sweep = sorted({t for t in (1, 8, 16, 32, 64, default_threads) if 1 <= t <= max(default_threads, 1)})
-    per_setting_s = 4.0
+    per_setting_s = 2.0
     results = {}
     t_all = time.perf_counter()
+    M = 10 ** 9 if phase == "world" else 0
+
+    def trainer():
+        return R.RefTrainer(arch, sd, X, Y, a.batch, max_iter_world_model=M)
     for t in sweep:
         torch.set_num_threads(t)
-        trc = R.RefTrainer(arch, sd, X, Y, a.batch, max_iter_world_model=(10 ** 9 if phase == "world" else 0))
+        trc = trainer()
         trc.step(max_batches=1)                                   # warm-up (allocator, thread pool)
         n, t0 = 0, time.perf_counter()
         while True:
             trc.step(max_batches=2)
             n += 2
             dt = time.perf_counter() - t0
-            if dt > per_setting_s or n >= 60:
+            if dt > per_setting_s or n >= 40:
                 break
         results[t] = n * a.batch / dt
-    torch.set_num_threads(default_threads)
     best = max(results, key=results.get)
-    return {"value": results[best], "unit": "samples/s", "cores": best, "threads_best": best,
+    # the measurement proper: whole epochs at the best thread count, bounded to ~25 s
+    torch.set_num_threads(best)
+    trc = trainer()
+    t0 = time.perf_counter()
+    trc.step()                                                    # warm-up epoch (not timed)
+    warm_s = time.perf_counter() - t0
+    epochs = 3 if warm_s * 3 < 25.0 else max(1, int(25.0 / max(warm_s, 1e-3)))
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        trc.step()
+    dt = time.perf_counter() - t0
+    value = epochs * len(X) / dt
+    torch.set_num_threads(default_threads)
+    ncores, nsock = physical_cores()
+    return {"value": value, "unit": "samples/s", "cores": best, "threads_best": best,
+            "physical_cores": ncores, "sockets": nsock, "host_cpus": os.cpu_count(),
+            "epochs_timed": epochs, "warmup_epochs": 1, "samples_per_epoch": len(X), "seconds_timed": dt,
             "value_1thread": results.get(1), "value_default_threads": results.get(default_threads),
             "default_threads": default_threads, "sweep": {str(k): v for k, v in results.items()},
-            "kind": "port", "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
-            "sample": "%s phase, minibatches of %d from a 10x1000 synthetic demo of the same dims, "
-                      "oracle/refpath.RefTrainer (stock torch CPU ops in the reference's op order: per-sample "
-                      "Dataset + collate, full forward incl. value branch, torch.optim.Adam, per-batch .item()); "
-                      "per thread count 1 warm-up minibatch then up to %.0f s / 60 minibatches; %.1f s in total"
-                      % (phase, a.batch, per_setting_s, time.perf_counter() - t_all)}
+            "kind": "port", "cpu_model": cpu_model(),
+            "sample": "%s phase, batch %d, the 10x1000 synthetic demo of the same dims (%d windows per epoch), "
+                      "oracle/refpath.RefTrainer (stock torch CPU ops in the reference's op order: per-sample Dataset + "
+                      "collate, full forward incl. value branch, torch.optim.Adam, per-batch .item()); thread sweep of "
+                      "%.0f s / <= 40 minibatches per count, then 1 warm-up epoch + %d timed epochs at %d threads "
+                      "(SURVEY.md 8d); %.1f s in total"
+                      % (phase, a.batch, len(X), per_setting_s, epochs, best, time.perf_counter() - t_all)}
 
 
 # ---------------------------------------------------------------------------------------------

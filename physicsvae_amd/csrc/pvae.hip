@@ -1490,7 +1490,14 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
         const float* dz = c->ws + w->dz[i];
         const float* xin = i == 0 ? c->ws + w->in : c->ws + w->act[i - 1];
         // (j == i: the launch also reads W_i, so the update MUST wait for the next one)
+#ifdef PVAE_DIAG_EPI_ADAM
+        // TIMING-ONLY diagnostic build (docs/experiments.md, round 5): Adam in the epilogue of the same-layer pair, as a
+        // second ("ping-pong") parameter arena would allow -- here it overwrites the W_i that the pair's input-gradient half
+        // is reading, so the results are wrong; launches, traffic and epilogues are those of the ping-pong schedule.
+        const bool defer = can_defer && j >= 0 && j != i && !with_fold;
+#else
         const bool defer = can_defer && j >= 0 && (!with_fold || j == i);
+#endif
         // (narrow launches -- a stack's last and first layer -- hand a big pending update on to the next hidden-layer
         //  pair of the step, when there is one: take_pending)
         const bool narrow = j == i && !with_fold && ((i == last && last >= 2) || (i == 0 && wide_follows_layer0));

@@ -536,7 +536,11 @@ class PhysicsVAE(nn.Module):
         st._cur_future_state = None
         st._cur_body_encoder_variable = v_s1
         st._cur_task_encoder_variable = t_z
-        st._lazy = (t_obs, 1, None, noise, st._rng_calls) if self.rollout_predicts_state == "lazy" else (t_obs, 1)
+        # the prediction is a launch-path forward on the same observation and the same (seed, offset) draws: deferred to the
+        # first read ("lazy"), made with this forward (True: as upstream, rmt:758) or never (False)
+        st._lazy = (t_obs, 1, None, noise, st._rng_calls) if self.rollout_predicts_state in ("lazy", True) else (t_obs, 1)
+        if self.rollout_predicts_state is True:
+            self._get_future_state()
         st._cur_value = None
         if self._latent_prior_type is False:
             st._mu, st._logvar = t_z, None

@@ -456,6 +456,10 @@ class TrainModel(torch_models.TrainModel):
             target = os.path.join(checkpoint_dir, fname)
             fn(target)
             print("Saved:", target)
+        if m._latent_prior is not None:               # tpv:462-466: the sixth file of a model with a learned prior mean
+            target = os.path.join(checkpoint_dir, "latent_prior.pt")
+            m.save_weights_latent_prior(target)
+            print("Saved:", target)
         return path
 
 

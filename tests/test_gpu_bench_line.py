@@ -91,5 +91,8 @@ def test_bench_plain_single_gpu_line():
     for roof in (d["roofline"], d["world_roofline"]):
         assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["peak"] == 157.3
     cb = d["cpu_baseline"]
-    assert cb["value"] >= cb["value_1thread"] > 0 and cb["threads_best"] in [int(k) for k in cb["sweep"]]
+    assert cb["value"] >= 0.8 * cb["value_1thread"] > 0 and cb["threads_best"] in [int(k) for k in cb["sweep"]]
+    # whole epochs after one warm-up epoch at the best thread count; physical cores reported beside the threads
+    assert cb["epochs_timed"] >= 1 and cb["warmup_epochs"] == 1 and cb["samples_per_epoch"] == 9990
+    assert cb["cores"] == cb["threads_best"] and cb["physical_cores"] and cb["physical_cores"] <= cb["host_cpus"]
     assert len(d["timing"]["region_values"]) == 3

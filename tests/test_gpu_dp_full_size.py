@@ -1,0 +1,60 @@
+"""BASELINE configs[3] and configs[4] at their REAL sizes, as far as one GPU allows: eight ranks (sharing the device when the
+box has fewer than eight GPUs: every "peer" is another process on the same device -- the mapping, flags, slice ownership and
+arithmetic of the exchange are exercised, the links are not) against ONE process that holds the global batch.
+
+  configs[3]: 8 ranks x 256 rows (global batch 2048), dim_state_body 197, dim_action 45, TE / MD / WM 4x1024
+  configs[4]: 8 ranks x 512 rows (global batch 4096), dim_state_body 400, dim_action 90, 4x1024
+
+Three optimizer steps in each phase from a common state, for both peer-mapped exchange forms and the torch.distributed
+(gloo) transport.  What the reference fixes (tm:131-161): one optimizer step per GLOBAL minibatch, whose loss is the
+unweighted mean over all of its rows -- so N ranks with B rows each must equal one process with N*B rows up to fp32
+summation order: losses 1e-5, update rel-L2 1e-3, replicas bit-identical, frozen stacks untouched."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dp_full_size_worker.py")
+
+
+def _run(tmp_path, config, form, world=8):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / ("%s_%s" % (config, form)))
+    ndev = max(torch.cuda.device_count(), 1)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PVAE_DP_EXCHANGE=form)
+    procs = [subprocess.Popen([sys.executable, WORKER, ROOT, out, config],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r % ndev), PVAE_LOCAL_DEVICE=str(r % ndev)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [torch.load(out + ".%d" % r) for r in range(world)]
+
+
+@pytest.mark.parametrize("form", ["p2p", "p2p_push", "default"])
+@pytest.mark.parametrize("config", ["c3", "c5"])
+def test_eight_ranks_at_baseline_sizes_match_one_process_with_the_global_batch(tmp_path, config, form):
+    res = _run(tmp_path, config, form)
+    per_gpu = {"c3": 256, "c5": 512}[config]
+    assert all(r["ranks"] == 8 and r["global_batch"] == 8 * per_gpu for r in res)
+    if form != "default":
+        assert all(r["in_library"] for r in res)
+    for phase in ("world", "joint"):
+        for r in res:
+            assert r[phase]["replicas_identical"] is True and r[phase]["timeouts"] == 0, (phase, r[phase])
+            assert r[phase]["losses_n_ranks"] == res[0][phase]["losses_n_ranks"]
+        e = res[0][phase]
+        print(config, form, phase, {k: v for k, v in e.items() if not k.startswith("losses")})
+        assert e["update_norm"] > 0.0 and e["frozen_untouched"] is True, e
+        assert e["losses_n_ranks"][0] != e["losses_n_ranks"][1]                 # the steps really trained
+        assert e["max_rel_loss_diff"] < 1e-5 and e["max_rel_term_diff"] < 1e-4, e
+        assert e["update_rel_l2_diff"] < 1e-3, e

@@ -142,8 +142,8 @@ def test_training_run_tracks_the_specification(prior):
     import os
     import tempfile
     d = tempfile.mkdtemp()
-    tr.save_checkpoint(d)
-    tr.model.save_weights_latent_prior(os.path.join(d, "latent_prior.pt"))
+    tr.save_checkpoint(d)                        # (writes latent_prior.pt itself when the model has one, tpv:462-466)
+    assert os.path.exists(os.path.join(d, "latent_prior.pt")) == (prior == R.PRIORS[1])
     tr2 = make_trainer(arch, data, batch, device=DEV)
     tr2.restore(os.path.join(d, "model.pth"))
     for k, v in tr.model.state_dict().items():

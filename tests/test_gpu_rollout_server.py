@@ -180,6 +180,39 @@ def test_module_forward_served_equals_module_forward_launched():
     assert not torch.equal(d1, d2) and torch.equal(d2, want)
 
 
+@pytest.mark.parametrize("noise", [False, True])
+def test_served_forward_honours_rollout_predicts_state(noise):
+    """`rollout_predicts_state` on the SERVED path (rmt:758: upstream evaluates forward_world with every forward): True --
+    the prediction is there when forward returns; "lazy" -- on first read; False -- never.  In each case it is the launch
+    path's prediction for the same observation and draws, bit for bit."""
+    arch, tr, obs = _default_trainer()
+    m = tr.model
+    m.eval()
+    m.latent_prior_noise = noise
+    m._st._rng_calls = 40
+    with torch.no_grad():
+        m.forward({"obs_flat": obs[:1].to(DEV)}, [], None)
+        want = m._cur_future_state.cpu().clone()
+    m.start_rollout_server(idle_ms=2000.0, lifetime_s=30.0)
+    try:
+        with torch.no_grad():
+            for setting in (True, "lazy", False):
+                m.rollout_predicts_state = setting
+                m._st._rng_calls = 40
+                m.forward({"obs_flat": obs[:1]}, [], None)
+                if setting is True:
+                    assert m._st._cur_future_state is not None              # evaluated with the forward, as upstream
+                    assert torch.equal(m._st._cur_future_state.cpu(), want)
+                elif setting == "lazy":
+                    assert m._st._cur_future_state is None
+                    assert torch.equal(m._cur_future_state.cpu(), want)
+                else:
+                    assert m._cur_future_state is None
+    finally:
+        m.rollout_predicts_state = "lazy"
+        m.stop_rollout_server()
+
+
 @pytest.mark.parametrize("mailbox", ["auto", "host"])
 def test_decoder_only_requests_equal_forward_decoder(mailbox, monkeypatch):
     """The "pass_through" rollout (envs/rllib_env_imitation.py:233-258): the caller draws z itself and calls

@@ -680,6 +680,21 @@ def test_prior_kinds_layout_and_state_dict():
         tr.model.set_learnable_task_encoder(True); tr.model.set_learnable_motor_decoder(True)
         tr.model.set_learnable_world_model(False); tr.model.set_learnable_latent_prior(True)
         assert tr.phase() == (_lib.PHASE_JOINT, want_joint)
+        # tpv:440-467: five files, and a sixth -- latent_prior.pt -- exactly when the model has a learned prior mean
+        import tempfile
+        d = tempfile.mkdtemp()
+        tr.save_checkpoint(d)
+        five = ["model.pt", "model.pth", "motor_decoder.pt", "task_encoder.pt", "world_model.pt"]
+        if prior == R.PRIORS[1]:
+            assert sorted(os.listdir(d)) == ["latent_prior.pt"] + five
+            got = torch.load(os.path.join(d, "latent_prior.pt"))
+            want = {k[len("_latent_prior."):]: v for k, v in ref_sd.items() if k.startswith("_latent_prior.")}
+            assert list(got) == list(want) and all(torch.equal(got[k], want[k]) for k in want)
+            tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, 2), 5))
+            tr.model.load_weights_latent_prior(os.path.join(d, "latent_prior.pt"))       # rmt:925-928
+            assert all(torch.equal(tr.model.state_dict()["_latent_prior." + k].cpu(), want[k]) for k in want)
+        else:
+            assert sorted(os.listdir(d)) == five
 
 
 def test_cond_rel_windows_match_the_reference_capture(golden, tmp_path):
