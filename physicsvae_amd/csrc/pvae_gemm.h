@@ -1121,6 +1121,16 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
 #if PVAE_WS_SUPER && !defined(PVAE_WS_SLOW0)
         if constexpr (!Pro::kActive) {
             for (int t0 = 0; t0 < nk; t0 += 2) {
+                // The fragments of tile t0 (read in the second half of the previous super-step) must have LEFT the LDS before
+                // this barrier: behind it the loaders restage that slot (tile t0+6) and the slot of t0-1 (tile t0+5), ONE
+                // phase after their last reads -- and nothing orders an LDS-DMA write behind a ds_read that is still queued
+                // (cdna_hip_programming.md: restage >= 2 phases after the last read, or 1 phase when an lgkmcnt retired the
+                // reads first).  Alone on the chip the reads return in ~100 cycles and the DMA data arrives >= 1000 cycles
+                // later; with other processes' workgroups on the same CU saturating its LDS port the window opens: round 5
+                // saw ~1 wrong 16- or 32-row tile per 100 hidden-layer launches with 4-8 processes on one GPU
+                // (tools/p2p_race_hunt.py; the one-barrier-per-tile ring restages two phases later and never showed it).
+                // The wait is free: the reads were issued before the 16 MFMAs of the previous half-step.
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                      // tiles t0+1 and t0+2 landed; slots of t0-1, t0 are free
                 asm volatile("" ::: "memory");
                 fread(lds + ((t0 + 1) % S) * kStage, F1);          // (past the end: stale slot, never used)

@@ -113,6 +113,10 @@ for name in ("world", "joint"):
             "max_rel_term_diff": float(((losses[:, 1:] - l1[:, 1:]).abs() / l1[:, 1:].abs().clamp_min(1e-6)).max()),
             "update_norm": float(d_1.norm()),
             "update_rel_l2_diff": float((d_dp - d_1).norm() / d_1.norm().clamp_min(1e-30)),
+            # elements whose update is off by more than a tenth of the largest update: Adam turns a gradient entry within
+            # rounding of zero into a +-lr step whose sign the summation order decides -- a handful of such entries is
+            # conditioning, thousands would be a stale read
+            "update_flip_fraction": float(((d_dp - d_1).abs() > 0.1 * d_1.abs().max()).double().mean()),
             "frozen_untouched": all(torch.equal(eng.segment(eng.params, [n]), eng.segment(start, [n])) for n in frozen)})
         del e1
     res[name] = entry

@@ -8,7 +8,9 @@ arithmetic of the exchange are exercised, the links are not) against ONE process
 Three optimizer steps in each phase from a common state, for both peer-mapped exchange forms and the torch.distributed
 (gloo) transport.  What the reference fixes (tm:131-161): one optimizer step per GLOBAL minibatch, whose loss is the
 unweighted mean over all of its rows -- so N ranks with B rows each must equal one process with N*B rows up to fp32
-summation order: losses 1e-5, update rel-L2 1e-3, replicas bit-identical, frozen stacks untouched."""
+summation order: losses 1e-5, update rel-L2 5e-3 with at most a handful of sign-flipped near-zero entries, replicas
+bit-identical, frozen stacks untouched.  The two peer-mapped forms sum in rank order: their results are bit-identical to each
+other (checked), run to run (tools/p2p_race_hunt.py)."""
 import os
 import socket
 import subprocess
@@ -57,4 +59,20 @@ def test_eight_ranks_at_baseline_sizes_match_one_process_with_the_global_batch(t
         assert e["update_norm"] > 0.0 and e["frozen_untouched"] is True, e
         assert e["losses_n_ranks"][0] != e["losses_n_ranks"][1]                 # the steps really trained
         assert e["max_rel_loss_diff"] < 1e-5 and e["max_rel_term_diff"] < 1e-4, e
-        assert e["update_rel_l2_diff"] < 1e-3, e
+        # (the update: Adam maps a gradient entry g to ~ lr g / (|g| + 1e-8), so an entry within fp32 rounding of zero moves by
+        #  +-lr with a sign the summation order decides.  ONE such entry of the 3.6 M / 7 M is 1e-3 of the update's L2 norm:
+        #  measured on configs[3]'s world phase, the rank-order sum of the peer-mapped exchange lands 2.7e-5 from the single
+        #  process and gloo's ring order 1.2e-3, same gradients otherwise.  So: rel-L2 5e-3 AND at most a few dozen entries off
+        #  by a sizeable step -- a stale read moves hundreds of thousands.)
+        assert e["update_rel_l2_diff"] < 5e-3 and e["update_flip_fraction"] < 1e-5, e
+
+
+@pytest.mark.parametrize("config", ["c3"])
+def test_the_two_peer_mapped_forms_agree_bit_for_bit_at_baseline_size(tmp_path, config):
+    """pull and push both sum the eight shard gradients in rank order: same parameters bit for bit, in both phases (a
+    race in either -- or in the kernels under eight processes' contention -- would break this; round 5 found one)."""
+    a = _run(tmp_path, config, "p2p")
+    b = _run(tmp_path, config, "p2p_push")
+    for phase in ("world", "joint"):
+        assert a[0][phase]["params_checksum"] == b[0][phase]["params_checksum"], phase
+        assert a[0][phase]["losses_n_ranks"] == b[0][phase]["losses_n_ranks"], phase

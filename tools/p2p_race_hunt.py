@@ -58,6 +58,8 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         tr = make_trainer(synth_demo(0, 1, 4, Db, Da), per_gpu, dev, width=W, depth=D, latent=Z, extra={"dp_exchange": form})
     eng, dp = tr.engine, tr.dp
+    if os.environ.get("PVAE_HUNT_MODE") == "local":     # the peers stay mapped, but every rank applies ITS OWN gradient: no peer traffic
+        eng.comm_mode("local")
     gen = torch.Generator(device=dev).manual_seed(0)
     states = torch.randn(E * T, Db, generator=gen, device=dev)
     actions = torch.randn(E * T, Da, generator=gen, device=dev).clamp_(-3, 3)
@@ -77,6 +79,7 @@ def main():
     start = eng.params.clone()
     eps_all = torch.randn(K, B, Z, generator=torch.Generator(device="cpu").manual_seed(1234)).to(dev)
     losses = torch.zeros(K, 5, dtype=torch.float32, device=dev)
+    junk = torch.ones(64 << 20, device=dev) if os.environ.get("PVAE_HUNT_FLUSH") == "1" else None
     ref = refg = None                                   # [K] parameter / gradient arenas of repetition 0
     bad = 0
     for rep in range(R):
@@ -86,7 +89,7 @@ def main():
         eng.exp_avg_sq.zero_()
         torch.cuda.synchronize()
         dist.barrier()
-        got, gotg = [], []
+        got, gotg, gotw = [], [], []
         t_rep = time.perf_counter()
         for i in range(K):
             first, rows, grows = dp.shard(i, n_win, per_gpu)
@@ -98,20 +101,53 @@ def main():
             if os.environ.get("PVAE_HUNT_SYNC") == "1":
                 torch.cuda.synchronize()
                 dist.barrier()
+            if os.environ.get("PVAE_HUNT_FLUSH") == "1":    # stream 256 MB through every XCD's L2: nothing cached before survives
+                junk_sum = junk.sum()
             got.append(eng.params.clone())
             gotg.append(eng.grads.clone())              # (the exchange leaves this rank's own gradient where the backward pass put it)
+            gotw.append(eng.workspace.clone())
         torch.cuda.synchronize()
         dt = time.perf_counter() - t_rep
         to = eng.p2p_status()[2] if eng.has_p2p else 0
         if to or dt > 1.0 or (rank == 0 and rep % 5 == 0):
             print("rank %d rep %d: %.2f s, %d waits gave up so far" % (rank, rep, dt, to), flush=True)
         if ref is None:
-            ref, refg = got, gotg
+            ref, refg, refw = got, gotg, gotw
             continue
+        for i in range(K):                      # which panel of the workspace is the first (in dataflow order) to differ?
+            if torch.equal(gotw[i].view(torch.int32), refw[i].view(torch.int32)):
+                continue
+            from physicsvae_amd import _lib as L_
+            import ctypes as C_
+            net = L_.NET_WM if wp else L_.NET_TE
+            lays = [l for l in eng.layers if l["net"] == net]
+            order = [("in", 0)] + [("act", j) for j in range(len(lays))] + [("dz", j) for j in reversed(range(len(lays)))]
+            kinds = {"in": 0, "d_in": 1, "act": 2, "dz": 3}
+            rep_ = []
+            for kind, j in order:
+                off = int(eng.lib.pvae_workspace_offset(C_.byref(eng.cfg), kinds[kind], net, j))
+                width = lays[0]["ld"] if kind == "in" else lays[j]["n_out_pad"]
+                a_ = gotw[i][off: off + 256 * width].view(256, width)
+                b_ = refw[i][off: off + 256 * width].view(256, width)
+                ne_ = (a_.view(torch.int32) != b_.view(torch.int32))
+                if int(ne_.sum()):
+                    rows_ = ne_.any(dim=1).nonzero().flatten()
+                    cols_ = ne_.any(dim=0).nonzero().flatten()
+                    rep_.append("%s[%d]: %d floats, rows %d..%d (%d rows), cols %d..%d (%d cols), max abs %.2e" %
+                                (kind, j, int(ne_.sum()), int(rows_[0]), int(rows_[-1]), rows_.numel(), int(cols_[0]), int(cols_[-1]),
+                                 cols_.numel(), float((a_ - b_).abs().max())))
+            print("rank %d rep %d step %d workspace: %s" % (rank, rep, i + 1, " | ".join(rep_) if rep_ else "(differences outside this net's panels)"), flush=True)
+            break
         for i in range(K):
             ng = int((gotg[i].view(torch.int32) != refg[i].view(torch.int32)).sum())
             if ng:
-                print("rank %d rep %d step %d: this rank's OWN gradient differs from repetition 0 in %d elements" % (rank, rep, i + 1, ng), flush=True)
+                dg = (gotg[i] - refg[i]).double()
+                wne = (gotw[i].view(torch.int32) != refw[i].view(torch.int32)).nonzero().flatten()
+                pprev = "n/a" if i == 0 else int((got[i - 1].view(torch.int32) != ref[i - 1].view(torch.int32)).sum())
+                print("rank %d rep %d step %d: this rank's OWN gradient differs from repetition 0 in %d elements (rel L2 %.3e, max abs %.3e); "
+                      "parameters before the step differ in %s elements; workspace differs in %d floats, first at %s of %d"
+                      % (rank, rep, i + 1, ng, float(dg.norm() / refg[i].double().norm()), float(dg.abs().max()), pprev, wne.numel(),
+                         int(wne[0]) if wne.numel() else None, gotw[i].numel()), flush=True)
                 break
         for i in range(K):
             ne = (got[i].view(torch.int32) != ref[i].view(torch.int32))
