@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PVAE_ABI_VERSION 7
+#define PVAE_ABI_VERSION 8
 
 typedef struct pvae_ctx pvae_ctx;
 
@@ -175,6 +175,19 @@ int pvae_bind_dataset(pvae_ctx* ctx, const float* states, const float* actions,
  * differences are formed once in float64 on the host, as the reference does.  NULL restores the
  * default; a new pvae_bind_dataset resets it. */
 int pvae_bind_dataset_next(pvae_ctx* ctx, const float* next_states);
+/* First layers that read the demonstration set where it lies (the torch.cat sites tpv:377, rmt:829, 842
+ * as address arithmetic inside the kernels' loaders).  The training-step entry points (pvae_train_step, _prefetch,
+ * pvae_dp_train_step) stage NOTHING when the step qualifies: the first layer of every stack fetches its rows of
+ * `states` / `actions` itself (16-byte chunks from 4-byte-aligned rows), the z / a_hat column blocks come from where the
+ * sampler / the decoder left them, and the two targets s_{t+1}, a_t are read from the set by the loss epilogues.  A step
+ * qualifies at lookahead 1 with the default prior, more than 4 rows, first layers wide enough for the 32x32 / 64-row
+ * tile kernels, no `next_states` array, and dataset allocations that are readable 16 bytes past their last row (checked
+ * at pvae_bind_dataset with hipMemGetAddressRange: a chunk may reach 12 bytes past a row).  Everything else -- and
+ * pvae_gather / pvae_set_batch + pvae_forward_backward always -- goes through the staging launch as before; both paths
+ * give the same bits.  pvae_set_direct(ctx, 0) switches the direct path off (default on); pvae_direct_active tells
+ * whether a step with these arguments would take it (1 / 0). */
+int pvae_set_direct(pvae_ctx* ctx, int on);
+int pvae_direct_active(pvae_ctx* ctx, int phase, int32_t rows, const pvae_step_params* sp, int fused);
 
 /* ---- hot path ------------------------------------------------------------------------ */
 /* Minibatch gather: windows [first_window, first_window+rows) -> network input panels.

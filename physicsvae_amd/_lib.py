@@ -34,7 +34,7 @@ MAX_HIDDEN = 15
 PRIOR_KINDS = {"normal_zero_mean_one_std": 0, "normal_state_mean_one_std": 1, "hypersphere_uniform": 2, False: 3}
 PHASE_WORLD, PHASE_JOINT = 0, 1
 FLAG_FUSED_ADAM, FLAG_NO_BACKWARD = 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 LOSS_MSE, LOSS_L1 = 0, 1
 EXCHANGE_ALLREDUCE, EXCHANGE_SHARDED, EXCHANGE_P2P, EXCHANGE_LOCAL, EXCHANGE_P2P_PUSH = 0, 1, 2, 3, 4
 P2P_BLOB_BYTES, P2P_MAX_RANKS = 512, 8
@@ -79,6 +79,8 @@ _SIGS = {
     "pvae_bind_dataset": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64]),
     "pvae_bind_dataset_next": (C.c_int, [_P, _P]),
     "pvae_invalidate_staging": (C.c_int, [_P]),
+    "pvae_set_direct": (C.c_int, [_P, C.c_int]),
+    "pvae_direct_active": (C.c_int, [_P, C.c_int, C.c_int32, _P, C.c_int]),
     "pvae_gather": (C.c_int, [_P, C.c_int64, C.c_int32, _P]),
     "pvae_set_batch": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "pvae_forward_backward": (C.c_int, [_P, C.c_int, C.c_int32, C.POINTER(StepParams), _P, _P,

@@ -174,6 +174,14 @@ struct pvae_ctx {
     int64_t n_rows = 0, n_windows = 0;
     int staged_rows = 0;
     double staged_rows_f = 0;    // rows of the batch being processed (for the profiler's flop count)
+    // First layers on the demonstration set where it lies (XSrc in pvae_gemm.h): the training-step entry
+    // points (pvae_train_step, _prefetch, pvae_dp_train_step) stage nothing when `direct_ok` holds -- the first layer of
+    // every stack gathers its rows of `states` / `actions` itself, the two targets are read from there by the loss
+    // epilogues.  pvae_gather / pvae_set_batch + pvae_forward_backward keep the panel path (inspection, explicit batches,
+    // lookahead > 1, evaluation, the other priors).  pvae_set_direct(ctx, 0) switches it off (A/B, parity tests).
+    bool direct = true;
+    bool data_slack = false;     // both dataset arrays are readable 16 bytes past their last row (checked at bind time)
+    struct { bool on = false; const int32_t* row = nullptr; } dx;    // the step in flight: window_row + first_window
     bool pair_launch = true;     // PVAE_PAIR=0 launches every contraction on its own (A/B)
     // gather prefetch (pvae_train_step_prefetch): what the alternate staging panels hold, and the
     // staging job the current step's last launch should carry
@@ -1281,11 +1289,14 @@ gemv_dense_kernel(const float* __restrict__ x, int ldx, int rows, const float* _
     }
 }
 
+static XSrc xsrc_of(const pvae_ctx* c, int net, int phase, bool with_s1, int rows);
 struct FwdTail {              // what the output layer's epilogue does besides bias
     const EpiMse* mse = nullptr;      // fused MSE loss + gradient
     float* out2 = nullptr;            // or: copy the first n2 output columns to out2[:, off2:]
     int ld2 = 0, off2 = 0, n2 = 0;
     const ProSampler* pro0 = nullptr; // layer 0 forms the sampler's z columns of its input itself (decoder, joint step)
+    const XSrc* xs0 = nullptr;        // layer 0 gathers its input rows from the demonstration set (direct steps)
+    const ProCols* cols0 = nullptr;   // ... and copies these columns over its input tile (world model: a_t / a_hat)
 };
 
 // `row0`: first row of the time-step block to run on (0 unless lookahead > 1)
@@ -1319,7 +1330,13 @@ static int forward_net(pvae_ctx* c, int n, int rows_pad, hipStream_t st, const F
             EpiBiasAct e{out, l.n_out_pad, c->params + l.b_off, l.act};
             e.n_valid = l.n_out;
             if (l.last && tail.out2) { e.out2 = tail.out2; e.ld2 = tail.ld2; e.off2 = tail.off2; e.n2 = tail.n2; }
-            if (l.index == 0 && tail.pro0)
+            if (l.index == 0 && tail.xs0 && tail.pro0)
+                HIP_TRY(gemm_forward_pro_gather(*tail.xs0, c->params + l.w_off, l.ld, rows_pad, l.n_out_pad, l.ld, e, *tail.pro0, st));
+            else if (l.index == 0 && tail.xs0 && tail.cols0)
+                HIP_TRY(gemm_forward_pro_gather(*tail.xs0, c->params + l.w_off, l.ld, rows_pad, l.n_out_pad, l.ld, e, *tail.cols0, st));
+            else if (l.index == 0 && tail.xs0)
+                HIP_TRY(gemm_forward_gather(*tail.xs0, c->params + l.w_off, l.ld, rows_pad, l.n_out_pad, l.ld, e, st));
+            else if (l.index == 0 && tail.pro0)
                 HIP_TRY(gemm_forward_pro(x, ldx, c->params + l.w_off, l.ld, rows_pad, l.n_out_pad, l.ld, e, *tail.pro0, st));
             else
                 HIP_TRY(gemm_forward_epi(x, ldx, c->params + l.w_off, l.ld, rows_pad, l.n_out_pad, l.ld, e, st));
@@ -1434,6 +1451,9 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
     // act_grad code of the layer whose output masks the input gradient of layer i (layer i - 1; none for i == 0)
     auto mask_act = [=](int i) { return i > 0 ? N->layers[i - 1].act : 1; };
     const int need = n == PVAE_NET_WM ? c->L.cfg.dim_action : c->L.cfg.latent;
+    // direct step: the weight gradient of layer 0 contracts over the gathered input (XSrc), not over a staged panel
+    const bool dx0 = c->dx.on && train && n != PVAE_NET_PR;
+    const XSrc xs0 = dx0 ? xsrc_of(c, n, n == PVAE_NET_WM ? PVAE_PHASE_WORLD : PVAE_PHASE_JOINT, true, (int)c->staged_rows_f) : XSrc();
     LossFinal foldv;
     memset(&foldv, 0, sizeof(foldv));
     if (fold) foldv = *fold;
@@ -1513,6 +1533,11 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
                     const SeedWindow sw = seed_window(seedv.s.c0, seedv.s.Z);
                     EpiSamplerSeed es = seedv.s;
                     es.c0 -= sw.lo;
+                    if (dx0)                  // (i == 0 too: the decoder's first layer, X = [s_t | z] gathered)
+                        HIP_TRY(gemm_bwd_pair_epi_gather(c->ws + w->dz[0], d.n_out_pad, c->params + d.w_off + sw.lo, d.ld, rows_pad,
+                                                         sw.width, d.n_out_pad, es, dz, l.n_out_pad, xs0, l.n_out_pad, l.ld,
+                                                         rows_pad, e, st, &ad));
+                    else
                     HIP_TRY(gemm_bwd_pair_epi(c->ws + w->dz[0], d.n_out_pad, c->params + d.w_off + sw.lo, d.ld, rows_pad,
                                               sw.width, d.n_out_pad, es, dz, l.n_out_pad, xin, l.ld, l.n_out_pad, l.ld,
                                               rows_pad, e, st, &ad));
@@ -1571,6 +1596,10 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
             if (with_fold) e0.loss = foldv;
             const bool carry = with_fold && c->next_stage.rows_pad > 0;
             const AdamPair ad = take_pending(c);
+            if (dx0) {                        // X gathered from the demonstration set: nothing was staged, nothing to stage
+                HIP_TRY(gemm_wgrad_pair_gather(c->ws + w->dz[0], l0.n_out_pad, xs0, l0.n_out_pad, l0.ld, e0, rows_pad, st, &ad));
+                return 0;
+            }
             HIP_TRY(gemm_wgrad_pair(c->ws + w->dz[0], l0.n_out_pad, c->ws + w->in, l0.ld, l0.n_out_pad, l0.ld, e0,
                                     (const float*)nullptr, 0, (const float*)nullptr, 0, 0, l0.ld, e0,
                                     rows_pad, st, carry ? &c->next_stage : nullptr, &ad));
@@ -1816,8 +1845,24 @@ int pvae_bind_dataset(pvae_ctx* c, const float* states, const float* actions, co
     c->next_states = nullptr;
     c->n_rows = n_rows; c->n_windows = n_windows;
     c->pf.valid = false;         // a minibatch gathered ahead came from the previous binding
+    // the gathered first layers fetch whole 16-byte chunks: the last one of a row may reach 12 bytes past it, i.e. past the
+    // array for its very last row.  Only allocations with that much room behind them qualify (else: the panel path).
+    auto roomy = [](const float* p, int64_t floats) {
+        void* base = nullptr; size_t size = 0;
+        if (hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)p) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return (const char*)(p + floats) + 16 <= (const char*)base + size;
+    };
+    c->data_slack = roomy(states, n_rows * c->L.cfg.dim_body) && roomy(actions, n_rows * c->L.cfg.dim_action);
     return 0;
 }
+
+int pvae_set_direct(pvae_ctx* c, int on) {
+    if (!c) return fail(-1, "null ctx");
+    c->direct = on != 0;
+    return 0;
+}
+// 1: the next training step on this binding would read the demonstration set directly (same arguments as the step)
+int pvae_direct_active(pvae_ctx* c, int phase, int32_t rows, const pvae_step_params* sp, int fused);
 
 int pvae_bind_dataset_next(pvae_ctx* c, const float* next_states) {
     if (!c) return fail(-1, "null ctx");
@@ -1862,6 +1907,7 @@ static int stage(pvae_ctx* c, long long first_window, const float* x, const floa
     int rc = check_ready(c, false);
     if (rc) return rc;
     if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
+    c->dx.on = false;
     const StageArgs a = stage_args(c, first_window, x, y, rows, from_set, steps, false);
     const int lf = PVAE_GATHER == 2 ? stage_lds_floats(a.Db, a.Da) : 0;
     hipLaunchKernelGGL(stage_batch_kernel, dim3((a.rows_pad + 3) / 4, steps), dim3(256), (size_t)4 * lf * sizeof(float), st, a, lf);
@@ -1928,6 +1974,54 @@ static bool sampler_folds(const pvae_ctx* c, int rows) {
            c->L.net[PVAE_NET_PR].layers.empty() && c->L.cfg.latent <= ProSampler::kMaxZ && c->L.cfg.latent % 4 == 0 &&
            rows > 4 &&
            MD.layers.size() > 1 && forward_pro_ok(pad32(rows), MD.layers[0].n_out_pad);
+}
+
+// ---- first layers on the demonstration set (XSrc) ------------------------------------------------------------
+// The gathered input of stack `net` in the step in flight.  `with_s1`: the second column block is part of the operand
+// (weight gradients; forward layers on 64-row tiles) -- false when a Pro patch of the launch supplies those columns.
+static XSrc xsrc_of(const pvae_ctx* c, int net, int phase, bool with_s1, int rows) {
+    const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
+    XSrc x;
+    memset(&x, 0, sizeof(x));
+    x.s0 = c->states; x.row0 = c->dx.row; x.ld0 = Db; x.rows = rows;
+    x.zero = c->ws + c->W.zero;
+    x.s1 = x.zero;
+    if (net == PVAE_NET_TE) { x.n0 = 2 * Db; return x; }               // [s_t | s_{t+1}]: one run of 2 Db floats of `states`
+    x.n0 = Db;
+    if (!with_s1) return x;
+    if (net == PVAE_NET_MD) {                                          // [s_t | z]: z where the sampler stored it
+        x.s1 = c->ws + c->W.net[PVAE_NET_MD].in + Db; x.row1 = nullptr; x.ld1 = c->L.net[PVAE_NET_MD].layers[0].ld; x.n1 = Z;
+    } else if (phase == PVAE_PHASE_WORLD) {                            // [s_t | a_t]
+        x.s1 = c->actions; x.row1 = c->dx.row; x.ld1 = Da; x.n1 = Da;
+    } else {                                                           // [s_t | a_hat]: the decoder's output panel
+        x.s1 = c->ws + c->W.net[PVAE_NET_MD].act.back(); x.row1 = nullptr; x.ld1 = c->L.net[PVAE_NET_MD].layers.back().n_out_pad; x.n1 = Da;
+    }
+    return x;
+}
+static bool sampler_folds(const pvae_ctx* c, int rows);
+// Can this training step read the demonstration set directly?  (Everything else keeps the staging launch.)
+static bool direct_ok(const pvae_ctx* c, int phase, int rows, const pvae_step_params* sp, bool fused) {
+    const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
+    if (!c->direct || !c->data_slack || !c->states || c->next_states || c->W.L != 1 || !c->pair_launch || !c->same_layer_pairs)
+        return false;
+    if (rows <= 4 || c->L.cfg.prior_kind != PVAE_PRIOR_ZERO_MEAN || !c->L.net[PVAE_NET_PR].layers.empty()) return false;
+    if (fused && !(c->defer_adam && c->grads)) return false;          // (the same-layer schedule of plan_backward_net)
+    if (Da > ProCols::kMaxN || Z > ProCols::kMaxN) return false;
+    const int rp = pad32(rows);
+    // a first layer on 64-row tiles has no Pro patch: its second column block is chunk-selected, which needs dim_body % 4 == 0
+    auto layer0_ok = [&](int net, bool second_block) {
+        const NetLayout& N = c->L.net[net];
+        if (N.layers.size() < 2) return false;
+        const int n = N.layers[0].n_out_pad;
+        if (!forward_gather_ok(rp, n)) return false;
+        return !(second_block && uses_64x32(rp, n) && (Db & 3));
+    };
+    if (phase == PVAE_PHASE_WORLD) return layer0_ok(PVAE_NET_WM, true);
+    if (!(sp->cycle_coeff > 0.0f)) return false;                      // (the action loss sits in the world model's seed epilogue)
+    if (!layer0_ok(PVAE_NET_TE, false) || !layer0_ok(PVAE_NET_MD, true) || !layer0_ok(PVAE_NET_WM, true)) return false;
+    // decoder on 32x32 tiles: z comes from the sampler prologue of that very launch
+    if (!uses_64x32(rp, c->L.net[PVAE_NET_MD].layers[0].n_out_pad) && !sampler_folds(c, rows)) return false;
+    return true;
 }
 
 struct StepShape {
@@ -2027,6 +2121,22 @@ static int run_forward(pvae_ctx* c, int phase, int rows, const pvae_step_params*
     mse.rows = rows; mse.D = Db; mse.l1 = S.l1;
     FwdTail wm_tail;
     wm_tail.mse = &mse;
+    // direct step: every stack's first layer gathers its rows itself, s_{t+1} is read from `states` by the loss epilogue
+    const bool dx = c->dx.on;
+    XSrc xs_te, xs_md, xs_wm;
+    ProCols wm_cols;
+    memset(&wm_cols, 0, sizeof(wm_cols));
+    if (dx) {
+        mse.target = c->states + Db; mse.ldt = Db; mse.trow = c->dx.row;          // row + 1 of the window's s_t
+        const bool wm64 = uses_64x32(S.rows_pad, WM.layers[0].n_out_pad);
+        xs_wm = xsrc_of(c, PVAE_NET_WM, phase, wm64, rows);
+        wm_tail.xs0 = &xs_wm;
+        if (!wm64) {
+            const XSrc full = xsrc_of(c, PVAE_NET_WM, phase, true, rows);
+            wm_cols.src = full.s1; wm_cols.row = full.row1; wm_cols.ld = full.ld1; wm_cols.c0 = Db; wm_cols.n = Da; wm_cols.rows = rows;
+            wm_tail.cols0 = &wm_cols;
+        }
+    }
     if (phase == PVAE_PHASE_WORLD) {
         // tpv:411-414: L = s_rec * MSE(s2, WM(s1, a_gt)); only the world model learns (tpv:326-329)
         mse.grad_scale = sp->s_rec_coeff * S.gs / (S.Bg * Db);
@@ -2047,7 +2157,9 @@ static int run_forward(pvae_ctx* c, int phase, int rows, const pvae_step_params*
     }
     // joint forward: [prior mean ->] TE -> sampler -> MD -> WM (rmt:742-771, 801-809)
     if (learned_prior && (rc = forward_net(c, PVAE_NET_PR, S.rows_pad, st))) return rc;
-    if ((rc = forward_net(c, PVAE_NET_TE, S.rows_pad, st))) return rc;
+    FwdTail te_tail;
+    if (dx) { xs_te = xsrc_of(c, PVAE_NET_TE, phase, false, rows); te_tail.xs0 = &xs_te; }
+    if ((rc = forward_net(c, PVAE_NET_TE, S.rows_pad, st, te_tail))) return rc;
     ProSampler pro;
     memset(&pro, 0, sizeof(pro));
     if (S.fold_sampler) {                      // the sampler rides in the decoder's first-layer launch
@@ -2067,6 +2179,7 @@ static int run_forward(pvae_ctx* c, int phase, int rows, const pvae_step_params*
     FwdTail md_tail;                           // a_hat also lands in the action columns of the WM input
     md_tail.out2 = w + wwm.in; md_tail.ld2 = WM.layers[0].ld; md_tail.off2 = Db; md_tail.n2 = Da;
     if (S.fold_sampler) md_tail.pro0 = &pro;
+    if (dx) { xs_md = xsrc_of(c, PVAE_NET_MD, phase, !S.fold_sampler, rows); md_tail.xs0 = &xs_md; }
     if ((rc = forward_net(c, PVAE_NET_MD, S.rows_pad, st, md_tail))) return rc;
     // cycle loss (tpv:417-419) fused into the world model's output layer
     mse.grad_scale = sp->cycle_coeff * S.gs / (S.Bg * Db);
@@ -2114,6 +2227,7 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
             memset(&sd.a, 0, sizeof(sd.a));
             sd.a.pred = w + wmd->act.back(); sd.a.ldp = ldo_md;
             sd.a.target = w + c->W.act_t; sd.a.ldt = pad64(Da);
+            if (c->dx.on) { sd.a.target = c->actions; sd.a.ldt = Da; sd.a.trow = c->dx.row; }     // a_t where it lies
             sd.a.dz = w + wmd->dz.back(); sd.a.ldz = ldo_md;
             sd.a.c0 = Db; sd.a.n = Da; sd.a.rows = rows;
             sd.a.grad_scale = ga; sd.a.l1 = S.l1;
@@ -3091,6 +3205,32 @@ static int exchange_bucket(pvae_ctx* c, int net, const Bucket& b, const pvae_ste
     return pvae_adam_segment(c, net, b.off, b.cnt, sp, cs);
 }
 
+// A training step that reads the demonstration set directly: nothing is staged; `dx` tells run_forward /
+// plan_backward_net to use the gathered first layers.  -> false: the step takes the staging launch as before.
+static bool enter_direct(pvae_ctx* c, int phase, int64_t first_window, int rows, const pvae_step_params* sp, bool fused) {
+    c->dx.on = false;
+    if (!sp || !c->states || first_window < 0 || rows < 1 || rows > c->L.cfg.max_batch || first_window + rows > c->n_windows) return false;
+    if (phase != PVAE_PHASE_WORLD && phase != PVAE_PHASE_JOINT) return false;
+    if (!direct_ok(c, phase, rows, sp, fused)) return false;
+    c->dx.on = true;
+    c->dx.row = c->window_row + first_window;
+    c->staged_rows = rows;
+    c->staged_rows_f = rows;
+    c->pf.valid = false;
+    c->next_stage.rows_pad = 0;
+    c->next_carried = false;
+    return true;
+}
+static void leave_direct(pvae_ctx* c) {
+    c->dx.on = false;
+    c->staged_rows = 0;          // the input panels do not hold this minibatch: a later pvae_forward_backward must stage first
+}
+int pvae_direct_active(pvae_ctx* c, int phase, int32_t rows, const pvae_step_params* sp, int fused) {
+    if (!c || !sp) return fail(-1, "null argument");
+    if (check_ready(c, true)) return 0;
+    return c->states && direct_ok(c, phase, rows, sp, fused != 0) ? 1 : 0;
+}
+
 int pvae_allreduce_grads(pvae_ctx* c, int64_t offset, int64_t count, void* stream) {
     int rc = check_ready(c, true);
     if (rc) return rc;
@@ -3143,8 +3283,11 @@ int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t row
         return join();
     }
     // gather prefetch as in pvae_train_step_prefetch: this rank's next shard rides in the last launch
-    const bool can = c->W.L == 1 && c->pair_launch && loss_out != nullptr && c->states != nullptr;
-    if (can && c->pf.valid && c->pf.first == first_window && c->pf.rows == rows && c->pf.states == c->states) {
+    const bool direct = enter_direct(c, phase, first_window, rows, sp, false);
+    const bool can = !direct && c->W.L == 1 && c->pair_launch && loss_out != nullptr && c->states != nullptr;
+    if (direct) {
+        // (first layers gather their rows themselves: no staging launch, nothing to prefetch)
+    } else if (can && c->pf.valid && c->pf.first == first_window && c->pf.rows == rows && c->pf.states == c->states) {
         flip_stage_panels(c);
         c->staged_rows = rows;
         c->staged_rows_f = rows;
@@ -3157,7 +3300,7 @@ int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t row
     if (can && next_rows > 0 && next_rows <= c->L.cfg.max_batch && next_first >= 0 &&
         next_first + next_rows <= c->n_windows)
         c->next_stage = stage_args(c, next_first, nullptr, nullptr, next_rows, true, 1, true);
-    if ((rc = check_step(c, phase, rows, sp, true, false))) return rc;
+    if ((rc = check_step(c, phase, rows, sp, true, false))) { if (direct) leave_direct(c); return rc; }
     StepShape S;
     if ((rc = step_shape(c, phase, rows, sp, loss_out, true, S))) return rc;
     if ((rc = run_forward(c, phase, rows, sp, eps, true, S, st))) return rc;
@@ -3197,11 +3340,19 @@ int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t row
     }
     c->next_stage.rows_pad = 0;
     c->next_carried = false;
+    if (direct) leave_direct(c);
     return rc;
 }
 
 int pvae_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t rows, const pvae_step_params* sp,
                     const float* eps, float* loss_out, void* stream) {
+    if (!c) return fail(-1, "null ctx");
+    if (!c->states) return fail(-2, "dataset not bound");
+    if (check_ready(c, true) == 0 && enter_direct(c, phase, first_window, rows, sp, true)) {
+        const int rc = pvae_forward_backward(c, phase, rows, sp, eps, loss_out, PVAE_FLAG_FUSED_ADAM, stream);
+        leave_direct(c);
+        return rc;
+    }
     int rc = pvae_gather(c, first_window, rows, stream);
     if (rc) return rc;
     return pvae_forward_backward(c, phase, rows, sp, eps, loss_out, PVAE_FLAG_FUSED_ADAM, stream);
@@ -3219,6 +3370,12 @@ int pvae_train_step_prefetch(pvae_ctx* c, int phase, int64_t first_window, int32
     if (!c) return fail(-1, "null ctx");
     if (!c->states) return fail(-2, "dataset not bound");
     int rc;
+    if (check_ready(c, true) == 0 && enter_direct(c, phase, first_window, rows, sp, true)) {
+        // (first layers gather their rows themselves: no staging launch, nothing to prefetch)
+        rc = pvae_forward_backward(c, phase, rows, sp, eps, loss_out, PVAE_FLAG_FUSED_ADAM, stream);
+        leave_direct(c);
+        return rc;
+    }
     const bool can = c->W.L == 1 && c->pair_launch && loss_out != nullptr;   // the carrier is the folding launch
     if (can && c->pf.valid && c->pf.first == first_window && c->pf.rows == rows && c->pf.states == c->states) {
         flip_stage_panels(c);                   // this minibatch is already staged

@@ -844,6 +844,51 @@ __device__ inline void wait_dma_tile(int younger) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// First layers that read the demonstration set where it lies (the torch.cat sites tpv:377, rmt:829, 842
+// as address arithmetic inside the loaders).  The input of a stack's first layer is a VIRTUAL matrix
+//     X[q][k] = s0[row0[q] * ld0 + k]                              k <  n0        (rows of `states`: s_t, or [s_t | s_{t+1}])
+//             = s1[(row1 ? row1[q] : q) * ld1 + (k - n0)]     n0 <= k <  n0 + n1   (a_t rows of `actions`, or a z / a_hat panel)
+//             = 0                                              elsewhere, and for q >= rows
+// never materialised: the forward kernels' loaders fetch every 16-byte chunk of a Q tile from the source that holds it
+// (LDS-DMA from 4-byte-aligned addresses lands at the aligned rate: tools/unaligned_probe.hip) and the weight-gradient
+// bodies do the same through registers, zeroing what lies beyond the valid columns exactly.  The sources must be
+// readable 16 bytes past their last element (pvae_bind_dataset checks the allocations).
+// ---------------------------------------------------------------------------------------
+struct XSrc {
+    const float* s0; const int32_t* row0; int ld0, n0;
+    const float* s1; const int32_t* row1; int ld1, n1;
+    int rows;
+    const float* zero;            // >= 256 zero bytes
+};
+// Q-operand policies of the wave-specialised forward kernels: where lane-slot (row q, 16-byte chunk at column c4) of
+// k-tile kt comes from.  QDense: the panel Q[q][ldq] (every launch but a gathered first layer).
+struct QDense {
+    struct Base { const float* p; };
+    __device__ inline Base base(const float* Q, int ldq, int q, int c4) const { return Base{Q + (size_t)q * ldq + c4}; }
+    __device__ inline const float* tile(const Base& b, int kt) const { return b.p + (size_t)kt * 64; }
+};
+// QGather: the virtual matrix above.  A chunk that straddles n0 (n0 % 4 != 0) comes from s0 with the first floats of
+// what follows the row in memory behind it: the launch's Pro patch overwrites those columns (n1 > 0 stacks), or they meet
+// W's zero pad columns (n1 == 0); likewise the floats past n0 + n1.  Forward only: garbage x 0 = 0, a gradient would not.
+struct QGather {
+    XSrc x;
+    struct Base { const float* p0; const float* p1; int c4; };
+    __device__ inline Base base(const float*, int, int q, int c4) const {
+        Base b;
+        b.c4 = q < x.rows ? c4 : (1 << 28);                          // (rows past the batch: every tile reads zeros)
+        const int qq = q < x.rows ? q : 0;
+        b.p0 = x.s0 + (size_t)x.row0[qq] * x.ld0 + c4;
+        b.p1 = x.n1 > 0 ? x.s1 + (size_t)(x.row1 ? x.row1[qq] : qq) * x.ld1 + (c4 - x.n0) : x.zero;
+        return b;
+    }
+    __device__ inline const float* tile(const Base& b, int kt) const {
+        const int k0 = b.c4 + kt * 64;
+        const float* p = k0 < x.n0 ? b.p0 + kt * 64 : b.p1 + kt * 64;
+        return (k0 < x.n0 || k0 - x.n0 < x.n1) && k0 < (1 << 28) ? p : x.zero + (b.c4 & 60);
+    }
+};
+
 // Prologue hook of the wave-specialised kernel: a launch can OWN some columns of its Q operand -- form them itself
 // instead of reading what a separate launch stored.  The compute waves `prepare` (request the inputs of those
 // values for the workgroup's 32 rows: the loads travel while the first k-tiles are contracted) and `patch` the
@@ -858,6 +903,43 @@ struct NoPro {
     __device__ inline bool needs(int) const { return false; }
     __device__ inline State prepare(int, int) const { return State(); }
     __device__ inline void patch(float*, float*, State&, int, int, int, int, int) const {}
+    __device__ inline void publish(const float*, int, int, int, int) const {}
+};
+
+// Pro patch that COPIES columns [c0, c0 + n) of the Q tile from a second source (the world model's first layer on the
+// gathered operand: [s_t | a_t] with a_t a row of `actions`, or [s_t | a_hat] with a_hat the decoder's output panel).
+// The loaders bring the s_t columns straight from `states`; the chunk that straddles c0 (dim_body % 4 != 0) arrives with
+// foreign floats behind s_t's last one, and this patch overwrites all n columns after the tile has landed.
+struct ProCols {
+    static constexpr bool kActive = true;
+    static constexpr int kMaxN = 96, kScratchFloats = 4;
+    static constexpr int kPer = 32 * kMaxN / 256;          // elements per thread at n = kMaxN
+    const float* src; const int32_t* row; int ld;          // value (q, j) = src[(row ? row[q] : q) * ld + j]
+    int c0, n, rows;
+    struct State { float v[kPer]; };
+    __device__ inline bool needs(int t) const { return t >= (c0 >> 6) && t <= ((c0 + n - 1) >> 6); }
+    __device__ inline State prepare(int q0, int tid) const {
+        State st;
+        const float* __restrict__ s_ = src;
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int e = tid + 256 * u, r = e / n, j = e - r * n, q = q0 + r;
+            const bool live = e < 32 * n && q < rows;
+            st.v[u] = live ? s_[(size_t)(row ? row[q] : q) * ld + j] : 0.f;
+        }
+        return st;
+    }
+    __device__ inline void patch(float* tile, float*, State& st, int t, int, int, int, int tid) const {
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int e = tid + 256 * u;
+            if (e >= 32 * n) break;
+            const int r = e / n, c = c0 + (e - r * n);
+            if ((c >> 6) != t) continue;
+            const int kc = c & 63;
+            tile[r * 64 + (((kc >> 2) ^ (r & 15)) << 2) + (kc & 3)] = st.v[u];
+        }
+    }
     __device__ inline void publish(const float*, int, int, int, int) const {}
 };
 
@@ -899,9 +981,9 @@ __device__ inline void l2_touch_share(float& sink, const float* Q, int ldq, int 
     }
 }
 
-template <bool P_ROW, class Epi, class Pro = NoPro>
+template <bool P_ROW, class Epi, class Pro = NoPro, class QS = QDense>
 __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, Epi& epi, const Pro& pro = Pro(),
-                                      float* scratch = nullptr) {
+                                      float* scratch = nullptr, const QS& qs = QS()) {
     // (PVAE_WS_SUPER=2: six slots, two k-tiles per barrier with the two after next already in flight -- plain kernel only)
     constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, S = (PVAE_WS_SUPER == 2 && !Pro::kActive) ? 6 : kWsStages;
     static_assert(S == 4 || PVAE_WS_SUPER == 2, "wait_dma_tile is written for a 4-slot ring");
@@ -937,11 +1019,11 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
     // the prologue alone took 0.67 us -- tools/timeline_probe.hip).
     if (!PVAE_PROBE(6) && wave < 8) {
         const int j = wave * 64 + lane;                   // 16-byte slot inside the 8 KB tile image
-        const float* s0q;
+        typename QS::Base s0q;
         const float* s0p;
         {
             const int row = j >> 4, c = (j & 15) ^ (row & 15);
-            s0q = Q + (size_t)(q0 + row) * ldq + c * 4;
+            s0q = qs.base(Q, ldq, q0 + row, c * 4);
         }
         if (P_ROW) {
             const int row = j >> 4, c = (j & 15) ^ (row & 15);
@@ -950,21 +1032,21 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
             const int r = j >> 3, k = r ^ ((r >> 2) & 1);
             s0p = P + (size_t)k * ldp + p0 + (j & 7) * 4;
         }
-        lds_dma16(s0q + (size_t)rot * BK, lds + wave * 256);
+        lds_dma16(qs.tile(s0q, rot), lds + wave * 256);
         lds_dma16(s0p + (size_t)rot * kstep_p, lds + kTile + wave * 256);
     }
 #endif
     if (wave >= 4) {
         // ---------------- loader waves ----------------  (s_setprio 1 here, or on the compute waves: +-0)
         const int u0 = wave - 4;
-        const float* sq[kWsPer];
+        typename QS::Base sq[kWsPer];
         const float* sp[kWsPer];
 #pragma unroll
         for (int u = 0; u < kWsPer; ++u) {
             const int j = (u0 + kWsLoaders * u) * 64 + lane;       // 16-byte slot inside the 8 KB tile image
             {
                 const int row = j >> 4, c = (j & 15) ^ (row & 15);
-                sq[u] = Q + (size_t)(q0 + row) * ldq + c * 4;
+                sq[u] = qs.base(Q, ldq, q0 + row, c * 4);
             }
             if (P_ROW) {
                 const int row = j >> 4, c = (j & 15) ^ (row & 15);
@@ -982,7 +1064,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
             if (PVAE_PROBE(2)) kt = 0;                    // probe: every step re-reads tile 0 (cache-resident)
 #pragma unroll
             for (int u = 0; u < kWsPer; ++u) {
-                lds_dma16(sq[u] + (size_t)kt * BK, slot + (u0 + kWsLoaders * u) * 256);
+                lds_dma16(qs.tile(sq[u], kt), slot + (u0 + kWsLoaders * u) * 256);
                 lds_dma16(sp[u] + (size_t)kt * kstep_p, slot + kTile + (u0 + kWsLoaders * u) * 256);
             }
         };
@@ -1206,8 +1288,8 @@ constexpr int kWs64Stages = PVAE_WS64_STAGES;
 // twice the MFMA work of the 24 KB of 64x32 -- 16 flop per DMA byte instead of 10.7; the k-loop is as long as its DMA stream
 // (docs/experiments.md), so that is what pays.  Ring 4 x 32 KB.  Same k-quarters per wave, same order: bit-identical again.
 template <int PT> constexpr int ws64_floats() { return (PT == 64 ? 4 : kWs64Stages) * (64 + PT) * 64; }
-template <bool P_ROW, class Epi, int PT = 32>
-__device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
+template <bool P_ROW, class Epi, int PT = 32, class QS = QDense>
+__device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga, Epi& epi, const QS& qs = QS()) {
     static_assert(PT == 32 || PT == 64, "P tile of 32 or 64 rows");
     constexpr int BK = 64, kTileQ = 64 * 64, kTileP = PT * 64, kStage = kTileQ + kTileP, S = PT == 64 ? 4 : kWs64Stages;
     constexpr int NB = PT / 16;                                  // 16-wide p blocks of the tile = P DMA instructions per loader wave
@@ -1255,7 +1337,7 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
     // 16-byte slot j of an operand image -> its global source (same swizzles as splitk_ws_body)
     auto src_q = [&](int j) {
         const int row = j >> 4, c = (j & 15) ^ (row & 15);
-        return Q + (size_t)(q0 + row) * ldq + c * 4;
+        return qs.base(Q, ldq, q0 + row, c * 4);
     };
     auto src_p = [&](int j) {
         if (P_ROW) {
@@ -1267,14 +1349,14 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
         return P + (size_t)k * ldp + p0 + (j & 7) * 4;
     };
     // k-tile 0 by all eight waves: Q image = 1024 slots (two per lane and wave), P image = 512 / 1024 (one / two)
-    lds_dma16(src_q(wave * 64 + lane), lds + wave * 256);
-    lds_dma16(src_q((wave + 8) * 64 + lane), lds + (wave + 8) * 256);
+    lds_dma16(qs.tile(src_q(wave * 64 + lane), 0), lds + wave * 256);
+    lds_dma16(qs.tile(src_q((wave + 8) * 64 + lane), 0), lds + (wave + 8) * 256);
     lds_dma16(src_p(wave * 64 + lane), lds + kTileQ + wave * 256);
     if (PT == 64) lds_dma16(src_p((wave + 8) * 64 + lane), lds + kTileQ + (wave + 8) * 256);
     if (wave >= 4) {
         // ---------------- loader waves: 4 Q + NB P instructions per tile ----------------
         const int u0 = wave - 4;
-        const float* sq[4];
+        typename QS::Base sq[4];
         const float* sp[NB];
 #pragma unroll
         for (int u = 0; u < 4; ++u) sq[u] = src_q((u0 + 4 * u) * 64 + lane);
@@ -1283,7 +1365,7 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
         auto issue = [&](int t) {
             float* slot = lds + (t % S) * kStage;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) lds_dma16(sq[u] + (size_t)t * BK, slot + (u0 + 4 * u) * 256);
+            for (int u = 0; u < 4; ++u) lds_dma16(qs.tile(sq[u], t), slot + (u0 + 4 * u) * 256);
 #pragma unroll
             for (int u = 0; u < NB; ++u) lds_dma16(sp[u] + (size_t)t * kstep_p, slot + kTileQ + (u0 + 4 * u) * 256);
         };
@@ -1436,6 +1518,29 @@ gemm_splitk_ws_pro_kernel(PVAE_GA_PARAMS(a_), Epi epi, Pro pro) {
     __shared__ __attribute__((aligned(16))) float scratch[Pro::kScratchFloats];
     splitk_ws_body<true, Epi, Pro>(lds, blockIdx.x, ga, epi, pro, scratch);
 }
+// the first layer of a stack on the gathered operand (XSrc): 32x32 tiles, plain or with a Pro patch; 64 x PT tiles
+template <class Epi>
+__global__ void __launch_bounds__(kWsThreads)
+gemm_splitk_ws_gather_kernel(PVAE_GA_PARAMS(a_), Epi epi, QGather qs) {
+    const GemmArgs ga = PVAE_GA_OF(a_);
+    __shared__ __attribute__((aligned(16))) float lds[PVAE_WS_SUPER == 2 ? 6 * 2 * 32 * 64 : kWsFloats];
+    splitk_ws_body<true, Epi, NoPro, QGather>(lds, blockIdx.x, ga, epi, NoPro(), nullptr, qs);
+}
+template <class Epi, class Pro>
+__global__ void __launch_bounds__(kWsThreads)
+gemm_splitk_ws_pro_gather_kernel(PVAE_GA_PARAMS(a_), Epi epi, Pro pro, QGather qs) {
+    const GemmArgs ga = PVAE_GA_OF(a_);
+    __shared__ __attribute__((aligned(16))) float lds[kWsFloats];
+    __shared__ __attribute__((aligned(16))) float scratch[Pro::kScratchFloats];
+    splitk_ws_body<true, Epi, Pro, QGather>(lds, blockIdx.x, ga, epi, pro, scratch, qs);
+}
+template <class Epi, int PT>
+__global__ void __launch_bounds__(512)
+gemm_splitk_ws64_gather_kernel(PVAE_GA_PARAMS(a_), Epi epi, QGather qs) {
+    const GemmArgs ga = PVAE_GA_OF(a_);
+    __shared__ __attribute__((aligned(16))) float lds[ws64_floats<PT>()];
+    splitk_ws64_body<true, Epi, PT, QGather>(lds, blockIdx.x, ga, epi, qs);
+}
 
 // ---- forward, 16x16 tile per workgroup (narrow output layers) ----------------------------------
 // An output layer with few features (197 / 64 / 45 -> 8 or fewer 32-wide p-tiles) gives the 32x32
@@ -1557,13 +1662,76 @@ gemm_splitk_reg16_kernel(PVAE_GA_PARAMS(a_), Epi epi) {
     splitk_reg16_body<P_ROW, Epi>(lds, blockIdx.x, ga, epi);
 }
 
+// ---- the gathered operand (XSrc) as the P = X operand of a weight-gradient body --------------------------------
+// A lane owns U 16-byte chunks per k-tile: columns k0 .. k0 + 3 of batch row t * BKR + row.  Every chunk is fetched with
+// TWO loads -- from the s0 row and from the s1 row (a zero line where the chunk has nothing from that source) -- and the
+// elements are selected by masks that do not depend on the tile: branch-free, so hipcc's wait counts stay exact, and
+// what lies beyond the valid columns is exactly zero (a gradient, unlike a forward product, must not see garbage there:
+// it would move W's pad columns off zero).  The chunk that straddles n0 takes its tail from the START of the s1 row,
+// shifted by n0 - k0 elements.  Row indices for the load D calls ahead are fetched BEFORE this call's data, so waiting
+// for them never waits for younger data (loads retire in order).
+struct PDense { static constexpr bool kGather = false; };
+struct PGather { static constexpr bool kGather = true; XSrc x; };
+template <int U, int BKR, int D>
+struct XLanes {
+    int k0[U], row[U], sh[U], j1[U];
+    unsigned keep0[U], keep1[U];
+    int i0[D][U], i1[D][U];                     // ring: indices for the NEXT load into register set s
+    __device__ inline void set(const XSrc& x, int u, int row_, int k0_) {
+        k0[u] = k0_; row[u] = row_;
+        keep0[u] = keep1[u] = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = k0_ + e;
+            if (c < x.n0) keep0[u] |= 1u << e;
+            else if (c < x.n0 + x.n1) keep1[u] |= 1u << e;
+        }
+        sh[u] = k0_ < x.n0 ? x.n0 - k0_ : 0;              // (> 0 only in the chunk that straddles n0: 1 .. 3)
+        if (sh[u] > 3) sh[u] = 0;                          // (a chunk wholly inside s0: keep1 is empty anyway)
+        j1[u] = k0_ > x.n0 ? k0_ - x.n0 : 0;
+    }
+    __device__ inline void fetch(const XSrc& x, int t, int s) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int r = t * BKR + row[u];
+            r = r < x.rows ? r : x.rows - 1;
+            i0[s][u] = x.row0[r];
+            i1[s][u] = x.row1 ? x.row1[r] : r;
+        }
+    }
+    // the chunk of tile t held in register set s (indices fetched earlier); then queue the indices of tile t_next
+    __device__ inline void load(const XSrc& x, int t, int t_next, int s, v4f (&out)[U]) {
+        int c0[U], c1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { c0[u] = i0[s][u]; c1[u] = i1[s][u]; }
+        fetch(x, t_next, s);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool valid = t * BKR + row[u] < x.rows;
+            const float* pa = (valid && keep0[u]) ? x.s0 + (size_t)c0[u] * x.ld0 + k0[u] : x.zero;
+            const float* pb = (valid && keep1[u]) ? x.s1 + (size_t)c1[u] * x.ld1 + j1[u] : x.zero;
+            const v4f a = *reinterpret_cast<const v4f*>(pa);
+            const v4f w = *reinterpret_cast<const v4f*>(pb);
+            const int d = sh[u];
+            v4f ws;
+            ws[0] = d == 0 ? w[0] : 0.f;
+            ws[1] = d == 0 ? w[1] : (d == 1 ? w[0] : 0.f);
+            ws[2] = d == 0 ? w[2] : (d == 1 ? w[1] : (d == 2 ? w[0] : 0.f));
+            ws[3] = d == 0 ? w[3] : (d == 1 ? w[2] : (d == 2 ? w[1] : w[0]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                out[u][e] = ((keep0[u] >> e) & 1u) ? a[e] : (((keep1[u] >> e) & 1u) ? ws[e] : 0.f);
+        }
+    }
+};
+
 // ---- wgrad: G[64 q][64 p] per workgroup, reduction over batch rows (BK = 32), both operands COL,
 // waves 2x2 with 32x32 each; the epilogue operands (Adam's p, m, v) are fetched under the loop --
 #ifndef PVAE_WGRAD_PIPE
 #define PVAE_WGRAD_PIPE 1      // 0: the plain loop (also what the ablation probes run)
 #endif
-template <class Epi, int ABL = 0>
-__device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
+template <class Epi, int ABL = 0, class PS = PDense>
+__device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, Epi& epi, const PS& ps = PS()) {
     constexpr int BK = 32, kTile = 32 * 64, kStage = 2 * kTile, D = PVAE_REG_DEPTH_W, S = 2;
     static_assert(S * kStage == kRegRingFloats, "LDS budget");
     const float* __restrict__ Q = ga.Q;
@@ -1585,6 +1753,7 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
     const float* sq[2];
     const float* sp[2];
     int slot_off[2];
+    XLanes<2, BK, D> xl;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int j = (wave + 4 * u) * 64 + lane;
@@ -1592,13 +1761,27 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
         const int row = j >> 4, c = (j & 15) ^ ((row & 1) << 3);
         sq[u] = Q + (size_t)row * ldq + q0 + c * 4;
         sp[u] = P + (size_t)row * ldp + p0 + c * 4;
+        if constexpr (PS::kGather) xl.set(ps.x, u, row, p0 + c * 4);
+    }
+    const int nk_ = K / BK;
+    if constexpr (PS::kGather) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) xl.fetch(ps.x, d < nk_ ? d : nk_ - 1, d);
     }
     v4f rg[D][4];
-    auto gload = [&](int t, v4f(&r)[4]) {
-        r[0] = *reinterpret_cast<const v4f*>(sq[0] + (size_t)t * BK * ldq);
-        r[1] = *reinterpret_cast<const v4f*>(sp[0] + (size_t)t * BK * ldp);
-        r[2] = *reinterpret_cast<const v4f*>(sq[1] + (size_t)t * BK * ldq);
-        r[3] = *reinterpret_cast<const v4f*>(sp[1] + (size_t)t * BK * ldp);
+    auto gload = [&](int t, v4f(&r)[4], int s_ = 0) {
+        if constexpr (PS::kGather) {
+            v4f o[2];
+            r[0] = *reinterpret_cast<const v4f*>(sq[0] + (size_t)t * BK * ldq);
+            r[2] = *reinterpret_cast<const v4f*>(sq[1] + (size_t)t * BK * ldq);
+            xl.load(ps.x, t, t + D < nk_ ? t + D : nk_ - 1, s_, o);
+            r[1] = o[0]; r[3] = o[1];
+        } else {
+            r[0] = *reinterpret_cast<const v4f*>(sq[0] + (size_t)t * BK * ldq);
+            r[1] = *reinterpret_cast<const v4f*>(sp[0] + (size_t)t * BK * ldp);
+            r[2] = *reinterpret_cast<const v4f*>(sq[1] + (size_t)t * BK * ldq);
+            r[3] = *reinterpret_cast<const v4f*>(sp[1] + (size_t)t * BK * ldp);
+        }
     };
     auto lwrite = [&](float* slot, const v4f(&r)[4]) {
         *reinterpret_cast<v4f*>(slot + slot_off[0]) = r[0];
@@ -1620,9 +1803,9 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
 
     const int nk = K / BK;
 #pragma unroll
-    for (int d = 0; d < D; ++d) gload(d < nk ? d : nk - 1, rg[d]);     // (clamped, not guarded: exact vmcnt)
+    for (int d = 0; d < D; ++d) gload(d < nk ? d : nk - 1, rg[d], d);     // (clamped, not guarded: exact vmcnt)
     lwrite(lds, rg[0]);
-    gload(D < nk ? D : nk - 1, rg[0]);
+    gload(D < nk ? D : nk - 1, rg[0], 0);
     // epilogue operands: queued behind the first D tiles, they arrive while the loop runs
     typename Epi::Pre pre[2][2];
 #pragma unroll
@@ -1660,10 +1843,10 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
                 if (!guarded) {
                     lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
                     const int tn = t + 1 + D < nk ? t + 1 + D : nk - 1;
-                    gload(tn, rg[(d + 1) % D]);
+                    gload(tn, rg[(d + 1) % D], (d + 1) % D);
                 } else if (t + 1 < nk) {
                     lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
-                    if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D]);
+                    if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D], (d + 1) % D);
                 }
             }
         }
@@ -1699,10 +1882,10 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
                     // with the guards it drained the whole prefetch queue before every LDS write.
                     lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
                     const int tn = t + 1 + D < nk ? t + 1 + D : nk - 1;
-                    gload(tn, rg[(d + 1) % D]);
+                    gload(tn, rg[(d + 1) % D], (d + 1) % D);
                 } else if (t + 1 < nk) {
                     lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
-                    if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D]);
+                    if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D], (d + 1) % D);
                 }
             }
         }
@@ -1738,8 +1921,8 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
 // tiles the same matrix gives four times the workgroups, each a quarter as long: the four waves
 // split every 64-row k-tile (16 rows = 4 MFMA k-steps each) over the whole tile and reduce through
 // LDS at the end, like the input-gradient body.  Needs K % 64 == 0 (wgrad_uses_32x32).
-template <class Epi>
-__device__ inline void wgrad32_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
+template <class Epi, class PS = PDense>
+__device__ inline void wgrad32_body(float* lds, int bid, const GemmArgs& ga, Epi& epi, const PS& ps = PS()) {
     constexpr int BK = 64, kTile = 64 * 32, kStage = 2 * kTile, D = PVAE_REG_DEPTH_W, S = 2;
     static_assert(S * kStage == kRegRingFloats, "LDS budget");
     static_assert(S * kStage >= 4 * 32 * 36, "ring must hold the split-K reduction buffer");
@@ -1763,6 +1946,7 @@ __device__ inline void wgrad32_body(float* lds, int bid, const GemmArgs& ga, Epi
     const float* sq[2];
     const float* sp[2];
     int slot_off[2];
+    XLanes<2, BK, D> xl;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int j = tid + 256 * u;
@@ -1770,13 +1954,27 @@ __device__ inline void wgrad32_body(float* lds, int bid, const GemmArgs& ga, Epi
         slot_off[u] = j * 4;
         sq[u] = Q + (size_t)row * ldq + q0 + c * 4;
         sp[u] = P + (size_t)row * ldp + p0 + c * 4;
+        if constexpr (PS::kGather) xl.set(ps.x, u, row, p0 + c * 4);
+    }
+    const int nk_ = K / BK;
+    if constexpr (PS::kGather) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) xl.fetch(ps.x, d < nk_ ? d : nk_ - 1, d);
     }
     v4f rg[D][4];
-    auto gload = [&](int t, v4f(&r)[4]) {
-        r[0] = *reinterpret_cast<const v4f*>(sq[0] + (size_t)t * BK * ldq);
-        r[1] = *reinterpret_cast<const v4f*>(sp[0] + (size_t)t * BK * ldp);
-        r[2] = *reinterpret_cast<const v4f*>(sq[1] + (size_t)t * BK * ldq);
-        r[3] = *reinterpret_cast<const v4f*>(sp[1] + (size_t)t * BK * ldp);
+    auto gload = [&](int t, v4f(&r)[4], int s_ = 0) {
+        if constexpr (PS::kGather) {
+            v4f o[2];
+            r[0] = *reinterpret_cast<const v4f*>(sq[0] + (size_t)t * BK * ldq);
+            r[2] = *reinterpret_cast<const v4f*>(sq[1] + (size_t)t * BK * ldq);
+            xl.load(ps.x, t, t + D < nk_ ? t + D : nk_ - 1, s_, o);
+            r[1] = o[0]; r[3] = o[1];
+        } else {
+            r[0] = *reinterpret_cast<const v4f*>(sq[0] + (size_t)t * BK * ldq);
+            r[1] = *reinterpret_cast<const v4f*>(sp[0] + (size_t)t * BK * ldp);
+            r[2] = *reinterpret_cast<const v4f*>(sq[1] + (size_t)t * BK * ldq);
+            r[3] = *reinterpret_cast<const v4f*>(sp[1] + (size_t)t * BK * ldp);
+        }
     };
     auto lwrite = [&](float* slot, const v4f(&r)[4]) {
         *reinterpret_cast<v4f*>(slot + slot_off[0]) = r[0];
@@ -1795,9 +1993,9 @@ __device__ inline void wgrad32_body(float* lds, int bid, const GemmArgs& ga, Epi
 
     const int nk = K / BK;
 #pragma unroll
-    for (int d = 0; d < D; ++d) gload(d < nk ? d : nk - 1, rg[d]);     // (clamped, not guarded: exact vmcnt)
+    for (int d = 0; d < D; ++d) gload(d < nk ? d : nk - 1, rg[d], d);     // (clamped, not guarded: exact vmcnt)
     lwrite(lds, rg[0]);
-    gload(D < nk ? D : nk - 1, rg[0]);
+    gload(D < nk ? D : nk - 1, rg[0], 0);
     const typename Epi::Pre pre = epi.load(q0 + (tid >> 3), p0 + ((tid & 7) << 2));   // arrives under the loop
     __syncthreads();
 
@@ -1823,10 +2021,10 @@ __device__ inline void wgrad32_body(float* lds, int bid, const GemmArgs& ga, Epi
                 if (!guarded) {
                     lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
                     const int tn = t + 1 + D < nk ? t + 1 + D : nk - 1;
-                    gload(tn, rg[(d + 1) % D]);
+                    gload(tn, rg[(d + 1) % D], (d + 1) % D);
                 } else if (t + 1 < nk) {
                     lwrite(lds + ((t + 1) & 1) * kStage, rg[(d + 1) % D]);
-                    if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D]);
+                    if (t + 1 + D < nk) gload(t + 1 + D, rg[(d + 1) % D], (d + 1) % D);
                 }
             }
         }
@@ -1866,10 +2064,10 @@ __device__ inline void wgrad32_body(float* lds, int bid, const GemmArgs& ga, Epi
 
 // either geometry, chosen per problem on the host
 constexpr int kPairLdsFloats = kRegRingFloats;
-template <class Epi, int ABL = 0>
-__device__ inline void wgrad_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
-    if (ga.tile32) wgrad32_body<Epi>(lds, bid, ga, epi);
-    else wgrad_reg_body<Epi, ABL>(lds, bid, ga, epi);
+template <class Epi, int ABL = 0, class PS = PDense>
+__device__ inline void wgrad_body(float* lds, int bid, const GemmArgs& ga, Epi& epi, const PS& ps = PS()) {
+    if (ga.tile32) wgrad32_body<Epi, PS>(lds, bid, ga, epi, ps);
+    else wgrad_reg_body<Epi, ABL, PS>(lds, bid, ga, epi, ps);
 }
 
 struct AdamScalars {
@@ -2041,6 +2239,36 @@ gemm_wgrad_reg_kernel(PVAE_GA_PARAMS(a_), int nw, Epi epi, AdamPair ad) {
 // those (sa.rows_pad of them) stage the NEXT minibatch into the
 // alternate input panels (StageArgs / stage_row below): the gather rides in the last launch of the
 // step that precedes it instead of being a launch of its own.
+// (PS = PGather: problem 1's X operand is the gathered first-layer input -- no staging workgroups then)
+template <class EpiW, class PS>
+__global__ void __launch_bounds__(256)
+wgrad_pair_gather_kernel(PVAE_GA2_PARAMS, int na, EpiW e1, EpiW e2, AdamPair ad, PS ps) {
+    __shared__ __attribute__((aligned(16))) float lds[kPairLdsFloats];
+    const GemmArgs g1 = PVAE_GA2_A, g2 = PVAE_GA2_B;
+    const int n1 = ga_grid(g1), n12 = n1 + ga_grid(g2);
+    const int b = blockIdx.x;
+    const int nb1 = bias_tiles(g1), nb2 = bias_tiles(g2);
+    if (b < n1) wgrad_body<EpiW, 0, PS>(lds, b, g1, e1, ps);
+    else if (b < n12) wgrad_body<EpiW>(lds, b - n1, g2, e2);
+    else if (b < n12 + nb1) bias_grad_body(lds, b - n12, g1, e1);
+    else if (b < n12 + nb1 + nb2) bias_grad_body(lds, b - n12 - nb1, g2, e2);
+    else adam_pair_body(ad, b - n12 - nb1 - nb2);
+}
+template <class EpiD, class EpiW, class PS>
+__global__ void __launch_bounds__(256)
+bwd_pair_gather_kernel(PVAE_GA2_PARAMS, EpiD ed, EpiW ew, AdamPair ad, PS ps) {
+    __shared__ __attribute__((aligned(16))) float lds[kPairLdsFloats];
+    const GemmArgs gd = PVAE_GA2_A, gw = PVAE_GA2_B;
+    const int nd = ga_grid(gd), nw = ga_grid(gw);
+    const int b = blockIdx.x;
+    if (b < nd) {
+        if (gd.tile16) splitk_reg16_body<false, EpiD>(lds, b, gd, ed);
+        else splitk_reg_body<false, EpiD, 0>(lds, b, gd, ed);
+    } else if (b < nd + nw) wgrad_body<EpiW, 0, PS>(lds, b - nd, gw, ew, ps);
+    else if (b < nd + nw + bias_tiles(gw)) bias_grad_body(lds, b - nd - nw, gw, ew);
+    else adam_pair_body(ad, b - nd - nw - bias_tiles(gw));
+}
+
 template <class EpiW>
 __global__ void __launch_bounds__(256)
 wgrad_pair_kernel(PVAE_GA2_PARAMS, int na, EpiW e1, EpiW e2, StageArgs sa, AdamPair ad) {
@@ -2185,11 +2413,14 @@ struct EpiMse {
     float* partial;
     int l1;                   // 0: nn.MSELoss (sum d^2, grad 2d/n), 1: nn.L1Loss (sum |d|, grad sign(d)/n)
     float sq = 0.f;
+    const int32_t* trow = nullptr;   // not null: the target of batch row q is row trow[q] of `target` (s_{t+1} read from
+                                     // `states` where it lies, 4-byte aligned; columns >= D are never used)
     struct Pre { v4f b, t; };
     __device__ inline Pre preload(int q, int p) const {
         Pre r;
         r.b = bias ? *reinterpret_cast<const v4f*>(bias + p) : v4f{0.f, 0.f, 0.f, 0.f};
-        r.t = *reinterpret_cast<const v4f*>(target + (size_t)q * ldt + p);
+        const size_t tq = trow ? (size_t)(q < rows ? trow[q] : trow[0]) : (size_t)q;
+        r.t = *reinterpret_cast<const v4f*>(target + tq * ldt + (trow && p >= D ? 0 : p));
         return r;
     }
     __device__ inline void operator()(int q, int p, v4f v, const Pre& pre) {
@@ -2256,6 +2487,7 @@ struct EpiActionSeed {
     int l1;
     float* partial;
     float sq = 0.f;
+    const int32_t* trow = nullptr;    // not null: the demonstrated action of batch row q is row trow[q] of `target` (`actions`)
     struct Pre {};
     __device__ inline Pre preload(int, int) const { return Pre(); }
     __device__ inline void operator()(int q, int p, v4f v, const Pre&) {
@@ -2266,7 +2498,7 @@ struct EpiActionSeed {
             if (c < 0 || c >= n) continue;
             float g = 0.f;
             if (q < rows) {
-                const float d = pred[(size_t)q * ldp + c] - target[(size_t)q * ldt + c];
+                const float d = pred[(size_t)q * ldp + c] - target[(size_t)(trow ? trow[q] : q) * ldt + c];
                 sq += l1 ? fabsf(d) : d * d;
                 g = grad_scale * (l1 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : d) + v[e];
             }
@@ -2487,6 +2719,39 @@ inline hipError_t gemm_forward_pro(const float* X, int ldx, const float* W, int 
     PVAE_LAUNCH((gemm_splitk_ws_pro_kernel<Epi, Pro>), dim3(g.grid), dim3(kWsThreads), st, PVAE_GA_PASS(ga), e, pro);
     return hipGetLastError();
 }
+// a stack's FIRST layer on the gathered operand (XSrc): same tile geometries as gemm_forward_epi, never the 16x16 kernel
+inline bool forward_gather_ok(int M, int N) { return !forward_uses_16x16(M, N) && !g_krot && !g_rowxcd; }
+template <class Epi>
+inline hipError_t gemm_forward_gather(const XSrc& xs, const float* W, int ldw, int M, int N, int K, const Epi& e, hipStream_t st) {
+    const QGather qs{xs};
+    if constexpr (std::is_same<Epi, EpiBiasAct>::value) {
+        if (uses_64x64(M, N)) {
+            GemmArgs ga{nullptr, 0, W, ldw, K, 0, 0, 0};
+            const GemmGrid g = make_grid_6464(M, N, ga);
+            PVAE_LAUNCH((gemm_splitk_ws64_gather_kernel<Epi, 64>), dim3(g.grid), dim3(512), st, PVAE_GA_PASS(ga), e, qs);
+            return hipGetLastError();
+        }
+        if (uses_64x32(M, N)) {
+            const GemmGrid g = make_grid(M, N, 64, 32);
+            const GemmArgs ga{nullptr, 0, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd};
+            PVAE_LAUNCH((gemm_splitk_ws64_gather_kernel<Epi, 32>), dim3(g.grid), dim3(512), st, PVAE_GA_PASS(ga), e, qs);
+            return hipGetLastError();
+        }
+    }
+    const GemmGrid g = make_grid(M, N, 32, 32);
+    const GemmArgs ga{nullptr, 0, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd};
+    PVAE_LAUNCH((gemm_splitk_ws_gather_kernel<Epi>), dim3(g.grid), dim3(kWsThreads), st, PVAE_GA_PASS(ga), e, qs);
+    return hipGetLastError();
+}
+template <class Epi, class Pro>
+inline hipError_t gemm_forward_pro_gather(const XSrc& xs, const float* W, int ldw, int M, int N, int K, const Epi& e,
+                                          const Pro& pro, hipStream_t st) {
+    const QGather qs{xs};
+    const GemmGrid g = make_grid(M, N, 32, 32);
+    const GemmArgs ga{nullptr, 0, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd};
+    PVAE_LAUNCH((gemm_splitk_ws_pro_gather_kernel<Epi, Pro>), dim3(g.grid), dim3(kWsThreads), st, PVAE_GA_PASS(ga), e, pro, qs);
+    return hipGetLastError();
+}
 inline hipError_t gemm_forward(const float* X, int ldx, const float* W, int ldw, const float* bias,
                                float* out, int ldo, int M, int N, int K, int act, hipStream_t st) {
     EpiBiasAct e{out, ldo, bias, act};
@@ -2580,6 +2845,31 @@ inline hipError_t gemm_wgrad_pair(const float* dZ1, int ldz1, const float* X1, i
     if (!ga_packable(w1.ga) || !ga_packable(w2.ga) || ga_grid(w1.ga) != w1.grid || ga_grid(w2.ga) != w2.grid) return hipErrorInvalidValue;
     PVAE_LAUNCH((wgrad_pair_kernel<EpiW>), dim3(w1.grid + w2.grid + w1.nbias + w2.nbias + adam_blocks(ad) + sa.rows_pad),
                 dim3(256), st, PVAE_GA2_PASS(w1.ga, w2.ga), adam_blocks(ad), e1, e2, sa, ad ? *ad : AdamPair());
+    return hipGetLastError();
+}
+// the same with problem 1's X gathered (XSrc) -- a stack's first layer; nothing to stage then
+template <class EpiW>
+inline hipError_t gemm_wgrad_pair_gather(const float* dZ1, int ldz1, const XSrc& xs, int N1, int Kin1, const EpiW& e1, int M,
+                                         hipStream_t st, const AdamPair* ad = nullptr) {
+    const WgradPlan w1 = plan_wgrad(dZ1, ldz1, nullptr, 0, N1, Kin1, M);
+    const WgradPlan w2 = plan_wgrad(nullptr, 0, nullptr, 0, 0, Kin1, M);
+    if (!ga_packable(w1.ga) || !ga_packable(w2.ga) || ga_grid(w1.ga) != w1.grid || ga_grid(w2.ga) != w2.grid) return hipErrorInvalidValue;
+    const PGather ps{xs};
+    PVAE_LAUNCH((wgrad_pair_gather_kernel<EpiW, PGather>), dim3(w1.grid + w2.grid + w1.nbias + w2.nbias + adam_blocks(ad)),
+                dim3(256), st, PVAE_GA2_PASS(w1.ga, w2.ga), adam_blocks(ad), e1, e1, ad ? *ad : AdamPair(), ps);
+    return hipGetLastError();
+}
+// input gradient (16x16 / 32x32 tiles, caller's epilogue) || weight gradient on the gathered X
+template <class EpiD, class EpiW>
+inline hipError_t gemm_bwd_pair_epi_gather(const float* dZd, int ldzd, const float* Wd, int ldwd, int Md, int Kind, int Nd,
+                                           const EpiD& ed, const float* dZw, int ldzw, const XSrc& xs, int Nw, int Kinw,
+                                           int Mw, const EpiW& ew, hipStream_t st, const AdamPair* ad = nullptr) {
+    const DgradPlan d = plan_dgrad(dZd, ldzd, Wd, ldwd, Md, Kind, Nd);
+    const WgradPlan w = plan_wgrad(dZw, ldzw, nullptr, 0, Nw, Kinw, Mw);
+    if (!ga_packable(d.ga) || !ga_packable(w.ga) || ga_grid(d.ga) != d.grid || ga_grid(w.ga) != w.grid) return hipErrorInvalidValue;
+    const PGather ps{xs};
+    PVAE_LAUNCH((bwd_pair_gather_kernel<EpiD, EpiW, PGather>), dim3(d.grid + w.grid + w.nbias + adam_blocks(ad)), dim3(256), st,
+                PVAE_GA2_PASS(d.ga, w.ga), ed, ew, ad ? *ad : AdamPair(), ps);
     return hipGetLastError();
 }
 // one launch: dX'[M][Kin'] = (dZ'[M][N'] W'[N'][Kin']) .* mask   ||   G[N][Kin] = dZ[M][N]^T X[M][Kin]

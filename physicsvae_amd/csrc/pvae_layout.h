@@ -123,6 +123,7 @@ struct Workspace {
     int64_t alt_s2 = 0, alt_act_t = 0;
     int64_t loss_part = 0;      // [5][kLossParts] partial sums
     int64_t obs_keep = 0;       // [4][2*Db] the observation rows of the last <= 4-row rollout call (pvae_infer)
+    int64_t zero = 0;           // 64 floats that nothing ever writes: what a gathered first-layer operand reads for "no source"
     int64_t total_floats = 0;
 };
 
@@ -156,6 +157,7 @@ inline Workspace make_workspace(const Layout& L) {
     W.alt_act_t = take((int64_t)W.Bp * pad64(L.cfg.dim_action));
     W.loss_part = take(5 * kLossParts);
     W.obs_keep = take(4 * 2 * (int64_t)L.cfg.dim_body);
+    W.zero = take(64);
     W.total_floats = off;
     return W;
 }

@@ -266,6 +266,17 @@ class HipEngine:
         if next_states is not None:
             _lib.check(self.lib.pvae_bind_dataset_next(self.ctx, next_states.data_ptr()), "pvae_bind_dataset_next")
 
+    def set_direct(self, on=True):
+        """Training steps read the demonstration set where it lies (no staging launch; include/pvae.h pvae_set_direct).
+        Default on; off = every step stages its input panels first (same bits)."""
+        self._need_gpu()
+        _lib.check(self.lib.pvae_set_direct(self.ctx, 1 if on else 0), "pvae_set_direct")
+
+    def direct_active(self, phase, rows, sp, fused=True):
+        """Would a training step with these arguments take the direct path?"""
+        self._need_gpu()
+        return bool(_lib.check(int(self.lib.pvae_direct_active(self.ctx, phase, int(rows), C.byref(sp), 1 if fused else 0))))
+
     def invalidate_staging(self):
         """Forget the staged / prefetched minibatch (something else is about to overwrite the panels)."""
         if self.ctx is not None:

@@ -158,8 +158,16 @@ class WindowDataset(torch_models.DatasetBase):
         d = torch.device(device)
         have = None if self._dev is None else self._dev[0].device
         if have is None or have.type != d.type or (d.index is not None and d.index != have.index):
-            self._dev = tuple(torch.from_numpy(a).to(device)
-                              for a in (self.states, self.actions, self.window_row))
+            def roomy(a):
+                # (16 readable bytes behind the last row: the first layers fetch the rows in 16-byte chunks where they lie,
+                #  include/pvae.h pvae_set_direct; without it the steps fall back to the staging launch)
+                a = torch.from_numpy(a)
+                buf = torch.empty(a.numel() + 16, dtype=a.dtype, device=device)
+                buf[a.numel():].zero_()
+                out = buf[: a.numel()].view(a.shape)
+                out.copy_(a)
+                return out
+            self._dev = (roomy(self.states), roomy(self.actions), torch.from_numpy(self.window_row).to(device))
             if self.next_states is not None:
                 self._dev = self._dev + (torch.from_numpy(self.next_states).to(device),)
         return self._dev
