@@ -184,8 +184,9 @@ int pvae_bind_dataset_next(pvae_ctx* ctx, const float* next_states);
  * tile kernels, no `next_states` array, and dataset allocations that are readable 16 bytes past their last row (checked
  * at pvae_bind_dataset with hipMemGetAddressRange: a chunk may reach 12 bytes past a row).  Everything else -- and
  * pvae_gather / pvae_set_batch + pvae_forward_backward always -- goes through the staging launch as before; both paths
- * give the same bits.  pvae_set_direct(ctx, 0) switches the direct path off (default on); pvae_direct_active tells
- * whether a step with these arguments would take it (1 / 0). */
+ * give the same bits.  OPT-IN: pvae_set_direct(ctx, 1) (default off -- at BASELINE's 256 rows per GPU the staged step is
+ * the faster one: its gather rides in the previous step's last launch); pvae_direct_active tells
+ * whether a step with these arguments would take the direct path (1 / 0). */
 int pvae_set_direct(pvae_ctx* ctx, int on);
 int pvae_direct_active(pvae_ctx* ctx, int phase, int32_t rows, const pvae_step_params* sp, int fused);
 

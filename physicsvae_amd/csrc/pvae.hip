@@ -178,10 +178,15 @@ struct pvae_ctx {
     // points (pvae_train_step, _prefetch, pvae_dp_train_step) stage nothing when `direct_ok` holds -- the first layer of
     // every stack gathers its rows of `states` / `actions` itself, the two targets are read from there by the loss
     // epilogues.  pvae_gather / pvae_set_batch + pvae_forward_backward keep the panel path (inspection, explicit batches,
-    // lookahead > 1, evaluation, the other priors).  pvae_set_direct(ctx, 0) switches it off (A/B, parity tests).
-    bool direct = true;
+    // lookahead > 1, evaluation, the other priors).  OPT-IN (pvae_set_direct(ctx, 1)): bit-identical to the staged step,
+    // but at 256 rows the staged step is the faster one -- its gather rides in the previous step's last launch for free,
+    // while a gathered first layer waits for its operand descriptor (kernel arguments that cannot be preloaded) before its
+    // first tile fetch: joint 252.3 vs 241.5 us, world 92.1 vs 87.3 (docs/experiments.md, round 5).
+    bool direct = false;
     bool data_slack = false;     // both dataset arrays are readable 16 bytes past their last row (checked at bind time)
-    struct { bool on = false; const int32_t* row = nullptr; } dx;    // the step in flight: window_row + first_window
+    struct { bool on = false; RowMap rm{}; } dx;                     // the step in flight: batch row -> row of the set
+    TouchRuns next_touch{};                                          // rows of the NEXT minibatch for the last launch to pre-touch
+    std::vector<int32_t> window_row_host;                            // copied at bind time: the host finds the episode jumps
     bool pair_launch = true;     // PVAE_PAIR=0 launches every contraction on its own (A/B)
     // gather prefetch (pvae_train_step_prefetch): what the alternate staging panels hold, and the
     // staging job the current step's last launch should carry
@@ -1597,7 +1602,8 @@ static void plan_backward_net(pvae_ctx* c, int n, int rows_pad, bool train, bool
             const bool carry = with_fold && c->next_stage.rows_pad > 0;
             const AdamPair ad = take_pending(c);
             if (dx0) {                        // X gathered from the demonstration set: nothing was staged, nothing to stage
-                HIP_TRY(gemm_wgrad_pair_gather(c->ws + w->dz[0], l0.n_out_pad, xs0, l0.n_out_pad, l0.ld, e0, rows_pad, st, &ad));
+                HIP_TRY(gemm_wgrad_pair_gather(c->ws + w->dz[0], l0.n_out_pad, xs0, l0.n_out_pad, l0.ld, e0, rows_pad, st, &ad,
+                                               with_fold && c->next_touch.blocks > 0 ? &c->next_touch : nullptr));
                 return 0;
             }
             HIP_TRY(gemm_wgrad_pair(c->ws + w->dz[0], l0.n_out_pad, c->ws + w->in, l0.ld, l0.n_out_pad, l0.ld, e0,
@@ -1853,12 +1859,29 @@ int pvae_bind_dataset(pvae_ctx* c, const float* states, const float* actions, co
         return (const char*)(p + floats) + 16 <= (const char*)base + size;
     };
     c->data_slack = roomy(states, n_rows * c->L.cfg.dim_body) && roomy(actions, n_rows * c->L.cfg.dim_action);
+    // window -> row on the host (RowMap: a minibatch's rows as two runs in kernel arguments instead of an index load in
+    // front of every first-layer launch).  The caller's array must be final when it is bound.
+    c->window_row_host.clear();
+    if (c->data_slack && c->direct) {                   // (pvae_set_direct after the bind: index loads instead -- still correct)
+        c->window_row_host.resize((size_t)n_windows);
+        if (hipMemcpy(c->window_row_host.data(), window_row, (size_t)n_windows * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipGetLastError();
+            c->window_row_host.clear();
+        }
+    }
     return 0;
 }
 
 int pvae_set_direct(pvae_ctx* c, int on) {
     if (!c) return fail(-1, "null ctx");
     c->direct = on != 0;
+    if (c->direct && c->data_slack && c->window_row && (int64_t)c->window_row_host.size() != c->n_windows) {
+        c->window_row_host.resize((size_t)c->n_windows);
+        if (hipMemcpy(c->window_row_host.data(), c->window_row, (size_t)c->n_windows * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipGetLastError();
+            c->window_row_host.clear();
+        }
+    }
     return 0;
 }
 // 1: the next training step on this binding would read the demonstration set directly (same arguments as the step)
@@ -1983,18 +2006,18 @@ static XSrc xsrc_of(const pvae_ctx* c, int net, int phase, bool with_s1, int row
     const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action, Z = c->L.cfg.latent;
     XSrc x;
     memset(&x, 0, sizeof(x));
-    x.s0 = c->states; x.row0 = c->dx.row; x.ld0 = Db; x.rows = rows;
+    x.s0 = c->states; x.rm = c->dx.rm; x.ld0 = Db; x.rows = rows;
     x.zero = c->ws + c->W.zero;
     x.s1 = x.zero;
     if (net == PVAE_NET_TE) { x.n0 = 2 * Db; return x; }               // [s_t | s_{t+1}]: one run of 2 Db floats of `states`
     x.n0 = Db;
     if (!with_s1) return x;
     if (net == PVAE_NET_MD) {                                          // [s_t | z]: z where the sampler stored it
-        x.s1 = c->ws + c->W.net[PVAE_NET_MD].in + Db; x.row1 = nullptr; x.ld1 = c->L.net[PVAE_NET_MD].layers[0].ld; x.n1 = Z;
+        x.s1 = c->ws + c->W.net[PVAE_NET_MD].in + Db; x.ind1 = 0; x.ld1 = c->L.net[PVAE_NET_MD].layers[0].ld; x.n1 = Z;
     } else if (phase == PVAE_PHASE_WORLD) {                            // [s_t | a_t]
-        x.s1 = c->actions; x.row1 = c->dx.row; x.ld1 = Da; x.n1 = Da;
+        x.s1 = c->actions; x.ind1 = 1; x.ld1 = Da; x.n1 = Da;
     } else {                                                           // [s_t | a_hat]: the decoder's output panel
-        x.s1 = c->ws + c->W.net[PVAE_NET_MD].act.back(); x.row1 = nullptr; x.ld1 = c->L.net[PVAE_NET_MD].layers.back().n_out_pad; x.n1 = Da;
+        x.s1 = c->ws + c->W.net[PVAE_NET_MD].act.back(); x.ind1 = 0; x.ld1 = c->L.net[PVAE_NET_MD].layers.back().n_out_pad; x.n1 = Da;
     }
     return x;
 }
@@ -2127,13 +2150,14 @@ static int run_forward(pvae_ctx* c, int phase, int rows, const pvae_step_params*
     ProCols wm_cols;
     memset(&wm_cols, 0, sizeof(wm_cols));
     if (dx) {
-        mse.target = c->states + Db; mse.ldt = Db; mse.trow = c->dx.row;          // row + 1 of the window's s_t
+        mse.target = c->states + Db; mse.ldt = Db; mse.tind = 1; mse.trm = c->dx.rm;   // row + 1 of the window's s_t
         const bool wm64 = uses_64x32(S.rows_pad, WM.layers[0].n_out_pad);
         xs_wm = xsrc_of(c, PVAE_NET_WM, phase, wm64, rows);
         wm_tail.xs0 = &xs_wm;
         if (!wm64) {
             const XSrc full = xsrc_of(c, PVAE_NET_WM, phase, true, rows);
-            wm_cols.src = full.s1; wm_cols.row = full.row1; wm_cols.ld = full.ld1; wm_cols.c0 = Db; wm_cols.n = Da; wm_cols.rows = rows;
+            wm_cols.src = full.s1; wm_cols.ind = full.ind1; wm_cols.rm = full.rm; wm_cols.ld = full.ld1; wm_cols.c0 = Db; wm_cols.n = Da;
+            wm_cols.rows = rows;
             wm_tail.cols0 = &wm_cols;
         }
     }
@@ -2227,7 +2251,7 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
             memset(&sd.a, 0, sizeof(sd.a));
             sd.a.pred = w + wmd->act.back(); sd.a.ldp = ldo_md;
             sd.a.target = w + c->W.act_t; sd.a.ldt = pad64(Da);
-            if (c->dx.on) { sd.a.target = c->actions; sd.a.ldt = Da; sd.a.trow = c->dx.row; }     // a_t where it lies
+            if (c->dx.on) { sd.a.target = c->actions; sd.a.ldt = Da; sd.a.tind = 1; sd.a.trm = c->dx.rm; }     // a_t where it lies
             sd.a.dz = w + wmd->dz.back(); sd.a.ldz = ldo_md;
             sd.a.c0 = Db; sd.a.n = Da; sd.a.rows = rows;
             sd.a.grad_scale = ga; sd.a.l1 = S.l1;
@@ -3205,6 +3229,39 @@ static int exchange_bucket(pvae_ctx* c, int net, const Bucket& b, const pvae_ste
     return pvae_adam_segment(c, net, b.off, b.cnt, sp, cs);
 }
 
+static RowMap row_map(const pvae_ctx* c, int64_t first_window, int rows) {
+    RowMap rm;
+    rm.row = c->window_row + first_window;
+    rm.seg = 0; rm.q1 = rows; rm.b0 = rm.b1 = 0;
+    if ((int64_t)c->window_row_host.size() == c->n_windows) {          // at most one jump inside the minibatch: two runs
+        const int32_t* wr = c->window_row_host.data() + first_window;
+        int jumps = 0, at = rows;
+        for (int q = 1; q < rows && jumps < 2; ++q)
+            if (wr[q] != wr[q - 1] + 1) { ++jumps; at = q; }
+        if (jumps < 2) { rm.seg = 1; rm.q1 = at; rm.b0 = wr[0]; rm.b1 = at < rows ? wr[at] : 0; }
+    }
+    return rm;
+}
+// the rows the NEXT minibatch's first layers will gather, as runs of 128-byte lines for the last launch of this step to touch
+static void plan_touch(pvae_ctx* c, int64_t next_first, int next_rows) {
+    memset(&c->next_touch, 0, sizeof(c->next_touch));
+    if (next_rows <= 0 || next_first < 0 || next_first + next_rows > c->n_windows) return;
+    const RowMap rm = row_map(c, next_first, next_rows);
+    if (!rm.seg) return;
+    const int Db = c->L.cfg.dim_body, Da = c->L.cfg.dim_action;
+    const int n[2] = {rm.q1, next_rows - rm.q1}, b[2] = {rm.b0, rm.b1};
+    int total = 0;
+    for (int s = 0; s < 2; ++s) {
+        if (n[s] <= 0) continue;
+        c->next_touch.p[2 * s] = c->states + (size_t)b[s] * Db;
+        c->next_touch.lines[2 * s] = (int)(((size_t)(n[s] + 1) * Db * 4 + 127) / 128);     // (+ 1: s_{t+1} of the run's last window)
+        c->next_touch.p[2 * s + 1] = c->actions + (size_t)b[s] * Da;
+        c->next_touch.lines[2 * s + 1] = (int)(((size_t)n[s] * Da * 4 + 127) / 128);
+        total += c->next_touch.lines[2 * s] + c->next_touch.lines[2 * s + 1];
+    }
+    c->next_touch.blocks = total > 0 ? (total + 255) / 256 : 0;
+    if (c->next_touch.blocks > 64) c->next_touch.blocks = 64;
+}
 // A training step that reads the demonstration set directly: nothing is staged; `dx` tells run_forward /
 // plan_backward_net to use the gathered first layers.  -> false: the step takes the staging launch as before.
 static bool enter_direct(pvae_ctx* c, int phase, int64_t first_window, int rows, const pvae_step_params* sp, bool fused) {
@@ -3213,7 +3270,8 @@ static bool enter_direct(pvae_ctx* c, int phase, int64_t first_window, int rows,
     if (phase != PVAE_PHASE_WORLD && phase != PVAE_PHASE_JOINT) return false;
     if (!direct_ok(c, phase, rows, sp, fused)) return false;
     c->dx.on = true;
-    c->dx.row = c->window_row + first_window;
+    c->dx.rm = row_map(c, first_window, rows);
+    memset(&c->next_touch, 0, sizeof(c->next_touch));
     c->staged_rows = rows;
     c->staged_rows_f = rows;
     c->pf.valid = false;
@@ -3286,7 +3344,8 @@ int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t row
     const bool direct = enter_direct(c, phase, first_window, rows, sp, false);
     const bool can = !direct && c->W.L == 1 && c->pair_launch && loss_out != nullptr && c->states != nullptr;
     if (direct) {
-        // (first layers gather their rows themselves: no staging launch, nothing to prefetch)
+        // (first layers gather their rows themselves: no staging launch; the last launch pre-touches the next shard's rows)
+        if (loss_out) plan_touch(c, next_first, next_rows);
     } else if (can && c->pf.valid && c->pf.first == first_window && c->pf.rows == rows && c->pf.states == c->states) {
         flip_stage_panels(c);
         c->staged_rows = rows;
@@ -3371,7 +3430,8 @@ int pvae_train_step_prefetch(pvae_ctx* c, int phase, int64_t first_window, int32
     if (!c->states) return fail(-2, "dataset not bound");
     int rc;
     if (check_ready(c, true) == 0 && enter_direct(c, phase, first_window, rows, sp, true)) {
-        // (first layers gather their rows themselves: no staging launch, nothing to prefetch)
+        // (first layers gather their rows themselves: no staging launch; the last launch pre-touches the next minibatch's rows)
+        if (loss_out) plan_touch(c, next_first, next_rows);
         rc = pvae_forward_backward(c, phase, rows, sp, eps, loss_out, PVAE_FLAG_FUSED_ADAM, stream);
         leave_direct(c);
         return rc;

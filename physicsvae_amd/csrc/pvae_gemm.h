@@ -847,17 +847,28 @@ __device__ inline void wait_dma_tile(int younger) {
 // ---------------------------------------------------------------------------------------
 // First layers that read the demonstration set where it lies (the torch.cat sites tpv:377, rmt:829, 842
 // as address arithmetic inside the loaders).  The input of a stack's first layer is a VIRTUAL matrix
-//     X[q][k] = s0[row0[q] * ld0 + k]                              k <  n0        (rows of `states`: s_t, or [s_t | s_{t+1}])
-//             = s1[(row1 ? row1[q] : q) * ld1 + (k - n0)]     n0 <= k <  n0 + n1   (a_t rows of `actions`, or a z / a_hat panel)
+//     X[q][k] = s0[row(q) * ld0 + k]                               k <  n0        (rows of `states`: s_t, or [s_t | s_{t+1}])
+//             = s1[(ind1 ? row(q) : q) * ld1 + (k - n0)]      n0 <= k <  n0 + n1   (a_t rows of `actions`, or a z / a_hat panel)
 //             = 0                                              elsewhere, and for q >= rows
 // never materialised: the forward kernels' loaders fetch every 16-byte chunk of a Q tile from the source that holds it
 // (LDS-DMA from 4-byte-aligned addresses lands at the aligned rate: tools/unaligned_probe.hip) and the weight-gradient
 // bodies do the same through registers, zeroing what lies beyond the valid columns exactly.  The sources must be
 // readable 16 bytes past their last element (pvae_bind_dataset checks the allocations).
 // ---------------------------------------------------------------------------------------
+// Which row of the demonstration set batch row q reads.  A minibatch is a run of consecutive windows, and window -> row is
+// the identity plus a jump at every episode end: with at most one jump inside the minibatch the map is two (base, start)
+// pairs that travel as kernel arguments (the host keeps a copy of `window_row` from bind time) -- no index load in front of
+// the first tile fetch of the launch.  Otherwise: the index array itself.
+struct RowMap {
+    const int32_t* row;           // window_row + first_window (used when !seg)
+    int seg, q1, b0, b1;          // seg: rows q < q1 read row b0 + q, the others b1 + (q - q1)
+    __device__ inline int at(int q) const { return seg ? (q < q1 ? b0 + q : b1 + (q - q1)) : row[q]; }
+};
 struct XSrc {
-    const float* s0; const int32_t* row0; int ld0, n0;
-    const float* s1; const int32_t* row1; int ld1, n1;
+    const float* s0; int ld0, n0;
+    const float* s1; int ld1, n1;
+    int ind1;                     // 1: s1 is row-indirect like s0 (a_t rows of `actions`); 0: s1 row = batch row (a panel)
+    RowMap rm;
     int rows;
     const float* zero;            // >= 256 zero bytes
 };
@@ -878,8 +889,9 @@ struct QGather {
         Base b;
         b.c4 = q < x.rows ? c4 : (1 << 28);                          // (rows past the batch: every tile reads zeros)
         const int qq = q < x.rows ? q : 0;
-        b.p0 = x.s0 + (size_t)x.row0[qq] * x.ld0 + c4;
-        b.p1 = x.n1 > 0 ? x.s1 + (size_t)(x.row1 ? x.row1[qq] : qq) * x.ld1 + (c4 - x.n0) : x.zero;
+        const int r = x.rm.at(qq);
+        b.p0 = x.s0 + (size_t)r * x.ld0 + c4;
+        b.p1 = x.n1 > 0 ? x.s1 + (size_t)(x.ind1 ? r : qq) * x.ld1 + (c4 - x.n0) : x.zero;
         return b;
     }
     __device__ inline const float* tile(const Base& b, int kt) const {
@@ -914,7 +926,8 @@ struct ProCols {
     static constexpr bool kActive = true;
     static constexpr int kMaxN = 96, kScratchFloats = 4;
     static constexpr int kPer = 32 * kMaxN / 256;          // elements per thread at n = kMaxN
-    const float* src; const int32_t* row; int ld;          // value (q, j) = src[(row ? row[q] : q) * ld + j]
+    const float* src; int ld, ind;                         // value (q, j) = src[(ind ? rm.at(q) : q) * ld + j]
+    RowMap rm;
     int c0, n, rows;
     struct State { float v[kPer]; };
     __device__ inline bool needs(int t) const { return t >= (c0 >> 6) && t <= ((c0 + n - 1) >> 6); }
@@ -925,7 +938,7 @@ struct ProCols {
         for (int u = 0; u < kPer; ++u) {
             const int e = tid + 256 * u, r = e / n, j = e - r * n, q = q0 + r;
             const bool live = e < 32 * n && q < rows;
-            st.v[u] = live ? s_[(size_t)(row ? row[q] : q) * ld + j] : 0.f;
+            st.v[u] = live ? s_[(size_t)(ind ? rm.at(q) : q) * ld + j] : 0.f;
         }
         return st;
     }
@@ -1695,8 +1708,8 @@ struct XLanes {
         for (int u = 0; u < U; ++u) {
             int r = t * BKR + row[u];
             r = r < x.rows ? r : x.rows - 1;
-            i0[s][u] = x.row0[r];
-            i1[s][u] = x.row1 ? x.row1[r] : r;
+            i0[s][u] = x.rm.at(r);
+            i1[s][u] = x.ind1 ? i0[s][u] : r;
         }
     }
     // the chunk of tile t held in register set s (indices fetched earlier); then queue the indices of tile t_next
@@ -2239,10 +2252,28 @@ gemm_wgrad_reg_kernel(PVAE_GA_PARAMS(a_), int nw, Epi epi, AdamPair ad) {
 // those (sa.rows_pad of them) stage the NEXT minibatch into the
 // alternate input panels (StageArgs / stage_row below): the gather rides in the last launch of the
 // step that precedes it instead of being a launch of its own.
+// What the step's LAST launch does for the NEXT minibatch of a direct run: nothing is staged, but the rows the next
+// step's first layers will gather are cold in HBM (an epoch walks the whole set once), and their first touch would sit on
+// the critical path of those launches (+2 us each, measured).  A few workgroups of this launch read one dword per
+// 128-byte line of those rows -- up to four contiguous runs: the state rows and the action rows of the (at most two)
+// episode segments of the minibatch -- so that the Infinity Cache holds them when the next step starts.
+struct TouchRuns {
+    const float* p[4];
+    int lines[4];                 // 128-byte lines per run (0: none)
+    int blocks;                   // workgroups that do the touching
+};
+__device__ inline void touch_body(const TouchRuns& t, int blk) {
+    float sink = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        for (int i = blk * 256 + (int)threadIdx.x; i < t.lines[r]; i += t.blocks * 256)
+            asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(t.p[r] + (size_t)i * 32) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory");
+}
 // (PS = PGather: problem 1's X operand is the gathered first-layer input -- no staging workgroups then)
 template <class EpiW, class PS>
 __global__ void __launch_bounds__(256)
-wgrad_pair_gather_kernel(PVAE_GA2_PARAMS, int na, EpiW e1, EpiW e2, AdamPair ad, PS ps) {
+wgrad_pair_gather_kernel(PVAE_GA2_PARAMS, int na, EpiW e1, EpiW e2, AdamPair ad, PS ps, TouchRuns touch) {
     __shared__ __attribute__((aligned(16))) float lds[kPairLdsFloats];
     const GemmArgs g1 = PVAE_GA2_A, g2 = PVAE_GA2_B;
     const int n1 = ga_grid(g1), n12 = n1 + ga_grid(g2);
@@ -2252,7 +2283,8 @@ wgrad_pair_gather_kernel(PVAE_GA2_PARAMS, int na, EpiW e1, EpiW e2, AdamPair ad,
     else if (b < n12) wgrad_body<EpiW>(lds, b - n1, g2, e2);
     else if (b < n12 + nb1) bias_grad_body(lds, b - n12, g1, e1);
     else if (b < n12 + nb1 + nb2) bias_grad_body(lds, b - n12 - nb1, g2, e2);
-    else adam_pair_body(ad, b - n12 - nb1 - nb2);
+    else if (b < n12 + nb1 + nb2 + na) adam_pair_body(ad, b - n12 - nb1 - nb2);
+    else touch_body(touch, b - n12 - nb1 - nb2 - na);
 }
 template <class EpiD, class EpiW, class PS>
 __global__ void __launch_bounds__(256)
@@ -2413,14 +2445,14 @@ struct EpiMse {
     float* partial;
     int l1;                   // 0: nn.MSELoss (sum d^2, grad 2d/n), 1: nn.L1Loss (sum |d|, grad sign(d)/n)
     float sq = 0.f;
-    const int32_t* trow = nullptr;   // not null: the target of batch row q is row trow[q] of `target` (s_{t+1} read from
-                                     // `states` where it lies, 4-byte aligned; columns >= D are never used)
+    int tind = 0;                    // 1: the target of batch row q is row trm.at(q) of `target` (s_{t+1} read from `states`
+    RowMap trm{};                    // where it lies, 4-byte aligned; columns >= D are never used)
     struct Pre { v4f b, t; };
     __device__ inline Pre preload(int q, int p) const {
         Pre r;
         r.b = bias ? *reinterpret_cast<const v4f*>(bias + p) : v4f{0.f, 0.f, 0.f, 0.f};
-        const size_t tq = trow ? (size_t)(q < rows ? trow[q] : trow[0]) : (size_t)q;
-        r.t = *reinterpret_cast<const v4f*>(target + tq * ldt + (trow && p >= D ? 0 : p));
+        const size_t tq = tind ? (size_t)trm.at(q < rows ? q : 0) : (size_t)q;
+        r.t = *reinterpret_cast<const v4f*>(target + tq * ldt + (tind && p >= D ? 0 : p));
         return r;
     }
     __device__ inline void operator()(int q, int p, v4f v, const Pre& pre) {
@@ -2487,7 +2519,8 @@ struct EpiActionSeed {
     int l1;
     float* partial;
     float sq = 0.f;
-    const int32_t* trow = nullptr;    // not null: the demonstrated action of batch row q is row trow[q] of `target` (`actions`)
+    int tind = 0;                     // 1: the demonstrated action of batch row q is row trm.at(q) of `target` (`actions`)
+    RowMap trm{};
     struct Pre {};
     __device__ inline Pre preload(int, int) const { return Pre(); }
     __device__ inline void operator()(int q, int p, v4f v, const Pre&) {
@@ -2498,7 +2531,7 @@ struct EpiActionSeed {
             if (c < 0 || c >= n) continue;
             float g = 0.f;
             if (q < rows) {
-                const float d = pred[(size_t)q * ldp + c] - target[(size_t)(trow ? trow[q] : q) * ldt + c];
+                const float d = pred[(size_t)q * ldp + c] - target[(size_t)(tind ? trm.at(q) : q) * ldt + c];
                 sq += l1 ? fabsf(d) : d * d;
                 g = grad_scale * (l1 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : d) + v[e];
             }
@@ -2850,13 +2883,16 @@ inline hipError_t gemm_wgrad_pair(const float* dZ1, int ldz1, const float* X1, i
 // the same with problem 1's X gathered (XSrc) -- a stack's first layer; nothing to stage then
 template <class EpiW>
 inline hipError_t gemm_wgrad_pair_gather(const float* dZ1, int ldz1, const XSrc& xs, int N1, int Kin1, const EpiW& e1, int M,
-                                         hipStream_t st, const AdamPair* ad = nullptr) {
+                                         hipStream_t st, const AdamPair* ad = nullptr, const TouchRuns* touch = nullptr) {
     const WgradPlan w1 = plan_wgrad(dZ1, ldz1, nullptr, 0, N1, Kin1, M);
     const WgradPlan w2 = plan_wgrad(nullptr, 0, nullptr, 0, 0, Kin1, M);
     if (!ga_packable(w1.ga) || !ga_packable(w2.ga) || ga_grid(w1.ga) != w1.grid || ga_grid(w2.ga) != w2.grid) return hipErrorInvalidValue;
     const PGather ps{xs};
-    PVAE_LAUNCH((wgrad_pair_gather_kernel<EpiW, PGather>), dim3(w1.grid + w2.grid + w1.nbias + w2.nbias + adam_blocks(ad)),
-                dim3(256), st, PVAE_GA2_PASS(w1.ga, w2.ga), adam_blocks(ad), e1, e1, ad ? *ad : AdamPair(), ps);
+    TouchRuns tr;
+    memset(&tr, 0, sizeof(tr));
+    if (touch) tr = *touch;
+    PVAE_LAUNCH((wgrad_pair_gather_kernel<EpiW, PGather>), dim3(w1.grid + w2.grid + w1.nbias + w2.nbias + adam_blocks(ad) + tr.blocks),
+                dim3(256), st, PVAE_GA2_PASS(w1.ga, w2.ga), adam_blocks(ad), e1, e1, ad ? *ad : AdamPair(), ps, tr);
     return hipGetLastError();
 }
 // input gradient (16x16 / 32x32 tiles, caller's epilogue) || weight gradient on the gathered X

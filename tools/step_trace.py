@@ -1,7 +1,7 @@
 """Print the kernel sequence of ONE steady-state optimizer step from a rocprofv3 kernel trace
 (<dir>/*_kernel_trace.csv): name, grid (workgroups), duration, gap to the previous kernel."""
 import csv, glob, sys, re
-f = glob.glob(sys.argv[1] + "/*kernel_trace.csv")[0]
+f = (glob.glob(sys.argv[1] + "/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
@@ -9,7 +9,7 @@ def short(n):
     n = re.sub(r"\(.*", "", n)
     return n.replace("void ", "")[:70]
 # a step starts at the kernel that follows the last launch of the previous step (wgrad_pair_kernel)
-idx = [i for i, r in enumerate(rows) if "wgrad_pair_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "wgrad_pair_kernel" in r["Kernel_Name"] or "wgrad_pair_gather_kernel" in r["Kernel_Name"]]
 # of the steady-state steps (second half of the trace) the one with the shortest wall time: under the tracer the host
 # sometimes falls behind the device for a few launches, which shows as gaps that an un-traced run does not have
 def wall(k):
