@@ -188,6 +188,15 @@ int pvae_bind_dataset_next(pvae_ctx* ctx, const float* next_states);
  * the faster one: its gather rides in the previous step's last launch); pvae_direct_active tells
  * whether a step with these arguments would take the direct path (1 / 0). */
 int pvae_set_direct(pvae_ctx* ctx, int on);
+/* Switches of schedule and tile geometry.  The library reads NO environment variable: what rounds 1-4 switched through
+ * PVAE_* variables is set here (the Python host, physicsvae_amd/engine.py, still maps those variables onto these calls for
+ * the tests and the A/B scripts).  Defaults are the production values.
+ *   ctx == NULL, process-wide kernel geometry:  "ws64" "ws6464" "ws6464_rows" "pair64" "dgrad16" (0 / 1), "wgrad32" (0 / 1 / 2),
+ *       "krot" "rowxcd" (0 / 1, experiments, default 0), "look_pair" "rollout_fused" (0 / 1)
+ *   ctx, that context's schedule:  "pair" "defer_adam" "same_layer" "fold_sampler" (0 / 1), "direct" (= pvae_set_direct),
+ *       "p2p_timeout_ms" (> 0), "p2p_selftest_flags_only" (0 / 1), "server_mailbox" (0 auto, 1 pinned host memory, 2 device)
+ * Every variant gives the same bits as the default (held by tests/test_gpu_shapes.py, test_gpu_fuzz.py).  -1: unknown name. */
+int pvae_set_option(pvae_ctx* ctx, const char* name, int64_t value);
 int pvae_direct_active(pvae_ctx* ctx, int phase, int32_t rows, const pvae_step_params* sp, int fused);
 
 /* ---- hot path ------------------------------------------------------------------------ */

@@ -80,6 +80,7 @@ _SIGS = {
     "pvae_bind_dataset_next": (C.c_int, [_P, _P]),
     "pvae_invalidate_staging": (C.c_int, [_P]),
     "pvae_set_direct": (C.c_int, [_P, C.c_int]),
+    "pvae_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "pvae_direct_active": (C.c_int, [_P, C.c_int, C.c_int32, _P, C.c_int]),
     "pvae_gather": (C.c_int, [_P, C.c_int64, C.c_int32, _P]),
     "pvae_set_batch": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
@@ -155,8 +156,41 @@ def load():
         fn.argtypes = args
     if lib.pvae_abi_version() != ABI_VERSION:
         raise RuntimeError("libpvae ABI version mismatch")
+    # The library itself reads no environment variable (include/pvae.h pvae_set_option).  The PVAE_* switches of the tests
+    # and the A/B scripts under tools/ are mapped onto that call here, once per process: kernel-geometry switches.
+    for env, (key, conv) in PROCESS_OPTIONS.items():
+        if env in os.environ:
+            rc = lib.pvae_set_option(None, key.encode(), conv(os.environ[env]))
+            if rc < 0:
+                raise RuntimeError("pvae_set_option(%s) failed: %s" % (key, lib.pvae_last_error().decode()))
     _lib = lib
     return lib
+
+
+def _flag(v):
+    return 0 if v[:1] == "0" else 1
+
+
+# environment variable -> (option name, value conversion); see include/pvae.h pvae_set_option
+PROCESS_OPTIONS = {
+    "PVAE_KROT": ("krot", _flag), "PVAE_ROWXCD": ("rowxcd", _flag), "PVAE_WS64": ("ws64", _flag),
+    "PVAE_WS6464": ("ws6464", _flag), "PVAE_WS6464_ROWS": ("ws6464_rows", _flag), "PVAE_PAIR64": ("pair64", _flag),
+    "PVAE_DGRAD16": ("dgrad16", _flag), "PVAE_WGRAD32": ("wgrad32", int), "PVAE_LOOK_PAIR": ("look_pair", _flag),
+    "PVAE_ROLLOUT_FUSED": ("rollout_fused", _flag),
+}
+CONTEXT_OPTIONS = {
+    "PVAE_PAIR": ("pair", _flag), "PVAE_DEFER_ADAM": ("defer_adam", _flag), "PVAE_SAME_LAYER": ("same_layer", _flag),
+    "PVAE_FOLD_SAMPLER": ("fold_sampler", _flag), "PVAE_DIRECT": ("direct", _flag),
+    "PVAE_P2P_TIMEOUT_MS": ("p2p_timeout_ms", int), "PVAE_P2P_SELFTEST_FLAGS_ONLY": ("p2p_selftest_flags_only", _flag),
+    "PVAE_SERVER_MAILBOX": ("server_mailbox", lambda v: {"h": 1, "d": 2}.get(v[:1], 0)),
+}
+
+
+def apply_context_options(lib, ctx):
+    """The per-context switches of the environment, applied to a freshly created context."""
+    for env, (key, conv) in CONTEXT_OPTIONS.items():
+        if env in os.environ:
+            check(lib.pvae_set_option(ctx, key.encode(), conv(os.environ[env])), "pvae_set_option(%s)" % key)
 
 
 def check(rc, what=""):

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <functional>
 #include <new>
+#include <string>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -200,6 +201,8 @@ struct pvae_ctx {
     AdamSeg held_adam;             // a big one that a narrow launch passed on to the next wide launch (take_pending)
     bool defer_adam = true;
     bool same_layer_pairs = true;  // PVAE_SAME_LAYER=0: wgrad_i rides with dgrad_{i-1} as before (A/B)
+    bool p2p_selftest_flags_only = false;   // option: the attach-time self-test skips the cached-arena part
+    int server_mailbox = 0;                 // option: where the rollout server's request block lives (0 auto, 1 host, 2 device)
     bool fold_sampler = true;      // the sampler runs as the prologue of the decoder's first-layer launch (PVAE_FOLD_SAMPLER=0: its own launch)
                                    // (ProSampler).  Off by default: one launch less, but the step is not shorter -- the kernel
                                    // trace shows 6.4-7.0 us for the merged launch against 4.4 + 4.6, and the un-profiled
@@ -244,12 +247,9 @@ static void server_free(pvae_ctx* c);
 
 // Minibatch staging as a launch of its own: one block per (padded) batch row and time step
 // (blockIdx.y = t < L); the work is stage_row (pvae_gemm.h).
-// (four rows per workgroup, one wave each.  PVAE_GATHER=2, what runs: the row's sources land in LDS by LDS-DMA and the
-//  panels are written with whole 16-byte stores, stage_row_lds; rows too wide for the wave's LDS, and PVAE_GATHER=1:
-//  stage_row_wave, branch-free dword-granular buffer accesses; PVAE_GATHER=0: round 3's stage_row_vec -- A/B builds)
-#ifndef PVAE_GATHER
-#define PVAE_GATHER 2
-#endif
+// (four rows per workgroup, one wave each: the row's sources land in LDS by LDS-DMA and the panels are written with whole
+//  16-byte stores, stage_row_lds; rows too wide for the wave's LDS: stage_row_wave, branch-free dword-granular buffer
+//  accesses.  Round 3's scalar-load form measured 14.2 / 30.3 us per 8192 windows against 14.0 / 20.0: docs/experiments.md)
 // per-wave LDS of the gather: the smallest power of two that holds a row's sources + one DMA group of slack (2 KB at the
 // configs[2] dims, 4 KB at configs[4]'s: all eight workgroups a CU can hold are resident at once); 0: rows too wide
 static inline int stage_lds_floats(int Db, int Da) {
@@ -264,14 +264,8 @@ __global__ void __launch_bounds__(256) stage_batch_kernel(StageArgs a, int lds_f
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                      // (provably wave-uniform: the row's
     const int r = blockIdx.x * 4 + w;                                                    //  descriptors / LDS base live in SGPRs)
     if (r >= a.rows_pad) return;
-#if PVAE_GATHER == 0
-    stage_row_vec(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63, 64);
-#elif PVAE_GATHER == 1
-    stage_row_wave(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63);
-#else
     if (lds_floats > 0) stage_row_lds(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63, stage_lds + w * lds_floats, lds_floats - 1);
     else stage_row_wave(a, r, blockIdx.y, a.rows_pad, threadIdx.x & 63);
-#endif
 }
 
 // s1 of step t+1 = world-model prediction of step t (tpv:421): copy the first Db columns of the
@@ -1795,15 +1789,41 @@ int pvae_create(const pvae_config* cfg, pvae_ctx** out) {
     c->L = L;
     c->W = make_workspace(L);
     memset(&c->next_stage, 0, sizeof(c->next_stage));
-    const char* pv = getenv("PVAE_PAIR");
-    c->pair_launch = !(pv && pv[0] == '0');
-    const char* da = getenv("PVAE_DEFER_ADAM");
-    c->defer_adam = !(da && da[0] == '0');
-    const char* sl = getenv("PVAE_SAME_LAYER");
-    c->same_layer_pairs = !(sl && sl[0] == '0');
-    const char* fs = getenv("PVAE_FOLD_SAMPLER");
-    c->fold_sampler = !(fs && fs[0] == '0');
     *out = c;
+    return 0;
+}
+
+// Switches of schedule and tile geometry (what used to be PVAE_* environment variables read inside the library): explicit,
+// through the ABI.  ctx == NULL: process-wide kernel-geometry switches; else that context's schedule.  The production
+// values are the defaults; the parity tests flip them to hold every variant to the same bits.
+static bool g_look_pair = true, g_rollout_fused = true;
+int pvae_set_option(pvae_ctx* c, const char* name, int64_t value) {
+    if (!name) return fail(-1, "null option name");
+    const std::string k(name);
+    const int v = (int)value;
+    if (!c) {
+        if (k == "krot") g_krot = v;
+        else if (k == "rowxcd") g_rowxcd = v;
+        else if (k == "ws64") g_ws64 = v;
+        else if (k == "ws6464") g_ws6464 = v;
+        else if (k == "ws6464_rows") g_ws6464_rows = v;
+        else if (k == "pair64") g_pair64 = v;
+        else if (k == "dgrad16") g_dgrad16 = v;
+        else if (k == "wgrad32") g_wgrad32 = v;
+        else if (k == "look_pair") g_look_pair = v != 0;
+        else if (k == "rollout_fused") g_rollout_fused = v != 0;
+        else return fail(-1, "unknown process-wide option '%s'", name);
+        return 0;
+    }
+    if (k == "pair") c->pair_launch = v != 0;
+    else if (k == "defer_adam") c->defer_adam = v != 0;
+    else if (k == "same_layer") c->same_layer_pairs = v != 0;
+    else if (k == "fold_sampler") c->fold_sampler = v != 0;
+    else if (k == "direct") return pvae_set_direct(c, v);
+    else if (k == "p2p_timeout_ms") { if (value > 0) c->p2p.timeout_ticks = (long long)value * 100000ll; }
+    else if (k == "p2p_selftest_flags_only") c->p2p_selftest_flags_only = v != 0;
+    else if (k == "server_mailbox") c->server_mailbox = v;             // 0 auto (device memory with a large BAR), 1 host, 2 device
+    else return fail(-1, "unknown context option '%s'", name);
     return 0;
 }
 
@@ -1932,7 +1952,7 @@ static int stage(pvae_ctx* c, long long first_window, const float* x, const floa
     if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
     c->dx.on = false;
     const StageArgs a = stage_args(c, first_window, x, y, rows, from_set, steps, false);
-    const int lf = PVAE_GATHER == 2 ? stage_lds_floats(a.Db, a.Da) : 0;
+    const int lf = stage_lds_floats(a.Db, a.Da);
     hipLaunchKernelGGL(stage_batch_kernel, dim3((a.rows_pad + 3) / 4, steps), dim3(256), (size_t)4 * lf * sizeof(float), st, a, lf);
     HIP_TRY(hipGetLastError());
     c->staged_rows = rows;
@@ -2497,7 +2517,7 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
     // input gradient of step 0 is launched, dz[i] is final for every step: its weight gradient (over all steps) can
     // share that launch -- the same-layer pairing of the lookahead-1 schedule (gradient stored, Adam deferred to
     // workgroups of the next launch), instead of 3 weight-gradient launches per stack at the end (PVAE_LOOK_PAIR=0).
-    static const bool look_pair_env = [] { const char* e = getenv("PVAE_LOOK_PAIR"); return !(e && e[0] == '0'); }();
+    const bool look_pair_env = g_look_pair;
     const bool can_defer = fused && c->defer_adam && c->grads != nullptr;
     const bool look_pair = backward && look_pair_env && c->pair_launch && c->same_layer_pairs && (!fused || can_defer);
     bool paired_done[PVAE_NUM_NETS] = {false, false, false, false};
@@ -2808,8 +2828,6 @@ int pvae_comm_init(pvae_ctx* c, int rank, int world, const void* id128) {
     RCCL_TRY(g_rccl.CommInitRank(&comm, world, id, rank));
     c->comm = comm; c->comm_rank = rank; c->comm_world = world;
     if ((rc = ensure_comm_stream(c))) return rc;
-    if (const char* e = getenv("PVAE_DP_BUCKET_MB")) c->bucket_bytes = (int64_t)(atof(e) * (1 << 20));
-    if (const char* e = getenv("PVAE_DP_SHARDED")) c->exchange_mode = e[0] == '1' ? PVAE_EXCHANGE_SHARDED : PVAE_EXCHANGE_ALLREDUCE;
     return 0;
 }
 
@@ -2928,14 +2946,9 @@ int pvae_p2p_open(pvae_ctx* c, int rank, int world, const void* blobs) {
         P.peer_staging[q] = (float*)((char*)base[3] + b.off[3]);
     }
     P.rank = rank; P.world = world; P.epoch = 0; P.open = true;
-    if (const char* e = getenv("PVAE_P2P_TIMEOUT_MS")) {
-        const long long ms = atoll(e);
-        if (ms > 0) P.timeout_ticks = ms * 100000ll;
-    }
     c->comm_rank = rank; c->comm_world = world;
     int rc = ensure_comm_stream(c);
     if (rc) return rc;
-    if (const char* e = getenv("PVAE_DP_BUCKET_MB")) c->bucket_bytes = (int64_t)(atof(e) * (1 << 20));
     return 0;
 }
 
@@ -2974,7 +2987,7 @@ int pvae_p2p_selftest(pvae_ctx* c, void* stream) {
     hipLaunchKernelGGL(p2p_selftest_kernel, dim3(1), dim3(64), 0, st, a, P.world, token);
     HIP_TRY(hipGetLastError());
     // (2) the cached arenas, through the exchange's own access paths (see p2p_self_prime_kernel)
-    const bool arenas = P.world > 1 && c->L.arena_floats >= kSelfFloats && getenv("PVAE_P2P_SELFTEST_FLAGS_ONLY") == nullptr;
+    const bool arenas = P.world > 1 && c->L.arena_floats >= kSelfFloats && !c->p2p_selftest_flags_only;
     if (arenas) {
         if (!P.self_buf) HIP_TRY(hipMalloc((void**)&P.self_buf, (2 * kSelfFloats + kSelfGrid) * sizeof(float)));
         SelfArgs s;
@@ -3496,11 +3509,8 @@ int pvae_read_tensor(pvae_ctx* c, int what, float* dst, int32_t rows, void* stre
 
 // pvae_infer / pvae_infer_logits: the action lands in a_hat[r * ld_a + 0 .. Da) and, when `log_std` is given, the
 // decoder's log-std vector behind it (AppendLogStd rmt:160-206: logits = [a_hat | log_std]).
-// PVAE_ROLLOUT_FUSED=0 (read once per process): rollout calls of <= 4 rows go through the staged path (A/B)
-static bool rollout_fused() {
-    static const bool on = [] { const char* e = getenv("PVAE_ROLLOUT_FUSED"); return !(e && e[0] == '0'); }();
-    return on;
-}
+// option "rollout_fused" = 0: rollout calls of <= 4 rows go through the staged path (A/B)
+static bool rollout_fused() { return g_rollout_fused; }
 static int infer_impl(pvae_ctx* c, const float* obs, int32_t rows, const float* eps, int noise, uint64_t rng_seed,
                       uint64_t rng_offset, float* a_hat, int ld_a, const float* log_std, float* s2_hat, float* z_out,
                       void* stream) {
@@ -4137,7 +4147,6 @@ int pvae_rollout_server_start(pvae_ctx* c, double idle_timeout_ms, double lifeti
     RolloutServer& S = *c->server;
     if (S.launched && S.mb && S.mb->state == 1) return 0;                 // already serving
     if (scope < 0) scope = S.scope;                                       // (a relaunch keeps what the caller chose)
-    if (const char* e = getenv("PVAE_SERVER_SCOPE")) scope = e[0] == 'x' ? 1 : e[0] == 'c' ? 2 : scope;
     if (scope < 0 || scope > 2) return fail(-1, "scope %d: 0 auto, 1 one XCD, 2 the whole chip", scope);
     S.scope = scope;
     if ((rc = server_plan(c, S, scope))) return rc;
@@ -4147,13 +4156,12 @@ int pvae_rollout_server_start(pvae_ctx* c, double idle_timeout_ms, double lifeti
         HIP_TRY(hipHostGetDevicePointer((void**)&S.mb_dev, (void*)S.mb, 0));
         // The request block: with a large BAR the host reaches device memory through the pointer itself (tools/bar_probe.py),
         // so the block lives in UNCACHED device memory -- the host pushes observation + request word, the kernel polls and
-        // reads local memory.  Otherwise (or PVAE_SERVER_MAILBOX=host) pinned host memory that the kernel pulls from.
+        // reads local memory.  Otherwise (or option "server_mailbox" = 1) pinned host memory that the kernel pulls from.
         int dev = 0, large_bar = 0;
         HIP_TRY(hipGetDevice(&dev));
         (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev);
-        const char* mbx = getenv("PVAE_SERVER_MAILBOX");
-        S.req_on_device = large_bar != 0 && !(mbx && mbx[0] == 'h');
-        if (mbx && mbx[0] == 'd') S.req_on_device = true;
+        S.req_on_device = large_bar != 0 && c->server_mailbox != 1;
+        if (c->server_mailbox == 2) S.req_on_device = true;
         if (S.req_on_device) {
             HIP_TRY(hipExtMallocWithFlags((void**)&S.req_dev, sizeof(SrvRequest), hipDeviceMallocUncached));
             HIP_TRY(hipMemset(S.req_dev, 0, sizeof(SrvRequest)));

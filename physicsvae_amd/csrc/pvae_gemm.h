@@ -68,24 +68,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // keeping the lines dirty in the writer's L2 buys nothing: they are written back when the kernel ends,
 // and the next launch waits for that (MI355X_MICROARCH.md, `boundary` row: + dirty bytes / 6 TB/s, i.e.
 // ~2.8 us behind the 17 MB a fused backward launch leaves behind).  `sc1` stores are written through
-// while the kernel is still computing.  PVAE_STORE_SC1=0 builds the plain stores (A/B).
-#ifndef PVAE_STORE_SC1
-#define PVAE_STORE_SC1 1
-#endif
+// while the kernel is still computing.  (Measured alternatives, docs/experiments.md round 3: `sc0 sc1` the same,
+// `nt` / `sc1 nt` 13 % slower -- the consumer launch then finds nothing in the Infinity Cache; plain stores +1 %.)
 __device__ inline void store_stream(float* p, const v4f& v) {
-#if PVAE_STORE_SC1 == 1
     // (s_nop 1: the store reads its four data registers over the following states and hipcc pads nothing
     //  inside an asm statement -- cdna_hip_programming.md 5.7)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#elif PVAE_STORE_SC1 == 2          // A/B variants of the cache-policy bits (profiles/r03_ab_store_policy.txt)
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#elif PVAE_STORE_SC1 == 3
-    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#elif PVAE_STORE_SC1 == 4
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#else
-    *reinterpret_cast<v4f*>(p) = v;
-#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -102,7 +90,7 @@ __device__ inline void store_stream(float* p, const v4f& v) {
 //   * the 4 waves of a workgroup split K instead of the tile (forward / dgrad): every wave owns
 //     the whole 32x32 output as 2x2 MFMA tiles, so each fragment feeds two MFMAs; partial tiles
 //     are summed through LDS in a fixed order at the end.
-// Tiles travel global -> VGPR (plain global_load_dwordx4, D register sets per lane, see PVAE_REG_DEPTH_*) ->
+// Tiles travel global -> VGPR (plain global_load_dwordx4, D register sets per lane, see kRegDepth*) ->
 // ds_write_b128 into a 2-slot LDS image.  The image is lane-linear (slot j = 16-byte chunk j of
 // the tile) with the chunk order XOR-permuted on the way in and, identically, on the fragment
 // read (involutions), which removes bank conflicts without padding:
@@ -193,63 +181,6 @@ __device__ inline void stage_row(const StageArgs& a, int r, int t, int rows_pad)
         }
         if (c < a.ld_s2) a.s2[prow * a.ld_s2 + c] = v2;
         if (c < a.ld_a) a.act_t[prow * a.ld_a + c] = va;
-    }
-}
-
-// The same row with 16-byte panel stores: `nl` lanes (lane = 0 .. nl-1) cover the row four columns at a time.  The
-// panels are 64-float aligned with 64-float-multiple widths, so every store is a whole aligned float4; the sources
-// (rows of `states` / `actions`: dim_body / dim_action floats, not 16-byte multiples) are read one float per
-// element.  Used by the stand-alone gather launch, where several rows share a workgroup (stage_batch_kernel):
-// per window it moves ~7 KB in ~30 stores per lane-group instead of ~110.
-__device__ inline void stage_row_vec(const StageArgs& a, int r, int t, int rows_pad, int lane, int nl) {
-    const int Db = a.Db, Da = a.Da;
-    const size_t prow = (size_t)t * rows_pad + r;
-    const bool valid = r < a.rows;
-    const bool first = t == 0;
-    const float* p1 = nullptr;
-    const float* p2 = nullptr;
-    const float* pa = nullptr;
-    if (valid) {
-        if (a.window_row) {
-            const long long s = (long long)a.window_row[a.first_window + r] + t;
-            p1 = a.states + s * Db;
-            p2 = a.next_states ? a.next_states + s * Db : p1 + Db;
-            pa = a.actions + s * Da;
-        } else {
-            p1 = a.x + ((size_t)r * a.L + t) * 2 * Db;
-            p2 = p1 + Db;
-            pa = a.y ? a.y + ((size_t)r * a.L + t) * Da : nullptr;
-        }
-    }
-    int ld_max = a.ld_te;
-    if (a.ld_md > ld_max) ld_max = a.ld_md;
-    if (a.ld_wm > ld_max) ld_max = a.ld_wm;
-    if (a.ld_s2 > ld_max) ld_max = a.ld_s2;
-    for (int c0 = lane * 4; c0 < ld_max; c0 += nl * 4) {
-        v4f v1, v2, va, ute, uwm;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = c0 + e;
-            v1[e] = (valid && first && c < Db) ? p1[c] : 0.f;
-            v2[e] = (valid && c < Db) ? p2[c] : 0.f;
-            va[e] = (valid && pa && c < Da) ? pa[c] : 0.f;
-            ute[e] = c < Db ? v1[e] : ((valid && c < 2 * Db) ? p2[c - Db] : 0.f);
-            uwm[e] = c < Db ? v1[e] : ((valid && pa && c < Db + Da) ? pa[c - Db] : 0.f);
-        }
-        if (a.pr_in && c0 < a.ld_pr) *reinterpret_cast<v4f*>(a.pr_in + prow * a.ld_pr + c0) = v1;
-        if (c0 < a.ld_te) *reinterpret_cast<v4f*>(a.te_in + prow * a.ld_te + c0) = ute;
-        if (c0 < a.ld_md) *reinterpret_cast<v4f*>(a.md_in + prow * a.ld_md + c0) = v1;       // z columns filled by the sampler
-        if (c0 < a.ld_wm) {
-            *reinterpret_cast<v4f*>(a.wm_in + prow * a.ld_wm + c0) = uwm;
-            if (a.wm_pred) {
-                v4f w;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) w[e] = c0 + e < Db ? v1[e] : 0.f;
-                *reinterpret_cast<v4f*>(a.wm_pred + prow * a.ld_wm + c0) = w;
-            }
-        }
-        if (c0 < a.ld_s2) *reinterpret_cast<v4f*>(a.s2 + prow * a.ld_s2 + c0) = v2;
-        if (c0 < a.ld_a) *reinterpret_cast<v4f*>(a.act_t + prow * a.ld_a + c0) = va;
     }
 }
 
@@ -410,23 +341,14 @@ __device__ inline void stage_row_lds(const StageArgs& a, int r, int t, int rows_
 // host-side default for GemmArgs::krot: off (measured: no gain); PVAE_KROT=1 enables
 // register sets in flight per lane in the register-staged kernels (A/B on the whole step: 2 / 2 /
 // 4 beats 4 / 4 / 4 by 1.8 %, 3 and 8 lose; compile-time switches for re-measuring)
-#ifndef PVAE_REG_DEPTH_D
-#define PVAE_REG_DEPTH_D 2
-#endif
-#ifndef PVAE_REG_DEPTH_D64
-#define PVAE_REG_DEPTH_D64 1       // the 64x32 input-gradient body of the >= 512-row pairs: one set (A/B at config-5 sizes:
-#endif                             // 1 / 2 / 3 sets = 397.8 / 402.4 / 424 us per joint step, profiles/r03_ab_regdepth_c5.txt)
-#ifndef PVAE_REG_DEPTH_16
-#define PVAE_REG_DEPTH_16 4
-#endif
-#ifndef PVAE_REG_DEPTH_W
-#define PVAE_REG_DEPTH_W 2
-#endif
-static int g_krot = [] { const char* e = getenv("PVAE_KROT"); return (e && e[0] == '1') ? 1 : 0; }();
+// register sets in flight per lane in the register-staged kernels (re-measured every round: 2 / 2 / 4 at 256 rows, 1 for the
+// 64x32 input-gradient body of the >= 512-row pairs; profiles/r03_ab_regdepth_final.txt, r03_ab_regdepth_c5.txt)
+constexpr int kRegDepthD = 2, kRegDepthD64 = 1, kRegDepth16 = 4, kRegDepthW = 2;
+static int g_krot = 0;                       // pvae_set_option(NULL, "krot", 1)
 // Experiment (off by default): XCD x takes q-tile (row block) x of a 256-row layer and ALL its p-tiles, instead of
 // all q-tiles of an eighth of the p-tiles -- the operand traffic a row-block-stationary multi-layer kernel would
 // have (every XCD streams the whole weight matrix through its L2).  Same tiles, same results.
-static int g_rowxcd = [] { const char* e = getenv("PVAE_ROWXCD"); return (e && e[0] == '1') ? 1 : 0; }();
+static int g_rowxcd = 0;                     // pvae_set_option(NULL, "rowxcd", 1)
 struct GemmArgs {
     const float* Q;
     int ldq;
@@ -517,7 +439,7 @@ __device__ inline void store_partial_32x32(float* red, const v4f (&acc)[2][2], i
 
 template <bool P_ROW, class Epi, int ABL = 0>
 __device__ inline void splitk_reg_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
-    constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, D = PVAE_REG_DEPTH_D, S = 2;
+    constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, D = kRegDepthD, S = 2;
     static_assert(S * kStage >= 4 * 32 * 36, "ring must hold the split-K reduction buffer");
     const float* __restrict__ Q = ga.Q;
     const float* __restrict__ P = ga.P;
@@ -675,7 +597,7 @@ __device__ inline void splitk_reg_body(float* lds, int bid, const GemmArgs& ga, 
 constexpr int kReg64RingFloats = 2 * (64 * 64 + 64 * 32);          // 2 slots x 24 KB = 48 KB
 template <class Epi>
 __device__ inline void splitk_reg64_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
-    constexpr int BK = 64, kTileQ = 64 * 64, kTileP = 64 * 32, kStage = kTileQ + kTileP, D = PVAE_REG_DEPTH_D64;
+    constexpr int BK = 64, kTileQ = 64 * 64, kTileP = 64 * 32, kStage = kTileQ + kTileP, D = kRegDepthD64;
     constexpr int RS = 36;
     static_assert(2 * kStage >= 4 * 64 * RS, "ring must hold the split-K reduction buffer");
     const float* __restrict__ Q = ga.Q;
@@ -811,18 +733,12 @@ gemm_splitk_reg_kernel(PVAE_GA_PARAMS(a_), Epi epi) {
 // Ring depth: 4 is the optimum on MI355X -- 3 starves, 5..8 get progressively slower (8: 8.5 us);
 // more requests in flight per CU do not help the L2 -> CU path, they hurt it.
 // Same LDS image / swizzles / split-K layout as splitk_reg_body, results are bit-identical.
-// Workgroup barriers per k-tile in the wave-specialised 32x32 kernel.  0: one barrier per tile, 4-slot ring (rounds 1-2).
-// 2 (what runs): super-steps of TWO tiles per barrier on a 6-slot ring -- at the barrier in front of tiles (t0, t0+1)
-// the tiles t0+1, t0+2 have landed, t0+3, t0+4 are in flight and t0+5, t0+6 are requested: half the barriers, the load
-// stream stays continuous; joint step 243.7 -> 241.5 us.  1: the same on the 4-slot ring (nothing in flight across a
-// barrier): 264.9 us -- the L2 -> LDS path needs the continuous stream (profiles/r03_ab_ws_superstep.txt).
-#ifndef PVAE_WS_SUPER
-#define PVAE_WS_SUPER 2
-#endif
-#ifndef PVAE_WS_LOADERS
-#define PVAE_WS_LOADERS 4        // loader waves of the wave-specialised kernel (8: 12-wave workgroups, A/B)
-#endif
-constexpr int kWsLoaders = PVAE_WS_LOADERS, kWsThreads = 256 + 64 * kWsLoaders, kWsPer = 8 / kWsLoaders;   // DMA pairs per loader wave and tile
+// Ring of the plain 32x32 kernel: SIX slots, super-steps of TWO k-tiles per workgroup barrier -- at the barrier in front of
+// tiles (t0, t0+1) the tiles t0+1, t0+2 have landed, t0+3, t0+4 are in flight and t0+5, t0+6 are requested: half the
+// barriers, a continuous load stream (joint step 243.7 -> 241.5 us).  The same on a 4-slot ring leaves nothing in flight
+// across a barrier and loses 9 % (profiles/r03_ab_ws_superstep.txt).  The Pro variant (a patch needs its own barrier per
+// patched tile) keeps one barrier per tile on four slots.
+constexpr int kWsLoaders = 4, kWsThreads = 256 + 64 * kWsLoaders, kWsPer = 8 / kWsLoaders;   // DMA pairs per loader wave and tile
 constexpr int kWsStages = 4;
 constexpr int kWsFloats = kWsStages * 2 * 32 * 64;       // 64 KB
 
@@ -956,50 +872,11 @@ struct ProCols {
     __device__ inline void publish(const float*, int, int, int, int) const {}
 };
 
-// Experiment (PVAE_L2_TOUCH=1 at build time; off in production): every XCD's L2 has to be filled with the operand panels
-// its 32 workgroups share (X is re-fetched by each XCD: the 2.2x over-fetch of the forward launches), and a k-tile whose
-// lines are still on their way from the Infinity Cache is what the LDS-DMA stream waits for.  Here the compute waves of a
-// workgroup -- which issue no vector-memory instruction inside the loop -- TOUCH, right after their share of k-tile 0, the
-// workgroup's share of everything its XCD will stream (one 4-byte load per 128-byte line, never waited for inside the
-// loop): the workgroups that share a Q row block split its K range among them, likewise the ones that share a P tile.
-// The loads land in one dead register that stays reserved until l2_touch_drain.
-#ifndef PVAE_L2_TOUCH
-#define PVAE_L2_TOUCH 0
-#endif
-__device__ inline void l2_touch(float& sink, const float* p) {
-    asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
-}
-__device__ inline void l2_touch_drain(float& sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory"); }
-template <bool P_ROW>
-__device__ inline void l2_touch_share(float& sink, const float* Q, int ldq, int q0, int rows_q, const float* P, int ldp, int p0,
-                                      int K, int xi, int nx, int wi, int nw, int wave, int lane) {
-    if (nx > 0 && K % (nx * 32) == 0) {                       // Q rows [q0, +rows_q), k-slice xi of nx
-        const int kx = K / nx, lines = kx / 32, total = rows_q * lines;
-        for (int i = wave * 64 + lane; i < total; i += 256) {
-            const int row = i / lines, ln = i - row * lines;
-            l2_touch(sink, Q + (size_t)(q0 + row) * ldq + xi * kx + ln * 32);
-        }
-    }
-    if (nw > 0 && K % (nw * 32) == 0) {                       // the P tile's k-slice wi of nw
-        const int kw = K / nw;
-        if (P_ROW) {
-            const int lines = kw / 32, total = 32 * lines;
-            for (int i = wave * 64 + lane; i < total; i += 256) {
-                const int row = i / lines, ln = i - row * lines;
-                l2_touch(sink, P + (size_t)(p0 + row) * ldp + wi * kw + ln * 32);
-            }
-        } else {
-            for (int i = wave * 64 + lane; i < kw; i += 256) l2_touch(sink, P + (size_t)(wi * kw + i) * ldp + p0);
-        }
-    }
-}
-
 template <bool P_ROW, class Epi, class Pro = NoPro, class QS = QDense>
 __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, Epi& epi, const Pro& pro = Pro(),
                                       float* scratch = nullptr, const QS& qs = QS()) {
-    // (PVAE_WS_SUPER=2: six slots, two k-tiles per barrier with the two after next already in flight -- plain kernel only)
-    constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, S = (PVAE_WS_SUPER == 2 && !Pro::kActive) ? 6 : kWsStages;
-    static_assert(S == 4 || PVAE_WS_SUPER == 2, "wait_dma_tile is written for a 4-slot ring");
+    // (plain kernel: six slots, two k-tiles per barrier; with a Pro patch: four slots, one barrier per tile)
+    constexpr int BK = 64, kTile = 32 * 64, kStage = 2 * kTile, S = Pro::kActive ? kWsStages : 6;
     const float* __restrict__ Q = ga.Q;
     const float* __restrict__ P = ga.P;
     const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
@@ -1025,7 +902,6 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
 
     const size_t kstep_p = P_ROW ? (size_t)BK : (size_t)BK * ldp;
     const int rot = k_rotation(ga, loc, tile_q, nk);
-#ifndef PVAE_WS_SLOW0
     // k-tile 0 is fetched by ALL eight waves (one eighth of each operand image per wave, two DMA
     // instructions each): it is in flight ~0.1 us after the workgroup starts instead of queueing
     // behind the loaders' three-tile prologue (each global_load_lds holds its wave ~150 cycles, so
@@ -1048,7 +924,6 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
         lds_dma16(qs.tile(s0q, rot), lds + wave * 256);
         lds_dma16(s0p + (size_t)rot * kstep_p, lds + kTile + wave * 256);
     }
-#endif
     if (wave >= 4) {
         // ---------------- loader waves ----------------  (s_setprio 1 here, or on the compute waves: +-0)
         const int u0 = wave - 4;
@@ -1081,15 +956,6 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
                 lds_dma16(sp[u] + (size_t)kt * kstep_p, slot + kTile + (u0 + kWsLoaders * u) * 256);
             }
         };
-#ifdef PVAE_WS_SLOW0
-#pragma unroll
-        for (int t = 0; t < S - 1; ++t)
-            if (t < nk) issue(t);
-        PVAE_MARK(256, 4);                                       // prologue loads issued
-        wait_dma_tile(nk - 1 < S - 2 ? nk - 1 : S - 2);          // tile 0 landed
-        PVAE_MARK(256, 5);
-        __builtin_amdgcn_s_barrier();
-#else
         if (1 < nk) issue(1);                                    // rides on tile 0's flight time
         PVAE_MARK(256, 4);
         if (1 < nk) wait_vmcnt<2 * kWsPer>(); else wait_vmcnt<0>();   // this wave's share of tile 0 landed
@@ -1099,41 +965,27 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
         if constexpr (Pro::kActive) {
             if (pro.needs(0)) __builtin_amdgcn_s_barrier();        // (the compute waves patch tile 0 in between)
         }
-#if PVAE_WS_SUPER
         if constexpr (!Pro::kActive) {
-            // super-steps of TWO k-tiles per workgroup barrier (half the barriers of the loop below).  At the barrier
-            // in front of tiles (t0, t0+1): t0+1 and t0+2 have landed, the fragments of t0 and everything older have
-            // been read, so the slots of t0-1 and t0 take t0+3 and t0+4 -- which have one super-step to land.
+            // super-steps of TWO k-tiles per workgroup barrier.  At the barrier in front of tiles (t0, t0+1): t0+1 and t0+2
+            // have landed, t0+3 and t0+4 are in flight; the slots of t0-1 and t0 (whose fragment reads the compute waves
+            // have retired, see there) take t0+5 and t0+6.
             if (2 < nk) issue(2);
-            if constexpr (S == 6) {
-                // six slots: t0+3 and t0+4 are already in flight when t0+1 and t0+2 are awaited (a continuous stream)
-                if (3 < nk) issue(3);
-                if (4 < nk) issue(4);
-                for (int t0 = 0; t0 < nk; t0 += 2) {
-                    const int younger = nk - 3 - t0;                   // tiles t0+3, t0+4 that exist
-                    if (younger >= 2) wait_vmcnt<4 * kWsPer>();
-                    else if (younger == 1) wait_vmcnt<2 * kWsPer>();
-                    else wait_vmcnt<0>();
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    if (t0 + 5 < nk) issue(t0 + 5);
-                    if (t0 + 6 < nk) issue(t0 + 6);
-                }
-            } else
+            if (3 < nk) issue(3);
+            if (4 < nk) issue(4);
             for (int t0 = 0; t0 < nk; t0 += 2) {
-                wait_vmcnt<0>();                                       // tiles t0+1, t0+2 (all that is in flight) landed
+                const int younger = nk - 3 - t0;                   // tiles t0+3, t0+4 that exist
+                if (younger >= 2) wait_vmcnt<4 * kWsPer>();
+                else if (younger == 1) wait_vmcnt<2 * kWsPer>();
+                else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (t0 + 3 < nk) issue(t0 + 3);
-                if (t0 + 4 < nk) issue(t0 + 4);
+                if (t0 + 5 < nk) issue(t0 + 5);
+                if (t0 + 6 < nk) issue(t0 + 6);
             }
-        } else
-#endif
-        {
+        } else {
 #pragma unroll
         for (int t = 2; t < S - 1; ++t)
             if (t < nk) issue(t);
-#endif
         for (int t = 0; t < nk; ++t) {
             // tile t+1 landed: younger tiles in flight = t+2 .. min(t+S-2, nk-1)
             int y = nk - 2 - t;
@@ -1147,9 +999,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
             }
             if (t + S - 1 < nk) issue(t + S - 1);                  // refill the slot tile t-1 vacated
         }
-#ifndef PVAE_WS_SLOW0
         }
-#endif
     } else {
         // ---------------- compute waves ----------------
         int oq[2];
@@ -1159,19 +1009,9 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
             oq[a] = row * 64 + (((4 * wave + lh) ^ (row & 15)) << 2);
         }
         const int kq = 16 * wave + 4 * lh;
-#ifndef PVAE_WS_SLOW0
         wait_vmcnt<0>();                                           // this wave's share of tile 0 landed
-#endif
         epre = epi.preload(q0 + (tid >> 3), p0 + ((tid & 7) << 2));   // epilogue operands: arrive under the loop
         typename Pro::State pst = pro.prepare(q0, tid);
-#if PVAE_L2_TOUCH
-        float l2sink = 0.f;
-        if (!ga.rowxcd) {
-            int np = tiles_p - xcd * ga.p_per_xcd;
-            if (np > ga.p_per_xcd) np = ga.p_per_xcd;
-            l2_touch_share<P_ROW>(l2sink, Q, ldq, q0, 32, P, ldp, p0, K, tile_p - xcd * ga.p_per_xcd, np, tile_q, tiles_q, wave, lane);
-        }
-#endif
         struct Frag { v4f q[2], p[2]; v2f c[4]; };
         auto fread = [&](const float* st, Frag& f) {
 #pragma unroll
@@ -1213,7 +1053,6 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
         }
         Frag F0, F1;
         fread(lds, F0);
-#if PVAE_WS_SUPER && !defined(PVAE_WS_SLOW0)
         if constexpr (!Pro::kActive) {
             for (int t0 = 0; t0 < nk; t0 += 2) {
                 // The fragments of tile t0 (read in the second half of the previous super-step) must have LEFT the LDS before
@@ -1238,7 +1077,6 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
                 }
             }
         } else
-#endif
         for (int t0 = 0; t0 < nk; t0 += 2) {
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
@@ -1262,9 +1100,6 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
                 }
             }
         }
-#if PVAE_L2_TOUCH
-        l2_touch_drain(l2sink);
-#endif
     }
     // split-K reduction through LDS (fixed order: compute wave 0..3), epilogue on float4s by the
     // 256 compute threads; every wave takes part in the barriers
@@ -1290,13 +1125,7 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
 // of 13).  One 64x32 workgroup per CU lands 24 KB per k-tile for the MFMA work of two 32x32 tiles (32 KB): a quarter
 // less DMA traffic per flop.  Every output element is still the sum of the same four k-quarters in the same order, so
 // results equal the 32x32 kernel's bit for bit.  Ring: 4 slots x 24 KB = 96 KB.
-#ifndef PVAE_XCD_GRID
-#define PVAE_XCD_GRID 0
-#endif
-#ifndef PVAE_WS64_STAGES
-#define PVAE_WS64_STAGES 4          // ring slots of the 64x32 kernel (24 KB each; A/B: 5, 6)
-#endif
-constexpr int kWs64Stages = PVAE_WS64_STAGES;
+constexpr int kWs64Stages = 4;      // ring slots of the 64x32 kernel (24 KB each; 5 and 6 slots measured 2-4 % slower)
 // PT = 32: the 64x32 tile above.  PT = 64 (round 4, 1024 rows and more): 64x64 outputs per workgroup, 32 KB per k-tile for
 // twice the MFMA work of the 24 KB of 64x32 -- 16 flop per DMA byte instead of 10.7; the k-loop is as long as its DMA stream
 // (docs/experiments.md), so that is what pays.  Ring 4 x 32 KB.  Same k-quarters per wave, same order: bit-identical again.
@@ -1315,15 +1144,6 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
     const int xcd = bid & 7, loc = bid >> 3;
     int tile_p = xcd * ga.p_per_xcd + loc / tiles_q;
     int tile_q = loc % tiles_q;
-#if PVAE_XCD_GRID
-    // Experiment: a 2 x 4 grid of XCDs over (row blocks, column blocks) instead of 1 x 8.  What the 8 L2s fetch from the
-    // fabric for one layer is 8 (X / a + W / b) with a b = 8: at 512 rows (X 2 MB, W 4 MB) 20 MB for 1 x 8, 16 MB for 2 x 4
-    // (at 256 rows both give 12 MB: the "2.2x over-fetch" of the forward launches is the floor of any XCD partition).
-    if (PT == 32 && tiles_q == 8 && tiles_p == 32 && ga.p_per_xcd == 4) {
-        tile_q = (xcd & 1) * 4 + (loc & 3);
-        tile_p = (xcd >> 1) * 8 + (loc >> 2);
-    }
-#endif
     if (PT == 64 && ga.rowxcd) {
         // Many row blocks (1024 rows and more): every XCD takes a RANGE OF ROW BLOCKS and walks all column blocks with it,
         // row blocks fastest -- its share of X (rq x 256 KB) stays in its L2 while the W tiles stream through once per
@@ -1414,14 +1234,6 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
         for (int h = 0; h < NB; ++h)
             epre[h] = PT == 64 ? epi.preload(q0 + 16 * h + (tid >> 4), p0 + ((tid & 15) << 2))
                                : epi.preload(q0 + 32 * h + (tid >> 3), p0 + ((tid & 7) << 2));
-#if PVAE_L2_TOUCH
-        float l2sink = 0.f;
-        if (PT == 32) {
-            int np = tiles_p - xcd * ga.p_per_xcd;
-            if (np > ga.p_per_xcd) np = ga.p_per_xcd;
-            l2_touch_share<P_ROW>(l2sink, Q, ldq, q0, 64, P, ldp, p0, K, tile_p - xcd * ga.p_per_xcd, np, tile_q, tiles_q, wave, lane);
-        }
-#endif
         struct Frag { v4f q[4], p[NB]; v2f c[4]; v4f c4[4]; };   // (P_ROW: p; P_COL: c at PT = 32, c4 at PT = 64)
         auto fread = [&](const float* st, Frag& f) {
 #pragma unroll
@@ -1468,9 +1280,6 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
                 }
             }
         }
-#if PVAE_L2_TOUCH
-        l2_touch_drain(l2sink);
-#endif
     }
     // split-K reduction through LDS (fixed order: compute wave 0..3), epilogue on float4s by the 256 compute threads
     __syncthreads();
@@ -1520,7 +1329,7 @@ template <bool P_ROW, class Epi>
 __global__ void __launch_bounds__(kWsThreads)
 gemm_splitk_ws_kernel(PVAE_GA_PARAMS(a_), Epi epi) {
     const GemmArgs ga = PVAE_GA_OF(a_);
-    __shared__ __attribute__((aligned(16))) float lds[PVAE_WS_SUPER == 2 ? 6 * 2 * 32 * 64 : kWsFloats];
+    __shared__ __attribute__((aligned(16))) float lds[6 * 2 * 32 * 64];
     splitk_ws_body<P_ROW, Epi>(lds, blockIdx.x, ga, epi);
 }
 template <class Epi, class Pro>
@@ -1536,7 +1345,7 @@ template <class Epi>
 __global__ void __launch_bounds__(kWsThreads)
 gemm_splitk_ws_gather_kernel(PVAE_GA_PARAMS(a_), Epi epi, QGather qs) {
     const GemmArgs ga = PVAE_GA_OF(a_);
-    __shared__ __attribute__((aligned(16))) float lds[PVAE_WS_SUPER == 2 ? 6 * 2 * 32 * 64 : kWsFloats];
+    __shared__ __attribute__((aligned(16))) float lds[6 * 2 * 32 * 64];
     splitk_ws_body<true, Epi, NoPro, QGather>(lds, blockIdx.x, ga, epi, NoPro(), nullptr, qs);
 }
 template <class Epi, class Pro>
@@ -1566,7 +1375,7 @@ gemm_splitk_ws64_gather_kernel(PVAE_GA_PARAMS(a_), Epi epi, QGather qs) {
 // (9.5 us), 256 of these.  Its P image is [64 k][16 p] row-major, read one dword per k-step.
 template <bool P_ROW, class Epi>
 __device__ inline void splitk_reg16_body(float* lds, int bid, const GemmArgs& ga, Epi& epi) {
-    constexpr int BK = 64, kTile = 16 * 64, kStage = 2 * kTile, D = PVAE_REG_DEPTH_16;
+    constexpr int BK = 64, kTile = 16 * 64, kStage = 2 * kTile, D = kRegDepth16;
     const float* __restrict__ Q = ga.Q;
     const float* __restrict__ P = ga.P;
     const int ldq = ga.ldq, ldp = ga.ldp, K = ga.K, tiles_q = ga.tiles_q, tiles_p = ga.tiles_p;
@@ -1740,12 +1549,9 @@ struct XLanes {
 
 // ---- wgrad: G[64 q][64 p] per workgroup, reduction over batch rows (BK = 32), both operands COL,
 // waves 2x2 with 32x32 each; the epilogue operands (Adam's p, m, v) are fetched under the loop --
-#ifndef PVAE_WGRAD_PIPE
-#define PVAE_WGRAD_PIPE 1      // 0: the plain loop (also what the ablation probes run)
-#endif
 template <class Epi, int ABL = 0, class PS = PDense>
 __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, Epi& epi, const PS& ps = PS()) {
-    constexpr int BK = 32, kTile = 32 * 64, kStage = 2 * kTile, D = PVAE_REG_DEPTH_W, S = 2;
+    constexpr int BK = 32, kTile = 32 * 64, kStage = 2 * kTile, D = kRegDepthW, S = 2;
     static_assert(S * kStage == kRegRingFloats, "LDS budget");
     const float* __restrict__ Q = ga.Q;
     const float* __restrict__ P = ga.P;
@@ -1905,7 +1711,7 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
         if (!(ABL & 8)) __syncthreads();
     };
     auto tile_step = [&](int t, int d, bool guarded) {
-        if constexpr (ABL == 0 && PVAE_WGRAD_PIPE) tile_step_piped(t, d, guarded);
+        if constexpr (ABL == 0) tile_step_piped(t, d, guarded);
         else tile_step_plain(t, d, guarded);
     };
     int t0 = 0;
@@ -1936,7 +1742,7 @@ __device__ inline void wgrad_reg_body(float* lds, int bid, const GemmArgs& ga, E
 // LDS at the end, like the input-gradient body.  Needs K % 64 == 0 (wgrad_uses_32x32).
 template <class Epi, class PS = PDense>
 __device__ inline void wgrad32_body(float* lds, int bid, const GemmArgs& ga, Epi& epi, const PS& ps = PS()) {
-    constexpr int BK = 64, kTile = 64 * 32, kStage = 2 * kTile, D = PVAE_REG_DEPTH_W, S = 2;
+    constexpr int BK = 64, kTile = 64 * 32, kStage = 2 * kTile, D = kRegDepthW, S = 2;
     static_assert(S * kStage == kRegRingFloats, "LDS budget");
     static_assert(S * kStage >= 4 * 32 * 36, "ring must hold the split-K reduction buffer");
     const float* __restrict__ Q = ga.Q;
@@ -2128,43 +1934,11 @@ struct AdamSeg {
     long long n4 = 0;          // float4 count (0: nothing pending)
     AdamScalars s{};
 };
-#ifndef PVAE_ADAM_BLOCKS
-#define PVAE_ADAM_BLOCKS 256        // workgroups per deferred-Adam segment (A/B: 128 / 256 / 512, profiles/r03_ab_adam_blocks.txt)
-#endif
-constexpr int kAdamBlocks = PVAE_ADAM_BLOCKS;
-#ifndef PVAE_ADAM_UNROLL
-#define PVAE_ADAM_UNROLL 1     // float4 elements per thread in flight (A/B: >1 issues all trips' loads up front)
-#endif
-#ifndef PVAE_ADAM_DELAY
-#define PVAE_ADAM_DELAY 0      // s_sleep argument (x64 clocks) before the first load (A/B: let the contractions' cold fetches go first)
-#endif
+constexpr int kAdamBlocks = 256;    // workgroups per deferred-Adam segment (128 / 512 measured slower: profiles/r03_ab_adam_blocks.txt)
 __device__ inline void adam_seg_body(const AdamSeg& a, int blk) {
-    long long i = blk * 256ll + threadIdx.x;
+    // (one float4 per thread in flight: two or four, and a delayed start, measured no better -- docs/experiments.md round 2)
     constexpr long long kStride = kAdamBlocks * 256ll;
-    constexpr int U = PVAE_ADAM_UNROLL;
-#if PVAE_ADAM_DELAY > 0
-    __builtin_amdgcn_s_sleep(PVAE_ADAM_DELAY);
-#endif
-    if (U > 1) {
-        for (; i + (U - 1) * kStride < a.n4; i += U * kStride) {
-            v4f pp[U], gg[U], mm[U], vv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                pp[u] = reinterpret_cast<v4f*>(a.p)[i + u * kStride];
-                gg[u] = reinterpret_cast<const v4f*>(a.g)[i + u * kStride];
-                mm[u] = reinterpret_cast<v4f*>(a.m)[i + u * kStride];
-                vv[u] = reinterpret_cast<v4f*>(a.v)[i + u * kStride];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                adam_update4(gg[u], pp[u], mm[u], vv[u], a.s);
-                store_stream(a.p + 4 * (i + u * kStride), pp[u]);
-                store_stream(a.m + 4 * (i + u * kStride), mm[u]);
-                store_stream(a.v + 4 * (i + u * kStride), vv[u]);
-            }
-        }
-    }
-    for (; i < a.n4; i += kStride) {
+    for (long long i = blk * 256ll + threadIdx.x; i < a.n4; i += kStride) {
         v4f pp = reinterpret_cast<v4f*>(a.p)[i];
         const v4f gg = reinterpret_cast<const v4f*>(a.g)[i];
         v4f mm = reinterpret_cast<v4f*>(a.m)[i];
@@ -2688,13 +2462,13 @@ inline GemmGrid make_grid(int rows_q, int cols_p, int bq, int bp) {
 }
 
 // 512 rows and more: 64x32 tiles (splitk_ws64_body) whenever they still give every CU a workgroup; PVAE_WS64=0: off (A/B)
-static int g_ws64 = [] { const char* e = getenv("PVAE_WS64"); return (e && e[0] == '0') ? 0 : 1; }();
+static int g_ws64 = 1;                       // pvae_set_option(NULL, "ws64", 0): off (tests compare the tilings bit for bit)
 inline bool uses_64x32(int M, int N) { return g_ws64 && M >= 512 && M % 64 == 0 && (M / 64) * (N / 32) >= 256; }
 // 1024 rows and more: 64x64 tiles whenever THEY still give every CU a workgroup; PVAE_WS6464=0: off (A/B)
-static int g_ws6464 = [] { const char* e = getenv("PVAE_WS6464"); return (e && e[0] == '0') ? 0 : 1; }();
+static int g_ws6464 = 1;                     // option "ws6464"
 inline bool uses_64x64(int M, int N) { return g_ws6464 && uses_64x32(M, N) && N % 64 == 0 && (M / 64) * (N / 64) >= 256; }
 // ... with the XCDs partitioning the ROW blocks (see splitk_ws64_body); PVAE_WS6464_ROWS=0: column ranges as elsewhere (A/B)
-static int g_ws6464_rows = [] { const char* e = getenv("PVAE_WS6464_ROWS"); return (e && e[0] == '0') ? 0 : 1; }();
+static int g_ws6464_rows = 1;                // option "ws6464_rows"
 inline GemmGrid make_grid_6464(int M, int N, GemmArgs& ga) {
     GemmGrid g = make_grid(M, N, 64, 64);
     ga.tiles_q = g.tiles_q; ga.tiles_p = g.tiles_p; ga.p_per_xcd = g.p_per_xcd;
@@ -2705,7 +2479,7 @@ inline GemmGrid make_grid_6464(int M, int N, GemmArgs& ga) {
     return g;
 }
 // ... and the input-gradient half of the fused backward pairs (PVAE_PAIR64=0: off, A/B)
-static int g_pair64 = [] { const char* e = getenv("PVAE_PAIR64"); return (e && e[0] == '0') ? 0 : 1; }();
+static int g_pair64 = 1;                     // option "pair64"
 inline bool pair_uses_64x32(int M, int N) { return g_pair64 && uses_64x32(M, N); }
 // narrow outputs: under 128 workgroups of 32x32 -> use 16x16 tiles (4x the workgroups)
 inline bool forward_uses_16x16(int M, int N) { return (M / 32) * (N / 32) < 128; }
@@ -2793,7 +2567,7 @@ inline hipError_t gemm_forward(const float* X, int ldx, const float* W, int ldw,
 // dgrad: dX[M][Kin] = (dZ[M][N] W[N][Kin]) .* (mask > 0)
 // Tile geometry: 32x32, or 16x16 when that leaves fewer than 128 workgroups (narrow first layers;
 // PVAE_DGRAD16=0 switches it off: A/B).
-static int g_dgrad16 = [] { const char* e = getenv("PVAE_DGRAD16"); return (e && e[0] == '0') ? 0 : 1; }();
+static int g_dgrad16 = 1;                    // option "dgrad16"
 inline bool dgrad_uses_16x16(int M, int Kin) { return g_dgrad16 && (M / 32) * (Kin / 32) < 128; }
 // workgroups whose epilogue sees a tile (= loss partials a seed epilogue writes)
 inline int dgrad_tiles(int M, int Kin) {
@@ -2841,7 +2615,7 @@ inline hipError_t gemm_dgrad(const float* dZ, int ldz, const float* W, int ldw, 
 // wgrad: G[N][Kin] = dZ[M][N]^T X[M][Kin]  (+ bias gradient, + optional loss finalisation)
 // Tile geometry per problem: 64x64, or 32x32 when that leaves at most half the CUs with a tile
 // (PVAE_WGRAD32=0 switches the small geometry off: A/B).
-static int g_wgrad32 = [] { const char* e = getenv("PVAE_WGRAD32"); return e ? atoi(e) : 1; }();   // 0: never, 2: always (A/B)
+static int g_wgrad32 = 1;                    // option "wgrad32": 0 never, 1 where it pays, 2 always
 inline bool wgrad_uses_32x32(int N, int Kin, int M) {
     return g_wgrad32 && ((N / 64) * (Kin / 64) <= 128 || g_wgrad32 == 2) && M % 64 == 0;
 }

@@ -199,8 +199,7 @@ class HipEngine:
         _lib.check(self.lib.pvae_bind_arenas(ctx, self.params.data_ptr(), self.grads.data_ptr(),
                                              self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()))
         _lib.check(self.lib.pvae_bind_workspace(ctx, self.workspace.data_ptr(), nbytes))
-        if os.environ.get("PVAE_DIRECT", "0") == "1":      # opt-in: first layers read the demonstration set where it lies
-            _lib.check(self.lib.pvae_set_direct(ctx, 1), "pvae_set_direct")   # (include/pvae.h pvae_set_direct; same bits)
+        _lib.apply_context_options(self.lib, ctx)          # (PVAE_PAIR, PVAE_DIRECT, ...: the library reads no environment)
         self._loss_scratch = torch.zeros(5, dtype=torch.float32, device=self.device)
 
     def __del__(self):
@@ -393,6 +392,17 @@ class HipEngine:
         assert len(unique_id) == 128
         _lib.check(self.lib.pvae_comm_init(self.ctx, int(rank), int(world), C.c_char_p(unique_id)), "pvae_comm_init")
         self.has_comm = True
+        self._dp_env()
+
+    def _dp_env(self):
+        """PVAE_DP_BUCKET_MB / PVAE_DP_SHARDED / PVAE_P2P_TIMEOUT_MS of the environment, applied through the ABI (the
+        library reads no environment variable)."""
+        if "PVAE_DP_BUCKET_MB" in os.environ:
+            self.comm_config(float(os.environ["PVAE_DP_BUCKET_MB"]))
+        if self.has_comm and not self.has_p2p and "PVAE_DP_SHARDED" in os.environ:
+            self.comm_mode(os.environ["PVAE_DP_SHARDED"][:1] == "1")
+        if "PVAE_P2P_TIMEOUT_MS" in os.environ:
+            _lib.check(self.lib.pvae_set_option(self.ctx, b"p2p_timeout_ms", int(os.environ["PVAE_P2P_TIMEOUT_MS"])))
 
     def comm_destroy(self):
         if self.ctx is not None and self.has_comm:
@@ -441,8 +451,11 @@ class HipEngine:
         """Map every peer's buffers (`blobs`: the exports of ranks 0 .. world-1 in rank order)."""
         self._need_gpu()
         assert len(blobs) == world and all(len(b) == _lib.P2P_BLOB_BYTES for b in blobs)
+        if "PVAE_P2P_SELFTEST_FLAGS_ONLY" in os.environ:
+            _lib.check(self.lib.pvae_set_option(self.ctx, b"p2p_selftest_flags_only", 1))
         _lib.check(self.lib.pvae_p2p_open(self.ctx, int(rank), int(world), C.c_char_p(b"".join(blobs))), "pvae_p2p_open")
         self.has_p2p = True
+        self._dp_env()
 
     def p2p_exchange(self, net, off, cnt, sp):
         """One slice of the gradient arena through the peer-mapped exchange (sum over the ranks by the slice owners,
@@ -590,6 +603,10 @@ class HipEngine:
         "auto" = one XCD when the stacks fit.  Raises RuntimeError when nothing fits: keep using `infer` / `infer_host`.
         While it is resident, device-wide synchronisations wait for it (at most `idle_ms` after the last request)."""
         self._need_gpu()
+        env = os.environ.get("PVAE_SERVER_SCOPE", "")[:1]         # (A/B: overrides the caller's choice, as the C getenv did)
+        scope = {"x": "xcd", "c": "chip"}.get(env, scope)
+        mbx = os.environ.get("PVAE_SERVER_MAILBOX", "")[:1]
+        _lib.check(self.lib.pvae_set_option(self.ctx, b"server_mailbox", {"h": 1, "d": 2}.get(mbx, 0)), "pvae_set_option")
         _lib.check(self.lib.pvae_rollout_server_start(self.ctx, float(idle_ms), float(lifetime_s),
                                                       {"auto": 0, "xcd": 1, "chip": 2}[scope]), "pvae_rollout_server_start")
         if self._srv_io is None:

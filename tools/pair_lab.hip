@@ -2,7 +2,7 @@
 // 256 weight-gradient workgroups on 64x64 tiles || bias-gradient workgroups || 256 deferred-Adam workgroups)
 // at the BASELINE sizes (256 x 1024 x 1024), on RANDOM operands (zero-filled buffers clock ~19 % higher,
 // MI355X_MICROARCH.md DVFS note), timed as the period of back-to-back launches on one stream.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/pair_lab.hip -o ab_libs/pair_lab [-DPVAE_STORE_SC1=0 ...]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/pair_lab.hip -o ab_libs/pair_lab
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -112,7 +112,7 @@ int main() {
                    pass ? "ZERO" : "random", us, ghz, per, 256 * 4 * 2048.0 / 32.0 * ghz * 1e9 / 1e12);
         }
     }
-    printf("variant: PVAE_STORE_SC1=%d\n", PVAE_STORE_SC1);
+    printf("variant: production stores (sc1 write-through)\n");
 #define T(ABL, parts, name) printf("  %-64s %6.2f us\n", name, time_pair<ABL>(st, dZ, W, X, act, dX, G, M, N, K, parts, ad, a, b))
     T(0, 15, "complete: dgrad || wgrad || bias || 256 Adam workgroups");
     T(0, 7, "no Adam workgroups");
