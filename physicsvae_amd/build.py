@@ -1,13 +1,22 @@
-"""Build libpvae_gfx950.so in-tree with hipcc (cross-compiles for gfx950 without a GPU)."""
+"""Build libpvae_gfx950.so in-tree with hipcc (cross-compiles for gfx950 without a GPU): one object per translation
+unit of physicsvae_amd/csrc (compiled in parallel), linked into one shared library."""
+import concurrent.futures
 import os
 import shutil
 import subprocess
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpvae_gfx950.so")
-SOURCES = ["pvae.hip", "pvae_gemm.h", "pvae_layout.h"]
+UNITS = ["pvae.hip", "pvae_exchange.hip", "pvae_rollout_server.hip", "pvae_probe.hip"]
+HEADERS = ["pvae_internal.h", "pvae_gemm.h", "pvae_layout.h"]
+SOURCES = UNITS + HEADERS
 HEADER = os.path.join(os.path.dirname(HERE), "include", "pvae.h")
+# -amdgpu-kernarg-preload-count: leading scalar / pointer kernel arguments arrive in SGPRs at wave launch (gfx950)
+# instead of by an s_load inside the kernel (pvae_gemm.h PVAE_GA_PARAMS; tools/kernarg_preload_probe.hip)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-Wall",
+         "-Wno-unused-function"]
 
 
 def _hipcc():
@@ -25,21 +34,39 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not is_stale():
+def build(force=False, verbose=False, defines=(), out=None):
+    """`defines`: extra -D flags (diagnostic builds under ab_libs/); `out`: where the library goes (default: in-tree)."""
+    out = out or LIB
+    if not force and out == LIB and not is_stale():
         return LIB
-    # -amdgpu-kernarg-preload-count: leading scalar / pointer kernel arguments arrive in SGPRs at wave launch (gfx950)
-    # instead of by an s_load inside the kernel (pvae_gemm.h PVAE_GA_PARAMS; tools/kernarg_preload_probe.hip)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-kernarg-preload-count=16",
-           "-Wall", "-Wno-unused-function", os.path.join(CSRC, "pvae.hip"), "-o", LIB + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    cc = _hipcc()
+    tmp = tempfile.mkdtemp(prefix="pvae_build_")
+    try:
+        def compile_unit(u):
+            obj = os.path.join(tmp, u.replace(".hip", ".o"))
+            cmd = [cc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, u), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise RuntimeError("hipcc failed on %s:\n%s%s" % (u, res.stdout, res.stderr))
+            return obj
+        with concurrent.futures.ThreadPoolExecutor(len(UNITS)) as pool:
+            objs = list(pool.map(compile_unit, UNITS))
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out + ".tmp"]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
+        os.replace(out + ".tmp", out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    outs = [a for a in sys.argv[1:] if not a.startswith("-D")]
+    print(build(force=True, verbose=True, defines=defs, out=os.path.abspath(outs[0]) if outs else None))

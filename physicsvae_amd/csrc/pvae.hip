@@ -4,242 +4,7 @@
 //
 // Reference lines restated by each kernel are cited at the kernel (tpv / tm / rmt as in
 // include/pvae.h).
-#include <hip/hip_runtime.h>
-#include <dlfcn.h>
-
-#include <chrono>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <functional>
-#include <new>
-#include <string>
-#include <thread>
-#include <utility>
-#include <vector>
-
-#include "pvae_gemm.h"
-#include "pvae_layout.h"
-
-using namespace pvae;
-
-// ---------------------------------------------------------------------------------------
-// error handling
-// ---------------------------------------------------------------------------------------
-static thread_local char g_err[512] = "";
-
-static int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-#define HIP_TRY(expr)                                                                    \
-    do {                                                                                 \
-        hipError_t e_ = (expr);                                                          \
-        if (e_ != hipSuccess) return fail(-10, "%s: %s", #expr, hipGetErrorString(e_));  \
-    } while (0)
-
-// ---------------------------------------------------------------------------------------
-// optional per-launch timing (HIP events on the launch stream)
-// ---------------------------------------------------------------------------------------
-struct Profiler {
-    bool on = false;
-    static constexpr int kMax = 8192;
-    hipEvent_t ev[kMax][2];
-    int cat[kMax];
-    double flops[kMax];
-    int n = 0, created = 0;
-    // begin() arms the slot's event pair; the launch wrapper (PVAE_LAUNCH, pvae_gemm.h) hands it to
-    // hipExtLaunchKernelGGL, so the pair brackets the kernel itself and not the launch seam.  Every
-    // profiled range holds exactly one launch; a range that launched nothing is dropped.
-    int begin(int category, double fl, hipStream_t) {
-        if (!on || n >= kMax) return -1;
-        if (n >= created) {
-            if (hipEventCreate(&ev[n][0]) != hipSuccess || hipEventCreate(&ev[n][1]) != hipSuccess) return -1;
-            created = n + 1;
-        }
-        cat[n] = category;
-        flops[n] = fl;
-        g_kernel_ev[0] = ev[n][0];
-        g_kernel_ev[1] = ev[n][1];
-        return n;
-    }
-    void end(int slot, hipStream_t) {
-        if (slot < 0) return;
-        if (!g_kernel_ev[0]) n = slot + 1;          // consumed by a launch
-        g_kernel_ev[0] = g_kernel_ev[1] = nullptr;
-    }
-    // a range that is not one of our launches (the RCCL collective): events recorded on the stream
-    // around the call; `fl` carries the payload bytes instead of flops
-    int begin_range(int category, double fl, hipStream_t st) {
-        if (!on || n >= kMax) return -1;
-        if (n >= created) {
-            if (hipEventCreate(&ev[n][0]) != hipSuccess || hipEventCreate(&ev[n][1]) != hipSuccess) return -1;
-            created = n + 1;
-        }
-        cat[n] = category;
-        flops[n] = fl;
-        if (hipEventRecord(ev[n][0], st) != hipSuccess) return -1;
-        return n;
-    }
-    void end_range(int slot, hipStream_t st) {
-        if (slot < 0) return;
-        if (hipEventRecord(ev[slot][1], st) == hipSuccess) n = slot + 1;
-    }
-};
-static Profiler g_prof;
-
-// ---------------------------------------------------------------------------------------
-// RCCL, resolved at run time.  PyTorch-ROCm ships its own librccl.so.1 and has it loaded; the
-// library binds to THAT instance (RTLD_NOLOAD first) instead of linking a second copy, and
-// falls back to the system one (/opt/rocm/lib) when used without torch.  Only the five entry
-// points of the data-parallel exchange are needed; prototypes as in rccl/rccl.h (2.2x).
-// ---------------------------------------------------------------------------------------
-struct RcclId { char internal[128]; };                 // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
-struct Rccl {
-    void* h = nullptr;
-    int (*GetUniqueId)(RcclId*) = nullptr;
-    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;          // id is passed BY VALUE
-    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*ReduceScatter)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;   // optional
-    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;            // optional
-    int (*CommDestroy)(void*) = nullptr;
-    int (*CommCount)(void*, int*) = nullptr;
-    int (*CommUserRank)(void*, int*) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-    bool ok() const { return h && GetUniqueId && CommInitRank && AllReduce && CommDestroy && GetErrorString; }
-};
-static Rccl g_rccl;
-enum { kNcclSum = 0, kNcclFloat32 = 7 };
-
-static int rccl_load() {
-    if (g_rccl.ok()) return 0;
-    const char* names[] = {"librccl.so.1", "librccl.so"};
-    void* h = nullptr;
-    for (const char* n : names)
-        if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;            // the instance torch already mapped
-    if (!h)
-        for (const char* n : names)
-            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!h) return fail(-20, "RCCL not found (librccl.so.1): %s", dlerror());
-    g_rccl.h = h;
-    g_rccl.GetUniqueId = (int (*)(RcclId*))dlsym(h, "ncclGetUniqueId");
-    g_rccl.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(h, "ncclCommInitRank");
-    g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
-    g_rccl.ReduceScatter = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclReduceScatter");
-    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
-    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
-    g_rccl.CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");           // optional (pvae_comm_info)
-    g_rccl.CommUserRank = (int (*)(void*, int*))dlsym(h, "ncclCommUserRank");
-    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.ok()) {
-        g_rccl = Rccl();
-        return fail(-20, "RCCL library lacks an expected symbol");
-    }
-    return 0;
-}
-#define RCCL_TRY(expr)                                                                        \
-    do {                                                                                      \
-        int r_ = (expr);                                                                      \
-        if (r_ != 0) return fail(-21, "%s: %s", #expr, g_rccl.GetErrorString(r_));            \
-    } while (0)
-
-struct pvae_ctx {
-    void* comm = nullptr;        // ncclComm_t of the data-parallel group (pvae_comm_init)
-    int comm_rank = 0, comm_world = 1;
-    // overlapped gradient exchange (pvae_dp_train_step): the buckets of a stack are reduced and
-    // applied on comm_stream while the compute stream keeps producing the next ones
-    hipStream_t comm_stream = nullptr;
-    static constexpr int kMaxBuckets = 64;
-    hipEvent_t bucket_ready[kMaxBuckets] = {};
-    hipEvent_t comm_done = nullptr;
-    int exchange_mode = 0;             // PVAE_EXCHANGE_*: all-reduce + replicated Adam, or sharded (ZeRO-1 shaped)
-    int64_t bucket_bytes = -1;         // > 0: bucketed + overlapped; 0: one bucket per stack, in line on the compute
-                                       // stream; -1 (default): chosen per step by auto_bucket_bytes()
-    int64_t bucket_bytes_now = 0;      // what the step in flight uses (exchange_buckets / dp_train_step)
-    int comm_test_delay_us = 0;        // tests: a spin kernel in front of every reduction
-    Layout L;
-    Workspace W;
-    float* params = nullptr;
-    float* grads = nullptr;
-    float* m = nullptr;
-    float* v = nullptr;
-    float* ws = nullptr;
-    const float* states = nullptr;
-    const float* next_states = nullptr;      // pvae_bind_dataset_next (null: next row of `states`)
-    const float* actions = nullptr;
-    const int32_t* window_row = nullptr;
-    int64_t n_rows = 0, n_windows = 0;
-    int staged_rows = 0;
-    double staged_rows_f = 0;    // rows of the batch being processed (for the profiler's flop count)
-    // First layers on the demonstration set where it lies (XSrc in pvae_gemm.h): the training-step entry
-    // points (pvae_train_step, _prefetch, pvae_dp_train_step) stage nothing when `direct_ok` holds -- the first layer of
-    // every stack gathers its rows of `states` / `actions` itself, the two targets are read from there by the loss
-    // epilogues.  pvae_gather / pvae_set_batch + pvae_forward_backward keep the panel path (inspection, explicit batches,
-    // lookahead > 1, evaluation, the other priors).  OPT-IN (pvae_set_direct(ctx, 1)): bit-identical to the staged step,
-    // but at 256 rows the staged step is the faster one -- its gather rides in the previous step's last launch for free,
-    // while a gathered first layer waits for its operand descriptor (kernel arguments that cannot be preloaded) before its
-    // first tile fetch: joint 252.3 vs 241.5 us, world 92.1 vs 87.3 (docs/experiments.md, round 5).
-    bool direct = false;
-    bool data_slack = false;     // both dataset arrays are readable 16 bytes past their last row (checked at bind time)
-    struct { bool on = false; RowMap rm{}; } dx;                     // the step in flight: batch row -> row of the set
-    TouchRuns next_touch{};                                          // rows of the NEXT minibatch for the last launch to pre-touch
-    std::vector<int32_t> window_row_host;                            // copied at bind time: the host finds the episode jumps
-    bool pair_launch = true;     // PVAE_PAIR=0 launches every contraction on its own (A/B)
-    // gather prefetch (pvae_train_step_prefetch): what the alternate staging panels hold, and the
-    // staging job the current step's last launch should carry
-    struct { bool valid = false; int64_t first = 0; int rows = 0; const float* states = nullptr; } pf;
-    StageArgs next_stage;        // rows_pad > 0: pending for the last launch of this step
-    bool next_carried = false;   // set by the launch that took it
-    bool seed_pads_clean = false;  // pad columns of the seed panels zeroed (see plan_backward)
-    // deferred Adam (AdamSeg, pvae_gemm.h): the layer whose gradient the last launch stored; the next
-    // weight-gradient launch of the step updates it with extra workgroups (PVAE_DEFER_ADAM=0: off)
-    AdamSeg pending_adam;          // the most recent one
-    AdamSeg held_adam;             // a big one that a narrow launch passed on to the next wide launch (take_pending)
-    bool defer_adam = true;
-    bool same_layer_pairs = true;  // PVAE_SAME_LAYER=0: wgrad_i rides with dgrad_{i-1} as before (A/B)
-    bool p2p_selftest_flags_only = false;   // option: the attach-time self-test skips the cached-arena part
-    int server_mailbox = 0;                 // option: where the rollout server's request block lives (0 auto, 1 host, 2 device)
-    bool fold_sampler = true;      // the sampler runs as the prologue of the decoder's first-layer launch (PVAE_FOLD_SAMPLER=0: its own launch)
-                                   // (ProSampler).  Off by default: one launch less, but the step is not shorter -- the kernel
-                                   // trace shows 6.4-7.0 us for the merged launch against 4.4 + 4.6, and the un-profiled
-                                   // step 254.8 vs 254.5 us (profiles/r03_ab_fold_sampler.txt, docs/experiments.md)
-    // peer-mapped exchange (PVAE_EXCHANGE_P2P): every rank's gradient arena, parameter arena and flag block,
-    // mapped into this process with hipIpcOpenMemHandle (index = rank; [rank] = the local pointers)
-    struct P2p {
-        bool open = false;
-        int rank = 0, world = 0;
-        unsigned* flags = nullptr;                       // own flag block (uncached device memory)
-        float* grads[PVAE_P2P_MAX_RANKS] = {};
-        float* params[PVAE_P2P_MAX_RANKS] = {};
-        unsigned* peer_flags[PVAE_P2P_MAX_RANKS] = {};
-        float* staging = nullptr;                        // own staging buffer of the push form (hipMalloc, arena-sized)
-        float* peer_staging[PVAE_P2P_MAX_RANKS] = {};
-        void* mapped[PVAE_P2P_MAX_RANKS][4] = {};        // what hipIpcOpenMemHandle returned (to close)
-        unsigned epoch = 0;                              // exchanges issued so far (identical on every rank)
-        float* self_buf = nullptr;                       // self-test scratch: saved regions + checksums (hipMalloc)
-        unsigned selftests = 0;                          // self-tests run since the flags were zeroed (identical on every rank)
-        long long timeout_ticks = 20ll * 100000000ll;    // 100 MHz wall clock
-    } p2p;
-    struct RolloutServer* server = nullptr;              // call-persistent rollout kernel (pvae_rollout_server_*)
-    // every call that changes parameters through this library counts here and leaves its stream: the rollout server re-reads
-    // its resident copy when the count moved (after that stream has drained)
-    unsigned long long param_version = 0;
-    hipStream_t param_stream = nullptr;                  // (NULL is a stream too: the default one)
-    bool param_pending = false;                          // work that writes the parameters may still be queued on it
-};
-static inline void params_touched(pvae_ctx* c, hipStream_t st, bool queued = true) {
-    ++c->param_version; c->param_stream = st; c->param_pending = queued;
-}
-static inline hipError_t params_settle(pvae_ctx* c) {
-    if (!c->param_pending) return hipSuccess;
-    c->param_pending = false;
-    return hipStreamSynchronize(c->param_stream);
-}
-static void server_free(pvae_ctx* c);
+#include "pvae_internal.h"
 
 // ---------------------------------------------------------------------------------------
 // glue kernels
@@ -337,45 +102,6 @@ mse_grad_kernel(const float* __restrict__ pred, int ldp, const float* __restrict
     }
     const float s = block_sum_256(acc);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
-}
-
-// Philox4x32-10 (Salmon et al., SC'11) -> one standard normal via Box-Muller.
-__device__ inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-// One Philox call = four standard normals: the draws of columns 4g .. 4g + 3 of row `row` (counter = {offset, row,
-// g}; two Box-Muller pairs from the four 32-bit outputs).  Hardware transcendentals (v_log_f32, v_sqrt_f32,
-// v_sin_f32 / v_cos_f32, which take their argument in revolutions: cos(2 pi u) is ONE instruction): ~1 ulp, which a
-// random draw does not notice, at a tenth of the instructions of logf / cosf -- the draws are formed inside a
-// contraction launch by every workgroup that needs them (ProSampler below), so their cost is multiplied.
-__device__ inline v4f philox_normal4(uint64_t seed, uint64_t offset, uint32_t row, uint32_t group) {
-    uint32_t c[4] = {(uint32_t)offset, (uint32_t)(offset >> 32), row, group};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    v4f n;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const float u1 = ((float)c[2 * h] + 0.5f) * 2.3283064365386963e-10f;       // (0, 1)
-        const float u2 = ((float)c[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
-        const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), log2 form
-        n[2 * h] = r * __builtin_amdgcn_cosf(u2);
-        n[2 * h + 1] = r * __builtin_amdgcn_sinf(u2);
-    }
-    return n;
-}
-__device__ inline float philox_normal(uint64_t seed, uint64_t offset, uint32_t row, uint32_t col) {
-    return philox_normal4(seed, offset, row, col >> 2)[col & 3];
 }
 
 // Reparameterisation sampler + KL-to-N(0,I) partial sums (rmt:734-740, 795-800; tpv:384-389):
@@ -666,415 +392,6 @@ adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __re
         reinterpret_cast<v4f*>(m)[i] = mm;
         reinterpret_cast<v4f*>(v)[i] = vv;
     }
-}
-
-// ---------------------------------------------------------------------------------------
-// Direct all-pairs gradient exchange over peer-mapped arenas (PVAE_EXCHANGE_P2P; SURVEY.md section 8e: "direct
-// reduce-scatter + all-gather across all 7 links").  ONE launch per bucket and rank:
-//   1. workgroup 0 tells every peer "my gradient of this bucket is final" (the launches that produced it precede
-//      this one in the stream): epoch -> peer's ready[me];
-//   2. every workgroup waits until all peers have told it the same (ready[q] >= epoch, local uncached memory);
-//   3. the rank owns slice `me` of the bucket: for each float4 of it, the N gradients are read straight from the
-//      N arenas (system-scope loads, all N in flight together), summed IN RANK ORDER, Adam is applied with the
-//      local moments, and the new parameters are written to the local arena AND pushed into every peer's;
-//   4. the last workgroup to finish (ticket) fences, tells every peer "done" and waits for every peer's "done":
-//      when the launch ends this rank's parameter arena is complete and its gradient arena may be overwritten.
-// Epochs only grow and every rank issues the same sequence of exchanges, so one word per (kind, source rank) is
-// enough and a peer that is one exchange ahead cannot be mistaken (>= comparisons).  Every wait is bounded: a
-// peer that never signals raises the error word instead of hanging the GPU.
-// Flag block (unsigned words): [0, 8) ready[src], [8, 16) done[src], 16 ticket, 17 waits that gave up.
-// ---------------------------------------------------------------------------------------
-//                              18 second ticket, [24, 32) pushed[src] (push form), [32, 40) self-test tokens,
-//                              [64, 96) self-test payload (4 words per source rank).
-constexpr int kP2pReady = 0, kP2pDone = 8, kP2pTicket = 16, kP2pErr = 17, kP2pTicket2 = 18, kP2pPushed = 24, kP2pSelf = 32,
-              kP2pPayload = 64, kP2pFlagBytes = 4096;
-struct P2pArgs {
-    float* g[PVAE_P2P_MAX_RANKS];           // gradient arenas, bucket offset applied (g[me]: local)
-    float* p[PVAE_P2P_MAX_RANKS];           // parameter arenas, bucket offset applied
-    unsigned* f[PVAE_P2P_MAX_RANKS];        // flag blocks
-    float* stage[PVAE_P2P_MAX_RANKS];       // staging buffers (push form): [N][slice] floats at each owner
-    float* m; float* v;                     // local moments, bucket offset applied
-    long long n4;                           // float4 elements in the bucket
-    int me;
-    unsigned epoch;
-    long long timeout_ticks;
-    AdamScalars s;
-};
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-__device__ inline unsigned p2p_ld(const unsigned* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ inline void p2p_st(unsigned* q, unsigned x) { __hip_atomic_store(q, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ inline bool p2p_wait(const unsigned* flag, unsigned epoch, long long timeout, unsigned* err) {
-    const long long t0 = wall_clock64();
-    while ((int)(p2p_ld(flag) - epoch) < 0) {
-        __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > timeout) { atomicAdd(err, 1u); return false; }
-    }
-    return true;
-}
-template <int N>
-__global__ void __launch_bounds__(256) p2p_exchange_kernel(P2pArgs a) {
-    unsigned* mine = a.f[a.me];
-    const int tid = threadIdx.x, me = a.me;
-    if (blockIdx.x == 0 && tid < N && tid != me) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");             // (system scope; the producing launches ended before this one began)
-        p2p_st(a.f[tid] + kP2pReady + me, a.epoch);
-    }
-    // A wait that gives up ABORTS the exchange on this rank: no peer gradient that may be unfinished is summed, no
-    // moment moves, nothing is pushed -- parameters and moments stay what they were before the launch, the error word
-    // says so (pvae_p2p_status), and the "done" hand-shake below still runs so that the peers are not left waiting.
-    __shared__ int abort_;
-    if (tid == 0) abort_ = 0;
-    __syncthreads();
-    if (tid < N && tid != me) {
-        if (!p2p_wait(mine + kP2pReady + tid, a.epoch, a.timeout_ticks, mine + kP2pErr)) abort_ = 1;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    }
-    __syncthreads();
-    const long long S = (a.n4 + N - 1) / N, lo = me * S, hi = lo + S < a.n4 ? lo + S : a.n4;
-    if (lo < hi && !abort_) {
-        // buffer descriptors over this rank's slice of every arena: loads / stores with sc0 sc1 (system scope,
-        // past this device's caches) that the compiler schedules and counts like any other memory operation
-        __amdgpu_buffer_rsrc_t rg[N], rp[N];
-        const unsigned bytes = (unsigned)((hi - lo) * 16);
-#pragma unroll
-        for (int q = 0; q < N; ++q) {
-            rg[q] = __builtin_amdgcn_make_buffer_rsrc(a.g[q] + 4 * lo, 0, bytes, 0x00020000);
-            rp[q] = __builtin_amdgcn_make_buffer_rsrc(a.p[q] + 4 * lo, 0, bytes, 0x00020000);
-        }
-        for (long long i = blockIdx.x * 256ll + tid; i < hi - lo; i += gridDim.x * 256ll) {
-            const unsigned off = (unsigned)(i * 16);
-            v4f g[N];
-#pragma unroll
-            for (int q = 0; q < N; ++q) g[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rg[q], off, 0, 17));
-            v4f pp = reinterpret_cast<const v4f*>(a.p[me])[lo + i];
-            v4f mm = reinterpret_cast<const v4f*>(a.m)[lo + i];
-            v4f vv = reinterpret_cast<const v4f*>(a.v)[lo + i];
-            v4f sum = g[0];
-#pragma unroll
-            for (int q = 1; q < N; ++q) sum += g[q];                // rank order, whoever owns the slice
-            adam_update4(sum, pp, mm, vv, a.s);
-            store_stream(a.m + 4 * (lo + i), mm);
-            store_stream(a.v + 4 * (lo + i), vv);
-#pragma unroll
-            for (int q = 0; q < N; ++q) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, pp), rp[q], off, 0, 17);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    __shared__ unsigned last;
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        last = atomicAdd(mine + kP2pTicket, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last) return;
-    if (tid == 0) mine[kP2pTicket] = 0;
-    if (tid < N && tid != me) {
-        p2p_st(a.f[tid] + kP2pDone + me, a.epoch);
-        p2p_wait(mine + kP2pDone + tid, a.epoch, a.timeout_ticks, mine + kP2pErr);
-    }
-}
-
-// The PUSH form of the same exchange (PVAE_EXCHANGE_P2P_PUSH): remote WRITES only.  Posted writes pipeline over a link
-// where reads are round trips, so this is the form a fabric with write-favouring links wants; which of the two wins
-// on xGMI is for the first multi-GPU run to say (bench.py's exchange_sweep times both).
-//   1. every rank writes, for each peer q, ITS contribution to slice q into slot `me` of q's staging buffer;
-//      the last workgroup to finish (ticket) fences and tells every peer "pushed";
-//   2. every workgroup waits for all peers' "pushed", then the owner sums its slice in rank order -- its own gradient
-//      from the arena, the others from its LOCAL staging (system-scope loads: remote agents wrote it) --, applies Adam
-//      and pushes the new parameters into every peer's parameter arena;
-//   3. last workgroup: "done" to every peer, wait for every peer's "done" (the staging may then be overwritten).
-template <int N>
-__global__ void __launch_bounds__(256) p2p_push_exchange_kernel(P2pArgs a) {
-    unsigned* mine = a.f[a.me];
-    const int tid = threadIdx.x, me = a.me;
-    const long long S = (a.n4 + N - 1) / N, stride = gridDim.x * 256ll;
-    __shared__ unsigned last;
-    {   // 1. scatter-push
-        __amdgpu_buffer_rsrc_t rs[N];
-#pragma unroll
-        for (int q = 0; q < N; ++q)
-            rs[q] = __builtin_amdgcn_make_buffer_rsrc(a.stage[q] + (size_t)me * S * 4, 0, (unsigned)(S * 16), 0x00020000);
-        for (long long i = blockIdx.x * 256ll + tid; i < S; i += stride) {
-#pragma unroll
-            for (int q = 0; q < N; ++q) {
-                if (q == me || q * S + i >= a.n4) continue;
-                const v4f g = reinterpret_cast<const v4f*>(a.g[me])[q * S + i];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, g), rs[q], (unsigned)(i * 16), 0, 17);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            last = atomicAdd(mine + kP2pTicket2, 1u) == gridDim.x - 1;
-        }
-        __syncthreads();
-        if (last) {
-            if (tid == 0) mine[kP2pTicket2] = 0;
-            if (tid < N && tid != me) p2p_st(a.f[tid] + kP2pPushed + me, a.epoch);
-        }
-    }
-    __shared__ int abort_;              // (see p2p_exchange_kernel: a wait that gives up aborts this rank's update)
-    if (tid == 0) abort_ = 0;
-    __syncthreads();
-    if (tid < N && tid != me) {       // 2. everything for my slice has arrived
-        if (!p2p_wait(mine + kP2pPushed + tid, a.epoch, a.timeout_ticks, mine + kP2pErr)) abort_ = 1;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    }
-    __syncthreads();
-    const long long lo = me * S, hi = lo + S < a.n4 ? lo + S : a.n4;
-    if (lo < hi && !abort_) {
-        const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(a.stage[me], 0, (unsigned)(N * S * 16), 0x00020000);
-        __amdgpu_buffer_rsrc_t rp[N];
-#pragma unroll
-        for (int q = 0; q < N; ++q) rp[q] = __builtin_amdgcn_make_buffer_rsrc(a.p[q] + 4 * lo, 0, (unsigned)((hi - lo) * 16), 0x00020000);
-        for (long long i = blockIdx.x * 256ll + tid; i < hi - lo; i += stride) {
-            v4f g[N];
-#pragma unroll
-            for (int q = 0; q < N; ++q)
-                g[q] = q == me ? reinterpret_cast<const v4f*>(a.g[me])[lo + i]
-                               : __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rst, (unsigned)((q * S + i) * 16), 0, 17));
-            v4f pp = reinterpret_cast<const v4f*>(a.p[me])[lo + i];
-            v4f mm = reinterpret_cast<const v4f*>(a.m)[lo + i];
-            v4f vv = reinterpret_cast<const v4f*>(a.v)[lo + i];
-            v4f sum = g[0];
-#pragma unroll
-            for (int q = 1; q < N; ++q) sum += g[q];                // rank order
-            adam_update4(sum, pp, mm, vv, a.s);
-            store_stream(a.m + 4 * (lo + i), mm);
-            store_stream(a.v + 4 * (lo + i), vv);
-#pragma unroll
-            for (int q = 0; q < N; ++q) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, pp), rp[q], (unsigned)(i * 16), 0, 17);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        last = atomicAdd(mine + kP2pTicket, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last) return;
-    if (tid == 0) mine[kP2pTicket] = 0;
-    if (tid < N && tid != me) {
-        p2p_st(a.f[tid] + kP2pDone + me, a.epoch);
-        p2p_wait(mine + kP2pDone + tid, a.epoch, a.timeout_ticks, mine + kP2pErr);
-    }
-}
-
-// Self-test of the mappings, run once when the peers are opened: every rank writes a 4-word record into its slot of
-// every peer's flag block (remote write), signals, waits for the peers' signals, checks the records that arrived in
-// its own block (written by remote agents) and reads back, from every peer's block, the record it wrote there
-// (remote read).  Anything wrong -- a mapping that does not reach the peer, a flag that never arrives -- raises the
-// error word within `timeout_ticks` instead of surfacing as a hang in the first training step.
-__global__ void p2p_selftest_kernel(P2pArgs a, int n, unsigned token) {
-    unsigned* mine = a.f[a.me];
-    const int q = threadIdx.x, me = a.me;
-    if (q >= n || q == me) return;
-    unsigned* theirs = a.f[q];
-    for (int wd = 0; wd < 4; ++wd) p2p_st(theirs + kP2pPayload + me * 4 + wd, wd == 0 ? token : wd == 1 ? (unsigned)me : wd == 2 ? (unsigned)q : 0xC0FFEEu);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    p2p_st(theirs + kP2pSelf + me, token);
-    p2p_wait(mine + kP2pSelf + q, token, a.timeout_ticks, mine + kP2pErr);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    const bool got = p2p_ld(mine + kP2pPayload + q * 4) == token && p2p_ld(mine + kP2pPayload + q * 4 + 1) == (unsigned)q &&
-                     p2p_ld(mine + kP2pPayload + q * 4 + 2) == (unsigned)me && p2p_ld(mine + kP2pPayload + q * 4 + 3) == 0xC0FFEEu;
-    const bool back = p2p_ld(theirs + kP2pPayload + me * 4) == token && p2p_ld(theirs + kP2pPayload + me * 4 + 3) == 0xC0FFEEu;
-    if (!got || !back) atomicAdd(mine + kP2pErr, 1u);
-}
-
-
-// ---- self-test of the CACHED arenas ---------------------------------------------------------
-// The flag block above is uncached memory; the arenas the exchange really moves are plain hipMalloc (coarse-grained)
-// memory that this device's L2s cache.  Peers overwrite this rank's parameters over the links while the lines may
-// still sit in the local L2s from the last forward pass, and the next forward launch starts behind an agent-scope
-// acquire only.  If a remote write left a stale line behind, every rank would train on old weights of the slices it
-// does not own -- and the replicas would still be bit-identical.  So, once per set-up, the very access paths of the
-// exchange are exercised on a TEST REGION of each buffer and every read-back is compared with what was written:
-//   parameters  first kSelfFloats floats of the arena (saved first, restored at the end), one 128-byte line per source
-//               rank: primed into the local L2s of all XCDs (LDS-DMA loads, the forward kernels' path, and plain
-//               loads), overwritten by the peers with the exchange's own `buffer_store ... sc0 sc1`, re-read by a FRESH
-//               dependent launch on every XCD through the same two load paths;
-//   staging     the 256-float tail of the staging buffer: primed, overwritten by the peers, read in the SAME launch
-//               behind the flag wait with the push form's system-scope loads, and again by the fresh launch;
-//   gradients   first kSelfFloats floats of the arena (saved / restored): the owner writes pattern A with plain stores, the
-//               peers read their line with the pull form's `buffer_load ... sc0 sc1`; the owner overwrites it with
-//               pattern B and the peers read again -- a reader-side stale line would return A.
-// Any mismatch or missing flag raises the error word; pvae_p2p_selftest then fails and the caller drops the form.
-constexpr int kP2pPrimed = 96, kP2pWritten = 104, kP2pGradB = 112, kP2pFin = 120;       // flag words, [src rank]
-constexpr int kSelfLine = 32, kSelfFloats = PVAE_P2P_MAX_RANKS * kSelfLine;             // 8 lines of 128 bytes
-constexpr int kSelfGrid = 64;                                                           // 8 workgroups on every XCD
-struct SelfArgs {
-    P2pArgs a;              // g / p / f / stage: the test regions' base pointers (stage: the tail), me, timeout
-    float* save;            // [2 * kSelfFloats]: what the parameter and gradient regions held
-    unsigned* sink;         // [kSelfGrid] checksums (keeps the priming loads alive)
-    int n;
-    unsigned token;
-};
-__device__ inline float self_pat(unsigned token, int src, int dst, int j, int round) {
-    return (float)(((token & 0xFFFFu) * 131u + (unsigned)src * 1021u + (unsigned)dst * 67u + (unsigned)round * 4099u) % 65521u) +
-           (float)j * 0.0078125f;                                     // exactly representable, distinct per (src, dst, j, round)
-}
-// the two paths a forward launch reads parameters through: LDS-DMA (default cache policy) and a plain 16-byte load
-__device__ inline v4f self_read_dma(const float* region, float* lds, int lane) {
-    lds_dma16(region + 4 * lane, lds);                                // 64 lanes x 16 bytes = the 1 KB region
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    return *reinterpret_cast<const v4f*>(lds + 4 * lane);
-}
-__global__ void __launch_bounds__(64) p2p_self_prime_kernel(SelfArgs s) {
-    __shared__ __attribute__((aligned(16))) float lds[kSelfFloats];
-    const int lane = threadIdx.x, me = s.a.me;
-    const v4f pd = self_read_dma(s.a.p[me], lds, lane);
-    const v4f pl = *reinterpret_cast<const v4f*>(s.a.p[me] + 4 * lane);
-    const v4f sl = *reinterpret_cast<const v4f*>(s.a.stage[me] + 4 * lane);
-    const v4f gl = *reinterpret_cast<const v4f*>(s.a.g[me] + 4 * lane);
-    if (blockIdx.x == 0) {
-        *reinterpret_cast<v4f*>(s.save + 4 * lane) = pl;
-        *reinterpret_cast<v4f*>(s.save + kSelfFloats + 4 * lane) = gl;
-        v4f a;                                                        // gradient pattern A: line q is what peer q will read
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = self_pat(s.token, me, (4 * lane + e) / kSelfLine, (4 * lane + e) % kSelfLine, 0);
-        *reinterpret_cast<v4f*>(s.a.g[me] + 4 * lane) = a;            // plain store, as an ordinary producer would
-    }
-    const float c = pd[0] + pd[3] + pl[1] + sl[2] + gl[0];
-    if (lane == 0) s.sink[blockIdx.x] = __float_as_uint(c);
-}
-// one wave: signal "primed", wait for the peers', write my lines into every peer's parameter and staging regions with the
-// exchange's stores, read my line of every peer's gradient region (pattern A) with the exchange's loads, signal
-// "written", wait for the peers', and check my staging region in this same launch (the push form's situation)
-__global__ void __launch_bounds__(64) p2p_self_write_kernel(SelfArgs s) {
-    unsigned* mine = s.a.f[s.a.me];
-    const int lane = threadIdx.x, me = s.a.me, n = s.n;
-    unsigned bad = 0;
-    if (lane < n && lane != me) {
-        p2p_st(s.a.f[lane] + kP2pPrimed + me, s.token);
-        p2p_wait(mine + kP2pPrimed + lane, s.token, s.a.timeout_ticks, mine + kP2pErr);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    }
-    __builtin_amdgcn_s_barrier();
-    for (int q = 0; q < n; ++q) {
-        if (q == me) continue;
-        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(s.a.p[q], 0, kSelfFloats * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(s.a.stage[q], 0, kSelfFloats * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(s.a.g[q], 0, kSelfFloats * 4, 0x00020000);
-        if (lane < kSelfLine / 4) {
-            v4f w;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = self_pat(s.token, me, q, 4 * lane + e, 0);
-            const unsigned off = (unsigned)((me * kSelfLine + 4 * lane) * 4);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, w), rp, off, 0, 17);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, w), rs, off, 0, 17);
-            const v4f g = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 17));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bad += g[e] != self_pat(s.token, q, me, 4 * lane + e, 0);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    __builtin_amdgcn_s_barrier();
-    if (lane < n && lane != me) {
-        p2p_st(s.a.f[lane] + kP2pWritten + me, s.token);
-        p2p_wait(mine + kP2pWritten + lane, s.token, s.a.timeout_ticks, mine + kP2pErr);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    }
-    __builtin_amdgcn_s_barrier();
-    const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(s.a.stage[me], 0, kSelfFloats * 4, 0x00020000);
-    const int q = (4 * lane) / kSelfLine;
-    if (q < n && q != me) {
-        const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rst, (unsigned)(lane * 16), 0, 17));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bad += v[e] != self_pat(s.token, q, me, (4 * lane + e) % kSelfLine, 0);
-    }
-    if (bad) atomicAdd(mine + kP2pErr, bad);
-}
-// the fresh dependent launch: every XCD re-reads the parameter region through both forward-pass load paths and the
-// staging region through plain and system-scope loads; the lines of the peers must hold what the peers wrote
-__global__ void __launch_bounds__(64) p2p_self_verify_kernel(SelfArgs s) {
-    __shared__ __attribute__((aligned(16))) float lds[kSelfFloats];
-    const int lane = threadIdx.x, me = s.a.me;
-    const v4f pd = self_read_dma(s.a.p[me], lds, lane);
-    const v4f pl = *reinterpret_cast<const v4f*>(s.a.p[me] + 4 * lane);
-    const v4f sl = *reinterpret_cast<const v4f*>(s.a.stage[me] + 4 * lane);
-    const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(s.a.stage[me], 0, kSelfFloats * 4, 0x00020000);
-    const v4f ss = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rst, (unsigned)(lane * 16), 0, 17));
-    const int q = (4 * lane) / kSelfLine;
-    unsigned bad = 0;
-    if (q < s.n && q != me) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float want = self_pat(s.token, q, me, (4 * lane + e) % kSelfLine, 0);
-            bad += (pd[e] != want) + (pl[e] != want) + (sl[e] != want) + (ss[e] != want);
-        }
-    }
-    if (bad) atomicAdd(s.a.f[me] + kP2pErr, bad);
-}
-// pattern B over the gradient region (plain stores); the next launch tells the peers and reads theirs
-__global__ void __launch_bounds__(64) p2p_self_gradb_kernel(SelfArgs s) {
-    const int lane = threadIdx.x, me = s.a.me;
-    v4f b;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) b[e] = self_pat(s.token, me, (4 * lane + e) / kSelfLine, (4 * lane + e) % kSelfLine, 1);
-    *reinterpret_cast<v4f*>(s.a.g[me] + 4 * lane) = b;
-}
-__global__ void __launch_bounds__(64) p2p_self_reread_kernel(SelfArgs s) {
-    unsigned* mine = s.a.f[s.a.me];
-    const int lane = threadIdx.x, me = s.a.me, n = s.n;
-    unsigned bad = 0;
-    if (lane < n && lane != me) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        p2p_st(s.a.f[lane] + kP2pGradB + me, s.token);
-        p2p_wait(mine + kP2pGradB + lane, s.token, s.a.timeout_ticks, mine + kP2pErr);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    }
-    __builtin_amdgcn_s_barrier();
-    for (int q = 0; q < n; ++q) {
-        if (q == me || lane >= kSelfLine / 4) continue;
-        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(s.a.g[q], 0, kSelfFloats * 4, 0x00020000);
-        const v4f g = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rg, (unsigned)((me * kSelfLine + 4 * lane) * 4), 0, 17));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bad += g[e] != self_pat(s.token, q, me, 4 * lane + e, 1);
-    }
-    if (bad) atomicAdd(mine + kP2pErr, bad);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (lane < n && lane != me) {                 // nobody restores its regions while a peer may still be reading them
-        p2p_st(s.a.f[lane] + kP2pFin + me, s.token);
-        p2p_wait(mine + kP2pFin + lane, s.token, s.a.timeout_ticks, mine + kP2pErr);
-    }
-}
-__global__ void __launch_bounds__(64) p2p_self_restore_kernel(SelfArgs s) {
-    const int lane = threadIdx.x, me = s.a.me;
-    *reinterpret_cast<v4f*>(s.a.p[me] + 4 * lane) = *reinterpret_cast<const v4f*>(s.save + 4 * lane);
-    *reinterpret_cast<v4f*>(s.a.g[me] + 4 * lane) = *reinterpret_cast<const v4f*>(s.save + kSelfFloats + 4 * lane);
-}
-
-// ---------------------------------------------------------------------------------------
-// host helpers
-// ---------------------------------------------------------------------------------------
-static AdamScalars adam_scalars(const pvae_step_params* sp, int net) {
-    // torch computes the bias corrections in Python floats (double): tm:119-122 -> torch/optim/adam.py
-    const int t = sp->adam_t[net] > 0 ? sp->adam_t[net] : 1;
-    const double bc1 = 1.0 - std::pow(sp->beta1, t);
-    const double bc2 = 1.0 - std::pow(sp->beta2, t);
-    AdamScalars s;
-    s.step_size = (float)(sp->lr / bc1);
-    s.inv_bc2_sqrt = (float)(1.0 / std::sqrt(bc2));
-    s.beta1 = (float)sp->beta1;
-    s.beta2 = (float)sp->beta2;
-    s.eps = (float)sp->adam_eps;
-    s.one_minus_beta1 = (float)(1.0 - sp->beta1);
-    s.one_minus_beta2 = (float)(1.0 - sp->beta2);
-    s.weight_decay = sp->weight_decay;
-    return s;
-}
-
-static int check_ready(const pvae_ctx* c, bool need_arenas) {
-    if (!c) return fail(-1, "null ctx");
-    if (!c->ws) return fail(-2, "workspace not bound");
-    if (need_arenas && !c->params) return fail(-2, "parameter arena not bound");
-    return 0;
 }
 
 // Rollout-batch forward layer (rows <= 4; rmt:742-771 runs at B = 1 inside the 30 Hz control
@@ -2804,444 +2121,6 @@ int pvae_adam(pvae_ctx* c, int net_mask, const pvae_step_params* sp, void* strea
 
 static void flip_stage_panels(pvae_ctx* c);
 
-// ---- data-parallel exchange inside the library ---------------------------------------------
-int pvae_comm_unique_id(void* id128) {
-    if (!id128) return fail(-1, "null id buffer");
-    int rc = rccl_load();
-    if (rc) return rc;
-    RcclId id;
-    RCCL_TRY(g_rccl.GetUniqueId(&id));
-    memcpy(id128, id.internal, sizeof(id.internal));
-    return 0;
-}
-
-static int ensure_comm_stream(pvae_ctx* c);
-int pvae_comm_init(pvae_ctx* c, int rank, int world, const void* id128) {
-    if (!c || !id128) return fail(-1, "null argument");
-    if (world < 1 || rank < 0 || rank >= world) return fail(-1, "rank %d outside [0, %d)", rank, world);
-    if (c->comm) return fail(-2, "communicator already initialised");
-    int rc = rccl_load();
-    if (rc) return rc;
-    RcclId id;
-    memcpy(id.internal, id128, sizeof(id.internal));
-    void* comm = nullptr;
-    RCCL_TRY(g_rccl.CommInitRank(&comm, world, id, rank));
-    c->comm = comm; c->comm_rank = rank; c->comm_world = world;
-    if ((rc = ensure_comm_stream(c))) return rc;
-    return 0;
-}
-
-// the exchange stream and its events (bucketed + overlapped exchange), shared by the RCCL and the peer-mapped transport
-static int ensure_comm_stream(pvae_ctx* c) {
-    if (c->comm_stream) return 0;
-    int lo = 0, hi = 0;                                   // hi = numerically lowest = most urgent
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIP_TRY(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, hi));
-    for (hipEvent_t& e : c->bucket_ready) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->comm_done, hipEventDisableTiming));
-    return 0;
-}
-
-// ---- peer-mapped exchange: set-up ------------------------------------------------------------
-struct P2pBlob {                                          // PVAE_P2P_BLOB_BYTES on the wire
-    uint32_t magic, abi;
-    int64_t arena_floats;
-    hipIpcMemHandle_t h[4];                               // allocations holding grads, params, flags, staging
-    int64_t off[4];                                       // byte offset of the buffer inside its allocation
-};
-static_assert(sizeof(P2pBlob) <= PVAE_P2P_BLOB_BYTES, "blob layout");
-constexpr uint32_t kP2pMagic = 0x50325056u;               // "PV2P"
-
-int pvae_p2p_export(pvae_ctx* c, void* blob) {
-    if (!c || !blob) return fail(-1, "null argument");
-    if (!c->params || !c->grads) return fail(-2, "parameter / gradient arenas not bound");
-    if (c->p2p.open) return fail(-2, "peer-mapped exchange is open: pvae_p2p_close before exporting again");
-    if (!c->p2p.flags) HIP_TRY(hipExtMallocWithFlags((void**)&c->p2p.flags, kP2pFlagBytes, hipDeviceMallocUncached));
-    // every set-up starts from a zeroed flag block (epochs restart at 0 in pvae_p2p_open): a block that an earlier,
-    // closed set-up left its epochs in would satisfy the first waits of the new one.  The exchange of the blobs that
-    // follows is the barrier between this and any peer's first write.
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(c->p2p.flags, 0, kP2pFlagBytes));
-    HIP_TRY(hipDeviceSynchronize());
-    c->p2p.selftests = 0;
-    P2pBlob b;
-    memset(&b, 0, sizeof(b));
-    b.magic = kP2pMagic; b.abi = PVAE_ABI_VERSION; b.arena_floats = c->L.arena_floats;
-    if (!c->p2p.staging) HIP_TRY(hipMalloc((void**)&c->p2p.staging, ((size_t)c->L.arena_floats + 256) * sizeof(float)));
-    void* ptrs[4] = {c->grads, c->params, c->p2p.flags, c->p2p.staging};
-    const char* what[4] = {"gradient arena", "parameter arena", "flag block", "staging buffer"};
-    for (int k = 0; k < 4; ++k) {
-        void* base = nullptr;
-        size_t size = 0;
-        if (hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, ptrs[k]) != hipSuccess || !base)
-            return fail(-10, "%s: not inside a hipMalloc allocation", what[k]);
-        hipError_t e = hipIpcGetMemHandle(&b.h[k], base);
-        if (e != hipSuccess)
-            return fail(-10, "hipIpcGetMemHandle(%s): %s (the arenas must come from hipMalloc -- PyTorch's default "
-                             "caching allocator, not expandable segments -- and HSA_ENABLE_IPC_MODE_LEGACY=0 must be set "
-                             "where the driver only supports dmabuf IPC)", what[k], hipGetErrorString(e));
-        b.off[k] = (char*)ptrs[k] - (char*)base;
-    }
-    memset(blob, 0, PVAE_P2P_BLOB_BYTES);
-    memcpy(blob, &b, sizeof(b));
-    return 0;
-}
-
-int pvae_p2p_close(pvae_ctx* c) {
-    if (!c) return fail(-1, "null ctx");
-    pvae_ctx::P2p& P = c->p2p;
-    for (int q = 0; q < PVAE_P2P_MAX_RANKS; ++q)
-        for (int k = 0; k < 4; ++k) {
-            if (!P.mapped[q][k]) continue;
-            bool dup = false;                             // one mapping may serve two buffers of a peer
-            for (int j = 0; j < k; ++j) dup = dup || P.mapped[q][j] == P.mapped[q][k];
-            if (!dup) (void)hipIpcCloseMemHandle(P.mapped[q][k]);
-        }
-    memset(P.mapped, 0, sizeof(P.mapped));
-    memset(P.grads, 0, sizeof(P.grads)); memset(P.params, 0, sizeof(P.params)); memset(P.peer_flags, 0, sizeof(P.peer_flags));
-    memset(P.peer_staging, 0, sizeof(P.peer_staging));
-    P.open = false; P.world = 0; P.rank = 0;
-    if (c->exchange_mode == PVAE_EXCHANGE_P2P || c->exchange_mode == PVAE_EXCHANGE_P2P_PUSH) c->exchange_mode = PVAE_EXCHANGE_ALLREDUCE;
-    if (!c->comm) { c->comm_world = 1; c->comm_rank = 0; }
-    return 0;
-}
-
-int pvae_p2p_open(pvae_ctx* c, int rank, int world, const void* blobs) {
-    if (!c || !blobs) return fail(-1, "null argument");
-    if (world < 1 || world > PVAE_P2P_MAX_RANKS || rank < 0 || rank >= world)
-        return fail(-1, "rank %d / world %d outside [0, %d]", rank, world, PVAE_P2P_MAX_RANKS);
-    pvae_ctx::P2p& P = c->p2p;
-    if (P.open) return fail(-2, "peer-mapped exchange already open");
-    if (!P.flags || !c->params || !c->grads) return fail(-2, "pvae_p2p_export first");
-    if (c->comm && (c->comm_world != world || c->comm_rank != rank))
-        return fail(-1, "rank %d / world %d differ from the RCCL communicator's %d / %d", rank, world, c->comm_rank, c->comm_world);
-    const char* all = (const char*)blobs;
-    for (int q = 0; q < world; ++q) {
-        P2pBlob b;
-        memcpy(&b, all + (size_t)q * PVAE_P2P_BLOB_BYTES, sizeof(b));
-        if (b.magic != kP2pMagic || b.abi != PVAE_ABI_VERSION || b.arena_floats != c->L.arena_floats) {
-            pvae_p2p_close(c);
-            return fail(-1, "blob of rank %d does not describe a matching ctx", q);
-        }
-        if (q == rank) {
-            P.grads[q] = c->grads; P.params[q] = c->params; P.peer_flags[q] = P.flags; P.peer_staging[q] = P.staging;
-            continue;
-        }
-        void* base[4] = {nullptr, nullptr, nullptr, nullptr};
-        for (int k = 0; k < 4; ++k) {
-            for (int j = 0; j < k; ++j)                   // two buffers inside one allocation: open it once
-                if (memcmp(&b.h[j], &b.h[k], sizeof(b.h[k])) == 0) base[k] = base[j];
-            if (!base[k]) {
-                hipError_t e = hipIpcOpenMemHandle(&base[k], b.h[k], hipIpcMemLazyEnablePeerAccess);
-                if (e != hipSuccess) {
-                    pvae_p2p_close(c);
-                    return fail(-10, "hipIpcOpenMemHandle(rank %d, buffer %d): %s", q, k, hipGetErrorString(e));
-                }
-            }
-            P.mapped[q][k] = base[k];
-        }
-        P.grads[q] = (float*)((char*)base[0] + b.off[0]);
-        P.params[q] = (float*)((char*)base[1] + b.off[1]);
-        P.peer_flags[q] = (unsigned*)((char*)base[2] + b.off[2]);
-        P.peer_staging[q] = (float*)((char*)base[3] + b.off[3]);
-    }
-    P.rank = rank; P.world = world; P.epoch = 0; P.open = true;
-    c->comm_rank = rank; c->comm_world = world;
-    int rc = ensure_comm_stream(c);
-    if (rc) return rc;
-    return 0;
-}
-
-int pvae_p2p_status(pvae_ctx* c, int* rank, int* world, uint32_t* timeouts, void* stream) {
-    if (!c) return fail(-1, "null ctx");
-    if (rank) *rank = c->p2p.open ? c->p2p.rank : 0;
-    if (world) *world = c->p2p.open ? c->p2p.world : 0;
-    if (timeouts) {
-        *timeouts = 0;
-        if (c->p2p.flags) {
-            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-            if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
-            HIP_TRY(hipMemcpy(timeouts, c->p2p.flags + kP2pErr, sizeof(uint32_t), hipMemcpyDeviceToHost));
-        }
-    }
-    return 0;
-}
-
-int pvae_p2p_selftest(pvae_ctx* c, void* stream) {
-    if (!c) return fail(-1, "null ctx");
-    pvae_ctx::P2p& P = c->p2p;
-    if (!P.open) return fail(-2, "peer-mapped exchange not open (pvae_p2p_open)");
-    hipStream_t st = (hipStream_t)stream;
-    P2pArgs a;
-    memset(&a, 0, sizeof(a));
-    for (int q = 0; q < P.world; ++q) a.f[q] = P.peer_flags[q];
-    a.me = P.rank;
-    a.timeout_ticks = P.timeout_ticks < 100000000ll ? P.timeout_ticks : 100000000ll;      // at most 1 s
-    // (one token per call, the same on every rank: the waits compare with >=, so a second self-test on the same flag
-    //  block must not be satisfied by the first one's tokens)
-    const unsigned token = 0x5E1F0000u + (++P.selftests) * 16u + (unsigned)P.world;
-    uint32_t before = 0, after = 0;
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipMemcpy(&before, P.flags + kP2pErr, sizeof(before), hipMemcpyDeviceToHost));
-    // (1) the uncached flag block: remote write, remote read, flag delivery
-    hipLaunchKernelGGL(p2p_selftest_kernel, dim3(1), dim3(64), 0, st, a, P.world, token);
-    HIP_TRY(hipGetLastError());
-    // (2) the cached arenas, through the exchange's own access paths (see p2p_self_prime_kernel)
-    const bool arenas = P.world > 1 && c->L.arena_floats >= kSelfFloats && !c->p2p_selftest_flags_only;
-    if (arenas) {
-        if (!P.self_buf) HIP_TRY(hipMalloc((void**)&P.self_buf, (2 * kSelfFloats + kSelfGrid) * sizeof(float)));
-        SelfArgs s;
-        memset(&s, 0, sizeof(s));
-        s.a = a;
-        for (int q = 0; q < P.world; ++q) {
-            s.a.g[q] = P.grads[q]; s.a.p[q] = P.params[q];
-            s.a.stage[q] = P.peer_staging[q] + c->L.arena_floats;        // the 256-float tail behind the arena-sized part
-        }
-        s.save = P.self_buf; s.sink = (unsigned*)(P.self_buf + 2 * kSelfFloats); s.n = P.world; s.token = token;
-        hipLaunchKernelGGL(p2p_self_prime_kernel, dim3(kSelfGrid), dim3(64), 0, st, s);
-        hipLaunchKernelGGL(p2p_self_write_kernel, dim3(1), dim3(64), 0, st, s);
-        hipLaunchKernelGGL(p2p_self_verify_kernel, dim3(kSelfGrid), dim3(64), 0, st, s);
-        hipLaunchKernelGGL(p2p_self_gradb_kernel, dim3(1), dim3(64), 0, st, s);
-        hipLaunchKernelGGL(p2p_self_reread_kernel, dim3(1), dim3(64), 0, st, s);
-        hipLaunchKernelGGL(p2p_self_restore_kernel, dim3(1), dim3(64), 0, st, s);
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipMemcpy(&after, P.flags + kP2pErr, sizeof(after), hipMemcpyDeviceToHost));
-    if (after != before) {
-        HIP_TRY(hipMemcpy(P.flags + kP2pErr, &before, sizeof(before), hipMemcpyHostToDevice));
-        return fail(-22, "peer-mapped exchange self-test failed on rank %d: %u record(s) / flag(s) / arena word(s) from peers wrong, "
-                         "stale or missing", P.rank, after - before);
-    }
-    return 0;
-}
-
-/* Zero the "waits that gave up" word (after the caller has dealt with them: a rejected calibration candidate,
- * a restored snapshot).  Synchronises `stream`. */
-int pvae_p2p_clear_errors(pvae_ctx* c, void* stream) {
-    if (!c) return fail(-1, "null ctx");
-    if (!c->p2p.flags) return 0;
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    if (c->comm_stream) HIP_TRY(hipStreamSynchronize(c->comm_stream));
-    const uint32_t zero = 0;
-    HIP_TRY(hipMemcpy(c->p2p.flags + kP2pErr, &zero, sizeof(zero), hipMemcpyHostToDevice));
-    return 0;
-}
-
-// one bucket through the peer-mapped exchange (see p2p_exchange_kernel)
-static int p2p_exchange(pvae_ctx* c, int net, int64_t off, int64_t cnt, const pvae_step_params* sp, hipStream_t cs) {
-    pvae_ctx::P2p& P = c->p2p;
-    if (!P.open) return fail(-2, "peer-mapped exchange not open (pvae_p2p_open)");
-    if (!c->m || !c->v) return fail(-2, "Adam moment arenas not bound");
-    if (P.grads[P.rank] != c->grads || P.params[P.rank] != c->params) return fail(-2, "arenas were re-bound after pvae_p2p_export");
-    if ((off & 3) || (cnt & 3) || cnt <= 0) return fail(-1, "bucket [%lld, +%lld) not float4-aligned", (long long)off, (long long)cnt);
-    // (the kernels address a bucket through 32-bit buffer descriptors: one bucket stays below 4 GiB -- a billion
-    //  parameters; larger stacks go through in several buckets, PVAE_DP_BUCKET_MB)
-    if (cnt + 4 * (int64_t)P.world >= ((int64_t)1 << 30)) return fail(-1, "bucket of %lld floats: the peer-mapped exchange takes < 2^30 per bucket", (long long)cnt);
-    P2pArgs a;
-    memset(&a, 0, sizeof(a));
-    for (int q = 0; q < P.world; ++q) {
-        a.g[q] = P.grads[q] + off; a.p[q] = P.params[q] + off; a.f[q] = P.peer_flags[q]; a.stage[q] = P.peer_staging[q];
-    }
-    const bool push = c->exchange_mode == PVAE_EXCHANGE_P2P_PUSH;
-    a.m = c->m + off; a.v = c->v + off;
-    a.n4 = cnt / 4; a.me = P.rank; a.epoch = ++P.epoch; a.timeout_ticks = P.timeout_ticks;
-    a.s = adam_scalars(sp, net);
-    const long long slice = (a.n4 + P.world - 1) / P.world;
-    int grid = (int)((slice + 255) / 256);
-    if (grid > 256) grid = 256;
-    if (grid < 1) grid = 1;
-    const int ps = g_prof.begin_range(4, (double)cnt * sizeof(float), cs);
-    switch (P.world) {
-#define PVAE_P2P_CASE(N) case N:                                                                         \
-        if (push) hipLaunchKernelGGL((p2p_push_exchange_kernel<N>), dim3(grid), dim3(256), 0, cs, a); \
-        else hipLaunchKernelGGL((p2p_exchange_kernel<N>), dim3(grid), dim3(256), 0, cs, a);           \
-        break;
-        PVAE_P2P_CASE(1) PVAE_P2P_CASE(2) PVAE_P2P_CASE(3) PVAE_P2P_CASE(4)
-        PVAE_P2P_CASE(5) PVAE_P2P_CASE(6) PVAE_P2P_CASE(7) PVAE_P2P_CASE(8)
-#undef PVAE_P2P_CASE
-        default: return fail(-1, "world %d", P.world);
-    }
-    HIP_TRY(hipGetLastError());
-    g_prof.end_range(ps, cs);
-    return 0;
-}
-
-int pvae_p2p_exchange(pvae_ctx* c, int net, int64_t offset, int64_t count, const pvae_step_params* sp, void* stream) {
-    int rc = check_ready(c, true);
-    if (rc) return rc;
-    if (!sp) return fail(-1, "null step params");
-    if (net < 0 || net >= PVAE_NUM_NETS) return fail(-1, "bad net id %d", net);
-    const NetLayout& N = c->L.net[net];
-    if (offset < N.off || count < 0 || offset + count > N.off + N.count)
-        return fail(-1, "segment [%lld, +%lld) not inside net %d", (long long)offset, (long long)count, net);
-    if (count == 0) return 0;
-    params_touched(c, (hipStream_t)stream);
-    return p2p_exchange(c, net, offset, count, sp, (hipStream_t)stream);
-}
-
-int pvae_comm_mode(pvae_ctx* c, int mode) {
-    if (!c) return fail(-1, "null ctx");
-    if (mode == PVAE_EXCHANGE_P2P || mode == PVAE_EXCHANGE_P2P_PUSH) {
-        if (!c->p2p.open) return fail(-2, "peer-mapped exchange not open (pvae_p2p_export / pvae_p2p_open)");
-        c->exchange_mode = mode;
-        return 0;
-    }
-    if (mode == PVAE_EXCHANGE_LOCAL) {
-        if (!c->comm && !c->p2p.open) return fail(-2, "no communicator and no peer-mapped exchange");
-        c->exchange_mode = mode;
-        return 0;
-    }
-    if (mode != PVAE_EXCHANGE_ALLREDUCE && mode != PVAE_EXCHANGE_SHARDED) return fail(-1, "unknown exchange mode %d", mode);
-    if (mode == PVAE_EXCHANGE_SHARDED) {
-        int rc = rccl_load();
-        if (rc) return rc;
-        if (!g_rccl.ReduceScatter || !g_rccl.AllGather) return fail(-20, "RCCL lacks ncclReduceScatter / ncclAllGather");
-    }
-    c->exchange_mode = mode;
-    return 0;
-}
-
-int pvae_comm_info(pvae_ctx* c, int* rank, int* nranks) {
-    if (!c || !rank || !nranks) return fail(-1, "null argument");
-    *rank = 0; *nranks = 0;
-    if (!c->comm) return 0;                    // no communicator: 0 ranks
-    if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(-20, "RCCL lacks ncclCommCount / ncclCommUserRank");
-    RCCL_TRY(g_rccl.CommCount(c->comm, nranks));
-    RCCL_TRY(g_rccl.CommUserRank(c->comm, rank));
-    return 0;
-}
-
-int pvae_comm_config(pvae_ctx* c, int64_t bucket_bytes, int32_t test_delay_us) {
-    if (!c) return fail(-1, "null ctx");
-    if (bucket_bytes < 0 || test_delay_us < 0 || test_delay_us > 100000) return fail(-1, "bad exchange settings");
-    c->bucket_bytes = bucket_bytes;
-    c->comm_test_delay_us = test_delay_us;
-    return 0;
-}
-
-int pvae_comm_destroy(pvae_ctx* c) {
-    if (!c) return fail(-1, "null ctx");
-    if (c->comm) {
-        RCCL_TRY(g_rccl.CommDestroy(c->comm));
-        c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0;
-    }
-    if (c->p2p.open) { c->comm_world = c->p2p.world; c->comm_rank = c->p2p.rank; }
-    if (c->comm_stream && !c->p2p.open) {
-        HIP_TRY(hipStreamSynchronize(c->comm_stream));
-        HIP_TRY(hipStreamDestroy(c->comm_stream));
-        c->comm_stream = nullptr;
-        for (hipEvent_t& e : c->bucket_ready) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-        if (c->comm_done) (void)hipEventDestroy(c->comm_done);
-        c->comm_done = nullptr;
-    }
-    return 0;
-}
-
-// Exchange buckets of one stack: whole layers, last layer first (the order the backward pass
-// finishes them), closed as soon as they hold bucket_bytes.  A function of the layout and the
-// bucket size only, so every rank -- also one whose shard of a ragged last batch is empty --
-// issues the same sequence of reductions.
-struct Bucket { int64_t off, cnt; };
-// Default exchange schedule.  With one rank there is nothing to hide: in line.  With several ranks the
-// all-reduce of a stack (14 MB) takes about as long over xGMI as the backward pass of a stack (~100 us), so
-// in the JOINT phase the decoder's reduction is worth hiding behind the encoder's backward pass even at the
-// ~27 us the two stream hand-offs cost (section 5 of DESIGN.md): 6 MiB buckets on the exchange stream.  The
-// world phase has one stack and ~36 us of backward left after its first bucket closes: in line.
-// A function of (communicator size, phase) only, so every rank chooses the same.
-static int64_t auto_bucket_bytes(const pvae_ctx* c, int phase) {
-    if (c->bucket_bytes >= 0) return c->bucket_bytes;
-    return (c->comm_world > 1 && phase == PVAE_PHASE_JOINT && c->comm_stream) ? (int64_t)6 << 20 : 0;
-}
-static std::vector<Bucket> exchange_buckets(const pvae_ctx* c, int net) {
-    const NetLayout& N = c->L.net[net];
-    std::vector<Bucket> out;
-    if (c->bucket_bytes_now <= 0) { out.push_back({N.off, N.count}); return out; }
-    int64_t end = N.off + N.count;
-    for (int i = (int)N.layers.size() - 1; i >= 0; --i) {
-        const int64_t lo = i == 0 ? N.off : N.layers[i].w_off;
-        if ((end - lo) * (int64_t)sizeof(float) >= c->bucket_bytes_now || i == 0) {
-            out.push_back({lo, end - lo});
-            end = lo;
-        }
-    }
-    return out;
-}
-
-int pvae_owned_slices(pvae_ctx* c, int phase, int net, int64_t* offsets, int64_t* counts, int32_t* replicated,
-                      int32_t max, int32_t* n) {
-    if (!c || !offsets || !counts || !replicated || !n) return fail(-1, "null argument");
-    if (net < 0 || net >= PVAE_NUM_NETS) return fail(-1, "bad net id %d", net);
-    if (phase != PVAE_PHASE_WORLD && phase != PVAE_PHASE_JOINT) return fail(-1, "unknown phase %d", phase);
-    *n = 0;
-    if (c->L.net[net].layers.empty()) return 0;
-    const int64_t N = c->comm_world > 0 ? c->comm_world : 1, r = c->comm_rank;
-    const int64_t keep = c->bucket_bytes_now;
-    c->bucket_bytes_now = auto_bucket_bytes(c, phase);
-    const std::vector<Bucket> bk = exchange_buckets(c, net);
-    c->bucket_bytes_now = keep;
-    const bool p2p = c->exchange_mode == PVAE_EXCHANGE_P2P || c->exchange_mode == PVAE_EXCHANGE_P2P_PUSH;
-    for (const Bucket& b : bk) {
-        int64_t off = b.off, cnt = b.cnt;
-        int rep = 1;
-        if (N > 1 && p2p) {
-            const int64_t n4 = b.cnt / 4, S = (n4 + N - 1) / N, lo = r * S, hi = lo + S < n4 ? lo + S : n4;
-            off = b.off + 4 * lo; cnt = lo < hi ? 4 * (hi - lo) : 0; rep = 0;
-        } else if (N > 1 && c->exchange_mode == PVAE_EXCHANGE_SHARDED && g_rccl.ReduceScatter && g_rccl.AllGather &&
-                   b.cnt % (N * 4) == 0 && b.cnt > 0) {
-            cnt = b.cnt / N; off = b.off + r * cnt; rep = 0;
-        }
-        if (*n >= max) return fail(-1, "more than %d buckets", (int)max);
-        offsets[*n] = off; counts[*n] = cnt; replicated[*n] = rep;
-        ++*n;
-    }
-    return 0;
-}
-
-__global__ void spin_kernel(long long ticks) {
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
-
-// Reduce one bucket over the ranks and apply Adam to it.  `cs` == `st`: in line.  Otherwise the
-// bucket is handed to the exchange stream behind an event, and the compute stream carries on.
-static int exchange_bucket(pvae_ctx* c, int net, const Bucket& b, const pvae_step_params* sp, hipStream_t st,
-                           hipStream_t cs, int& n_events) {
-    int rc;
-    if (cs != st) {
-        if (n_events >= pvae_ctx::kMaxBuckets) return fail(-2, "more than %d exchange buckets in a step", pvae_ctx::kMaxBuckets);
-        hipEvent_t e = c->bucket_ready[n_events++];
-        HIP_TRY(hipEventRecord(e, st));
-        HIP_TRY(hipStreamWaitEvent(cs, e, 0));
-    }
-    if (c->comm_test_delay_us > 0) {
-        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, cs, (long long)c->comm_test_delay_us * 100);   // 100 MHz
-        HIP_TRY(hipGetLastError());
-    }
-    // Sharded exchange (PVAE_EXCHANGE_SHARDED, ZeRO-1 shaped): every rank reduces only ITS 1/N slice of the
-    // bucket (reduce-scatter, in place), applies Adam to that slice (1/N of the p, g, m, v traffic) and the
-    // updated parameter slices are all-gathered in place.  Same bytes on the links as a ring all-reduce;
-    // the moments of the other ranks' slices are never touched here (they stay at whatever they were).
-    if (c->exchange_mode == PVAE_EXCHANGE_P2P || c->exchange_mode == PVAE_EXCHANGE_P2P_PUSH)
-        return p2p_exchange(c, net, b.off, b.cnt, sp, cs);
-    if (c->exchange_mode == PVAE_EXCHANGE_LOCAL) return pvae_adam_segment(c, net, b.off, b.cnt, sp, cs);
-    const int64_t N = c->comm_world;
-    if (c->exchange_mode == PVAE_EXCHANGE_SHARDED && g_rccl.ReduceScatter && g_rccl.AllGather &&
-        b.cnt % (N * 4) == 0 && b.cnt > 0) {
-        const int64_t slice = b.cnt / N, mine = b.off + c->comm_rank * slice;
-        int ps = g_prof.begin_range(4, (double)b.cnt * sizeof(float), cs);
-        RCCL_TRY(g_rccl.ReduceScatter(c->grads + b.off, c->grads + mine, (size_t)slice, kNcclFloat32, kNcclSum, c->comm, cs));
-        g_prof.end_range(ps, cs);
-        if ((rc = pvae_adam_segment(c, net, mine, slice, sp, cs))) return rc;
-        ps = g_prof.begin_range(4, (double)b.cnt * sizeof(float), cs);
-        RCCL_TRY(g_rccl.AllGather(c->params + mine, c->params + b.off, (size_t)slice, kNcclFloat32, c->comm, cs));
-        g_prof.end_range(ps, cs);
-        return 0;
-    }
-    if ((rc = pvae_allreduce_grads(c, b.off, b.cnt, cs))) return rc;
-    return pvae_adam_segment(c, net, b.off, b.cnt, sp, cs);
-}
-
 static RowMap row_map(const pvae_ctx* c, int64_t first_window, int rows) {
     RowMap rm;
     rm.row = c->window_row + first_window;
@@ -3300,21 +2179,6 @@ int pvae_direct_active(pvae_ctx* c, int phase, int32_t rows, const pvae_step_par
     if (!c || !sp) return fail(-1, "null argument");
     if (check_ready(c, true)) return 0;
     return c->states && direct_ok(c, phase, rows, sp, fused != 0) ? 1 : 0;
-}
-
-int pvae_allreduce_grads(pvae_ctx* c, int64_t offset, int64_t count, void* stream) {
-    int rc = check_ready(c, true);
-    if (rc) return rc;
-    if (!c->comm) return fail(-2, "no communicator (pvae_comm_init)");
-    if (!c->grads) return fail(-2, "gradient arena not bound");
-    if (offset < 0 || count < 0 || offset + count > c->L.arena_floats)
-        return fail(-1, "slice [%lld, +%lld) outside the arena", (long long)offset, (long long)count);
-    if (count == 0) return 0;
-    const int ps = g_prof.begin_range(4, (double)count * sizeof(float), (hipStream_t)stream);
-    RCCL_TRY(g_rccl.AllReduce(c->grads + offset, c->grads + offset, (size_t)count, kNcclFloat32, kNcclSum, c->comm,
-                              (hipStream_t)stream));
-    g_prof.end_range(ps, (hipStream_t)stream);
-    return 0;
 }
 
 int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t rows, const pvae_step_params* sp,
@@ -3620,738 +2484,6 @@ static int infer_impl(pvae_ctx* c, const float* obs, int32_t rows, const float* 
 
 }   // extern "C"
 
-// ---------------------------------------------------------------------------------------
-// Call-persistent rollout server (rmt:742-771 at B = 1; callers envs/rllib_env_imitation.py:215-266).
-//
-// The per-layer launches above cost the control loop 7 dependent launches whose weights are a cold fetch each
-// (35 us device -> device).  Here ONE kernel stays resident across calls on the 32 CUs of ONE XCD.  It copies the
-// encoder's and the decoder's weights into LDS once (every workgroup holds the rows of 1/32 of every layer's output
-// features: 3.4 MB over 32 x 160 KB for the default stacks), then serves requests from a mailbox in pinned host
-// memory: workgroup 0 polls the request word over PCIe, fetches the observation, and releases the other 31
-// through a word in the XCD's L2; every layer is a GEMV from LDS-resident weights followed by the single-XCD L2
-// barrier of tools/xcd_barrier.hip (arrive = atomic add that executes in the L2, poll = sc1 load, payload = plain
-// stores drained before arriving and read back with sc1 loads: 1.2 us per round); the sampler of rmt:734-740 is
-// formed in place by every workgroup; after the last barrier workgroup 0 writes [a_hat | mu | logvar | z] to the
-// mailbox and then the completion word.  No launch, no stream operation and no cold weight fetch per call.
-// The arithmetic of a feature is gemv_rollout_kernel's, operation for operation (same lane -> k mapping, same fma
-// chain, same butterfly), so the action equals pvae_infer's bit for bit.
-// Bounded by construction: workgroup 0 gives up after `idle_ticks` without a request (the host relaunches on the
-// next call), every spin re-checks an absolute lifetime, and a stop command ends it at once.  While it is resident,
-// a DEVICE-wide synchronisation (hipDeviceSynchronize, hipFree) waits for it -- at most the idle time-out.
-// ---------------------------------------------------------------------------------------
-constexpr int kSrvMaxLayers = 12, kSrvMaxObs = 2048, kSrvMaxOut = 1024;
-struct SrvRequest {                       // host -> device.  Lives in DEVICE memory when the host can write it directly
-    // (large BAR: the host PUSHES the observation and the kernel polls local memory), else in pinned host memory (the
-    // kernel PULLS over PCIe).  ONE 32-byte line of control words, then the observation.
-    volatile uint32_t req_seq;            // written LAST by the host: request number
-    uint32_t cmd;                         // 0 infer, 1 stop, 2 reload the weights from the arena, then infer,
-                                          // 3 decoder only ("pass_through", rllib_env_imitation.py:233-258): obs = [s1 (Db) | z (Z)]
-    uint32_t noise, pad0;
-    uint32_t seed_lo, seed_hi, off_lo, off_hi;
-    uint32_t pad1[8];
-    float obs[kSrvMaxObs];
-};
-struct SrvReply {                         // device -> host, pinned host memory (the host spins on its own RAM)
-    volatile uint32_t done_seq;           // written LAST by the device: the request this result belongs to
-    volatile uint32_t state;              // 0 not started, 1 serving, 2 exited (idle / stop / lifetime), 3 refused (placement)
-    uint32_t served, pad2[13];
-    float out[kSrvMaxOut];                // [a_hat (Da) | mu (Z) | logvar (Z) | z (Z)]
-};
-struct SrvLayer { long long w_off, b_off; int ld, n_out_pad, n_out, act, F, lds_off; };   // F: features per group (the last
-                                                                                          // active group may own fewer)
-constexpr int kSrvActStride = 2048;
-struct SrvArgs {
-    SrvLayer layer[kSrvMaxLayers];
-    int n_layers, n_te;                   // layers [0, n_te) are the encoder's, the rest the decoder's
-    int groups, one_xcd;                  // 32 workgroups on ONE XCD, or 256 over the whole chip (stacks too big for one XCD's LDS)
-    int xcd;                              // which XCD (one_xcd): servers of one process take different ones
-    int Db, Da, Z, prior_kind;
-    const float* params;
-    unsigned long long* acts;             // [n_layers + 1][kSrvActStride] TAGGED values: slot 0 = the observation, slot l + 1 = layer l's output
-    unsigned* sync;                       // device words: 0 start-up barrier, 1 go_seq, 2..8 the request's control words, 16 xcc of group 0, 17 error, 18 group 0 has left
-    SrvRequest* req;                      // device view of the request block
-    SrvReply* mb;                         // device view of the reply block
-    int obs_direct;                       // the request block is device memory: every group reads the observation from it
-    long long idle_ticks, life_ticks;     // 100 MHz wall clock
-    int xs_off;                           // float offset of the input vector inside the dynamic LDS
-    unsigned seq0;                        // requests served by earlier instances (this one answers seq0 + 1, ...)
-    unsigned long long* dbg;              // [64] wall-clock stamps of group 0 for the LAST request (pvae_rollout_server_timeline)
-};
-__device__ inline unsigned srv_ldu(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // sc1: past the L1
-// A value travels between workgroups as ONE 8-byte word {tag, float bits}: the consumer polls the word itself (sc1 loads,
-// served by the XCD's L2) until it carries the tag of this request and layer -- no barrier between a layer and the next,
-// one L2 round trip after the producer's store has landed.  Tags only grow (request * 16 + layer), so a word left over from
-// an earlier request can never be mistaken.
-__device__ inline void srv_put(unsigned long long* slot, float v, unsigned tag) {
-    __hip_atomic_store(slot, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ inline float srv_get(const unsigned long long* slot, unsigned tag, long long t_start, long long life, int& failed,
-                                const unsigned* gone) {
-    unsigned long long u;
-    unsigned spins = 0;
-    while ((unsigned)((u = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag) {
-        // (a producer that never comes: group 0 left on its idle time-out just as this request arrived, or the lifetime is over)
-        if ((++spins & 255u) == 0 && (srv_ldu(gone) != 0u || wall_clock64() - t_start > life)) { failed = 1; break; }
-    }
-    return __uint_as_float((unsigned)u);
-}
-
-__device__ inline void srv_get2(const unsigned long long* p0, const unsigned long long* p1, unsigned tag, float& v0, float& v1,
-                                long long t_start, long long life, int& failed, const unsigned* gone) {
-    unsigned long long u0, u1;
-    unsigned spins = 0;
-    for (;;) {
-        u0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        u1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(u0 >> 32) == tag && (unsigned)(u1 >> 32) == tag) break;
-        if ((++spins & 255u) == 0 && (srv_ldu(gone) != 0u || wall_clock64() - t_start > life)) { failed = 1; break; }
-    }
-    v0 = __uint_as_float((unsigned)u0);
-    v1 = __uint_as_float((unsigned)u1);
-}
-// xs[k] = word k of `prev` for k = tid, tid + 256, ... < n (tag `tag`), ALL of a thread's words polled together: their loads are
-// in flight at once and a spin costs one round trip whatever the layer's width (one word after the other, a 1024-wide input
-// cost four round trips per layer: 34 us for the 4x1024 stacks against 19 now)
-__device__ inline void srv_get_row(float* xs, const unsigned long long* prev, int n, int ld, unsigned tag, int tid, long long t_start,
-                                   long long life, int& failed, const unsigned* gone) {
-    constexpr int kMax = kSrvActStride / 256;
-    unsigned long long u[kMax];
-    unsigned spins = 0;
-    for (;;) {
-        bool all = true;
-#pragma unroll
-        for (int i = 0; i < kMax; ++i) {
-            const int k = tid + 256 * i;
-            u[i] = k < n ? __hip_atomic_load(prev + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
-        }
-#pragma unroll
-        for (int i = 0; i < kMax; ++i) all = all && (unsigned)(u[i] >> 32) == tag;
-        if (all) break;
-        if ((++spins & 255u) == 0 && (srv_ldu(gone) != 0u || wall_clock64() - t_start > life)) { failed = 1; break; }
-    }
-#pragma unroll
-    for (int i = 0; i < kMax; ++i) {
-        const int k = tid + 256 * i;
-        if (k < ld) xs[k] = k < n ? __uint_as_float((unsigned)u[i]) : 0.f;
-    }
-}
-
-// Lane 0's value of `for (o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64)`: the halving tree r[i] += r[i + h], h = 32 ... 1
-// (additions commute, so only the association matters), with the two cross-row steps as gfx950's permlane swaps and the
-// four in-row steps as DPP row shifts -- register moves, where __shfl_xor compiles to a ds_bpermute round trip per step.
-// Lanes other than 0 hold partial garbage.
-__device__ inline float srv_tree_sum(float v) {
-    unsigned u = __float_as_uint(v);
-    v += __uint_as_float(__builtin_amdgcn_permlane32_swap(u, u, false, false)[1]);       // lanes 0..31 += lanes 32..63
-    u = __float_as_uint(v);
-    v += __uint_as_float(__builtin_amdgcn_permlane16_swap(u, u, false, false)[1]);       // lanes 0..15 += lanes 16..31
-    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x108, 0xf, 0xf, true));   // row_shl:8
-    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x104, 0xf, 0xf, true));
-    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x102, 0xf, 0xf, true));
-    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x101, 0xf, 0xf, true));
-    return v;
-}
-
-__global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float srv_lds[];
-    __shared__ unsigned s_word[8];
-    __shared__ int s_failed;
-    if (a.one_xcd && (int)(blockIdx.x & 7) != a.xcd) return;   // workgroup b runs on XCD b % 8: the 32 of one XCD stay
-    const int g = a.one_xcd ? blockIdx.x >> 3 : blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long t_start = wall_clock64();
-    float* xs = srv_lds + a.xs_off;
-    unsigned* ctr = a.sync;
-    if (tid == 0) s_failed = 0;
-    // placement check: all 32 groups must sit on the XCD of group 0 (the hand-overs live in ITS L2)
-    const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;
-    if (tid == 0) {
-        if (g == 0) {
-            __hip_atomic_store(a.sync + 1, a.seq0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (go word: nothing new yet)
-            __hip_atomic_store(a.sync + 16, xcc + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        unsigned x0;
-        while ((x0 = srv_ldu(a.sync + 16)) == 0u) {
-            if (wall_clock64() - t_start > a.life_ticks) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (a.one_xcd && x0 != xcc + 1u) atomicAdd(a.sync + 17, 1u);
-    }
-    auto load_weights = [&]() {
-        for (int l = 0; l < a.n_layers; ++l) {
-            const SrvLayer L = a.layer[l];
-            int nf = L.n_out_pad - g * L.F;                // this group's features of the layer (0: none -- narrow layers
-            nf = nf < 0 ? 0 : (nf > L.F ? L.F : nf);       //  leave the last groups idle)
-            const int n4 = nf * L.ld / 4;                  // its rows are contiguous in the arena
-            const v4f* src = reinterpret_cast<const v4f*>(a.params + L.w_off + (long long)g * L.F * L.ld);
-            v4f* dst = reinterpret_cast<v4f*>(srv_lds + L.lds_off);
-            for (int i = tid; i < n4; i += 256) dst[i] = src[i];
-            if (tid < nf) srv_lds[L.lds_off + L.F * L.ld + tid] = a.params[L.b_off + g * L.F + tid];
-        }
-        __syncthreads();
-    };
-    load_weights();
-    bool alive = true;
-    {   // start-up barrier in the XCD's L2 (once): everybody placed, checked and loaded
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned ok = 1;
-            while (srv_ldu(ctr) < (unsigned)a.groups) {
-                if (wall_clock64() - t_start > a.life_ticks) { ok = 0; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            s_word[7] = ok;
-        }
-        __syncthreads();
-        if (s_word[7] == 0) alive = false;
-    }
-    if (alive && srv_ldu(a.sync + 17) != 0u) {              // not on one XCD: refuse (the host falls back to the launches)
-        if (g == 0 && tid == 0) { a.mb->state = 3; __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
-        return;
-    }
-    if (g == 0 && tid == 0 && alive) { a.mb->state = 1; __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
-    unsigned last = a.seq0;                                // (request numbers keep growing across instances of the kernel:
-    while (alive) {                                        //  the tags of the hand-over words derive from them)
-        // ---- wait for a request: wave 0 of group 0 polls the mailbox's control line, the other groups the go word in the L2 ----
-        if (g == 0) {
-            if (wave == 0) {
-                const long long t_idle = wall_clock64();
-                const unsigned* line = (const unsigned*)&a.req->req_seq;
-                unsigned w = 0, seq = last, cmd = 1;
-                for (;;) {
-                    if (lane < 8) w = __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // one 32-byte read
-                    seq = __builtin_amdgcn_readlane(w, 0);
-                    if (seq != last) { cmd = __builtin_amdgcn_readlane(w, 1); break; }
-                    const long long now = wall_clock64();
-                    if (now - t_idle > a.idle_ticks || now - t_start > a.life_ticks) { seq = last + 1u; cmd = 1; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                // (no acquire fence: it would invalidate the L2, ~1.7 us; everything read after this point is read with
-                //  system- / agent-scope loads that do not hit stale lines, issued behind the load that saw the request word)
-                if (lane == 0) { s_word[0] = seq; s_word[1] = cmd; }
-                if (lane >= 2 && lane < 8) s_word[lane] = w;                   // noise, pad, seed lo / hi, offset lo / hi
-                if (!a.obs_direct) {
-                    // release the other groups at once (they start polling the observation's words)
-                    if (lane >= 1 && lane < 8)
-                        __hip_atomic_store(a.sync + 1 + lane, lane == 1 ? cmd : w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the control words have landed; a release store would
-                    if (lane == 0) __hip_atomic_store(a.sync + 1, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   //  write the L2 back)
-                }
-            }
-            __syncthreads();
-            if (s_word[1] != 1u && !a.obs_direct) {        // the observation: pinned host memory -> slot 0, tagged
-                const unsigned tag0 = s_word[0] * 16u;
-                const int n = s_word[1] == 3u ? a.Db + a.Z : 2 * a.Db;
-                for (int i = tid; i < n; i += 256)
-                    srv_put(a.acts + i, __hip_atomic_load(a.req->obs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), tag0);
-            }
-        } else if (a.obs_direct) {
-            // the request block is device memory: every group watches its control line itself (no hop through group 0);
-            // group 0's own exits (idle time-out, lifetime) still arrive through the go word
-            if (wave == 0) {
-                const unsigned* line = (const unsigned*)&a.req->req_seq;
-                unsigned w = 0, seq = last, cmd = 1, polls = 0;
-                for (;;) {
-                    if (lane < 8) w = __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    seq = __builtin_amdgcn_readlane(w, 0);
-                    if (seq != last) { cmd = __builtin_amdgcn_readlane(w, 1); break; }
-                    if ((++polls & 15u) == 0) {
-                        if (srv_ldu(a.sync + 18) != 0u || wall_clock64() - t_start > a.life_ticks + 100000000ll) { seq = last + 1u; cmd = 1; w = 0; break; }
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                // (no acquire fence: it would invalidate the L2, ~1.7 us; everything read after this point is read with
-                //  system- / agent-scope loads that do not hit stale lines, issued behind the load that saw the request word)
-                if (lane == 0) { s_word[0] = seq; s_word[1] = cmd; }
-                if (lane >= 2 && lane < 8) s_word[lane] = w;
-            }
-        } else {
-            if (tid == 0) {
-                unsigned seq;
-                while ((seq = srv_ldu(a.sync + 1)) == last) {
-                    if (wall_clock64() - t_start > a.life_ticks + 100000000ll) { seq = last + 1u; break; }   // (group 0 is gone)
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                s_word[0] = seq;
-                s_word[1] = 1;
-                if (seq == srv_ldu(a.sync + 1))
-                    for (int i = 1; i < 8; ++i) s_word[i] = srv_ldu(a.sync + 1 + i);
-            }
-        }
-        __syncthreads();
-        last = s_word[0];
-        const unsigned cmd = s_word[1];
-        if (cmd == 1u) break;
-        if (cmd == 2u) load_weights();
-        const int noise = (int)s_word[2];
-        const unsigned long long seed = s_word[4] | ((unsigned long long)s_word[5] << 32);
-        const unsigned long long offset = s_word[6] | ((unsigned long long)s_word[7] << 32);
-        const unsigned tag0 = last * 16u;
-        int failed = 0;
-        const bool stamp = g == 0 && tid == 0;
-        if (stamp) { a.dbg[0] = wall_clock64(); a.dbg[62] = (unsigned long long)clock64(); }   // request seen by group 0 (+ shader clock)
-        // ---- the layers: inputs polled word by word, outputs published word by word ----
-        const bool decode_only = cmd == 3u;                                  // the caller supplies z: the encoder is skipped
-        for (int l = decode_only ? a.n_te : 0; l < a.n_layers; ++l) {
-            const SrvLayer L = a.layer[l];
-            const unsigned long long* prev = a.acts + (size_t)l * kSrvActStride;   // slot l: the previous layer's output (0: obs)
-            const unsigned tagp = tag0 + (unsigned)l;
-            if (l == 0) {                                                    // [s1 | s2 | 0]
-                if (a.obs_direct) {                                          // (complete before the request word)
-                    for (int k = tid; k < L.ld; k += 256)
-                        xs[k] = k < 2 * a.Db ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
-                } else {
-                    srv_get_row(xs, a.acts, 2 * a.Db, L.ld, tag0, tid, t_start, a.life_ticks, failed, a.sync + 18);
-                }
-            } else if (l == a.n_te && decode_only) {                         // [s1 | z | 0] as the caller sent it
-                if (a.obs_direct) {
-                    for (int k = tid; k < L.ld; k += 256)
-                        xs[k] = k < a.Db + a.Z ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
-                } else {
-                    srv_get_row(xs, a.acts, a.Db + a.Z, L.ld, tag0, tid, t_start, a.life_ticks, failed, a.sync + 18);
-                }
-            } else if (l == a.n_te) {                                        // [s1 | z | 0], the sampler formed in place
-                for (int k = tid; k < L.ld; k += 256) {
-                    float v = 0.f;
-                    if (k < a.Db) v = a.obs_direct ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                                   : srv_get(a.acts + k, tag0, t_start, a.life_ticks, failed, a.sync + 18);
-                    else if (k < a.Db + a.Z) {
-                        const int j = k - a.Db;
-                        if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_get(prev + j, tagp, t_start, a.life_ticks, failed, a.sync + 18);
-                        else {
-                            const float e = noise ? philox_normal(seed, offset, 0, j) : 0.f;       // (before the wait: off its path)
-                            float mu, lv;
-                            srv_get2(prev + j, prev + a.Z + j, tagp, mu, lv, t_start, a.life_ticks, failed, a.sync + 18);
-                            v = mu + e * expf(0.5f * lv);
-                        }
-                    }
-                    xs[k] = v;
-                }
-            } else {
-                srv_get_row(xs, prev, L.ld, L.ld, tagp, tid, t_start, a.life_ticks, failed, a.sync + 18);
-            }
-            if (failed) s_failed = 1;
-            __syncthreads();
-            if (stamp) a.dbg[1 + 2 * l] = wall_clock64();                    // layer l: inputs in LDS
-            const float* Wl = srv_lds + L.lds_off;
-            unsigned long long* outp = a.acts + (size_t)(l + 1) * kSrvActStride;
-            // one wave per feature, gemv_rollout_kernel's sum operation for operation -- four features of the wave at a time,
-            // so that their reductions overlap, and the butterfly as register moves (srv_tree_sum) instead of six
-            // ds_bpermute round trips per feature
-            int nf = L.n_out_pad - g * L.F;
-            nf = nf < 0 ? 0 : (nf > L.F ? L.F : nf);
-            for (int f0 = wave; f0 < nf; f0 += 16) {
-                const int cnt = (nf - f0 + 3) >> 2;                          // features f0, f0 + 4, ... of this wave in this pass
-                auto rows = [&](auto nrows) {                                // (one unguarded body per count: the LDS reads of a
-                    constexpr int N = decltype(nrows)::value;                //  k-step are in flight together)
-                    float acc[N];
-#pragma unroll
-                    for (int i = 0; i < N; ++i) acc[i] = 0.f;
-                    for (int k = lane * 4; k < L.ld; k += 256) {
-                        const v4f xv = *reinterpret_cast<const v4f*>(xs + k);
-                        v4f wv[N];
-#pragma unroll
-                        for (int i = 0; i < N; ++i) wv[i] = *reinterpret_cast<const v4f*>(Wl + (f0 + 4 * i) * L.ld + k);
-#pragma unroll
-                        for (int i = 0; i < N; ++i)
-                            acc[i] = fmaf(wv[i].x, xv.x, fmaf(wv[i].y, xv.y, fmaf(wv[i].z, xv.z, fmaf(wv[i].w, xv.w, acc[i]))));
-                    }
-#ifdef PVAE_SRV_FINE
-                    if (stamp && l == 4) a.dbg[40] = wall_clock64();
-#endif
-#pragma unroll
-                    for (int i = 0; i < N; ++i) acc[i] = srv_tree_sum(acc[i]);
-#ifdef PVAE_SRV_FINE
-                    if (stamp && l == 4) a.dbg[41] = wall_clock64();
-#endif
-                    // lane i finishes feature i (bias, activation, hand-over word): the N epilogues run side by side instead of
-                    // one after the other on lane 0 (0.6 us of a 1.3 us layer when they did)
-                    float mine = 0.f;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) {
-                        const float si = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc[i]), 0));
-                        mine = lane == i ? si : mine;
-                    }
-                    if (lane < N) {
-                        const int f = f0 + 4 * lane, n = g * L.F + f;
-                        float v = mine + Wl[L.F * L.ld + f];
-                        v = (L.act > 1 && n >= L.n_out) ? 0.f : act_apply(v, L.act);
-                        srv_put(outp + n, v, tagp + 1u);
-                    }
-                };
-#ifdef PVAE_SRV_FINE
-                if (stamp && l == 4) a.dbg[39] = wall_clock64();
-#endif
-                if (cnt >= 4) rows(std::integral_constant<int, 4>());
-                else if (cnt == 3) rows(std::integral_constant<int, 3>());
-                else if (cnt == 2) rows(std::integral_constant<int, 2>());
-                else rows(std::integral_constant<int, 1>());
-            }
-            // (a bare barrier: only LDS is shared here.  __syncthreads() would also wait for the hand-over stores above to be
-            //  acknowledged by the memory system -- half a microsecond per layer that now overlaps the next layer's polling)
-#ifdef PVAE_SRV_FINE
-            if (stamp && l == 4) a.dbg[42] = wall_clock64();
-#endif
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (stamp) a.dbg[2 + 2 * l] = wall_clock64();                    // layer l: this group's outputs published
-            if (s_failed) break;
-        }
-        if (s_failed) { alive = false; break; }
-        // ---- result: group 0 -> mailbox, payload first, completion word last ----
-        if (g == 0) {
-            const unsigned long long* md_out = a.acts + (size_t)a.n_layers * kSrvActStride;
-            const unsigned long long* te_out = a.acts + (size_t)a.n_te * kSrvActStride;
-            const unsigned tag_md = tag0 + (unsigned)a.n_layers, tag_te = tag0 + (unsigned)a.n_te;
-            const int n_out = decode_only ? a.Da : a.Da + 3 * a.Z;           // (decoder only: just the action)
-            for (int i = tid; i < n_out; i += 256) {
-                float v;
-                if (i < a.Da) v = srv_get(md_out + i, tag_md, t_start, a.life_ticks, failed, a.sync + 18);
-                else if (i < a.Da + 2 * a.Z) v = a.prior_kind == PVAE_PRIOR_NONE && i >= a.Da + a.Z ? 0.f
-                                                 : srv_get(te_out + (i - a.Da), tag_te, t_start, a.life_ticks, failed, a.sync + 18);
-                else {                                                       // z as the decoder saw it (same expression as above)
-                    const int j = i - a.Da - 2 * a.Z;
-                    if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_get(te_out + j, tag_te, t_start, a.life_ticks, failed, a.sync + 18);
-                    else {
-                        const float e = noise ? philox_normal(seed, offset, 0, j) : 0.f;
-                        float mu, lv;
-                        srv_get2(te_out + j, te_out + a.Z + j, tag_te, mu, lv, t_start, a.life_ticks, failed, a.sync + 18);
-                        v = mu + e * expf(0.5f * lv);
-                    }
-                }
-                __hip_atomic_store(a.mb->out + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            // (no read of host memory on this path, and no release fence -- it would write the whole L2 back, twice: the payload
-            //  went out as system-scope stores that are not cached, the wait above saw them acknowledged, and posted writes of
-            //  one agent arrive in order)
-            if (tid == 0) {
-                __hip_atomic_store(&a.mb->done_seq, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                a.dbg[1 + 2 * a.n_layers] = wall_clock64();                  // completion word issued
-                a.dbg[2 + 2 * a.n_layers] = (unsigned long long)a.n_layers;
-                a.dbg[63] = (unsigned long long)clock64();
-            }
-        }
-    }
-    if (g == 0 && tid == 0) {
-        __hip_atomic_store(a.sync + 18, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);       // "group 0 has left" (see srv_get)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        __hip_atomic_store(&a.mb->state, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-struct RolloutServer {
-    SrvReply* mb = nullptr;               // hipHostMalloc (mapped)
-    SrvReply* mb_dev = nullptr;
-    SrvRequest* req = nullptr;            // host view of the request block (device mode: the device pointer itself, written through the BAR)
-    SrvRequest* req_dev = nullptr;
-    bool req_on_device = false;
-    unsigned* sync = nullptr;             // device
-    unsigned long long* dbg = nullptr;    // device: group 0's stamps of the last request
-    unsigned long long* acts = nullptr;   // device: tagged hand-over words
-    hipStream_t stream = nullptr;
-    SrvArgs args{};
-    size_t lds_bytes = 0;
-    uint32_t seq = 0, served = 0;
-    unsigned long long loaded_version = 0;   // pvae_ctx::param_version of the resident weights
-    int scope = 0, xcd = -1;
-    bool launched = false;
-    double idle_ms = 100.0, life_s = 600.0;
-};
-
-// LDS bytes per workgroup when every layer's output features are dealt out over `groups` workgroups (0: a layer or the
-// observation is wider than the server takes); fills S.args.layer / counts
-static size_t server_layout(pvae_ctx* c, RolloutServer& S, int groups) {
-    const NetLayout& TE = c->L.net[PVAE_NET_TE];
-    const NetLayout& MD = c->L.net[PVAE_NET_MD];
-    SrvArgs& a = S.args;
-    memset(&a, 0, sizeof(a));
-    int off = 0, max_ld = 0, i = 0;
-    for (const NetLayout* N : {&TE, &MD})
-        for (const Layer& l : N->layers) {
-            SrvLayer& L = a.layer[i++];
-            L.w_off = l.w_off; L.b_off = l.b_off; L.ld = l.ld; L.n_out_pad = l.n_out_pad; L.n_out = l.n_out; L.act = l.act;
-            L.F = (l.n_out_pad + groups - 1) / groups;
-            if (l.n_out_pad > kSrvActStride || l.ld > kSrvActStride) return 0;
-            L.lds_off = off;
-            off += L.F * l.ld + ((L.F + 3) & ~3);                         // rows + biases (16-byte granules)
-            if (l.ld > max_ld) max_ld = l.ld;
-        }
-    a.n_layers = i; a.n_te = (int)TE.layers.size();
-    a.groups = groups; a.one_xcd = groups == 32 ? 1 : 0;
-    a.Db = c->L.cfg.dim_body; a.Da = c->L.cfg.dim_action; a.Z = c->L.cfg.latent; a.prior_kind = c->L.cfg.prior_kind;
-    a.xs_off = off;
-    return (size_t)(off + max_ld) * sizeof(float);
-}
-
-// scope: 0 = one XCD if the stacks fit its CUs' LDS, else the whole chip; 1 = one XCD; 2 = the whole chip
-static int server_plan(pvae_ctx* c, RolloutServer& S, int scope) {
-    const int n = (int)(c->L.net[PVAE_NET_TE].layers.size() + c->L.net[PVAE_NET_MD].layers.size());
-    if (n > kSrvMaxLayers) return fail(-24, "rollout server: %d layers (at most %d)", n, kSrvMaxLayers);
-    if (c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE)
-        return fail(-24, "rollout server: this latent prior is served by the per-layer launches only");
-    if (2 * c->L.cfg.dim_body > kSrvMaxObs || c->L.cfg.dim_action + 3 * c->L.cfg.latent > kSrvMaxOut)
-        return fail(-24, "rollout server: observation / action too wide");
-    constexpr size_t kFit = 156 * 1024;
-    size_t need = 0;
-    for (int groups : {32, 256}) {
-        if ((groups == 32 && scope == 2) || (groups == 256 && scope == 1)) continue;
-        need = server_layout(c, S, groups);
-        if (need == 0) return fail(-24, "rollout server: a layer wider than %d", kSrvActStride);
-        if (need <= kFit) { S.lds_bytes = need; return 0; }
-    }
-    return fail(-24, "rollout server: the encoder's and decoder's weights need %zu KB of LDS per workgroup even when dealt out over "
-                     "%s, more than a CU has: these stacks are served by the per-layer launches", need / 1024,
-                scope == 1 ? "the 32 CUs of one XCD" : "all 256 CUs");
-}
-
-static int server_launch(pvae_ctx* c, RolloutServer& S) {
-    HIP_TRY(hipMemsetAsync(S.sync, 0, 64 * sizeof(unsigned), S.stream));
-    S.mb->state = 0; S.mb->done_seq = S.seq;
-    S.req->cmd = 0; S.req->req_seq = S.seq;
-    __builtin_ia32_sfence();                                    // (device-resident request block: write-combined stores)
-    HIP_TRY(params_settle(c));                                   // (the launch reads the parameters as they are NOW)
-    S.loaded_version = c->param_version;
-    S.args.seq0 = S.seq;
-    S.args.params = c->params;
-    S.args.idle_ticks = (long long)(S.idle_ms * 1e5);
-    S.args.life_ticks = (long long)(S.life_s * 1e8);
-    HIP_TRY(hipFuncSetAttribute((const void*)rollout_server_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes));
-    hipLaunchKernelGGL(rollout_server_kernel, dim3(256), dim3(256), S.lds_bytes, S.stream, S.args);
-    HIP_TRY(hipGetLastError());
-    S.launched = true;
-    // until the kernel reports "serving" (or refuses): bounded
-    const auto t0 = std::chrono::steady_clock::now();
-    while (S.mb->state == 0) {
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0)
-            return fail(-25, "rollout server: the kernel did not come up within 5 s");
-        std::this_thread::yield();
-    }
-    if (S.mb->state == 3) {
-        HIP_TRY(hipStreamSynchronize(S.stream));
-        S.launched = false;
-        return fail(-24, "rollout server: its 32 workgroups were not placed on one XCD; use scope 2 (whole chip) or the per-layer launches");
-    }
-    return 0;
-}
-
-extern "C" {
-/* see include/pvae.h */
-int pvae_rollout_server_start(pvae_ctx* c, double idle_timeout_ms, double lifetime_s, int scope) {
-    int rc = check_ready(c, true);
-    if (rc) return rc;
-    if (!c->server) c->server = new RolloutServer();
-    RolloutServer& S = *c->server;
-    if (S.launched && S.mb && S.mb->state == 1) return 0;                 // already serving
-    if (scope < 0) scope = S.scope;                                       // (a relaunch keeps what the caller chose)
-    if (scope < 0 || scope > 2) return fail(-1, "scope %d: 0 auto, 1 one XCD, 2 the whole chip", scope);
-    S.scope = scope;
-    if ((rc = server_plan(c, S, scope))) return rc;
-    if (!S.mb) {
-        HIP_TRY(hipHostMalloc((void**)&S.mb, sizeof(SrvReply), hipHostMallocMapped));
-        memset((void*)S.mb, 0, sizeof(SrvReply));
-        HIP_TRY(hipHostGetDevicePointer((void**)&S.mb_dev, (void*)S.mb, 0));
-        // The request block: with a large BAR the host reaches device memory through the pointer itself (tools/bar_probe.py),
-        // so the block lives in UNCACHED device memory -- the host pushes observation + request word, the kernel polls and
-        // reads local memory.  Otherwise (or option "server_mailbox" = 1) pinned host memory that the kernel pulls from.
-        int dev = 0, large_bar = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev);
-        S.req_on_device = large_bar != 0 && c->server_mailbox != 1;
-        if (c->server_mailbox == 2) S.req_on_device = true;
-        if (S.req_on_device) {
-            HIP_TRY(hipExtMallocWithFlags((void**)&S.req_dev, sizeof(SrvRequest), hipDeviceMallocUncached));
-            HIP_TRY(hipMemset(S.req_dev, 0, sizeof(SrvRequest)));
-            HIP_TRY(hipDeviceSynchronize());
-            S.req = S.req_dev;
-        } else {
-            HIP_TRY(hipHostMalloc((void**)&S.req, sizeof(SrvRequest), hipHostMallocMapped));
-            memset((void*)S.req, 0, sizeof(SrvRequest));
-            HIP_TRY(hipHostGetDevicePointer((void**)&S.req_dev, (void*)S.req, 0));
-        }
-        HIP_TRY(hipMalloc((void**)&S.sync, 64 * sizeof(unsigned)));
-        HIP_TRY(hipMalloc((void**)&S.dbg, 64 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(S.dbg, 0, 64 * sizeof(unsigned long long)));
-        HIP_TRY(hipMalloc((void**)&S.acts, (size_t)(kSrvMaxLayers + 1) * kSrvActStride * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(S.acts, 0, (size_t)(kSrvMaxLayers + 1) * kSrvActStride * sizeof(unsigned long long)));
-        int lo = 0, hi = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));               // lo: least urgent.  A priority of its own = a hardware
-        HIP_TRY(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, lo));   // queue no compute stream is mapped onto
-    }
-    if (S.launched) { HIP_TRY(hipStreamSynchronize(S.stream)); S.launched = false; }   // an instance that gave up (idle): reap it
-    if (idle_timeout_ms > 0) S.idle_ms = idle_timeout_ms;
-    if (lifetime_s > 0) S.life_s = lifetime_s;
-    S.args.mb = S.mb_dev; S.args.req = S.req_dev; S.args.obs_direct = S.req_on_device ? 1 : 0;
-    S.args.sync = S.sync; S.args.acts = S.acts; S.args.dbg = S.dbg;
-    // (every server of this process on an XCD of its own: two engines can serve side by side)
-    static int next_xcd = 0;
-    if (S.xcd < 0) S.xcd = next_xcd++ & 7;
-    S.args.xcd = S.xcd;
-    return server_launch(c, S);
-}
-
-static int server_request(pvae_ctx* c, uint32_t cmd, const float* obs, int noise, uint64_t seed, uint64_t offset, double timeout_ms) {
-    RolloutServer& S = *c->server;
-    SrvReply* mb = S.mb;
-    SrvRequest* rq = S.req;
-    if (obs) memcpy((void*)rq->obs, obs, (size_t)(cmd == 3u ? S.args.Db + S.args.Z : 2 * S.args.Db) * sizeof(float));
-    rq->cmd = cmd; rq->noise = noise ? 1u : 0u;
-    rq->seed_lo = (uint32_t)seed; rq->seed_hi = (uint32_t)(seed >> 32); rq->off_lo = (uint32_t)offset; rq->off_hi = (uint32_t)(offset >> 32);
-    const uint32_t seq = ++S.seq;
-    // the request word goes LAST: behind a store fence when the block is device memory (write-combined stores through the
-    // BAR may leave the core out of order; posted PCIe writes then arrive in the order they left)
-    if (S.req_on_device) __builtin_ia32_sfence();
-    __atomic_store_n(&rq->req_seq, seq, __ATOMIC_RELEASE);
-    if (S.req_on_device) __builtin_ia32_sfence();
-    if (cmd == 1) return 0;
-    const auto t0 = std::chrono::steady_clock::now();
-    unsigned spins = 0;
-    while (__atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) != seq) {
-        if ((++spins & 1023u) == 0) {
-            if (__atomic_load_n(&mb->state, __ATOMIC_ACQUIRE) != 1u) return 1;           // the kernel left (idle time-out raced the request)
-            if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeout_ms)
-                return fail(-25, "rollout server: no answer within %.1f ms", timeout_ms);
-        }
-    }
-    return 0;
-}
-
-int pvae_rollout_server_infer(pvae_ctx* c, const float* obs, int noise, uint64_t rng_seed, uint64_t rng_offset, int reload,
-                              float* a_hat, float* mu_logvar, float* z, double timeout_ms) {
-    if (!c || !c->server || !c->server->mb) return fail(-2, "rollout server not started (pvae_rollout_server_start)");
-    if (!obs || !a_hat) return fail(-1, "obs / a_hat is null");
-    RolloutServer& S = *c->server;
-    if (timeout_ms <= 0) timeout_ms = 1000.0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if (!S.launched || S.mb->state != 1u) {                  // it left after its idle time: bring it back (weights re-read)
-            int rc = pvae_rollout_server_start(c, 0, 0, -1);
-            if (rc) return rc;
-            reload = 0;
-        }
-        if (S.loaded_version != c->param_version) {              // optimizer steps went through this library since: re-read
-            HIP_TRY(params_settle(c));
-            S.loaded_version = c->param_version;
-            reload = 1;
-        }
-        const int r = server_request(c, reload ? 2u : 0u, obs, noise, rng_seed, rng_offset, timeout_ms);
-        if (r < 0) return r;
-        if (r == 0) {
-            ++S.served;
-            const int Da = S.args.Da, Z = S.args.Z;
-            memcpy(a_hat, (const void*)S.mb->out, (size_t)Da * sizeof(float));
-            if (mu_logvar) memcpy(mu_logvar, (const void*)(S.mb->out + Da), (size_t)2 * Z * sizeof(float));
-            if (z) memcpy(z, (const void*)(S.mb->out + Da + 2 * Z), (size_t)Z * sizeof(float));
-            return 0;
-        }
-    }
-    return fail(-25, "rollout server: the kernel left twice while a request was pending");
-}
-
-/* forward_decoder at B = 1 ("pass_through" rollouts, rllib_env_imitation.py:233-258: z drawn by the caller): s1_z = [s1 (Db) | z (Z)]
- * -> a_hat[Da], the same bits as pvae_net_forward(PVAE_NET_MD) on that row.  The encoder's layers are skipped. */
-int pvae_rollout_server_decode(pvae_ctx* c, const float* s1_z, float* a_hat, double timeout_ms) {
-    if (!c || !c->server || !c->server->mb) return fail(-2, "rollout server not started (pvae_rollout_server_start)");
-    if (!s1_z || !a_hat) return fail(-1, "s1_z / a_hat is null");
-    RolloutServer& S = *c->server;
-    if (timeout_ms <= 0) timeout_ms = 1000.0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if (S.launched && S.mb->state == 1u && S.loaded_version != c->param_version) {
-            int rc = pvae_rollout_server_stop(c);                // (no reload form of this request: a relaunch re-reads)
-            if (rc) return rc;
-        }
-        if (!S.launched || S.mb->state != 1u) {
-            int rc = pvae_rollout_server_start(c, 0, 0, -1);
-            if (rc) return rc;
-        }
-        const int r = server_request(c, 3u, s1_z, 0, 0, 0, timeout_ms);
-        if (r < 0) return r;
-        if (r == 0) {
-            ++S.served;
-            memcpy(a_hat, (const void*)S.mb->out, (size_t)S.args.Da * sizeof(float));
-            return 0;
-        }
-    }
-    return fail(-25, "rollout server: the kernel left twice while a request was pending");
-}
-
-/* n requests back to back with the SAME observation, each timed on the host clock inside this call (what a compiled host
- * sees; a Python caller adds its own call overhead): us[i] = host observation -> host action of request i. */
-int pvae_rollout_server_selfbench(pvae_ctx* c, const float* obs, int noise, int32_t n, double* us) {
-    if (!c || !c->server || !c->server->mb) return fail(-2, "rollout server not started (pvae_rollout_server_start)");
-    if (!obs || !us || n < 1) return fail(-1, "bad arguments");
-    std::vector<float> a(c->server->args.Da);
-    for (int i = 0; i < n; ++i) {
-        const auto t0 = std::chrono::steady_clock::now();
-        const int rc = pvae_rollout_server_infer(c, obs, noise, 1, (uint64_t)i, 0, a.data(), nullptr, nullptr, 1000.0);
-        us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        if (rc) return rc;
-    }
-    return 0;
-}
-
-/* Where the last request's time went on the device: us[0] = 0 (request seen by workgroup 0), us[1 + 2 l] = layer l's inputs
- * in LDS, us[2 + 2 l] = layer l's outputs published, us[1 + 2 n_layers] = completion word issued; *n = entries written. */
-int pvae_rollout_server_timeline(pvae_ctx* c, double* us, int32_t max, int32_t* n) {
-    if (!c || !c->server || !c->server->dbg) return fail(-2, "rollout server not started (pvae_rollout_server_start)");
-    unsigned long long t[64];
-    HIP_TRY(hipMemcpy(t, c->server->dbg, sizeof(t), hipMemcpyDeviceToHost));
-    const int cnt = 2 + 2 * c->server->args.n_layers;
-    int m = 0;
-    for (; m < cnt && m < max; ++m) us[m] = (double)(long long)(t[m] - t[0]) / 100.0;
-    // last entry: the shader clock during the request, MHz (s_memtime ticks per microsecond of the 100 MHz wall clock)
-    if (m < max && cnt >= 2 && t[cnt - 1] > t[0]) us[m++] = (double)(long long)(t[63] - t[62]) / ((double)(long long)(t[cnt - 1] - t[0]) / 100.0);
-#ifdef PVAE_SRV_FINE
-    for (int k = 39; k <= 42 && m < max; ++k) us[m++] = (double)(long long)(t[k] - t[0]) / 100.0;
-#endif
-    if (n) *n = m;
-    return 0;
-}
-
-int pvae_rollout_server_stop(pvae_ctx* c) {
-    if (!c) return fail(-1, "null ctx");
-    if (!c->server || !c->server->mb) return 0;
-    RolloutServer& S = *c->server;
-    if (S.launched) {
-        if (S.mb->state == 1u) server_request(c, 1u, nullptr, 0, 0, 0, 0);
-        HIP_TRY(hipStreamSynchronize(S.stream));                 // bounded: stop command, else idle time-out, else lifetime
-        S.launched = false;
-    }
-    return 0;
-}
-
-int pvae_params_changed(pvae_ctx* c, void* stream) {
-    if (!c) return fail(-1, "null ctx");
-    params_touched(c, (hipStream_t)stream);
-    return 0;
-}
-
-int pvae_rollout_server_status(pvae_ctx* c, int32_t* serving, uint32_t* served, int32_t* lds_bytes) {
-    if (!c) return fail(-1, "null ctx");
-    const RolloutServer* S = c->server;
-    if (serving) *serving = (S && S->mb && S->launched && S->mb->state == 1u) ? (S->req_on_device ? 2 : 1) : 0;   // 2: request block in device memory
-    if (served) *served = S ? S->served : 0u;
-    if (lds_bytes) *lds_bytes = S ? (int32_t)S->lds_bytes * (S->args.one_xcd ? 1 : -1) : 0;   // (negative: dealt out over the whole chip)
-    return 0;
-}
-}   // extern "C"
-
-static void server_free(pvae_ctx* c) {
-    if (!c->server) return;
-    (void)pvae_rollout_server_stop(c);
-    RolloutServer& S = *c->server;
-    if (S.stream) (void)hipStreamDestroy(S.stream);
-    if (S.sync) (void)hipFree(S.sync);
-    if (S.dbg) (void)hipFree(S.dbg);
-    if (S.acts) (void)hipFree(S.acts);
-    if (S.mb) (void)hipHostFree((void*)S.mb);
-    if (S.req) { if (S.req_on_device) (void)hipFree((void*)S.req); else (void)hipHostFree((void*)S.req); }
-    delete c->server;
-    c->server = nullptr;
-}
-
 extern "C" {
 int pvae_rollout_is_fused(void) { return rollout_fused() ? 1 : 0; }
 
@@ -4440,96 +2572,6 @@ int pvae_reparam(pvae_ctx* c, const float* mu_logvar, int32_t rows, const float*
     return launch_sampler(c, mu_logvar, ldte, eps, c->ws + c->W.eps, c->ws + c->W.net[PVAE_NET_MD].in, ld_md, rows, rows,
                           noise ? 1 : 0, (unsigned long long)rng_seed, (unsigned long long)rng_offset, (float*)nullptr,
                           z_out, (const float*)nullptr, 0, st);
-}
-
-// Shader clock sustained while every SIMD issues fp32 MFMAs back to back on the caller's operands (DVFS:
-// the chip clocks to its power budget, and MFMA power depends on how much the operands toggle -- zeros
-// run at the 2.4 GHz spec clock, real weights ~10 % lower).  One workgroup reports shader cycles
-// (s_memtime) against the 100 MHz wall clock.
-__global__ void __launch_bounds__(256)
-mfma_clock_kernel(const float* __restrict__ src, int n_src, float* __restrict__ sink, int n, unsigned long long* out) {
-    // eight different operand pairs per lane, cycled: consecutive MFMAs see different values, as in a real
-    // contraction (with ONE constant pair the multiplier array hardly switches and the probe reads high)
-    float a[8], b[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        a[u] = src[(threadIdx.x + 256 * blockIdx.x + 4099 * u) % n_src];
-        b[u] = src[(7919 + threadIdx.x + 17 * blockIdx.x + 6151 * u) % n_src];
-    }
-    v4f acc[4] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
-    const unsigned long long w0 = wall_clock64(), c0 = clock64();
-    for (int i = 0; i < n; i += 2) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc[u & 3], 0, 0, 0);
-    }
-    const unsigned long long c1 = clock64(), w1 = wall_clock64();
-    const v4f s4 = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    if (s4[0] == 123.456f) sink[threadIdx.x] = s4[1];              // keeps the MFMAs alive; never true in practice
-    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
-}
-
-int pvae_mfma_clock_probe(const float* operands, int64_t n_operands, float* scratch, double* ghz, double* tflops_peak,
-                          void* stream) {
-    if (!operands || n_operands < 8192 || !scratch || !ghz || !tflops_peak) return fail(-1, "bad probe arguments");
-    hipStream_t st = (hipStream_t)stream;
-    int cus = 0, dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    unsigned long long* d_out = reinterpret_cast<unsigned long long*>(scratch);      // 16 bytes, then the sink
-    const int n_src = (int)(n_operands > (1 << 30) ? (1 << 30) : n_operands);
-    // the power-management loop reacts over milliseconds: ~10 ms of this load before the launch that is read
-    // (two launches still report the 2.38 GHz the chip starts at; after 2 ms it has settled near 2.17)
-    for (int rep = 0; rep < 30; ++rep)
-        hipLaunchKernelGGL(mfma_clock_kernel, dim3(4 * cus), dim3(256), 0, st, operands, n_src, scratch + 64, 2048, d_out);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
-    unsigned long long h[2] = {0, 0};
-    HIP_TRY(hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost));
-    if (!h[1]) return fail(-10, "clock probe measured nothing");
-    *ghz = (double)h[0] / ((double)h[1] * 10.0);                    // cycles / ns
-    *tflops_peak = (double)cus * 256.0 * *ghz * 1e9 / 1e12;         // 256 FLOP / clk / CU (MI355X_MICROARCH.md)
-    return 0;
-}
-
-int pvae_profile_enable(int on) {
-    g_prof.on = on != 0;
-    if (on) g_prof.n = 0;
-    return 0;
-}
-
-int pvae_profile_read(int category, double* total_ms, int64_t* launches, double* total_flops) {
-    if (!total_ms || !launches || !total_flops) return fail(-1, "null output");
-    double ms = 0, fl = 0;
-    int64_t cnt = 0;
-    for (int i = 0; i < g_prof.n; ++i) {
-        if (g_prof.cat[i] != category) continue;
-        HIP_TRY(hipEventSynchronize(g_prof.ev[i][1]));
-        float t = 0;
-        HIP_TRY(hipEventElapsedTime(&t, g_prof.ev[i][0], g_prof.ev[i][1]));
-        ms += t; fl += g_prof.flops[i]; ++cnt;
-    }
-    *total_ms = ms; *launches = cnt; *total_flops = fl;
-    return 0;
-}
-
-int pvae_gemm_probe(int kind, const float* a, int lda, const float* b, int ldb, float* cc, int ldc,
-                    const float* bias_or_mask, int ld_mask, int m, int n, int k, int relu, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    if (!a || !b || !cc) return fail(-1, "null operand");
-    if (kind == 0) {
-        if (m % 32 || n % 32 || k % 64) return fail(-1, "forward probe needs M%%32==0, N%%32==0, K%%64==0");
-        HIP_TRY(gemm_forward(a, lda, b, ldb, bias_or_mask, cc, ldc, m, n, k, relu, st));
-    } else if (kind == 1) {
-        if (m % 32 || k % 32 || n % 64) return fail(-1, "dgrad probe needs M%%32==0, K%%32==0, N%%64==0");
-        HIP_TRY(gemm_dgrad(a, lda, b, ldb, bias_or_mask, ld_mask, cc, ldc, m, k, n, st));
-    } else if (kind == 2) {
-        if (m % 32 || n % 64 || k % 64) return fail(-1, "wgrad probe needs M%%32==0, N%%64==0, K%%64==0");
-        EpiGradStore e{cc, ldc};
-        HIP_TRY(gemm_wgrad(a, lda, b, ldb, n, k, m, e, st));
-    } else {
-        return fail(-1, "unknown probe kind %d", kind);
-    }
-    return 0;
 }
 
 }  // extern "C"

@@ -344,11 +344,11 @@ __device__ inline void stage_row_lds(const StageArgs& a, int r, int t, int rows_
 // register sets in flight per lane in the register-staged kernels (re-measured every round: 2 / 2 / 4 at 256 rows, 1 for the
 // 64x32 input-gradient body of the >= 512-row pairs; profiles/r03_ab_regdepth_final.txt, r03_ab_regdepth_c5.txt)
 constexpr int kRegDepthD = 2, kRegDepthD64 = 1, kRegDepth16 = 4, kRegDepthW = 2;
-static int g_krot = 0;                       // pvae_set_option(NULL, "krot", 1)
+inline int g_krot = 0;                       // pvae_set_option(NULL, "krot", 1)
 // Experiment (off by default): XCD x takes q-tile (row block) x of a 256-row layer and ALL its p-tiles, instead of
 // all q-tiles of an eighth of the p-tiles -- the operand traffic a row-block-stationary multi-layer kernel would
 // have (every XCD streams the whole weight matrix through its L2).  Same tiles, same results.
-static int g_rowxcd = 0;                     // pvae_set_option(NULL, "rowxcd", 1)
+inline int g_rowxcd = 0;                     // pvae_set_option(NULL, "rowxcd", 1)
 struct GemmArgs {
     const float* Q;
     int ldq;
@@ -2440,7 +2440,7 @@ struct EpiGradAdam {          // weight gradient consumed in registers by Adam (
 // When the profiler arms a pair of events, the next launch goes through hipExtLaunchKernelGGL, which
 // stamps them with the kernel's own start and end on the device (what rocprofv3 reports as the kernel
 // duration); events recorded around a plain launch would include the launch seam.
-static hipEvent_t g_kernel_ev[2] = {nullptr, nullptr};
+inline hipEvent_t g_kernel_ev[2] = {nullptr, nullptr};
 #define PVAE_LAUNCH(kernel, grid, block, st, ...)                                                          \
     do {                                                                                                   \
         if (g_kernel_ev[0]) {                                                                              \
@@ -2462,13 +2462,13 @@ inline GemmGrid make_grid(int rows_q, int cols_p, int bq, int bp) {
 }
 
 // 512 rows and more: 64x32 tiles (splitk_ws64_body) whenever they still give every CU a workgroup; PVAE_WS64=0: off (A/B)
-static int g_ws64 = 1;                       // pvae_set_option(NULL, "ws64", 0): off (tests compare the tilings bit for bit)
+inline int g_ws64 = 1;                       // pvae_set_option(NULL, "ws64", 0): off (tests compare the tilings bit for bit)
 inline bool uses_64x32(int M, int N) { return g_ws64 && M >= 512 && M % 64 == 0 && (M / 64) * (N / 32) >= 256; }
 // 1024 rows and more: 64x64 tiles whenever THEY still give every CU a workgroup; PVAE_WS6464=0: off (A/B)
-static int g_ws6464 = 1;                     // option "ws6464"
+inline int g_ws6464 = 1;                     // option "ws6464"
 inline bool uses_64x64(int M, int N) { return g_ws6464 && uses_64x32(M, N) && N % 64 == 0 && (M / 64) * (N / 64) >= 256; }
 // ... with the XCDs partitioning the ROW blocks (see splitk_ws64_body); PVAE_WS6464_ROWS=0: column ranges as elsewhere (A/B)
-static int g_ws6464_rows = 1;                // option "ws6464_rows"
+inline int g_ws6464_rows = 1;                // option "ws6464_rows"
 inline GemmGrid make_grid_6464(int M, int N, GemmArgs& ga) {
     GemmGrid g = make_grid(M, N, 64, 64);
     ga.tiles_q = g.tiles_q; ga.tiles_p = g.tiles_p; ga.p_per_xcd = g.p_per_xcd;
@@ -2479,7 +2479,7 @@ inline GemmGrid make_grid_6464(int M, int N, GemmArgs& ga) {
     return g;
 }
 // ... and the input-gradient half of the fused backward pairs (PVAE_PAIR64=0: off, A/B)
-static int g_pair64 = 1;                     // option "pair64"
+inline int g_pair64 = 1;                     // option "pair64"
 inline bool pair_uses_64x32(int M, int N) { return g_pair64 && uses_64x32(M, N); }
 // narrow outputs: under 128 workgroups of 32x32 -> use 16x16 tiles (4x the workgroups)
 inline bool forward_uses_16x16(int M, int N) { return (M / 32) * (N / 32) < 128; }
@@ -2567,7 +2567,7 @@ inline hipError_t gemm_forward(const float* X, int ldx, const float* W, int ldw,
 // dgrad: dX[M][Kin] = (dZ[M][N] W[N][Kin]) .* (mask > 0)
 // Tile geometry: 32x32, or 16x16 when that leaves fewer than 128 workgroups (narrow first layers;
 // PVAE_DGRAD16=0 switches it off: A/B).
-static int g_dgrad16 = 1;                    // option "dgrad16"
+inline int g_dgrad16 = 1;                    // option "dgrad16"
 inline bool dgrad_uses_16x16(int M, int Kin) { return g_dgrad16 && (M / 32) * (Kin / 32) < 128; }
 // workgroups whose epilogue sees a tile (= loss partials a seed epilogue writes)
 inline int dgrad_tiles(int M, int Kin) {
@@ -2615,7 +2615,7 @@ inline hipError_t gemm_dgrad(const float* dZ, int ldz, const float* W, int ldw, 
 // wgrad: G[N][Kin] = dZ[M][N]^T X[M][Kin]  (+ bias gradient, + optional loss finalisation)
 // Tile geometry per problem: 64x64, or 32x32 when that leaves at most half the CUs with a tile
 // (PVAE_WGRAD32=0 switches the small geometry off: A/B).
-static int g_wgrad32 = 1;                    // option "wgrad32": 0 never, 1 where it pays, 2 always
+inline int g_wgrad32 = 1;                    // option "wgrad32": 0 never, 1 where it pays, 2 always
 inline bool wgrad_uses_32x32(int N, int Kin, int M) {
     return g_wgrad32 && ((N / 64) * (Kin / 64) <= 128 || g_wgrad32 == 2) && M % 64 == 0;
 }
