@@ -1366,7 +1366,7 @@ static bool direct_ok(const pvae_ctx* c, int phase, int rows, const pvae_step_pa
         return false;
     if (rows <= 4 || c->L.cfg.prior_kind != PVAE_PRIOR_ZERO_MEAN || !c->L.net[PVAE_NET_PR].layers.empty()) return false;
     if (fused && !(c->defer_adam && c->grads)) return false;          // (the same-layer schedule of plan_backward_net)
-    if (Da > ProCols::kMaxN || Z > ProCols::kMaxN) return false;
+    if (Da > ProCols::kMaxN || Z > ProCols::kMaxN || Db < 64 || 2 * Db >= 65536) return false;
     const int rp = pad32(rows);
     // a first layer on 64-row tiles has no Pro patch: its second column block is chunk-selected, which needs dim_body % 4 == 0
     auto layer0_ok = [&](int net, bool second_block) {
@@ -2161,8 +2161,10 @@ static bool enter_direct(pvae_ctx* c, int phase, int64_t first_window, int rows,
     if (!sp || !c->states || first_window < 0 || rows < 1 || rows > c->L.cfg.max_batch || first_window + rows > c->n_windows) return false;
     if (phase != PVAE_PHASE_WORLD && phase != PVAE_PHASE_JOINT) return false;
     if (!direct_ok(c, phase, rows, sp, fused)) return false;
+    const RowMap rm = row_map(c, first_window, rows);
+    if (!rm.seg) return false;             // (more than one episode jump inside the minibatch, or no host copy of window_row)
     c->dx.on = true;
-    c->dx.rm = row_map(c, first_window, rows);
+    c->dx.rm = rm;
     memset(&c->next_touch, 0, sizeof(c->next_touch));
     c->staged_rows = rows;
     c->staged_rows_f = rows;

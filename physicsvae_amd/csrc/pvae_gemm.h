@@ -776,9 +776,10 @@ __device__ inline void wait_dma_tile(int younger) {
 // pairs that travel as kernel arguments (the host keeps a copy of `window_row` from bind time) -- no index load in front of
 // the first tile fetch of the launch.  Otherwise: the index array itself.
 struct RowMap {
-    const int32_t* row;           // window_row + first_window (used when !seg)
-    int seg, q1, b0, b1;          // seg: rows q < q1 read row b0 + q, the others b1 + (q - q1)
-    __device__ inline int at(int q) const { return seg ? (q < q1 ? b0 + q : b1 + (q - q1)) : row[q]; }
+    const int32_t* row;           // window_row + first_window (host side only: not read by the kernels)
+    int seg, q1, b0, b1;          // rows q < q1 read row b0 + q, the others b1 + (q - q1); seg = 0: more than one jump --
+                                  // such a minibatch (episodes shorter than the batch) takes the staging launch instead
+    __device__ inline int at(int q) const { return q < q1 ? b0 + q : b1 + (q - q1); }   // (pure arithmetic: no load, no branch)
 };
 struct XSrc {
     const float* s0; int ld0, n0;
@@ -791,31 +792,48 @@ struct XSrc {
 // Q-operand policies of the wave-specialised forward kernels: where lane-slot (row q, 16-byte chunk at column c4) of
 // k-tile kt comes from.  QDense: the panel Q[q][ldq] (every launch but a gathered first layer).
 struct QDense {
+    static constexpr bool kAlwaysFast = true;
     struct Base { const float* p; };
     __device__ inline Base base(const float* Q, int ldq, int q, int c4) const { return Base{Q + (size_t)q * ldq + c4}; }
+    __device__ inline bool fast(int) const { return true; }
+    __device__ inline const float* tile_fast(const Base& b, int kt) const { return b.p + (size_t)kt * 64; }
     __device__ inline const float* tile(const Base& b, int kt) const { return b.p + (size_t)kt * 64; }
 };
-// QGather: the virtual matrix above.  A chunk that straddles n0 (n0 % 4 != 0) comes from s0 with the first floats of
+// QGather: the virtual matrix above.  Its s0 run -- base pointer, row stride, width, the batch's rows as two (base, start)
+// runs -- travels in the kernel's leading scalar arguments, which gfx950 preloads into SGPRs: the k-tiles that lie wholly
+// inside [0, n0) (`fast`) are fetched without waiting for anything else.  The rest (`x`: the s1 block, the zero line, the
+// index array for a minibatch with more than one episode jump) arrives by s_load while those tiles are in flight and is
+// first touched by a tile that needs it.  A chunk that straddles n0 (n0 % 4 != 0) comes from s0 with the first floats of
 // what follows the row in memory behind it: the launch's Pro patch overwrites those columns (n1 > 0 stacks), or they meet
-// W's zero pad columns (n1 == 0); likewise the floats past n0 + n1.  Forward only: garbage x 0 = 0, a gradient would not.
+// W's zero pad columns (n1 == 0); likewise the floats past n0 + n1.  Rows past the batch re-read the batch's last row
+// (their outputs are never used and their gradient rows are zero).  Forward only: garbage x 0 = 0, a gradient would not.
 struct QGather {
+    static constexpr bool kAlwaysFast = false;
+    const float* s0; int ld0, n0, rows, q1, b0, b1, seg;
     XSrc x;
-    struct Base { const float* p0; const float* p1; int c4; };
+    struct Base { const float* p0; int c4, q, r; };
     __device__ inline Base base(const float*, int, int q, int c4) const {
         Base b;
-        b.c4 = q < x.rows ? c4 : (1 << 28);                          // (rows past the batch: every tile reads zeros)
-        const int qq = q < x.rows ? q : 0;
-        const int r = x.rm.at(qq);
-        b.p0 = x.s0 + (size_t)r * x.ld0 + c4;
-        b.p1 = x.n1 > 0 ? x.s1 + (size_t)(x.ind1 ? r : qq) * x.ld1 + (c4 - x.n0) : x.zero;
+        b.q = q < rows ? q : rows - 1;
+        b.r = b.q < q1 ? b0 + b.q : b1 + (b.q - q1);
+        b.c4 = c4;
+        b.p0 = s0 + (size_t)b.r * ld0 + c4;
         return b;
     }
+    __device__ inline bool fast(int kt) const { return (kt + 1) * 64 <= n0; }              // (uniform: a scalar branch)
+    __device__ inline const float* tile_fast(const Base& b, int kt) const { return b.p0 + kt * 64; }
     __device__ inline const float* tile(const Base& b, int kt) const {
-        const int k0 = b.c4 + kt * 64;
-        const float* p = k0 < x.n0 ? b.p0 + kt * 64 : b.p1 + kt * 64;
-        return (k0 < x.n0 || k0 - x.n0 < x.n1) && k0 < (1 << 28) ? p : x.zero + (b.c4 & 60);
+        const int k0 = b.c4 + kt * 64, j = k0 - n0;
+        if (k0 < n0) return b.p0 + kt * 64;
+        return j < x.n1 ? x.s1 + (size_t)(x.ind1 ? b.r : b.q) * x.ld1 + j : x.zero + (b.c4 & 60);
     }
 };
+// the leading (preloadable) arguments of the gathered forward kernels: 14 dwords
+#define PVAE_GG_PARAMS const float* g_s0, const float* g_P, int g_ld0n0, int g_ldp, int g_K, int g_tq, int g_tp, int g_ppx, int g_fl, \
+                       int g_rq1, int g_b0, int g_b1
+#define PVAE_GG_GA GemmArgs{nullptr, 0, g_P, g_ldp, g_K, g_tq, g_tp, g_ppx, g_fl & 7, (g_fl >> 3) & 1, (g_fl >> 4) & 1, (g_fl >> 5) & 1}
+#define PVAE_GG_QS(xs) QGather{g_s0, g_ld0n0 & 0xffff, (int)((unsigned)g_ld0n0 >> 16), (g_rq1 & 0xffff) + 1, (int)((unsigned)g_rq1 >> 16) + 1, \
+                               g_b0, g_b1, (g_fl >> 6) & 1, xs}
 
 // Prologue hook of the wave-specialised kernel: a launch can OWN some columns of its Q operand -- form them itself
 // instead of reading what a separate launch stored.  The compute waves `prepare` (request the inputs of those
@@ -921,7 +939,8 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
             const int r = j >> 3, k = r ^ ((r >> 2) & 1);
             s0p = P + (size_t)k * ldp + p0 + (j & 7) * 4;
         }
-        lds_dma16(qs.tile(s0q, rot), lds + wave * 256);
+        if (QS::kAlwaysFast || qs.fast(rot)) lds_dma16(qs.tile_fast(s0q, rot), lds + wave * 256);
+        else lds_dma16(qs.tile(s0q, rot), lds + wave * 256);
         lds_dma16(s0p + (size_t)rot * kstep_p, lds + kTile + wave * 256);
     }
     if (wave >= 4) {
@@ -950,10 +969,18 @@ __device__ inline void splitk_ws_body(float* lds, int bid, const GemmArgs& ga, E
             int kt = t + rot;                             // k-tile this workgroup reads at step t
             if (kt >= nk) kt -= nk;
             if (PVAE_PROBE(2)) kt = 0;                    // probe: every step re-reads tile 0 (cache-resident)
+            if (QS::kAlwaysFast || qs.fast(kt)) {
 #pragma unroll
-            for (int u = 0; u < kWsPer; ++u) {
-                lds_dma16(qs.tile(sq[u], kt), slot + (u0 + kWsLoaders * u) * 256);
-                lds_dma16(sp[u] + (size_t)kt * kstep_p, slot + kTile + (u0 + kWsLoaders * u) * 256);
+                for (int u = 0; u < kWsPer; ++u) {
+                    lds_dma16(qs.tile_fast(sq[u], kt), slot + (u0 + kWsLoaders * u) * 256);
+                    lds_dma16(sp[u] + (size_t)kt * kstep_p, slot + kTile + (u0 + kWsLoaders * u) * 256);
+                }
+            } else {                              // (a gathered first layer's last tiles: the second block, the zero line)
+#pragma unroll
+                for (int u = 0; u < kWsPer; ++u) {
+                    lds_dma16(qs.tile(sq[u], kt), slot + (u0 + kWsLoaders * u) * 256);
+                    lds_dma16(sp[u] + (size_t)kt * kstep_p, slot + kTile + (u0 + kWsLoaders * u) * 256);
+                }
             }
         };
         if (1 < nk) issue(1);                                    // rides on tile 0's flight time
@@ -1182,8 +1209,13 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
         return P + (size_t)k * ldp + p0 + (j & 7) * 4;
     };
     // k-tile 0 by all eight waves: Q image = 1024 slots (two per lane and wave), P image = 512 / 1024 (one / two)
-    lds_dma16(qs.tile(src_q(wave * 64 + lane), 0), lds + wave * 256);
-    lds_dma16(qs.tile(src_q((wave + 8) * 64 + lane), 0), lds + (wave + 8) * 256);
+    if (QS::kAlwaysFast || qs.fast(0)) {
+        lds_dma16(qs.tile_fast(src_q(wave * 64 + lane), 0), lds + wave * 256);
+        lds_dma16(qs.tile_fast(src_q((wave + 8) * 64 + lane), 0), lds + (wave + 8) * 256);
+    } else {
+        lds_dma16(qs.tile(src_q(wave * 64 + lane), 0), lds + wave * 256);
+        lds_dma16(qs.tile(src_q((wave + 8) * 64 + lane), 0), lds + (wave + 8) * 256);
+    }
     lds_dma16(src_p(wave * 64 + lane), lds + kTileQ + wave * 256);
     if (PT == 64) lds_dma16(src_p((wave + 8) * 64 + lane), lds + kTileQ + (wave + 8) * 256);
     if (wave >= 4) {
@@ -1197,8 +1229,13 @@ __device__ inline void splitk_ws64_body(float* lds, int bid, const GemmArgs& ga,
         for (int u = 0; u < NB; ++u) sp[u] = src_p((u0 + 4 * u) * 64 + lane);
         auto issue = [&](int t) {
             float* slot = lds + (t % S) * kStage;
+            if (QS::kAlwaysFast || qs.fast(t)) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) lds_dma16(qs.tile(sq[u], t), slot + (u0 + 4 * u) * 256);
+                for (int u = 0; u < 4; ++u) lds_dma16(qs.tile_fast(sq[u], t), slot + (u0 + 4 * u) * 256);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) lds_dma16(qs.tile(sq[u], t), slot + (u0 + 4 * u) * 256);
+            }
 #pragma unroll
             for (int u = 0; u < NB; ++u) lds_dma16(sp[u] + (size_t)t * kstep_p, slot + kTileQ + (u0 + 4 * u) * 256);
         };
@@ -1343,25 +1380,25 @@ gemm_splitk_ws_pro_kernel(PVAE_GA_PARAMS(a_), Epi epi, Pro pro) {
 // the first layer of a stack on the gathered operand (XSrc): 32x32 tiles, plain or with a Pro patch; 64 x PT tiles
 template <class Epi>
 __global__ void __launch_bounds__(kWsThreads)
-gemm_splitk_ws_gather_kernel(PVAE_GA_PARAMS(a_), Epi epi, QGather qs) {
-    const GemmArgs ga = PVAE_GA_OF(a_);
+gemm_splitk_ws_gather_kernel(PVAE_GG_PARAMS, Epi epi, XSrc xs) {
+    const GemmArgs ga = PVAE_GG_GA;
     __shared__ __attribute__((aligned(16))) float lds[6 * 2 * 32 * 64];
-    splitk_ws_body<true, Epi, NoPro, QGather>(lds, blockIdx.x, ga, epi, NoPro(), nullptr, qs);
+    splitk_ws_body<true, Epi, NoPro, QGather>(lds, blockIdx.x, ga, epi, NoPro(), nullptr, PVAE_GG_QS(xs));
 }
 template <class Epi, class Pro>
 __global__ void __launch_bounds__(kWsThreads)
-gemm_splitk_ws_pro_gather_kernel(PVAE_GA_PARAMS(a_), Epi epi, Pro pro, QGather qs) {
-    const GemmArgs ga = PVAE_GA_OF(a_);
+gemm_splitk_ws_pro_gather_kernel(PVAE_GG_PARAMS, Epi epi, Pro pro, XSrc xs) {
+    const GemmArgs ga = PVAE_GG_GA;
     __shared__ __attribute__((aligned(16))) float lds[kWsFloats];
     __shared__ __attribute__((aligned(16))) float scratch[Pro::kScratchFloats];
-    splitk_ws_body<true, Epi, Pro, QGather>(lds, blockIdx.x, ga, epi, pro, scratch, qs);
+    splitk_ws_body<true, Epi, Pro, QGather>(lds, blockIdx.x, ga, epi, pro, scratch, PVAE_GG_QS(xs));
 }
 template <class Epi, int PT>
 __global__ void __launch_bounds__(512)
-gemm_splitk_ws64_gather_kernel(PVAE_GA_PARAMS(a_), Epi epi, QGather qs) {
-    const GemmArgs ga = PVAE_GA_OF(a_);
+gemm_splitk_ws64_gather_kernel(PVAE_GG_PARAMS, Epi epi, XSrc xs) {
+    const GemmArgs ga = PVAE_GG_GA;
     __shared__ __attribute__((aligned(16))) float lds[ws64_floats<PT>()];
-    splitk_ws64_body<true, Epi, PT, QGather>(lds, blockIdx.x, ga, epi, qs);
+    splitk_ws64_body<true, Epi, PT, QGather>(lds, blockIdx.x, ga, epi, PVAE_GG_QS(xs));
 }
 
 // ---- forward, 16x16 tile per workgroup (narrow output layers) ----------------------------------
@@ -1496,53 +1533,34 @@ struct PDense { static constexpr bool kGather = false; };
 struct PGather { static constexpr bool kGather = true; XSrc x; };
 template <int U, int BKR, int D>
 struct XLanes {
-    int k0[U], row[U], sh[U], j1[U];
-    unsigned keep0[U], keep1[U];
-    int i0[D][U], i1[D][U];                     // ring: indices for the NEXT load into register set s
-    __device__ inline void set(const XSrc& x, int u, int row_, int k0_) {
-        k0[u] = k0_; row[u] = row_;
-        keep0[u] = keep1[u] = 0u;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = k0_ + e;
-            if (c < x.n0) keep0[u] |= 1u << e;
-            else if (c < x.n0 + x.n1) keep1[u] |= 1u << e;
-        }
-        sh[u] = k0_ < x.n0 ? x.n0 - k0_ : 0;              // (> 0 only in the chunk that straddles n0: 1 .. 3)
-        if (sh[u] > 3) sh[u] = 0;                          // (a chunk wholly inside s0: keep1 is empty anyway)
-        j1[u] = k0_ > x.n0 ? k0_ - x.n0 : 0;
-    }
-    __device__ inline void fetch(const XSrc& x, int t, int s) {
+    int k0[U], row[U];            // (everything else is recomputed per load from these and the wave-uniform descriptor:
+                                  //  the weight-gradient bodies sit at the edge of three waves per SIMD)
+    __device__ inline void set(const XSrc&, int u, int row_, int k0_) { k0[u] = k0_; row[u] = row_; }
+    __device__ inline void fetch(const XSrc&, int, int) {}
+    // the chunks of tile t (t_next, s: unused -- the row map is arithmetic for a minibatch with at most one episode jump;
+    // otherwise an index load precedes the data, which only the rare minibatch with several jumps pays)
+    __device__ inline void load(const XSrc& x, int t, int, int, v4f (&out)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            int r = t * BKR + row[u];
-            r = r < x.rows ? r : x.rows - 1;
-            i0[s][u] = x.rm.at(r);
-            i1[s][u] = x.ind1 ? i0[s][u] : r;
-        }
-    }
-    // the chunk of tile t held in register set s (indices fetched earlier); then queue the indices of tile t_next
-    __device__ inline void load(const XSrc& x, int t, int t_next, int s, v4f (&out)[U]) {
-        int c0[U], c1[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { c0[u] = i0[s][u]; c1[u] = i1[s][u]; }
-        fetch(x, t_next, s);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool valid = t * BKR + row[u] < x.rows;
-            const float* pa = (valid && keep0[u]) ? x.s0 + (size_t)c0[u] * x.ld0 + k0[u] : x.zero;
-            const float* pb = (valid && keep1[u]) ? x.s1 + (size_t)c1[u] * x.ld1 + j1[u] : x.zero;
+            const int rr = t * BKR + row[u], k = k0[u];
+            const bool valid = rr < x.rows;
+            const int rc = valid ? rr : x.rows - 1;
+            const int i0 = x.rm.at(rc), i1 = x.ind1 ? i0 : rc;
+            const bool has0 = k < x.n0, has1 = k + 3 >= x.n0 && k < x.n0 + x.n1;
+            const int d = has0 ? x.n0 - k : 0;                             // 1 .. 3 in the chunk that straddles n0, else 0 or >= 4
+            // (always an address inside the row: what a source does not contribute, and every row past the batch, is masked below)
+            const float* pa = x.s0 + (size_t)i0 * x.ld0 + (has0 ? k : 0);
+            const float* pb = x.s1 + (size_t)i1 * x.ld1 + (has1 && k > x.n0 ? k - x.n0 : 0);
             const v4f a = *reinterpret_cast<const v4f*>(pa);
             const v4f w = *reinterpret_cast<const v4f*>(pb);
-            const int d = sh[u];
-            v4f ws;
+            v4f ws;                                                        // w shifted right by d elements (d < 4)
             ws[0] = d == 0 ? w[0] : 0.f;
             ws[1] = d == 0 ? w[1] : (d == 1 ? w[0] : 0.f);
             ws[2] = d == 0 ? w[2] : (d == 1 ? w[1] : (d == 2 ? w[0] : 0.f));
             ws[3] = d == 0 ? w[3] : (d == 1 ? w[2] : (d == 2 ? w[1] : w[0]));
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                out[u][e] = ((keep0[u] >> e) & 1u) ? a[e] : (((keep1[u] >> e) & 1u) ? ws[e] : 0.f);
+                out[u][e] = !valid ? 0.f : (k + e < x.n0 ? a[e] : (k + e < x.n0 + x.n1 ? ws[e] : 0.f));
         }
     }
 };
@@ -2044,24 +2062,35 @@ __device__ inline void touch_body(const TouchRuns& t, int blk) {
             asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(t.p[r] + (size_t)i * 32) : "memory");
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory");
 }
-// (PS = PGather: problem 1's X operand is the gathered first-layer input -- no staging workgroups then)
-template <class EpiW, class PS>
-__global__ void __launch_bounds__(256)
-wgrad_pair_gather_kernel(PVAE_GA2_PARAMS, int na, EpiW e1, EpiW e2, AdamPair ad, PS ps, TouchRuns touch) {
+// The step's trailing weight gradient on the gathered first-layer input (no second problem, no staging workgroups).  The
+// whole operand descriptor travels in the 14 preloadable leading dwords -- the s0 and s1 runs, their strides and widths,
+// the batch's rows as two (base, start) runs -- so that the first tile fetch waits for no s_load (`rest` is only read for
+// the index array of a minibatch with more than one episode jump).
+template <class EpiW>
+__global__ void __launch_bounds__(256, 3)       // (three waves per SIMD, as the staged kernel gets on its own: <= 168 VGPRs)
+wgrad_pair_gather_kernel(const float* aQ, const float* g_s0, const float* g_s1, unsigned a_ld, unsigned a_t, unsigned a_k,
+                         unsigned g_ld0n0, unsigned g_ld1n1, unsigned g_rq1, int g_b0, int g_b1, int na, EpiW e1, AdamPair ad,
+                         TouchRuns touch, XSrc rest) {
     __shared__ __attribute__((aligned(16))) float lds[kPairLdsFloats];
-    const GemmArgs g1 = PVAE_GA2_A, g2 = PVAE_GA2_B;
-    const int n1 = ga_grid(g1), n12 = n1 + ga_grid(g2);
+    GemmArgs g1 = ga_unpack(aQ, nullptr, a_ld, a_t, a_k);
+    const int gfl = g1.krot;                     // (the rotation bits carry: bit 0 = two-run row map, bit 1 = s1 row-indirect)
+    g1.krot = 0;
+    PGather ps;
+    ps.x = rest;
+    ps.x.s0 = g_s0; ps.x.ld0 = (int)(g_ld0n0 & 0xffffu); ps.x.n0 = (int)(g_ld0n0 >> 16);
+    ps.x.s1 = g_s1; ps.x.ld1 = (int)(g_ld1n1 & 0xffffu); ps.x.n1 = (int)(g_ld1n1 >> 16);
+    ps.x.ind1 = (gfl >> 1) & 1;
+    ps.x.rows = (int)(g_rq1 & 0xffffu) + 1;
+    ps.x.rm.seg = gfl & 1; ps.x.rm.q1 = (int)(g_rq1 >> 16) + 1; ps.x.rm.b0 = g_b0; ps.x.rm.b1 = g_b1;
+    const int n1 = ga_grid(g1), nb1 = bias_tiles(g1);
     const int b = blockIdx.x;
-    const int nb1 = bias_tiles(g1), nb2 = bias_tiles(g2);
-    if (b < n1) wgrad_body<EpiW, 0, PS>(lds, b, g1, e1, ps);
-    else if (b < n12) wgrad_body<EpiW>(lds, b - n1, g2, e2);
-    else if (b < n12 + nb1) bias_grad_body(lds, b - n12, g1, e1);
-    else if (b < n12 + nb1 + nb2) bias_grad_body(lds, b - n12 - nb1, g2, e2);
-    else if (b < n12 + nb1 + nb2 + na) adam_pair_body(ad, b - n12 - nb1 - nb2);
-    else touch_body(touch, b - n12 - nb1 - nb2 - na);
+    if (b < n1) wgrad_body<EpiW, 0, PGather>(lds, b, g1, e1, ps);
+    else if (b < n1 + nb1) bias_grad_body(lds, b - n1, g1, e1);
+    else if (b < n1 + nb1 + na) adam_pair_body(ad, b - n1 - nb1);
+    else touch_body(touch, b - n1 - nb1 - na);
 }
 template <class EpiD, class EpiW, class PS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 bwd_pair_gather_kernel(PVAE_GA2_PARAMS, EpiD ed, EpiW ew, AdamPair ad, PS ps) {
     __shared__ __attribute__((aligned(16))) float lds[kPairLdsFloats];
     const GemmArgs gd = PVAE_GA2_A, gw = PVAE_GA2_B;
@@ -2528,35 +2557,41 @@ inline hipError_t gemm_forward_pro(const float* X, int ldx, const float* W, int 
 }
 // a stack's FIRST layer on the gathered operand (XSrc): same tile geometries as gemm_forward_epi, never the 16x16 kernel
 inline bool forward_gather_ok(int M, int N) { return !forward_uses_16x16(M, N) && !g_krot && !g_rowxcd; }
+#define PVAE_GG_PASS(xs, ga) (xs).s0, (ga).P, (int)((unsigned)(xs).ld0 | ((unsigned)(xs).n0 << 16)), (ga).ldp, (ga).K, (ga).tiles_q, (ga).tiles_p, \
+                             (ga).p_per_xcd, ga_flags(ga) | ((xs).rm.seg ? 64 : 0), (int)((unsigned)((xs).rows - 1) | ((unsigned)((xs).rm.q1 - 1) << 16)), \
+                             (xs).rm.b0, (xs).rm.b1
+inline bool gather_packable(const XSrc& xs) {
+    return xs.ld0 > 0 && xs.ld0 < 65536 && xs.n0 >= 64 && xs.n0 < 65536 && xs.rows >= 1 && xs.rows <= 65536 && xs.rm.q1 >= 1 && xs.rm.q1 <= 65536;
+}
 template <class Epi>
 inline hipError_t gemm_forward_gather(const XSrc& xs, const float* W, int ldw, int M, int N, int K, const Epi& e, hipStream_t st) {
-    const QGather qs{xs};
+    if (!gather_packable(xs)) return hipErrorInvalidValue;
     if constexpr (std::is_same<Epi, EpiBiasAct>::value) {
         if (uses_64x64(M, N)) {
             GemmArgs ga{nullptr, 0, W, ldw, K, 0, 0, 0};
             const GemmGrid g = make_grid_6464(M, N, ga);
-            PVAE_LAUNCH((gemm_splitk_ws64_gather_kernel<Epi, 64>), dim3(g.grid), dim3(512), st, PVAE_GA_PASS(ga), e, qs);
+            PVAE_LAUNCH((gemm_splitk_ws64_gather_kernel<Epi, 64>), dim3(g.grid), dim3(512), st, PVAE_GG_PASS(xs, ga), e, xs);
             return hipGetLastError();
         }
         if (uses_64x32(M, N)) {
             const GemmGrid g = make_grid(M, N, 64, 32);
             const GemmArgs ga{nullptr, 0, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd};
-            PVAE_LAUNCH((gemm_splitk_ws64_gather_kernel<Epi, 32>), dim3(g.grid), dim3(512), st, PVAE_GA_PASS(ga), e, qs);
+            PVAE_LAUNCH((gemm_splitk_ws64_gather_kernel<Epi, 32>), dim3(g.grid), dim3(512), st, PVAE_GG_PASS(xs, ga), e, xs);
             return hipGetLastError();
         }
     }
     const GemmGrid g = make_grid(M, N, 32, 32);
     const GemmArgs ga{nullptr, 0, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd};
-    PVAE_LAUNCH((gemm_splitk_ws_gather_kernel<Epi>), dim3(g.grid), dim3(kWsThreads), st, PVAE_GA_PASS(ga), e, qs);
+    PVAE_LAUNCH((gemm_splitk_ws_gather_kernel<Epi>), dim3(g.grid), dim3(kWsThreads), st, PVAE_GG_PASS(xs, ga), e, xs);
     return hipGetLastError();
 }
 template <class Epi, class Pro>
 inline hipError_t gemm_forward_pro_gather(const XSrc& xs, const float* W, int ldw, int M, int N, int K, const Epi& e,
                                           const Pro& pro, hipStream_t st) {
-    const QGather qs{xs};
+    if (!gather_packable(xs)) return hipErrorInvalidValue;
     const GemmGrid g = make_grid(M, N, 32, 32);
     const GemmArgs ga{nullptr, 0, W, ldw, K, g.tiles_q, g.tiles_p, g.p_per_xcd};
-    PVAE_LAUNCH((gemm_splitk_ws_pro_gather_kernel<Epi, Pro>), dim3(g.grid), dim3(kWsThreads), st, PVAE_GA_PASS(ga), e, pro, qs);
+    PVAE_LAUNCH((gemm_splitk_ws_pro_gather_kernel<Epi, Pro>), dim3(g.grid), dim3(kWsThreads), st, PVAE_GG_PASS(xs, ga), e, pro, xs);
     return hipGetLastError();
 }
 inline hipError_t gemm_forward(const float* X, int ldx, const float* W, int ldw, const float* bias,
@@ -2658,15 +2693,19 @@ inline hipError_t gemm_wgrad_pair(const float* dZ1, int ldz1, const float* X1, i
 template <class EpiW>
 inline hipError_t gemm_wgrad_pair_gather(const float* dZ1, int ldz1, const XSrc& xs, int N1, int Kin1, const EpiW& e1, int M,
                                          hipStream_t st, const AdamPair* ad = nullptr, const TouchRuns* touch = nullptr) {
-    const WgradPlan w1 = plan_wgrad(dZ1, ldz1, nullptr, 0, N1, Kin1, M);
-    const WgradPlan w2 = plan_wgrad(nullptr, 0, nullptr, 0, 0, Kin1, M);
-    if (!ga_packable(w1.ga) || !ga_packable(w2.ga) || ga_grid(w1.ga) != w1.grid || ga_grid(w2.ga) != w2.grid) return hipErrorInvalidValue;
-    const PGather ps{xs};
+    WgradPlan w1 = plan_wgrad(dZ1, ldz1, nullptr, 0, N1, Kin1, M);
+    if (!ga_packable(w1.ga) || ga_grid(w1.ga) != w1.grid || !gather_packable(xs) || xs.ld1 < 0 || xs.ld1 >= 65536 || xs.n1 < 0 ||
+        xs.n1 >= 65536)
+        return hipErrorInvalidValue;
+    w1.ga.krot = (xs.rm.seg ? 1 : 0) | (xs.ind1 ? 2 : 0);
     TouchRuns tr;
     memset(&tr, 0, sizeof(tr));
     if (touch) tr = *touch;
-    PVAE_LAUNCH((wgrad_pair_gather_kernel<EpiW, PGather>), dim3(w1.grid + w2.grid + w1.nbias + w2.nbias + adam_blocks(ad) + tr.blocks),
-                dim3(256), st, PVAE_GA2_PASS(w1.ga, w2.ga), adam_blocks(ad), e1, e1, ad ? *ad : AdamPair(), ps, tr);
+    const float* s1 = xs.n1 > 0 ? xs.s1 : xs.s0;                 // (never dereferenced for a value when n1 == 0, but always an address)
+    PVAE_LAUNCH((wgrad_pair_gather_kernel<EpiW>), dim3(w1.grid + w1.nbias + adam_blocks(ad) + tr.blocks), dim3(256), st,
+                w1.ga.Q, xs.s0, s1, ga_pack_ld(w1.ga), ga_pack_t(w1.ga), ga_pack_k(w1.ga), (unsigned)xs.ld0 | ((unsigned)xs.n0 << 16),
+                (unsigned)xs.ld1 | ((unsigned)xs.n1 << 16), (unsigned)(xs.rows - 1) | ((unsigned)(xs.rm.q1 - 1) << 16), xs.rm.b0, xs.rm.b1,
+                adam_blocks(ad), e1, ad ? *ad : AdamPair(), tr, xs);
     return hipGetLastError();
 }
 // input gradient (16x16 / 32x32 tiles, caller's epilogue) || weight gradient on the gathered X
