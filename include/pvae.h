@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PVAE_ABI_VERSION 8
+#define PVAE_ABI_VERSION 9
 
 typedef struct pvae_ctx pvae_ctx;
 
@@ -96,7 +96,17 @@ typedef struct pvae_config {
      * [PVAE_NET_*][hidden layer]; zeroed = the uniform stack described by <net>_width / act_kind. */
     int32_t layer_width[PVAE_NUM_NETS][16]; /* > 0: width of that hidden layer instead of <net>_width    */
     int32_t layer_act[PVAE_NUM_NETS][16];   /* > 0: 1 + PVAE_ACT_* of that hidden layer instead of act_kind */
+    /* `task_encoder_inputs` / `motor_decoder_inputs` (rmt:470, 485; 607-613, 646-653, 776-783, 822-829): which of
+     * (body, task) the encoder reads -- s_t, s_{t+1} -- and which of (body, task) the decoder reads -- s_t, z.
+     * PVAE_INPUT_* bits; 0 = both (a zeroed field keeps the default).  A subset is a COLUMN WINDOW of the same
+     * first-layer weight block: the block keeps its full-width layout [body | task], the columns outside the window
+     * are structural zeros (never touched by initialisation or checkpoints, and kept exactly zero by training: the
+     * staged input panels hold zeros there, so their weight gradient is exactly zero); pvae_layer_info reports the
+     * window (n_in, col0), so a checkpoint tensor has the reference's shape. */
+    int32_t te_inputs, md_inputs;
 } pvae_config;
+#define PVAE_INPUT_BODY 1
+#define PVAE_INPUT_TASK 2
 
 typedef struct pvae_layer_info {
     int32_t net;       /* PVAE_NET_*                                    */
@@ -108,7 +118,8 @@ typedef struct pvae_layer_info {
     int64_t w_offset;  /* float offset of W[0][0] in the arena          */
     int64_t b_offset;  /* float offset of bias[0] in the arena          */
     int32_t act;       /* PVAE_ACT_* applied to this layer's output (PVAE_ACT_LINEAR for the output layer) */
-    int32_t reserved;
+    int32_t col0;      /* first column of the checkpoint tensor inside the block's rows: W[r][c] of the checkpoint is
+                          arena[w_offset + r * ld + col0 + c] (non-zero only for a first layer on an input subset) */
 } pvae_layer_info;
 
 /* Loss weights and Adam hyper-parameters of one optimizer step.

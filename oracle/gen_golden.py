@@ -675,6 +675,65 @@ def case_helper(name, arch, batch=6):
     print("wrote", name, "keys", len(fix["sd_keys"]), "max |logits| mean", float(np.abs(fix["mean_logits"]).max()))
 
 
+def case_subsets(name, arch, batch=8):
+    """`task_encoder_inputs` / `motor_decoder_inputs` (rmt:470, 485; 607-613, 646-653, 776-783, 822-829): the
+    reference's model built by its trainer with subsets of ["body", "task"] switched on in custom_model_config
+    (the trainer passes the dict through).  Per combination: the state-dict layout (the first layers are narrower),
+    and one minibatch of the reference's own compute_loss in both phases at seeded weights -- total, z, the world
+    model's prediction, every gradient."""
+    combos = [(("task",), ("body", "task")), (("body",), ("task",)), (("body", "task"), ("body",)), (("task",), ("task",))]
+    data = R.synth_demo(seed=0, n_episodes=2, n_steps=14, dim_body=arch["Db"], dim_action=arch["Da"], kind="iid")
+    fix = {"combos": np.array(["%s/%s" % ("+".join(t), "+".join(d)) for t, d in combos])}
+    with tempfile.TemporaryDirectory() as td:
+        pkl = os.path.join(td, "demo.pkl")
+        R.write_demo(pkl, data)
+        for ci, (te_in, md_in) in enumerate(combos):
+            orig = T.update_model_config
+
+            def update_model_config(trainer_config):
+                orig(trainer_config)
+                cmc = trainer_config["model"]["custom_model_config"]
+                cmc["task_encoder_inputs"] = list(te_in)
+                cmc["motor_decoder_inputs"] = list(md_in)
+            T.update_model_config = update_model_config
+            try:
+                tr = make_reference_trainer(pkl, arch, batch, m_world=2)
+            finally:
+                T.update_model_config = orig
+            ref_sd = tr.model.state_dict()
+            pre = "c%d_" % ci
+            fix[pre + "sd_keys"] = np.array(list(ref_sd.keys()))
+            fix[pre + "sd_shapes"] = np.array([list(v.shape) + [0] * (2 - v.dim()) for v in ref_sd.values()])
+            sarch = R.with_inputs(arch, te_in, md_in)
+            tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(sarch, seed=1), seed=3))
+            x, y = next(iter(tr.train_loader))
+            eps = R.eps_stream(2, arch["Z"])(0, (x.shape[0], arch["Z"]))
+            fix[pre + "eps"] = eps.numpy()
+            for world in (True, False):
+                tag = pre + ("world" if world else "joint")
+                m = tr.model
+                m.set_learnable_task_encoder(not world)
+                m.set_learnable_motor_decoder(not world)
+                m.set_learnable_world_model(world)
+                tr.read_loss_fn_coeff(world=world)
+                m.train()
+                tr.optimizer.zero_grad()
+                with EpsPatch(lambda c, shape: eps):
+                    loss = tr.compute_loss(y, x)
+                loss.backward()
+                fix[tag + "_total"] = loss.detach().numpy()
+                fix[tag + "_z"] = m._cur_task_encoder_variable.detach().numpy()
+                fix[tag + "_future_state"] = m._cur_future_state.detach().numpy()
+                grads = grads_of(m)
+                fix[tag + "_grad_keys"] = np.array(list(grads.keys()))
+                for k, g in grads.items():
+                    fix["%s_grad::%s" % (tag, k)] = g.numpy()
+            print("  ", fix["combos"][ci], "world", fix[pre + "world_total"], "joint", fix[pre + "joint_total"])
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *wd(arch["te"]), *wd(arch["md"]), *wd(arch["wm"]), 2, 14, batch])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
+    print("wrote", name)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -719,6 +778,7 @@ def main():
         "ingest_rel_tiny": lambda: case_ingest_rel("ingest_rel_tiny", tiny),
         "noprior_tiny": lambda: case_noprior("noprior_tiny", tiny, 2, 14, 8),
         "helper_tiny": lambda: case_helper("helper_tiny", tiny),
+        "subsets_tiny": lambda: case_subsets("subsets_tiny", tiny),
         "helper_default": lambda: case_helper("helper_default", dflt),
         # the trainer's "act_fn" (hidden activation of every stack) and Adam's weight_decay: config keys a user edits
         "single_tiny_tanh": lambda: case_single("single_tiny_tanh", dict(tiny, act="tanh"), 2, 14, 8, full=True),

@@ -88,6 +88,25 @@ def make_arch(dim_body, dim_action, latent=32, te=(256, 2), md=(512, 3), wm=(102
                 pr=tuple(pr) if pr is not None else tuple(te), act=act)
 
 
+BOTH = ("body", "task")
+
+
+def with_inputs(arch, te_inputs=BOTH, md_inputs=BOTH):
+    """`arch` with `task_encoder_inputs` / `motor_decoder_inputs` (rmt:470, 485): which of the two halves of the
+    observation the task encoder reads (rmt:609-612, 776-783) and which of (s_body, z) the motor decoder reads
+    (rmt:646-652, 822-829).  Any non-empty subset of ("body", "task"), in that order."""
+    for v in (te_inputs, md_inputs):
+        assert tuple(v) in (BOTH, ("body",), ("task",)), v
+    return dict(arch, te_inputs=tuple(te_inputs), md_inputs=tuple(md_inputs))
+
+
+def input_widths(arch):
+    """(task encoder's, motor decoder's) input width: rmt:607-612, 646-653 (dim_state_task = dim_body in training)."""
+    Db, Z = arch["Db"], arch["Z"]
+    te, md = arch.get("te_inputs", BOTH), arch.get("md_inputs", BOTH)
+    return (Db * ("body" in te) + Db * ("task" in te), Db * ("body" in md) + Z * ("task" in md))
+
+
 HELPER_DEFAULT = ((128, "relu"), (128, "relu"))        # motor_decoder_helper_layers' hidden part (rmt:491-495); output: tanh
 
 
@@ -152,10 +171,11 @@ def net_layer_dims(arch):
     prior = arch.get("prior", PRIORS[0])
     te_out = Z if (prior == "hypersphere_uniform" or prior is False) else 2 * Z   # rmt:618-623
     learned = [("_latent_prior", chain(Db, arch.get("pr", arch["te"]), Z))] if prior == PRIORS[1] else []
+    te_in, md_in = input_widths(arch)
     return OrderedDict(learned + [                                             # rmt:627-635 comes first
-        ("_task_encoder", chain(2 * Db, arch["te"], te_out)),      # rmt:638-644, 612-613
-        ("_motor_decoder", chain(Db + Z, arch["md"], Da)),         # rmt:646-668
-    ] + ([("_motor_decoder_helper", chain(Db + Z, arch["mh"], Da))] if arch.get("mh") else []) + [   # rmt:670-680
+        ("_task_encoder", chain(te_in, arch["te"], te_out)),       # rmt:638-644, 607-613
+        ("_motor_decoder", chain(md_in, arch["md"], Da)),          # rmt:646-668
+    ] + ([("_motor_decoder_helper", chain(md_in, arch["mh"], Da))] if arch.get("mh") else []) + [   # rmt:670-680
         ("_world_model", chain(Db + Da, arch["wm"], Db)),          # rmt:682-689
         ("_value_branch", chain(2 * Db, arch["vb"], 1)),           # rmt:693-699
     ])
@@ -349,8 +369,8 @@ class _Stack(nn.Module):
 
 
 class RefModel(nn.Module):
-    """PhysicsVAE restated (rmt:461-950) for latent_prior_type "normal_zero_mean_one_std",
-    inputs ["body","task"] for both TE and MD, constant log_std (sample_std 0.1)."""
+    """PhysicsVAE restated (rmt:461-950): the latent priors of PRIORS (and False), any `task_encoder_inputs` /
+    `motor_decoder_inputs` (with_inputs), the helper (with_helper), constant log_std (sample_std 0.1)."""
 
     def __init__(self, arch):
         super().__init__()
@@ -383,7 +403,9 @@ class RefModel(nn.Module):
     def forward(self, obs):
         Db, Da, Z = self.arch["Db"], self.arch["Da"], self.arch["Z"]
         obs = obs.float()
-        h = self._task_encoder(obs)                                   # rmt:788-793
+        te_in = self.arch.get("te_inputs", BOTH)                      # rmt:776-783
+        obs_task = obs if te_in == BOTH else (obs[..., :Db] if te_in == ("body",) else obs[..., Db:])
+        h = self._task_encoder(obs_task)                              # rmt:788-793
         if self.prior is False:                                       # rmt:815-816: the code is the encoder output
             self.cur_mu, self.cur_logvar, self.cur_prior_mu = h, None, None
             z = h
@@ -402,7 +424,8 @@ class RefModel(nn.Module):
             if self.prior == "normal_state_mean_one_std":             # rmt:801-809
                 self.cur_prior_mu = self._latent_prior(obs[..., :Db])
         self.cur_z = z
-        zin = torch.cat([obs[..., :Db], z], dim=-1)
+        md_in = self.arch.get("md_inputs", BOTH)                      # rmt:822-829
+        zin = torch.cat(([obs[..., :Db]] if "body" in md_in else []) + ([z] if "task" in md_in else []), dim=-1)
         a_hat = self._motor_decoder(zin)                              # rmt:822-831
         if self.arch.get("mh"):                                       # rmt:833-835
             a_hat = a_hat + self.arch["mh_range"] * self._motor_decoder_helper(zin)

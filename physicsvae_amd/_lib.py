@@ -34,7 +34,7 @@ MAX_HIDDEN = 15
 PRIOR_KINDS = {"normal_zero_mean_one_std": 0, "normal_state_mean_one_std": 1, "hypersphere_uniform": 2, False: 3}
 PHASE_WORLD, PHASE_JOINT = 0, 1
 FLAG_FUSED_ADAM, FLAG_NO_BACKWARD = 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 LOSS_MSE, LOSS_L1 = 0, 1
 EXCHANGE_ALLREDUCE, EXCHANGE_SHARDED, EXCHANGE_P2P, EXCHANGE_LOCAL, EXCHANGE_P2P_PUSH = 0, 1, 2, 3, 4
 P2P_BLOB_BYTES, P2P_MAX_RANKS = 512, 8
@@ -44,13 +44,18 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dim_body", "dim_action", "latent", "te_width", "te_depth", "md_width", "md_depth",
         "wm_width", "wm_depth", "max_batch", "lookahead", "prior_kind", "pr_width", "pr_depth", "act_kind")] + [
-        ("layer_width", (C.c_int32 * 16) * NUM_NETS), ("layer_act", (C.c_int32 * 16) * NUM_NETS)]
+        ("layer_width", (C.c_int32 * 16) * NUM_NETS), ("layer_act", (C.c_int32 * 16) * NUM_NETS),
+        ("te_inputs", C.c_int32), ("md_inputs", C.c_int32)]
+
+
+INPUT_BODY, INPUT_TASK = 1, 2                                     # pvae_config.te_inputs / md_inputs bits (0 = both)
+INPUT_BITS = {("body", "task"): 0, ("body",): INPUT_BODY, ("task",): INPUT_TASK}
 
 
 class LayerInfo(C.Structure):
     _fields_ = [("net", C.c_int32), ("index", C.c_int32), ("n_in", C.c_int32),
                 ("n_out", C.c_int32), ("ld", C.c_int32), ("n_out_pad", C.c_int32),
-                ("w_offset", C.c_int64), ("b_offset", C.c_int64), ("act", C.c_int32), ("reserved", C.c_int32)]
+                ("w_offset", C.c_int64), ("b_offset", C.c_int64), ("act", C.c_int32), ("col0", C.c_int32)]
 
 
 class StepParams(C.Structure):

@@ -43,7 +43,7 @@ scatter_state_kernel(const float* __restrict__ src, int lds_, int rows, int Db, 
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
         const int r = idx / Db, c = idx - r * Db;
         const float v = src[(size_t)r * lds_ + c];
-        d0[(size_t)r * ld0 + c] = v;
+        if (d0) d0[(size_t)r * ld0 + c] = v;
         if (d1) d1[(size_t)r * ld1 + c] = v;
         if (d2) d2[(size_t)r * ld2 + c] = v;
         if (d3) d3[(size_t)r * ld3 + c] = v;
@@ -1041,9 +1041,9 @@ int pvae_layer(const pvae_config* cfg, int i, pvae_layer_info* out) {
         const NetLayout& N = L.net[n];
         if (i < (int)N.layers.size()) {
             const Layer& l = N.layers[i];
-            out->net = l.net; out->index = l.index; out->n_in = l.n_in; out->n_out = l.n_out;
+            out->net = l.net; out->index = l.index; out->n_in = l.n_in; out->n_out = l.n_out; out->col0 = l.col0;
             out->ld = l.ld; out->n_out_pad = l.n_out_pad; out->w_offset = l.w_off; out->b_offset = l.b_off;
-            out->act = l.act == 0 ? PVAE_ACT_LINEAR : l.act - 1; out->reserved = 0;
+            out->act = l.act == 0 ? PVAE_ACT_LINEAR : l.act - 1;
             return 0;
         }
         i -= (int)N.layers.size();
@@ -1258,6 +1258,8 @@ static StageArgs stage_args(const pvae_ctx* c, long long first_window, const flo
         a.pr_in = w + (alt ? c->W.alt_in[PVAE_NET_PR] : c->W.net[PVAE_NET_PR].in);
         a.ld_pr = c->L.net[PVAE_NET_PR].layers[0].ld;
     }
+    const int te = c->L.cfg.te_inputs, md = c->L.cfg.md_inputs;          // input subsets: the blocks left out are staged as zeros
+    a.in_off = (te == PVAE_INPUT_TASK ? 1 : 0) | (te == PVAE_INPUT_BODY ? 2 : 0) | (md == PVAE_INPUT_TASK ? 4 : 0);
     return a;
 }
 
@@ -1308,11 +1310,19 @@ static int sampler_grid(const pvae_ctx* c, int rows_pad) {
     const int Z = c->L.cfg.latent;
     return (rows_pad * Z + 255) / 256 < 64 ? (rows_pad * Z + 255) / 256 : 64;
 }
+// Where the sampler's z goes: columns [Db, Db + Z) of the decoder's input panel -- or, for a decoder that reads s_t only
+// (motor_decoder_inputs = ["body"], rmt:822-829), of a side panel of the same shape: the code is still drawn, kept for
+// pvae_read_tensor and priced by the KL term, but must not sit in the operand of the decoder's weight gradient (the
+// weights of those columns are structural zeros and stay so because the operand is zero there).
+static int64_t z_panel(const pvae_ctx* c) {
+    return c->L.cfg.md_inputs == PVAE_INPUT_BODY ? c->W.z_side : c->W.net[PVAE_NET_MD].in;
+}
 static int launch_sampler(pvae_ctx* c, const float* te_out, int ldte, const float* eps, float* eps_used, float* md_in,
                           int ld_md, int rows, int rows_pad, int noise, unsigned long long seed,
                           unsigned long long offset, float* partial, float* z_dense, const float* mu_p, int ldmp,
                           hipStream_t st) {
     const int Db = c->L.cfg.dim_body, Z = c->L.cfg.latent;
+    md_in += z_panel(c) - c->W.net[PVAE_NET_MD].in;
     if (c->L.cfg.prior_kind >= PVAE_PRIOR_HYPERSPHERE) {
         hipLaunchKernelGGL(sphere_kernel, dim3((rows_pad + 3) / 4), dim3(256), 0, st, te_out, ldte, eps, eps_used, md_in,
                            ld_md, Db, Z, rows, rows_pad, noise, seed, offset, partial, z_dense,
@@ -1331,6 +1341,7 @@ static int launch_sampler(pvae_ctx* c, const float* te_out, int ldte, const floa
 static bool sampler_folds(const pvae_ctx* c, int rows) {
     const NetLayout& MD = c->L.net[PVAE_NET_MD];
     return c->fold_sampler && c->pair_launch && c->W.L == 1 && c->L.cfg.prior_kind == PVAE_PRIOR_ZERO_MEAN &&
+           c->L.cfg.md_inputs != PVAE_INPUT_BODY &&
            c->L.net[PVAE_NET_PR].layers.empty() && c->L.cfg.latent <= ProSampler::kMaxZ && c->L.cfg.latent % 4 == 0 &&
            rows > 4 &&
            MD.layers.size() > 1 && forward_pro_ok(pad32(rows), MD.layers[0].n_out_pad);
@@ -1365,6 +1376,7 @@ static bool direct_ok(const pvae_ctx* c, int phase, int rows, const pvae_step_pa
     if (!c->direct || !c->data_slack || !c->states || c->next_states || c->W.L != 1 || !c->pair_launch || !c->same_layer_pairs)
         return false;
     if (rows <= 4 || c->L.cfg.prior_kind != PVAE_PRIOR_ZERO_MEAN || !c->L.net[PVAE_NET_PR].layers.empty()) return false;
+    if ((c->L.cfg.te_inputs | c->L.cfg.md_inputs) % 3 != 0) return false;      // input subsets: the staged panels carry the zeros
     if (fused && !(c->defer_adam && c->grads)) return false;          // (the same-layer schedule of plan_backward_net)
     if (Da > ProCols::kMaxN || Z > ProCols::kMaxN || Db < 64 || 2 * Db >= 65536) return false;
     const int rp = pad32(rows);
@@ -1704,7 +1716,7 @@ static int run_forward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_ste
         if ((rc = forward_net(c, PVAE_NET_TE, u.rows_pad, st, FwdTail(), bt))) return rc;
         hipLaunchKernelGGL(reparam_kernel, dim3(S.gridz), dim3(256), 0, st, w + wte.act.back() + bt * ldo_te, ldo_te,
                            eps ? eps + (size_t)t * rows * Z : (const float*)nullptr, w + c->W.eps + bt * Z,
-                           w + wmd.in + bt * ld_md, ld_md, Db, Z, rows, u.rows_pad, 1,
+                           w + z_panel(c) + bt * ld_md, ld_md, Db, Z, rows, u.rows_pad, 1,
                            (unsigned long long)sp->rng_seed, (unsigned long long)(sp->rng_offset + t),
                            part + 2 * kLossParts + t * S.gridz, (float*)nullptr);
         HIP_TRY(hipGetLastError());
@@ -1732,8 +1744,11 @@ static int run_forward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_ste
             const int64_t nt = u.blk(t + 1), np = u.blk(u.T + t + 1);
             const int grid = (rows * Db + 255) / 256 < 256 ? (rows * Db + 255) / 256 : 256;
             hipLaunchKernelGGL(scatter_state_kernel, dim3(grid), dim3(256), 0, st,
-                               w + wwm.act.back() + bp * ldo_wm, ldo_wm, rows, Db, w + wte.in + nt * ld_te, ld_te,
-                               w + wmd.in + nt * ld_md, ld_md, w + wwm.in + np * ld_wm, ld_wm,
+                               w + wwm.act.back() + bp * ldo_wm, ldo_wm, rows, Db,
+                               // (input subsets: a stack that does not read s_t keeps zeros there)
+                               c->L.cfg.te_inputs == PVAE_INPUT_TASK ? (float*)nullptr : w + wte.in + nt * ld_te, ld_te,
+                               c->L.cfg.md_inputs == PVAE_INPUT_TASK ? (float*)nullptr : w + wmd.in + nt * ld_md, ld_md,
+                               w + wwm.in + np * ld_wm, ld_wm,
                                u.use_g ? w + wwm.in + nt * ld_wm : (float*)nullptr, ld_wm);
             HIP_TRY(hipGetLastError());
         }
@@ -2355,7 +2370,7 @@ int pvae_read_tensor(pvae_ctx* c, int what, float* dst, int32_t rows, void* stre
         case 1:
             if (c->L.cfg.prior_kind >= PVAE_PRIOR_HYPERSPHERE) return fail(-1, "this encoder has no logvar");
             src = c->ws + wte.act.back(); ld = c->L.net[PVAE_NET_TE].layers.back().n_out_pad; col0 = Z; nc = Z; break;
-        case 2: src = c->ws + c->W.net[PVAE_NET_MD].in; ld = c->L.net[PVAE_NET_MD].layers[0].ld; col0 = Db; nc = Z; break;
+        case 2: src = c->ws + z_panel(c); ld = c->L.net[PVAE_NET_MD].layers[0].ld; col0 = Db; nc = Z; break;
         case 3: src = c->ws + c->W.net[PVAE_NET_MD].act.back(); ld = c->L.net[PVAE_NET_MD].layers.back().n_out_pad; col0 = 0; nc = Da; break;
         case 4: src = c->ws + c->W.net[PVAE_NET_WM].act.back(); ld = c->L.net[PVAE_NET_WM].layers.back().n_out_pad; col0 = 0; nc = Db;
                 if (c->W.L > 1) blk += (int64_t)c->W.L * rows_pad;      // the predicted-action invocation

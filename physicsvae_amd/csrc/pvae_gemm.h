@@ -137,6 +137,9 @@ struct StageArgs {
     float* act_t; int ld_a;
     float* wm_pred;
     float* pr_in; int ld_pr;      // input panel of the learned prior stack [s1 | 0] (null: no such stack)
+    int in_off = 0;               // input subsets (pvae_config.te_inputs / md_inputs): blocks written as ZEROS -- 1: the encoder's
+                                  // s_t, 2: the encoder's s_{t+1}, 4: the decoder's s_t (the weights there are structural zeros;
+                                  // a zero operand keeps their gradient exactly zero)
 };
 
 __device__ inline void stage_row(const StageArgs& a, int r, int t, int rows_pad) {
@@ -170,9 +173,10 @@ __device__ inline void stage_row(const StageArgs& a, int r, int t, int rows_pad)
         if (c < a.ld_te) {
             float u = v1;
             if (c >= Db) u = (valid && c < 2 * Db) ? p2[c - Db] : 0.f;
+            if (a.in_off & (c < Db ? 1 : 2)) u = 0.f;
             a.te_in[prow * a.ld_te + c] = u;
         }
-        if (c < a.ld_md) a.md_in[prow * a.ld_md + c] = v1;      // z columns filled by reparam
+        if (c < a.ld_md) a.md_in[prow * a.ld_md + c] = (a.in_off & 4) ? 0.f : v1;      // z columns filled by reparam
         if (c < a.ld_wm) {
             float u = v1;
             if (c >= Db) u = (valid && pa && c < Db + Da) ? pa[c - Db] : 0.f;
@@ -250,8 +254,9 @@ __device__ inline void stage_row_wave(const StageArgs& a, int r, int t, int rows
             const unsigned off = (unsigned)c * 4u;
             const unsigned u1 = __builtin_bit_cast(unsigned, v1[k]);
             __builtin_amdgcn_raw_buffer_store_b32(u1, dpr, off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c < Db ? v1[k] : v2[k]), dte, off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(u1, dmd, off, 0, 0);            // z columns filled by the sampler
+            const float ute = (a.in_off & (c < Db ? 1 : 2)) ? 0.f : (c < Db ? v1[k] : v2[k]);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ute), dte, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((a.in_off & 4) ? 0u : u1, dmd, off, 0, 0);   // z columns filled by the sampler
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c < Db ? v1[k] : vw[k]), dwm, off, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(u1, dwp, off, 0, 0);            // a_hat columns filled by the decoder
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vt[k]), ds2, off, 0, 0);
@@ -329,8 +334,9 @@ __device__ inline void stage_row_lds(const StageArgs& a, int r, int t, int rows_
         }
     };
     const bool s1_on = valid && first;
-    put(a.te_in, a.ld_te, [&](int c, int& i, bool& on) { i = c; on = c < Db ? s1_on : (valid && c < 2 * Db); });
-    put(a.md_in, a.ld_md, [&](int c, int& i, bool& on) { i = c; on = s1_on && c < Db; });          // z columns filled by the sampler
+    const bool te_b = s1_on && !(a.in_off & 1), te_t = valid && !(a.in_off & 2), md_b = s1_on && !(a.in_off & 4);
+    put(a.te_in, a.ld_te, [&](int c, int& i, bool& on) { i = c; on = c < Db ? te_b : (te_t && c < 2 * Db); });
+    put(a.md_in, a.ld_md, [&](int c, int& i, bool& on) { i = c; on = md_b && c < Db; });           // z columns filled by the sampler
     put(a.wm_in, a.ld_wm, [&](int c, int& i, bool& on) { i = c < Db ? c : c + Db; on = c < Db ? s1_on : (have_a && c < Db + Da); });
     put(a.wm_pred, a.ld_wm, [&](int c, int& i, bool& on) { i = c; on = s1_on && c < Db; });        // a_hat columns filled by the decoder
     put(a.pr_in, a.ld_pr, [&](int c, int& i, bool& on) { i = c; on = s1_on && c < Db; });

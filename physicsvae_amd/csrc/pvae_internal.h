@@ -182,8 +182,8 @@ struct pvae_ctx {
     // epilogues.  pvae_gather / pvae_set_batch + pvae_forward_backward keep the panel path (inspection, explicit batches,
     // lookahead > 1, evaluation, the other priors).  OPT-IN (pvae_set_direct(ctx, 1)): bit-identical to the staged step,
     // but at 256 rows the staged step is the faster one -- its gather rides in the previous step's last launch for free,
-    // while a gathered first layer waits for its operand descriptor (kernel arguments that cannot be preloaded) before its
-    // first tile fetch: joint 252.3 vs 241.5 us, world 92.1 vs 87.3 (docs/experiments.md, round 5).
+    // while the gathered layer-0 weight gradients assemble every chunk of X from two unaligned loads and a select in the
+    // launch that also carries the Adam epilogue: joint 250.0 vs 240.3 us, world 92.2 vs 86.6 (docs/experiments.md, round 5).
     bool direct = false;
     bool data_slack = false;     // both dataset arrays are readable 16 bytes past their last row (checked at bind time)
     struct { bool on = false; RowMap rm{}; } dx;                     // the step in flight: batch row -> row of the set
@@ -229,10 +229,14 @@ struct pvae_ctx {
     // every call that changes parameters through this library counts here and leaves its stream: the rollout server re-reads
     // its resident copy when the count moved (after that stream has drained)
     unsigned long long param_version = 0;
-    hipStream_t param_stream = nullptr;                  // (NULL is a stream too: the default one)
+    hipStream_t param_stream = nullptr;                  // (NULL is a stream too: the default one.  The caller's stream must
+                                                         //  outlive the writes it queued, as for any other call here.)
     bool param_pending = false;                          // work that writes the parameters may still be queued on it
 };
 static inline void params_touched(pvae_ctx* c, hipStream_t st, bool queued = true) {
+    // one stream is remembered: writes still queued on ANOTHER one are drained here (a caller that switches streams with
+    // parameter writes in flight -- rare, and it costs that caller one wait -- instead of a server that reloads too early)
+    if (c->param_pending && c->param_stream != st) (void)hipStreamSynchronize(c->param_stream);
     ++c->param_version; c->param_stream = st; c->param_pending = queued;
 }
 static inline hipError_t params_settle(pvae_ctx* c) {

@@ -18,6 +18,8 @@ struct Layer {
     int64_t w_off, b_off;
     bool last;
     int act = 0;                  // act_apply / act_grad code of this layer's output: 0 linear, 1 + PVAE_ACT_* otherwise
+    int col0 = 0;                 // first layer on an input subset: the checkpoint tensor is columns [col0, col0 + n_in) of the
+                                  // block's rows (ld and the kernels' K stay those of the full-width input)
 };
 
 struct NetLayout {
@@ -57,6 +59,7 @@ inline Layout make_layout(const pvae_config& c) {
         L.why = "latent priors other than normal_zero_mean_one_std need lookahead == 1";
         return L;
     }
+    if (c.te_inputs < 0 || c.te_inputs > 3 || c.md_inputs < 0 || c.md_inputs > 3) { L.why = "te_inputs / md_inputs: PVAE_INPUT_* bits"; return L; }
     const bool learned = c.prior_kind == PVAE_PRIOR_STATE_MEAN;
     if (learned && (c.pr_width <= 0 || c.pr_depth <= 0 || c.pr_depth > 15)) { L.why = "prior stack width/depth out of range"; return L; }
     const int Db = c.dim_body, Da = c.dim_action, Z = c.latent;
@@ -73,14 +76,20 @@ inline Layout make_layout(const pvae_config& c) {
         N.n_in = ins[n];
         N.n_out = outs[n];
         int prev = ins[n];
+        // input subsets (rmt:607-613, 646-653): the window of the full-width first layer that the checkpoint tensor is
+        int win0 = 0, win = ins[n];
+        const int sel = n == PVAE_NET_TE ? c.te_inputs : (n == PVAE_NET_MD ? c.md_inputs : 0);
+        if (sel == PVAE_INPUT_BODY) win = Db;
+        else if (sel == PVAE_INPUT_TASK) { win0 = Db; win = ins[n] - Db; }
         for (int i = 0; i <= depths[n]; ++i) {
             Layer l;
-            l.net = n; l.index = i; l.n_in = prev;
+            l.net = n; l.index = i; l.n_in = i == 0 ? win : prev;
+            l.col0 = i == 0 ? win0 : 0;
             l.last = (i == depths[n]);
             l.n_out = l.last ? outs[n] : (c.layer_width[n][i] > 0 ? c.layer_width[n][i] : widths[n]);
             const int act_pub = l.last ? PVAE_ACT_LINEAR : (c.layer_act[n][i] > 0 ? c.layer_act[n][i] - 1 : c.act_kind);
             l.act = act_pub == PVAE_ACT_LINEAR ? 0 : act_pub + 1;
-            l.ld = pad64(l.n_in);
+            l.ld = pad64(prev);
             l.n_out_pad = pad64(l.n_out);
             // (the fused backward launches carry row strides in 16 bits: pvae_gemm.h ga_packable)
             if (l.ld >= 65536 || l.n_out_pad >= 65536) { L.why = "layer wider than 65535 (padded) unsupported"; return L; }
@@ -123,6 +132,7 @@ struct Workspace {
     int64_t alt_s2 = 0, alt_act_t = 0;
     int64_t loss_part = 0;      // [5][kLossParts] partial sums
     int64_t obs_keep = 0;       // [4][2*Db] the observation rows of the last <= 4-row rollout call (pvae_infer)
+    int64_t z_side = 0;         // motor_decoder_inputs = ["body"] only: where the sampler's z goes instead of the decoder's input panel
     int64_t zero = 0;           // 64 floats that nothing ever writes: what a gathered first-layer operand reads for "no source"
     int64_t total_floats = 0;
 };
@@ -157,6 +167,8 @@ inline Workspace make_workspace(const Layout& L) {
     W.alt_act_t = take((int64_t)W.Bp * pad64(L.cfg.dim_action));
     W.loss_part = take(5 * kLossParts);
     W.obs_keep = take(4 * 2 * (int64_t)L.cfg.dim_body);
+    if (L.cfg.md_inputs == PVAE_INPUT_BODY)
+        W.z_side = take((int64_t)W.net[PVAE_NET_MD].slots * W.Bp * L.net[PVAE_NET_MD].layers[0].ld);
     W.zero = take(64);
     W.total_floats = off;
     return W;

@@ -1,5 +1,6 @@
 // pvae_rollout_server.hip -- the call-persistent rollout server (rmt:742-771 at B = 1).  gfx950 only.
 #include "pvae_internal.h"
+#include <atomic>
 
 // ---------------------------------------------------------------------------------------
 // Call-persistent rollout server (rmt:742-771 at B = 1; callers envs/rllib_env_imitation.py:215-266).
@@ -27,11 +28,15 @@ struct SrvRequest {                       // host -> device.  Lives in DEVICE me
     volatile uint32_t req_seq;            // written LAST by the host: request number
     uint32_t cmd;                         // 0 infer, 1 stop, 2 reload the weights from the arena, then infer,
                                           // 3 decoder only ("pass_through", rllib_env_imitation.py:233-258): obs = [s1 (Db) | z (Z)]
-    uint32_t noise, pad0;
+    uint32_t noise, check;                // check: srv_check() of the other seven words -- the kernel takes a line only when it
+                                          // matches, so a read of the line that saw req_seq but an older cmd / seed is re-polled
     uint32_t seed_lo, seed_hi, off_lo, off_hi;
     uint32_t pad1[8];
     float obs[kSrvMaxObs];
 };
+__host__ __device__ inline uint32_t srv_check(uint32_t seq, uint32_t cmd, uint32_t noise, uint32_t s0, uint32_t s1, uint32_t o0, uint32_t o1) {
+    return 0x5eedc0deu ^ seq ^ (cmd * 0x9e3779b1u) ^ (noise << 7) ^ s0 ^ (s1 * 3u) ^ (o0 * 5u) ^ (o1 * 7u);
+}
 struct SrvReply {                         // device -> host, pinned host memory (the host spins on its own RAM)
     volatile uint32_t done_seq;           // written LAST by the device: the request this result belongs to
     volatile uint32_t state;              // 0 not started, 1 serving, 2 exited (idle / stop / lifetime), 3 refused (placement)
@@ -58,6 +63,12 @@ struct SrvArgs {
     unsigned seq0;                        // requests served by earlier instances (this one answers seq0 + 1, ...)
     unsigned long long* dbg;              // [64] wall-clock stamps of group 0 for the LAST request (pvae_rollout_server_timeline)
 };
+// the control line as eight lanes read it (lane i: word i): whole iff word 3 is srv_check() of the other seven
+__device__ inline bool srv_line_whole(unsigned w) {
+    return srv_check(__builtin_amdgcn_readlane(w, 0), __builtin_amdgcn_readlane(w, 1), __builtin_amdgcn_readlane(w, 2),
+                     __builtin_amdgcn_readlane(w, 4), __builtin_amdgcn_readlane(w, 5), __builtin_amdgcn_readlane(w, 6),
+                     __builtin_amdgcn_readlane(w, 7)) == (unsigned)__builtin_amdgcn_readlane(w, 3);
+}
 __device__ inline unsigned srv_ldu(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // sc1: past the L1
 // A value travels between workgroups as ONE 8-byte word {tag, float bits}: the consumer polls the word itself (sc1 loads,
 // served by the XCD's L2) until it carries the tag of this request and layer -- no barrier between a layer and the next,
@@ -201,9 +212,9 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                 const unsigned* line = (const unsigned*)&a.req->req_seq;
                 unsigned w = 0, seq = last, cmd = 1;
                 for (;;) {
-                    if (lane < 8) w = __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // one 32-byte read
+                    if (lane < 8) w = __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // eight lanes, one 32-byte line
                     seq = __builtin_amdgcn_readlane(w, 0);
-                    if (seq != last) { cmd = __builtin_amdgcn_readlane(w, 1); break; }
+                    if (seq != last && srv_line_whole(w)) { cmd = __builtin_amdgcn_readlane(w, 1); break; }
                     const long long now = wall_clock64();
                     if (now - t_idle > a.idle_ticks || now - t_start > a.life_ticks) { seq = last + 1u; cmd = 1; break; }
                     __builtin_amdgcn_s_sleep(1);
@@ -236,7 +247,7 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                 for (;;) {
                     if (lane < 8) w = __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     seq = __builtin_amdgcn_readlane(w, 0);
-                    if (seq != last) { cmd = __builtin_amdgcn_readlane(w, 1); break; }
+                    if (seq != last && srv_line_whole(w)) { cmd = __builtin_amdgcn_readlane(w, 1); break; }
                     if ((++polls & 15u) == 0) {
                         if (srv_ldu(a.sync + 18) != 0u || wall_clock64() - t_start > a.life_ticks + 100000000ll) { seq = last + 1u; cmd = 1; w = 0; break; }
                     }
@@ -264,7 +275,12 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
         last = s_word[0];
         const unsigned cmd = s_word[1];
         if (cmd == 1u) break;
-        if (cmd == 2u) load_weights();
+        if (cmd == 2u) {
+            // the arena was rewritten (Adam's stores from other XCDs, an SDMA copy) while this kernel was resident: no kernel
+            // boundary has invalidated this XCD's L2 / this CU's L1 since, so do it here (off the served path's common case)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            load_weights();
+        }
         const int noise = (int)s_word[2];
         const unsigned long long seed = s_word[4] | ((unsigned long long)s_word[5] << 32);
         const unsigned long long offset = s_word[6] | ((unsigned long long)s_word[7] << 32);
@@ -568,8 +584,8 @@ int pvae_rollout_server_start(pvae_ctx* c, double idle_timeout_ms, double lifeti
     S.args.mb = S.mb_dev; S.args.req = S.req_dev; S.args.obs_direct = S.req_on_device ? 1 : 0;
     S.args.sync = S.sync; S.args.acts = S.acts; S.args.dbg = S.dbg;
     // (every server of this process on an XCD of its own: two engines can serve side by side)
-    static int next_xcd = 0;
-    if (S.xcd < 0) S.xcd = next_xcd++ & 7;
+    static std::atomic<int> next_xcd{0};
+    if (S.xcd < 0) S.xcd = next_xcd.fetch_add(1) & 7;
     S.args.xcd = S.xcd;
     return server_launch(c, S);
 }
@@ -582,6 +598,7 @@ static int server_request(pvae_ctx* c, uint32_t cmd, const float* obs, int noise
     rq->cmd = cmd; rq->noise = noise ? 1u : 0u;
     rq->seed_lo = (uint32_t)seed; rq->seed_hi = (uint32_t)(seed >> 32); rq->off_lo = (uint32_t)offset; rq->off_hi = (uint32_t)(offset >> 32);
     const uint32_t seq = ++S.seq;
+    rq->check = srv_check(seq, cmd, rq->noise, rq->seed_lo, rq->seed_hi, rq->off_lo, rq->off_hi);
     // the request word goes LAST: behind a store fence when the block is device memory (write-combined stores through the
     // BAR may leave the core out of order; posted PCIe writes then arrive in the order they left)
     if (S.req_on_device) __builtin_ia32_sfence();

@@ -59,8 +59,13 @@ class Arch:
     (per-layer widths and activations, what custom_model_config's *_layers can describe, rmt:462-510)."""
 
     def __init__(self, dim_body, dim_action, latent, te, md, wm, prior="normal_zero_mean_one_std", pr=None,
-                 act="relu"):
+                 act="relu", te_inputs=("body", "task"), md_inputs=("body", "task")):
         self.Db, self.Da, self.Z = int(dim_body), int(dim_action), int(latent)
+        # task_encoder_inputs / motor_decoder_inputs (rmt:470, 485): column windows of the full-width first layers
+        self.te_inputs, self.md_inputs = tuple(te_inputs), tuple(md_inputs)
+        for name, v in (("task_encoder_inputs", self.te_inputs), ("motor_decoder_inputs", self.md_inputs)):
+            if v not in _lib.INPUT_BITS:
+                raise NotImplementedError("%s = %r: a non-empty subset of ['body', 'task'], in that order" % (name, list(v)))
         if prior not in PRIOR_KINDS:
             raise NotImplementedError("Unknown latent_prior_type:%s" % (prior,))      # rmt:624-625
         self.prior = prior                       # latent_prior_type (rmt:614-635; oracle/refpath.py PRIORS)
@@ -84,10 +89,12 @@ class Arch:
             for i, (w, a) in enumerate(zip(st.widths, st.acts)):
                 cfg.layer_width[net][i] = w
                 cfg.layer_act[net][i] = 1 + _lib.LAYER_ACTS[a]
+        cfg.te_inputs, cfg.md_inputs = _lib.INPUT_BITS[self.te_inputs], _lib.INPUT_BITS[self.md_inputs]
         return cfg
 
     def key(self):
-        return (self.Db, self.Da, self.Z, self.te.key(), self.md.key(), self.wm.key(), self.prior, self.pr.key(), self.act)
+        return (self.Db, self.Da, self.Z, self.te.key(), self.md.key(), self.wm.key(), self.prior, self.pr.key(), self.act,
+                self.te_inputs, self.md_inputs)
 
 
 class GraphedInfer:
@@ -222,7 +229,7 @@ class HipEngine:
     def _view(self, arena, info, kind):
         if kind == "weight":
             blk = arena[info["w_offset"]: info["w_offset"] + info["n_out_pad"] * info["ld"]]
-            return blk.view(info["n_out_pad"], info["ld"])[: info["n_out"], : info["n_in"]]
+            return blk.view(info["n_out_pad"], info["ld"])[: info["n_out"], info["col0"]: info["col0"] + info["n_in"]]
         return arena[info["b_offset"]: info["b_offset"] + info["n_out"]]
 
     def named_views(self, arena=None):

@@ -273,8 +273,9 @@ class PhysicsVAE(nn.Module):
             raise NotImplementedError(cfg["log_std_type"])                      # rmt:182-183
         if cfg["latent_prior_type"] not in PRIOR_KINDS:
             raise NotImplementedError("Unknown latent_prior_type:%s" % (cfg["latent_prior_type"],))    # rmt:624-625
-        if cfg["task_encoder_inputs"] != ["body", "task"] or cfg["motor_decoder_inputs"] != ["body", "task"]:
-            raise NotImplementedError("task-encoder / motor-decoder inputs must be ['body','task']")
+        # rmt:470, 485: any non-empty subset of ["body", "task"] -- a column window of the full-width first layer (engine.Arch)
+        self._task_encoder_inputs = list(cfg["task_encoder_inputs"])
+        self._motor_decoder_inputs = list(cfg["motor_decoder_inputs"])
 
         self.dim_state_body = int(np.prod(cfg["observation_space_body"].shape))
         self.dim_state_task = int(np.prod(cfg["observation_space_task"].shape))
@@ -300,7 +301,7 @@ class PhysicsVAE(nn.Module):
         used = {a for st in ((te, md, wm, pr) if learned_prior else (te, md, wm)) for a in st.acts}
         act = next(iter(used)) if len(used) == 1 and next(iter(used)) != "linear" else "relu"
         self.arch = Arch(self.dim_state_body, self.dim_action, Z, te, md, wm, prior=self._latent_prior_type,
-                         pr=pr, act=act)
+                         pr=pr, act=act, te_inputs=self._task_encoder_inputs, md_inputs=self._motor_decoder_inputs)
         device = cfg["device"] or ("cuda" if torch.cuda.is_available() else "cpu")
         self.engine = HipEngine(self.arch, int(cfg["max_batch"]), device=device,
                                 lookahead=int(cfg.get("lookahead", 1) or 1))
@@ -332,7 +333,9 @@ class PhysicsVAE(nn.Module):
         self._motor_decoder_helper_range = cfg.get("motor_decoder_helper_range")
         if cfg.get("motor_decoder_helper_enable"):
             widths, acts, inits = _helper_stack(cfg["motor_decoder_helper_layers"], self._motor_decoder_helper_range)
-            dims, prev = [], self.dim_state_body + Z
+            # (the helper reads what the decoder reads, rmt:646-653, 674-680)
+            dims, prev = [], (self.dim_state_body * ("body" in self._motor_decoder_inputs) +
+                              Z * ("task" in self._motor_decoder_inputs))
             for width in widths:
                 dims.append((prev, width))
                 prev = width
@@ -623,6 +626,9 @@ class PhysicsVAE(nn.Module):
         a_hat = self.engine.net_forward(NET_MD, z)
         mh = self._motor_decoder_helper
         if mh is not None:                                            # rmt:833-835
+            if self._motor_decoder_inputs != ["body", "task"]:        # rmt:822-829: the helper's own weights are compact
+                z = z[..., : self.dim_state_body] if self._motor_decoder_inputs == ["body"] else z[..., self.dim_state_body:]
+                z = z.contiguous()
             if torch.is_grad_enabled():
                 add = mh(z.float())
             else:

@@ -116,9 +116,14 @@ class DataParallel:
                 ok, err = False, str(exc)
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=engine.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        head = None
         if int(flag.item()) == 1:
             # every rank has its peers mapped: prove remote write / remote read / flag delivery before the first step
-            # (bounded: a mapping that does not reach its peer fails within a second instead of hanging a training step)
+            # (bounded: a mapping that does not reach its peer fails within a second instead of hanging a training step).
+            # The arena part of the test writes patterns into the first 1 KB of the LIVE parameter and gradient arenas
+            # and restores them itself -- but after a wait that timed out, a late peer's store can land behind that
+            # restore.  So the words are kept here too, and put back once every rank has unmapped its peers (below).
+            head = (engine.params[:256].clone(), engine.grads[:256].clone())
             try:
                 engine.p2p_selftest()
             except Exception as exc:                               # noqa: BLE001
@@ -127,6 +132,11 @@ class DataParallel:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         if int(flag.item()) != 1:
             engine.p2p_close()
+            if head is not None:
+                torch.cuda.synchronize(engine.device)
+                dist.barrier(group=self.group)                     # nobody can reach this rank's arenas any more
+                engine.params[:256].copy_(head[0]); engine.grads[:256].copy_(head[1])
+                engine.params_changed()
             if self.rank == 0 or err:
                 print("[physicsvae_amd] peer-mapped exchange unavailable (%s)" % (err or "another rank failed"), file=sys.stderr)
             return False

@@ -327,6 +327,10 @@ class TrainModel(tune.Trainable):
         """`dp_exchange = "auto"`: time every exchange form this build and this machine offer on the first global
         minibatch (parameters and moments restored afterwards) and keep the fastest whose replicas stay bit-identical."""
         eng, dp = self.engine, self.dp
+        if getattr(self, "dp_sharded", False) and eng.in_library_exchange:
+            # the form about to be replaced left every rank with valid Adam moments for its own slices only; the next
+            # form may own differently (or replicate): assemble them on every rank while the ownership is still known
+            self.gather_moments()
         if not eng.in_library_exchange:
             dp.attach(eng)
         first, rows, global_rows = dp.shard(0, len(loader.dataset), loader.batch_size)
@@ -345,6 +349,13 @@ class TrainModel(tune.Trainable):
         self.optimizer.net_steps.update(counts)
         self.dp_exchange_chosen = chosen
         if chosen is None:                         # nothing in-library qualified: the torch.distributed transport carries on
+            # -- for real: the engine is left in whatever form the last rejected candidate set, so detach it (dp_step
+            # routes on eng.in_library_exchange) and forget the previous phase's sharding
+            self.dp_sharded = False
+            if eng.has_p2p:
+                eng.p2p_close()
+            if eng.has_comm:
+                eng.comm_destroy()
             if dp.rank == 0:
                 print("[physicsvae_amd] dp_exchange auto: no in-library exchange form available (%s); using torch.distributed"
                       % self.dp_exchange_report, file=sys.stderr)

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pvae_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.pvae_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_layout_queries_without_gpu():
@@ -990,3 +990,39 @@ def test_build_command_keeps_the_kernarg_preload_switch():
     for kernel in ("gemm_splitk_ws_kernel(PVAE_GA_PARAMS(a_)", "gemm_splitk_reg16_kernel(PVAE_GA_PARAMS(a_)",
                    "bwd_pair_kernel(PVAE_GA2_PARAMS", "wgrad_pair_kernel(PVAE_GA2_PARAMS"):
         assert kernel in hdr, kernel
+
+
+def test_input_subsets_layout_matches_the_reference_capture(golden):
+    """task_encoder_inputs / motor_decoder_inputs (rmt:470, 485): the reference builds narrower first layers; same keys
+    and shapes here -- as column windows of the full-width weight blocks, whose other columns are structural zeros that
+    neither the initialisation nor a state-dict load touches."""
+    g = golden("subsets_tiny")
+    base = arch_from_meta(g["meta"])
+    n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
+    data = R.synth_demo(0, n_ep, n_steps, base["Db"], base["Da"], kind="iid")
+    Db, Z = base["Db"], base["Z"]
+    for ci, combo in enumerate(g["combos"]):
+        te_in, md_in = (tuple(part.split("+")) for part in str(combo).split("/"))
+        arch = R.with_inputs(base, te_in, md_in)
+        tr = make_trainer(arch, data, batch, device="cpu")
+        sd = tr.model.state_dict()
+        assert list(sd.keys()) == [str(k) for k in g["c%d_sd_keys" % ci]]
+        for (k, v), shp in zip(sd.items(), g["c%d_sd_shapes" % ci]):
+            assert list(v.shape) == [int(x) for x in shp[: v.dim()]], k
+        assert [(k, tuple(v.shape)) for k, v in sd.items()] == R.state_dict_spec(arch)
+        eng = tr.engine
+        want = {_lib.NET_TE: {("body", "task"): (0, 2 * Db), ("body",): (0, Db), ("task",): (Db, Db)}[te_in],
+                _lib.NET_MD: {("body", "task"): (0, Db + Z), ("body",): (0, Db), ("task",): (Db, Z)}[md_in]}
+        tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3))
+        for info in eng.layers:
+            if info["index"] == 0 and info["net"] in want:
+                assert (info["col0"], info["n_in"]) == want[info["net"]]
+                assert info["ld"] == 64 * ((sum({_lib.NET_TE: (Db, Db), _lib.NET_MD: (Db, Z)}[info["net"]]) + 63) // 64)
+                blk = eng.params[info["w_offset"]: info["w_offset"] + info["n_out_pad"] * info["ld"]].view(info["n_out_pad"], info["ld"])
+                inside = blk[: info["n_out"], info["col0"]: info["col0"] + info["n_in"]]
+                assert float(inside.abs().min()) > 0.0
+                assert int((blk != 0).sum()) == inside.numel()                    # everything outside the window is zero
+            else:
+                assert info["col0"] == 0
+    with pytest.raises(NotImplementedError):
+        make_trainer(dict(base, te_inputs=("task", "body")), data, batch, device="cpu")

@@ -418,3 +418,38 @@ def test_known_answer_run_of_the_reference(golden):
     np.testing.assert_allclose(losses[:2], g["world_epoch_losses"], rtol=1e-7)
     np.testing.assert_allclose(losses[2:], g["joint_epoch_losses"], rtol=1e-6)
     np.testing.assert_allclose(g["world_epoch_losses"], [1.0004073202989663, 0.9972580170175832], rtol=1e-12)
+
+
+def subset_combos(g):
+    return [tuple(tuple(part.split("+")) for part in str(c).split("/")) for c in g["combos"]]
+
+
+def test_input_subsets_restatement_matches_reference(golden):
+    """`task_encoder_inputs` / `motor_decoder_inputs` (rmt:470, 485; 607-613, 646-653, 776-783, 822-829): for every
+    captured combination the restated model has the reference's state-dict layout (narrower first layers) and, at the
+    same seeded weights, minibatch and sampler draws, the reference's total, code, prediction and gradients in both
+    phases -- including which parameters receive a gradient at all (a decoder on ["body"] leaves the encoder with the
+    KL term's gradient only)."""
+    g = golden("subsets_tiny")
+    base = arch_from_meta(g["meta"])
+    n_ep, n_steps, batch = [int(v) for v in g["meta"][9:12]]
+    data = R.synth_demo(0, n_ep, n_steps, base["Db"], base["Da"], kind="iid")
+    X, Y = R.build_windows(data)
+    x, y = next(iter(R.make_loader(X, Y, batch)))
+    for ci, (te_in, md_in) in enumerate(subset_combos(g)):
+        arch = R.with_inputs(base, te_in, md_in)
+        pre = "c%d_" % ci
+        spec = R.state_dict_spec(arch)
+        assert [k for k, _ in spec] == list(g[pre + "sd_keys"])
+        assert [list(s) + [0] * (2 - len(s)) for _, s in spec] == g[pre + "sd_shapes"].tolist()
+        sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+        eps = torch.from_numpy(g[pre + "eps"])
+        for world in (True, False):
+            tag = pre + ("world" if world else "joint")
+            out = R.loss_and_grads(arch, sd, x, y, eps, world)
+            np.testing.assert_allclose(out["total"].numpy(), g[tag + "_total"], rtol=1e-6)
+            np.testing.assert_allclose(out["z"].numpy(), g[tag + "_z"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(out["future_state"].numpy(), g[tag + "_future_state"], rtol=1e-5, atol=1e-6)
+            assert list(out["grads"].keys()) == list(g[tag + "_grad_keys"])
+            for k, gr in out["grads"].items():
+                np.testing.assert_allclose(gr.numpy(), g["%s_grad::%s" % (tag, k)], rtol=1e-4, atol=1e-8)

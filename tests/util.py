@@ -57,6 +57,9 @@ def make_trainer(arch, data, batch, m_world=2, device=None, eps_fn=None, lr_step
     if arch.get("prior") == R.PRIORS[1] and tuple(arch["pr"]) != tuple(arch["te"]):
         cfg["model"]["custom_model_config"]["latent_prior_layers"] = T.gen_layers(arch["pr"][0], arch["pr"][1])
     cfg["lr_schedule_params"] = {"step_size": lr_step, "gamma": 0.7}
+    for key, name in (("te_inputs", "task_encoder_inputs"), ("md_inputs", "motor_decoder_inputs")):   # rmt:470, 485: dict edits
+        if key in arch:
+            cfg["model"]["custom_model_config"][name] = list(arch[key])
     if device is not None:
         cfg["model"]["custom_model_config"]["device"] = device
     if eps_fn is not None:
