@@ -61,8 +61,9 @@ def test_one_minibatch_matches_the_reference_capture(golden, ci):
         assert float(loss[0]) == pytest.approx(float(g[tag + "_total"]), rel=1e-5)
         want = R.loss_and_grads(arch, sd, x, y, eps, world)
         assert float(loss[0]) == pytest.approx(float(want["total"]), rel=1e-5)
-        assert max_err_scaled(eng.read("z", batch).cpu(), g[tag + "_z"]) < 2e-5
-        assert max_err_scaled(eng.read("s2_hat", batch).cpu(), g[tag + "_future_state"]) < 2e-5
+        if not world:        # (the world phase runs the world model alone: its loss terms need nothing else, tpv:331-335)
+            assert max_err_scaled(eng.read("z", batch).cpu(), g[tag + "_z"]) < 2e-5
+            assert max_err_scaled(eng.read("s2_hat", batch).cpu(), g[tag + "_future_state"]) < 2e-5
         gv = eng.named_views(eng.grads)
         for k in g[tag + "_grad_keys"]:
             k = str(k)
@@ -180,7 +181,7 @@ def test_served_forward_and_direct_refusal_with_subsets():
     ref_m.latent_prior_noise = False
     tr.model.latent_prior_noise = False
     X, _ = R.build_windows(data)
-    obs = X[:1, 0, :]
+    obs = torch.as_tensor(X[:1, 0, :], dtype=torch.float32)
     with torch.no_grad():
         want = ref_m(obs)
     tr.model.start_rollout_server()
