@@ -36,14 +36,18 @@
 extern "C" {
 #endif
 
-#define PVAE_ABI_VERSION 9
+#define PVAE_ABI_VERSION 10
 
 typedef struct pvae_ctx pvae_ctx;
 
 /* PVAE_NET_PR: the learned prior mean `_latent_prior` (rmt:627-635), present only with
- * PVAE_PRIOR_STATE_MEAN.  Arena order is TE | MD | PR | WM, so that the stacks trained together in
- * the joint phase (TE, MD, PR) form one contiguous segment. */
-enum { PVAE_NET_TE = 0, PVAE_NET_MD = 1, PVAE_NET_WM = 2, PVAE_NET_PR = 3, PVAE_NUM_NETS = 4 };
+ * PVAE_PRIOR_STATE_MEAN.  PVAE_NET_MH: the motor decoder's helper `_motor_decoder_helper` (rmt:670-680, 833-835),
+ * present only with pvae_config.mh_depth > 0: a second stack on the decoder's input whose tanh output, scaled by
+ * mh_range, is added to the action; the reference's supervised loss sees that term inside a_hat, so the joint phase
+ * trains the helper with the decoder (pvae_step_params.adam_t[PVAE_NET_MH] == 0: frozen for this step).
+ * Arena order is TE | MD | MH | PR | WM, so that the stacks trained together in the joint phase form one
+ * contiguous segment. */
+enum { PVAE_NET_TE = 0, PVAE_NET_MD = 1, PVAE_NET_WM = 2, PVAE_NET_PR = 3, PVAE_NET_MH = 4, PVAE_NUM_NETS = 5 };
 /* latent_prior_type (rmt:614-635, 795-819; tpv:384-409).  Only the first runs upstream; the other two
  * follow the specification in oracle/refpath.py (the reference sketches them and crashes):
  *   ZERO_MEAN   "normal_zero_mean_one_std"  KL(N(mu,s^2) || N(0,1))
@@ -104,6 +108,11 @@ typedef struct pvae_config {
      * staged input panels hold zeros there, so their weight gradient is exactly zero); pvae_layer_info reports the
      * window (n_in, col0), so a checkpoint tensor has the reference's shape. */
     int32_t te_inputs, md_inputs;
+    /* motor_decoder_helper_enable / _layers / _range (rmt:490-498): mh_depth hidden layers (0: no helper) of mh_width
+     * (layer_width / layer_act[PVAE_NET_MH] per layer), an output layer of dim_action values ending in tanh, input =
+     * the decoder's (md_inputs applies); needs lookahead == 1 and mh_range > 0 (asserted upstream, rmt:672-673). */
+    int32_t mh_width, mh_depth;
+    float mh_range;
 } pvae_config;
 #define PVAE_INPUT_BODY 1
 #define PVAE_INPUT_TASK 2

@@ -734,6 +734,78 @@ def case_subsets(name, arch, batch=8):
     print("wrote", name)
 
 
+def case_helper_train(name, arch, n_ep=3, n_steps=21, batch=8, m_world=2, n_epochs=5):
+    """Supervised training of a model with `motor_decoder_helper_enable` (rmt:490-498, 670-680, 833-835): the helper's
+    term sits inside a_hat, so the reference's own compute_loss / optimizer train the helper together with the decoder
+    (nothing ever freezes it: tpv:326-329, 347-350 switch encoder, decoder and world model only).  Recorded: one
+    minibatch in both phases at seeded weights (total, every gradient -- the helper has none in the world phase and one
+    in the joint phase), and the reference's own training loop over `n_epochs` epochs (epoch losses, final weights)."""
+    harch = R.with_helper(arch)
+    data = R.synth_demo(seed=0, n_episodes=n_ep, n_steps=n_steps, dim_body=arch["Db"], dim_action=arch["Da"], kind="dynamics")
+    fix = {}
+    with tempfile.TemporaryDirectory() as td:
+        pkl = os.path.join(td, "demo.pkl")
+        R.write_demo(pkl, data)
+        orig = T.update_model_config
+
+        def update_model_config(trainer_config):
+            orig(trainer_config)
+            trainer_config["model"]["custom_model_config"]["motor_decoder_helper_enable"] = True
+        T.update_model_config = update_model_config
+        try:
+            tr = make_reference_trainer(pkl, arch, batch, m_world=m_world)
+        finally:
+            T.update_model_config = orig
+        m = tr.model
+        fix["helper_range"] = np.array(m._motor_decoder_helper_range)
+        sd = R.perturb_biases(R.init_state_dict(harch, seed=1), seed=3)
+        k_out = "_motor_decoder_helper._model.%d._model.0.weight" % len(harch["mh"])
+        sd[k_out] = sd[k_out] * 60.0               # (norm 0.01 rows would make the helper's term 1e-3 of the action)
+        m.load_state_dict(sd)
+        x, y = next(iter(tr.train_loader))
+        eps = R.eps_stream(2, arch["Z"])(0, (x.shape[0], arch["Z"]))
+        fix["eps"] = eps.numpy()
+        for world in (True, False):
+            tag = "world" if world else "joint"
+            m.set_learnable_task_encoder(not world)
+            m.set_learnable_motor_decoder(not world)
+            m.set_learnable_world_model(world)
+            tr.read_loss_fn_coeff(world=world)
+            m.train()
+            tr.optimizer.zero_grad()
+            with EpsPatch(lambda c, shape: eps):
+                loss = tr.compute_loss(y, x)
+            loss.backward()
+            fix[tag + "_total"] = loss.detach().numpy()
+            grads = grads_of(m)
+            fix[tag + "_grad_keys"] = np.array(list(grads.keys()))
+            for k, g in grads.items():
+                fix["%s_grad::%s" % (tag, k)] = g.numpy()
+        # the reference's own loop from the same weights, in a fresh trainer (phase switch after m_world epochs)
+        T.update_model_config = update_model_config
+        try:
+            tr = make_reference_trainer(pkl, arch, batch, m_world=m_world)
+        finally:
+            T.update_model_config = orig
+        tr.lr_scheduler = torch.optim.lr_scheduler.StepLR(tr.optimizer, step_size=2, gamma=0.7)
+        tr.model.load_state_dict(sd)
+        es = R.eps_stream(2, arch["Z"])
+        losses = []
+        with EpsPatch(lambda c, shape: es(c, shape)):
+            for e in range(n_epochs):
+                losses.append(tr.train()["mean_train_loss"])
+        fix["epoch_losses"] = np.array(losses, dtype=np.float64)
+        for k, v in tr.model.state_dict().items():
+            fix["final::" + k] = v.detach().numpy().copy()
+        named = dict(tr.model.named_parameters())
+        fix["adam_keys"] = np.array(list(named.keys()))
+        fix["adam_steps"] = np.array([float(tr.optimizer.state.get(p, {}).get("step", -1.0)) for p in named.values()])
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *wd(arch["te"]), *wd(arch["md"]), *wd(arch["wm"]), n_ep, n_steps, batch,
+                            m_world, n_epochs])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
+    print("wrote", name, "world", fix["world_total"], "joint", fix["joint_total"], "epochs", losses)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -779,6 +851,7 @@ def main():
         "noprior_tiny": lambda: case_noprior("noprior_tiny", tiny, 2, 14, 8),
         "helper_tiny": lambda: case_helper("helper_tiny", tiny),
         "subsets_tiny": lambda: case_subsets("subsets_tiny", tiny),
+        "helper_train_tiny": lambda: case_helper_train("helper_train_tiny", tiny),
         "helper_default": lambda: case_helper("helper_default", dflt),
         # the trainer's "act_fn" (hidden activation of every stack) and Adam's weight_decay: config keys a user edits
         "single_tiny_tanh": lambda: case_single("single_tiny_tanh", dict(tiny, act="tanh"), 2, 14, 8, full=True),

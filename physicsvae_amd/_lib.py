@@ -22,9 +22,11 @@ import torch  # noqa: F401  (load order matters)
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PVAE_LIB_PATH") or os.path.join(HERE, "libpvae_gfx950.so")   # env: A/B builds
 
-NET_TE, NET_MD, NET_WM, NET_PR = 0, 1, 2, 3
-NUM_NETS = 4
-NET_NAMES = {NET_TE: "_task_encoder", NET_MD: "_motor_decoder", NET_WM: "_world_model", NET_PR: "_latent_prior"}
+NET_TE, NET_MD, NET_WM, NET_PR, NET_MH = 0, 1, 2, 3, 4
+NUM_NETS = 5
+NET_NAMES = {NET_TE: "_task_encoder", NET_MD: "_motor_decoder", NET_WM: "_world_model", NET_PR: "_latent_prior",
+             NET_MH: "_motor_decoder_helper"}
+ARENA_ORDER = (NET_TE, NET_MD, NET_MH, NET_PR, NET_WM)           # pvae_layout.h kArenaOrder
 # latent_prior_type (rmt:614-635) -> pvae_config.prior_kind
 ACT_KINDS = {"relu": 0, "tanh": 1, "sigmoid": 2, "elu": 3}      # pvae_config.act_kind (get_activation_fn rmt:30-46)
 ACT_LINEAR = 4                                                   # per-layer only: no activation after a hidden layer
@@ -34,7 +36,7 @@ MAX_HIDDEN = 15
 PRIOR_KINDS = {"normal_zero_mean_one_std": 0, "normal_state_mean_one_std": 1, "hypersphere_uniform": 2, False: 3}
 PHASE_WORLD, PHASE_JOINT = 0, 1
 FLAG_FUSED_ADAM, FLAG_NO_BACKWARD = 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 LOSS_MSE, LOSS_L1 = 0, 1
 EXCHANGE_ALLREDUCE, EXCHANGE_SHARDED, EXCHANGE_P2P, EXCHANGE_LOCAL, EXCHANGE_P2P_PUSH = 0, 1, 2, 3, 4
 P2P_BLOB_BYTES, P2P_MAX_RANKS = 512, 8
@@ -45,7 +47,8 @@ class Config(C.Structure):
         "dim_body", "dim_action", "latent", "te_width", "te_depth", "md_width", "md_depth",
         "wm_width", "wm_depth", "max_batch", "lookahead", "prior_kind", "pr_width", "pr_depth", "act_kind")] + [
         ("layer_width", (C.c_int32 * 16) * NUM_NETS), ("layer_act", (C.c_int32 * 16) * NUM_NETS),
-        ("te_inputs", C.c_int32), ("md_inputs", C.c_int32)]
+        ("te_inputs", C.c_int32), ("md_inputs", C.c_int32),
+        ("mh_width", C.c_int32), ("mh_depth", C.c_int32), ("mh_range", C.c_float)]
 
 
 INPUT_BODY, INPUT_TASK = 1, 2                                     # pvae_config.te_inputs / md_inputs bits (0 = both)

@@ -74,6 +74,36 @@ __device__ inline float block_sum_256(float v) {
     return block_sum_256(v, red);
 }
 
+// The motor decoder's helper (rmt:833-835): a_hat[:, :Da] += range * h, h = the helper stack's tanh output.  The decoder's
+// output layer has already left a second copy of its own a_hat in the action columns of the world model's input panel.
+__global__ void __launch_bounds__(256)
+helper_add_kernel(float* __restrict__ a_hat, int lda, const float* __restrict__ h, int ldh, float* __restrict__ wm_in,
+                  int ldw, int col0, int rows, int Da, float range) {
+    const int total = rows * Da;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int r = idx / Da, c = idx - r * Da;
+        const float v = __fmaf_rn(range, h[(size_t)r * ldh + c], a_hat[(size_t)r * lda + c]);
+        a_hat[(size_t)r * lda + c] = v;
+        if (wm_in) wm_in[(size_t)r * ldw + col0 + c] = v;
+    }
+}
+// ... and its backward: the gradient wrt the action reaches the helper's pre-activation through range * tanh'
+// (dz_h = range * (1 - h^2) * d a_hat); pad rows / columns of the panel are written as zeros.
+__global__ void __launch_bounds__(256)
+helper_seed_kernel(const float* __restrict__ dz_a, int lda, const float* __restrict__ h, float* __restrict__ dz_h, int ldh,
+                   int rows, int rows_pad, int Da, float range) {
+    const int total = rows_pad * ldh;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int r = idx / ldh, c = idx - r * ldh;
+        float g = 0.f;
+        if (r < rows && c < Da) {
+            const float t = h[idx];
+            g = range * (1.0f - t * t) * dz_a[(size_t)r * lda + c];
+        }
+        dz_h[idx] = g;
+    }
+}
+
 // nn.MSELoss (tm:99; or nn.L1Loss, tm:100-101, when l1) of pred vs target over rows x D, plus its
 // gradient:
 //   partial[b] = sum (pred - target)^2 over this block's rows      (finalize scales by 1/(B*D))
@@ -1377,6 +1407,7 @@ static bool direct_ok(const pvae_ctx* c, int phase, int rows, const pvae_step_pa
         return false;
     if (rows <= 4 || c->L.cfg.prior_kind != PVAE_PRIOR_ZERO_MEAN || !c->L.net[PVAE_NET_PR].layers.empty()) return false;
     if ((c->L.cfg.te_inputs | c->L.cfg.md_inputs) % 3 != 0) return false;      // input subsets: the staged panels carry the zeros
+    if (!c->L.net[PVAE_NET_MH].layers.empty()) return false;                     // the helper reads the staged decoder panel
     if (fused && !(c->defer_adam && c->grads)) return false;          // (the same-layer schedule of plan_backward_net)
     if (Da > ProCols::kMaxN || Z > ProCols::kMaxN || Db < 64 || 2 * Db >= 65536) return false;
     const int rp = pad32(rows);
@@ -1428,8 +1459,10 @@ static int step_shape(pvae_ctx* c, int phase, int rows, const pvae_step_params* 
     S.kl_active = phase == PVAE_PHASE_JOINT && sp->kl_coeff > 0.0f && sp->a_rec_coeff > 0.0f &&   // tpv:381-384
                   c->L.cfg.prior_kind != PVAE_PRIOR_NONE;                 // (`if self.latent_prior_type and ...`)
     // (the sphere's backward needs a dot product over a whole latent row, which no tile epilogue sees)
+    // (a helper stack sits between the two hand-overs -- its seed reads the decoder's, its input gradient joins the
+    //  decoder's before the sampler backward -- so a helper model takes the stand-alone glue kernels)
     S.seed_sampler = backward && phase == PVAE_PHASE_JOINT && c->W.L == 1 && c->pair_launch &&
-                     c->L.cfg.prior_kind < PVAE_PRIOR_HYPERSPHERE;
+                     c->L.cfg.prior_kind < PVAE_PRIOR_HYPERSPHERE && c->L.net[PVAE_NET_MH].layers.empty();
     S.seed_action = S.seed_sampler && S.cyc_grad;
     float* part = c->ws + c->W.loss_part;
     memset(&S.lf, 0, sizeof(S.lf));
@@ -1554,6 +1587,15 @@ static int run_forward(pvae_ctx* c, int phase, int rows, const pvae_step_params*
     if (S.fold_sampler) md_tail.pro0 = &pro;
     if (dx) { xs_md = xsrc_of(c, PVAE_NET_MD, phase, !S.fold_sampler, rows); md_tail.xs0 = &xs_md; }
     if ((rc = forward_net(c, PVAE_NET_MD, S.rows_pad, st, md_tail))) return rc;
+    const NetLayout& MH = c->L.net[PVAE_NET_MH];
+    if (!MH.layers.empty()) {                  // rmt:833-835: the helper's term joins the action before anything reads it
+        if ((rc = forward_net(c, PVAE_NET_MH, S.rows_pad, st))) return rc;
+        const int grid = (rows * Da + 255) / 256 < 256 ? (rows * Da + 255) / 256 : 256;
+        hipLaunchKernelGGL(helper_add_kernel, dim3(grid), dim3(256), 0, st, w + wmd.act.back(), MD.layers.back().n_out_pad,
+                           w + c->W.net[PVAE_NET_MH].act.back(), MH.layers.back().n_out_pad, w + wwm.in, WM.layers[0].ld, Db,
+                           rows, Da, c->L.cfg.mh_range);
+        HIP_TRY(hipGetLastError());
+    }
     // cycle loss (tpv:417-419) fused into the world model's output layer
     mse.grad_scale = sp->cycle_coeff * S.gs / (S.Bg * Db);
     mse.partial = part + 4 * kLossParts;
@@ -1624,6 +1666,24 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
         };
     }
     if (!backward) return;
+    const NetLayout* MH = &c->L.net[PVAE_NET_MH];
+    const NetWork* wmh = &c->W.net[PVAE_NET_MH];
+    const bool helper = !MH->layers.empty();
+    if (helper) {
+        // d a_hat (just formed above: reconstruction + what came back through the world model) -> the helper's output layer,
+        // then the helper's own backward: trained like the decoder (adam_t[PVAE_NET_MH] > 0) or passed through
+        const int rows_pad = S.rows_pad, ldh = MH->layers.back().n_out_pad;
+        const float range = c->L.cfg.mh_range;
+        plan.emplace_back();
+        plan.back().run = [=]() -> int {
+            const int tot = rows_pad * ldh;
+            hipLaunchKernelGGL(helper_seed_kernel, dim3((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256), dim3(256), 0, st,
+                               w + wmd->dz.back(), ldo_md, w + wmh->act.back(), w + wmh->dz.back(), ldh, rows, rows_pad, Da, range);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        };
+        plan_backward_net(c, PVAE_NET_MH, S.rows_pad, sp->adam_t[PVAE_NET_MH] > 0, true, sp, fused, st, nullptr, plan);
+    }
     const float kls = S.kl_active ? sp->kl_coeff / S.Bg : 0.0f;
     InputSeed ss;
     if (seed_sampler) {
@@ -1649,6 +1709,13 @@ static void plan_backward(pvae_ctx* c, int phase, int rows, const pvae_step_para
         const int tot = rows_pad * TE->layers.back().n_out_pad;
         plan.emplace_back();
         plan.back().run = [=]() -> int {
+            if (helper) {                      // z feeds the helper too: its input gradient joins the decoder's
+                const int grid = (rows * Z + 255) / 256 < 256 ? (rows * Z + 255) / 256 : 256;
+                hipLaunchKernelGGL(add_cols_kernel, dim3(grid), dim3(256), 0, st, w + wmd->d_in + Db, MD->layers[0].ld, rows, Z,
+                                   (const float*)(w + wmh->d_in + Db), MH->layers[0].ld, (const float*)nullptr, 0,
+                                   (const float*)nullptr, 0, (const float*)nullptr, 0);
+                HIP_TRY(hipGetLastError());
+            }
             if (sphere) {
                 hipLaunchKernelGGL(sphere_bwd_kernel, dim3((rows_pad + 3) / 4), dim3(256), 0, st, w + wmd->d_in,
                                    MD->layers[0].ld, Db, w + wte->act.back(), TE->layers.back().n_out_pad, w + c->W.eps,
@@ -1817,7 +1884,7 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
     std::vector<int> train_nets;
     if (joint) { train_nets.push_back(PVAE_NET_MD); train_nets.push_back(PVAE_NET_TE); }
     else train_nets.push_back(PVAE_NET_WM);
-    int krows_of[PVAE_NUM_NETS] = {0, 0, 0, 0};
+    int krows_of[PVAE_NUM_NETS] = {};
     if (backward) {
         for (int n : train_nets) {
             const NetLayout* N = &NL[n];
@@ -1852,7 +1919,7 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
     const bool look_pair_env = g_look_pair;
     const bool can_defer = fused && c->defer_adam && c->grads != nullptr;
     const bool look_pair = backward && look_pair_env && c->pair_launch && c->same_layer_pairs && (!fused || can_defer);
-    bool paired_done[PVAE_NUM_NETS] = {false, false, false, false};
+    bool paired_done[PVAE_NUM_NETS] = {};
     // layers last .. lo of stack n: dgrad_i over row block `slot` || wgrad_i over rows [0, krows); then, when lo == 1,
     // layer 0's weight gradient on its own.  `with_fold`: the stack's last launch also finalises the losses.
     auto paired_chain = [&](int n, int slot, int lo, bool with_fold) {
@@ -2211,7 +2278,9 @@ int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t row
     hipStream_t st = (hipStream_t)stream;
     params_touched(c, st);
     const bool learned_prior = !c->L.net[PVAE_NET_PR].layers.empty();
-    const int nets[3] = {phase == PVAE_PHASE_WORLD ? PVAE_NET_WM : PVAE_NET_MD,
+    const bool helper = !c->L.net[PVAE_NET_MH].layers.empty() && sp->adam_t[PVAE_NET_MH] > 0;
+    const int nets[4] = {phase == PVAE_PHASE_WORLD || !helper ? -1 : PVAE_NET_MH,
+                         phase == PVAE_PHASE_WORLD ? PVAE_NET_WM : PVAE_NET_MD,
                          phase == PVAE_PHASE_WORLD ? -1 : (learned_prior ? PVAE_NET_PR : PVAE_NET_TE),
                          phase == PVAE_PHASE_WORLD || !learned_prior ? -1 : PVAE_NET_TE};      // backward order
     c->bucket_bytes_now = auto_bucket_bytes(c, phase);
@@ -2401,7 +2470,8 @@ static int infer_impl(pvae_ctx* c, const float* obs, int32_t rows, const float* 
     if (ld_a < c->L.cfg.dim_action * (log_std ? 2 : 1)) return fail(-1, "row stride %d of the action buffer is too small", ld_a);
     hipStream_t st = (hipStream_t)stream;
     if (rows < 1 || rows > c->L.cfg.max_batch) return fail(-1, "rows %d outside [1, %d]", rows, c->L.cfg.max_batch);
-    const bool fused_rollout = rollout_fused();
+    const bool helper = !c->L.net[PVAE_NET_MH].layers.empty();          // (its term joins between decoder and world model: staged path)
+    const bool fused_rollout = rollout_fused() && !helper;
     if (rows <= 4 && fused_rollout) {
         // latency path of the control loop (rmt:742-771 at B = 1): no staging / sampler / copy launches, the
         // input panels of a staged training minibatch are not touched
@@ -2473,7 +2543,7 @@ static int infer_impl(pvae_ctx* c, const float* obs, int32_t rows, const float* 
     // The decoder's output layer can write a second copy of a_hat: into the world model's input
     // panel when the prediction is wanted, else straight into the caller's buffer (row counts the
     // GEMV kernel covers exactly -- the control loop's B = 1 -- so no padded row is written).
-    const bool direct = !s2_hat && (rows == 1 || rows == 2 || rows == 4);
+    const bool direct = !helper && !s2_hat && (rows == 1 || rows == 2 || rows == 4);
     FwdTail md_tail;
     if (direct) {
         md_tail.out2 = a_hat; md_tail.ld2 = ld_a; md_tail.off2 = 0; md_tail.n2 = Da;
@@ -2481,6 +2551,15 @@ static int infer_impl(pvae_ctx* c, const float* obs, int32_t rows, const float* 
         md_tail.out2 = w + c->W.net[PVAE_NET_WM].in; md_tail.ld2 = WM.layers[0].ld; md_tail.off2 = Db; md_tail.n2 = Da;
     }
     if ((rc = forward_net(c, PVAE_NET_MD, rows_pad, st, md_tail))) return rc;
+    if (helper) {                              // rmt:833-835
+        const NetLayout& MH = c->L.net[PVAE_NET_MH];
+        if ((rc = forward_net(c, PVAE_NET_MH, rows_pad, st))) return rc;
+        const int grid = (rows * Da + 255) / 256 < 256 ? (rows * Da + 255) / 256 : 256;
+        hipLaunchKernelGGL(helper_add_kernel, dim3(grid), dim3(256), 0, st, w + c->W.net[PVAE_NET_MD].act.back(),
+                           MD.layers.back().n_out_pad, w + c->W.net[PVAE_NET_MH].act.back(), MH.layers.back().n_out_pad,
+                           w + c->W.net[PVAE_NET_WM].in, WM.layers[0].ld, Db, rows, Da, c->L.cfg.mh_range);
+        HIP_TRY(hipGetLastError());
+    }
     if (!direct) {
         hipLaunchKernelGGL(copy_cols_kernel, dim3(32), dim3(256), 0, st, w + c->W.net[PVAE_NET_MD].act.back(),
                            MD.layers.back().n_out_pad, 0, a_hat, ld_a, 0, rows, Da);

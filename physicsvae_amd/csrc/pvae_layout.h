@@ -37,7 +37,7 @@ struct Layout {
 };
 
 // order of the stacks in the arena (and of pvae_layer's enumeration)
-constexpr int kArenaOrder[PVAE_NUM_NETS] = {PVAE_NET_TE, PVAE_NET_MD, PVAE_NET_PR, PVAE_NET_WM};
+constexpr int kArenaOrder[PVAE_NUM_NETS] = {PVAE_NET_TE, PVAE_NET_MD, PVAE_NET_MH, PVAE_NET_PR, PVAE_NET_WM};
 
 inline Layout make_layout(const pvae_config& c) {
     Layout L;
@@ -63,22 +63,27 @@ inline Layout make_layout(const pvae_config& c) {
     const bool learned = c.prior_kind == PVAE_PRIOR_STATE_MEAN;
     if (learned && (c.pr_width <= 0 || c.pr_depth <= 0 || c.pr_depth > 15)) { L.why = "prior stack width/depth out of range"; return L; }
     const int Db = c.dim_body, Da = c.dim_action, Z = c.latent;
-    // rmt:638-644 (618-621: Z outputs on the hypersphere), 646-668, 682-689, 627-635
-    const int ins[PVAE_NUM_NETS] = {2 * Db, Db + Z, Db + Da, Db};
-    const int outs[PVAE_NUM_NETS] = {c.prior_kind >= PVAE_PRIOR_HYPERSPHERE ? Z : 2 * Z, Da, Db, Z};
-    const int widths[PVAE_NUM_NETS] = {c.te_width, c.md_width, c.wm_width, c.pr_width};
-    const int depths[PVAE_NUM_NETS] = {c.te_depth, c.md_depth, c.wm_depth, c.pr_depth};
+    const bool helper = c.mh_depth > 0;
+    if (c.mh_depth < 0 || c.mh_depth > 15) { L.why = "helper depth out of range"; return L; }
+    if (helper && (c.mh_width <= 0 || !(c.mh_range > 0.0f))) { L.why = "helper: mh_width and mh_range must be positive (rmt:672-673)"; return L; }
+    if (helper && c.lookahead != 1) { L.why = "a model with the motor decoder's helper needs lookahead == 1"; return L; }
+    // rmt:638-644 (618-621: Z outputs on the hypersphere), 646-668, 682-689, 627-635, 670-680
+    const int ins[PVAE_NUM_NETS] = {2 * Db, Db + Z, Db + Da, Db, Db + Z};
+    const int outs[PVAE_NUM_NETS] = {c.prior_kind >= PVAE_PRIOR_HYPERSPHERE ? Z : 2 * Z, Da, Db, Z, Da};
+    const int widths[PVAE_NUM_NETS] = {c.te_width, c.md_width, c.wm_width, c.pr_width, c.mh_width};
+    const int depths[PVAE_NUM_NETS] = {c.te_depth, c.md_depth, c.wm_depth, c.pr_depth, c.mh_depth};
     int64_t off = 0;
     for (int n : kArenaOrder) {
         NetLayout& N = L.net[n];
         N.off = off;
         if (n == PVAE_NET_PR && !learned) continue;          // no such stack: an empty segment
+        if (n == PVAE_NET_MH && !helper) continue;
         N.n_in = ins[n];
         N.n_out = outs[n];
         int prev = ins[n];
         // input subsets (rmt:607-613, 646-653): the window of the full-width first layer that the checkpoint tensor is
         int win0 = 0, win = ins[n];
-        const int sel = n == PVAE_NET_TE ? c.te_inputs : (n == PVAE_NET_MD ? c.md_inputs : 0);
+        const int sel = n == PVAE_NET_TE ? c.te_inputs : ((n == PVAE_NET_MD || n == PVAE_NET_MH) ? c.md_inputs : 0);
         if (sel == PVAE_INPUT_BODY) win = Db;
         else if (sel == PVAE_INPUT_TASK) { win0 = Db; win = ins[n] - Db; }
         for (int i = 0; i <= depths[n]; ++i) {
@@ -87,7 +92,8 @@ inline Layout make_layout(const pvae_config& c) {
             l.col0 = i == 0 ? win0 : 0;
             l.last = (i == depths[n]);
             l.n_out = l.last ? outs[n] : (c.layer_width[n][i] > 0 ? c.layer_width[n][i] : widths[n]);
-            const int act_pub = l.last ? PVAE_ACT_LINEAR : (c.layer_act[n][i] > 0 ? c.layer_act[n][i] - 1 : c.act_kind);
+            const int act_pub = l.last ? (n == PVAE_NET_MH ? PVAE_ACT_TANH : PVAE_ACT_LINEAR)      // (rmt:672: the helper ends in tanh)
+                                       : (c.layer_act[n][i] > 0 ? c.layer_act[n][i] - 1 : c.act_kind);
             l.act = act_pub == PVAE_ACT_LINEAR ? 0 : act_pub + 1;
             l.ld = pad64(prev);
             l.n_out_pad = pad64(l.n_out);
@@ -128,7 +134,7 @@ struct Workspace {
     int64_t eps = 0;            // eps actually used [L*Bp][Z]
     // second set of staging panels (lookahead 1 only): the gather of minibatch n+1 is written here
     // by tail blocks of step n's last launch, then the two sets swap roles (pvae_train_step_prefetch)
-    int64_t alt_in[PVAE_NUM_NETS] = {0, 0, 0, 0};
+    int64_t alt_in[PVAE_NUM_NETS] = {};
     int64_t alt_s2 = 0, alt_act_t = 0;
     int64_t loss_part = 0;      // [5][kLossParts] partial sums
     int64_t obs_keep = 0;       // [4][2*Db] the observation rows of the last <= 4-row rollout call (pvae_infer)
@@ -151,7 +157,8 @@ inline Workspace make_workspace(const Layout& L) {
         if (N.layers.empty()) continue;
         const int64_t slots = (T > 1 && n == PVAE_NET_WM) ? 2 * T : T;
         W.net[n].slots = (int)slots;
-        W.net[n].in = take(slots * W.Bp * N.layers[0].ld);
+        // (the helper reads the decoder's input panel: PVAE_NET_MD < PVAE_NET_MH, so that one is carved already)
+        W.net[n].in = n == PVAE_NET_MH ? W.net[PVAE_NET_MD].in : take(slots * W.Bp * N.layers[0].ld);
         W.net[n].d_in = take(slots * W.Bp * N.layers[0].ld);
         for (const Layer& l : N.layers) {
             W.net[n].act.push_back(take(slots * W.Bp * l.n_out_pad));
@@ -162,7 +169,8 @@ inline Workspace make_workspace(const Layout& L) {
     W.act_t = take(T * W.Bp * pad64(L.cfg.dim_action));
     W.eps = take(T * W.Bp * L.cfg.latent);
     for (int n = 0; n < PVAE_NUM_NETS; ++n)
-        if (!L.net[n].layers.empty()) W.alt_in[n] = take((int64_t)W.Bp * L.net[n].layers[0].ld);
+        if (!L.net[n].layers.empty())
+            W.alt_in[n] = n == PVAE_NET_MH ? W.alt_in[PVAE_NET_MD] : take((int64_t)W.Bp * L.net[n].layers[0].ld);
     W.alt_s2 = take((int64_t)W.Bp * pad64(L.cfg.dim_body));
     W.alt_act_t = take((int64_t)W.Bp * pad64(L.cfg.dim_action));
     W.loss_part = take(5 * kLossParts);

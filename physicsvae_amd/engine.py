@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_KINDS, FLAG_FUSED_ADAM, FLAG_NO_BACKWARD, NET_MD, NET_NAMES, NET_PR, NET_TE, NET_WM, NUM_NETS, PRIOR_KINDS
+from ._lib import ACT_KINDS, FLAG_FUSED_ADAM, FLAG_NO_BACKWARD, NET_MD, NET_MH, NET_NAMES, NET_PR, NET_TE, NET_WM, NUM_NETS, PRIOR_KINDS
 
 TENSOR_IDS = {"mu": 0, "logvar": 1, "z": 2, "a_hat": 3, "s2_hat": 4, "eps": 5, "prior_mu": 6}
 
@@ -59,7 +59,7 @@ class Arch:
     (per-layer widths and activations, what custom_model_config's *_layers can describe, rmt:462-510)."""
 
     def __init__(self, dim_body, dim_action, latent, te, md, wm, prior="normal_zero_mean_one_std", pr=None,
-                 act="relu", te_inputs=("body", "task"), md_inputs=("body", "task")):
+                 act="relu", te_inputs=("body", "task"), md_inputs=("body", "task"), mh=None, mh_range=0.5):
         self.Db, self.Da, self.Z = int(dim_body), int(dim_action), int(latent)
         # task_encoder_inputs / motor_decoder_inputs (rmt:470, 485): column windows of the full-width first layers
         self.te_inputs, self.md_inputs = tuple(te_inputs), tuple(md_inputs)
@@ -74,6 +74,11 @@ class Arch:
         self.act = act                           # the trainer's "act_fn" (tpv:262): the default of every stack
         self.te, self.md, self.wm = Stack.of(te, act), Stack.of(md, act), Stack.of(wm, act)
         self.pr = Stack.of(pr, act) if pr is not None else self.te      # learned prior stack
+        # the motor decoder's helper (rmt:490-498, 670-680): hidden layers `mh` (None: no helper), tanh output x mh_range
+        self.mh = Stack.of(mh, act) if mh is not None else None
+        self.mh_range = float(mh_range)
+        if self.mh is not None and not self.mh_range > 0:
+            raise AssertionError("motor_decoder_helper_range must be positive (rmt:673)")
 
     @property
     def te_out(self):
@@ -83,8 +88,10 @@ class Arch:
         cfg = _lib.Config(self.Db, self.Da, self.Z, self.te[0], self.te[1], self.md[0],
                           self.md[1], self.wm[0], self.wm[1], int(max_batch), int(lookahead),
                           PRIOR_KINDS[self.prior], self.pr[0], self.pr[1], ACT_KINDS[self.act])
-        for net, st in ((NET_TE, self.te), (NET_MD, self.md), (NET_WM, self.wm), (NET_PR, self.pr)):
-            if st.uniform(self.act):             # (a zeroed row: the uniform stack the scalar fields describe)
+        if self.mh is not None:
+            cfg.mh_width, cfg.mh_depth, cfg.mh_range = self.mh[0], self.mh[1], self.mh_range
+        for net, st in ((NET_TE, self.te), (NET_MD, self.md), (NET_WM, self.wm), (NET_PR, self.pr), (NET_MH, self.mh)):
+            if st is None or st.uniform(self.act):             # (a zeroed row: the uniform stack the scalar fields describe)
                 continue
             for i, (w, a) in enumerate(zip(st.widths, st.acts)):
                 cfg.layer_width[net][i] = w
@@ -94,7 +101,7 @@ class Arch:
 
     def key(self):
         return (self.Db, self.Da, self.Z, self.te.key(), self.md.key(), self.wm.key(), self.prior, self.pr.key(), self.act,
-                self.te_inputs, self.md_inputs)
+                self.te_inputs, self.md_inputs, self.mh.key() if self.mh is not None else None, self.mh_range)
 
 
 class GraphedInfer:
@@ -161,7 +168,7 @@ class HipEngine:
         self.lookahead = int(lookahead)          # steps unrolled per sample (tpv:277, 367-428)
         # the library's <= 4-row rollout path: the LIBRARY's effective setting (it reads PVAE_ROLLOUT_FUSED once per
         # process), asked -- not re-read from the environment here, where the two could disagree
-        self.fused_rollout = bool(self.lib.pvae_rollout_is_fused())
+        self.fused_rollout = bool(self.lib.pvae_rollout_is_fused()) and arch.mh is None    # (helper models: staged path, pvae.hip infer_impl)
         self.device = torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:
             # an indexed device, so that comparisons with tensor.device (always indexed) are exact
@@ -176,7 +183,7 @@ class HipEngine:
             _lib.check(self.lib.pvae_layer(C.byref(self.cfg), i, C.byref(info)))
             self.layers.append({f: getattr(info, f) for f, _ in _lib.LayerInfo._fields_})
         self.segments = {}
-        for net in (NET_TE, NET_MD, NET_WM, NET_PR):
+        for net in (NET_TE, NET_MD, NET_WM, NET_PR, NET_MH):
             off, cnt = C.c_int64(), C.c_int64()
             _lib.check(self.lib.pvae_net_segment(C.byref(self.cfg), net, C.byref(off), C.byref(cnt)))
             self.segments[net] = (off.value, cnt.value)

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ._lib import NET_MD, NET_NAMES, NET_PR, NET_TE, NET_WM, PRIOR_KINDS
+from ._lib import NET_MD, NET_MH, NET_NAMES, NET_PR, NET_TE, NET_WM, PRIOR_KINDS
 from .engine import Arch, HipEngine, Stack
 
 
@@ -300,20 +300,31 @@ class PhysicsVAE(nn.Module):
         # stacks that differ from it travel layer by layer (pvae_config.layer_width / layer_act)
         used = {a for st in ((te, md, wm, pr) if learned_prior else (te, md, wm)) for a in st.acts}
         act = next(iter(used)) if len(used) == 1 and next(iter(used)) != "linear" else "relu"
+        # The helper (rmt:670-680, 833-835): a residual policy on the decoder's input whose tanh output, scaled by
+        # `motor_decoder_helper_range`, is added to the action.  A fifth stack of the arena (PVAE_NET_MH): upstream's
+        # supervised loss sees its term inside a_hat, so the joint phase trains it with the decoder.
+        self._motor_decoder_helper_range = cfg.get("motor_decoder_helper_range")
+        mh = mh_init = None
+        if cfg.get("motor_decoder_helper_enable"):
+            widths, acts, mh_init = _helper_stack(cfg["motor_decoder_helper_layers"], self._motor_decoder_helper_range)
+            mh = Stack(widths, acts)
+            if int(cfg.get("lookahead", 1) or 1) != 1:
+                raise NotImplementedError("motor_decoder_helper_enable with lookahead > 1 is not built")
         self.arch = Arch(self.dim_state_body, self.dim_action, Z, te, md, wm, prior=self._latent_prior_type,
-                         pr=pr, act=act, te_inputs=self._task_encoder_inputs, md_inputs=self._motor_decoder_inputs)
+                         pr=pr, act=act, te_inputs=self._task_encoder_inputs, md_inputs=self._motor_decoder_inputs,
+                         mh=mh, mh_range=self._motor_decoder_helper_range if mh is not None else 0.5)
         device = cfg["device"] or ("cuda" if torch.cuda.is_available() else "cpu")
         self.engine = HipEngine(self.arch, int(cfg["max_batch"]), device=device,
                                 lookahead=int(cfg.get("lookahead", 1) or 1))
 
         views = self.engine.named_views()
-        per_net = {n: [] for n in (NET_TE, NET_MD, NET_WM, NET_PR)}
+        per_net = {n: [] for n in (NET_TE, NET_MD, NET_WM, NET_PR, NET_MH)}
         for info in self.engine.layers:
             base = "%s._model.%d._model.0." % (NET_NAMES[info["net"]], info["index"])
             per_net[info["net"]].append(((info["n_in"], info["n_out"]),
                                          (views[base + "weight"], views[base + "bias"])))
 
-        stacks = {NET_TE: (te, te_init), NET_MD: (md, md_init), NET_WM: (wm, wm_init), NET_PR: (pr, pr_init)}
+        stacks = {NET_TE: (te, te_init), NET_MD: (md, md_init), NET_WM: (wm, wm_init), NET_PR: (pr, pr_init), NET_MH: (mh, mh_init)}
 
         def build(net, **kw):
             dims = [d for d, _ in per_net[net]]
@@ -325,23 +336,11 @@ class PhysicsVAE(nn.Module):
         self._task_encoder = build(NET_TE)
         self._motor_decoder = build(NET_MD, append_log_std=True, sample_std=cfg["sample_std"],
                                     log_std_type=cfg["log_std_type"], device=self.engine.device)
-        # The helper (rmt:670-680, 833-835): a residual policy on the decoder's input whose tanh output, scaled by
-        # `motor_decoder_helper_range`, is added to the action.  train_physics_vae.py never builds it (RL fine-tuning
-        # does), so -- like the value branch -- it stays plain torch parameters: evaluated by `pvae_mlp_forward`, or by
-        # the torch module itself under autograd so that a policy-gradient learner can train it as upstream.
+        # (registered between the motor decoder and the world model, as upstream: the state-dict order)
         self._motor_decoder_helper = None
-        self._motor_decoder_helper_range = cfg.get("motor_decoder_helper_range")
-        if cfg.get("motor_decoder_helper_enable"):
-            widths, acts, inits = _helper_stack(cfg["motor_decoder_helper_layers"], self._motor_decoder_helper_range)
-            # (the helper reads what the decoder reads, rmt:646-653, 674-680)
-            dims, prev = [], (self.dim_state_body * ("body" in self._motor_decoder_inputs) +
-                              Z * ("task" in self._motor_decoder_inputs))
-            for width in widths:
-                dims.append((prev, width))
-                prev = width
-            dims.append((prev, self.dim_action))
-            self._motor_decoder_helper = FC(dims, act=acts, inits=inits, out_act="tanh").to(self.engine.device)
-            self.__dict__["_mh_acts"] = acts
+        if mh is not None:
+            self._motor_decoder_helper = build(NET_MH, out_act="tanh")
+            self.__dict__["_mh_acts"] = list(mh.acts)
         self._world_model = build(NET_WM)
         self.__dict__["_als"] = self._motor_decoder._model[-1]      # (a plain reference: module lookups cost microseconds per forward)
         vb_dims, prev = [], self.dim_state
@@ -444,8 +443,7 @@ class PhysicsVAE(nn.Module):
         (`_cur_task_encoder_mu`, `value_function()`): the rollout loop reads neither."""
         obs = input_dict["obs_flat"].float()
         eng = self.engine
-        if (obs.dim() != 2 or obs.shape[0] > eng.max_batch or self._latent_prior is not None or eng.lookahead != 1
-                or self._motor_decoder_helper is not None):       # (the helper's term joins between decoder and world model)
+        if obs.dim() != 2 or obs.shape[0] > eng.max_batch or self._latent_prior is not None or eng.lookahead != 1:
             return self._forward_staged(obs, state, seq_lens, eps)
         rows = obs.shape[0]
         noise = bool(self.latent_prior_noise)
@@ -759,4 +757,5 @@ class PhysicsVAE(nn.Module):
         def on(m):      # (a state_independent log_std follows `free_log_std`, not the stack: rmt:939-941)
             return m is not None and all(p.requires_grad for n, p in m.named_parameters() if "log_std" not in n)
         return [n for n, m in ((NET_TE, self._task_encoder), (NET_MD, self._motor_decoder),
-                               (NET_WM, self._world_model), (NET_PR, self._latent_prior)) if on(m)]
+                               (NET_WM, self._world_model), (NET_PR, self._latent_prior),
+                               (NET_MH, self._motor_decoder_helper)) if on(m)]

@@ -24,7 +24,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from . import parallel, tune
-from ._lib import NET_MD, NET_PR, NET_TE, NET_WM, PHASE_JOINT, PHASE_WORLD
+from ._lib import NET_MD, NET_MH, NET_PR, NET_TE, NET_WM, PHASE_JOINT, PHASE_WORLD
 
 EPSILON = np.finfo(np.float32).eps
 
@@ -132,7 +132,7 @@ class HipAdam(optim.Optimizer):
     def __init__(self, params, engine, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.engine = engine
-        self.net_steps = {NET_TE: 0, NET_MD: 0, NET_WM: 0, NET_PR: 0}
+        self.net_steps = {NET_TE: 0, NET_MD: 0, NET_WM: 0, NET_PR: 0, NET_MH: 0}
 
     @property
     def lr(self):
@@ -142,7 +142,9 @@ class HipAdam(optim.Optimizer):
         """Advance and return adam_t for the nets updated by the coming step."""
         for n in nets:
             self.net_steps[n] += 1
-        return [max(self.net_steps[n], 1) for n in (NET_TE, NET_MD, NET_WM, NET_PR)]
+        # (the helper's entry doubles as its switch: 0 = frozen for this step, include/pvae.h PVAE_NET_MH)
+        return [max(self.net_steps[n], 1) for n in (NET_TE, NET_MD, NET_WM, NET_PR)] + \
+               [max(self.net_steps[NET_MH], 1) if NET_MH in nets else 0]
 
     def step(self, closure=None):
         # the update itself is issued by TrainModel (fused or after the all-reduce)
@@ -163,11 +165,6 @@ class TrainModel(tune.Trainable):
     # -- Trainable hooks ------------------------------------------------------------------
     def setup(self, config):
         self.model = self.create_model(config)
-        if getattr(self.model, "_motor_decoder_helper", None) is not None:
-            # upstream's supervised loss would see the helper's term in a_hat (rmt:833-835) and train the helper with the
-            # decoder; the HIP step computes the decoder's action alone -- refuse instead of training a different model
-            raise NotImplementedError("supervised training with motor_decoder_helper_enable is not built: the helper is served "
-                                      "on the rollout path (PhysicsVAE.forward / forward_decoder) only")
         self.engine = self.model.engine
         self.device = self.engine.device
         self.dp = parallel.DataParallel.from_env()
@@ -249,10 +246,15 @@ class TrainModel(tune.Trainable):
     def phase(self):
         """World phase <=> only the world model is learnable (tpv:326-329 / 347-350)."""
         nets = self.model.learnable_nets()
+        # The motor decoder's helper (rmt:670-680) is never frozen by the trainer (tpv:326-329, 347-350 switch encoder,
+        # decoder and world model only): in the world phase it receives no gradient (lookahead 1: the loss does not depend
+        # on a_hat) and torch's Adam skips it; in the joint phase it trains with the decoder.
+        helper = [NET_MH] if NET_MH in nets else []
+        nets = [n for n in nets if n != NET_MH]
         if nets == [NET_WM]:
             return PHASE_WORLD, nets
         if nets in ([NET_TE, NET_MD], [NET_TE, NET_MD, NET_PR]):     # (+ the learned prior mean, when configured)
-            return PHASE_JOINT, nets
+            return PHASE_JOINT, nets + helper
         raise NotImplementedError("learnable nets %s: the trainer only uses {WM} or {TE, MD}" % nets)
 
     def step_params(self, nets, global_rows, train):
@@ -495,7 +497,8 @@ class TrainModel(tune.Trainable):
             return False
         import torch.distributed as dist
         mask = torch.zeros_like(eng.exp_avg, dtype=torch.bool)
-        for net, phase in ((NET_WM, PHASE_WORLD), (NET_TE, PHASE_JOINT), (NET_MD, PHASE_JOINT), (NET_PR, PHASE_JOINT)):
+        for net, phase in ((NET_WM, PHASE_WORLD), (NET_TE, PHASE_JOINT), (NET_MD, PHASE_JOINT), (NET_PR, PHASE_JOINT),
+                           (NET_MH, PHASE_JOINT)):
             for off, cnt, rep in eng.owned_slices(phase, net):
                 if cnt > 0 and (not rep or dp.rank == 0):
                     mask[off: off + cnt] = True

@@ -431,7 +431,7 @@ class TrainModel(torch_models.TrainModel):
         return create_model(config)
 
     def step_params(self, nets, global_rows, train):
-        t = self.optimizer.next_counts(nets) if train else [1, 1, 1]
+        t = self.optimizer.next_counts(nets) if train else [1, 1, 1, 1, 0]
         return make_step_params(lr=self.optimizer.lr, adam_t=t, a_rec=self.a_rec_coeff,
                                 kl=self.vae_kl_coeff, s_rec=self.s_rec_coeff, cyc=self.vae_cycle_coeff,
                                 global_rows=global_rows, loss=self.loss_name,

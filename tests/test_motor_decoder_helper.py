@@ -76,7 +76,7 @@ def test_helper_state_dict_layout_and_files_match_the_reference(golden, name, ar
     assert not os.path.exists(os.path.join(str(tmp_path), "none.pt"))
 
 
-def test_helper_config_is_checked_like_upstream_and_supervised_training_is_refused(tmp_path):
+def test_helper_config_is_checked_like_upstream_and_the_trainer_takes_a_helper_model(tmp_path):
     cfg, _ = _helper_model(TINY, "cpu", tmp_path)
     cmc = cfg["model"]["custom_model_config"]
     bad = [dict(l) for l in cmc["motor_decoder_helper_layers"]]
@@ -86,14 +86,30 @@ def test_helper_config_is_checked_like_upstream_and_supervised_training_is_refus
         T.create_model(dict(cfg, model=dict(cfg["model"], custom_model_config=cmc2)))
     with pytest.raises(AssertionError):                                        # rmt:673
         T.create_model(dict(cfg, model=dict(cfg["model"], custom_model_config=dict(cmc, motor_decoder_helper_range=0.0))))
-    # the supervised trainer would have to train the helper inside a_hat (upstream does): refused by name
+    # the supervised trainer trains the helper inside a_hat, as upstream does (tests/test_gpu_helper_training.py); the
+    # helper is a fifth stack of the arena, between the motor decoder and the learned prior / world model
     data = R.synth_demo(0, 2, 14, 7, 3)
     from util import make_trainer
+    from physicsvae_amd import _lib
     tr = make_trainer(TINY, data, 8, device="cpu")
-    assert tr.model._motor_decoder_helper is None
+    assert tr.model._motor_decoder_helper is None and tr.engine.segments[_lib.NET_MH][1] == 0
     full = dict(tr.config)
     full["model"] = dict(full["model"], custom_model_config=dict(full["model"]["custom_model_config"], motor_decoder_helper_enable=True))
-    with pytest.raises(NotImplementedError, match="motor_decoder_helper_enable"):
+    th = T.TrainModel(full)
+    eng = th.engine
+    assert th.model._motor_decoder_helper is not None and eng.segments[_lib.NET_MH][1] > 0
+    assert eng.segments[_lib.NET_MD][0] + eng.segments[_lib.NET_MD][1] == eng.segments[_lib.NET_MH][0]
+    assert eng.segments[_lib.NET_MH][0] + eng.segments[_lib.NET_MH][1] == eng.segments[_lib.NET_WM][0]
+    assert [(k, tuple(v.shape)) for k, v in th.model.state_dict().items()] == R.state_dict_spec(R.with_helper(TINY))
+    assert th.phase() == (_lib.PHASE_WORLD, [_lib.NET_WM])                  # (the helper has no gradient there, lookahead 1)
+    th.model.set_learnable_task_encoder(True); th.model.set_learnable_motor_decoder(True); th.model.set_learnable_world_model(False)
+    assert th.phase() == (_lib.PHASE_JOINT, [_lib.NET_TE, _lib.NET_MD, _lib.NET_MH])
+    assert th.optimizer.next_counts([_lib.NET_TE, _lib.NET_MD, _lib.NET_MH]) == [1, 1, 1, 1, 1]
+    th.model.set_learnable_motor_decoder_helper(False)
+    assert th.phase() == (_lib.PHASE_JOINT, [_lib.NET_TE, _lib.NET_MD])
+    assert th.optimizer.next_counts([_lib.NET_TE, _lib.NET_MD])[4] == 0     # adam_t[PVAE_NET_MH] = 0: frozen for that step
+    full["lookahead"] = 2
+    with pytest.raises(NotImplementedError, match="lookahead"):
         T.TrainModel(full)
 
 

@@ -453,3 +453,38 @@ def test_input_subsets_restatement_matches_reference(golden):
             assert list(out["grads"].keys()) == list(g[tag + "_grad_keys"])
             for k, gr in out["grads"].items():
                 np.testing.assert_allclose(gr.numpy(), g["%s_grad::%s" % (tag, k)], rtol=1e-4, atol=1e-8)
+
+
+def test_helper_training_restatement_matches_reference(golden):
+    """Supervised training of a helper model (rmt:670-680, 833-835): the reference's loss sees the helper's term in a_hat and
+    its optimizer trains the helper with the decoder.  One minibatch in both phases (the helper has no gradient in the world
+    phase, one in the joint phase) and the reference's own five-epoch loop: epoch losses, final weights, Adam step counts."""
+    g = golden("helper_train_tiny")
+    base = arch_from_meta(g["meta"])
+    arch = R.with_helper(base, rng=float(g["helper_range"]))
+    n_ep, n_steps, batch, m_world, n_epochs = [int(v) for v in g["meta"][9:14]]
+    data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
+    X, Y = R.build_windows(data)
+    x, y = next(iter(R.make_loader(X, Y, batch)))
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    k_out = "_motor_decoder_helper._model.%d._model.0.weight" % len(arch["mh"])
+    sd[k_out] = sd[k_out] * 60.0
+    eps = torch.from_numpy(g["eps"])
+    for world in (True, False):
+        tag = "world" if world else "joint"
+        out = R.loss_and_grads(arch, sd, x, y, eps, world)
+        np.testing.assert_allclose(out["total"].numpy(), g[tag + "_total"], rtol=1e-6)
+        assert list(out["grads"].keys()) == list(g[tag + "_grad_keys"])
+        assert any(k.startswith("_motor_decoder_helper") for k in out["grads"]) == (not world)
+        for k, gr in out["grads"].items():
+            np.testing.assert_allclose(gr.numpy(), g["%s_grad::%s" % (tag, k)], rtol=1e-4, atol=1e-8)
+    tr = R.RefTrainer(arch, sd, X, Y, batch, m_world, lr_step=2, eps_fn=R.eps_stream(2, arch["Z"]))
+    losses = [tr.step()["mean_train_loss"] for _ in range(n_epochs)]
+    np.testing.assert_allclose(losses, g["epoch_losses"], rtol=1e-5)
+    for k, v in tr.model.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), g["final::" + k], rtol=2e-3, atol=2e-6, err_msg=k)
+    nb = len(tr.loader)
+    steps = dict(zip((str(k) for k in g["adam_keys"]), g["adam_steps"]))
+    assert steps["_world_model._model.0._model.0.weight"] == nb * m_world
+    assert steps["_motor_decoder_helper._model.0._model.0.weight"] == nb * (n_epochs - m_world)
+    assert steps["_motor_decoder._model.0._model.0.weight"] == nb * (n_epochs - m_world)
