@@ -21,7 +21,7 @@
 // next call), every spin re-checks an absolute lifetime, and a stop command ends it at once.  While it is resident,
 // a DEVICE-wide synchronisation (hipDeviceSynchronize, hipFree) waits for it -- at most the idle time-out.
 // ---------------------------------------------------------------------------------------
-constexpr int kSrvMaxLayers = 12, kSrvMaxObs = 2048, kSrvMaxOut = 1024;
+constexpr int kSrvMaxLayers = 16, kSrvMaxObs = 2048, kSrvMaxOut = 1024;
 struct SrvRequest {                       // host -> device.  Lives in DEVICE memory when the host can write it directly
     // (large BAR: the host PUSHES the observation and the kernel polls local memory), else in pinned host memory (the
     // kernel PULLS over PCIe).  ONE 32-byte line of control words, then the observation.
@@ -48,7 +48,9 @@ struct SrvLayer { long long w_off, b_off; int ld, n_out_pad, n_out, act, F, lds_
 constexpr int kSrvActStride = 2048;
 struct SrvArgs {
     SrvLayer layer[kSrvMaxLayers];
-    int n_layers, n_te;                   // layers [0, n_te) are the encoder's, the rest the decoder's
+    int n_layers, n_te;                   // layers [0, n_te) are the encoder's, [n_te, n_md) the decoder's,
+    int n_md;                             // [n_md, n_layers) the motor decoder's helper's (rmt:670-680; none: n_md == n_layers)
+    float mh_range;                       // a_hat = decoder + mh_range * helper (rmt:833-835)
     int groups, one_xcd;                  // 32 workgroups on ONE XCD, or 256 over the whole chip (stacks too big for one XCD's LDS)
     int xcd;                              // which XCD (one_xcd): servers of one process take different ones
     int Db, Da, Z, prior_kind;
@@ -292,8 +294,12 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
         const bool decode_only = cmd == 3u;                                  // the caller supplies z: the encoder is skipped
         for (int l = decode_only ? a.n_te : 0; l < a.n_layers; ++l) {
             const SrvLayer L = a.layer[l];
-            const unsigned long long* prev = a.acts + (size_t)l * kSrvActStride;   // slot l: the previous layer's output (0: obs)
-            const unsigned tagp = tag0 + (unsigned)l;
+            // the helper's first layer reads what the decoder's first layer read: [s1 | z | 0], z from the ENCODER's output slot
+            const bool dec_in = l == a.n_te || (l == a.n_md && a.n_md < a.n_layers);
+            const int lp = dec_in ? a.n_te : l;
+            const unsigned long long* prev = a.acts + (size_t)lp * kSrvActStride;  // slot l: the previous layer's output (0: obs)
+            const unsigned tagp = tag0 + (unsigned)lp;
+            const unsigned tago = tag0 + (unsigned)l + 1u;                         // tag of THIS layer's outputs (slot l + 1)
             if (l == 0) {                                                    // [s1 | s2 | 0]
                 if (a.obs_direct) {                                          // (complete before the request word)
                     for (int k = tid; k < L.ld; k += 256)
@@ -301,14 +307,14 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                 } else {
                     srv_get_row(xs, a.acts, 2 * a.Db, L.ld, tag0, tid, t_start, a.life_ticks, failed, a.sync + 18);
                 }
-            } else if (l == a.n_te && decode_only) {                         // [s1 | z | 0] as the caller sent it
+            } else if (dec_in && decode_only) {                              // [s1 | z | 0] as the caller sent it
                 if (a.obs_direct) {
                     for (int k = tid; k < L.ld; k += 256)
                         xs[k] = k < a.Db + a.Z ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
                 } else {
                     srv_get_row(xs, a.acts, a.Db + a.Z, L.ld, tag0, tid, t_start, a.life_ticks, failed, a.sync + 18);
                 }
-            } else if (l == a.n_te) {                                        // [s1 | z | 0], the sampler formed in place
+            } else if (dec_in) {                                             // [s1 | z | 0], the sampler formed in place
                 for (int k = tid; k < L.ld; k += 256) {
                     float v = 0.f;
                     if (k < a.Db) v = a.obs_direct ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
@@ -374,7 +380,7 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                         const int f = f0 + 4 * lane, n = g * L.F + f;
                         float v = mine + Wl[L.F * L.ld + f];
                         v = (L.act > 1 && n >= L.n_out) ? 0.f : act_apply(v, L.act);
-                        srv_put(outp + n, v, tagp + 1u);
+                        srv_put(outp + n, v, tago);
                     }
                 };
 #ifdef PVAE_SRV_FINE
@@ -399,14 +405,19 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
         if (s_failed) { alive = false; break; }
         // ---- result: group 0 -> mailbox, payload first, completion word last ----
         if (g == 0) {
-            const unsigned long long* md_out = a.acts + (size_t)a.n_layers * kSrvActStride;
+            const unsigned long long* md_out = a.acts + (size_t)a.n_md * kSrvActStride;
             const unsigned long long* te_out = a.acts + (size_t)a.n_te * kSrvActStride;
-            const unsigned tag_md = tag0 + (unsigned)a.n_layers, tag_te = tag0 + (unsigned)a.n_te;
+            const unsigned long long* mh_out = a.acts + (size_t)a.n_layers * kSrvActStride;
+            const unsigned tag_md = tag0 + (unsigned)a.n_md, tag_te = tag0 + (unsigned)a.n_te, tag_mh = tag0 + (unsigned)a.n_layers;
+            const bool helper = a.n_md < a.n_layers;
             const int n_out = decode_only ? a.Da : a.Da + 3 * a.Z;           // (decoder only: just the action)
             for (int i = tid; i < n_out; i += 256) {
                 float v;
-                if (i < a.Da) v = srv_get(md_out + i, tag_md, t_start, a.life_ticks, failed, a.sync + 18);
-                else if (i < a.Da + 2 * a.Z) v = a.prior_kind == PVAE_PRIOR_NONE && i >= a.Da + a.Z ? 0.f
+                if (i < a.Da) {
+                    v = srv_get(md_out + i, tag_md, t_start, a.life_ticks, failed, a.sync + 18);
+                    if (helper)                                              // (helper_add_kernel's expression: same bits)
+                        v = __fmaf_rn(a.mh_range, srv_get(mh_out + i, tag_mh, t_start, a.life_ticks, failed, a.sync + 18), v);
+                } else if (i < a.Da + 2 * a.Z) v = a.prior_kind == PVAE_PRIOR_NONE && i >= a.Da + a.Z ? 0.f
                                                  : srv_get(te_out + (i - a.Da), tag_te, t_start, a.life_ticks, failed, a.sync + 18);
                 else {                                                       // z as the decoder saw it (same expression as above)
                     const int j = i - a.Da - 2 * a.Z;
@@ -464,10 +475,11 @@ struct RolloutServer {
 static size_t server_layout(pvae_ctx* c, RolloutServer& S, int groups) {
     const NetLayout& TE = c->L.net[PVAE_NET_TE];
     const NetLayout& MD = c->L.net[PVAE_NET_MD];
+    const NetLayout& MH = c->L.net[PVAE_NET_MH];                         // (empty without a helper)
     SrvArgs& a = S.args;
     memset(&a, 0, sizeof(a));
     int off = 0, max_ld = 0, i = 0;
-    for (const NetLayout* N : {&TE, &MD})
+    for (const NetLayout* N : {&TE, &MD, &MH})
         for (const Layer& l : N->layers) {
             SrvLayer& L = a.layer[i++];
             L.w_off = l.w_off; L.b_off = l.b_off; L.ld = l.ld; L.n_out_pad = l.n_out_pad; L.n_out = l.n_out; L.act = l.act;
@@ -477,7 +489,8 @@ static size_t server_layout(pvae_ctx* c, RolloutServer& S, int groups) {
             off += L.F * l.ld + ((L.F + 3) & ~3);                         // rows + biases (16-byte granules)
             if (l.ld > max_ld) max_ld = l.ld;
         }
-    a.n_layers = i; a.n_te = (int)TE.layers.size();
+    a.n_layers = i; a.n_te = (int)TE.layers.size(); a.n_md = a.n_te + (int)MD.layers.size();
+    a.mh_range = c->L.cfg.mh_range;
     a.groups = groups; a.one_xcd = groups == 32 ? 1 : 0;
     a.Db = c->L.cfg.dim_body; a.Da = c->L.cfg.dim_action; a.Z = c->L.cfg.latent; a.prior_kind = c->L.cfg.prior_kind;
     a.xs_off = off;
@@ -486,7 +499,8 @@ static size_t server_layout(pvae_ctx* c, RolloutServer& S, int groups) {
 
 // scope: 0 = one XCD if the stacks fit its CUs' LDS, else the whole chip; 1 = one XCD; 2 = the whole chip
 static int server_plan(pvae_ctx* c, RolloutServer& S, int scope) {
-    const int n = (int)(c->L.net[PVAE_NET_TE].layers.size() + c->L.net[PVAE_NET_MD].layers.size());
+    const int n = (int)(c->L.net[PVAE_NET_TE].layers.size() + c->L.net[PVAE_NET_MD].layers.size() +
+                        c->L.net[PVAE_NET_MH].layers.size());
     if (n > kSrvMaxLayers) return fail(-24, "rollout server: %d layers (at most %d)", n, kSrvMaxLayers);
     if (c->L.cfg.prior_kind == PVAE_PRIOR_HYPERSPHERE)
         return fail(-24, "rollout server: this latent prior is served by the per-layer launches only");

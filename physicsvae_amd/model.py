@@ -478,7 +478,7 @@ class PhysicsVAE(nn.Module):
 
     # -- the call-persistent rollout server (opt-in; include/pvae.h pvae_rollout_server_*) -------------------
     def start_rollout_server(self, idle_ms=100.0, lifetime_s=600.0, scope="auto"):
-        """Serve `forward` at B = 1 from the resident rollout kernel (one XCD, encoder + decoder weights in LDS, mailbox
+        """Serve `forward` at B = 1 from the resident rollout kernel (one XCD, encoder + decoder [+ helper] weights in LDS, mailbox
         in pinned host memory): a forward whose observation arrives as a CPU tensor of ONE row then costs no launch and
         no device copy, and returns CPU tensors (the 30 Hz control loop of envs/rllib_env_imitation.py:215-266 hands the
         action to a CPU simulator anyway).  Same action as the launch path, bit for bit; mu / logvar / z come with it;
@@ -487,9 +487,6 @@ class PhysicsVAE(nn.Module):
         after writes the library cannot see).
         `scope`: "xcd" (one XCD), "chip" (all CUs: stacks too big for one XCD, e.g. 4x1024), "auto".  Raises RuntimeError when
         nothing fits: the launch path stays in use."""
-        if self._motor_decoder_helper is not None:
-            raise NotImplementedError("the rollout server serves encoder + decoder; a model with motor_decoder_helper_enable "
-                                      "keeps the launch path")
         self.engine.rollout_server_start(idle_ms=idle_ms, lifetime_s=lifetime_s, scope=scope)
         self.__dict__["_srv_on"] = True
 

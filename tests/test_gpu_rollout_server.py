@@ -359,3 +359,52 @@ def test_server_latency_is_below_the_launch_path():
         us = np.sort(eng.rollout_server_selfbench(o, n=500))
         print("inside the library call: %.1f us median" % us[len(us) // 2])
         assert us[len(us) // 2] < med_s + 1.0
+
+
+@pytest.mark.parametrize("noise", [False, True])
+def test_server_serves_a_helper_model_bit_for_bit(noise):
+    """`motor_decoder_helper_enable` (rmt:670-680, 833-835): the helper's layers follow the decoder's in the resident kernel
+    (their first layer reads the decoder's input again), workgroup 0 adds range * h with helper_add_kernel's expression.
+    Same action as the launch path `pvae_infer` (which adds the term in the library), bit for bit -- also for decoder-only
+    requests -- and the module's served forward equals its launched forward."""
+    from test_gpu_helper_training import _trainer, _weights
+    base = R.make_arch(197, 45)
+    h, sd = _weights(base)
+    data = R.synth_demo(0, 2, 40, 197, 45, kind="dynamics")
+    tr = _trainer(base, data, 8, device=DEV)
+    tr.model.load_state_dict(sd)
+    eng = tr.engine
+    X, _ = R.build_windows(data)
+    obs = torch.from_numpy(np.asarray(X)).float()[:, 0, :]
+    ref = R.RefModel(h)
+    ref.load_state_dict(sd)
+    ref.latent_prior_noise = False
+    with served(eng):
+        assert eng.rollout_server_status()[0]
+        for i in range(8):
+            o = obs[i]
+            a, ml, z = (x.copy() for x in eng.rollout_server_infer(o.numpy(), noise=noise, seed=11, offset=1000 + i))
+            want_a, _, want_z = eng.infer(o[None].to(DEV), noise=noise, seed=11, offset=1000 + i, want_s2=False)
+            assert np.array_equal(a, want_a[0].cpu().numpy()) and np.array_equal(z, want_z[0].cpu().numpy())
+            if not noise:
+                with torch.no_grad():
+                    lg = ref(o[None])
+                assert float(np.abs(a - lg[0, :45].numpy()).max()) < 2e-5 * max(1.0, float(lg.abs().max()))
+            # decoder only ("pass_through"): the caller supplies z
+            sz = torch.cat([o[:197], torch.from_numpy(z)])
+            a2 = eng.rollout_server_decode(sz.numpy()).copy()
+            assert np.array_equal(a2, a)
+    # the module surface
+    tr.model.eval()
+    tr.model.latent_prior_noise = noise
+    tr.model._st._rng_calls = 100
+    with torch.no_grad():
+        launched = [tr.model.forward({"obs_flat": obs[i][None].to(DEV)}, [], None)[0].cpu() for i in range(3)]
+    tr.model._st._rng_calls = 100
+    tr.model.start_rollout_server(idle_ms=2000.0, lifetime_s=30.0)
+    try:
+        for i in range(3):
+            lg, _ = tr.model.forward({"obs_flat": obs[i][None]}, [], None)
+            assert torch.equal(lg, launched[i])
+    finally:
+        tr.model.stop_rollout_server()

@@ -166,6 +166,14 @@ def test_helper_forward_matches_the_reference_and_the_oracle(golden, name, arch,
     ((plain + h["mh_range"] * ref_h._motor_decoder_helper(zin)) ** 2).sum().backward()
     for (k, p), (_, q) in zip(m._motor_decoder_helper.named_parameters(), ref_h._motor_decoder_helper.named_parameters()):
         assert p.grad is not None and float((p.grad.cpu() - q.grad).abs().max()) <= 1e-4 * max(1e-6, float(q.grad.abs().max())), k
-    # a helper model keeps the launch path: the resident server serves encoder + decoder only
-    with pytest.raises(NotImplementedError):
-        m.start_rollout_server()
+    # the resident server serves helper models too (tests/test_gpu_rollout_server.py): the served action is the launched one
+    m.latent_prior_noise = False
+    with torch.no_grad():
+        want, _ = m.forward({"obs_flat": obs[:1].cuda()}, [], None)
+    m.start_rollout_server(idle_ms=500.0, lifetime_s=30.0)
+    try:
+        with torch.no_grad():
+            got, _ = m.forward({"obs_flat": obs[:1].cpu()}, [], None)
+    finally:
+        m.stop_rollout_server()
+    assert torch.equal(got.cpu(), want.cpu())
