@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PVAE_ABI_VERSION 10
+#define PVAE_ABI_VERSION 11
 
 typedef struct pvae_ctx pvae_ctx;
 
@@ -481,6 +481,11 @@ int pvae_rollout_server_infer(pvae_ctx* ctx, const float* obs, int noise, uint64
 /* forward_decoder at B = 1 (rmt:822-837; the "pass_through" rollout of envs/rllib_env_imitation.py:233-258, where the caller draws
  * z itself): s1_z = [s1 (Db) | z (Z)] (host) -> a_hat[Da] (host), the same bits as pvae_net_forward(PVAE_NET_MD) on that row.
  * The encoder's layers are skipped. */
+/* The same for 1 <= rows <= 4 observations in ONE request (rmt:742-771 serves any batch): obs[rows][2*Db] ->
+ * a_hat[rows][Da] (+ mu_logvar[rows][2*Z], z[rows][Z]); row r draws Philox row r, as pvae_infer does -- bit-identical
+ * to pvae_infer on the same rows.  Every weight fragment read from LDS feeds all rows. */
+int pvae_rollout_server_infer_rows(pvae_ctx* ctx, const float* obs, int32_t rows, int noise, uint64_t rng_seed,
+                                   uint64_t rng_offset, int reload, float* a_hat, float* mu_logvar, float* z, double timeout_ms);
 int pvae_rollout_server_decode(pvae_ctx* ctx, const float* s1_z, float* a_hat, double timeout_ms);
 int pvae_rollout_server_stop(pvae_ctx* ctx);
 /* The caller wrote the parameter arena itself (load_state_dict / load_weights*, rmt:870-928; a torch optimizer) with work

@@ -36,7 +36,7 @@ MAX_HIDDEN = 15
 PRIOR_KINDS = {"normal_zero_mean_one_std": 0, "normal_state_mean_one_std": 1, "hypersphere_uniform": 2, False: 3}
 PHASE_WORLD, PHASE_JOINT = 0, 1
 FLAG_FUSED_ADAM, FLAG_NO_BACKWARD = 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 LOSS_MSE, LOSS_L1 = 0, 1
 EXCHANGE_ALLREDUCE, EXCHANGE_SHARDED, EXCHANGE_P2P, EXCHANGE_LOCAL, EXCHANGE_P2P_PUSH = 0, 1, 2, 3, 4
 P2P_BLOB_BYTES, P2P_MAX_RANKS = 512, 8
@@ -114,6 +114,7 @@ _SIGS = {
     "pvae_rollout_is_fused": (C.c_int, []),
     "pvae_rollout_server_start": (C.c_int, [_P, C.c_double, C.c_double, C.c_int]),
     "pvae_rollout_server_infer": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _P, _P, _P, C.c_double]),
+    "pvae_rollout_server_infer_rows": (C.c_int, [_P, _P, C.c_int32, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _P, _P, _P, C.c_double]),
     "pvae_rollout_server_decode": (C.c_int, [_P, _P, _P, C.c_double]),
     "pvae_rollout_server_stop": (C.c_int, [_P]),
     "pvae_params_changed": (C.c_int, [_P, _P]),

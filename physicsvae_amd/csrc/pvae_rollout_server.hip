@@ -21,13 +21,20 @@
 // next call), every spin re-checks an absolute lifetime, and a stop command ends it at once.  While it is resident,
 // a DEVICE-wide synchronisation (hipDeviceSynchronize, hipFree) waits for it -- at most the idle time-out.
 // ---------------------------------------------------------------------------------------
-constexpr int kSrvMaxLayers = 16, kSrvMaxObs = 2048, kSrvMaxOut = 1024;
+constexpr int kSrvMaxLayers = 16, kSrvMaxObs = 4096, kSrvMaxOut = 2048;
+constexpr int kSrvActStride = 2048;
+// words of one hand-over slot of an instance that takes `rmax` rows per request: rmax rows of kSrvActStride words -- plus, for
+// the multi-row instance, an odd number of 128-byte lines, so that consecutive slots do not start 64 KB apart (slots 64 KB
+// apart cost the SINGLE-row kernel 0.8 us per request when it used this layout: profiles/r05_ab_server_b1.txt)
+__host__ __device__ constexpr size_t srv_slot_words(int rmax) { return (size_t)rmax * kSrvActStride + (rmax > 1 ? 1040 : 0); }
+constexpr int kSrvMaxRows = 4;              // rows per request (rmt:742-771 serves any batch; the control loop's is 1)
 struct SrvRequest {                       // host -> device.  Lives in DEVICE memory when the host can write it directly
     // (large BAR: the host PUSHES the observation and the kernel polls local memory), else in pinned host memory (the
     // kernel PULLS over PCIe).  ONE 32-byte line of control words, then the observation.
     volatile uint32_t req_seq;            // written LAST by the host: request number
-    uint32_t cmd;                         // 0 infer, 1 stop, 2 reload the weights from the arena, then infer,
+    uint32_t cmd;                         // low byte: 0 infer, 1 stop, 2 reload the weights from the arena, then infer,
                                           // 3 decoder only ("pass_through", rllib_env_imitation.py:233-258): obs = [s1 (Db) | z (Z)]
+                                          // bits 8-9: rows - 1 of this request (obs = rows x [...], densely packed)
     uint32_t noise, check;                // check: srv_check() of the other seven words -- the kernel takes a line only when it
                                           // matches, so a read of the line that saw req_seq but an older cmd / seed is re-polled
     uint32_t seed_lo, seed_hi, off_lo, off_hi;
@@ -45,7 +52,6 @@ struct SrvReply {                         // device -> host, pinned host memory 
 };
 struct SrvLayer { long long w_off, b_off; int ld, n_out_pad, n_out, act, F, lds_off; };   // F: features per group (the last
                                                                                           // active group may own fewer)
-constexpr int kSrvActStride = 2048;
 struct SrvArgs {
     SrvLayer layer[kSrvMaxLayers];
     int n_layers, n_te;                   // layers [0, n_te) are the encoder's, [n_te, n_md) the decoder's,
@@ -55,13 +61,13 @@ struct SrvArgs {
     int xcd;                              // which XCD (one_xcd): servers of one process take different ones
     int Db, Da, Z, prior_kind;
     const float* params;
-    unsigned long long* acts;             // [n_layers + 1][kSrvActStride] TAGGED values: slot 0 = the observation, slot l + 1 = layer l's output
+    unsigned long long* acts;             // [n_layers + 1][RMAX of the instance][kSrvActStride] TAGGED values: slot 0 = the observation, slot l + 1 = layer l's output
     unsigned* sync;                       // device words: 0 start-up barrier, 1 go_seq, 2..8 the request's control words, 16 xcc of group 0, 17 error, 18 group 0 has left
     SrvRequest* req;                      // device view of the request block
     SrvReply* mb;                         // device view of the reply block
     int obs_direct;                       // the request block is device memory: every group reads the observation from it
     long long idle_ticks, life_ticks;     // 100 MHz wall clock
-    int xs_off;                           // float offset of the input vector inside the dynamic LDS
+    int xs_off, xs_ld;                    // float offset of the input vectors inside the dynamic LDS, floats per row (kSrvMaxRows of them)
     unsigned seq0;                        // requests served by earlier instances (this one answers seq0 + 1, ...)
     unsigned long long* dbg;              // [64] wall-clock stamps of group 0 for the LAST request (pvae_rollout_server_timeline)
 };
@@ -146,6 +152,12 @@ __device__ inline float srv_tree_sum(float v) {
     return v;
 }
 
+// RMAX: the most rows a request to this instance may carry.  The instance a server starts with is RMAX = 1 -- the control
+// loop's kernel, nothing of the multi-row code in it (15.2 us at the default stacks; with the 4-row bodies compiled into the
+// same function the register allocator spilled twice as many SGPRs in the layer loop: 17.5 us) --; the first request with
+// more than one row replaces it by the RMAX = 4 instance (pvae_rollout_server_infer_rows), which serves 1-4 rows from then on.
+// HELPER: the stacks include the motor decoder's helper (layers [n_md, n_layers)); without one that code is not in the instance.
+template <int RMAX, bool HELPER>
 __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float srv_lds[];
     __shared__ unsigned s_word[8];
@@ -234,11 +246,13 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                 }
             }
             __syncthreads();
-            if (s_word[1] != 1u && !a.obs_direct) {        // the observation: pinned host memory -> slot 0, tagged
+            if ((s_word[1] & 0xffu) != 1u && !a.obs_direct) {   // the observation(s): pinned host memory -> slot 0, tagged
                 const unsigned tag0 = s_word[0] * 16u;
-                const int n = s_word[1] == 3u ? a.Db + a.Z : 2 * a.Db;
-                for (int i = tid; i < n; i += 256)
-                    srv_put(a.acts + i, __hip_atomic_load(a.req->obs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), tag0);
+                const int n = (s_word[1] & 0xffu) == 3u ? a.Db + a.Z : 2 * a.Db, nr = RMAX == 1 ? 1 : (int)((s_word[1] >> 8) & 3u) + 1;
+                for (int r = 0; r < nr; ++r)
+                    for (int i = tid; i < n; i += 256)
+                        srv_put(a.acts + (size_t)r * kSrvActStride + i,
+                                __hip_atomic_load(a.req->obs + r * n + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), tag0);
             }
         } else if (a.obs_direct) {
             // the request block is device memory: every group watches its control line itself (no hop through group 0);
@@ -275,7 +289,8 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
         }
         __syncthreads();
         last = s_word[0];
-        const unsigned cmd = s_word[1];
+        const unsigned cmd = s_word[1] & 0xffu;
+        const int rows = RMAX == 1 ? 1 : (int)((s_word[1] >> 8) & 3u) + 1;  // rows of this request
         if (cmd == 1u) break;
         if (cmd == 2u) {
             // the arena was rewritten (Adam's stores from other XCDs, an SDMA copy) while this kernel was resident: no kernel
@@ -295,101 +310,127 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
         for (int l = decode_only ? a.n_te : 0; l < a.n_layers; ++l) {
             const SrvLayer L = a.layer[l];
             // the helper's first layer reads what the decoder's first layer read: [s1 | z | 0], z from the ENCODER's output slot
-            const bool dec_in = l == a.n_te || (l == a.n_md && a.n_md < a.n_layers);
+            const bool dec_in = l == a.n_te || (HELPER && l == a.n_md);
             const int lp = dec_in ? a.n_te : l;
-            const unsigned long long* prev = a.acts + (size_t)lp * kSrvActStride;  // slot l: the previous layer's output (0: obs)
+            const unsigned long long* prev0 = a.acts + (size_t)lp * srv_slot_words(RMAX);   // slot l: the previous layer's output (0: obs)
             const unsigned tagp = tag0 + (unsigned)lp;
             const unsigned tago = tag0 + (unsigned)l + 1u;                         // tag of THIS layer's outputs (slot l + 1)
-            if (l == 0) {                                                    // [s1 | s2 | 0]
-                if (a.obs_direct) {                                          // (complete before the request word)
-                    for (int k = tid; k < L.ld; k += 256)
-                        xs[k] = k < 2 * a.Db ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
-                } else {
-                    srv_get_row(xs, a.acts, 2 * a.Db, L.ld, tag0, tid, t_start, a.life_ticks, failed, a.sync + 18);
-                }
-            } else if (dec_in && decode_only) {                              // [s1 | z | 0] as the caller sent it
-                if (a.obs_direct) {
-                    for (int k = tid; k < L.ld; k += 256)
-                        xs[k] = k < a.Db + a.Z ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
-                } else {
-                    srv_get_row(xs, a.acts, a.Db + a.Z, L.ld, tag0, tid, t_start, a.life_ticks, failed, a.sync + 18);
-                }
-            } else if (dec_in) {                                             // [s1 | z | 0], the sampler formed in place
-                for (int k = tid; k < L.ld; k += 256) {
-                    float v = 0.f;
-                    if (k < a.Db) v = a.obs_direct ? __hip_atomic_load(a.req->obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                                   : srv_get(a.acts + k, tag0, t_start, a.life_ticks, failed, a.sync + 18);
-                    else if (k < a.Db + a.Z) {
-                        const int j = k - a.Db;
-                        if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_get(prev + j, tagp, t_start, a.life_ticks, failed, a.sync + 18);
-                        else {
-                            const float e = noise ? philox_normal(seed, offset, 0, j) : 0.f;       // (before the wait: off its path)
-                            float mu, lv;
-                            srv_get2(prev + j, prev + a.Z + j, tagp, mu, lv, t_start, a.life_ticks, failed, a.sync + 18);
-                            v = mu + e * expf(0.5f * lv);
-                        }
+            const int n_obs = decode_only ? a.Db + a.Z : 2 * a.Db;                // floats per row of the request block
+            for (int r = 0; r < rows; ++r) {
+                float* xr = xs + r * a.xs_ld;
+                const unsigned long long* prev = prev0 + (size_t)r * kSrvActStride;
+                const unsigned long long* obs_w = a.acts + (size_t)r * kSrvActStride;      // slot 0, row r
+                const float* obs_r = a.req->obs + r * n_obs;
+                if (l == 0) {                                                    // [s1 | s2 | 0]
+                    if (a.obs_direct) {                                          // (complete before the request word)
+                        for (int k = tid; k < L.ld; k += 256)
+                            xr[k] = k < 2 * a.Db ? __hip_atomic_load(obs_r + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
+                    } else {
+                        srv_get_row(xr, obs_w, 2 * a.Db, L.ld, tag0, tid, t_start, a.life_ticks, failed, a.sync + 18);
                     }
-                    xs[k] = v;
+                } else if (dec_in && decode_only) {                              // [s1 | z | 0] as the caller sent it
+                    if (a.obs_direct) {
+                        for (int k = tid; k < L.ld; k += 256)
+                            xr[k] = k < a.Db + a.Z ? __hip_atomic_load(obs_r + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
+                    } else {
+                        srv_get_row(xr, obs_w, a.Db + a.Z, L.ld, tag0, tid, t_start, a.life_ticks, failed, a.sync + 18);
+                    }
+                } else if (dec_in) {                                             // [s1 | z | 0], the sampler formed in place
+                    for (int k = tid; k < L.ld; k += 256) {
+                        float v = 0.f;
+                        if (k < a.Db) v = a.obs_direct ? __hip_atomic_load(obs_r + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                                       : srv_get(obs_w + k, tag0, t_start, a.life_ticks, failed, a.sync + 18);
+                        else if (k < a.Db + a.Z) {
+                            const int j = k - a.Db;
+                            if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_get(prev + j, tagp, t_start, a.life_ticks, failed, a.sync + 18);
+                            else {
+                                const float e = noise ? philox_normal(seed, offset, r, j) : 0.f;   // (before the wait: off its path)
+                                float mu, lv;
+                                srv_get2(prev + j, prev + a.Z + j, tagp, mu, lv, t_start, a.life_ticks, failed, a.sync + 18);
+                                v = mu + e * expf(0.5f * lv);
+                            }
+                        }
+                        xr[k] = v;
+                    }
+                } else {
+                    srv_get_row(xr, prev, L.ld, L.ld, tagp, tid, t_start, a.life_ticks, failed, a.sync + 18);
                 }
-            } else {
-                srv_get_row(xs, prev, L.ld, L.ld, tagp, tid, t_start, a.life_ticks, failed, a.sync + 18);
             }
             if (failed) s_failed = 1;
             __syncthreads();
             if (stamp) a.dbg[1 + 2 * l] = wall_clock64();                    // layer l: inputs in LDS
             const float* Wl = srv_lds + L.lds_off;
-            unsigned long long* outp = a.acts + (size_t)(l + 1) * kSrvActStride;
+            unsigned long long* outp = a.acts + (size_t)(l + 1) * srv_slot_words(RMAX);     // (+ r * kSrvActStride: row r)
             // one wave per feature, gemv_rollout_kernel's sum operation for operation -- four features of the wave at a time,
             // so that their reductions overlap, and the butterfly as register moves (srv_tree_sum) instead of six
-            // ds_bpermute round trips per feature
+            // ds_bpermute round trips per feature.  More than one row: every weight fragment read from LDS feeds all rows
+            // (R = 2 or 4 accumulators per feature; a 3-row request runs the 4-row body and drops the last row).
             int nf = L.n_out_pad - g * L.F;
             nf = nf < 0 ? 0 : (nf > L.F ? L.F : nf);
             for (int f0 = wave; f0 < nf; f0 += 16) {
                 const int cnt = (nf - f0 + 3) >> 2;                          // features f0, f0 + 4, ... of this wave in this pass
-                auto rows = [&](auto nrows) {                                // (one unguarded body per count: the LDS reads of a
-                    constexpr int N = decltype(nrows)::value;                //  k-step are in flight together)
-                    float acc[N];
+                auto body = [&](auto nfeat, auto nrows) {                    // (one unguarded body per count: the LDS reads of a
+                    constexpr int N = decltype(nfeat)::value, R = decltype(nrows)::value;   // k-step are in flight together)
+                    float acc[N][R];
 #pragma unroll
-                    for (int i = 0; i < N; ++i) acc[i] = 0.f;
+                    for (int i = 0; i < N; ++i)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[i][r] = 0.f;
                     for (int k = lane * 4; k < L.ld; k += 256) {
-                        const v4f xv = *reinterpret_cast<const v4f*>(xs + k);
+                        v4f xv[R];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) xv[r] = *reinterpret_cast<const v4f*>(xs + (R == 1 ? 0 : r * a.xs_ld) + k);
                         v4f wv[N];
 #pragma unroll
                         for (int i = 0; i < N; ++i) wv[i] = *reinterpret_cast<const v4f*>(Wl + (f0 + 4 * i) * L.ld + k);
 #pragma unroll
                         for (int i = 0; i < N; ++i)
-                            acc[i] = fmaf(wv[i].x, xv.x, fmaf(wv[i].y, xv.y, fmaf(wv[i].z, xv.z, fmaf(wv[i].w, xv.w, acc[i]))));
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+                                acc[i][r] = fmaf(wv[i].x, xv[r].x, fmaf(wv[i].y, xv[r].y, fmaf(wv[i].z, xv[r].z, fmaf(wv[i].w, xv[r].w, acc[i][r]))));
                     }
 #ifdef PVAE_SRV_FINE
                     if (stamp && l == 4) a.dbg[40] = wall_clock64();
 #endif
 #pragma unroll
-                    for (int i = 0; i < N; ++i) acc[i] = srv_tree_sum(acc[i]);
+                    for (int i = 0; i < N; ++i)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[i][r] = srv_tree_sum(acc[i][r]);
 #ifdef PVAE_SRV_FINE
                     if (stamp && l == 4) a.dbg[41] = wall_clock64();
 #endif
-                    // lane i finishes feature i (bias, activation, hand-over word): the N epilogues run side by side instead of
-                    // one after the other on lane 0 (0.6 us of a 1.3 us layer when they did)
+                    // lane i + 4 r finishes feature i of row r (bias, activation, hand-over word): the epilogues run side by side
+                    // instead of one after the other on lane 0 (0.6 us of a 1.3 us layer when they did)
                     float mine = 0.f;
 #pragma unroll
-                    for (int i = 0; i < N; ++i) {
-                        const float si = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc[i]), 0));
-                        mine = lane == i ? si : mine;
-                    }
-                    if (lane < N) {
-                        const int f = f0 + 4 * lane, n = g * L.F + f;
+                    for (int i = 0; i < N; ++i)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const float si = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc[i][r]), 0));
+                            mine = lane == i + 4 * r ? si : mine;
+                        }
+                    if (lane < 4 * R && (lane & 3) < N && (lane >> 2) < rows) {
+                        const int f = f0 + 4 * (lane & 3), n = g * L.F + f;
                         float v = mine + Wl[L.F * L.ld + f];
                         v = (L.act > 1 && n >= L.n_out) ? 0.f : act_apply(v, L.act);
-                        srv_put(outp + n, v, tago);
+                        srv_put(outp + (R == 1 ? 0 : (size_t)(lane >> 2) * kSrvActStride) + n, v, tago);
                     }
                 };
 #ifdef PVAE_SRV_FINE
                 if (stamp && l == 4) a.dbg[39] = wall_clock64();
 #endif
-                if (cnt >= 4) rows(std::integral_constant<int, 4>());
-                else if (cnt == 3) rows(std::integral_constant<int, 3>());
-                else if (cnt == 2) rows(std::integral_constant<int, 2>());
-                else rows(std::integral_constant<int, 1>());
+                auto feat = [&](auto nrows) {
+                    if (cnt >= 4) body(std::integral_constant<int, 4>(), nrows);
+                    else if (cnt == 3) body(std::integral_constant<int, 3>(), nrows);
+                    else if (cnt == 2) body(std::integral_constant<int, 2>(), nrows);
+                    else body(std::integral_constant<int, 1>(), nrows);
+                };
+                if constexpr (RMAX == 1) feat(std::integral_constant<int, 1>());
+                else {
+                    if (rows == 1) feat(std::integral_constant<int, 1>());
+                    else if (rows == 2) feat(std::integral_constant<int, 2>());
+                    else feat(std::integral_constant<int, 4>());
+                }
             }
             // (a bare barrier: only LDS is shared here.  __syncthreads() would also wait for the hand-over stores above to be
             //  acknowledged by the memory system -- half a microsecond per layer that now overlaps the next layer's polling)
@@ -405,13 +446,14 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
         if (s_failed) { alive = false; break; }
         // ---- result: group 0 -> mailbox, payload first, completion word last ----
         if (g == 0) {
-            const unsigned long long* md_out = a.acts + (size_t)a.n_md * kSrvActStride;
-            const unsigned long long* te_out = a.acts + (size_t)a.n_te * kSrvActStride;
-            const unsigned long long* mh_out = a.acts + (size_t)a.n_layers * kSrvActStride;
+            constexpr bool helper = HELPER;
             const unsigned tag_md = tag0 + (unsigned)a.n_md, tag_te = tag0 + (unsigned)a.n_te, tag_mh = tag0 + (unsigned)a.n_layers;
-            const bool helper = a.n_md < a.n_layers;
-            const int n_out = decode_only ? a.Da : a.Da + 3 * a.Z;           // (decoder only: just the action)
-            for (int i = tid; i < n_out; i += 256) {
+            const int n_out = decode_only ? a.Da : a.Da + 3 * a.Z;           // (decoder only: just the action) -- per row
+            for (int ri = tid; ri < rows * n_out; ri += 256) {
+                const int r = RMAX == 1 ? 0 : ri / n_out, i = ri - r * n_out;
+                const unsigned long long* md_out = a.acts + (size_t)a.n_md * srv_slot_words(RMAX) + (size_t)r * kSrvActStride;
+                const unsigned long long* te_out = a.acts + (size_t)a.n_te * srv_slot_words(RMAX) + (size_t)r * kSrvActStride;
+                const unsigned long long* mh_out = a.acts + (size_t)a.n_layers * srv_slot_words(RMAX) + (size_t)r * kSrvActStride;
                 float v;
                 if (i < a.Da) {
                     v = srv_get(md_out + i, tag_md, t_start, a.life_ticks, failed, a.sync + 18);
@@ -423,13 +465,13 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
                     const int j = i - a.Da - 2 * a.Z;
                     if (a.prior_kind == PVAE_PRIOR_NONE) v = srv_get(te_out + j, tag_te, t_start, a.life_ticks, failed, a.sync + 18);
                     else {
-                        const float e = noise ? philox_normal(seed, offset, 0, j) : 0.f;
+                        const float e = noise ? philox_normal(seed, offset, r, j) : 0.f;
                         float mu, lv;
                         srv_get2(te_out + j, te_out + a.Z + j, tag_te, mu, lv, t_start, a.life_ticks, failed, a.sync + 18);
                         v = mu + e * expf(0.5f * lv);
                     }
                 }
-                __hip_atomic_store(a.mb->out + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.mb->out + ri, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -466,6 +508,7 @@ struct RolloutServer {
     uint32_t seq = 0, served = 0;
     unsigned long long loaded_version = 0;   // pvae_ctx::param_version of the resident weights
     int scope = 0, xcd = -1;
+    int max_rows = 1;                     // rows per request the resident instance takes (1, or kSrvMaxRows after the first multi-row request)
     bool launched = false;
     double idle_ms = 100.0, life_s = 600.0;
 };
@@ -493,8 +536,8 @@ static size_t server_layout(pvae_ctx* c, RolloutServer& S, int groups) {
     a.mh_range = c->L.cfg.mh_range;
     a.groups = groups; a.one_xcd = groups == 32 ? 1 : 0;
     a.Db = c->L.cfg.dim_body; a.Da = c->L.cfg.dim_action; a.Z = c->L.cfg.latent; a.prior_kind = c->L.cfg.prior_kind;
-    a.xs_off = off;
-    return (size_t)(off + max_ld) * sizeof(float);
+    a.xs_off = off; a.xs_ld = max_ld;
+    return (size_t)(off + S.max_rows * max_ld) * sizeof(float);
 }
 
 // scope: 0 = one XCD if the stacks fit its CUs' LDS, else the whole chip; 1 = one XCD; 2 = the whole chip
@@ -530,8 +573,15 @@ static int server_launch(pvae_ctx* c, RolloutServer& S) {
     S.args.params = c->params;
     S.args.idle_ticks = (long long)(S.idle_ms * 1e5);
     S.args.life_ticks = (long long)(S.life_s * 1e8);
-    HIP_TRY(hipFuncSetAttribute((const void*)rollout_server_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes));
-    hipLaunchKernelGGL(rollout_server_kernel, dim3(256), dim3(256), S.lds_bytes, S.stream, S.args);
+    const bool helper = S.args.n_md < S.args.n_layers;
+#define PVAE_SRV_GO(R, H)                                                                                                                 \
+    do {                                                                                                                                  \
+        HIP_TRY(hipFuncSetAttribute((const void*)rollout_server_kernel<R, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes)); \
+        hipLaunchKernelGGL((rollout_server_kernel<R, H>), dim3(256), dim3(256), S.lds_bytes, S.stream, S.args);                             \
+    } while (0)
+    if (S.max_rows == 1) { if (helper) PVAE_SRV_GO(1, true); else PVAE_SRV_GO(1, false); }
+    else { if (helper) PVAE_SRV_GO(kSrvMaxRows, true); else PVAE_SRV_GO(kSrvMaxRows, false); }
+#undef PVAE_SRV_GO
     HIP_TRY(hipGetLastError());
     S.launched = true;
     // until the kernel reports "serving" (or refuses): bounded
@@ -586,8 +636,8 @@ int pvae_rollout_server_start(pvae_ctx* c, double idle_timeout_ms, double lifeti
         HIP_TRY(hipMalloc((void**)&S.sync, 64 * sizeof(unsigned)));
         HIP_TRY(hipMalloc((void**)&S.dbg, 64 * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(S.dbg, 0, 64 * sizeof(unsigned long long)));
-        HIP_TRY(hipMalloc((void**)&S.acts, (size_t)(kSrvMaxLayers + 1) * kSrvActStride * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(S.acts, 0, (size_t)(kSrvMaxLayers + 1) * kSrvActStride * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void**)&S.acts, (size_t)(kSrvMaxLayers + 1) * srv_slot_words(kSrvMaxRows) * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(S.acts, 0, (size_t)(kSrvMaxLayers + 1) * srv_slot_words(kSrvMaxRows) * sizeof(unsigned long long)));
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));               // lo: least urgent.  A priority of its own = a hardware
         HIP_TRY(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, lo));   // queue no compute stream is mapped onto
@@ -604,11 +654,14 @@ int pvae_rollout_server_start(pvae_ctx* c, double idle_timeout_ms, double lifeti
     return server_launch(c, S);
 }
 
-static int server_request(pvae_ctx* c, uint32_t cmd, const float* obs, int noise, uint64_t seed, uint64_t offset, double timeout_ms) {
+static int server_request(pvae_ctx* c, uint32_t cmd, const float* obs, int noise, uint64_t seed, uint64_t offset, double timeout_ms,
+                          int rows = 1) {
     RolloutServer& S = *c->server;
     SrvReply* mb = S.mb;
     SrvRequest* rq = S.req;
-    if (obs) memcpy((void*)rq->obs, obs, (size_t)(cmd == 3u ? S.args.Db + S.args.Z : 2 * S.args.Db) * sizeof(float));
+    if (obs) memcpy((void*)rq->obs, obs, (size_t)rows * (cmd == 3u ? S.args.Db + S.args.Z : 2 * S.args.Db) * sizeof(float));
+    const uint32_t op = cmd;
+    cmd |= (uint32_t)(rows - 1) << 8;                            // (bits 8-9: rows - 1)
     rq->cmd = cmd; rq->noise = noise ? 1u : 0u;
     rq->seed_lo = (uint32_t)seed; rq->seed_hi = (uint32_t)(seed >> 32); rq->off_lo = (uint32_t)offset; rq->off_hi = (uint32_t)(offset >> 32);
     const uint32_t seq = ++S.seq;
@@ -618,7 +671,7 @@ static int server_request(pvae_ctx* c, uint32_t cmd, const float* obs, int noise
     if (S.req_on_device) __builtin_ia32_sfence();
     __atomic_store_n(&rq->req_seq, seq, __ATOMIC_RELEASE);
     if (S.req_on_device) __builtin_ia32_sfence();
-    if (cmd == 1) return 0;
+    if (op == 1) return 0;
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     while (__atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) != seq) {
@@ -633,10 +686,30 @@ static int server_request(pvae_ctx* c, uint32_t cmd, const float* obs, int noise
 
 int pvae_rollout_server_infer(pvae_ctx* c, const float* obs, int noise, uint64_t rng_seed, uint64_t rng_offset, int reload,
                               float* a_hat, float* mu_logvar, float* z, double timeout_ms) {
+    return pvae_rollout_server_infer_rows(c, obs, 1, noise, rng_seed, rng_offset, reload, a_hat, mu_logvar, z, timeout_ms);
+}
+
+int pvae_rollout_server_infer_rows(pvae_ctx* c, const float* obs, int32_t rows, int noise, uint64_t rng_seed, uint64_t rng_offset,
+                                   int reload, float* a_hat, float* mu_logvar, float* z, double timeout_ms) {
     if (!c || !c->server || !c->server->mb) return fail(-2, "rollout server not started (pvae_rollout_server_start)");
     if (!obs || !a_hat) return fail(-1, "obs / a_hat is null");
     RolloutServer& S = *c->server;
+    if (rows < 1 || rows > kSrvMaxRows) return fail(-1, "rollout server: rows %d outside [1, %d]", (int)rows, kSrvMaxRows);
+    if (rows * 2 * S.args.Db > kSrvMaxObs || rows * (S.args.Da + 3 * S.args.Z) > kSrvMaxOut)
+        return fail(-24, "rollout server: %d rows of this observation / action do not fit the mailbox", (int)rows);
     if (timeout_ms <= 0) timeout_ms = 1000.0;
+    if (rows > S.max_rows) {
+        // the first request with more than one row: the single-row instance makes way for the multi-row one (once; a few
+        // hundred microseconds).  If the wider input buffer no longer fits the LDS plan, the single-row instance stays.
+        int rc = pvae_rollout_server_stop(c);
+        if (rc) return rc;
+        S.max_rows = kSrvMaxRows;
+        if ((rc = pvae_rollout_server_start(c, 0, 0, -1))) {
+            S.max_rows = 1;
+            return rc;
+        }
+        reload = 0;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (!S.launched || S.mb->state != 1u) {                  // it left after its idle time: bring it back (weights re-read)
             int rc = pvae_rollout_server_start(c, 0, 0, -1);
@@ -648,14 +721,17 @@ int pvae_rollout_server_infer(pvae_ctx* c, const float* obs, int noise, uint64_t
             S.loaded_version = c->param_version;
             reload = 1;
         }
-        const int r = server_request(c, reload ? 2u : 0u, obs, noise, rng_seed, rng_offset, timeout_ms);
+        const int r = server_request(c, reload ? 2u : 0u, obs, noise, rng_seed, rng_offset, timeout_ms, rows);
         if (r < 0) return r;
         if (r == 0) {
             ++S.served;
-            const int Da = S.args.Da, Z = S.args.Z;
-            memcpy(a_hat, (const void*)S.mb->out, (size_t)Da * sizeof(float));
-            if (mu_logvar) memcpy(mu_logvar, (const void*)(S.mb->out + Da), (size_t)2 * Z * sizeof(float));
-            if (z) memcpy(z, (const void*)(S.mb->out + Da + 2 * Z), (size_t)Z * sizeof(float));
+            const int Da = S.args.Da, Z = S.args.Z, n_out = Da + 3 * Z;
+            for (int q = 0; q < rows; ++q) {                 // reply row q: [a_hat | mu | logvar | z]
+                const float* o = (const float*)S.mb->out + (size_t)q * n_out;
+                memcpy(a_hat + (size_t)q * Da, o, (size_t)Da * sizeof(float));
+                if (mu_logvar) memcpy(mu_logvar + (size_t)q * 2 * Z, o + Da, (size_t)2 * Z * sizeof(float));
+                if (z) memcpy(z + (size_t)q * Z, o + Da + 2 * Z, (size_t)Z * sizeof(float));
+            }
             return 0;
         }
     }

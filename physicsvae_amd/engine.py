@@ -646,6 +646,25 @@ class HipEngine:
             _lib.check(rc, "pvae_rollout_server_infer")
         return n_a, n_ml, n_z
 
+    def rollout_server_infer_rows(self, obs, noise=True, seed=0, offset=0, reload=False, timeout_ms=1000.0):
+        """obs [rows, 2 Db], 1 <= rows <= 4 -> (a_hat [rows, Da], mu_logvar [rows, 2 Z], z [rows, Z]) as fresh numpy arrays:
+        ONE request to the resident kernel (every weight fragment read from LDS feeds all rows); the same values as
+        `infer(obs, noise=noise, seed=seed, offset=offset)`, bit for bit."""
+        import numpy as _np
+        if self._srv_io is None:
+            raise RuntimeError("rollout server not started (rollout_server_start)")
+        if isinstance(obs, torch.Tensor):
+            obs = obs.detach().cpu().numpy()
+        x = _np.ascontiguousarray(obs, dtype=_np.float32).reshape(-1, 2 * self.arch.Db)
+        rows = x.shape[0]
+        a = _np.empty((rows, self.arch.Da), _np.float32)
+        ml = _np.empty((rows, 2 * self.arch.Z), _np.float32)
+        z = _np.empty((rows, self.arch.Z), _np.float32)
+        _lib.check(self.lib.pvae_rollout_server_infer_rows(self.ctx, x.ctypes.data, rows, 1 if noise else 0, int(seed), int(offset),
+                                                           1 if reload else 0, a.ctypes.data, ml.ctypes.data, z.ctypes.data,
+                                                           float(timeout_ms)), "pvae_rollout_server_infer_rows")
+        return a, ml, z
+
     def params_changed(self, stream=None):
         """The parameter arena was written outside the library (load_state_dict, a torch optimizer): holders of a copy -- the
         rollout server's LDS -- refresh before their next answer.  Optimizer steps through the library count by themselves."""

@@ -448,9 +448,9 @@ class PhysicsVAE(nn.Module):
         rows = obs.shape[0]
         noise = bool(self.latent_prior_noise)
         st = self._st
-        if (self.__dict__.get("_srv_on") and rows == 1 and obs.device.type == "cpu" and (eps is None or not noise)
+        if (self.__dict__.get("_srv_on") and rows <= 4 and obs.device.type == "cpu" and (eps is None or not noise)
                 and self._latent_prior_type != "hypersphere_uniform"):
-            return self._forward_served(obs, state, noise)
+            return self._forward_served(obs, state, noise) if rows == 1 else self._forward_served_rows(obs, state, noise)
         obs = obs.to(eng.device)
         st._rng_calls += 1
         # (eager on purpose: with the input assembly, the sampler and the output copies inside the layer
@@ -546,6 +546,30 @@ class PhysicsVAE(nn.Module):
             st._mu, st._logvar = v_mu, v_lv
         st._cur_latent_prior_mu = None
         return t_log.clone(), state
+
+    def _forward_served_rows(self, obs, state, noise):
+        """2-4 rows in ONE request to the resident kernel (pvae_rollout_server_infer_rows); same contract as `_forward_served`,
+        fresh tensors per call."""
+        st = self._st
+        st._rng_calls += 1
+        rows, Z = obs.shape[0], self._task_encoder_output_dim
+        a, ml, z = self.engine.rollout_server_infer_rows(obs, noise=noise, seed=self._rng_seed, offset=st._rng_calls)
+        ls = self.__dict__["_als"].log_std.detach().cpu().reshape(1, -1).expand(rows, -1)
+        logits = torch.cat([torch.from_numpy(a), ls], dim=1)                  # [a_hat | log_std] (AppendLogStd, rmt:160-206)
+        t_obs, t_ml, t_z = obs.clone(), torch.from_numpy(ml), torch.from_numpy(z)
+        st._cur_future_state = None
+        st._cur_body_encoder_variable = t_obs[:, : self.dim_state_body]
+        st._cur_task_encoder_variable = t_z
+        st._lazy = (t_obs, rows, None, noise, st._rng_calls) if self.rollout_predicts_state in ("lazy", True) else (t_obs, rows)
+        if self.rollout_predicts_state is True:
+            self._get_future_state()
+        st._cur_value = None
+        if self._latent_prior_type is False:
+            st._mu, st._logvar = t_z, None
+        else:
+            st._mu, st._logvar = t_ml[:, :Z], t_ml[:, Z:]
+        st._cur_latent_prior_mu = None
+        return logits, state
 
     def _forward_staged(self, obs, state, seq_lens, eps=None):
         """The same forward stage by stage (forward_encoder / forward_decoder / forward_world): batches

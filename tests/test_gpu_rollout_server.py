@@ -408,3 +408,54 @@ def test_server_serves_a_helper_model_bit_for_bit(noise):
             assert torch.equal(lg, launched[i])
     finally:
         tr.model.stop_rollout_server()
+
+
+@pytest.mark.parametrize("helper", [False, True])
+@pytest.mark.parametrize("noise", [False, True])
+def test_server_serves_two_to_four_rows_in_one_request(noise, helper):
+    """pvae_rollout_server_infer_rows: 1 <= rows <= 4 observations per request (rmt:742-771 serves any batch); every weight
+    fragment read from LDS feeds all rows (2 or 4 accumulators per feature; 3 rows run the 4-row body).  Action, mu / logvar
+    and z of every row equal `pvae_infer` on the same rows (row r draws Philox row r), bit for bit -- with and without a
+    helper stack -- and the single-row request in between still equals its own launch path."""
+    if helper:
+        from test_gpu_helper_training import _trainer, _weights
+        base = R.make_arch(197, 45)
+        h, sd = _weights(base)
+        data = R.synth_demo(0, 2, 40, 197, 45, kind="dynamics")
+        tr = _trainer(base, data, 8, device=DEV)
+        tr.model.load_state_dict(sd)
+        X, _ = R.build_windows(data)
+        obs = torch.from_numpy(np.asarray(X)).float()[:, 0, :]
+    else:
+        _, tr, obs = _default_trainer()
+    eng = tr.engine
+    Z = eng.arch.Z
+    with served(eng):
+        for i, rows in enumerate((2, 3, 4, 1, 4, 2)):
+            o = obs[i: i + rows]
+            a, ml, z = eng.rollout_server_infer_rows(o.numpy(), noise=noise, seed=11, offset=2000 + i)
+            want_a, _, want_z = eng.infer(o.to(DEV), noise=noise, seed=11, offset=2000 + i, want_s2=False)
+            assert a.shape == (rows, 45) and np.array_equal(a, want_a.cpu().numpy())
+            assert np.array_equal(z, want_z.cpu().numpy())
+            assert np.array_equal(ml[:, :Z], eng.read("mu", rows).cpu().numpy())
+            a1, _, z1 = (x.copy() for x in eng.rollout_server_infer(o[0].numpy(), noise=noise, seed=11, offset=2000 + i))
+            assert np.array_equal(a1, a[0]) and np.array_equal(z1, z[0])       # (row 0 of a batch == the single-row request)
+        with pytest.raises(RuntimeError):
+            eng.rollout_server_infer_rows(obs[:5].numpy())
+    # the module surface: 3 CPU rows, served == launched
+    m = tr.model
+    m.eval()
+    m.latent_prior_noise = noise
+    m._st._rng_calls = 50
+    with torch.no_grad():
+        want = m.forward({"obs_flat": obs[:3].to(DEV)}, [], None)[0].cpu()
+        want_z, want_s2 = m.task_encoder_variable().cpu().clone(), m._cur_future_state.cpu().clone()
+    m._st._rng_calls = 50
+    m.start_rollout_server(idle_ms=2000.0, lifetime_s=30.0)
+    try:
+        with torch.no_grad():
+            got = m.forward({"obs_flat": obs[:3]}, [], None)[0]
+            assert torch.equal(got, want) and torch.equal(m.task_encoder_variable().cpu(), want_z)
+            assert torch.equal(m._cur_future_state.cpu(), want_s2)
+    finally:
+        m.stop_rollout_server()

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pvae_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.pvae_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_layout_queries_without_gpu():
