@@ -253,6 +253,14 @@ def cpu_model():
     return "unknown"
 
 
+def p2p_timeout_ms():
+    """How long a peer-mapped wait may take in this run before it gives up: a fraction of a second with one rank per GPU
+    (a peer that never answers must not cost the library's default 20 s per wait) -- but ranks that SHARE a GPU are
+    time-sliced, one step of 8 such ranks takes ~230 ms and a wait can sit out several slices (the round-4 line and one of
+    round 5's lost their `exchange_sweep` entries to a 250 ms limit there)."""
+    return "5000" if os.environ.get("PVAE_BENCH_SHARED_GPU") == "1" else "250"
+
+
 def physical_cores():
     """(physical cores, sockets) of this host from /proc/cpuinfo's (physical id, core id) pairs; (None, None) if unreadable."""
     try:
@@ -455,7 +463,7 @@ def main():
         # The exchange form is chosen by measurement, before the warm-up: every form this build and this machine offer
         # runs the same 6 + 24 steps from the same state (snapshotted, restored), the slowest rank's time counts, and a
         # form whose replicas do not stay bit-identical is out (parallel.DataParallel.autotune_exchange).
-        os.environ.setdefault("PVAE_P2P_TIMEOUT_MS", "250")
+        os.environ.setdefault("PVAE_P2P_TIMEOUT_MS", p2p_timeout_ms())
         ph, nets_ = set_phase(a.phase)
         chosen, report = dp.autotune_exchange(eng, lambda n: run_steps(ph, nets_, n, 0))
         autotune = {"chosen": chosen or "library default (no candidate qualified)", "candidates": report}
@@ -747,7 +755,7 @@ def main():
                 if mode in ("p2p", "p2p_push"):
                     # (a peer that never answers must cost this run a fraction of a second per wait, not the
                     #  library's default 20 s: the time-out is read when the peers are mapped)
-                    os.environ.setdefault("PVAE_P2P_TIMEOUT_MS", "250")
+                    os.environ.setdefault("PVAE_P2P_TIMEOUT_MS", p2p_timeout_ms())
                     if not dp.attach_p2p(eng, mode):               # collective: every rank agrees on the outcome
                         return {"skipped": "peer-mapped exchange could not be set up (see stderr)"}
                 elif mode == "local":

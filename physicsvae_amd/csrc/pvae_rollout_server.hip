@@ -136,6 +136,61 @@ __device__ inline void srv_get_row(float* xs, const unsigned long long* prev, in
     }
 }
 
+// The same for the rows of a multi-row request at once (row r of the slot: prev + r * kSrvActStride -> xs + r * xs_ld): every
+// row's words are in flight together, so a layer's inputs cost ONE round trip after the producers' stores instead of one per row.
+template <int R>
+__device__ inline void srv_get_rows(float* xs, int xs_ld, const unsigned long long* prev, int rows, int n, int ld, unsigned tag, int tid,
+                                    long long t_start, long long life, int& failed, const unsigned* gone) {
+    constexpr int kMax = kSrvActStride / 256;
+    unsigned long long u[R][kMax];
+    unsigned spins = 0;
+    for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < kMax; ++i) {
+                const int k = tid + 256 * i;
+                u[r][i] = (r < rows && k < n) ? __hip_atomic_load(prev + (size_t)r * kSrvActStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                              : ((unsigned long long)tag << 32);
+            }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < kMax; ++i) all = all && (unsigned)(u[r][i] >> 32) == tag;
+        if (all) break;
+        if ((++spins & 255u) == 0 && (srv_ldu(gone) != 0u || wall_clock64() - t_start > life)) { failed = 1; break; }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int i = 0; i < kMax; ++i) {
+            const int k = tid + 256 * i;
+            if (r < rows && k < ld) xs[r * xs_ld + k] = k < n ? __uint_as_float((unsigned)u[r][i]) : 0.f;
+        }
+}
+// (mu, logvar) of latent j for every row of a multi-row request, polled together
+template <int R>
+__device__ inline void srv_get2_rows(const unsigned long long* p0, const unsigned long long* p1, int rows, unsigned tag, float (&v0)[R],
+                                     float (&v1)[R], long long t_start, long long life, int& failed, const unsigned* gone) {
+    unsigned long long u0[R], u1[R];
+    unsigned spins = 0;
+    for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            u0[r] = r < rows ? __hip_atomic_load(p0 + (size_t)r * kSrvActStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+            u1[r] = r < rows ? __hip_atomic_load(p1 + (size_t)r * kSrvActStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) all = all && (unsigned)(u0[r] >> 32) == tag && (unsigned)(u1[r] >> 32) == tag;
+        if (all) break;
+        if ((++spins & 255u) == 0 && (srv_ldu(gone) != 0u || wall_clock64() - t_start > life)) { failed = 1; break; }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { v0[r] = __uint_as_float((unsigned)u0[r]); v1[r] = __uint_as_float((unsigned)u1[r]); }
+}
+
 // Lane 0's value of `for (o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64)`: the halving tree r[i] += r[i + h], h = 32 ... 1
 // (additions commute, so only the association matters), with the two cross-row steps as gfx950's permlane swaps and the
 // four in-row steps as DPP row shifts -- register moves, where __shfl_xor compiles to a ds_bpermute round trip per step.
@@ -316,7 +371,37 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
             const unsigned tagp = tag0 + (unsigned)lp;
             const unsigned tago = tag0 + (unsigned)l + 1u;                         // tag of THIS layer's outputs (slot l + 1)
             const int n_obs = decode_only ? a.Db + a.Z : 2 * a.Db;                // floats per row of the request block
-            for (int r = 0; r < rows; ++r) {
+            // more than one row: the rows' hand-over words are polled TOGETHER wherever a layer waits for its producers
+            bool formed = false;
+            if constexpr (RMAX > 1) {
+                if (rows > 1 && !dec_in && !(l == 0 && a.obs_direct)) {
+                    // (layer 0: slot 0 = the observations group 0 copied; else the previous layer's outputs)
+                    srv_get_rows<RMAX>(xs, a.xs_ld, l == 0 ? a.acts : prev0, rows, l == 0 ? 2 * a.Db : L.ld, L.ld, l == 0 ? tag0 : tagp, tid,
+                                       t_start, a.life_ticks, failed, a.sync + 18);
+                    formed = true;
+                } else if (rows > 1 && dec_in && !decode_only && a.prior_kind != PVAE_PRIOR_NONE) {
+                    for (int k = tid; k < L.ld; k += 256) {
+                        if (k >= a.Db && k < a.Db + a.Z) {
+                            const int j = k - a.Db;
+                            float mu[RMAX], lv[RMAX];
+                            srv_get2_rows<RMAX>(prev0 + j, prev0 + a.Z + j, rows, tagp, mu, lv, t_start, a.life_ticks, failed, a.sync + 18);
+                            for (int r = 0; r < rows; ++r) {
+                                const float e = noise ? philox_normal(seed, offset, r, j) : 0.f;
+                                xs[r * a.xs_ld + k] = mu[r] + e * expf(0.5f * lv[r]);
+                            }
+                        } else {
+                            for (int r = 0; r < rows; ++r) {
+                                float v = 0.f;
+                                if (k < a.Db) v = a.obs_direct ? __hip_atomic_load(a.req->obs + r * n_obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                                               : srv_get(a.acts + (size_t)r * kSrvActStride + k, tag0, t_start, a.life_ticks, failed, a.sync + 18);
+                                xs[r * a.xs_ld + k] = v;
+                            }
+                        }
+                    }
+                    formed = true;
+                }
+            }
+            for (int r = 0; r < (formed ? 0 : rows); ++r) {
                 float* xr = xs + r * a.xs_ld;
                 const unsigned long long* prev = prev0 + (size_t)r * kSrvActStride;
                 const unsigned long long* obs_w = a.acts + (size_t)r * kSrvActStride;      // slot 0, row r
