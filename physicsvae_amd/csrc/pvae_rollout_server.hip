@@ -374,10 +374,20 @@ __global__ void __launch_bounds__(256) rollout_server_kernel(SrvArgs a) {
             // more than one row: the rows' hand-over words are polled TOGETHER wherever a layer waits for its producers
             bool formed = false;
             if constexpr (RMAX > 1) {
-                if (rows > 1 && !dec_in && !(l == 0 && a.obs_direct)) {
+                if (rows > 1 && l == 0 && a.obs_direct) {
+                    // the observations sit in the request block (device memory): every row's loads in flight together
+                    for (int idx = tid; idx < rows * L.ld; idx += 256) {
+                        const int r = idx / L.ld, k = idx - r * L.ld;
+                        xs[r * a.xs_ld + k] = k < 2 * a.Db ? __hip_atomic_load(a.req->obs + r * n_obs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
+                    }
+                    formed = true;
+                } else if (rows > 1 && !dec_in) {
                     // (layer 0: slot 0 = the observations group 0 copied; else the previous layer's outputs)
-                    srv_get_rows<RMAX>(xs, a.xs_ld, l == 0 ? a.acts : prev0, rows, l == 0 ? 2 * a.Db : L.ld, L.ld, l == 0 ? tag0 : tagp, tid,
-                                       t_start, a.life_ticks, failed, a.sync + 18);
+                    const unsigned long long* src = l == 0 ? a.acts : prev0;
+                    const int n_in = l == 0 ? 2 * a.Db : L.ld;
+                    const unsigned tg = l == 0 ? tag0 : tagp;
+                    if (rows == 2) srv_get_rows<2>(xs, a.xs_ld, src, rows, n_in, L.ld, tg, tid, t_start, a.life_ticks, failed, a.sync + 18);
+                    else srv_get_rows<RMAX>(xs, a.xs_ld, src, rows, n_in, L.ld, tg, tid, t_start, a.life_ticks, failed, a.sync + 18);
                     formed = true;
                 } else if (rows > 1 && dec_in && !decode_only && a.prior_kind != PVAE_PRIOR_NONE) {
                     for (int k = tid; k < L.ld; k += 256) {
