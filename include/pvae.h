@@ -472,7 +472,8 @@ int pvae_infer_logits(pvae_ctx* ctx, const float* obs, int32_t rows, const float
  *   pvae_rollout_server_infer_rows  the same for 1-4 observations in one request.  A server starts as the single-row
  *                               instance of the kernel; the first request with more rows swaps in the multi-row instance
  *                               (once, a few hundred microseconds; it needs LDS for four input vectors -- -24 if that no
- *                               longer fits, the single-row instance then stays).  A model with the motor decoder's helper
+ *                               longer fits, the single-row instance then stays); it serves until pvae_rollout_server_stop.
+ *                               A model with the motor decoder's helper
  *                               (pvae_config.mh_depth > 0) is served with the helper's layers behind the decoder's.
  *   pvae_rollout_server_stop    ends the kernel (also done by pvae_destroy).
  *   pvae_rollout_server_status  *lds_bytes < 0: dealt out over the whole chip (|value| bytes per workgroup).

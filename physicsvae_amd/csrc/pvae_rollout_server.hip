@@ -842,7 +842,9 @@ int pvae_rollout_server_decode(pvae_ctx* c, const float* s1_z, float* a_hat, dou
     if (timeout_ms <= 0) timeout_ms = 1000.0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (S.launched && S.mb->state == 1u && S.loaded_version != c->param_version) {
+            const int keep_rows = S.max_rows;
             int rc = pvae_rollout_server_stop(c);                // (no reload form of this request: a relaunch re-reads)
+            S.max_rows = keep_rows;
             if (rc) return rc;
         }
         if (!S.launched || S.mb->state != 1u) {
@@ -902,6 +904,7 @@ int pvae_rollout_server_stop(pvae_ctx* c) {
         HIP_TRY(hipStreamSynchronize(S.stream));                 // bounded: stop command, else idle time-out, else lifetime
         S.launched = false;
     }
+    S.max_rows = 1;                                              // (an explicit stop: the next start is the single-row instance again)
     return 0;
 }
 
