@@ -565,7 +565,11 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s, batch %d/GPU, TE/MD/WM 4x1024, %s phase" % (workload, a.batch, a.phase),
                    "phase": a.phase, "global_batch": a.batch * a.gpus, "parallelism": "dp%d" % a.gpus,
-                   "exchange": transport},
+                   "exchange": transport,
+                   # first layers: "staged" = the gather launch materialises the input / target panels (the default: it rides in
+                   # the previous step's last launch); "direct" = PVAE_DIRECT=1, the first layers read the demonstration set
+                   # in place (bit-identical, slower at this size: docs/experiments.md, round 5)
+                   "first_layers": "direct" if os.environ.get("PVAE_DIRECT", "0") not in ("", "0") else "staged"},
         "timing": {"timed_steps_per_region": timed_steps, "regions": REPEATS, "statistic": "median",
                    "region_values": rates},
         "rccl_ranks": comm_ranks, "rccl_rank": comm_rank,
