@@ -237,3 +237,65 @@ def test_data_parallel_step_equals_fused_step_with_a_helper():
         want = ref(obs.cpu())
     assert max_err_scaled(logits.cpu(), want) < 2e-5
     assert max_err_scaled(tr.model._cur_future_state.cpu(), ref.cur_future_state) < 2e-5
+
+
+@pytest.mark.parametrize("md_in", [("task",), ("body",)])
+def test_helper_on_a_decoder_input_subset(md_in):
+    """The helper reads what the decoder reads (rmt:646-653, 674-680): with `motor_decoder_inputs` a subset, its first layer
+    is the same column window of the shared input panel.  One minibatch of both phases and four fused joint steps against
+    the oracle (restated model: narrower first layers for decoder AND helper)."""
+    base = R.with_inputs(R.make_arch(197, 45, latent=32, te=(128, 2), md=(128, 2), wm=(128, 2)), ("body", "task"), md_in)
+    h = R.with_helper(base)
+    sd = R.perturb_biases(R.init_state_dict(h, seed=1), seed=3)
+    k_out = "_motor_decoder_helper._model.%d._model.0.weight" % len(h["mh"])
+    sd[k_out] = sd[k_out] * 60.0
+    rows = 64
+    data = R.synth_demo(0, 2, 200, 197, 45, kind="dynamics")
+    X, Y = R.build_windows(data)
+    tr = _trainer(base, data, rows, device=DEV)
+    assert [(k, tuple(v.shape)) for k, v in tr.model.state_dict().items()] == R.state_dict_spec(h)
+    tr.model.load_state_dict(sd)
+    eng = tr.engine
+    x, y = next(iter(R.make_loader(X, Y, rows)))
+    es = R.eps_stream(2, 32)
+    eps = es(0, (rows, 32))
+    for world in (True, False):
+        eng.set_batch(x, y)
+        eng.grads.fill_(float("nan"))
+        loss = eng.forward_backward(_lib.PHASE_WORLD if world else _lib.PHASE_JOINT, rows, _sp(world, rows), eps=eps.to(DEV),
+                                    fused_adam=False).cpu()
+        keep = R.relu_kink_margin(h, sd, x, y, eps, world) > 4e-6
+        want = R.loss_and_grads(h, sd, x, y, eps, world)
+        assert float(loss[0]) == pytest.approx(float(want["total"]), rel=1e-5)
+        if bool(keep.all()):
+            gv = eng.named_views(eng.grads)
+            for k, gr in want["grads"].items():
+                assert max_err_scaled(gv[k].cpu(), gr) < 1e-4, k
+    ref = R.RefModel(h)
+    ref.load_state_dict(sd)
+    ref.set_learnable("_world_model", False)
+    ref.set_learnable("_value_branch", False)
+    opt = torch.optim.Adam(list(ref.parameters()), lr=5e-4)
+    eng.exp_avg.zero_(); eng.exp_avg_sq.zero_()
+    for i in range(4):
+        xi = torch.as_tensor(X[i * rows: (i + 1) * rows], dtype=torch.float32)
+        yi = torch.as_tensor(Y[i * rows: (i + 1) * rows], dtype=torch.float32)
+        e = es(i, (rows, 32))
+        ref.eps_source = lambda shape, e=e: e
+        opt.zero_grad()
+        total, _ = R.compute_loss(ref, xi, yi, R.phase_coeffs(False))
+        total.backward()
+        opt.step()
+        eng.set_batch(xi, yi)
+        loss = eng.forward_backward(_lib.PHASE_JOINT, rows, _sp(False, rows, t=i + 1), eps=e.to(DEV), fused_adam=True).cpu()
+        assert float(loss[0]) == pytest.approx(float(total.detach()), rel=2e-4)
+    ref_sd = ref.state_dict()
+    for k, v in tr.model.state_dict().items():
+        if not k.startswith(("_value_branch", "_world_model")):
+            assert max_err_scaled(v.cpu(), ref_sd[k]) < 2e-3, k
+    # structural zeros of BOTH first layers on the shared panel
+    for info in eng.layers:
+        if info["index"] == 0 and info["net"] in (_lib.NET_MD, _lib.NET_MH):
+            blk = eng.params[info["w_offset"]: info["w_offset"] + info["n_out_pad"] * info["ld"]].view(info["n_out_pad"], info["ld"])
+            out = torch.cat([blk[:, : info["col0"]].reshape(-1), blk[:, info["col0"] + info["n_in"]:].reshape(-1)])
+            assert float(out.abs().max()) == 0.0
