@@ -16,7 +16,6 @@ from util import arch_from_meta, make_trainer, max_err_scaled
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-HELPER = {"model": None}
 
 
 def _trainer(arch, data, batch, **kw):
