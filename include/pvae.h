@@ -17,8 +17,9 @@
  *     GPU; a ctx is not thread-safe.
  *   - all arithmetic is fp32 (v_mfma_f32_16x16x4_f32 for the contractions).
  *
- * Parameter arena.  The three trainable stacks live in ONE flat fp32 arena
- *   [ task encoder | motor decoder | world model ]
+ * Parameter arena.  The trainable stacks live in ONE flat fp32 arena
+ *   [ task encoder | motor decoder | decoder helper | learned prior | world model ]      (TE | MD | MH | PR | WM;
+ *   MH and PR are empty segments unless the configuration has them -- see the PVAE_NET_* enum below)
  * each Linear stored as W[n_out_pad][ld] (row-major, ld = n_in rounded up to 64 floats,
  * n_out_pad = n_out rounded up to 64) followed by bias[n_out_pad]; pad entries are zero
  * and stay zero.  The checkpoint tensor `<net>._model.<i>._model.0.weight` of shape
@@ -484,14 +485,16 @@ int pvae_infer_logits(pvae_ctx* ctx, const float* obs, int32_t rows, const float
 int pvae_rollout_server_start(pvae_ctx* ctx, double idle_timeout_ms, double lifetime_s, int scope);
 int pvae_rollout_server_infer(pvae_ctx* ctx, const float* obs, int noise, uint64_t rng_seed, uint64_t rng_offset, int reload,
                               float* a_hat, float* mu_logvar, float* z, double timeout_ms);
-/* forward_decoder at B = 1 (rmt:822-837; the "pass_through" rollout of envs/rllib_env_imitation.py:233-258, where the caller draws
- * z itself): s1_z = [s1 (Db) | z (Z)] (host) -> a_hat[Da] (host), the same bits as pvae_net_forward(PVAE_NET_MD) on that row.
- * The encoder's layers are skipped. */
-/* The same for 1 <= rows <= 4 observations in ONE request (rmt:742-771 serves any batch): obs[rows][2*Db] ->
- * a_hat[rows][Da] (+ mu_logvar[rows][2*Z], z[rows][Z]); row r draws Philox row r, as pvae_infer does -- bit-identical
- * to pvae_infer on the same rows.  Every weight fragment read from LDS feeds all rows. */
+/* pvae_rollout_server_infer for 1 <= rows <= 4 observations in ONE request (rmt:742-771 serves any batch):
+ * obs[rows][2*Db] -> a_hat[rows][Da] (+ mu_logvar[rows][2*Z], z[rows][Z]); row r draws Philox row r, as pvae_infer does --
+ * bit-identical to pvae_infer on the same rows.  Every weight fragment read from LDS feeds all rows. */
 int pvae_rollout_server_infer_rows(pvae_ctx* ctx, const float* obs, int32_t rows, int noise, uint64_t rng_seed,
                                    uint64_t rng_offset, int reload, float* a_hat, float* mu_logvar, float* z, double timeout_ms);
+/* forward_decoder at B = 1 (rmt:822-837; the "pass_through" rollout of envs/rllib_env_imitation.py:233-258, where the caller draws
+ * z itself): s1_z = [s1 (Db) | z (Z)] (host) -> a_hat[Da] (host).  The encoder's layers are skipped.
+ * Without a helper: the same bits as pvae_net_forward(PVAE_NET_MD) on that row.  With one (pvae_config.mh_depth > 0) the
+ * reply is decoder + mh_range * helper (rmt:833-835), formed by ONE fma in the kernel (as the served full request does):
+ * within an ulp of a host that adds mh_range * h to pvae_net_forward's row itself (tests/test_gpu_rollout_server.py). */
 int pvae_rollout_server_decode(pvae_ctx* ctx, const float* s1_z, float* a_hat, double timeout_ms);
 int pvae_rollout_server_stop(pvae_ctx* ctx);
 /* The caller wrote the parameter arena itself (load_state_dict / load_weights*, rmt:870-928; a torch optimizer) with work

@@ -394,13 +394,15 @@ copy_cols_kernel(const float* __restrict__ src, int lds_, int src_col0, float* _
     }
 }
 
-// dst[rows_pad][ld] = zero-padded copy of dense src[rows][n]
+// dst[rows_pad][ld] = zero-padded copy of dense src[rows][n]; only the columns [c0, c0 + nw) of src are taken (the
+// window a first layer with an input subset reads: whatever the caller put in the other columns meets structural-zero
+// weights, and the panel keeps exact zeros there like a staged one)
 __global__ void __launch_bounds__(256)
-pad_copy_kernel(const float* __restrict__ src, int n, int rows, float* __restrict__ dst, int ld, int rows_pad) {
+pad_copy_kernel(const float* __restrict__ src, int n, int rows, float* __restrict__ dst, int ld, int rows_pad, int c0, int nw) {
     const int total = rows_pad * ld;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
         const int r = idx / ld, c = idx - r * ld;
-        dst[idx] = (r < rows && c < n) ? src[(size_t)r * n + c] : 0.f;
+        dst[idx] = (r < rows && c < n && c >= c0 && c < c0 + nw) ? src[(size_t)r * n + c] : 0.f;
     }
 }
 
@@ -1406,7 +1408,9 @@ static bool direct_ok(const pvae_ctx* c, int phase, int rows, const pvae_step_pa
     if (!c->direct || !c->data_slack || !c->states || c->next_states || c->W.L != 1 || !c->pair_launch || !c->same_layer_pairs)
         return false;
     if (rows <= 4 || c->L.cfg.prior_kind != PVAE_PRIOR_ZERO_MEAN || !c->L.net[PVAE_NET_PR].layers.empty()) return false;
-    if ((c->L.cfg.te_inputs | c->L.cfg.md_inputs) % 3 != 0) return false;      // input subsets: the staged panels carry the zeros
+    // input subsets: the staged panels carry the zeros.  Each field on its own -- BODY (1) on one stack and TASK (2) on
+    // the other OR to 3, which is also what "both" is spelt as
+    if (c->L.cfg.te_inputs % 3 != 0 || c->L.cfg.md_inputs % 3 != 0) return false;
     if (!c->L.net[PVAE_NET_MH].layers.empty()) return false;                     // the helper reads the staged decoder panel
     if (fused && !(c->defer_adam && c->grads)) return false;          // (the same-layer schedule of plan_backward_net)
     if (Da > ProCols::kMaxN || Z > ProCols::kMaxN || Db < 64 || 2 * Db >= 65536) return false;
@@ -2642,7 +2646,7 @@ int pvae_net_forward(pvae_ctx* c, int net, const float* in, int32_t rows, float*
     int grid = (rows_pad * ld + 255) / 256;
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(pad_copy_kernel, dim3(grid), dim3(256), 0, st, in, N.n_in, rows, c->ws + c->W.net[net].in, ld,
-                       rows_pad);
+                       rows_pad, N.layers[0].col0, N.layers[0].n_in);
     HIP_TRY(hipGetLastError());
     c->staged_rows = 0;     // the training panels are no longer a coherent batch
     c->staged_rows_f = rows;

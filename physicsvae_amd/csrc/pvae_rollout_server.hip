@@ -796,8 +796,17 @@ int pvae_rollout_server_infer_rows(pvae_ctx* c, const float* obs, int32_t rows, 
     if (rows > S.max_rows) {
         // the first request with more than one row: the single-row instance makes way for the multi-row one (once; a few
         // hundred microseconds).  If the wider input buffer no longer fits the LDS plan, the single-row instance stays.
-        int rc = pvae_rollout_server_stop(c);
-        if (rc) return rc;
+        // Planned BEFORE the resident instance is stopped, so a refusal (-24) leaves it serving single rows.
+        const SrvArgs keep_args = S.args;
+        const size_t keep_lds = S.lds_bytes;
+        S.max_rows = kSrvMaxRows;
+        int rc = server_plan(c, S, S.scope);
+        if (rc) {
+            S.max_rows = 1; S.args = keep_args; S.lds_bytes = keep_lds;
+            return rc;
+        }
+        S.max_rows = 1; S.args = keep_args; S.lds_bytes = keep_lds;      // (stop() talks to the instance that is resident)
+        if ((rc = pvae_rollout_server_stop(c))) return rc;
         S.max_rows = kSrvMaxRows;
         if ((rc = pvae_rollout_server_start(c, 0, 0, -1))) {
             S.max_rows = 1;

@@ -450,7 +450,18 @@ class PhysicsVAE(nn.Module):
         st = self._st
         if (self.__dict__.get("_srv_on") and rows <= 4 and obs.device.type == "cpu" and (eps is None or not noise)
                 and self._latent_prior_type != "hypersphere_uniform"):
-            return self._forward_served(obs, state, noise) if rows == 1 else self._forward_served_rows(obs, state, noise)
+            if rows == 1:
+                return self._forward_served(obs, state, noise)
+            if not self.__dict__.get("_srv_rows_off"):
+                try:
+                    return self._forward_served_rows(obs, state, noise)
+                except RuntimeError as e:
+                    # the multi-row instance was refused (its four input vectors do not fit the LDS plan: -24): the single-row
+                    # instance stays resident (include/pvae.h) and 2-4-row observations take the launch path from now on
+                    if "rollout server" not in str(e):
+                        raise
+                    self.__dict__["_srv_rows_off"] = True
+                    st._rng_calls -= 1                 # (the launch path below draws at the offset the request would have)
         obs = obs.to(eng.device)
         st._rng_calls += 1
         # (eager on purpose: with the input assembly, the sampler and the output copies inside the layer
