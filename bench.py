@@ -560,7 +560,10 @@ def main():
         transport = "torch.distributed (%s) bucketed async all-reduce + per-bucket Adam" % dist.get_backend()
     out = {
         "metric": METRIC,
-        "value": value, "unit": "samples/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+        "value": value, "unit": "samples/s", "n_gpus": a.gpus,
+        # steps = what `ms_per_step` / `value` were timed over: ONE region of that many optimizer steps (the median of
+        # `timing.regions` such regions); --steps below MIN_TIMED_STEPS is raised to it (`steps_requested` echoes the flag)
+        "steps": timed_steps, "steps_requested": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s, batch %d/GPU, TE/MD/WM 4x1024, %s phase" % (workload, a.batch, a.phase),

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PVAE_ABI_VERSION 11
+#define PVAE_ABI_VERSION 12
 
 typedef struct pvae_ctx pvae_ctx;
 
@@ -273,6 +273,13 @@ int pvae_backward_stage(pvae_ctx* ctx, int phase, int32_t rows, const pvae_step_
                         int* ready_net, int* num_stages);
 int pvae_adam_segment(pvae_ctx* ctx, int net, int64_t offset, int64_t count, const pvae_step_params* sp,
                       void* stream);
+/* The backward pass of a (phase, sp) step as pvae_backward_stage would walk it, WITHOUT launching anything: stage k
+ * finishes the slice [offset[k], +count[k]) of net[k] (count 0: none).  At most `max` entries are written; *num_stages
+ * is the total.  Does not depend on the rows of the minibatch nor on what is staged -- so a rank whose shard of a ragged
+ * last global minibatch is EMPTY (no launch at all on it) can issue the very sequence of collectives its peers issue
+ * behind their stages (tm:142-143 on N GPUs; physicsvae_amd/torch_models.py dp_step). */
+int pvae_backward_plan(pvae_ctx* ctx, int phase, const pvae_step_params* sp, int64_t* offset, int64_t* count, int* net,
+                       int max, int* num_stages);
 
 /* Data-parallel exchange issued by the library itself (RCCL over xGMI; one process per GPU).
  * Replaces what DistributedDataParallel would add around tm:142-143; the reference has no

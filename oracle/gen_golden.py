@@ -42,7 +42,7 @@ def resolve_grid(cfg):
 
 
 def make_reference_trainer(pkl, arch, batch, m_world, num_data=None, lookahead=1, loss="MSE", prior=None,
-                           weight_decay=None):
+                           weight_decay=None, shuffle=None):
     argv = ["--data_train", pkl, "--batch_size", str(batch), "--max_iter", "1000",
             "--max_iter_world_model", str(m_world), "--latent_dim", str(arch["Z"])]
     T.args = T.arg_parser().parse_args(argv)
@@ -61,6 +61,8 @@ def make_reference_trainer(pkl, arch, batch, m_world, num_data=None, lookahead=1
     cfg["act_fn"] = arch.get("act", "relu")   # tpv:262 -> gen_layers(act_hidden=...) for every stack
     if weight_decay is not None:
         cfg["weight_decay"] = weight_decay    # tpv:253 -> torch.optim.Adam(weight_decay=...) (tm:119-122)
+    if shuffle is not None:
+        cfg["shuffle_data"] = shuffle         # tm:181 reads this key (tpv:260 sets "suffle_data": users fix the typo)
     orig = T.gen_layers
 
     def gen_layers(width, depth, **kw):
@@ -431,6 +433,49 @@ def case_training(name, arch, n_ep, n_steps, batch, m_world, n_epochs, full, lr_
         fix["weight_decay"] = np.array(float(weight_decay))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
     print("wrote", name, "losses", losses, "lrs", lrs)
+
+
+def case_shuffle(name, arch, n_ep, n_steps, batch, m_world, n_epochs, seed=1234):
+    """`shuffle_data: True` (tm:166-175, 181): the reference's own DataLoader shuffles every pass with a RandomSampler
+    seeded from torch's default generator.  Captured under torch.manual_seed(seed) set right before the first epoch:
+    every epoch's sample order (the indices its dataset is asked for), the epoch losses across the phase switch and the
+    final weights.  eps is the usual patched stream, which does not touch the default generator, so the loader's two
+    draws per pass are the only ones."""
+    data = R.synth_demo(seed=0, n_episodes=n_ep, n_steps=n_steps, dim_body=arch["Db"],
+                        dim_action=arch["Da"], kind="dynamics")
+    fix = {}
+    with tempfile.TemporaryDirectory() as td:
+        pkl = os.path.join(td, "demo.pkl")
+        R.write_demo(pkl, data)
+        tr = make_reference_trainer(pkl, arch, batch, m_world=m_world, shuffle=True)
+        assert type(tr.train_loader.sampler).__name__ == "RandomSampler"
+        tr.lr_scheduler = torch.optim.lr_scheduler.StepLR(tr.optimizer, step_size=2, gamma=0.7)
+        tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3))
+        eps_fn = R.eps_stream(2, arch["Z"])
+        ds_cls = type(tr.train_loader.dataset)
+        orig_get, asked = ds_cls.__getitem__, []
+
+        def getitem(self, i):
+            asked.append(int(i))
+            return orig_get(self, i)
+        ds_cls.__getitem__ = getitem
+        losses = []
+        try:
+            torch.manual_seed(seed)
+            with EpsPatch(lambda c, shape: eps_fn(c, shape)):
+                for e in range(n_epochs):
+                    del asked[:]
+                    losses.append(tr.train()["mean_train_loss"])
+                    fix["order_epoch%d" % e] = np.array(asked, dtype=np.int64)
+        finally:
+            ds_cls.__getitem__ = orig_get
+        for k, v in tr.model.state_dict().items():
+            fix["final::" + k] = v.detach().numpy().copy()
+    fix["epoch_losses"] = np.array(losses, dtype=np.float64)
+    fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *wd(arch["te"]), *wd(arch["md"]), *wd(arch["wm"]),
+                            n_ep, n_steps, batch, m_world, n_epochs, seed])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
+    print("wrote", name, "losses", losses, "first order", fix["order_epoch0"][:8])
 
 
 def case_anchor(name):
@@ -865,12 +910,14 @@ def main():
         "look2_c1": lambda: case_lookahead("look2_c1", c1, 2, 200, 64, lookahead=2, full=False),
         "l1_tiny": lambda: case_lookahead("l1_tiny", tiny, 2, 15, 8, lookahead=1, full=True, loss="L1"),
         "l1_look2_c1": lambda: case_lookahead("l1_look2_c1", c1, 2, 200, 64, lookahead=2, full=False, loss="L1"),
+        "shuffle_tiny": lambda: case_shuffle("shuffle_tiny", tiny, 3, 21, 8, m_world=2, n_epochs=5),
         "train_tiny_look2": lambda: case_training("train_tiny_look2", tiny, 3, 22, 8, m_world=2, n_epochs=5,
                                                   full=True, lookahead=2),
     }
     for k, fn in jobs.items():
         if a.only is None or a.only == k:
-            fn()
+            torch.manual_seed(0)              # every fixture from the same generator state, whatever ran before it:
+            fn()                              # `--only NAME` and a full run write the same bytes (oracle/verify_golden.py)
 
 
 if __name__ == "__main__":

@@ -335,10 +335,11 @@ class WindowDataset(torch.utils.data.Dataset):
         return torch.Tensor(self.X[i]), torch.Tensor(self.Y[i])
 
 
-def make_loader(X, Y, batch_size):
+def make_loader(X, Y, batch_size, shuffle=None):
     """tm:166-193: shuffle is None in practice (the "suffle_data" typo, tpv:260 vs tm:181)
-    -> SequentialSampler, drop_last False."""
-    return torch.utils.data.DataLoader(WindowDataset(X, Y), batch_size=batch_size, shuffle=None)
+    -> SequentialSampler, drop_last False.  With `shuffle_data` spelt right (tm:181) it is torch's own shuffled
+    loader: a RandomSampler seeded from the default generator on every pass."""
+    return torch.utils.data.DataLoader(WindowDataset(X, Y), batch_size=batch_size, shuffle=shuffle)
 
 
 # --------------------------------------------------------------------------------------
@@ -618,12 +619,12 @@ class RefTrainer:
     flip when `iter == max_iter_world_model` is seen *before* the increment."""
 
     def __init__(self, arch, sd, X, Y, batch_size, max_iter_world_model, lr=5e-4,
-                 lr_step=50, lr_gamma=0.7, coeff_cfg=None, eps_fn=None, loss="MSE", weight_decay=0.0):
+                 lr_step=50, lr_gamma=0.7, coeff_cfg=None, eps_fn=None, loss="MSE", weight_decay=0.0, shuffle=None):
         self.arch = arch
         self.loss = loss
         self.model = RefModel(arch)
         self.model.load_state_dict(sd)
-        self.loader = make_loader(X, Y, batch_size)
+        self.loader = make_loader(X, Y, batch_size, shuffle)
         self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)   # tm:119-122
         self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=lr_step, gamma=lr_gamma)
         self.max_iter_world_model = max_iter_world_model

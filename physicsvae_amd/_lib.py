@@ -36,7 +36,7 @@ MAX_HIDDEN = 15
 PRIOR_KINDS = {"normal_zero_mean_one_std": 0, "normal_state_mean_one_std": 1, "hypersphere_uniform": 2, False: 3}
 PHASE_WORLD, PHASE_JOINT = 0, 1
 FLAG_FUSED_ADAM, FLAG_NO_BACKWARD = 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 LOSS_MSE, LOSS_L1 = 0, 1
 EXCHANGE_ALLREDUCE, EXCHANGE_SHARDED, EXCHANGE_P2P, EXCHANGE_LOCAL, EXCHANGE_P2P_PUSH = 0, 1, 2, 3, 4
 P2P_BLOB_BYTES, P2P_MAX_RANKS = 512, 8
@@ -100,6 +100,8 @@ _SIGS = {
                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int),
                                       C.POINTER(C.c_int)]),
     "pvae_adam_segment": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.POINTER(StepParams), _P]),
+    "pvae_backward_plan": (C.c_int, [_P, C.c_int, C.POINTER(StepParams), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "pvae_comm_unique_id": (C.c_int, [_P]),
     "pvae_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "pvae_comm_destroy": (C.c_int, [_P]),

@@ -2163,6 +2163,25 @@ int pvae_backward_stage(pvae_ctx* c, int phase, int32_t rows, const pvae_step_pa
     return plan[stage].run();
 }
 
+int pvae_backward_plan(pvae_ctx* c, int phase, const pvae_step_params* sp, int64_t* offset, int64_t* count, int* net,
+                       int max, int* num_stages) {
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!sp) return fail(-1, "null step params");
+    if (phase != PVAE_PHASE_WORLD && phase != PVAE_PHASE_JOINT) return fail(-1, "unknown phase %d", phase);
+    StepShape S;
+    if ((rc = step_shape(c, phase, 1, sp, nullptr, true, S))) return rc;
+    Plan plan;                                  // (stages are closures: building them launches nothing and changes no state)
+    plan_backward(c, phase, 1, sp, true, false, S, (hipStream_t) nullptr, plan);
+    if (num_stages) *num_stages = (int)plan.size();
+    for (int k = 0; k < (int)plan.size() && k < max; ++k) {
+        if (offset) offset[k] = plan[k].ready_off;
+        if (count) count[k] = plan[k].ready_cnt;
+        if (net) net[k] = plan[k].net;
+    }
+    return 0;
+}
+
 int pvae_adam_segment(pvae_ctx* c, int net, int64_t offset, int64_t count, const pvae_step_params* sp,
                       void* stream) {
     int rc = check_ready(c, true);

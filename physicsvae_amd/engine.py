@@ -259,9 +259,10 @@ class HipEngine:
         return arena[lo:hi]
 
     # -- data ---------------------------------------------------------------------------
-    def bind_dataset(self, states, actions, window_row, next_states=None):
+    def bind_dataset(self, states, actions, window_row, next_states=None, check=True):
         """`next_states` (optional, row-aligned with `states`): what the second half of x / the target s2
-        is read from instead of the next state row (cond "rel", tpv:149-150)."""
+        is read from instead of the next state row (cond "rel", tpv:149-150).  `check=False`: `window_row` is a
+        permutation of a table that was checked when it was bound (a shuffled epoch): no read-back, no host sync."""
         self._need_gpu()
         if self.dataset is not None and self.dataset[0] is states and self.dataset[1] is actions \
                 and self.dataset[2] is window_row and self.dataset[3] is next_states:
@@ -270,7 +271,8 @@ class HipEngine:
         actions = actions.to(self.device, torch.float32).contiguous()
         window_row = window_row.to(self.device, torch.int32).contiguous()
         assert states.shape[1] == self.arch.Db and actions.shape[1] == self.arch.Da
-        assert int(window_row.max()) + self.lookahead < states.shape[0] + (1 if next_states is not None else 0)
+        if check:
+            assert int(window_row.max()) + self.lookahead < states.shape[0] + (1 if next_states is not None else 0)
         if next_states is not None:
             next_states = next_states.to(self.device, torch.float32).contiguous()
             assert next_states.shape == states.shape
@@ -358,6 +360,17 @@ class HipEngine:
             C.byref(off), C.byref(cnt), C.byref(net), C.byref(n)), "pvae_backward_stage")
         seg = (off.value, cnt.value) if cnt.value else None
         return seg, net.value, n.value
+
+    def backward_plan(self, phase, sp):
+        """[(net, offset, count)] per stage of the backward pass, in stage order (count 0: the stage finishes no slice);
+        nothing is launched.  Independent of the minibatch's rows (`pvae_backward_plan`)."""
+        self._need_gpu()
+        n = C.c_int()
+        cap = 128
+        off, cnt, net = (C.c_int64 * cap)(), (C.c_int64 * cap)(), (C.c_int * cap)()
+        _lib.check(self.lib.pvae_backward_plan(self.ctx, phase, C.byref(sp), off, cnt, net, cap, C.byref(n)), "pvae_backward_plan")
+        assert n.value <= cap
+        return [(net[k], off[k], cnt[k]) for k in range(n.value)]
 
     def adam_segment(self, net, off, cnt, sp):
         self._need_gpu()

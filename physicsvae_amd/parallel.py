@@ -148,6 +148,18 @@ class DataParallel:
             dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
         return tensor
 
+    def broadcast(self, tensor, device=None):
+        """Rank 0's `tensor` on every rank (a shuffled epoch's sample order: every rank slices the SAME permutation).  A
+        host tensor travels as it is over gloo and through `device` over RCCL, which moves device memory only."""
+        if self.world <= 1 or not (dist.is_available() and dist.is_initialized()):
+            return tensor
+        if dist.get_backend(self.group) == "nccl" and not tensor.is_cuda:
+            t = tensor.to(device)
+            dist.broadcast(t, src=0, group=self.group)
+            return t.cpu()
+        dist.broadcast(tensor, src=0, group=self.group)
+        return tensor
+
 
 EXCHANGE_FORMS = ("inline", "bucketed", "sharded", "p2p", "p2p_push")
 

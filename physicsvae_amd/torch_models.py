@@ -97,19 +97,41 @@ class DatasetBase(torch.utils.data.Dataset):
 
 
 class WindowLoader:
-    """Sequential, non-shuffled, keep-last-partial minibatch schedule over a window dataset
-    -- what `DataLoader(dataset, batch_size, shuffle=None)` yields in the reference (tm:166-175;
-    the "suffle_data" typo of tpv:260 means shuffle is always None).  `len()` = number of
-    minibatches; iterating yields the same (x, y) float32 tensors as the reference's loader
-    (host side, for inspection); `spans()` yields (first_window, rows) for the HIP path."""
+    """Keep-last-partial minibatch schedule over a window dataset -- what `DataLoader(dataset, batch_size,
+    shuffle=shuffle)` yields in the reference (tm:166-175).  Upstream's config never shuffles (the "suffle_data" typo of
+    tpv:260 leaves `shuffle_data` None at tm:181), but the loader honours the key, and so does this one:
+
+    * `shuffle` false: windows in order (SequentialSampler).
+    * `shuffle` true: every pass over the loader draws a fresh permutation exactly as torch's loader does --
+      `DataLoader.__iter__` takes ONE int64 from the default generator (`_base_seed`), `RandomSampler.__iter__`
+      (generator=None) takes ONE more, seeds a private `torch.Generator` with it and yields
+      `torch.randperm(n, generator=g)` -- so under the same `torch.manual_seed` the sample order equals the reference's
+      (pinned by tests/golden/shuffle_tiny.npz).  The HIP path consumes the permutation as a permuted window -> row
+      TABLE bound for the epoch (`epoch_table`): minibatches stay runs of consecutive table entries, so the gather, its
+      prefetch and the data-parallel sharding (ranks slice the permuted order) are the sequential path's.
+
+    `len()` = number of minibatches; iterating yields the same (x, y) float32 tensors as the reference's loader (host
+    side, for inspection); `spans()` yields (first, rows) positions in the epoch's order for the HIP path."""
 
     def __init__(self, dataset, batch_size, shuffle=None):
-        if shuffle:
-            raise NotImplementedError("shuffled sampling: the reference never shuffles (tpv:260 vs tm:181)")
-        self.dataset, self.batch_size = dataset, int(batch_size)
+        self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), bool(shuffle)
+        self.order = None               # the current pass's permutation (host int64), None when sequential
 
     def __len__(self):
         return math.ceil(len(self.dataset) / self.batch_size)
+
+    def new_epoch(self):
+        """Start a pass: draws the permutation of a shuffled loader (see the class comment for the draws) and returns it
+        (None: sequential)."""
+        if not self.shuffle:
+            self.order = None
+            return None
+        torch.empty((), dtype=torch.int64).random_()                       # DataLoader iterator's _base_seed
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())    # RandomSampler's private generator
+        g = torch.Generator()
+        g.manual_seed(seed)
+        self.order = torch.randperm(len(self.dataset), generator=g)
+        return self.order
 
     def spans(self):
         n = len(self.dataset)
@@ -117,8 +139,10 @@ class WindowLoader:
             yield first, min(self.batch_size, n - first)
 
     def __iter__(self):
+        order = self.new_epoch()
         for first, rows in self.spans():
-            xs, ys = zip(*(self.dataset[i] for i in range(first, first + rows)))
+            idx = range(first, first + rows) if order is None else order[first: first + rows].tolist()
+            xs, ys = zip(*(self.dataset[i] for i in idx))
             yield torch.stack(xs), torch.stack(ys)
 
 
@@ -157,6 +181,25 @@ class HipAdam(optim.Optimizer):
         """{key: (exp_avg view, exp_avg_sq view)} in checkpoint key naming."""
         m, v = self.engine.named_views(self.engine.exp_avg), self.engine.named_views(self.engine.exp_avg_sq)
         return {k: (m[k], v[k]) for k in m}
+
+
+def dp_buckets(plan, limit=None):
+    """Gradient buckets of a data-parallel step on the torch.distributed transport.  `plan`: [(net, offset, count)] per
+    backward stage (HipEngine.backward_plan).  A bucket grows while the next finished slice belongs to the same stack and
+    lies directly below it in the arena (layers finish last to first), and closes at a stack boundary or once it holds
+    `limit` floats.  Returns [(net, lo, hi, last_stage)]: the bucket is final after stage `last_stage`."""
+    out, cur = [], None
+    for k, (net, off, cnt) in enumerate(plan):
+        if not cnt:
+            continue
+        if cur is not None and (cur[0] != net or off + cnt != cur[1]):
+            out.append(tuple(cur)); cur = None
+        cur = [net, off, cur[2] if cur is not None else off + cnt, k]
+        if limit is not None and cur[2] - cur[1] >= limit:
+            out.append(tuple(cur)); cur = None
+    if cur is not None:
+        out.append(tuple(cur))
+    return out
 
 
 class TrainModel(tune.Trainable):
@@ -266,7 +309,15 @@ class TrainModel(tune.Trainable):
         figure is the plain mean of minibatch means, tm:145)."""
         eng, dp = self.engine, self.dp
         phase, nets = self.phase()
-        eng.bind_dataset(*loader.dataset.device_arrays(eng.device))
+        arrays = loader.dataset.device_arrays(eng.device)
+        order = loader.new_epoch() if hasattr(loader, "new_epoch") else None
+        if order is None:
+            eng.bind_dataset(*arrays)
+        else:
+            # a shuffled pass (tm:166-175 with shuffle_data): the window -> row table in this pass's order, bound for the
+            # pass; positions [first, first + rows) of it are the minibatches.  Every rank slices rank 0's permutation.
+            order = dp.broadcast(order, eng.device)
+            eng.bind_dataset(arrays[0], arrays[1], arrays[2][order.to(eng.device)], *arrays[3:], check=False)
         n_glob = dp.global_steps(len(loader.dataset), loader.batch_size)
         if train and dp.collective and self.dp_exchange == "auto" and phase not in self.dp_exchange_reports:
             # (per phase: the world phase trains one stack and has nothing to overlap an exchange with, the joint phase
@@ -385,37 +436,30 @@ class TrainModel(tune.Trainable):
             eng.dp_train_step(phase, first, rows, sp, eps=eps, loss_out=loss_out,
                               next_span=next_span if self.prefetch_gather else None)
             return
-        if not rows:                              # empty shard of a ragged last global batch
-            seg = eng.segment(eng.grads, nets)
-            seg.zero_()
-            dp.all_reduce(seg)
-            for net in nets:
-                self._apply_update(net, eng.segments[net][0], eng.segments[net][1], sp)
-            return
+        # Buckets = runs of slices the backward pass finishes, merged while they stay inside one stack and adjacent in the
+        # arena, closed at `dp_bucket_mb`: computed from the PLAN (pvae_backward_plan: no launch, independent of the
+        # minibatch's rows), so that every rank -- also one whose shard of a ragged last global batch is empty and launches
+        # nothing -- issues the same collectives, of the same sizes, in the same order.
         limit = int(self.dp_bucket_mb * (1 << 20) / 4) if self.dp_bucket_mb > 0 else None
+        buckets = dp_buckets(eng.backward_plan(phase, sp), limit)      # [(net, lo, hi, last_stage)]
+        if not rows:                              # empty shard: zero gradient through the same collectives, then Adam
+            for net, lo, hi, _ in buckets:        # (all reductions first, then the updates: the order its peers use)
+                eng.grads[lo:hi].zero_()
+                dp.all_reduce(eng.grads[lo:hi])
+            for net, lo, hi, _ in buckets:
+                self._apply_update(net, lo, hi - lo, sp)
+            return
         eng.gather(first, rows)
         eng.forward_seed(phase, rows, sp, eps=eps)
-        pending, k, n = [], 0, 1
-        cur = None                                # open bucket: [net, lo, hi)
-
-        def close():
-            nonlocal cur
-            if cur is not None:
-                net, lo, hi = cur
-                pending.append((net, lo, hi - lo, dp.all_reduce_async(eng.grads[lo:hi])))
-                cur = None
-
+        pending, k, n, b = [], 0, 1, 0
         while k < n:
-            seg, net, n = eng.backward_stage(phase, rows, sp, k, loss_out=loss_out)
-            if seg is not None:
-                off, cnt = seg
-                if cur is not None and (cur[0] != net or off + cnt != cur[1]):
-                    close()                       # other net, or not adjacent below the open bucket
-                cur = [net, off, cur[2] if cur is not None else off + cnt]
-                if limit is not None and cur[2] - cur[1] >= limit:
-                    close()
+            _, _, n = eng.backward_stage(phase, rows, sp, k, loss_out=loss_out)
+            while b < len(buckets) and buckets[b][3] == k:          # every slice of the bucket is final: reduce it
+                net, lo, hi, _ = buckets[b]
+                pending.append((net, lo, hi - lo, dp.all_reduce_async(eng.grads[lo:hi])))
+                b += 1
             k += 1
-        close()
+        assert b == len(buckets), "backward plan and backward stages disagree"
         for net, off, cnt, work in pending:
             if work is not None:
                 work.wait()

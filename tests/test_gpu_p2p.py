@@ -27,9 +27,13 @@ arch = R.make_arch(23, 7, latent=8, te=(64, 2), md=(96, 2), wm=(128, 3))
 data = R.synth_demo(0, 3, 40, 23, 7, kind="dynamics")          # 117 windows
 per_gpu = int(sys.argv[3])
 look = int(os.environ.get("P2P_TEST_LOOKAHEAD", "1"))
+extra = {"lookahead": look} if look > 1 else {}
+if os.environ.get("P2P_TEST_SHUFFLE") == "1":
+    extra["shuffle_data"] = True
+    torch.manual_seed(100 + rank)              # every rank would draw ANOTHER order: rank 0's is what all must use
 with contextlib.redirect_stdout(io.StringIO()):
     tr = make_trainer(arch, data, per_gpu, m_world=1, device="cuda:0", eps_fn=R.eps_stream(2, 8),
-                      extra={"lookahead": look} if look > 1 else None)
+                      extra=extra or None)
 tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, 1), 3))
 eng = tr.engine
 if "P2P_TEST_DELAY_US" in os.environ:          # a spin kernel in front of every exchange launch, a different one per rank
@@ -167,6 +171,35 @@ def test_p2p_two_ranks_equal_the_allreduce_exchange_bit_for_bit(tmp_path, form):
         assert torch.equal(a["sd"][k], b["sd"][k]), k
         assert torch.equal(a["sd"][k], plain[0]["sd"][k]), k
     assert a["losses"] == plain[0]["losses"] and a["steps"] == plain[0]["steps"]
+
+
+def test_torch_transport_with_an_empty_shard_issues_its_peers_collectives(tmp_path):
+    """117 windows, 24 per rank, two ranks: the last global minibatch leaves rank 1 with NO rows, in the world phase and
+    in the joint phase (two stacks = two buckets; with PVAE_DP_BUCKET_MB one per layer).  On the torch.distributed
+    transport the empty rank launches nothing, so it takes the sequence of collectives from the backward PLAN
+    (pvae_backward_plan, torch_models.dp_buckets) -- same sizes, same order as its peer issues behind its stages, or gloo
+    would pair a bucket with a whole segment.  Replicas bit-identical, equal to the peer-mapped exchange (two ranks: every
+    sum is g0 + g1), whatever the bucket size."""
+    p2p = _run(tmp_path, 2, 24, "p2p24", port="29591", PVAE_DP_EXCHANGE="p2p")
+    plain = _run(tmp_path, 2, 24, "plain24", port="29592", PVAE_DP_EXCHANGE="default")
+    small = _run(tmp_path, 2, 24, "small24", port="29593", PVAE_DP_EXCHANGE="default", PVAE_DP_BUCKET_MB="0.01")
+    for k in p2p[0]["sd"]:
+        assert torch.equal(plain[0]["sd"][k], plain[1]["sd"][k]), k
+        assert torch.equal(plain[0]["sd"][k], p2p[0]["sd"][k]), k
+        assert torch.equal(plain[0]["sd"][k], small[0]["sd"][k]) and torch.equal(small[0]["sd"][k], small[1]["sd"][k]), k
+    assert plain[0]["losses"] == p2p[0]["losses"] == small[0]["losses"] and plain[0]["steps"] == p2p[0]["steps"]
+
+
+def test_shuffled_epochs_data_parallel_use_rank_zeros_order(tmp_path):
+    """shuffle_data with two ranks whose default generators are seeded differently: every pass uses rank 0's permutation
+    (broadcast), each rank taking its slice of it -- replicas bit-identical, every window seen once per epoch (the losses
+    equal those of the same run on the torch.distributed transport), and not the sequential run's."""
+    a = _run(tmp_path, 2, 16, "shuf", port="29594", PVAE_DP_EXCHANGE="p2p", P2P_TEST_SHUFFLE="1")
+    b = _run(tmp_path, 2, 16, "shufplain", port="29595", PVAE_DP_EXCHANGE="default", P2P_TEST_SHUFFLE="1")
+    seq = _run(tmp_path, 2, 16, "seq", port="29596", PVAE_DP_EXCHANGE="p2p")
+    for k in a[0]["sd"]:
+        assert torch.equal(a[0]["sd"][k], a[1]["sd"][k]) and torch.equal(a[0]["sd"][k], b[0]["sd"][k]), k
+    assert a[0]["losses"] == b[0]["losses"] and a[0]["losses"] != seq[0]["losses"]
 
 
 def test_p2p_bucketed_overlapped_equals_in_line(tmp_path):

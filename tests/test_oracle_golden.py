@@ -373,6 +373,25 @@ def test_training_run_matches_reference(golden, name):
                                        rtol=1e-3, atol=1e-12)
 
 
+def test_shuffled_training_run_matches_reference(golden):
+    """The reference's trainer with `shuffle_data: True` (tm:166-175, 181) under torch.manual_seed: the restatement, whose
+    loader is torch's own shuffled DataLoader, reproduces its epoch losses across the phase switch and its final weights."""
+    g = golden("shuffle_tiny")
+    arch = arch_from_meta(g)
+    n_ep, n_steps, batch, m_world, n_epochs, seed = [int(v) for v in g["meta"][9:15]]
+    data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
+    X, Y = R.build_windows(data)
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    tr = R.RefTrainer(arch, sd, X, Y, batch, m_world, lr_step=2, eps_fn=R.eps_stream(2, arch["Z"]), shuffle=True)
+    torch.manual_seed(seed)
+    losses = [tr.step()["mean_train_loss"] for _ in range(n_epochs)]
+    np.testing.assert_allclose(losses, g["epoch_losses"], rtol=1e-5)
+    for k, v in tr.model.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), g["final::" + k], rtol=2e-3, atol=2e-5)
+    # not the sequential run: the order matters to every loss after the first step
+    assert abs(losses[-1] - float(golden("train_tiny")["epoch_losses"][-1])) > 1e-4
+
+
 def test_world_model_frozen_after_switch(golden):
     g = golden("train_tiny")
     m_world = int(g["meta"][12])
@@ -488,3 +507,22 @@ def test_helper_training_restatement_matches_reference(golden):
     assert steps["_world_model._model.0._model.0.weight"] == nb * m_world
     assert steps["_motor_decoder_helper._model.0._model.0.weight"] == nb * (n_epochs - m_world)
     assert steps["_motor_decoder._model.0._model.0.weight"] == nb * (n_epochs - m_world)
+
+
+def test_fixtures_regenerate_byte_for_byte():
+    """The pin checks itself: the committed generator, run against the reference, writes the committed fixtures byte for
+    byte (oracle/verify_golden.py).  Dev container only -- the GPU box has no reference, the test skips there.  The
+    `*tiny*` fixtures (21 of 36, 20 s) always; all of them (5 min on 4 cores, profiles/r06_verify_golden.txt) with
+    PVAE_VERIFY_GOLDEN_ALL=1."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import verify_golden as V
+    if not os.path.isdir(V.REF):
+        pytest.skip("no reference at %s" % V.REF)
+    names = V.fixture_names()
+    if os.environ.get("PVAE_VERIFY_GOLDEN_ALL") != "1":
+        names = [n for n in names if "tiny" in n]
+    assert len(names) >= 20
+    bad = V.verify(names)
+    assert not bad, bad
