@@ -136,7 +136,17 @@ class DataParallel:
                 torch.cuda.synchronize(engine.device)
                 dist.barrier(group=self.group)                     # nobody can reach this rank's arenas any more
                 engine.params[:256].copy_(head[0]); engine.grads[:256].copy_(head[1])
+                # ... and not trusted on its own word: the tested words of the parameter arena travel once more from rank 0
+                # (the replicas were identical when the test began), then every rank's WHOLE arena is compared -- a form
+                # that failed its self-test must not leave replicas that differ anywhere behind.
+                if self.world > 1:
+                    t = engine.params[:256].clone()
+                    dist.broadcast(t, src=0, group=self.group)
+                    engine.params[:256].copy_(t)
                 engine.params_changed()
+                if self.world > 1 and not _replicas_identical(self, engine):
+                    raise RuntimeError("peer-mapped exchange: the self-test failed AND the replicas' parameters differ after "
+                                       "its test words were restored -- refusing to train on")
             if self.rank == 0 or err:
                 print("[physicsvae_amd] peer-mapped exchange unavailable (%s)" % (err or "another rank failed"), file=sys.stderr)
             return False

@@ -24,28 +24,38 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dp_full_size_worker.py")
 
 
-def _run(tmp_path, config, form, world=8):
+FORMS = ("default", "p2p", "p2p_push")
+_cache = {}
+
+
+def _run(tmp_path_factory, config, world=8):
+    """ONE set of eight processes per configuration runs the three exchange forms one after the other (one rendezvous, one
+    demonstration set, one single-process reference per phase): -> {form: [result of rank 0 .. 7]}."""
+    if config in _cache:
+        return _cache[config]
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    out = str(tmp_path / ("%s_%s" % (config, form)))
+    out = str(tmp_path_factory.mktemp("dp_full") / config)
     ndev = max(torch.cuda.device_count(), 1)
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "PVAE_DP_EXCHANGE")}
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0",
-               PVAE_DP_EXCHANGE=form)
+               PVAE_DP_FORMS=",".join(FORMS))
     procs = [subprocess.Popen([sys.executable, WORKER, ROOT, out, config],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r % ndev), PVAE_LOCAL_DEVICE=str(r % ndev)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
-    return [torch.load(out + ".%d" % r) for r in range(world)]
+    per_rank = [torch.load(out + ".%d" % r) for r in range(world)]
+    _cache[config] = {f: [pr[f] for pr in per_rank] for f in FORMS}
+    return _cache[config]
 
 
 @pytest.mark.parametrize("form", ["p2p", "p2p_push", "default"])
 @pytest.mark.parametrize("config", ["c3", "c5"])
-def test_eight_ranks_at_baseline_sizes_match_one_process_with_the_global_batch(tmp_path, config, form):
-    res = _run(tmp_path, config, form)
+def test_eight_ranks_at_baseline_sizes_match_one_process_with_the_global_batch(tmp_path_factory, config, form):
+    res = _run(tmp_path_factory, config)[form]
     per_gpu = {"c3": 256, "c5": 512}[config]
     assert all(r["ranks"] == 8 and r["global_batch"] == 8 * per_gpu for r in res)
     if form != "default":
@@ -67,12 +77,12 @@ def test_eight_ranks_at_baseline_sizes_match_one_process_with_the_global_batch(t
         assert e["update_rel_l2_diff"] < 5e-3 and e["update_flip_fraction"] < 1e-5, e
 
 
-@pytest.mark.parametrize("config", ["c3"])
-def test_the_two_peer_mapped_forms_agree_bit_for_bit_at_baseline_size(tmp_path, config):
+@pytest.mark.parametrize("config", ["c3", "c5"])
+def test_the_two_peer_mapped_forms_agree_bit_for_bit_at_baseline_size(tmp_path_factory, config):
     """pull and push both sum the eight shard gradients in rank order: same parameters bit for bit, in both phases (a
     race in either -- or in the kernels under eight processes' contention -- would break this; round 5 found one)."""
-    a = _run(tmp_path, config, "p2p")
-    b = _run(tmp_path, config, "p2p_push")
+    r = _run(tmp_path_factory, config)
+    a, b = r["p2p"], r["p2p_push"]
     for phase in ("world", "joint"):
         assert a[0][phase]["params_checksum"] == b[0][phase]["params_checksum"], phase
         assert a[0][phase]["losses_n_ranks"] == b[0][phase]["losses_n_ranks"], phase

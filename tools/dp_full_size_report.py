@@ -19,7 +19,7 @@ for i, form in enumerate(forms):
         port = s.getsockname()[1]
     out = os.path.join(tempfile.mkdtemp(), "r")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
-    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0", PVAE_DP_EXCHANGE=form)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0", PVAE_DP_FORMS=form)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_full_size_worker.py"), ROOT, out, config],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r % ndev), PVAE_LOCAL_DEVICE=str(r % ndev)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -27,6 +27,6 @@ for i, form in enumerate(forms):
     if any(p.returncode for p in procs):
         print(form, "FAILED", outs[0][-1500:])
         continue
-    res = torch.load(out + ".0")
+    res = torch.load(out + ".0")[form]
     for ph in ("world", "joint"):
         print(json.dumps({"config": config, "form": form, "run": i, "phase": ph, **res[ph]}), flush=True)
