@@ -779,7 +779,7 @@ def case_subsets(name, arch, batch=8):
     print("wrote", name)
 
 
-def case_helper_train(name, arch, n_ep=3, n_steps=21, batch=8, m_world=2, n_epochs=5):
+def case_helper_train(name, arch, n_ep=3, n_steps=21, batch=8, m_world=2, n_epochs=5, lookahead=1):
     """Supervised training of a model with `motor_decoder_helper_enable` (rmt:490-498, 670-680, 833-835): the helper's
     term sits inside a_hat, so the reference's own compute_loss / optimizer train the helper together with the decoder
     (nothing ever freezes it: tpv:326-329, 347-350 switch encoder, decoder and world model only).  Recorded: one
@@ -798,7 +798,7 @@ def case_helper_train(name, arch, n_ep=3, n_steps=21, batch=8, m_world=2, n_epoc
             trainer_config["model"]["custom_model_config"]["motor_decoder_helper_enable"] = True
         T.update_model_config = update_model_config
         try:
-            tr = make_reference_trainer(pkl, arch, batch, m_world=m_world)
+            tr = make_reference_trainer(pkl, arch, batch, m_world=m_world, lookahead=lookahead)
         finally:
             T.update_model_config = orig
         m = tr.model
@@ -810,6 +810,9 @@ def case_helper_train(name, arch, n_ep=3, n_steps=21, batch=8, m_world=2, n_epoc
         x, y = next(iter(tr.train_loader))
         eps = R.eps_stream(2, arch["Z"])(0, (x.shape[0], arch["Z"]))
         fix["eps"] = eps.numpy()
+        # (lookahead > 1: one draw per unrolled step, eps(t); the world phase then reaches the helper too -- the state the
+        #  world model is asked to continue from is its own prediction under the HELPED action, tpv:417-421)
+        eps_t = [R.eps_stream(2, arch["Z"])(t, (x.shape[0], arch["Z"])) for t in range(lookahead)]
         for world in (True, False):
             tag = "world" if world else "joint"
             m.set_learnable_task_encoder(not world)
@@ -818,7 +821,7 @@ def case_helper_train(name, arch, n_ep=3, n_steps=21, batch=8, m_world=2, n_epoc
             tr.read_loss_fn_coeff(world=world)
             m.train()
             tr.optimizer.zero_grad()
-            with EpsPatch(lambda c, shape: eps):
+            with EpsPatch((lambda c, shape: eps) if lookahead == 1 else (lambda c, shape: eps_t[c % lookahead])):
                 loss = tr.compute_loss(y, x)
             loss.backward()
             fix[tag + "_total"] = loss.detach().numpy()
@@ -829,7 +832,7 @@ def case_helper_train(name, arch, n_ep=3, n_steps=21, batch=8, m_world=2, n_epoc
         # the reference's own loop from the same weights, in a fresh trainer (phase switch after m_world epochs)
         T.update_model_config = update_model_config
         try:
-            tr = make_reference_trainer(pkl, arch, batch, m_world=m_world)
+            tr = make_reference_trainer(pkl, arch, batch, m_world=m_world, lookahead=lookahead)
         finally:
             T.update_model_config = orig
         tr.lr_scheduler = torch.optim.lr_scheduler.StepLR(tr.optimizer, step_size=2, gamma=0.7)
@@ -846,7 +849,7 @@ def case_helper_train(name, arch, n_ep=3, n_steps=21, batch=8, m_world=2, n_epoc
         fix["adam_keys"] = np.array(list(named.keys()))
         fix["adam_steps"] = np.array([float(tr.optimizer.state.get(p, {}).get("step", -1.0)) for p in named.values()])
     fix["meta"] = np.array([arch["Db"], arch["Da"], arch["Z"], *wd(arch["te"]), *wd(arch["md"]), *wd(arch["wm"]), n_ep, n_steps, batch,
-                            m_world, n_epochs])
+                            m_world, n_epochs] + ([lookahead] if lookahead > 1 else []))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fix)
     print("wrote", name, "world", fix["world_total"], "joint", fix["joint_total"], "epochs", losses)
 
@@ -897,6 +900,7 @@ def main():
         "helper_tiny": lambda: case_helper("helper_tiny", tiny),
         "subsets_tiny": lambda: case_subsets("subsets_tiny", tiny),
         "helper_train_tiny": lambda: case_helper_train("helper_train_tiny", tiny),
+        "helper_train_look2_tiny": lambda: case_helper_train("helper_train_look2_tiny", tiny, n_steps=22, lookahead=2),
         "helper_default": lambda: case_helper("helper_default", dflt),
         # the trainer's "act_fn" (hidden activation of every stack) and Adam's weight_decay: config keys a user edits
         "single_tiny_tanh": lambda: case_single("single_tiny_tanh", dict(tiny, act="tanh"), 2, 14, 8, full=True),

@@ -1794,6 +1794,16 @@ static int run_forward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_ste
         FwdTail md_tail;                       // a_hat -> action columns of the predicted-action WM input
         md_tail.out2 = w + wwm.in + bp * ld_wm; md_tail.ld2 = ld_wm; md_tail.off2 = Db; md_tail.n2 = Da;
         if ((rc = forward_net(c, PVAE_NET_MD, u.rows_pad, st, md_tail, bt))) return rc;
+        if (!c->L.net[PVAE_NET_MH].layers.empty()) {        // rmt:833-835 in every unrolled step: a_hat_t += range * helper(x_t)
+            const NetLayout& MH = c->L.net[PVAE_NET_MH];
+            const int ldo_md = MD.layers.back().n_out_pad, ldo_mh = MH.layers.back().n_out_pad;
+            if ((rc = forward_net(c, PVAE_NET_MH, u.rows_pad, st, FwdTail(), bt))) return rc;
+            const int grid = (rows * Da + 255) / 256 < 256 ? (rows * Da + 255) / 256 : 256;
+            hipLaunchKernelGGL(helper_add_kernel, dim3(grid), dim3(256), 0, st, w + wmd.act.back() + bt * ldo_md, ldo_md,
+                               w + c->W.net[PVAE_NET_MH].act.back() + bt * ldo_mh, ldo_mh, w + wwm.in + bp * ld_wm, ld_wm, Db,
+                               rows, Da, c->L.cfg.mh_range);
+            HIP_TRY(hipGetLastError());
+        }
         EpiMse mse;
         memset(&mse, 0, sizeof(mse));
         mse.target = w + c->W.s2 + bt * pad64(Db); mse.ldt = pad64(Db);
@@ -1885,7 +1895,16 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
     // Weight gradients contract over ALL steps at once (row blocks stacked): rows [0, krows) of a trainable stack.
     // Row blocks that receive no gradient are cut off the end or zero-filled; the fills go first (nothing writes
     // those blocks afterwards).
+    // The motor decoder's helper (rmt:670-680, 833-835) sits in every step's a_hat_t.  Nothing in the trainer freezes it
+    // (tpv:326-329, 347-350), and with lookahead > 1 the WORLD phase reaches it as well: the state the world model continues
+    // from is its own prediction under the helped action (tpv:417-421).  So it is a trainable stack of both phases here
+    // (adam_t[PVAE_NET_MH] == 0: frozen for this step), and the world phase's step 0 -- whose frozen decoder and encoder
+    // lead nowhere -- still has to bring the action's gradient to it.
+    const bool helper = !NL[PVAE_NET_MH].layers.empty();
+    const bool mh_train = helper && sp->adam_t[PVAE_NET_MH] > 0;
+    const NetWork* wmh = &NW[PVAE_NET_MH];
     std::vector<int> train_nets;
+    if (mh_train) train_nets.push_back(PVAE_NET_MH);
     if (joint) { train_nets.push_back(PVAE_NET_MD); train_nets.push_back(PVAE_NET_TE); }
     else train_nets.push_back(PVAE_NET_WM);
     int krows_of[PVAE_NUM_NETS] = {};
@@ -1897,7 +1916,7 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
             if (n == PVAE_NET_WM) {
                 for (int t = 0; t < T; ++t) act.push_back(u.use_g);
                 for (int t = 0; t < T; ++t) act.push_back(p_act[t]);
-            } else {
+            } else {                               // (decoder, encoder, helper: one block per step that the action's gradient reaches)
                 for (int t = 0; t < T; ++t) act.push_back(md_act[t]);
             }
             int blocks = (int)act.size();
@@ -1986,6 +2005,7 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
         // step 0 in the WORLD phase: what flows back through the (frozen) decoder and encoder of step 0 reaches no
         // trainable parameter -- only the world model's own layers above layer 0 need their input gradients
         const bool upstream = joint || t > 0;
+        const bool up_a = upstream || mh_train;   // the action's gradient of this step is wanted (by the helper, if by nobody else)
         const bool pair_wm = look_pair && t == 0 && !joint && krows_of[PVAE_NET_WM] > 0;
         if (backward && u.use_g) {
             if (pair_wm && !p_act[t]) paired_chain(PVAE_NET_WM, t, 1, true);    // (no predicted-action chain follows)
@@ -2006,10 +2026,10 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
                     return 0;
                 });
             }
-            if (pair_wm) paired_chain(PVAE_NET_WM, T + t, 1, true);
-            else dgrad_chain(PVAE_NET_WM, T + t, upstream);
+            if (pair_wm) paired_chain(PVAE_NET_WM, T + t, up_a ? 0 : 1, true);
+            else dgrad_chain(PVAE_NET_WM, T + t, up_a);
         }
-        if (!upstream) continue;
+        if (!up_a) continue;
         // action reconstruction (tpv:381-382) + gradient arriving through the world model
         if (md_act[t] || (joint && sp->a_rec_coeff > 0.0f)) {
             const float ga = joint ? sp->a_rec_coeff * S.gs / (S.Bg * Da) : 0.0f;
@@ -2026,9 +2046,37 @@ static void plan_backward_unrolled(pvae_ctx* c, int phase, int rows, const pvae_
             });
         }
         if (!backward || !md_act[t]) continue;
+        if (helper) {
+            // d a_hat_t (just formed) -> the helper's output layer through range * tanh', then its own layers; its input
+            // gradient matters where the decoder's does (z -> encoder, s1_t -> the previous step)
+            const int ldh = NL[PVAE_NET_MH].layers.back().n_out_pad;
+            const float range = c->L.cfg.mh_range;
+            push([=]() -> int {
+                const int tot = rows_pad * ldh;
+                hipLaunchKernelGGL(helper_seed_kernel, dim3((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256), dim3(256), 0, st,
+                                   w + wmd->dz.back() + bt * ldo_md, ldo_md, w + wmh->act.back() + bt * ldh,
+                                   w + wmh->dz.back() + bt * ldh, ldh, rows, rows_pad, Da, range);
+                HIP_TRY(hipGetLastError());
+                return 0;
+            });
+            dgrad_chain(PVAE_NET_MH, t, upstream);
+        }
+        if (!upstream) continue;
         const bool pair_here = look_pair && t == 0 && joint;
         if (pair_here && krows_of[PVAE_NET_MD] > 0) paired_chain(PVAE_NET_MD, t, 0, false);
         else dgrad_chain(PVAE_NET_MD, t, true);
+        if (helper) {                              // x_t = [s1_t | z_t] feeds the helper too: its input gradient joins the decoder's
+            const int ld_mh = NL[PVAE_NET_MH].layers[0].ld;
+            push([=]() -> int {
+                const int n = Db + Z;
+                const int grid = (rows * n + 255) / 256 < 256 ? (rows * n + 255) / 256 : 256;
+                hipLaunchKernelGGL(add_cols_kernel, dim3(grid), dim3(256), 0, st, w + wmd->d_in + bt * ld_md, ld_md, rows, n,
+                                   (const float*)(w + wmh->d_in + bt * ld_mh), ld_mh, (const float*)nullptr, 0,
+                                   (const float*)nullptr, 0, (const float*)nullptr, 0);
+                HIP_TRY(hipGetLastError());
+                return 0;
+            });
+        }
         {
             const float kls = S.kl_active ? sp->kl_coeff / S.Bg : 0.0f;
             const int tot = rows_pad * ldo_te;
@@ -2302,7 +2350,8 @@ int pvae_dp_train_step(pvae_ctx* c, int phase, int64_t first_window, int32_t row
     params_touched(c, st);
     const bool learned_prior = !c->L.net[PVAE_NET_PR].layers.empty();
     const bool helper = !c->L.net[PVAE_NET_MH].layers.empty() && sp->adam_t[PVAE_NET_MH] > 0;
-    const int nets[4] = {phase == PVAE_PHASE_WORLD || !helper ? -1 : PVAE_NET_MH,
+    // (the helper trains with the decoder in the joint phase and, with lookahead > 1, in the world phase too: plan_backward_unrolled)
+    const int nets[4] = {(phase == PVAE_PHASE_WORLD && c->W.L == 1) || !helper ? -1 : PVAE_NET_MH,
                          phase == PVAE_PHASE_WORLD ? PVAE_NET_WM : PVAE_NET_MD,
                          phase == PVAE_PHASE_WORLD ? -1 : (learned_prior ? PVAE_NET_PR : PVAE_NET_TE),
                          phase == PVAE_PHASE_WORLD || !learned_prior ? -1 : PVAE_NET_TE};      // backward order

@@ -66,7 +66,6 @@ inline Layout make_layout(const pvae_config& c) {
     const bool helper = c.mh_depth > 0;
     if (c.mh_depth < 0 || c.mh_depth > 15) { L.why = "helper depth out of range"; return L; }
     if (helper && (c.mh_width <= 0 || !(c.mh_range > 0.0f))) { L.why = "helper: mh_width and mh_range must be positive (rmt:672-673)"; return L; }
-    if (helper && c.lookahead != 1) { L.why = "a model with the motor decoder's helper needs lookahead == 1"; return L; }
     // rmt:638-644 (618-621: Z outputs on the hypersphere), 646-668, 682-689, 627-635, 670-680
     const int ins[PVAE_NUM_NETS] = {2 * Db, Db + Z, Db + Da, Db, Db + Z};
     const int outs[PVAE_NUM_NETS] = {c.prior_kind >= PVAE_PRIOR_HYPERSPHERE ? Z : 2 * Z, Da, Db, Z, Da};

@@ -308,8 +308,6 @@ class PhysicsVAE(nn.Module):
         if cfg.get("motor_decoder_helper_enable"):
             widths, acts, mh_init = _helper_stack(cfg["motor_decoder_helper_layers"], self._motor_decoder_helper_range)
             mh = Stack(widths, acts)
-            if int(cfg.get("lookahead", 1) or 1) != 1:
-                raise NotImplementedError("motor_decoder_helper_enable with lookahead > 1 is not built")
         self.arch = Arch(self.dim_state_body, self.dim_action, Z, te, md, wm, prior=self._latent_prior_type,
                          pr=pr, act=act, te_inputs=self._task_encoder_inputs, md_inputs=self._motor_decoder_inputs,
                          mh=mh, mh_range=self._motor_decoder_helper_range if mh is not None else 0.5)

@@ -290,12 +290,14 @@ class TrainModel(tune.Trainable):
         """World phase <=> only the world model is learnable (tpv:326-329 / 347-350)."""
         nets = self.model.learnable_nets()
         # The motor decoder's helper (rmt:670-680) is never frozen by the trainer (tpv:326-329, 347-350 switch encoder,
-        # decoder and world model only): in the world phase it receives no gradient (lookahead 1: the loss does not depend
-        # on a_hat) and torch's Adam skips it; in the joint phase it trains with the decoder.
+        # decoder and world model only): in the world phase with lookahead 1 it receives no gradient (the loss does not
+        # depend on a_hat) and torch's Adam skips it; with lookahead > 1 the world phase reaches it -- the state the world
+        # model continues from is its own prediction under the helped action (tpv:417-421) -- and Adam's counter for it runs
+        # from the first epoch; in the joint phase it trains with the decoder.
         helper = [NET_MH] if NET_MH in nets else []
         nets = [n for n in nets if n != NET_MH]
         if nets == [NET_WM]:
-            return PHASE_WORLD, nets
+            return PHASE_WORLD, nets + (helper if self.engine.lookahead > 1 else [])
         if nets in ([NET_TE, NET_MD], [NET_TE, NET_MD, NET_PR]):     # (+ the learned prior mean, when configured)
             return PHASE_JOINT, nets + helper
         raise NotImplementedError("learnable nets %s: the trainer only uses {WM} or {TE, MD}" % nets)

@@ -298,3 +298,102 @@ def test_helper_on_a_decoder_input_subset(md_in):
             blk = eng.params[info["w_offset"]: info["w_offset"] + info["n_out_pad"] * info["ld"]].view(info["n_out_pad"], info["ld"])
             out = torch.cat([blk[:, : info["col0"]].reshape(-1), blk[:, info["col0"] + info["n_in"]:].reshape(-1)])
             assert float(out.abs().max()) == 0.0
+
+
+def test_helper_with_lookahead_two_matches_the_reference_capture(golden):
+    """`motor_decoder_helper_enable` with lookahead 2 (tpv:367-428; rmt:833-835 inside every unrolled step), against the
+    reference's own compute_loss / backward / training loop (tests/golden/helper_train_look2_tiny.npz).  One minibatch in
+    both phases: total and every gradient -- in the WORLD phase the helper has one too (the state the world model continues
+    from is its own prediction under the helped action, tpv:417-421), the frozen decoder and encoder none.  Then the
+    five-epoch run across the switch: epoch losses, final weights, and Adam's counters -- the helper's runs from the first
+    epoch, the decoder's from the switch."""
+    g = golden("helper_train_look2_tiny")
+    base = arch_from_meta(g["meta"])
+    h, sd = _weights(base)
+    n_ep, n_steps, batch, m_world, n_epochs, L = [int(v) for v in g["meta"][9:15]]
+    assert L == 2
+    data = R.synth_demo(0, n_ep, n_steps, base["Db"], base["Da"], kind="dynamics")
+    X, Y = R.build_windows(data, lookahead=L)
+    x, y = next(iter(R.make_loader(X, Y, batch)))
+    tr = _trainer(base, data, batch, device=DEV, extra={"lookahead": L})
+    tr.model.load_state_dict(sd)
+    eng = tr.engine
+    es = R.eps_stream(2, base["Z"])
+    eps = torch.stack([es(t, (batch, base["Z"])) for t in range(L)])
+    for world in (True, False):
+        tag = "world" if world else "joint"
+        eng.set_batch(x, y)
+        eng.grads.fill_(float("nan"))
+        loss = eng.forward_backward(_lib.PHASE_WORLD if world else _lib.PHASE_JOINT, batch, _sp(world, batch), eps=eps.to(DEV),
+                                    fused_adam=False).cpu()
+        assert float(loss[0]) == pytest.approx(float(g[tag + "_total"]), rel=1e-5)
+        gv = eng.named_views(eng.grads)
+        keys = [str(k) for k in g[tag + "_grad_keys"]]
+        assert any(k.startswith("_motor_decoder_helper") for k in keys)
+        if world:
+            assert not any(k.startswith(("_motor_decoder.", "_task_encoder")) for k in keys)
+        for k in keys:
+            ref = torch.from_numpy(g["%s_grad::%s" % (tag, k)])
+            assert max_err_scaled(gv[k].cpu(), ref) < 1e-4, (tag, k)
+    # the reference's loop
+    tr = _trainer(base, data, batch, m_world=m_world, device=DEV, lr_step=2, eps_fn=R.eps_stream(2, base["Z"]),
+                  extra={"lookahead": L})
+    tr.model.load_state_dict(sd)
+    before = {k: v.clone() for k, v in tr.model.state_dict().items()}
+    ours = []
+    for e in range(n_epochs):
+        ours.append(tr.train()["mean_train_loss"])
+        if e + 1 == m_world:                         # the world phase moved the world model AND the helper, nothing else
+            now = tr.model.state_dict()
+            for k in before:
+                moved = not torch.equal(now[k], before[k])
+                assert moved == k.startswith(("_world_model", "_motor_decoder_helper")), k
+    np.testing.assert_allclose(ours, g["epoch_losses"], rtol=1e-3)
+    for k, v in tr.model.state_dict().items():
+        if not k.startswith("_value_branch"):
+            assert max_err_scaled(v.cpu(), g["final::" + k]) < 5e-3, k
+    nb = len(tr.train_loader)
+    steps = dict(zip((str(k) for k in g["adam_keys"]), g["adam_steps"]))
+    assert tr.optimizer.net_steps[_lib.NET_WM] == nb * m_world == steps["_world_model._model.0._model.0.weight"]
+    assert tr.optimizer.net_steps[_lib.NET_MH] == nb * n_epochs == steps["_motor_decoder_helper._model.0._model.0.weight"]
+    assert tr.optimizer.net_steps[_lib.NET_MD] == nb * (n_epochs - m_world) == steps["_motor_decoder._model.0._model.0.weight"]
+
+
+def test_helper_with_lookahead_fused_equals_stored_gradient_plus_flat_adam():
+    """lookahead 3 with a helper at wider dims: the fused step (weight gradients with Adam in their launches, the paired
+    schedule of step 0) and the gradient-store step followed by the flat Adam kernel agree bit for bit in both phases, over
+    three steps; with the helper frozen (adam_t[PVAE_NET_MH] = 0) its tensors do not move."""
+    base = R.make_arch(23, 7, latent=8, te=(64, 2), md=(96, 2), wm=(128, 3))
+    h, sd = _weights(base)
+    data = R.synth_demo(0, 3, 40, 23, 7, kind="dynamics")
+    tr = _trainer(base, data, 32, device=DEV, extra={"lookahead": 3})
+    eng = tr.engine
+    X, Y = R.build_windows(data, lookahead=3)
+    x, y = next(iter(R.make_loader(X, Y, 32)))
+    es = R.eps_stream(2, 8)
+    eps = torch.stack([es(t, (32, 8)) for t in range(3)]).to(DEV)
+    mh_off, mh_cnt = eng.segments[_lib.NET_MH]
+    for world in (True, False):
+        phase = _lib.PHASE_WORLD if world else _lib.PHASE_JOINT
+        nets = ([_lib.NET_WM] if world else [_lib.NET_TE, _lib.NET_MD]) + [_lib.NET_MH]
+        for frozen in (False, True):
+            res = []
+            for fused in (True, False):
+                tr.model.load_state_dict(sd)
+                eng.exp_avg.zero_(); eng.exp_avg_sq.zero_()
+                for t in (1, 2, 3):
+                    sp = _sp(world, 32, t)
+                    if frozen:
+                        sp.adam_t[_lib.NET_MH] = 0
+                    eng.set_batch(x, y)
+                    eng.forward_backward(phase, 32, sp, eps=eps, fused_adam=fused)
+                    if not fused:
+                        eng.adam([n for n in nets if not (frozen and n == _lib.NET_MH)], sp)
+                res.append((eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone()))
+            for a, b in zip(*res):
+                assert torch.equal(a, b), (world, frozen)
+            p0 = eng.params.clone()
+            tr.model.load_state_dict(sd)
+            moved = not torch.equal(res[0][0][mh_off: mh_off + mh_cnt], eng.params[mh_off: mh_off + mh_cnt])
+            assert moved == (not frozen), (world, frozen)
+            del p0

@@ -119,25 +119,40 @@ def _check(c, seed):
         tr.model.load_state_dict(sd)
 
 
-def test_schedule_and_geometry_switches_keep_parity():
+@pytest.mark.parametrize("switches", [{"PVAE_WGRAD32": "0", "PVAE_DGRAD16": "0"}, {"PVAE_WGRAD32": "2"}, {"PVAE_SAME_LAYER": "0"},
+                                      {"PVAE_DEFER_ADAM": "0"}], ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
+def test_schedule_and_geometry_switches_keep_parity(switches):
     """The narrow-layer geometries (32x32 weight-gradient tiles, 16x16 first-layer input-gradient
     tiles) are chosen per problem at launch time; PVAE_WGRAD32=0 / PVAE_DGRAD16=0 force the wide
     tiles everywhere and PVAE_WGRAD32=2 the narrow weight-gradient tiles everywhere.
     PVAE_SAME_LAYER=0 pairs wgrad_i with dgrad_{i-1} (the schedule used when the update cannot be
-    deferred), PVAE_DEFER_ADAM=0 keeps Adam in every weight-gradient epilogue.  The switches are
-    read when the library / context is created, so the sweep above runs again in fresh processes:
-    every variant meets the same oracle tolerances and the same fused == flat Adam identity."""
+    deferred), PVAE_DEFER_ADAM=0 keeps Adam in every weight-gradient epilogue.  The geometry switches are process-wide
+    options of the library (pvae_set_option(NULL, ...)), the schedule switches are read when a context is created: both are
+    set here for the duration of the sweep above (24 of the 40 random shapes), in this process, and put back: every variant meets
+    the same oracle tolerances and the same fused == flat Adam identity."""
     import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for env in ({"PVAE_WGRAD32": "0", "PVAE_DGRAD16": "0"}, {"PVAE_WGRAD32": "2"}, {"PVAE_SAME_LAYER": "0"},
-                {"PVAE_DEFER_ADAM": "0"}):
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_shapes.py"), "-q", "-x",
-                            "-m", "gpu", "-k", "random_shapes", "-p", "no:cacheprovider"],
-                           env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, (env, r.stdout[-2000:], r.stderr[-1000:])
-        assert "40 passed" in r.stdout, (env, r.stdout[-500:])
+    lib = _lib.load()
+    defaults = {"PVAE_WGRAD32": 1, "PVAE_DGRAD16": 1}
+    saved = {k: os.environ.get(k) for k in switches}
+    try:
+        for k, v in switches.items():
+            if k in _lib.PROCESS_OPTIONS:
+                key, conv = _lib.PROCESS_OPTIONS[k]
+                assert lib.pvae_set_option(None, key.encode(), conv(v)) >= 0
+            else:
+                assert k in _lib.CONTEXT_OPTIONS
+                os.environ[k] = v                      # (apply_context_options reads it when the trainer creates its context)
+        for seed in range(24):                             # (the first 24 of the 40 shapes: every kernel family and both lookaheads)
+            _check(_case(seed), seed)
+    finally:
+        for k, v in saved.items():
+            if k in _lib.PROCESS_OPTIONS:
+                key, _ = _lib.PROCESS_OPTIONS[k]
+                lib.pvae_set_option(None, key.encode(), defaults[k])
+            elif v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def test_64x32_tiles_equal_32x32_tiles_bit_for_bit(tmp_path):

@@ -108,9 +108,12 @@ def test_helper_config_is_checked_like_upstream_and_the_trainer_takes_a_helper_m
     th.model.set_learnable_motor_decoder_helper(False)
     assert th.phase() == (_lib.PHASE_JOINT, [_lib.NET_TE, _lib.NET_MD])
     assert th.optimizer.next_counts([_lib.NET_TE, _lib.NET_MD])[4] == 0     # adam_t[PVAE_NET_MH] = 0: frozen for that step
+    # lookahead > 1 (tpv:367-428): the WORLD phase reaches the helper too -- the state the world model continues from is its
+    # own prediction under the helped action -- so it joins the world phase's trainable stacks there
     full["lookahead"] = 2
-    with pytest.raises(NotImplementedError, match="lookahead"):
-        T.TrainModel(full)
+    t2 = T.TrainModel(full)
+    assert t2.engine.lookahead == 2 and t2.phase() == (_lib.PHASE_WORLD, [_lib.NET_WM, _lib.NET_MH])
+    assert t2.optimizer.next_counts([_lib.NET_WM, _lib.NET_MH]) == [1, 1, 1, 1, 1]
 
 
 @pytest.mark.gpu

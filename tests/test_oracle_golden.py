@@ -474,27 +474,33 @@ def test_input_subsets_restatement_matches_reference(golden):
                 np.testing.assert_allclose(gr.numpy(), g["%s_grad::%s" % (tag, k)], rtol=1e-4, atol=1e-8)
 
 
-def test_helper_training_restatement_matches_reference(golden):
+@pytest.mark.parametrize("name", ["helper_train_tiny", "helper_train_look2_tiny"])
+def test_helper_training_restatement_matches_reference(golden, name):
     """Supervised training of a helper model (rmt:670-680, 833-835): the reference's loss sees the helper's term in a_hat and
-    its optimizer trains the helper with the decoder.  One minibatch in both phases (the helper has no gradient in the world
-    phase, one in the joint phase) and the reference's own five-epoch loop: epoch losses, final weights, Adam step counts."""
-    g = golden("helper_train_tiny")
+    its optimizer trains the helper with the decoder.  One minibatch in both phases and the reference's own five-epoch
+    loop: epoch losses, final weights, Adam step counts.  lookahead 1: the helper has no gradient in the world phase and
+    one in the joint phase.  lookahead 2 (tpv:367-428): the world phase reaches it too -- the state the world model
+    continues from is its own prediction under the HELPED action (tpv:417-421) -- so its Adam counter runs from the first
+    epoch while the decoder's starts at the switch."""
+    g = golden(name)
     base = arch_from_meta(g["meta"])
     arch = R.with_helper(base, rng=float(g["helper_range"]))
     n_ep, n_steps, batch, m_world, n_epochs = [int(v) for v in g["meta"][9:14]]
+    L = int(g["meta"][14]) if len(g["meta"]) > 14 else 1
     data = R.synth_demo(0, n_ep, n_steps, arch["Db"], arch["Da"], kind="dynamics")
-    X, Y = R.build_windows(data)
+    X, Y = R.build_windows(data, lookahead=L)
     x, y = next(iter(R.make_loader(X, Y, batch)))
     sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
     k_out = "_motor_decoder_helper._model.%d._model.0.weight" % len(arch["mh"])
     sd[k_out] = sd[k_out] * 60.0
-    eps = torch.from_numpy(g["eps"])
+    es = R.eps_stream(2, arch["Z"])
+    eps = torch.from_numpy(g["eps"]) if L == 1 else torch.stack([es(t, (x.shape[0], arch["Z"])) for t in range(L)])
     for world in (True, False):
         tag = "world" if world else "joint"
         out = R.loss_and_grads(arch, sd, x, y, eps, world)
         np.testing.assert_allclose(out["total"].numpy(), g[tag + "_total"], rtol=1e-6)
         assert list(out["grads"].keys()) == list(g[tag + "_grad_keys"])
-        assert any(k.startswith("_motor_decoder_helper") for k in out["grads"]) == (not world)
+        assert any(k.startswith("_motor_decoder_helper") for k in out["grads"]) == (not world or L > 1)
         for k, gr in out["grads"].items():
             np.testing.assert_allclose(gr.numpy(), g["%s_grad::%s" % (tag, k)], rtol=1e-4, atol=1e-8)
     tr = R.RefTrainer(arch, sd, X, Y, batch, m_world, lr_step=2, eps_fn=R.eps_stream(2, arch["Z"]))
@@ -505,7 +511,7 @@ def test_helper_training_restatement_matches_reference(golden):
     nb = len(tr.loader)
     steps = dict(zip((str(k) for k in g["adam_keys"]), g["adam_steps"]))
     assert steps["_world_model._model.0._model.0.weight"] == nb * m_world
-    assert steps["_motor_decoder_helper._model.0._model.0.weight"] == nb * (n_epochs - m_world)
+    assert steps["_motor_decoder_helper._model.0._model.0.weight"] == nb * (n_epochs if L > 1 else n_epochs - m_world)
     assert steps["_motor_decoder._model.0._model.0.weight"] == nb * (n_epochs - m_world)
 
 
