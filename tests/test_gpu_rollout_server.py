@@ -394,6 +394,13 @@ def test_server_serves_a_helper_model_bit_for_bit(noise):
             sz = torch.cat([o[:197], torch.from_numpy(z)])
             a2 = eng.rollout_server_decode(sz.numpy()).copy()
             assert np.array_equal(a2, a)
+            # ... and against forward_decoder on the LAUNCH path (pvae_net_forward(MD) + range * helper added in torch): the
+            # kernel forms decoder + range * h with one fma, so the two agree to an ulp of the action, not to the bit
+            # (include/pvae.h pvae_rollout_server_decode)
+            with torch.no_grad():
+                lg2, _ = tr.model.forward_decoder(o[None, :197].to(DEV), torch.from_numpy(z)[None].to(DEV))
+            want2 = lg2[0, :45].cpu().numpy()
+            assert float(np.abs(a2 - want2).max()) <= 4e-7 * max(1.0, float(np.abs(want2).max()))
     # the module surface
     tr.model.eval()
     tr.model.latent_prior_noise = noise

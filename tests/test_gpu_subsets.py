@@ -194,3 +194,48 @@ def test_served_forward_and_direct_refusal_with_subsets():
     eng.set_direct(True)
     sp = make_step_params(lr=5e-4, a_rec=1.0, kl=1.0, s_rec=0.0, cyc=1e-3, global_rows=256)
     assert not eng.direct_active(_lib.PHASE_JOINT, 256, sp, fused=True)
+
+
+@pytest.mark.parametrize("te_in,md_in", [(("body",), ("task",)), (("task",), ("body",)), (("body", "task"), ("body",)),
+                                         (("task",), ("body", "task"))])
+def test_direct_first_layers_decline_every_subset(te_in, md_in):
+    """pvae_set_direct with ANY input subset on either stack keeps the staged panels (they carry the structural zeros): also
+    when one stack reads only the body and the other only the task block -- PVAE_INPUT_BODY | PVAE_INPUT_TASK of the two
+    fields together spells "both", which a guard on their OR let through (advisor, round 5)."""
+    wide = R.make_arch(197, 45, latent=32, te=(512, 2), md=(512, 2), wm=(512, 2))     # (first layers on the 32x32 tile kernels)
+    arch = R.with_inputs(wide, te_in, md_in)
+    data = R.synth_demo(0, 2, 300, 197, 45, kind="dynamics")
+    tr = make_trainer(arch, data, 256, device=DEV)
+    eng = tr.engine
+    eng.bind_dataset(*tr.train_loader.dataset.device_arrays(eng.device))
+    eng.set_direct(True)
+    sp = make_step_params(lr=5e-4, a_rec=1.0, kl=1.0, s_rec=0.0, cyc=1e-3, global_rows=256)
+    assert not eng.direct_active(_lib.PHASE_JOINT, 256, sp, fused=True)
+    full = make_trainer(wide, data, 256, device=DEV)
+    full.engine.bind_dataset(*full.train_loader.dataset.device_arrays(full.engine.device))
+    full.engine.set_direct(True)
+    assert full.engine.direct_active(_lib.PHASE_JOINT, 256, sp, fused=True)        # (the guard is about subsets, nothing else)
+
+
+def test_forward_decoder_between_training_steps_keeps_the_zero_block_exact():
+    """motor_decoder_inputs = ["body"]: the z columns of the decoder's input panel must stay zero for its layer-0 weight
+    gradient (the sampler writes z to a side panel).  `forward_decoder` -- pvae_net_forward(PVAE_NET_MD) on a caller's
+    [s | z] rows -- copies only the WINDOW of those rows into the panel, so a rollout-style call between two optimizer steps
+    leaves nothing behind: gradients, parameters and both moments outside the window stay exactly zero."""
+    arch = R.with_inputs(R.make_arch(23, 7, latent=8, te=(64, 2), md=(96, 2), wm=(128, 2)), ("body", "task"), ("body",))
+    data = R.synth_demo(0, 2, 80, 23, 7, kind="dynamics")
+    tr = make_trainer(arch, data, 32, m_world=1, device=DEV, eps_fn=R.eps_stream(2, 8))
+    tr.model.load_state_dict(R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3))
+    eng = tr.engine
+    tr.train()                                     # world epoch
+    z_body = torch.randn(32, 23, device=DEV)
+    z_task = torch.randn(32, 8, device=DEV) * 3.0
+    for _ in range(2):                             # joint epochs with rollout-style decoder calls in between
+        with torch.no_grad():
+            a, _ = tr.model.forward_decoder(z_body, z_task)
+            b, _ = tr.model.forward_decoder(z_body, z_task * 0.0)
+        assert torch.equal(a, b)                   # a ["body"] decoder does not see z at all
+        tr.train()
+        assert _outside_window(eng, eng.grads) == 0.0
+        assert _outside_window(eng, eng.params) == 0.0
+        assert _outside_window(eng, eng.exp_avg) == 0.0 and _outside_window(eng, eng.exp_avg_sq) == 0.0
