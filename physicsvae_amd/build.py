@@ -26,12 +26,30 @@ def _hipcc():
     raise RuntimeError("hipcc not found: cannot build libpvae_gfx950.so")
 
 
+STAMP = LIB + ".sha256"         # digest of the sources + flags the in-tree library was built from (git-ignored, travels with it)
+
+
+def source_digest(defines=()):
+    import hashlib
+    h = hashlib.sha256()
+    for d in [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]:
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read() + b"\0")
+    h.update(" ".join(FLAGS + ["-D" + d for d in defines]).encode())
+    return h.hexdigest()
+
+
 def is_stale():
+    """By CONTENT, not by modification time: a copy of the tree (the snapshot a GPU box receives) keeps no usable mtimes, and a
+    spurious rebuild there costs every pytest session 30 s -- or, with several sessions starting at once, lets two linkers
+    write the same file."""
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        with open(STAMP) as f:
+            return f.read().strip() != source_digest()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False, defines=(), out=None):
@@ -53,13 +71,20 @@ def build(force=False, verbose=False, defines=(), out=None):
             return obj
         with concurrent.futures.ThreadPoolExecutor(len(UNITS)) as pool:
             objs = list(pool.map(compile_unit, UNITS))
-        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out + ".tmp"]
+        link_tmp = os.path.join(tmp, "lib.so")                    # (private to this build: concurrent builds cannot interleave)
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", link_tmp]
         if verbose:
             print(" ".join(cmd))
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
-        os.replace(out + ".tmp", out)
+        shutil.copyfile(link_tmp, out + ".tmp.%d" % os.getpid())
+        os.chmod(out + ".tmp.%d" % os.getpid(), 0o755)
+        os.replace(out + ".tmp.%d" % os.getpid(), out)
+        if out == LIB:
+            with open(STAMP + ".tmp.%d" % os.getpid(), "w") as f:
+                f.write(source_digest(defines) + "\n")
+            os.replace(STAMP + ".tmp.%d" % os.getpid(), STAMP)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out

@@ -34,7 +34,7 @@ cd "$ROOT"
 python bench.py > "$O/${TAG}_bench_default.json" 2> "$O/${TAG}_bench_default.err"
 python bench.py --phase world --no-cpu-baseline > "$O/${TAG}_bench_world.json" 2> "$O/${TAG}_bench_world.err"
 python bench.py --config c5 --no-cpu-baseline > "$O/${TAG}_bench_c5.json" 2> "$O/${TAG}_bench_c5.err"
-python bench.py --gpus 2 --no-cpu-baseline > "$O/${TAG}_bench_n2_shared_gpu.json" 2> "$O/${TAG}_bench_n2.err"
+python bench.py --gpus 2 --no-cpu-baseline | grep "^{" > "$O/${TAG}_bench_n2_shared_gpu.json" 2> "$O/${TAG}_bench_n2.err"
 rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -12 > "$O/${TAG}_hw.txt"; lscpu | head -20 >> "$O/${TAG}_hw.txt"
 find "$O" -name '*.db' -delete
 ls "$O" | grep "^${TAG}_" | head -60
