@@ -45,7 +45,10 @@ typedef struct pvae_ctx pvae_ctx;
  * PVAE_PRIOR_STATE_MEAN.  PVAE_NET_MH: the motor decoder's helper `_motor_decoder_helper` (rmt:670-680, 833-835),
  * present only with pvae_config.mh_depth > 0: a second stack on the decoder's input whose tanh output, scaled by
  * mh_range, is added to the action; the reference's supervised loss sees that term inside a_hat, so the joint phase
- * trains the helper with the decoder (pvae_step_params.adam_t[PVAE_NET_MH] == 0: frozen for this step).
+ * trains the helper with the decoder (pvae_step_params.adam_t[PVAE_NET_MH] == 0: frozen for this step).  With
+ * lookahead > 1 (tpv:367-428) the helper runs in every unrolled step and the WORLD phase trains it too -- the state the
+ * world model continues from is its own prediction under the helped action (tpv:417-421) -- as upstream, whose trainer
+ * never freezes it.
  * Arena order is TE | MD | MH | PR | WM, so that the stacks trained together in the joint phase form one
  * contiguous segment. */
 enum { PVAE_NET_TE = 0, PVAE_NET_MD = 1, PVAE_NET_WM = 2, PVAE_NET_PR = 3, PVAE_NET_MH = 4, PVAE_NUM_NETS = 5 };
@@ -111,7 +114,7 @@ typedef struct pvae_config {
     int32_t te_inputs, md_inputs;
     /* motor_decoder_helper_enable / _layers / _range (rmt:490-498): mh_depth hidden layers (0: no helper) of mh_width
      * (layer_width / layer_act[PVAE_NET_MH] per layer), an output layer of dim_action values ending in tanh, input =
-     * the decoder's (md_inputs applies); needs lookahead == 1 and mh_range > 0 (asserted upstream, rmt:672-673). */
+     * the decoder's (md_inputs applies); needs mh_range > 0 (asserted upstream, rmt:672-673). */
     int32_t mh_width, mh_depth;
     float mh_range;
 } pvae_config;
