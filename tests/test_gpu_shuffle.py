@@ -54,3 +54,23 @@ def test_shuffled_epochs_with_prefetch_equal_explicit_gathers():
     assert sds[0][1] == sds[1][1]
     for k in sds[0][0]:
         assert torch.equal(sds[0][0][k], sds[1][0][k]), k
+
+
+@pytest.mark.parametrize("lookahead", [1, 2])
+def test_shuffled_runs_track_the_oracle_trainer(lookahead):
+    """Shuffled passes against the oracle's trainer (whose loader IS torch's shuffled DataLoader) under the same
+    torch.manual_seed, at wider dims, with lookahead 1 and 2 (the permuted table holds the windows' first rows; an unrolled
+    sample reads rows + t): per-epoch losses across the phase switch within 1e-3."""
+    arch = R.make_arch(23, 7, latent=8, te=(64, 2), md=(96, 2), wm=(128, 3))
+    data = R.synth_demo(0, 3, 40, 23, 7, kind="dynamics")
+    X, Y = R.build_windows(data, lookahead=lookahead)
+    sd = R.perturb_biases(R.init_state_dict(arch, seed=1), seed=3)
+    ref = R.RefTrainer(arch, sd, X, Y, 16, 2, lr_step=2, eps_fn=R.eps_stream(2, 8), shuffle=True)
+    torch.manual_seed(99)
+    want = [ref.step()["mean_train_loss"] for _ in range(4)]
+    tr = make_trainer(arch, data, 16, m_world=2, device=DEV, eps_fn=R.eps_stream(2, 8), lr_step=2,
+                      extra={"shuffle_data": True, "lookahead": lookahead})
+    tr.model.load_state_dict(sd)
+    torch.manual_seed(99)
+    got = [tr.train()["mean_train_loss"] for _ in range(4)]
+    np.testing.assert_allclose(got, want, rtol=1e-3)
